@@ -1,0 +1,153 @@
+/*
+ * nerfca_hip.h -- C ABI of libnerfca_hip.so: the MI355X (gfx950) implementation of NeRF-CA's
+ * ray-sampling -> (static + dynamic) MLP -> log-space X-ray compositing path.
+ *
+ * The reference (kirstenmaas/NeRF-CA @ 2024-10-22) is pure Python/PyTorch and has no FFI of its
+ * own; every entry point below therefore names the reference *Python* interface it replaces
+ * (paths relative to the reference root).  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless it says "host";
+ *   - buffers are caller-owned, contiguous, 16-byte aligned; the library allocates nothing that
+ *     outlives a call except a small pool of timing events (nca_timing_*);
+ *   - kernels are enqueued on `stream` (a hipStream_t passed as void*) and the call returns
+ *     without synchronising; no exceptions cross the ABI;
+ *   - return value 0 = ok, negative = error (NCA_E_*); nca_last_error() gives the message of the
+ *     calling thread's last failure.  Unsupported configurations are errors, never fallbacks.
+ *
+ * Index bookkeeping (bit-exact with the reference): sample n = r*S + s (ray-major,
+ * train/model_helpers.py:118-122), sigma outputs are [R,S] row-major.
+ */
+#ifndef NERFCA_HIP_H
+#define NERFCA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NCA_ABI_VERSION 1
+
+enum {
+    NCA_OK = 0,
+    NCA_E_INVALID = -1,     /* bad argument / inconsistent sizes */
+    NCA_E_UNSUPPORTED = -2, /* configuration the kernels do not implement */
+    NCA_E_HIP = -3,         /* a HIP runtime call failed */
+    NCA_E_WORKSPACE = -4    /* workspace too small */
+};
+
+/* positional-encoding families of CPPN.pos_enc / Temporal.pos_enc (model/CPPN.py:112-135) */
+enum {
+    NCA_ENC_NONE = 0,    /* pos_enc == 'none': features = x                                  */
+    NCA_ENC_BANDS = 1,   /* any windowed / plain mode: [x, sin(2^k x), sin(2^k x + pi/2)] * w */
+    NCA_ENC_FOURIER = 2  /* 'fourier': [sin(2 pi x g), cos(2 pi x g)]                         */
+};
+
+/* output activations of get_activation_func (train/model_helpers.py:63-70) */
+enum { NCA_ACT_SIGMOID = 0, NCA_ACT_SOFTPLUS = 1, NCA_ACT_CLAMP = 2 };
+
+/* arithmetic of the MLP contractions */
+enum {
+    NCA_PREC_F32 = 0, /* f32 MFMA (v_mfma_f32_32x32x2_f32): parity mode, 1e-5 rel vs reference */
+    NCA_PREC_BF16 = 1 /* bf16 MFMA operands, f32 accumulate: throughput mode                  */
+};
+
+/* One coordinate MLP: model/CPPN.py:6-69 (T == 0) or model/Temporal.py:6-93 (T > 0).
+ * Parameters live in ONE flat f32 buffer in nn.Module.parameters() order:
+ *   [time_latents P*T]  W0[F,K0] b0[F]  {W_i[F,F] b_i[F]} x n_hidden
+ *   [Wskip[F,F+K0] bskip[F]  {W[F,F] b[F]} x (n_late-1)]   Wo[1,F] bo[1]
+ * with K0 = enc features + T. */
+typedef struct NcaNet {
+    int32_t F;        /* num_filters: 32, 64 or 128                          */
+    int32_t n_hidden; /* num_early_layers (F->F layers after the input layer) */
+    int32_t n_late;   /* num_late_layers (CPPN only; skip connection)         */
+    int32_t enc_mode; /* NCA_ENC_*                                            */
+    int32_t L;        /* pos_enc_basis                                        */
+    int32_t T;        /* num_time_dim; 0 for the static net                   */
+    int32_t P;        /* rows of time_latents (10 in the reference)           */
+    int32_t reserved;
+} NcaNet;
+
+/* A batch of rays and the per-step sampling state: the arguments of
+ * obtain_train_predictions_iter / _static (train/model_helpers.py:99-160). */
+typedef struct NcaRays {
+    int64_t R;              /* rays                                                          */
+    int32_t S;              /* samples per ray                                               */
+    int32_t ray_is_f64;     /* origins/dirs are double (the real script) or float            */
+    const void* origins;    /* [R,3]                                                         */
+    const void* dirs;       /* [R,3] (not normalised, train/proj_helpers.py:83)              */
+    const int32_t* phase;   /* heart phase ids in [0,P); element (r,s) at r*stride_r+s*stride_s */
+    int64_t phase_stride_r;
+    int64_t phase_stride_s;
+    const float* z;         /* jittered depths: [S] (z_stride_r = 0) or [R,S] (fine pass)    */
+    int64_t z_stride_r;
+    const double* dists;    /* [S] interval lengths incl. the 1e-10 tail (model_helpers.py:73) */
+    const float* I0;        /* [R] initial log-intensities                                   */
+    int32_t act;            /* NCA_ACT_*                                                     */
+    int32_t single_field;   /* 0: composite (sigma scaled);  1: render_volume_density (one net, sigma un-scaled) */
+    float scale;            /* scale_value, 1e-2                                             */
+    int32_t reserved;
+} NcaRays;
+
+int nca_abi_version(void);
+const char* nca_last_error(void);
+
+/* ---- parameter bookkeeping ------------------------------------------------------------ */
+
+/* Number of f32 parameters of `net` (== sum(p.numel() for p in module.parameters())). */
+int64_t nca_param_count(const NcaNet* net);
+/* Bytes of the MFMA-ordered weight image produced by nca_pack_weights. */
+int64_t nca_packed_bytes(const NcaNet* net, int32_t prec);
+/* Re-order the flat natural parameters into the LDS images the kernels stream
+ * (run once per optimiser step).  `window` = per-band weights f32[L] (freq_mask_alpha /
+ * windowed_pos_enc, model/CPPN.py:137-159; ones when un-windowed), `fourier` = f32[3L] or NULL. */
+int nca_pack_weights(const NcaNet* net, const float* params, void* packed, int32_t prec, void* stream);
+
+/* ---- ray path: replaces obtain_train_predictions_iter/_static + get_predictions_* +
+ *      render_volume_density[_composite] (train/model_helpers.py:28-160) ------------------ */
+
+/* Forward.  net_d/packed_d/win_d may be NULL when rays->single_field == 1.
+ *   pix   f64[R]    = I0 - sum_s (sigma_s + sigma_d) * dists
+ *   sig_s f32[R,S], sig_d f32[R,S]  (activation * scale; un-scaled in single_field mode)
+ *   work  scratch of nca_render_fwd_workspace() bytes. */
+int64_t nca_render_fwd_workspace(const NcaRays* rays);
+int nca_render_fwd(const NcaRays* rays, int32_t prec,
+                   const NcaNet* net_s, const void* packed_s, const float* win_s, const float* four_s,
+                   const NcaNet* net_d, const void* packed_d, const float* win_d, const float* four_d,
+                   const float* latents_d, /* = params_d (time_latents are its first P*T floats) */
+                   double* pix, float* sig_s, float* sig_d, void* work, int64_t work_bytes, void* stream);
+
+/* Backward with recompute.  Upstream gradients g_pix f64[R], g_sig_s/g_sig_d f32[R,S] (NULL = 0).
+ * Writes (overwrites) grads_s / grads_d, flat f32 in the natural parameter order.
+ * `params_*` are the natural flat parameters (needed for the latent gradient). */
+int64_t nca_render_bwd_workspace(const NcaRays* rays, const NcaNet* net_s, const NcaNet* net_d, int32_t prec,
+                                 int64_t max_bytes);
+int nca_render_bwd(const NcaRays* rays, int32_t prec,
+                   const NcaNet* net_s, const void* packed_s, const float* win_s, const float* four_s, const float* params_s,
+                   const NcaNet* net_d, const void* packed_d, const float* win_d, const float* four_d, const float* params_d,
+                   const double* g_pix, const float* g_sig_s, const float* g_sig_d,
+                   float* grads_s, float* grads_d, void* work, int64_t work_bytes, void* stream);
+
+/* ---- point path: replaces CPPN.forward / Temporal.forward_composite on arbitrary points
+ *      (model/CPPN.py:88-110, model/Temporal.py:138-151) ---------------------------------- */
+int nca_mlp_fwd(const NcaNet* net, int32_t prec, const void* packed, const float* win, const float* four,
+                const float* params, int64_t N, const float* pts /*[N,3]*/, const int32_t* phase /*[N] or NULL*/,
+                float* raw /*[N]*/, void* stream);
+int64_t nca_mlp_bwd_workspace(const NcaNet* net, int32_t prec, int64_t N, int64_t max_bytes);
+int nca_mlp_bwd(const NcaNet* net, int32_t prec, const void* packed, const float* win, const float* four,
+                const float* params, int64_t N, const float* pts, const int32_t* phase, const float* g_raw /*[N]*/,
+                float* grads, void* work, int64_t work_bytes, void* stream);
+
+/* ---- in-library kernel timing (HIP events on the launch stream), used by bench.py -------- */
+enum { NCA_K_PACK = 0, NCA_K_FWD = 1, NCA_K_BWD_DGRAD = 2, NCA_K_BWD_WGRAD = 3, NCA_K_BWD_REDUCE = 4, NCA_K_COUNT = 5 };
+int nca_timing_enable(int32_t on);
+/* Synchronises the recorded events and returns accumulated milliseconds and launch count. */
+int nca_timing_read(int32_t kind, double* total_ms, int64_t* launches);
+int nca_timing_reset(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERFCA_HIP_H */

@@ -1,0 +1,106 @@
+"""ctypes binding of libnerfca_hip.so (include/nerfca_hip.h).
+
+The library is the product's compute path.  There is no fallback: if it cannot be loaded,
+``lib()`` raises, and every op that needs it raises with it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libnerfca_hip.so")
+
+ENC_NONE, ENC_BANDS, ENC_FOURIER = 0, 1, 2
+ACT_SIGMOID, ACT_SOFTPLUS, ACT_CLAMP = 0, 1, 2
+PREC_F32, PREC_BF16 = 0, 1
+K_PACK, K_FWD, K_BWD_DGRAD, K_BWD_WGRAD, K_BWD_REDUCE = 0, 1, 2, 3, 4
+KERNEL_KINDS = {"pack": K_PACK, "fwd": K_FWD, "bwd_dgrad": K_BWD_DGRAD, "bwd_wgrad": K_BWD_WGRAD, "bwd_reduce": K_BWD_REDUCE}
+
+
+class NcaNet(C.Structure):
+    _fields_ = [("F", C.c_int32), ("n_hidden", C.c_int32), ("n_late", C.c_int32), ("enc_mode", C.c_int32),
+                ("L", C.c_int32), ("T", C.c_int32), ("P", C.c_int32), ("reserved", C.c_int32)]
+
+
+class NcaRays(C.Structure):
+    _fields_ = [("R", C.c_int64), ("S", C.c_int32), ("ray_is_f64", C.c_int32),
+                ("origins", C.c_void_p), ("dirs", C.c_void_p),
+                ("phase", C.c_void_p), ("phase_stride_r", C.c_int64), ("phase_stride_s", C.c_int64),
+                ("z", C.c_void_p), ("z_stride_r", C.c_int64),
+                ("dists", C.c_void_p), ("I0", C.c_void_p),
+                ("act", C.c_int32), ("single_field", C.c_int32), ("scale", C.c_float), ("reserved", C.c_int32)]
+
+
+class NcaError(RuntimeError):
+    pass
+
+
+_lib: Optional[C.CDLL] = None
+
+# name -> (restype, argtypes); every symbol include/nerfca_hip.h declares
+_P, _I32, _I64 = C.c_void_p, C.c_int32, C.c_int64
+SYMBOLS = {
+    "nca_abi_version": (C.c_int, []),
+    "nca_last_error": (C.c_char_p, []),
+    "nca_param_count": (_I64, [C.POINTER(NcaNet)]),
+    "nca_packed_bytes": (_I64, [C.POINTER(NcaNet), _I32]),
+    "nca_pack_weights": (C.c_int, [C.POINTER(NcaNet), _P, _P, _I32, _P]),
+    "nca_render_fwd_workspace": (_I64, [C.POINTER(NcaRays)]),
+    "nca_render_fwd": (C.c_int, [C.POINTER(NcaRays), _I32, C.POINTER(NcaNet), _P, _P, _P, C.POINTER(NcaNet), _P, _P, _P, _P,
+                                 _P, _P, _P, _P, _I64, _P]),
+    "nca_render_bwd_workspace": (_I64, [C.POINTER(NcaRays), C.POINTER(NcaNet), C.POINTER(NcaNet), _I32, _I64]),
+    "nca_render_bwd": (C.c_int, [C.POINTER(NcaRays), _I32, C.POINTER(NcaNet), _P, _P, _P, _P, C.POINTER(NcaNet), _P, _P, _P, _P,
+                                 _P, _P, _P, _P, _P, _P, _I64, _P]),
+    "nca_mlp_fwd": (C.c_int, [C.POINTER(NcaNet), _I32, _P, _P, _P, _P, _I64, _P, _P, _P, _P]),
+    "nca_mlp_bwd_workspace": (_I64, [C.POINTER(NcaNet), _I32, _I64, _I64]),
+    "nca_mlp_bwd": (C.c_int, [C.POINTER(NcaNet), _I32, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _I64, _P]),
+    "nca_timing_enable": (C.c_int, [_I32]),
+    "nca_timing_read": (C.c_int, [_I32, C.POINTER(C.c_double), C.POINTER(_I64)]),
+    "nca_timing_reset": (C.c_int, []),
+}
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the HIP library; raise loudly if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NcaError(f"{LIB_PATH} is missing: build it with `make` (or __graft_entry__.build()). "
+                           "There is no CPU or PyTorch fallback for the fused ray path.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        if handle.nca_abi_version() != 1:
+            raise NcaError("libnerfca_hip.so ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+def check(rc: int) -> int:
+    """Raise NcaError with the library's message when a call returned a negative code."""
+    if rc < 0:
+        raise NcaError(f"libnerfca_hip: {lib().nca_last_error().decode()} (code {rc})")
+    return rc
+
+
+def ptr(t) -> Optional[int]:
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def timing_enable(on: bool) -> None:
+    check(lib().nca_timing_enable(1 if on else 0))
+
+
+def timing_reset() -> None:
+    check(lib().nca_timing_reset())
+
+
+def timing_read(kind: str):
+    ms, n = C.c_double(0.0), C.c_int64(0)
+    check(lib().nca_timing_read(KERNEL_KINDS[kind], C.byref(ms), C.byref(n)))
+    return ms.value, n.value

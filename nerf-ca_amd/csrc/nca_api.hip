@@ -1,0 +1,545 @@
+// nca_api.hip -- the C ABI of include/nerfca_hip.h: argument checking, workspace planning and
+// kernel sequencing.  No torch types, no allocation of device memory, no synchronisation
+// (except nca_timing_read, which waits for the events it reports).
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <mutex>
+#include <vector>
+#include "nca_kernels.hpp"
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHK(expr)                                                                     \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess) return fail(NCA_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// ---------------------------------------------------------------------------------- timing
+namespace {
+struct TimedSpan { hipEvent_t a, b; int kind; };
+std::mutex g_tmu;
+bool g_timing = false;
+std::vector<TimedSpan> g_spans;
+std::vector<hipEvent_t> g_free;
+double g_ms[NCA_K_COUNT];
+int64_t g_cnt[NCA_K_COUNT];
+
+hipEvent_t get_event() {
+    if (!g_free.empty()) { hipEvent_t e = g_free.back(); g_free.pop_back(); return e; }
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+struct Span {
+    int kind; hipStream_t st; hipEvent_t a = nullptr, b = nullptr; bool on;
+    Span(int k, hipStream_t s) : kind(k), st(s) {
+        std::lock_guard<std::mutex> lk(g_tmu);
+        on = g_timing;
+        if (on) { a = get_event(); b = get_event(); if (a && b) hipEventRecord(a, st); else on = false; }
+    }
+    ~Span() {
+        if (!on) return;
+        hipEventRecord(b, st);
+        std::lock_guard<std::mutex> lk(g_tmu);
+        g_spans.push_back({a, b, kind});
+    }
+};
+
+void drain_spans() {
+    for (auto& s : g_spans) {
+        float ms = 0.f;
+        if (hipEventSynchronize(s.b) == hipSuccess && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+            g_ms[s.kind] += ms;
+            g_cnt[s.kind] += 1;
+        }
+        g_free.push_back(s.a);
+        g_free.push_back(s.b);
+    }
+    g_spans.clear();
+}
+
+int num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+}  // namespace
+
+extern "C" int nca_timing_enable(int32_t on) {
+    std::lock_guard<std::mutex> lk(g_tmu);
+    g_timing = on != 0;
+    return NCA_OK;
+}
+extern "C" int nca_timing_reset(void) {
+    std::lock_guard<std::mutex> lk(g_tmu);
+    drain_spans();
+    memset(g_ms, 0, sizeof(g_ms));
+    memset(g_cnt, 0, sizeof(g_cnt));
+    return NCA_OK;
+}
+extern "C" int nca_timing_read(int32_t kind, double* total_ms, int64_t* launches) {
+    if (kind < 0 || kind >= NCA_K_COUNT) return fail(NCA_E_INVALID, "timing kind %d out of range", kind);
+    std::lock_guard<std::mutex> lk(g_tmu);
+    drain_spans();
+    if (total_ms) *total_ms = g_ms[kind];
+    if (launches) *launches = g_cnt[kind];
+    return NCA_OK;
+}
+
+// ---------------------------------------------------------------------------------- basics
+extern "C" int nca_abi_version(void) { return NCA_ABI_VERSION; }
+extern "C" const char* nca_last_error(void) { return g_err; }
+
+static int layout_of(const NcaNet* net, NcaLayout* y) {
+    if (!net) return fail(NCA_E_INVALID, "net is NULL");
+    const char* why = "";
+    int rc = nca_build_layout(*net, y, &why);
+    if (rc != NCA_OK) return fail(rc, "%s", why);
+    return NCA_OK;
+}
+
+extern "C" int64_t nca_param_count(const NcaNet* net) {
+    NcaLayout y;
+    int rc = layout_of(net, &y);
+    return rc == NCA_OK ? y.n_params : rc;
+}
+
+extern "C" int64_t nca_packed_bytes(const NcaNet* net, int32_t prec) {
+    NcaLayout y;
+    int rc = layout_of(net, &y);
+    if (rc != NCA_OK) return rc;
+    if (prec != NCA_PREC_F32) return fail(NCA_E_UNSUPPORTED, "precision %d not built", prec);
+    return y.packed_bytes;
+}
+
+extern "C" int nca_pack_weights(const NcaNet* net, const float* params, void* packed, int32_t prec, void* stream) {
+    NcaLayout y;
+    int rc = layout_of(net, &y);
+    if (rc != NCA_OK) return rc;
+    if (prec != NCA_PREC_F32) return fail(NCA_E_UNSUPPORTED, "precision %d not built", prec);
+    if (!params || !packed) return fail(NCA_E_INVALID, "params/packed is NULL");
+    Span sp(NCA_K_PACK, (hipStream_t)stream);
+    HIPCHK(nca_launch_pack_f32(y, params, packed, (hipStream_t)stream));
+    return NCA_OK;
+}
+
+// ---------------------------------------------------------------------------------- helpers
+static inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+struct NetBind {
+    const NcaNet* net; const void* packed; const float* win; const float* four; const float* params;
+};
+
+static int fill_net(const NetBind& b, NcaNetArgs* na) {
+    int rc = layout_of(b.net, &na->lay);
+    if (rc != NCA_OK) return rc;
+    if (!b.packed) return fail(NCA_E_INVALID, "packed weights pointer is NULL");
+    if (na->lay.enc_mode == NCA_ENC_BANDS && !b.win) return fail(NCA_E_INVALID, "band window is NULL");
+    if (na->lay.enc_mode == NCA_ENC_FOURIER && !b.four) return fail(NCA_E_INVALID, "fourier coefficients are NULL");
+    if (na->lay.T > 0 && !b.params) return fail(NCA_E_INVALID, "dynamic net needs its natural parameters (time latents)");
+    na->win = b.win;
+    na->four = b.four;
+    na->lat = na->lay.T > 0 ? b.params + na->lay.lat_off : nullptr;
+    na->row0 = 0;
+    return NCA_OK;
+}
+
+static int add_stage(NcaFusedArgs* a, const void* base, uint32_t off, uint32_t bytes) {
+    if (a->nstages >= NCA_MAX_STAGES) return fail(NCA_E_UNSUPPORTED, "too many weight stages");
+    a->stage[a->nstages].ptr = static_cast<const char*>(base) + off;
+    a->stage[a->nstages].bytes = (bytes + 15u) & ~15u;
+    a->stage[a->nstages].pad = 0;
+    a->nstages++;
+    return NCA_OK;
+}
+
+static int build_stages(NcaFusedArgs* a, const NetBind* binds, bool bwd) {
+    a->nstages = 0;
+    for (int n = 0; n < a->nnets; ++n) {
+        const NcaLayout& y = a->net[n].lay;
+        for (int j = 0; j < y.NL; ++j) {
+            int rc = add_stage(a, binds[n].packed, y.layer[j].img_off, y.layer[j].img_bytes);
+            if (rc) return rc;
+        }
+        if (bwd)
+            for (int j = y.NL - 1; j >= 1; --j) {
+                int rc = add_stage(a, binds[n].packed, y.layer[j].imgT_off, y.layer[j].imgT_bytes);
+                if (rc) return rc;
+            }
+    }
+    return NCA_OK;
+}
+
+static int64_t scratch_rows(const NcaLayout& y) { return y.K0rows_pad + (int64_t)(y.NL - 1) * y.F + (int64_t)y.NL * y.F; }
+
+static int check_rays(const NcaRays* r) {
+    if (!r) return fail(NCA_E_INVALID, "rays is NULL");
+    if (r->R <= 0 || r->S <= 0) return fail(NCA_E_INVALID, "empty ray batch (R=%lld, S=%d)", (long long)r->R, r->S);
+    if (!r->origins || !r->dirs || !r->z || !r->dists || !r->I0) return fail(NCA_E_INVALID, "a ray input pointer is NULL");
+    if (r->act < 0 || r->act > 2) return fail(NCA_E_INVALID, "unknown activation %d", r->act);
+    return NCA_OK;
+}
+
+static void rays_to_args(const NcaRays* r, NcaFusedArgs* a) {
+    a->mode = NCA_MODE_RAYS;
+    a->S = r->S;
+    a->nchunk = (r->S + 31) / 32;
+    a->ray_is_f64 = r->ray_is_f64;
+    a->act = r->act;
+    a->single = r->single_field;
+    a->scale = r->scale;
+    a->origins = r->origins;
+    a->dirs = r->dirs;
+    a->phase = r->phase;
+    a->ps_r = r->phase_stride_r;
+    a->ps_s = r->phase_stride_s;
+    a->z = r->z;
+    a->zs_r = r->z_stride_r;
+    a->dists = r->dists;
+}
+
+// ---------------------------------------------------------------------------------- forward
+extern "C" int64_t nca_render_fwd_workspace(const NcaRays* rays) {
+    int rc = check_rays(rays);
+    if (rc) return rc;
+    return align_up(rays->R * ((rays->S + 31) / 32) * (int64_t)sizeof(double), 256);
+}
+
+extern "C" int nca_render_fwd(const NcaRays* rays, int32_t prec,
+                              const NcaNet* net_s, const void* packed_s, const float* win_s, const float* four_s,
+                              const NcaNet* net_d, const void* packed_d, const float* win_d, const float* four_d,
+                              const float* latents_d,
+                              double* pix, float* sig_s, float* sig_d, void* work, int64_t work_bytes, void* stream) {
+    int rc = check_rays(rays);
+    if (rc) return rc;
+    if (prec != NCA_PREC_F32) return fail(NCA_E_UNSUPPORTED, "precision %d not built", prec);
+    if (!pix || !sig_s || (!rays->single_field && !sig_d)) return fail(NCA_E_INVALID, "an output pointer is NULL");
+    if (!rays->single_field && !net_d) return fail(NCA_E_INVALID, "composite render needs the dynamic net");
+    const int64_t need = nca_render_fwd_workspace(rays);
+    if (!work || work_bytes < need) return fail(NCA_E_WORKSPACE, "forward workspace %lld < %lld bytes", (long long)work_bytes, (long long)need);
+
+    static thread_local NcaFusedArgs a;
+    memset(&a, 0, sizeof(a));
+    rays_to_args(rays, &a);
+    a.nnets = rays->single_field ? 1 : 2;
+    NetBind binds[2] = {{net_s, packed_s, win_s, four_s, nullptr}, {net_d, packed_d, win_d, four_d, latents_d}};
+    for (int n = 0; n < a.nnets; ++n) {
+        rc = fill_net(binds[n], &a.net[n]);
+        if (rc) return rc;
+    }
+    if (a.net[0].lay.T > 0 && !rays->single_field) return fail(NCA_E_INVALID, "first net of a composite render must be static (T == 0)");
+    if (a.nnets == 2 && a.net[0].lay.F != a.net[1].lay.F) return fail(NCA_E_UNSUPPORTED, "static and dynamic nets must have the same num_filters (%d vs %d)", a.net[0].lay.F, a.net[1].lay.F);
+    for (int n = 0; n < a.nnets; ++n)
+        if (a.net[n].lay.T > 0 && !rays->phase) return fail(NCA_E_INVALID, "dynamic net needs phase ids");
+    rc = build_stages(&a, binds, false);
+    if (rc) return rc;
+    a.ntiles = rays->R * a.nchunk;
+    a.ray0 = 0;
+    a.part = static_cast<double*>(work);
+    a.sig_s = sig_s;
+    a.sig_d = sig_d;
+    const int64_t ngroups = (a.ntiles + NCA_WAVES - 1) / NCA_WAVES;
+    const int grid = (int)(ngroups < num_cus() ? ngroups : num_cus());
+    hipStream_t st = (hipStream_t)stream;
+    {
+        Span sp(NCA_K_FWD, st);
+        HIPCHK(nca_launch_fused_f32(a.net[0].lay.F, a, false, grid, st));
+    }
+    HIPCHK(nca_launch_pix_f32(rays->R, a.nchunk, rays->I0, a.part, pix, st));
+    return NCA_OK;
+}
+
+// ---------------------------------------------------------------------------------- backward
+struct BwdPlan {
+    int64_t rows;          // scratch rows over all nets
+    int64_t slab_stride;   // floats per split slab
+    int n_split, njobs, grid;
+    int64_t units_per_chunk;   // rays (or 32-point tiles) per launch
+    int64_t tiles_per_unit;
+    int64_t bytes_fixed, bytes_total;
+    int64_t off_slab, off_oslab, off_scratch;
+};
+
+static int plan_bwd(const NcaLayout* lays, int nnets, int64_t units, int64_t tiles_per_unit, int64_t budget, BwdPlan* p) {
+    p->rows = 0;
+    p->slab_stride = 0;
+    p->njobs = 0;
+    for (int n = 0; n < nnets; ++n) {
+        p->rows += scratch_rows(lays[n]);
+        p->slab_stride += lays[n].n_params;
+        for (int j = 0; j < lays[n].NL; ++j) p->njobs += lays[n].layer[j].kind == NCA_IN_SKIP ? 2 : 1;
+    }
+    for (int n = 0; n < nnets; ++n) p->slab_stride += (int64_t)lays[n].F * lays[n].P;
+    p->slab_stride = align_up(p->slab_stride, 64);
+    if (p->njobs > NCA_MAX_JOBS) return fail(NCA_E_UNSUPPORTED, "too many wgrad jobs");
+    const int cus = num_cus();
+    p->tiles_per_unit = tiles_per_unit;
+    const int F = lays[0].F;
+    // fixed parts sized for the largest possible launch geometry
+    const int64_t max_grid = cus;
+    int nsplit = (2 * cus + p->njobs - 1) / p->njobs;
+    if (nsplit < 1) nsplit = 1;
+    const int64_t slab_bytes = align_up((int64_t)nsplit * p->slab_stride * 4, 256);
+    const int64_t oslab_bytes = align_up(max_grid * 2 * (F + 1) * 4, 256);
+    p->bytes_fixed = slab_bytes + oslab_bytes;
+    const int64_t per_unit = p->rows * tiles_per_unit * 32 * 4;
+    int64_t upc = units;
+    if (budget > 0) {
+        int64_t avail = budget - p->bytes_fixed;
+        int64_t fit = avail > 0 ? avail / per_unit : 0;
+        if (fit < 1) fit = 1;
+        if (fit < upc) upc = fit;
+    }
+    p->units_per_chunk = upc;
+    const int64_t tiles = upc * tiles_per_unit;
+    if ((int64_t)nsplit > tiles) nsplit = (int)tiles;
+    p->n_split = nsplit;
+    const int64_t ngroups = (tiles + NCA_WAVES - 1) / NCA_WAVES;
+    p->grid = (int)(ngroups < cus ? ngroups : cus);
+    p->off_slab = 0;
+    p->off_oslab = slab_bytes;
+    p->off_scratch = slab_bytes + oslab_bytes;
+    p->bytes_total = p->off_scratch + align_up(per_unit * upc, 256);
+    return NCA_OK;
+}
+
+static int add_jobs(NcaWgradArgs* w, const NcaLayout& y, int64_t row0, int64_t slab_off, int64_t onehot_off) {
+    const int64_t hrow0 = row0 + y.K0rows_pad;                    // inputs of layers 1..NL-1
+    const int64_t drow0 = hrow0 + (int64_t)(y.NL - 1) * y.F;      // D_0 .. D_{NL-1}
+    for (int j = 0; j < y.NL; ++j) {
+        const NcaLayerL& l = y.layer[j];
+        bool bias_done = false;
+        if (l.kind != NCA_IN_HID) {
+            NcaWgradJob& g = w->job[w->njobs++];
+            g.F = y.F;
+            g.d_row0 = drow0 + (int64_t)j * y.F;
+            g.b_row0 = row0;
+            g.ncols_w = y.K0;
+            g.P = (j == 0) ? y.P : 0;
+            g.b_rows_pad = (int32_t)align_up(g.ncols_w + g.P, 32);
+            g.out_off = slab_off + l.w_off;
+            g.out_ld = l.K;
+            g.out_col0 = 0;
+            g.onehot_off = onehot_off;
+            g.bias_off = slab_off + l.b_off;
+            bias_done = true;
+        }
+        if (l.kind != NCA_IN_ENC) {
+            NcaWgradJob& g = w->job[w->njobs++];
+            g.F = y.F;
+            g.d_row0 = drow0 + (int64_t)j * y.F;
+            g.b_row0 = hrow0 + (int64_t)(j - 1) * y.F;
+            g.ncols_w = y.F;
+            g.P = 0;
+            g.b_rows_pad = y.F;
+            g.out_off = slab_off + l.w_off;
+            g.out_ld = l.K;
+            g.out_col0 = l.kind == NCA_IN_SKIP ? y.K0 : 0;
+            g.onehot_off = 0;
+            g.bias_off = bias_done ? -1 : slab_off + l.b_off;
+        }
+    }
+    return NCA_OK;
+}
+
+static int run_bwd(NcaFusedArgs& a, const NetBind* binds, int64_t units, int64_t tiles_per_unit, float* const* grads,
+                   void* work, int64_t work_bytes, hipStream_t st) {
+    NcaLayout lays[2];
+    for (int n = 0; n < a.nnets; ++n) lays[n] = a.net[n].lay;
+    BwdPlan p;
+    int rc = plan_bwd(lays, a.nnets, units, tiles_per_unit, work_bytes, &p);
+    if (rc) return rc;
+    if (!work || work_bytes < p.bytes_total) return fail(NCA_E_WORKSPACE, "backward workspace %lld < %lld bytes", (long long)work_bytes, (long long)p.bytes_total);
+    char* wb = static_cast<char*>(work);
+    float* slab = reinterpret_cast<float*>(wb + p.off_slab);
+    float* oslab = reinterpret_cast<float*>(wb + p.off_oslab);
+    float* scratch = reinterpret_cast<float*>(wb + p.off_scratch);
+
+    rc = build_stages(&a, binds, true);
+    if (rc) return rc;
+    int64_t row = 0, soff = 0;
+    for (int n = 0; n < a.nnets; ++n) { a.net[n].row0 = row; row += scratch_rows(lays[n]); }
+    int64_t slab_off[2] = {0, 0}, onehot_off[2] = {0, 0};
+    for (int n = 0; n < a.nnets; ++n) { slab_off[n] = soff; soff += lays[n].n_params; }
+    for (int n = 0; n < a.nnets; ++n) { onehot_off[n] = soff; soff += (int64_t)lays[n].F * lays[n].P; }
+
+    static thread_local NcaWgradArgs w;
+    memset(&w, 0, sizeof(w));
+    for (int n = 0; n < a.nnets; ++n) add_jobs(&w, lays[n], a.net[n].row0, slab_off[n], onehot_off[n]);
+    w.scratch = scratch;
+    w.slab = slab;
+    w.slab_stride = p.slab_stride;
+
+    a.scratch = scratch;
+    a.oslab = oslab;
+    const int F = lays[0].F;
+    int chunk = 0;
+    for (int64_t u0 = 0; u0 < units; u0 += p.units_per_chunk, ++chunk) {
+        const int64_t nu = (u0 + p.units_per_chunk <= units) ? p.units_per_chunk : units - u0;
+        a.ntiles = nu * tiles_per_unit;
+        a.Nc = a.ntiles * 32;
+        a.accumulate = chunk > 0;
+        if (a.mode == NCA_MODE_RAYS) a.ray0 = u0; else a.n0 = u0 * 32;
+        {
+            Span sp(NCA_K_BWD_DGRAD, st);
+            HIPCHK(nca_launch_fused_f32(F, a, true, p.grid, st));
+        }
+        w.Nc = a.Nc;
+        w.accumulate = chunk > 0;
+        {
+            Span sp(NCA_K_BWD_WGRAD, st);
+            HIPCHK(nca_launch_wgrad_f32(w, p.n_split, st));
+        }
+    }
+    NcaReduceArgs r;
+    memset(&r, 0, sizeof(r));
+    r.slab = slab;
+    r.slab_stride = p.slab_stride;
+    r.n_split = p.n_split;
+    r.n_wg = p.grid;
+    r.oslab = oslab;
+    r.oslab_stride = 2 * (F + 1);
+    for (int n = 0; n < a.nnets; ++n) {
+        r.n_params[n] = lays[n].n_params;
+        r.n_total += lays[n].n_params;
+        NcaReduceNet& rn = r.net[n];
+        rn.grads = grads[n];
+        rn.params = binds[n].params;
+        rn.slab_off = slab_off[n];
+        rn.onehot_off = onehot_off[n];
+        rn.F = lays[n].F; rn.T = lays[n].T; rn.P = lays[n].P; rn.K0 = lays[n].K0; rn.Kenc = lays[n].Kenc;
+        rn.w0_off = lays[n].layer[0].w_off;
+        rn.lat_count = (int64_t)lays[n].P * lays[n].T;
+        rn.wo_off = lays[n].wo_off;
+    }
+    {
+        Span sp(NCA_K_BWD_REDUCE, st);
+        HIPCHK(nca_launch_reduce_f32(r, st));
+    }
+    return NCA_OK;
+}
+
+extern "C" int64_t nca_render_bwd_workspace(const NcaRays* rays, const NcaNet* net_s, const NcaNet* net_d, int32_t prec, int64_t max_bytes) {
+    int rc = check_rays(rays);
+    if (rc) return rc;
+    if (prec != NCA_PREC_F32) return fail(NCA_E_UNSUPPORTED, "precision %d not built", prec);
+    NcaLayout lays[2];
+    int nn = rays->single_field ? 1 : 2;
+    rc = layout_of(net_s, &lays[0]);
+    if (rc) return rc;
+    if (nn == 2) { rc = layout_of(net_d, &lays[1]); if (rc) return rc; }
+    BwdPlan p;
+    rc = plan_bwd(lays, nn, rays->R, (rays->S + 31) / 32, max_bytes, &p);
+    if (rc) return rc;
+    return p.bytes_total;
+}
+
+extern "C" int nca_render_bwd(const NcaRays* rays, int32_t prec,
+                              const NcaNet* net_s, const void* packed_s, const float* win_s, const float* four_s, const float* params_s,
+                              const NcaNet* net_d, const void* packed_d, const float* win_d, const float* four_d, const float* params_d,
+                              const double* g_pix, const float* g_sig_s, const float* g_sig_d,
+                              float* grads_s, float* grads_d, void* work, int64_t work_bytes, void* stream) {
+    int rc = check_rays(rays);
+    if (rc) return rc;
+    if (prec != NCA_PREC_F32) return fail(NCA_E_UNSUPPORTED, "precision %d not built", prec);
+    if (!g_pix) return fail(NCA_E_INVALID, "g_pix is NULL");
+    if (!grads_s || (!rays->single_field && !grads_d)) return fail(NCA_E_INVALID, "a gradient output pointer is NULL");
+    if (!params_s || (!rays->single_field && !params_d)) return fail(NCA_E_INVALID, "natural parameters are required");
+    static thread_local NcaFusedArgs a;
+    memset(&a, 0, sizeof(a));
+    rays_to_args(rays, &a);
+    a.nnets = rays->single_field ? 1 : 2;
+    NetBind binds[2] = {{net_s, packed_s, win_s, four_s, params_s}, {net_d, packed_d, win_d, four_d, params_d}};
+    for (int n = 0; n < a.nnets; ++n) {
+        rc = fill_net(binds[n], &a.net[n]);
+        if (rc) return rc;
+    }
+    if (a.nnets == 2 && a.net[0].lay.F != a.net[1].lay.F) return fail(NCA_E_UNSUPPORTED, "static and dynamic nets must have the same num_filters");
+    for (int n = 0; n < a.nnets; ++n)
+        if (a.net[n].lay.T > 0 && !rays->phase) return fail(NCA_E_INVALID, "dynamic net needs phase ids");
+    a.g_pix = g_pix;
+    a.g_sig_s = g_sig_s;
+    a.g_sig_d = g_sig_d;
+    float* grads[2] = {grads_s, grads_d};
+    return run_bwd(a, binds, rays->R, a.nchunk, grads, work, work_bytes, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------- point path
+extern "C" int nca_mlp_fwd(const NcaNet* net, int32_t prec, const void* packed, const float* win, const float* four,
+                           const float* params, int64_t N, const float* pts, const int32_t* phase, float* raw, void* stream) {
+    if (prec != NCA_PREC_F32) return fail(NCA_E_UNSUPPORTED, "precision %d not built", prec);
+    if (N <= 0) return fail(NCA_E_INVALID, "empty point batch");
+    if (!pts || !raw) return fail(NCA_E_INVALID, "pts/raw is NULL");
+    static thread_local NcaFusedArgs a;
+    memset(&a, 0, sizeof(a));
+    a.mode = NCA_MODE_POINTS;
+    a.nnets = 1;
+    NetBind binds[2] = {{net, packed, win, four, params}, {}};
+    int rc = fill_net(binds[0], &a.net[0]);
+    if (rc) return rc;
+    if (a.net[0].lay.T > 0 && !phase) return fail(NCA_E_INVALID, "dynamic net needs phase ids");
+    rc = build_stages(&a, binds, false);
+    if (rc) return rc;
+    a.N = N;
+    a.n0 = 0;
+    a.pts = pts;
+    a.phase = phase;
+    a.raw_out = raw;
+    a.ntiles = (N + 31) / 32;
+    const int64_t ngroups = (a.ntiles + NCA_WAVES - 1) / NCA_WAVES;
+    const int grid = (int)(ngroups < num_cus() ? ngroups : num_cus());
+    Span sp(NCA_K_FWD, (hipStream_t)stream);
+    HIPCHK(nca_launch_fused_f32(a.net[0].lay.F, a, false, grid, (hipStream_t)stream));
+    return NCA_OK;
+}
+
+extern "C" int64_t nca_mlp_bwd_workspace(const NcaNet* net, int32_t prec, int64_t N, int64_t max_bytes) {
+    if (prec != NCA_PREC_F32) return fail(NCA_E_UNSUPPORTED, "precision %d not built", prec);
+    if (N <= 0) return fail(NCA_E_INVALID, "empty point batch");
+    NcaLayout lay;
+    int rc = layout_of(net, &lay);
+    if (rc) return rc;
+    BwdPlan p;
+    rc = plan_bwd(&lay, 1, (N + 31) / 32, 1, max_bytes, &p);
+    if (rc) return rc;
+    return p.bytes_total;
+}
+
+extern "C" int nca_mlp_bwd(const NcaNet* net, int32_t prec, const void* packed, const float* win, const float* four,
+                           const float* params, int64_t N, const float* pts, const int32_t* phase, const float* g_raw,
+                           float* grads, void* work, int64_t work_bytes, void* stream) {
+    if (prec != NCA_PREC_F32) return fail(NCA_E_UNSUPPORTED, "precision %d not built", prec);
+    if (N <= 0) return fail(NCA_E_INVALID, "empty point batch");
+    if (!pts || !g_raw || !grads || !params) return fail(NCA_E_INVALID, "a pointer is NULL");
+    static thread_local NcaFusedArgs a;
+    memset(&a, 0, sizeof(a));
+    a.mode = NCA_MODE_POINTS;
+    a.nnets = 1;
+    NetBind binds[2] = {{net, packed, win, four, params}, {}};
+    int rc = fill_net(binds[0], &a.net[0]);
+    if (rc) return rc;
+    if (a.net[0].lay.T > 0 && !phase) return fail(NCA_E_INVALID, "dynamic net needs phase ids");
+    a.N = N;
+    a.pts = pts;
+    a.phase = phase;
+    a.g_raw = g_raw;
+    float* gr[2] = {grads, nullptr};
+    return run_bwd(a, binds, (N + 31) / 32, 1, gr, work, work_bytes, (hipStream_t)stream);
+}

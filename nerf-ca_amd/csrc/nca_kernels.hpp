@@ -1,0 +1,107 @@
+// nca_kernels.hpp -- kernel argument blocks and launcher prototypes (internal).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "nca_layout.hpp"
+
+#define NCA_NT 512      // threads per workgroup of the fused kernel: 8 waves, 2 per SIMD
+#define NCA_WAVES 8
+
+enum { NCA_MODE_RAYS = 0, NCA_MODE_POINTS = 1 };
+
+struct NcaStage {
+    const void* ptr;   // image in the packed buffer
+    uint32_t bytes;    // multiple of 16
+    uint32_t pad;
+};
+
+struct NcaNetArgs {
+    NcaLayout lay;
+    const float* win;    // f32[L] band weights
+    const float* four;   // f32[3L] fourier coefficients (or null)
+    const float* lat;    // f32[P*T] time latents (or null)
+    int64_t row0;        // first scratch row of this net (backward only)
+};
+
+struct NcaFusedArgs {
+    int32_t mode, nnets;
+    int64_t ntiles;      // wave tiles (32 samples each) in this launch
+    // rays
+    int64_t ray0;        // first ray of this launch
+    int32_t S, nchunk;   // samples per ray, tiles per ray
+    int32_t ray_is_f64, act, single;
+    float scale;
+    const void* origins;
+    const void* dirs;
+    const int32_t* phase;
+    int64_t ps_r, ps_s;
+    const float* z;
+    int64_t zs_r;
+    const double* dists;
+    // points
+    int64_t N, n0;
+    const float* pts;
+    // outputs (forward)
+    double* part;        // [ntiles] per-tile partial ray sums
+    float* sig_s;
+    float* sig_d;
+    float* raw_out;
+    // backward
+    const double* g_pix;
+    const float* g_sig_s;
+    const float* g_sig_d;
+    const float* g_raw;
+    float* scratch;      // [rows][Nc] feature-major layer inputs H and output gradients D
+    int64_t Nc;          // scratch columns (= ntiles * 32)
+    float* oslab;        // [grid][2][F+1] output-layer gradient partials
+    int32_t accumulate;  // add to oslab instead of overwriting (ray chunks after the first)
+    int32_t nstages;
+    NcaNetArgs net[2];
+    NcaStage stage[NCA_MAX_STAGES];
+};
+
+struct NcaWgradJob {
+    int32_t F;            // rows of D
+    int32_t b_rows_pad;   // rows of H rounded up to 32
+    int64_t d_row0, b_row0;
+    int32_t ncols_w;      // H rows that are real weight columns
+    int32_t P;            // further H rows that are one-hot phase rows
+    int64_t out_off;      // slab offset (floats) of W
+    int32_t out_ld, out_col0;
+    int64_t onehot_off;   // slab offset of the [F][P] one-hot block
+    int64_t bias_off;     // slab offset of the bias gradient, or -1
+};
+
+struct NcaWgradArgs {
+    const float* scratch;
+    int64_t Nc;
+    float* slab;
+    int64_t slab_stride;
+    int32_t accumulate, njobs;
+    NcaWgradJob job[NCA_MAX_JOBS];
+};
+
+struct NcaReduceNet {
+    float* grads;
+    const float* params;
+    int64_t slab_off;     // where this net's natural block starts inside a slab
+    int64_t onehot_off;
+    int32_t F, T, P, K0, Kenc, w0_off;
+    int64_t lat_count, wo_off;
+};
+
+struct NcaReduceArgs {
+    int64_t n_total;
+    int64_t n_params[2];
+    const float* slab;
+    int64_t slab_stride;
+    int32_t n_split, n_wg;
+    const float* oslab;
+    int64_t oslab_stride;
+    NcaReduceNet net[2];
+};
+
+hipError_t nca_launch_pack_f32(const NcaLayout& y, const float* prm, void* out, hipStream_t st);
+hipError_t nca_launch_fused_f32(int F, const NcaFusedArgs& a, bool bwd, int grid, hipStream_t st);
+hipError_t nca_launch_wgrad_f32(const NcaWgradArgs& a, int nsplit, hipStream_t st);
+hipError_t nca_launch_reduce_f32(const NcaReduceArgs& a, hipStream_t st);
+hipError_t nca_launch_pix_f32(int64_t R, int nchunk, const float* I0, const double* part, double* pix, hipStream_t st);

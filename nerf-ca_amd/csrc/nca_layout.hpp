@@ -1,0 +1,136 @@
+// nca_layout.hpp -- geometry shared by host code and kernels: where each layer's parameters sit in
+// the natural flat buffer, and how they are re-ordered into the images the MFMA loops stream.
+//
+// Orientation used everywhere: activations are kept TRANSPOSED, H[feature][sample], with the sample
+// on the MFMA lane (column) and the features in accumulator registers.  A layer is D = W * H:
+//   A operand  = weights   W[out-feature row][k]      (streamed from an LDS image)
+//   B operand  = H[k][sample]                          (the previous layer's accumulator registers,
+//                                                       used in place: no lane movement, no LDS)
+// For v_mfma_f32_32x32x2_f32 the accumulator register i of lane-half h holds row rho(i)+4h, so the
+// k order of a hidden layer is permuted: k-step s = 16t+i reads rows 32t + rho(i) + 4h (h = 0,1).
+#pragma once
+#include <stdint.h>
+#include "../../include/nerfca_hip.h"
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define NCA_HD __host__ __device__
+#else
+#define NCA_HD
+#endif
+
+#define NCA_MAX_LAYERS 12
+#define NCA_MAX_STAGES 48
+#define NCA_MAX_JOBS 40
+
+enum { NCA_IN_ENC = 0, NCA_IN_HID = 1, NCA_IN_SKIP = 2 };
+
+struct NcaLayerL {
+    int32_t kind;        // NCA_IN_*
+    int32_t K;           // natural fan-in
+    int32_t ksteps;      // MFMA k-steps of the whole layer
+    int32_t ksteps_enc;  // of which: encoded-input steps (ENC / SKIP layers)
+    int32_t w_off;       // natural flat offsets (floats)
+    int32_t b_off;
+    uint32_t img_off;    // forward image  (bytes from the packed base)
+    uint32_t img_bytes;  // incl. bias tail (and Wo/bo tail on the last layer)
+    uint32_t imgT_off;   // transposed image for dgrad (hidden part only); 0 bytes on layer 0
+    uint32_t imgT_bytes;
+};
+
+struct NcaLayout {
+    int32_t F, MT, NL;          // width, row tiles (F/32), number of F-wide layers
+    int32_t enc_mode, L, T, P;
+    int32_t Kenc;               // encoded coordinate features (3, 3+6L or 6L)
+    int32_t K0;                 // Kenc + T
+    int32_t enc_steps;          // k-steps that carry the K0 inputs
+    int32_t K0rows;             // rows of the stored input block: K0 (+ P one-hot phase rows when T > 0)
+    int32_t K0rows_pad;         // rounded up to 32
+    int32_t lat_off, wo_off, bo_off, n_params;
+    uint32_t packed_bytes, max_img_bytes;
+    NcaLayerL layer[NCA_MAX_LAYERS];
+};
+
+NCA_HD inline int nca_rho(int i) { return (i & 3) + 8 * (i >> 2); }
+// natural row of hidden k-step s, lane-half h
+NCA_HD inline int nca_kidx_hidden(int s, int h) { return 32 * (s >> 4) + nca_rho(s & 15) + 4 * h; }
+
+// natural input-feature indices (a for lane-half 0, b for lane-half 1) of encoded k-step s; -1 = zero pad
+NCA_HD inline void nca_enc_pair(const NcaLayout& y, int s, int* ia, int* ib) {
+    int base = 0;
+    if (y.enc_mode == NCA_ENC_FOURIER) {
+        int n = 3 * y.L;
+        if (s < n) { *ia = s; *ib = n + s; return; }
+        base = n;
+    } else {
+        if (s == 0) { *ia = 0; *ib = 1; return; }
+        if (s == 1) { *ia = 2; *ib = -1; return; }
+        base = 2;
+        if (y.enc_mode == NCA_ENC_BANDS) {
+            int n = 3 * y.L;
+            if (s < 2 + n) {
+                int k = (s - 2) / 3, c = (s - 2) % 3;
+                *ia = 3 + 6 * k + c;
+                *ib = 6 + 6 * k + c;
+                return;
+            }
+            base = 2 + n;
+        }
+    }
+    int u = s - base;
+    *ia = y.Kenc + 2 * u;
+    *ib = (2 * u + 1 < y.T) ? y.Kenc + 2 * u + 1 : -1;
+}
+
+// sizes of the f32 images
+NCA_HD inline uint32_t nca_img_w_bytes(int ksteps, int MT) { return (uint32_t)ksteps * 64u * (uint32_t)MT * 4u; }
+NCA_HD inline uint32_t nca_img_tail_bytes(int MT) { return 2u * (uint32_t)MT * 16u * 4u; }  // bias (or Wo) in accumulator order
+
+inline int nca_build_layout(const NcaNet& n, NcaLayout* out, const char** why) {
+    NcaLayout y{};
+    if (!(n.F == 32 || n.F == 64 || n.F == 128)) { *why = "num_filters must be 32, 64 or 128"; return NCA_E_UNSUPPORTED; }
+    if (n.n_hidden < 0 || n.n_late < 0 || 1 + n.n_hidden + n.n_late > NCA_MAX_LAYERS) { *why = "too many layers"; return NCA_E_UNSUPPORTED; }
+    if (n.T < 0 || n.T > 32 || (n.T > 0 && n.P <= 0) || n.P > 64) { *why = "num_time_dim must be in [0,32], phases in [1,64]"; return NCA_E_UNSUPPORTED; }
+    if (n.T > 0 && n.n_late > 0) { *why = "Temporal with num_late_layers > 0 has no output in the reference (Temporal.py:128-135)"; return NCA_E_UNSUPPORTED; }
+    if (n.enc_mode < 0 || n.enc_mode > 2 || n.L < 0 || n.L > 16) { *why = "bad positional encoding"; return NCA_E_UNSUPPORTED; }
+    if (n.enc_mode != NCA_ENC_NONE && n.L == 0) { *why = "pos_enc_basis == 0 with an encoding: use NCA_ENC_NONE"; return NCA_E_INVALID; }
+    y.F = n.F; y.MT = n.F / 32; y.NL = 1 + n.n_hidden + n.n_late;
+    y.enc_mode = n.enc_mode; y.L = n.L; y.T = n.T; y.P = n.T > 0 ? n.P : 0;
+    y.Kenc = n.enc_mode == NCA_ENC_NONE ? 3 : (n.enc_mode == NCA_ENC_BANDS ? 3 + 6 * n.L : 6 * n.L);
+    y.K0 = y.Kenc + n.T;
+    int coord_steps = n.enc_mode == NCA_ENC_NONE ? 2 : (n.enc_mode == NCA_ENC_BANDS ? 2 + 3 * n.L : 3 * n.L);
+    y.enc_steps = coord_steps + (n.T + 1) / 2;
+    y.K0rows = y.K0 + y.P;
+    y.K0rows_pad = (y.K0rows + 31) / 32 * 32;
+    if (y.K0rows_pad > 128) { *why = "encoded input wider than 128 rows"; return NCA_E_UNSUPPORTED; }
+    int off = 0;
+    y.lat_off = 0;
+    off += y.P * y.T;
+    uint32_t boff = 0, maxb = 0;
+    for (int j = 0; j < y.NL; ++j) {
+        NcaLayerL& l = y.layer[j];
+        if (j == 0) { l.kind = NCA_IN_ENC; l.K = y.K0; l.ksteps_enc = y.enc_steps; l.ksteps = y.enc_steps; }
+        else if (n.n_late > 0 && j == 1 + n.n_hidden) { l.kind = NCA_IN_SKIP; l.K = y.K0 + y.F; l.ksteps_enc = y.enc_steps; l.ksteps = y.enc_steps + y.F / 2; }
+        else { l.kind = NCA_IN_HID; l.K = y.F; l.ksteps_enc = 0; l.ksteps = y.F / 2; }
+        l.w_off = off; off += y.F * l.K;
+        l.b_off = off; off += y.F;
+        l.img_off = boff;
+        l.img_bytes = nca_img_w_bytes(l.ksteps, y.MT) + nca_img_tail_bytes(y.MT) + (j == y.NL - 1 ? nca_img_tail_bytes(y.MT) + 16u : 0u);
+        boff += (l.img_bytes + 255u) & ~255u;
+        if (l.img_bytes > maxb) maxb = l.img_bytes;
+    }
+    for (int j = 0; j < y.NL; ++j) {
+        NcaLayerL& l = y.layer[j];
+        if (l.kind == NCA_IN_ENC) { l.imgT_off = 0; l.imgT_bytes = 0; continue; }
+        l.imgT_off = boff;
+        l.imgT_bytes = nca_img_w_bytes(y.F / 2, y.MT);
+        boff += (l.imgT_bytes + 255u) & ~255u;
+        if (l.imgT_bytes > maxb) maxb = l.imgT_bytes;
+    }
+    y.wo_off = off; off += y.F;
+    y.bo_off = off; off += 1;
+    y.n_params = off;
+    y.packed_bytes = boff;
+    y.max_img_bytes = maxb;
+    *out = y;
+    return NCA_OK;
+}

@@ -1,0 +1,279 @@
+"""PyTorch-side plumbing around the C ABI: device buffers, streams and autograd seams.
+
+``FieldBinding`` ties one coordinate network (an ``nn.Module`` owning ``nn.Parameter``s with the
+reference's state-dict keys) to the library: it keeps the parameters in ONE flat f32 buffer in
+``parameters()`` order (each ``nn.Parameter`` is a view into it), describes the net as an
+``NcaNet`` and caches the MFMA-ordered weight image, re-packing only when a parameter changed.
+
+``render_rays`` / ``eval_points`` are the two autograd entry points.  Nothing here computes the
+path with torch ops: if the HIP library is missing these raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _capi
+from ._capi import NcaNet, NcaRays, check, ptr
+
+_ACT = {"softplus": _capi.ACT_SOFTPLUS, "clamp": _capi.ACT_CLAMP}  # anything else -> sigmoid (model_helpers.py:63-70)
+
+# upper bound on the backward workspace (layer inputs + output gradients of one ray chunk)
+BWD_WORKSPACE_BYTES = 6 << 30
+
+
+def act_code(name: str) -> int:
+    return _ACT.get(name, _capi.ACT_SIGMOID)
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_cuda(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise _capi.NcaError(f"{what} must live on the GPU: the fused NeRF-CA path has no CPU implementation "
+                             f"(got device {t.device})")
+
+
+class FieldBinding:
+    """Flat parameters + packed weight image of one network."""
+
+    def __init__(self, module: torch.nn.Module, net: NcaNet, prec: int = _capi.PREC_F32):
+        self.module = module
+        self.net = net
+        self.prec = prec
+        self.flat: Optional[torch.Tensor] = None
+        self.packed: Optional[torch.Tensor] = None
+        self._packed_key = None
+        self._offsets: List[int] = []
+        self.reflatten()
+
+    # -- parameters ---------------------------------------------------------------------------
+    def params(self) -> List[torch.nn.Parameter]:
+        return list(self.module.parameters())
+
+    def n_params(self) -> int:
+        return sum(p.numel() for p in self.module.parameters())
+
+    def reflatten(self) -> None:
+        """(Re)create the flat buffer on the parameters' current device and re-point every
+        ``nn.Parameter`` at its slice.  Called at construction and after ``module.to(...)``."""
+        ps = self.params()
+        if not ps:
+            return
+        dev = ps[0].device
+        flat = torch.empty(sum(p.numel() for p in ps), dtype=torch.float32, device=dev)
+        self._offsets = []
+        off = 0
+        with torch.no_grad():
+            for p in ps:
+                n = p.numel()
+                flat[off:off + n].copy_(p.detach().reshape(-1).to(torch.float32))
+                p.data = flat[off:off + n].view(p.shape)
+                self._offsets.append(off)
+                off += n
+        self.flat = flat
+        self.packed = None
+        self._packed_key = None
+
+    def _is_flat(self) -> bool:
+        if self.flat is None:
+            return False
+        base = self.flat.data_ptr()
+        for p, off in zip(self.params(), self._offsets):
+            if p.data_ptr() != base + 4 * off or p.dtype != torch.float32:
+                return False
+        return True
+
+    def ensure_packed(self) -> torch.Tensor:
+        if not self._is_flat():
+            self.reflatten()
+        _require_cuda(self.flat, "network parameters")
+        key = (self.flat.data_ptr(), self.flat._version, tuple(p._version for p in self.params()))
+        if self.packed is None or key != self._packed_key:
+            lib = _capi.lib()
+            expect = lib.nca_param_count(C.byref(self.net))
+            check(expect)
+            if expect != self.flat.numel():
+                raise _capi.NcaError(f"parameter count mismatch: module has {self.flat.numel()}, descriptor expects {expect}")
+            nbytes = check(lib.nca_packed_bytes(C.byref(self.net), self.prec))
+            if self.packed is None or self.packed.numel() != nbytes or self.packed.device != self.flat.device:
+                self.packed = torch.empty(nbytes, dtype=torch.uint8, device=self.flat.device)
+            check(lib.nca_pack_weights(C.byref(self.net), ptr(self.flat), ptr(self.packed), self.prec, _stream()))
+            self._packed_key = key
+        return self.packed
+
+    def split_grads(self, gflat: torch.Tensor) -> List[torch.Tensor]:
+        out = []
+        for p, off in zip(self.params(), self._offsets):
+            out.append(gflat[off:off + p.numel()].view(p.shape))
+        return out
+
+
+def _f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    if t is None:
+        return None
+    return t.detach().to(torch.float32).contiguous()
+
+
+class _RayBatch:
+    """Device-side, dtype-normalised view of the arguments of obtain_train_predictions_iter."""
+
+    def __init__(self, origins, directions, phases, I0, z, dists, act: str, single: bool, scale: float):
+        _require_cuda(origins, "ray origins")
+        self.R = origins.shape[0]
+        self.f64 = origins.dtype == torch.float64
+        rdt = torch.float64 if self.f64 else torch.float32
+        self.o = origins.detach().to(rdt).contiguous()
+        self.d = directions.detach().to(rdt).contiguous()
+        dev = origins.device
+        self.z = z.detach().to(device=dev, dtype=torch.float32).contiguous()
+        self.S = self.z.shape[-1]
+        self.z_stride_r = 0 if self.z.dim() == 1 else self.S
+        self.dists = dists.detach().to(device=dev, dtype=torch.float64).contiguous()
+        self.I0 = I0.detach().to(device=dev, dtype=torch.float32).contiguous()
+        self.ph = None
+        self.ps_r = self.ps_s = 0
+        if phases is not None:
+            ph = phases.detach().to(device=dev, dtype=torch.int32)
+            if ph.dim() == 1:            # one id per ray
+                ph = ph.contiguous()
+                self.ps_r, self.ps_s = 1, 0
+            else:                        # [R, S] as run_composite.py:265 builds it
+                ph = ph.reshape(self.R, -1).contiguous()
+                self.ps_r, self.ps_s = ph.shape[1], 1
+            self.ph = ph
+        self.act, self.single, self.scale = act_code(act), 1 if single else 0, float(scale)
+
+    def desc(self) -> NcaRays:
+        return NcaRays(R=self.R, S=self.S, ray_is_f64=1 if self.f64 else 0, origins=ptr(self.o), dirs=ptr(self.d),
+                       phase=ptr(self.ph), phase_stride_r=self.ps_r, phase_stride_s=self.ps_s, z=ptr(self.z),
+                       z_stride_r=self.z_stride_r, dists=ptr(self.dists), I0=ptr(self.I0), act=self.act,
+                       single_field=self.single, scale=self.scale, reserved=0)
+
+
+class _RenderFn(torch.autograd.Function):
+    """pix, sigma_s, sigma_d = fused(rays; params_s, params_d)."""
+
+    @staticmethod
+    def forward(ctx, batch: _RayBatch, bs: FieldBinding, bd: Optional[FieldBinding], n_s: int, *params):
+        lib = _capi.lib()
+        dev = batch.o.device
+        packed_s = bs.ensure_packed()
+        packed_d = bd.ensure_packed() if bd is not None else None
+        win_s, four_s = bs.module._enc_buffers()
+        win_d, four_d = bd.module._enc_buffers() if bd is not None else (None, None)
+        R, S = batch.R, batch.S
+        pix = torch.empty(R, dtype=torch.float64, device=dev)
+        sig_s = torch.empty((R, S), dtype=torch.float32, device=dev)
+        sig_d = torch.empty((R, S), dtype=torch.float32, device=dev) if bd is not None else None
+        desc = batch.desc()
+        wbytes = check(lib.nca_render_fwd_workspace(C.byref(desc)))
+        work = torch.empty(wbytes, dtype=torch.uint8, device=dev)
+        check(lib.nca_render_fwd(C.byref(desc), bs.prec,
+                                 C.byref(bs.net), ptr(packed_s), ptr(win_s), ptr(four_s),
+                                 C.byref(bd.net) if bd is not None else None, ptr(packed_d), ptr(win_d), ptr(four_d),
+                                 ptr(bd.flat) if bd is not None else None,
+                                 ptr(pix), ptr(sig_s), ptr(sig_d), ptr(work), wbytes, _stream()))
+        ctx.batch, ctx.bs, ctx.bd = batch, bs, bd
+        ctx.keep = (packed_s, packed_d, win_s, four_s, win_d, four_d)
+        ctx.flat_versions = (bs.flat._version, bd.flat._version if bd is not None else 0)
+        if not batch.f64:
+            pix = pix.to(torch.float32)
+        if bd is None:
+            return pix, sig_s
+        return pix, sig_s, sig_d
+
+    @staticmethod
+    def backward(ctx, g_pix, g_sig_s, g_sig_d=None):
+        lib = _capi.lib()
+        batch, bs, bd = ctx.batch, ctx.bs, ctx.bd
+        packed_s, packed_d, win_s, four_s, win_d, four_d = ctx.keep
+        if (bs.flat._version, bd.flat._version if bd is not None else 0) != ctx.flat_versions:
+            raise _capi.NcaError("network parameters were modified between forward and backward")
+        dev = batch.o.device
+        gp = torch.zeros(batch.R, dtype=torch.float64, device=dev) if g_pix is None else g_pix.detach().to(torch.float64).contiguous()
+        gs, gd = _f32c(g_sig_s), _f32c(g_sig_d)
+        grads_s = torch.empty(bs.flat.numel(), dtype=torch.float32, device=dev)
+        grads_d = torch.empty(bd.flat.numel(), dtype=torch.float32, device=dev) if bd is not None else None
+        desc = batch.desc()
+        net_d = C.byref(bd.net) if bd is not None else None
+        wbytes = check(lib.nca_render_bwd_workspace(C.byref(desc), C.byref(bs.net), net_d, bs.prec, BWD_WORKSPACE_BYTES))
+        work = torch.empty(wbytes, dtype=torch.uint8, device=dev)
+        check(lib.nca_render_bwd(C.byref(desc), bs.prec,
+                                 C.byref(bs.net), ptr(packed_s), ptr(win_s), ptr(four_s), ptr(bs.flat),
+                                 net_d, ptr(packed_d), ptr(win_d), ptr(four_d), ptr(bd.flat) if bd is not None else None,
+                                 ptr(gp), ptr(gs), ptr(gd), ptr(grads_s), ptr(grads_d), ptr(work), wbytes, _stream()))
+        bs.last_grad = grads_s
+        out = bs.split_grads(grads_s)
+        if bd is not None:
+            bd.last_grad = grads_d
+            out = out + bd.split_grads(grads_d)
+        return (None, None, None, None, *out)
+
+
+def render_rays(static_model, temp_model, origins, directions, phases, I0, z, dists, act="softplus", single=False, scale=1e-2):
+    """Fused query-point -> encoding -> MLP(s) -> activation -> ray sum.
+
+    Composite (``temp_model`` given): returns ``(pix[R], sigma_s[R,S], sigma_d[R,S])`` as
+    render_volume_density_composite does (model_helpers.py:72-84).  ``single=True`` renders one net as
+    render_volume_density does (un-scaled sigma, model_helpers.py:86-97) and returns ``(pix, sigma)``.
+    ``pix`` is f64 when the rays are f64 (the real script), f32 otherwise.
+    """
+    bs: FieldBinding = static_model._binding
+    bd: Optional[FieldBinding] = temp_model._binding if temp_model is not None else None
+    if single and bd is not None:
+        raise ValueError("single-field render takes exactly one network")
+    batch = _RayBatch(origins, directions, phases, I0, z, dists, act, single or bd is None, scale)
+    params = bs.params() + (bd.params() if bd is not None else [])
+    return _RenderFn.apply(batch, bs, bd, len(bs.params()), *params)
+
+
+class _PointsFn(torch.autograd.Function):
+    """raw[n] = net(points[n] (, phase[n]))  --  CPPN.forward / Temporal.forward_composite."""
+
+    @staticmethod
+    def forward(ctx, binding: FieldBinding, pts: torch.Tensor, phase: Optional[torch.Tensor], *params):
+        lib = _capi.lib()
+        packed = binding.ensure_packed()
+        win, four = binding.module._enc_buffers()
+        N = pts.shape[0]
+        raw = torch.empty(N, dtype=torch.float32, device=pts.device)
+        check(lib.nca_mlp_fwd(C.byref(binding.net), binding.prec, ptr(packed), ptr(win), ptr(four), ptr(binding.flat), N,
+                              ptr(pts), ptr(phase), ptr(raw), _stream()))
+        ctx.binding, ctx.keep = binding, (packed, win, four, pts, phase)
+        ctx.flat_version = binding.flat._version
+        return raw.view(N, 1)
+
+    @staticmethod
+    def backward(ctx, g_raw):
+        lib = _capi.lib()
+        binding = ctx.binding
+        packed, win, four, pts, phase = ctx.keep
+        if binding.flat._version != ctx.flat_version:
+            raise _capi.NcaError("network parameters were modified between forward and backward")
+        N = pts.shape[0]
+        g = _f32c(g_raw).reshape(-1)
+        grads = torch.empty(binding.flat.numel(), dtype=torch.float32, device=pts.device)
+        wbytes = check(lib.nca_mlp_bwd_workspace(C.byref(binding.net), binding.prec, N, BWD_WORKSPACE_BYTES))
+        work = torch.empty(wbytes, dtype=torch.uint8, device=pts.device)
+        check(lib.nca_mlp_bwd(C.byref(binding.net), binding.prec, ptr(packed), ptr(win), ptr(four), ptr(binding.flat), N,
+                              ptr(pts), ptr(phase), ptr(g), ptr(grads), ptr(work), wbytes, _stream()))
+        binding.last_grad = grads
+        return (None, None, None, *binding.split_grads(grads))
+
+
+def eval_points(model, pts: torch.Tensor, phase: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Evaluate one network on arbitrary points: f32[n,3] (, ids[n]) -> f32[n,1]."""
+    _require_cuda(pts, "query points")
+    binding: FieldBinding = model._binding
+    if pts.shape[0] == 0:
+        return torch.empty((0, 1), dtype=torch.float32, device=pts.device)
+    p = pts.detach().reshape(-1, 3).to(torch.float32).contiguous()
+    ph = None
+    if phase is not None:
+        ph = phase.detach().flatten().to(device=p.device, dtype=torch.int32).contiguous()
+    return _PointsFn.apply(binding, p, ph, *binding.params())

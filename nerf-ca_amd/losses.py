@@ -1,0 +1,70 @@
+"""Pixel loss and D2NeRF-style separation regularisers (train/model_helpers.py:189-262, 284-288).
+
+All terms are computed from sigma_s, sigma_d [R,S], the interval lengths dists[S] and the per-ray
+weights in one place.  These are torch device ops for now (SURVEY.md 8(f) rank 1 fuses them).
+"""
+from __future__ import annotations
+
+import torch
+
+_EPS = 1e-10
+_CLIP = 1e-19
+
+
+def blend_weight(sigma_s, sigma_d):
+    """(blendw, max sigma_s, max sigma_d)  -- compute_ratio, model_helpers.py:189-198."""
+    with torch.no_grad():
+        top_s, top_d = sigma_s.max(), sigma_d.max()
+    return sigma_d / (sigma_s + sigma_d + _EPS), top_s, top_d
+
+
+def binary_entropy_of_blend(blendw, clip_threshold=_CLIP, skewness=1):
+    """compute_blendw_loss, model_helpers.py:200-204."""
+    b = torch.clip(blendw ** skewness, min=clip_threshold, max=1 - clip_threshold)
+    nb = torch.clip(1 - b, min=clip_threshold)
+    h = -(b * b.log() + nb * nb.log())
+    return h.mean(dim=-1).mean()
+
+
+def ray_entropy(sigma, dists, mask_threshold=0.1, clip_threshold=_CLIP, use_weighting=False, weighted_pixs=(), weighted_thresh=0.25):
+    """compute_sigma_s_ray_loss, model_helpers.py:206-224 -> (masked mean entropy, mean ray sum)."""
+    mass = sigma * dists
+    total = mass.sum(dim=-1, keepdim=True)
+    keep = (total >= mask_threshold).flatten().int()
+    if len(weighted_pixs) > 0 and use_weighting:
+        strong = torch.zeros_like(keep)
+        strong[: weighted_pixs.shape[0]] = (weighted_pixs > 1 + weighted_thresh).int()
+        keep = keep | strong
+    prob = mass / total.clamp(min=clip_threshold)
+    ent = keep * -(prob * (prob + _EPS).log()).sum(dim=-1)
+    return ent.mean(), total.mean()
+
+
+def occlusion(sigma, dists, reg_perc=0.1, use_back=False):
+    """compute_occl_loss, model_helpers.py:226-248.  With use_back=False the (all-ones) back mask is
+    OR-ed in, so every sample counts and this is the mean ray sum."""
+    run = torch.cumsum(dists, dim=0)
+    front = run < reg_perc * run[-1]
+    back = run > (1 - reg_perc) * run[-1] if use_back else torch.ones_like(front)
+    m = (front | back).to(sigma.dtype if sigma.dtype == dists.dtype else dists.dtype)
+    return (sigma * dists * m).sum(dim=-1).mean()
+
+
+def all_terms(static_sigma, temp_sigma, dists, weighted_pixs, run_args):
+    """compute_losses, model_helpers.py:250-262: the reference's 11-tuple."""
+    bw, top_s, top_d = blend_weight(static_sigma, temp_sigma)
+    favor = binary_entropy_of_blend(bw, skewness=run_args.skewness_val)
+    s_ent, s_sum = ray_entropy(static_sigma, dists, mask_threshold=run_args.entro_mask_thre)
+    d_ent, d_sum = ray_entropy(temp_sigma, dists, mask_threshold=run_args.entro_mask_thre,
+                               use_weighting=run_args.entro_use_weighting, weighted_pixs=weighted_pixs,
+                               weighted_thresh=run_args.entro_weighted_thresh)
+    occl = occlusion(temp_sigma, dists, run_args.occl_reg_perc)
+    mass = static_sigma * dists
+    return bw.mean(), top_s, top_d, favor, s_ent, s_sum, d_ent, d_sum, occl, mass.sum(), (mass ** 2).sum()
+
+
+class WeightedSquaredError(torch.nn.Module):
+    """weighted_MSELoss, model_helpers.py:284-288 (the caller takes .mean())."""
+
+    def forward(self, preds, gts, weights):
+        return (preds - gts) ** 2 * weights

@@ -1,0 +1,141 @@
+"""Drop-in for the reference's ``train/model_helpers.py``: same function names, arguments and return
+values, with the ray path routed through the fused HIP kernels.
+
+  obtain_train_predictions_iter / _static  -> ONE fused launch per call (sampling of query points,
+      positional encoding, both MLPs, activation and the ray sum never leave the chip); the
+      reference's Python chunk loop (get_minibatches*, model_helpers.py:14-61) has no counterpart
+      because nothing is materialised per chunk -- ``batch_size`` is accepted and ignored.
+  get_predictions_static / _composite      -> fused point kernels.
+  render_volume_density[_composite]        -> elementwise + row sum on raw fields the caller already
+      holds (the evaluation path of run_composite.py:361, 407-413).
+
+An extra keyword ``t_rand`` on the two ``obtain_*`` functions injects the stratified-sampling draw
+(the reference draws it internally with ``torch.rand``); tests use it to replay golden vectors.
+"""
+import torch
+
+from .. import fused as _fused
+from ..losses import (WeightedSquaredError as weighted_MSELoss, all_terms as compute_losses,  # noqa: F401
+                      binary_entropy_of_blend as compute_blendw_loss, blend_weight as _blend_weight,
+                      occlusion as compute_occl_loss, ray_entropy as compute_sigma_s_ray_loss)
+from ..schedules import exp_param_decay, linear_param_decay  # noqa: F401
+
+
+def compute_ratio(sigma_s, sigma_d, favor_s_opt=None, sigma_s_max=None, sigma_d_max=None, weight_max=0.05):
+    return _blend_weight(sigma_s, sigma_d)
+
+
+def randomize_depth(z_vals, device, t_rand=None):
+    """Stratified jitter inside each depth bin (model_helpers.py:3-12): ONE vector per step, shared by
+    all rays.  The uniform draw comes from the CPU generator, as in the reference."""
+    mid = 0.5 * (z_vals[..., 1:] + z_vals[..., :-1])
+    hi = torch.cat([mid, z_vals[..., -1:]], -1)
+    lo = torch.cat([z_vals[..., :1], mid], -1)
+    u = torch.rand(z_vals.shape) if t_rand is None else t_rand
+    return (lo + (hi - lo) * u.to(device)).to(device)
+
+
+def get_minibatches(inputs, chunksize=1024 * 8):
+    return [[inputs[i:i + chunksize]] for i in range(0, inputs.shape[0], chunksize)]
+
+
+def get_minibatches_time(inputs, time_inputs, chunksize=1024 * 8):
+    return [[inputs[i:i + chunksize], time_inputs[i:i + chunksize]] for i in range(0, inputs.shape[0], chunksize)]
+
+
+def get_predictions_static(static_model, flattened_query_points, chunksize):
+    """f32[n,3] -> f32[n,1] (model_helpers.py:28-39); one fused launch, no chunk loop."""
+    return static_model(flattened_query_points)
+
+
+def get_predictions_composite(static_model, temp_model, flattened_query_points, flattened_time_points, chunksize, use_nerf_acc=False):
+    """model_helpers.py:41-61 -> (static f32[n,1], dynamic f32[n,1])."""
+    s = None if use_nerf_acc else static_model(flattened_query_points)
+    d = temp_model.forward_composite(flattened_query_points, flattened_time_points)
+    return s, d
+
+
+def get_activation_func(output_activation):
+    """model_helpers.py:63-70: only the exact strings 'softplus' and 'clamp' are special."""
+    if output_activation == "softplus":
+        return torch.nn.Softplus()
+    if output_activation == "clamp":
+        return lambda x: torch.nn.functional.hardtanh(torch.nn.Softplus()(x), min_val=0.0, max_val=1.0)
+    return torch.nn.Sigmoid()
+
+
+def _interval_lengths(depth_values, like):
+    """cat(z[1:] - z[:-1], 1e-10) with the tail in the ray directions' dtype (model_helpers.py:73-74)."""
+    tail = torch.tensor([1e-10], dtype=like.dtype, device=like.device).expand(depth_values[..., :1].shape)
+    return torch.cat((depth_values[..., 1:] - depth_values[..., :-1], tail), dim=-1)
+
+
+def render_volume_density_composite(static_radiance_field, temp_radiance_field, initial_intensities, ray_directions, depth_values,
+                                    output_activation="softplus", scale_value=1e-2):
+    dists = _interval_lengths(depth_values, ray_directions)
+    f = get_activation_func(output_activation)
+    static_sigma = f(static_radiance_field[..., -1]) * scale_value
+    temp_sigma = f(temp_radiance_field[..., -1]) * scale_value
+    int_map = initial_intensities - ((static_sigma + temp_sigma) * dists).sum(dim=-1)
+    return int_map, static_sigma, temp_sigma, dists
+
+
+def render_volume_density(radiance_field, initial_intensities, ray_directions, depth_values, output_activation="softplus", scale_value=1e-2):
+    dists = _interval_lengths(depth_values, ray_directions)
+    sigma_a = get_activation_func(output_activation)(radiance_field[..., -1])
+    int_map = initial_intensities - (sigma_a * dists * scale_value).sum(dim=-1)
+    return int_map, sigma_a, dists
+
+
+def obtain_train_predictions_static(static_model, batch_origins, batch_directions, batch_initial_intensities, depth_values,
+                                    output_activation, batch_size, device, t_rand=None):
+    """model_helpers.py:99-113 -> (pix[R], un-scaled sigma[R,S], dists[S]) in one fused launch."""
+    z = randomize_depth(depth_values, device, t_rand)
+    dists = _interval_lengths(z, batch_directions)
+    pix, sigma = _fused.render_rays(static_model, None, batch_origins, batch_directions, None, batch_initial_intensities, z, dists,
+                                    act=output_activation, single=True)
+    return pix, sigma, dists
+
+
+def obtain_train_predictions_iter(static_model_coarse, temp_model_coarse, static_model_fine, temp_model_fine, batch_origins,
+                                  batch_directions, batch_phases, batch_initial_intensities, depth_values, output_activation,
+                                  batch_size, depth_samples_per_ray_fine, device, t_rand=None, u_fine=None):
+    """model_helpers.py:115-160 -> the reference's 8-tuple; the coarse pass is one fused launch."""
+    z = randomize_depth(depth_values, device, t_rand)
+    dists_c = _interval_lengths(z, batch_directions)
+    pix_c, sig_s_c, sig_d_c = _fused.render_rays(static_model_coarse, temp_model_coarse, batch_origins, batch_directions, batch_phases,
+                                                 batch_initial_intensities, z, dists_c, act=output_activation)
+    pix_f = sig_s_f = sig_d_f = dists_f = None
+    if depth_samples_per_ray_fine > 0:
+        R, n_coarse = pix_c.shape[0], z.shape[0]
+        total = sig_s_c + sig_d_c
+        jump = torch.cat([torch.full_like(total[:, :1], 1e-10), (total[:, 1:] - total[:, :-1]).abs()], dim=-1)
+        jump = jump / jump.max()                                   # batch-wide max (model_helpers.py:139)
+        z_rows = z[None, :].repeat(R, 1)
+        mids = 0.5 * (z_rows[..., 1:] + z_rows[..., :-1])
+        z_new = sample_pdf(mids, jump[..., 1:-1], depth_samples_per_ray_fine, device, u=u_fine)
+        z_all, _ = torch.sort(torch.cat([z_new, z_rows.detach()], -1), -1)
+        z0 = z_all[0, :]                                           # dists of ray 0 for every ray (model_helpers.py:150)
+        dists_f = _interval_lengths(z0, batch_directions)
+        phase_per_ray = batch_phases[:, 0] if batch_phases.dim() > 1 else batch_phases
+        pix_f, sig_s_f, sig_d_f = _fused.render_rays(static_model_fine, temp_model_fine, batch_origins, batch_directions, phase_per_ray,
+                                                     batch_initial_intensities, z_all, dists_f, act=output_activation)
+    return pix_c, sig_s_c, sig_d_c, dists_c, pix_f, sig_s_f, sig_d_f, dists_f
+
+
+def sample_pdf(bins, weights, N_samples, device, u=None):
+    """Inverse-transform sampling of fine depths (model_helpers.py:162-187); ``u`` injects the draw."""
+    w = weights + 1e-5
+    cdf = torch.cumsum(w / w.sum(dim=-1, keepdim=True), -1)
+    cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], dim=-1)
+    if u is None:
+        u = torch.rand(list(cdf.shape[:-1]) + [N_samples])
+    u = u.to(w)
+    hit = torch.searchsorted(cdf, u, right=True)
+    lo = (hit - 1).clamp(min=0)
+    hi = hit.clamp(max=cdf.shape[-1] - 1)
+    c_lo, c_hi = cdf.gather(1, lo), cdf.gather(1, hi)
+    b_lo, b_hi = bins.gather(1, lo), bins.gather(1, hi)
+    span = c_hi - c_lo
+    span = torch.where(span < 1e-5, torch.ones_like(span), span)
+    return b_lo + (u - c_lo) / span * (b_hi - b_lo)

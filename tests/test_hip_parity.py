@@ -1,0 +1,209 @@
+"""GPU parity: the HIP path (through the C ABI) against the golden fixtures captured from the
+reference and against the CPU oracle on seeded inputs.
+
+Tolerance (BASELINE.json north_star): 1e-5 relative in fp32, measured per tensor as
+max|a-b| / max|b|; index bookkeeping exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import nerfca_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def model_def(F, early, late, pos_enc="free_windowed", L=12, T=0, gauss=None, sigma=2, device="cpu"):
+    d = dict(num_early_layers=early, num_late_layers=late, num_filters=F, num_input_channels=3, num_output_channels=1,
+             use_bias=True, pos_enc=pos_enc, pos_enc_window_start=1, pos_enc_basis=L, fourier_sigma=sigma,
+             fourier_gaussian=gauss, act_func="relu", device=device)
+    if T:
+        d.update(num_input_times=1, use_time_latents=True, num_time_dim=T)
+    return d
+
+
+def make_static(params, dev, **kw):
+    from nerfca_amd.model.CPPN import CPPN
+    m = CPPN(model_def(device=dev, **kw))
+    m.load_state_dict(params)
+    return m.to(dev)
+
+
+def make_dynamic(params, dev, **kw):
+    from nerfca_amd.model.Temporal import Temporal
+    m = Temporal(model_def(device=dev, **kw))
+    m.load_state_dict(params)
+    return m.to(dev)
+
+
+def grads_of(model):
+    return {k: p.grad.detach().cpu() for k, p in model.named_parameters()}
+
+
+# ------------------------------------------------------------------------------------------
+def test_library_loaded():
+    from nerfca_amd import _capi
+    assert _capi.lib().nca_abi_version() == 1
+
+
+@pytest.mark.parametrize("F,early", [(F, e) for F in (32, 64, 128) for e in (0, 4)])
+def test_points_static_vs_reference(golden, dev, F, early):
+    g = golden("mlps")
+    tag = f"F{F}_e{early}_l0"
+    m = make_static(g.prefixed(f"s_{tag}_p_"), dev, F=F, early=early, late=0)
+    m.update_freq_mask_alpha(60000, 150000)
+    x = g["x"].to(dev)
+    y = m(x)
+    assert y.shape == (96, 1)
+    assert rel_err(y.cpu(), g[f"s_{tag}_y"]) < TOL
+    (y * g["gout"].to(dev)).sum().backward()
+    got = grads_of(m)
+    for k, ref in g.prefixed(f"s_{tag}_g_").items():
+        assert rel_err(got[k], ref) < TOL, k
+
+
+@pytest.mark.parametrize("F,early", [(F, e) for F in (32, 64, 128) for e in (0, 4)])
+def test_points_dynamic_vs_reference(golden, dev, F, early):
+    g = golden("mlps")
+    tag = f"F{F}_e{early}_l0"
+    m = make_dynamic(g.prefixed(f"d_{tag}_p_"), dev, F=F, early=early, late=0, T=8)
+    m.update_freq_mask_alpha(60000, 150000)
+    y = m.forward_composite(g["x"].to(dev), g["ts"].to(dev))
+    assert rel_err(y.cpu(), g[f"d_{tag}_y"]) < TOL
+    (y * g["gout"].to(dev)).sum().backward()
+    got = grads_of(m)
+    for k, ref in g.prefixed(f"d_{tag}_g_").items():
+        assert rel_err(got[k], ref) < TOL, k
+
+
+@pytest.mark.parametrize("enc", ["none", "vanilla", "nerfies_windowed", "fourier"])
+def test_points_other_encodings(golden, dev, enc):
+    g = golden("mlps")
+    L = 0 if enc == "none" else 6
+    gauss = g["enc_fourier_gauss"] if enc == "fourier" else None
+    s = make_static(g.prefixed(f"enc_{enc}_sp_"), dev, F=64, early=2, late=0, pos_enc=enc, L=L, gauss=gauss, sigma=3)
+    t = make_dynamic(g.prefixed(f"enc_{enc}_dp_"), dev, F=64, early=2, late=0, pos_enc=enc, L=L, T=4, gauss=gauss, sigma=3)
+    if enc == "nerfies_windowed":
+        s.update_windowed_alpha(30000, 100000)
+        t.update_windowed_alpha(30000, 100000)
+    x = g["x"].to(dev)
+    ys, yd = s(x), t.forward_composite(x, g["ts"].to(dev))
+    assert rel_err(ys.cpu(), g[f"enc_{enc}_ys"]) < TOL
+    assert rel_err(yd.cpu(), g[f"enc_{enc}_yd"]) < TOL
+    ((ys + yd) * g["gout"].to(dev)).sum().backward()
+    gs, gd = grads_of(s), grads_of(t)
+    for k, ref in g.prefixed(f"enc_{enc}_sg_").items():
+        assert rel_err(gs[k], ref) < TOL, k
+    for k, ref in g.prefixed(f"enc_{enc}_dg_").items():
+        assert rel_err(gd[k], ref) < TOL, k
+
+
+@pytest.mark.parametrize("R,S", [(8, 16), (64, 192)])
+@pytest.mark.parametrize("dtn", ["f64", "f32"])
+def test_render_forward_vs_reference(golden, dev, R, S, dtn):
+    """obtain_train_predictions_iter (coarse) on the reference's own inputs and weights."""
+    from nerfca_amd.train import model_helpers as MH
+    g = golden("predict_iter")
+    tag = f"R{R}_S{S}_{dtn}_fine0"
+    F = 128 if S == 192 else 64
+    s = make_static(g.prefixed(f"{tag}_sp_"), dev, F=F, early=4, late=0)
+    t = make_dynamic(g.prefixed(f"{tag}_dp_"), dev, F=F, early=4, late=0, T=8)
+    s.update_freq_mask_alpha(75000, 150000)
+    t.update_freq_mask_alpha(75000, 150000)
+    phs = g[f"{tag}_ph"][:, None].repeat(1, S).to(dev)
+    res = MH.obtain_train_predictions_iter(s, t, None, None, g[f"{tag}_o"].to(dev), g[f"{tag}_d"].to(dev), phs,
+                                           g[f"{tag}_I0"].to(dev), g[f"{tag}_z"].to(dev), "softplus", 32768, 0, dev,
+                                           t_rand=g[f"{tag}_t_rand"])
+    names = ["pix_c", "sig_s_c", "sig_d_c", "dists_c"]
+    for n, v in zip(names, res[:4]):
+        ref = g[f"{tag}_{n}"]
+        assert v.dtype == ref.dtype and tuple(v.shape) == tuple(ref.shape), n
+        assert rel_err(v.cpu(), ref) < TOL, n
+    assert all(v is None for v in res[4:])
+
+
+@pytest.mark.parametrize("R,S,F", [(8, 16, 32), (33, 50, 64), (64, 192, 128), (7, 500, 128)])
+@pytest.mark.parametrize("f64", [True, False])
+def test_render_backward_vs_oracle(dev, R, S, F, f64):
+    """All parameter gradients of a random scalar functional of (pix, sigma_s, sigma_d)."""
+    from nerfca_amd import render_rays
+    gen = torch.Generator().manual_seed(1234 + R + S)
+    ss = O.NetSpec(num_filters=F, num_early_layers=3, num_time_dim=0)
+    sd = O.NetSpec(num_filters=F, num_early_layers=3, num_time_dim=8)
+    ps, pd = O.init_params(ss, gen), O.init_params(sd, gen)
+    win = O.freq_mask_alpha(12, 75000, 150000, 1)[0]
+    dt = torch.float64 if f64 else torch.float32
+    o = (torch.rand(R, 3, generator=gen) * 0.2 + torch.tensor([3.0, -2.0, 2.5])).to(dt)
+    d = (torch.rand(R, 3, generator=gen) - 0.5).to(dt)
+    d = d / d.norm(dim=-1, keepdim=True) * 1.001
+    ph = torch.randint(0, 10, (R,), generator=gen)
+    z = O.stratified_depths(O.depth_values(3.4259, 5.5741, S), torch.rand(S, generator=gen))
+    I0 = torch.full((R,), 2.15991)
+    cp, cs, cd = torch.randn(R, generator=gen).to(dt), torch.randn(R, S, generator=gen), torch.randn(R, S, generator=gen)
+
+    pso = {k: v.clone().requires_grad_(True) for k, v in ps.items()}
+    pdo = {k: v.clone().requires_grad_(True) for k, v in pd.items()}
+    pix, a, b, dists = O.predict_iter(pso, ss, win, pdo, sd, win, o, d, ph[:, None].repeat(1, S), I0, z)[:4]
+    ((pix * cp).sum() + (a * cs).sum() * 50 + (b * cd).sum() * 50).backward()
+
+    s = make_static(ps, dev, F=F, early=3, late=0)
+    t = make_dynamic(pd, dev, F=F, early=3, late=0, T=8)
+    s.update_freq_mask_alpha(75000, 150000)
+    t.update_freq_mask_alpha(75000, 150000)
+    pix2, a2, b2 = render_rays(s, t, o.to(dev), d.to(dev), ph.to(dev), I0.to(dev), z.to(dev), dists.to(dev))
+    assert pix2.dtype == pix.dtype
+    assert rel_err(pix2.cpu(), pix) < TOL and rel_err(a2.cpu(), a) < TOL and rel_err(b2.cpu(), b) < TOL
+    ((pix2 * cp.to(dev)).sum() + (a2 * cs.to(dev)).sum() * 50 + (b2 * cd.to(dev)).sum() * 50).backward()
+    gs, gd = grads_of(s), grads_of(t)
+    for k in pso:
+        assert rel_err(gs[k], pso[k].grad) < TOL, ("static", k)
+    for k in pdo:
+        assert rel_err(gd[k], pdo[k].grad) < TOL, ("dynamic", k)
+
+
+def test_render_static_only_vs_reference(golden, dev):
+    """obtain_train_predictions_static (run_nerf.py path): un-scaled sigma is returned."""
+    from nerfca_amd.train import model_helpers as MH
+    g = golden("predict_iter")
+    s = make_static(g.prefixed("static_sp_"), dev, F=128, early=4, late=0)
+    s.update_freq_mask_alpha(40000, 80000)
+    pix, sig, dists = MH.obtain_train_predictions_static(s, g["static_o"].to(dev), g["static_d"].to(dev), g["static_I0"].to(dev),
+                                                        g["static_z"].to(dev), "softplus", 32768, dev, t_rand=g["static_t_rand"])
+    assert rel_err(pix.cpu(), g["static_pix"]) < TOL
+    assert rel_err(sig.cpu(), g["static_sig"]) < TOL
+    assert torch.equal(dists.cpu(), g["static_dists"])
+
+
+def test_backward_is_deterministic(dev):
+    """Split-slab reduction, no atomics: two runs give bit-identical gradients."""
+    from nerfca_amd import render_rays
+    gen = torch.Generator().manual_seed(5)
+    ss, sd = O.NetSpec(num_filters=128), O.NetSpec(num_filters=128, num_time_dim=8)
+    s = make_static(O.init_params(ss, gen), dev, F=128, early=4, late=0)
+    t = make_dynamic(O.init_params(sd, gen), dev, F=128, early=4, late=0, T=8)
+    for m in (s, t):
+        m.update_freq_mask_alpha(75000, 150000)
+    R, S = 300, 192
+    o = (torch.rand(R, 3, generator=gen) + 2).double().to(dev)
+    d = (torch.rand(R, 3, generator=gen) - 0.5).double().to(dev)
+    ph = torch.randint(0, 10, (R,), generator=gen).to(dev)
+    z = O.depth_values(3.4, 5.6, S).to(dev)
+    dists = O.ray_dists(z.cpu(), torch.float64).to(dev)
+    I0 = torch.full((R,), 2.0, device=dev)
+    outs = []
+    for _ in range(2):
+        for m in (s, t):
+            m.zero_grad()
+        pix, a, b = render_rays(s, t, o, d, ph, I0, z, dists)
+        (pix.sum() + a.sum() + 2 * b.sum()).backward()
+        outs.append(torch.cat([p.grad.flatten() for p in list(s.parameters()) + list(t.parameters())]).clone())
+    assert torch.equal(outs[0], outs[1])

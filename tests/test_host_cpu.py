@@ -1,0 +1,225 @@
+"""CPU tests of the host-side mirror of the reference interface and of the C-ABI library surface.
+
+No compute call goes to the library here (there is no GPU): we check that it loads, exports every
+symbol of include/nerfca_hip.h, answers the pure-host queries, and that unsupported configurations
+are explicit errors.
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, rel_err
+
+
+def model_def(F=128, early=4, late=0, pos_enc="free_windowed", L=12, T=0, gauss=None):
+    d = dict(num_early_layers=early, num_late_layers=late, num_filters=F, num_input_channels=3, num_output_channels=1,
+             use_bias=True, pos_enc=pos_enc, pos_enc_window_start=1, pos_enc_basis=L, fourier_sigma=2,
+             fourier_gaussian=gauss, act_func="relu", device="cpu")
+    if T:
+        d.update(num_input_times=1, use_time_latents=True, num_time_dim=T)
+    return d
+
+
+# ----------------------------------------------------------------------------- C ABI surface
+def test_library_exports_every_declared_symbol():
+    from nerfca_amd import _capi
+    header = open(os.path.join(ROOT, "include", "nerfca_hip.h")).read()
+    declared = set(re.findall(r"\b(nca_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    lib = C.CDLL(_capi.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in nerfca_hip.h but not exported"
+    assert declared == set(_capi.SYMBOLS), "ctypes table and header disagree"
+    assert _capi.lib().nca_abi_version() == 1
+
+
+def test_param_count_and_packed_size_match_reference_nets():
+    from nerfca_amd import _capi
+    from nerfca_amd.model.CPPN import CPPN
+    from nerfca_amd.model.Temporal import Temporal
+    s, t = CPPN(model_def()), Temporal(model_def(T=8))
+    assert sum(p.numel() for p in s.parameters()) == 75905
+    assert sum(p.numel() for p in t.parameters()) == 77009      # a7
+    lib = _capi.lib()
+    assert lib.nca_param_count(C.byref(s._binding.net)) == 75905
+    assert lib.nca_param_count(C.byref(t._binding.net)) == 77009
+    assert lib.nca_packed_bytes(C.byref(s._binding.net), _capi.PREC_F32) > 4 * 75905
+
+
+def test_unsupported_configs_are_explicit_errors():
+    from nerfca_amd import _capi
+    lib = _capi.lib()
+    bad = _capi.NcaNet(F=48, n_hidden=4, n_late=0, enc_mode=1, L=12, T=0, P=0, reserved=0)
+    assert lib.nca_param_count(C.byref(bad)) == -2
+    assert b"num_filters" in lib.nca_last_error()
+    late_dyn = _capi.NcaNet(F=64, n_hidden=1, n_late=2, enc_mode=1, L=4, T=4, P=10, reserved=0)
+    assert lib.nca_param_count(C.byref(late_dyn)) == -2
+    with pytest.raises(_capi.NcaError):
+        _capi.check(lib.nca_packed_bytes(C.byref(bad), 0))
+
+
+def test_fused_path_refuses_cpu_tensors():
+    from nerfca_amd import _capi
+    from nerfca_amd.model.CPPN import CPPN
+    m = CPPN(model_def(F=32, early=1))
+    m.update_freq_mask_alpha(1, 10)
+    with pytest.raises(_capi.NcaError, match="GPU"):
+        m(torch.zeros(4, 3))
+
+
+# ----------------------------------------------------------------------------- drop-in module surface
+def test_state_dict_keys_and_save_blob(golden, tmp_path):
+    from nerfca_amd.model.CPPN import CPPN
+    from nerfca_amd.model.Temporal import Temporal
+    g = golden("checkpoint_keys")
+    s, t = CPPN(model_def(late=2)), Temporal(model_def(T=8))
+    assert list(s.state_dict().keys()) == list(g.np("static_late2_keys"))
+    assert list(t.state_dict().keys()) == list(g.np("temporal_keys"))
+    assert [str(tuple(v.shape)) for v in t.state_dict().values()] == list(g.np("temporal_shapes"))
+    for name, m in (("static", s), ("temporal", t)):
+        m.update_freq_mask_alpha(10, 100)
+        f = tmp_path / f"{name}.pth"
+        m.save(str(f), {"note": 1})
+        blob = torch.load(str(f), weights_only=False)
+        assert list(blob.keys()) == list(g.np(f"{name}_save_keys"))
+        assert blob["version"] == str(g.np(f"{name}_save_version"))
+
+
+def test_same_seed_same_init_as_reference(golden):
+    """Layers are created in the reference's order, so a torch seed reproduces its initial weights."""
+    from nerfca_amd.model.CPPN import CPPN
+    g = golden("mlps")
+    torch.manual_seed(1000 + 128 + 4 * 7 + 0)
+    m = CPPN(model_def(F=128, early=4, late=0))
+    for k, v in g.prefixed("s_F128_e4_l0_p_").items():
+        assert torch.equal(m.state_dict()[k], v), k
+
+
+def test_parameters_are_views_of_one_flat_buffer():
+    from nerfca_amd.model.Temporal import Temporal
+    t = Temporal(model_def(T=8))
+    b = t._binding
+    assert b.flat.numel() == 77009
+    names = [n for n, _ in t.named_parameters()]
+    assert names[0] == "time_latents" and names[-1] == "output_linear.0.bias"
+    off = 0
+    for p in t.parameters():
+        assert p.data_ptr() == b.flat.data_ptr() + 4 * off
+        off += p.numel()
+    with torch.no_grad():
+        t.time_latents.add_(1.0)
+    assert torch.equal(b.flat[:80].view(10, 8), t.time_latents.detach())
+    t.to(torch.device("cpu"))  # _apply re-flattens
+    assert t._binding._is_flat()
+
+
+def test_schedules_and_windows(golden):
+    from nerfca_amd.model.CPPN import CPPN
+    from nerfca_amd.schedules import linear_param_decay
+    g = golden("schedules")
+    m = CPPN(model_def())
+    for it, mask, a in zip(g.np("free_its"), g.np("free_masks"), g.np("free_alphas")):
+        m.update_freq_mask_alpha(int(it), 150000)
+        assert np.array_equal(m.freq_mask_alpha.numpy(), mask) and float(m.windowed_alpha) == float(a)
+    its = g.np("decay_iters")
+    assert np.array_equal(np.array([linear_param_decay(int(i), 1e-12, 1e-10, 100000, delay_steps=40000) for i in its], dtype=np.float64), g.np("decay_favor"))
+    gp = golden("posenc")
+    m = CPPN(model_def(pos_enc="nerfies_windowed"))
+    for a in (0.0, 3.3, 12.0):
+        m.windowed_alpha = a
+        assert torch.equal(m.windowed_pos_enc(12, "pts"), gp[f"nerfies_window_a{a}"])
+        assert torch.equal(m.pos_enc(gp["x"], 12, "pts"), gp[f"nerfies_a{a}"])
+    m = CPPN(model_def())
+    with pytest.raises(AttributeError):
+        m._band_window()  # free_windowed before the first update_freq_mask_alpha (SURVEY 8a notes)
+
+
+def test_temporal_quirks_raise_like_reference():
+    from nerfca_amd.model.Temporal import Temporal
+    d = model_def(T=8)
+    d["use_time_latents"] = False
+    with pytest.raises(UnboundLocalError):
+        Temporal(d).forward_composite(torch.zeros(2, 3), torch.zeros(2))
+
+
+# ----------------------------------------------------------------------------- data loader + geometry
+VIEWS = [[-30, 30], [-30, -30], [60, -30], [60, 30], [-5, 40]]
+
+
+def test_ray_geometry_and_table(golden, tmp_path):
+    from nerfca_amd.train import data_helpers as DH, proj_helpers as PH
+    g = golden("geometry")
+    geo = dict(DSD=25.0, DSO=4.5, nDetector=[16, 16], dDetector=[2.0 / 16, 2.0 / 16], offDetector=[0.0, 0.0])
+    assert np.array_equal(PH.source_matrix_tigre(np.array([0, 0, -4.5]), -30, 30), g.np("n16_pose_v0"))
+    for i, (th, ph) in enumerate(VIEWS):
+        ro, rd = PH.get_ray_values_tigre(th, ph, 0, geo, "cpu")
+        assert np.array_equal(ro, g.np(f"n16_v{i}_o")) and np.array_equal(rd, g.np(f"n16_v{i}_d"))
+    W = H = 5
+    geo = dict(DSD=25.0, DSO=4.5, nDetector=[W, H], dDetector=[0.3, 0.5], offDetector=[0.05, -0.1])
+    frames = []
+    for k, (v, p) in enumerate(zip(g.np("table_views"), g.np("table_phase_in"))):
+        fp, wp = tmp_path / f"i{k}.npy", tmp_path / f"v{k}.npy"
+        np.save(fp, g.np("table_imgs")[k])
+        np.save(wp, g.np("table_vars")[k])
+        frames.append(dict(theta=float(v[0]), phi=float(v[1]), larm=0, file_path=str(fp), weighted_file_path=str(wp),
+                           img_min_max=[0.2, 1.7], heart_phase=int(p)))
+    rays, phases = DH.prepare_data_for_loader_tigre(frames, geo, W, H, 8, 0.5, "cpu")
+    assert rays.dtype == np.float64 and np.array_equal(rays, g.np("table_rays"))
+    assert phases.dtype == g.np("table_phases").dtype and np.array_equal(phases, g.np("table_phases"))
+    assert torch.equal(DH.create_depth_values(3.4259, 5.5741, 192, "cpu"), golden("depth")["z"])
+
+
+def test_randomize_depth_matches_reference_draw(golden):
+    from nerfca_amd.train import model_helpers as MH
+    g = golden("depth")
+    torch.manual_seed(303)
+    assert torch.equal(MH.randomize_depth(g["z"], "cpu"), g["z_jit"])       # same CPU generator stream
+    assert torch.equal(MH.randomize_depth(g["z"], "cpu", t_rand=g["t_rand"]), g["z_jit"])
+
+
+# ----------------------------------------------------------------------------- losses / render helpers
+@pytest.mark.parametrize("dtn", ["f64", "f32"])
+def test_losses_match_reference(golden, dtn):
+    from types import SimpleNamespace
+    from nerfca_amd.train import model_helpers as MH
+    g = golden("losses")
+    args = SimpleNamespace(favor_s_opt=None, skewness_val=1.0, entro_mask_thre=1e-4, entro_use_weighting=True,
+                           entro_weighted_thresh=0.03, occl_reg_perc=0.2)
+    a = g[f"{dtn}_sig_s"].clone().requires_grad_(True)
+    b = g[f"{dtn}_sig_d"].clone().requires_grad_(True)
+    res = MH.compute_losses(a, b, g[f"{dtn}_dists"], g[f"{dtn}_wpix"], args)
+    names = ["blendw", "sig_s_max", "sig_d_max", "favor", "s_ent", "s_sum", "d_ent", "d_sum", "occl", "l1", "l2"]
+    for n, v in zip(names, res):
+        assert rel_err(v, g[f"{dtn}_{n}"]) < 1e-6, n
+    (0.7 * res[3] + 1.3 * res[4] + 0.9 * res[6] + 0.5 * res[8] + 0.25 * res[9] + 2.0 * res[10]).backward()
+    assert rel_err(a.grad, g[f"{dtn}_g_sig_s"]) < 1e-6 and rel_err(b.grad, g[f"{dtn}_g_sig_d"]) < 1e-6
+    assert torch.equal(MH.weighted_MSELoss()(g[f"{dtn}_mse_pred"], g[f"{dtn}_mse_gt"], g[f"{dtn}_wpix"]), g[f"{dtn}_mse"])
+    assert rel_err(MH.compute_occl_loss(b, g[f"{dtn}_dists"], 0.2, use_back=True), g[f"{dtn}_occl_back"]) < 1e-6
+
+
+@pytest.mark.parametrize("act", ["softplus", "clamp", "Softplus"])
+def test_render_helpers_match_reference(golden, act):
+    from nerfca_amd.train import model_helpers as MH
+    g = golden("render")
+    for dtn, dt in (("f64", torch.float64), ("f32", torch.float32)):
+        dirs = torch.zeros(12, 3, dtype=dt)
+        out = MH.render_volume_density_composite(g["raw_s"], g["raw_d"], g["I0"], dirs, g["z"], act)
+        for v, n in zip(out, ("pix", "sig_s", "sig_d", "dists")):
+            assert torch.equal(v, g[f"comp_{dtn}_{act}_{n}"]), n
+        out = MH.render_volume_density(g["raw_s"], g["I0"], dirs, g["z"], act)
+        for v, n in zip(out, ("pix", "sig", "dists")):
+            assert torch.equal(v, g[f"single_{dtn}_{act}_{n}"]), n
+
+
+def test_sample_pdf_matches_oracle():
+    from nerfca_amd.train import model_helpers as MH
+    from oracle import nerfca_oracle as O
+    gen = torch.Generator().manual_seed(3)
+    bins = torch.sort(torch.rand(6, 15, generator=gen), -1)[0]
+    w = torch.rand(6, 14, generator=gen)
+    u = torch.rand(6, 9, generator=gen)
+    assert torch.equal(MH.sample_pdf(bins, w, 9, "cpu", u=u), O.sample_pdf(bins, w, u))
