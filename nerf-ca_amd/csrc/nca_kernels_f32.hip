@@ -180,7 +180,7 @@ __device__ __forceinline__ void enc_steps(const NcaLayout& y, const float (&p)[3
 template <int F>
 struct FusedCfg {
     static constexpr int MT = F / 32;
-    static constexpr int IMG_MAX = F * F * 2 + 2 * (2 * MT * 16 * 4) + 16;          // hidden image + bias + Wo/bo tails
+    static constexpr int IMG_MAX = NCA_MAX_KSTEPS * 64 * MT * 4 + 2 * (2 * MT * 16 * 4) + 16;   // largest image: k-steps + bias + Wo/bo tails
     static constexpr int BUF_BYTES = (IMG_MAX + 255) & ~255;
     static constexpr int PF = (BUF_BYTES + NCA_NT * 16 - 1) / (NCA_NT * 16);       // 16-byte prefetch registers per thread
 };
@@ -300,14 +300,14 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
                         load_a<MT>(imgl + s * 64 * MT, av);
 #pragma unroll
                         for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bop, acc[m], 0, 0, 0);
-                        if (BWD && jj == 0) {
+                        if (BWD && jj == 0 && tvalid) {
                             int ia, ib;
                             nca_enc_pair(y, s, &ia, &ib);
                             const int row = lh ? ib : ia;
                             if (row >= 0) henc[(int64_t)row * a.Nc + col] = bop;
                         }
                     });
-                    if (BWD && jj == 0 && y.P > 0) {
+                    if (BWD && jj == 0 && y.P > 0 && tvalid) {
                         // one-hot phase rows: their "weight gradient" is sum_n [phase_n = p] D0[:, n]
                         for (int pp = lh; pp < y.P; pp += 2) henc[(int64_t)(y.K0 + pp) * a.Nc + col] = (pp == phc) ? 1.f : 0.f;
                     }
@@ -330,8 +330,8 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) hprev[m][i] = fmaxf(acc[m][i], 0.f);
 
-                if (BWD && jj + 1 < y.NL) {
-                    // input of layer jj+1, feature-major
+                if (BWD && jj + 1 < y.NL && tvalid) {
+                    // input of layer jj+1, feature-major (waves past the last tile write nothing)
                     float* hh = hs + (int64_t)(y.K0rows_pad + jj * F) * a.Nc + col;
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
                             for (int i = 0; i < 16; ++i) {
                                 const float dv = hprev[m][i] > 0.f ? wo[(lh * MT + m) * 16 + i] * g : 0.f;
                                 hprev[m][i] = dv;
-                                dd[(int64_t)(32 * m + nca_rho(i) + 4 * lh) * a.Nc] = dv;
+                                if (tvalid) dd[(int64_t)(32 * m + nca_rho(i) + 4 * lh) * a.Nc] = dv;
                             }
                     }
                 }
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
                             const int64_t ro = (int64_t)(32 * m + nca_rho(i) + 4 * lh) * a.Nc;
                             const float dv = hh[ro] > 0.f ? acc[m][i] : 0.f;
                             hprev[m][i] = dv;
-                            dd[ro] = dv;
+                            if (tvalid) dd[ro] = dv;
                         }
                     {
                         uint4* dst = reinterpret_cast<uint4*>(smem + (cur ^ 1) * BUF);

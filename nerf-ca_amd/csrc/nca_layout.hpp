@@ -21,6 +21,7 @@
 #define NCA_MAX_LAYERS 12
 #define NCA_MAX_STAGES 48
 #define NCA_MAX_JOBS 40
+#define NCA_MAX_KSTEPS 64   // k-steps one LDS weight image may hold (a hidden layer of width 128 uses all 64)
 
 enum { NCA_IN_ENC = 0, NCA_IN_HID = 1, NCA_IN_SKIP = 2 };
 
@@ -111,6 +112,7 @@ inline int nca_build_layout(const NcaNet& n, NcaLayout* out, const char** why) {
         if (j == 0) { l.kind = NCA_IN_ENC; l.K = y.K0; l.ksteps_enc = y.enc_steps; l.ksteps = y.enc_steps; }
         else if (n.n_late > 0 && j == 1 + n.n_hidden) { l.kind = NCA_IN_SKIP; l.K = y.K0 + y.F; l.ksteps_enc = y.enc_steps; l.ksteps = y.enc_steps + y.F / 2; }
         else { l.kind = NCA_IN_HID; l.K = y.F; l.ksteps_enc = 0; l.ksteps = y.F / 2; }
+        if (l.ksteps > NCA_MAX_KSTEPS) { *why = "a layer needs more than 64 MFMA k-steps (encoded input too wide for this num_filters)"; return NCA_E_UNSUPPORTED; }
         l.w_off = off; off += y.F * l.K;
         l.b_off = off; off += y.F;
         l.img_off = boff;

@@ -131,10 +131,29 @@ def test_render_forward_vs_reference(golden, dev, R, S, dtn):
     assert all(v is None for v in res[4:])
 
 
+def _oracle_render_grads(ps, ss, pd, sd, win, o, d, ph, I0, z, cp, cs, cd, dt):
+    """Outputs and all parameter gradients of the oracle evaluated in dtype `dt` (same f32 query points)."""
+    S = z.shape[0]
+    pso = {k: v.clone().to(dt).requires_grad_(True) for k, v in ps.items()}
+    pdo = {k: v.clone().to(dt).requires_grad_(True) for k, v in pd.items()}
+    pts = O.query_points(o, d, z).to(dt)
+    w = win.to(dt)
+    raw_s = O.static_forward(pso, ss, pts, w).reshape(o.shape[0], S, -1)
+    raw_d = O.dynamic_forward(pdo, sd, pts, ph[:, None].repeat(1, S).flatten(), w).reshape(o.shape[0], S, -1)
+    pix, a, b, dists = O.composite(raw_s, raw_d, I0.to(dt), d, z.to(dt))
+    ((pix * cp).sum() + (a * cs).sum() * 50 + (b * cd).sum() * 50).backward()
+    return pix, a, b, dists, pso, pdo
+
+
 @pytest.mark.parametrize("R,S,F", [(8, 16, 32), (33, 50, 64), (64, 192, 128), (7, 500, 128)])
 @pytest.mark.parametrize("f64", [True, False])
 def test_render_backward_vs_oracle(dev, R, S, F, f64):
-    """All parameter gradients of a random scalar functional of (pix, sigma_s, sigma_d)."""
+    """All parameter gradients of a random scalar functional of (pix, sigma_s, sigma_d).
+
+    Outputs: 1e-5.  Gradients: 1e-5, widened to 3x the f32 oracle's own distance from the f64 oracle
+    when that is larger -- a ReLU whose pre-activation lies within rounding of zero flips its mask, which
+    moves a gradient by O(1/N); the reference's fp32 arithmetic has exactly the same property, so
+    its measured rounding noise on the same inputs is the meaningful floor."""
     from nerfca_amd import render_rays
     gen = torch.Generator().manual_seed(1234 + R + S)
     ss = O.NetSpec(num_filters=F, num_early_layers=3, num_time_dim=0)
@@ -150,10 +169,8 @@ def test_render_backward_vs_oracle(dev, R, S, F, f64):
     I0 = torch.full((R,), 2.15991)
     cp, cs, cd = torch.randn(R, generator=gen).to(dt), torch.randn(R, S, generator=gen), torch.randn(R, S, generator=gen)
 
-    pso = {k: v.clone().requires_grad_(True) for k, v in ps.items()}
-    pdo = {k: v.clone().requires_grad_(True) for k, v in pd.items()}
-    pix, a, b, dists = O.predict_iter(pso, ss, win, pdo, sd, win, o, d, ph[:, None].repeat(1, S), I0, z)[:4]
-    ((pix * cp).sum() + (a * cs).sum() * 50 + (b * cd).sum() * 50).backward()
+    pix, a, b, dists, ps32, pd32 = _oracle_render_grads(ps, ss, pd, sd, win, o, d, ph, I0, z, cp, cs, cd, torch.float32)
+    _, _, _, _, ps64, pd64 = _oracle_render_grads(ps, ss, pd, sd, win, o, d, ph, I0, z, cp, cs, cd, torch.float64)
 
     s = make_static(ps, dev, F=F, early=3, late=0)
     t = make_dynamic(pd, dev, F=F, early=3, late=0, T=8)
@@ -163,11 +180,10 @@ def test_render_backward_vs_oracle(dev, R, S, F, f64):
     assert pix2.dtype == pix.dtype
     assert rel_err(pix2.cpu(), pix) < TOL and rel_err(a2.cpu(), a) < TOL and rel_err(b2.cpu(), b) < TOL
     ((pix2 * cp.to(dev)).sum() + (a2 * cs.to(dev)).sum() * 50 + (b2 * cd.to(dev)).sum() * 50).backward()
-    gs, gd = grads_of(s), grads_of(t)
-    for k in pso:
-        assert rel_err(gs[k], pso[k].grad) < TOL, ("static", k)
-    for k in pdo:
-        assert rel_err(gd[k], pdo[k].grad) < TOL, ("dynamic", k)
+    for name, got, p32, p64 in (("static", grads_of(s), ps32, ps64), ("dynamic", grads_of(t), pd32, pd64)):
+        for k in p32:
+            floor = rel_err(p32[k].grad, p64[k].grad)
+            assert rel_err(got[k], p64[k].grad) < max(TOL, 3 * floor), (name, k, floor)
 
 
 def test_render_static_only_vs_reference(golden, dev):
@@ -207,3 +223,35 @@ def test_backward_is_deterministic(dev):
         (pix.sum() + a.sum() + 2 * b.sum()).backward()
         outs.append(torch.cat([p.grad.flatten() for p in list(s.parameters()) + list(t.parameters())]).clone())
     assert torch.equal(outs[0], outs[1])
+
+
+def test_backward_is_linear_in_upstream_gradient(dev):
+    """Size-independent property at a realistic batch: with the weights fixed, the backward pass is a
+    linear map of (g_pix, g_sigma_s, g_sigma_d) -- the recomputed ReLU masks are identical between
+    calls -- so grads(g1 + g2) == grads(g1) + grads(g2) up to f32 summation rounding."""
+    from nerfca_amd import render_rays
+    gen = torch.Generator().manual_seed(11)
+    ss, sd = O.NetSpec(num_filters=128), O.NetSpec(num_filters=128, num_time_dim=8)
+    s = make_static(O.init_params(ss, gen), dev, F=128, early=4, late=0)
+    t = make_dynamic(O.init_params(sd, gen), dev, F=128, early=4, late=0, T=8)
+    for m in (s, t):
+        m.update_freq_mask_alpha(75000, 150000)
+    R, S = 2048, 192
+    o = (torch.rand(R, 3, generator=gen) * 0.2 + torch.tensor([3.0, -2.0, 2.5])).double().to(dev)
+    d = (torch.rand(R, 3, generator=gen) - 0.5).double().to(dev)
+    ph = torch.randint(0, 10, (R,), generator=gen).to(dev)
+    z = O.stratified_depths(O.depth_values(3.4259, 5.5741, S), torch.rand(S, generator=gen))
+    dists = O.ray_dists(z, torch.float64).to(dev)
+    z = z.to(dev)
+    I0 = torch.full((R,), 2.15991, device=dev)
+    coef = [(torch.randn(R, generator=gen).double().to(dev), torch.randn(R, S, generator=gen).to(dev), torch.randn(R, S, generator=gen).to(dev))
+            for _ in range(2)]
+    coef.append(tuple(a + b for a, b in zip(*coef)))
+    flat = []
+    for cp, cs, cd in coef:
+        for m in (s, t):
+            m.zero_grad()
+        pix, a, b = render_rays(s, t, o, d, ph, I0, z, dists)
+        ((pix * cp).sum() + (a * cs).sum() * 50 + (b * cd).sum() * 50).backward()
+        flat.append(torch.cat([p.grad.flatten() for p in list(s.parameters()) + list(t.parameters())]).double().cpu())
+    assert rel_err(flat[2], flat[0] + flat[1]) < 2e-6
