@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training rays/sec of the composite NeRF-CA step on synthetic
+256^2-detector x 192-samples/ray batches (BASELINE.json metric, configs[1]).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch: ray gather (GPU-resident table), fused
+forward, all losses, fused backward, (all-reduce), Adam + LinearLR.  Inputs are resident in HBM when
+the timed region starts.  Weak scaling: every rank renders --rays rays per step.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the kernel with the largest share of the timed
+region, measured with HIP events on the launch stream inside the library (nca_timing_*);
+`cpu_baseline` is the CPU oracle (reference-equivalent torch CPU ops) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# algorithmic work per sample of the default nets (recompute NOT counted)
+FLOP_FWD, FLOP_DGRAD, FLOP_WGRAD = 303104, 264704, 303104
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}       # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rays", type=int, default=65536, help="rays per step per GPU (one full 256^2 detector)")
+    ap.add_argument("--det", type=int, default=256)
+    ap.add_argument("--samples", type=int, default=192)
+    ap.add_argument("--prec", default="f32", choices=["f32"])
+    ap.add_argument("--cpu-rays", type=int, default=2048, help="rays per step of the CPU baseline sample")
+    ap.add_argument("--cpu-steps", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--views", type=int, default=4)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, data, cfg_kwargs):
+    """Reference-equivalent CPU path (oracle) on a bounded sample of the same workload."""
+    from oracle import nerfca_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    R, S = args.cpu_rays, args.samples
+    gen = torch.Generator().manual_seed(0)
+    ss, sd = O.NetSpec(num_filters=128), O.NetSpec(num_filters=128, num_time_dim=8)
+    tr = O.OracleTrainer(O.init_params(ss, gen), ss, O.init_params(sd, gen), sd)
+    ids = torch.randint(0, data.rays_train.shape[0], (R,), generator=gen)
+    rays = data.rays_train.cpu().index_select(0, ids)
+    ph = data.phases_train.cpu().index_select(0, ids)
+    o, d, gt, w = rays[:, 0, :], rays[:, 1, :], rays[:, 2, 0], rays[:, 3, 0]
+    I0 = torch.full((R,), float(data.geo["max_pixel_value"]))
+    z0 = O.depth_values(data.geo["near_thresh"], data.geo["far_thresh"], S)
+    phs = ph[:, None].repeat(1, S)
+
+    def one(i):
+        zj = O.stratified_depths(z0, torch.rand(S, generator=gen))
+        tr.step(75000 + i, o, d, phs, I0, zj, gt, w)
+
+    one(0)
+    t0 = time.perf_counter()
+    for i in range(args.cpu_steps):
+        one(1 + i)
+    dt = time.perf_counter() - t0
+    return {"value": R * args.cpu_steps / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+            "sample": f"{args.cpu_steps} full training steps of {R} rays x {S} samples (same nets, losses, Adam) with torch CPU ops, "
+                      f"{dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from nerfca_amd import _capi, synthetic
+    from nerfca_amd.model.CPPN import CPPN
+    from nerfca_amd.model.Temporal import Temporal
+    from nerfca_amd.train.trainer import CompositeTrainer, TrainConfig
+    _capi.lib()   # fail loudly if the HIP library is missing
+
+    views = synthetic.TRAIN_VIEWS if args.views == 4 else synthetic.TRAIN_VIEWS_8[: args.views]
+    data = synthetic.make_dataset(args.det, args.samples, dev, views=views)
+    torch.manual_seed(1)
+    sdef, tdef = synthetic.net_definitions(dev)
+    s, t = CPPN(sdef).to(dev), Temporal(tdef).to(dev)
+    cfg = TrainConfig(depth_samples_per_ray_coarse=args.samples, img_sample_size=args.rays * world)
+    tr = CompositeTrainer(cfg, s, t, data, dev, rank=rank, world=world, seed=0)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    base_iter = 75000    # steady state: half of the frequency bands open
+    for i in range(args.warmup):
+        tr.step(base_iter + i)
+    barrier()
+    _capi.timing_reset()
+    _capi.timing_enable(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss, _, _ = tr.step(base_iter + args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    _capi.timing_enable(False)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        n_samp = args.rays * args.samples * args.steps               # per GPU over the timed region
+        kern = {}
+        for name, flop in (("fwd", FLOP_FWD), ("bwd_dgrad", FLOP_DGRAD), ("bwd_wgrad", FLOP_WGRAD), ("bwd_reduce", 0), ("pack", 0)):
+            ms, n = _capi.timing_read(name)
+            kern[name] = {"ms_total": ms, "launches": n, "avg_ms": ms / n if n else None,
+                          "tflops": (flop * n_samp / (ms * 1e-3) / 1e12) if ms > 0 and flop else None}
+        dom = max(("fwd", "bwd_dgrad", "bwd_wgrad"), key=lambda k: kern[k]["ms_total"])
+        peak = PEAK_TFLOPS[args.prec]
+        roof = {"bound": "mfma", "kernel": dom, "achieved": kern[dom]["tflops"], "peak": peak, "unit": "TFLOP/s",
+                "frac": kern[dom]["tflops"] / peak if kern[dom]["tflops"] else None, "traffic": None,
+                "avg_launch_ms": kern[dom]["avg_ms"], "launches": kern[dom]["launches"],
+                "kernel_time_share": kern[dom]["ms_total"] / (dt * 1e3), "all_kernels": kern}
+        out = {"metric": "training rays/sec (256^2 det, 192 samples/ray)", "value": args.rays * world * args.steps / dt, "unit": "rays/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.prec, "data": "synthetic",
+               "config": {"workload": f"run_composite XCAT {args.views}-view x 10 phases, {args.det}^2 detector x {args.samples} samples/ray, "
+                                      f"{args.rays} rays/step/GPU (one full detector), F=128 x 4 hidden layers x 2 nets, L=12, fwd+losses+bwd+Adam",
+                          "rays_per_step_per_gpu": args.rays, "samples_per_ray": args.samples, "parallelism": f"ray-sharded dp{world}"},
+               "roofline": roof, "final_loss": float(loss)}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, data, None)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

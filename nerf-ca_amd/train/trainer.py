@@ -1,0 +1,168 @@
+"""The composite training step of run_composite.py:227-312 around the fused ray path, with ray-sharded
+data parallelism: one process per GPU, every rank draws the SAME global batch (same seed) and
+renders its contiguous slice; one all-reduce(SUM) of the flat gradient per step, then the identical
+Adam update everywhere.
+
+Loss normalisation under sharding: terms that are means over rays use local sums
+divided by the GLOBAL ray count; ``static_l1``/``static_l2`` are sums over the batch and stay sums.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .. import losses as LS
+from ..schedules import linear_param_decay
+from . import model_helpers as MH
+
+
+@dataclass
+class TrainConfig:
+    """The hot-path keys of train/composite.txt (defaults = that file)."""
+    depth_samples_per_ray_coarse: int = 500
+    img_sample_size: int = 1024
+    batch_size: int = 32768
+    lr: float = 1e-3
+    lr_end_factor: float = 0.01
+    lr_decay_steps: int = 150000
+    var_sample_perc: float = 50
+    var_sample_thre: float = 3
+    entro_mask_thre: float = 1e-4
+    entro_use_weighting: bool = True
+    entro_weighted_thresh: float = 0.03
+    favor_s_weight_start: float = 1e-12
+    favor_s_weight_end: float = 1e-10
+    favor_s_weight_delay_steps: int = 40000
+    dynamic_entro_weight_start: float = 1e-10
+    dynamic_entro_weight_end: float = 1e-8
+    occl_weight_start: float = 1e-8
+    occl_weight_end: float = 1e-4
+    l1_weight_start: float = 1e-8
+    l1_weight_end: float = 1e-15
+    hyperparam_decay_steps: int = 100000
+    weighted_loss_max: float = 1
+    occl_reg_perc: float = 0.2
+    skewness_val: float = 1.0
+    favor_s_opt: Optional[str] = None
+    output_activation: str = "softplus"
+    static_pos_enc: str = "free_windowed"
+    temp_pos_enc: str = "free_windowed"
+    static_pos_enc_window_decay_steps: int = 150000
+    temp_pos_enc_window_decay_steps: int = 150000
+
+
+class CompositeTrainer:
+    def __init__(self, cfg: TrainConfig, static_model, temp_model, data, device, rank: int = 0, world: int = 1,
+                 seed: int = 0, render: Optional[Callable] = None, fused_adam: Optional[bool] = None):
+        self.cfg, self.s, self.t, self.data, self.device = cfg, static_model, temp_model, data, device
+        self.rank, self.world, self.seed = rank, world, seed
+        self.render = render or MH._fused.render_rays
+        self.params = list(temp_model.parameters()) + list(static_model.parameters())   # run_composite.py:192
+        kw = {}
+        if fused_adam is None:
+            fused_adam = device.type == "cuda" if isinstance(device, torch.device) else str(device).startswith("cuda")
+        if fused_adam:
+            kw["fused"] = True
+        self.opt = torch.optim.Adam([{"params": self.params, "lr": cfg.lr}], lr=cfg.lr, **kw)
+        self.sched = torch.optim.lr_scheduler.LinearLR(self.opt, start_factor=1, end_factor=cfg.lr_end_factor, total_iters=cfg.lr_decay_steps)
+        self.depth = MH_depth(data.geo, cfg.depth_samples_per_ray_coarse, device)
+        self.I0 = torch.full((cfg.img_sample_size,), data.geo["max_pixel_value"], dtype=torch.float32, device=device)
+        self.n_var = int((cfg.var_sample_perc / 100.0) * cfg.img_sample_size) if cfg.var_sample_perc > 0 else 0
+
+    # -- per-step host work (identical on every rank) ------------------------------------------
+    def update_windows(self, n_iter: int) -> None:
+        c = self.cfg
+        for m, enc, steps in ((self.s, c.static_pos_enc, c.static_pos_enc_window_decay_steps),
+                              (self.t, c.temp_pos_enc, c.temp_pos_enc_window_decay_steps)):
+            if enc == "nerfies_windowed":
+                m.update_windowed_alpha(n_iter, steps)
+            elif enc == "free_windowed":
+                m.update_freq_mask_alpha(n_iter, steps)
+
+    def draw_ray_ids(self, n_iter: int) -> np.ndarray:
+        """Importance sampling of run_composite.py:250-260 with a per-step seeded generator."""
+        rng = np.random.default_rng([self.seed, n_iter])
+        c, d = self.cfg, self.data
+        if c.var_sample_perc > 0 and len(d.var_ray_ids) > 0:
+            ids = np.concatenate((rng.choice(d.non_var_ray_ids, size=c.img_sample_size - self.n_var),
+                                  rng.choice(d.var_ray_ids, size=self.n_var)))
+            rng.shuffle(ids)
+            return ids
+        return rng.integers(low=0, high=d.rays_train.shape[0], size=c.img_sample_size)
+
+    def draw_jitter(self, n_iter: int) -> torch.Tensor:
+        g = torch.Generator().manual_seed(self.seed * 1000003 + n_iter)
+        return torch.rand(self.depth.shape, generator=g)
+
+    def loss_weights(self, n_iter: int):
+        c = self.cfg
+        return (linear_param_decay(n_iter, c.favor_s_weight_start, c.favor_s_weight_end, c.hyperparam_decay_steps, c.favor_s_weight_delay_steps),
+                linear_param_decay(n_iter, c.dynamic_entro_weight_start, c.dynamic_entro_weight_end, c.hyperparam_decay_steps),
+                linear_param_decay(n_iter, c.occl_weight_start, c.occl_weight_end, c.hyperparam_decay_steps, c.favor_s_weight_delay_steps),
+                linear_param_decay(n_iter, c.l1_weight_start, c.l1_weight_end, c.hyperparam_decay_steps))
+
+    # -- one optimisation step -----------------------------------------------------------------
+    def local_loss(self, n_iter: int, ids: np.ndarray, t_rand: torch.Tensor):
+        """Loss contribution of this rank's slice of the global batch (sums to the global loss)."""
+        c = self.cfg
+        R = len(ids)
+        lo, hi = (R * self.rank) // self.world, (R * (self.rank + 1)) // self.world
+        my = torch.as_tensor(ids[lo:hi], device=self.device)
+        rays = self.data.rays_train.index_select(0, my)                  # f64 [r,4,3]  (run_composite.py:262)
+        phases = self.data.phases_train.index_select(0, my)
+        o, d, gt, w = rays[:, 0, :], rays[:, 1, :], rays[:, 2, 0], rays[:, 3, 0]
+        z = MH.randomize_depth(self.depth, self.device, t_rand)
+        dists = MH._interval_lengths(z, d)
+        pix, sig_s, sig_d = self.render(self.s, self.t, o, d, phases, self.I0[: hi - lo], z, dists, act=c.output_activation)
+        share = (hi - lo) / R                                            # local mean -> share of the global mean
+        pixel = MH.weighted_MSELoss()(pix, gt, w).mean() * share
+        terms = LS.all_terms(sig_s, sig_d, dists, w, c)
+        fav_w, ent_w, occ_w, l1_w = self.loss_weights(n_iter)
+        favor, d_ent, occl, l1, l2 = terms[3], terms[6], terms[8], terms[9], terms[10]
+        loss = pixel + fav_w * favor * share + ent_w * d_ent * share + occ_w * occl * share + l1_w * l2 + l1_w * l1
+        return loss, pixel, terms
+
+    def step(self, n_iter: int):
+        self.update_windows(n_iter)
+        ids = self.draw_ray_ids(n_iter)
+        loss, pixel, terms = self.local_loss(n_iter, ids, self.draw_jitter(n_iter))
+        self.opt.zero_grad(set_to_none=True)
+        loss.backward()
+        if self.world > 1:
+            self.allreduce_grads()
+        self.opt.step()
+        self.sched.step()
+        return loss.detach(), pixel.detach(), terms
+
+    def allreduce_grads(self) -> None:
+        """ONE all-reduce(SUM) over a flat f32 buffer of every gradient (152 914 floats by default)."""
+        grads = [p.grad for p in self.params]
+        flat = torch._utils._flatten_dense_tensors(grads)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        for g, r in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
+            g.copy_(r)
+
+    # -- held-out view (run_composite.py:346-403) ------------------------------------------------
+    @torch.no_grad()
+    def evaluate(self, n_iter: int, chunk_rays: int = 65536):
+        c, d = self.cfg, self.data
+        z = MH.randomize_depth(self.depth, self.device, torch.full(self.depth.shape, 0.5))
+        dists = MH._interval_lengths(z, d.test_directions)
+        out = []
+        for i in range(0, d.test_origins.shape[0], chunk_rays):
+            o, dd = d.test_origins[i:i + chunk_rays], d.test_directions[i:i + chunk_rays]
+            ph = torch.full((o.shape[0],), d.test_phase, dtype=torch.int32, device=self.device)
+            I0 = torch.full((o.shape[0],), d.geo["max_pixel_value"], dtype=torch.float32, device=self.device)
+            out.append(self.render(self.s, self.t, o, dd, ph, I0, z, dists, act=c.output_activation)[0].float())
+        pred = torch.cat(out)
+        mse = ((pred - d.test_image) ** 2).mean()
+        return {"test_mse": mse, "test_psnr_mse": -10.0 * torch.log10(mse), "pred": pred}
+
+
+def MH_depth(geo, n, device):
+    from .data_helpers import create_depth_values
+    return create_depth_values(geo["near_thresh"], geo["far_thresh"], n, device)
