@@ -46,10 +46,23 @@ def parse():
     return ap.parse_args()
 
 
+def host_cores() -> int:
+    """CPUs this process may really use: affinity mask capped by the cgroup quota (the GPU box shows
+    256 logical CPUs but grants 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(args, data, cfg_kwargs):
     """Reference-equivalent CPU path (oracle) on a bounded sample of the same workload."""
     from oracle import nerfca_oracle as O
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     R, S = args.cpu_rays, args.samples
     gen = torch.Generator().manual_seed(0)

@@ -164,7 +164,7 @@ static int fill_net(const NetBind& b, NcaNetArgs* na) {
 static int add_stage(NcaFusedArgs* a, const void* base, uint32_t off, uint32_t bytes) {
     if (a->nstages >= NCA_MAX_STAGES) return fail(NCA_E_UNSUPPORTED, "too many weight stages");
     a->stage[a->nstages].ptr = static_cast<const char*>(base) + off;
-    a->stage[a->nstages].bytes = (bytes + 15u) & ~15u;
+    a->stage[a->nstages].bytes = (bytes + 1023u) & ~1023u;   // whole 1 KiB DMA pieces (the pack kernel zero-fills the padding)
     a->stage[a->nstages].pad = 0;
     a->nstages++;
     return NCA_OK;
@@ -394,14 +394,15 @@ static int run_bwd(NcaFusedArgs& a, const NetBind* binds, int64_t units, int64_t
     for (int64_t u0 = 0; u0 < units; u0 += p.units_per_chunk, ++chunk) {
         const int64_t nu = (u0 + p.units_per_chunk <= units) ? p.units_per_chunk : units - u0;
         a.ntiles = nu * tiles_per_unit;
-        a.Nc = a.ntiles * 32;
+        a.rows_total = p.rows;
         a.accumulate = chunk > 0;
         if (a.mode == NCA_MODE_RAYS) a.ray0 = u0; else a.n0 = u0 * 32;
         {
             Span sp(NCA_K_BWD_DGRAD, st);
             HIPCHK(nca_launch_fused_f32(F, a, true, p.grid, st));
         }
-        w.Nc = a.Nc;
+        w.rows_total = p.rows;
+        w.ntiles = a.ntiles;
         w.accumulate = chunk > 0;
         {
             Span sp(NCA_K_BWD_WGRAD, st);

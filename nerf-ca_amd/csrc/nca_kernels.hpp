@@ -50,8 +50,8 @@ struct NcaFusedArgs {
     const float* g_sig_s;
     const float* g_sig_d;
     const float* g_raw;
-    float* scratch;      // [rows][Nc] feature-major layer inputs H and output gradients D
-    int64_t Nc;          // scratch columns (= ntiles * 32)
+    float* scratch;      // [tile][rows_total][32]: layer inputs H and output gradients D of each 32-sample tile
+    int64_t rows_total;  // scratch rows per tile over all nets
     float* oslab;        // [grid][2][F+1] output-layer gradient partials
     int32_t accumulate;  // add to oslab instead of overwriting (ray chunks after the first)
     int32_t nstages;
@@ -72,8 +72,8 @@ struct NcaWgradJob {
 };
 
 struct NcaWgradArgs {
-    const float* scratch;
-    int64_t Nc;
+    const float* scratch;   // [tile][rows_total][32]
+    int64_t rows_total, ntiles;
     float* slab;
     int64_t slab_stride;
     int32_t accumulate, njobs;

@@ -119,6 +119,25 @@ __device__ __forceinline__ double half_sum(double v) {
     return v;
 }
 
+// One hidden-width contraction acc[m] += W[m-tile][k] * B[k] over the F/2 k-steps of an image whose B
+// operands are the previous layer's accumulator registers.  The A fragment of step s+1 is read
+// while step s's MFMAs issue; the scheduling barrier keeps the compiler from hoisting dozens of LDS
+// reads (and their registers) to the top of the unrolled loop.
+template <int MT>
+__device__ __forceinline__ void hidden_steps(const float* __restrict__ ih, const f32x16 (&b)[MT], f32x16 (&acc)[MT]) {
+    constexpr int NS = 16 * MT;
+    float av[2][MT];
+    load_a<MT>(ih, av[0]);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (s + 1 < NS) load_a<MT>(ih + (s + 1) * 64 * MT, av[(s + 1) & 1]);
+        const float bop = b[s >> 4][s & 15];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][m], bop, acc[m], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // Encoded input generator: calls step(s, a, b) once per k-step with the two features of the pair
 // (a feeds lane-half 0, b lane-half 1), in the order fixed by nca_enc_pair.
 //   bands:   sin(2^k x) and sin(fl32(2^k x + fl32(pi/2)))  (model/CPPN.py:121-123), times window[k].
@@ -161,7 +180,8 @@ __device__ __forceinline__ void enc_steps(const NcaLayout& y, const float (&p)[3
         const int n = 3 * y.L;
         for (int i = 0; i < n; ++i) {
             const int c = i % 3;
-            const float v = __fmul_rn(__fmul_rn(NCA_TWO_PI_F, p[c]), four[i]);
+            const float pc = c == 0 ? p[0] : (c == 1 ? p[1] : p[2]);
+            const float v = __fmul_rn(__fmul_rn(NCA_TWO_PI_F, pc), four[i]);
             double sv, cv;
             sincos((double)v, &sv, &cv);
             step(s++, (float)sv, (float)cv);
@@ -181,32 +201,57 @@ template <int F>
 struct FusedCfg {
     static constexpr int MT = F / 32;
     static constexpr int IMG_MAX = NCA_MAX_KSTEPS * 64 * MT * 4 + 2 * (2 * MT * 16 * 4) + 16;   // largest image: k-steps + bias + Wo/bo tails
-    static constexpr int BUF_BYTES = (IMG_MAX + 255) & ~255;
-    static constexpr int PF = (BUF_BYTES + NCA_NT * 16 - 1) / (NCA_NT * 16);       // 16-byte prefetch registers per thread
+    static constexpr int BUF_BYTES = (IMG_MAX + 1023) & ~1023;
 };
+
+// small per-net constants staged once per workgroup into LDS (so that no ordinary global load sits
+// between a weight DMA and its consumer): band window, fourier coefficients, time latents
+#define NCA_CONST_WIN 16
+#define NCA_CONST_FOUR 48
+#define NCA_CONST_LAT 2048
+#define NCA_CONST_NET_FLOATS (NCA_CONST_WIN + NCA_CONST_FOUR + NCA_CONST_LAT)
+#define NCA_CONST_BYTES (2 * NCA_CONST_NET_FLOATS * 4)
+
+// LDS-DMA one weight image (whole 1 KiB pieces, round-robin over the waves) into `dst`
+__device__ __forceinline__ void stage_issue(const NcaStage& st, char* dst, int wave, int lane) {
+    const int npiece = (int)(st.bytes >> 10);
+    const char* src = reinterpret_cast<const char*>(st.ptr) + lane * 16;
+    for (int c = wave; c < npiece; c += NCA_WAVES) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)c * 1024),
+                                         (__attribute__((address_space(3))) void*)(dst + c * 1024), 16, 0, 0);
+    }
+}
+__device__ __forceinline__ void stage_publish() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
 
 template <int F, bool BWD>
 __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a) {
     constexpr int MT = FusedCfg<F>::MT;
     constexpr int BUF = FusedCfg<F>::BUF_BYTES;
-    constexpr int PF = FusedCfg<F>::PF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // [buf0][buf1][per-wave output-layer gradient sums: WAVES x 2 nets x (F+1)]
-    float* osum = reinterpret_cast<float*>(smem + 2 * BUF);
+    // [buf0][buf1][constants of both nets][per-wave output-layer gradient sums: WAVES x 2 nets x (F+1)]
+    float* cst = reinterpret_cast<float*>(smem + 2 * BUF);
+    float* osum = reinterpret_cast<float*>(smem + 2 * BUF + NCA_CONST_BYTES);
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lj = lane & 31, lh = lane >> 5;
 
+    for (int net = 0; net < a.nnets; ++net) {
+        const NcaNetArgs& na = a.net[net];
+        float* c = cst + net * NCA_CONST_NET_FLOATS;
+        if (na.win) for (int i = tid; i < na.lay.L; i += NCA_NT) c[i] = na.win[i];
+        if (na.four) for (int i = tid; i < 3 * na.lay.L; i += NCA_NT) c[NCA_CONST_WIN + i] = na.four[i];
+        if (na.lat) for (int i = tid; i < na.lay.P * na.lay.T; i += NCA_NT) c[NCA_CONST_WIN + NCA_CONST_FOUR + i] = na.lat[i];
+    }
     if (BWD) {
         for (int i = tid; i < NCA_WAVES * 2 * (F + 1); i += NCA_NT) osum[i] = 0.f;
     }
+    __syncthreads();
 
     // stage 0 -> buffer 0
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(a.stage[0].ptr);
-        const int n16 = (int)(a.stage[0].bytes >> 4);
-        for (int i = tid; i < n16; i += NCA_NT) reinterpret_cast<uint4*>(smem)[i] = src[i];
-    }
-    __syncthreads();
+    stage_issue(a.stage[0], smem, wave, lane);
+    stage_publish();
     int cur = 0, si = 0;
 
     const int64_t ngroups = (a.ntiles + NCA_WAVES - 1) / NCA_WAVES;
@@ -250,7 +295,11 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
         if (a.phase) {
             ph = a.mode == NCA_MODE_RAYS ? a.phase[ray * a.ps_r + (int64_t)smp * a.ps_s] : a.phase[n];
         }
-        const int64_t col = tl * 32 + lj;   // column in the backward scratch
+        // backward scratch is tile-major: scratch[tile][row][32 columns].  A wave owns one tile, so every
+        // row it touches sits at a compile-time offset (row * 128 B) from one per-lane base; lane-half h
+        // owns rows rho(i)+4h and carries those 4 rows in its base.
+        float* const tbase = BWD ? a.scratch + (tl * a.rows_total + 4 * lh) * 32 + lj : nullptr;
+        float* const tcol = BWD ? a.scratch + tl * a.rows_total * 32 + lj : nullptr;
 
         float raw[2] = {0.f, 0.f};
 
@@ -260,8 +309,12 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
             const NcaNetArgs& na = a.net[net];
             const NcaLayout& y = na.lay;
             int phc = ph < 0 ? 0 : (ph >= y.P ? y.P - 1 : ph);
-            const float* lat = y.T > 0 ? na.lat + phc * y.T : nullptr;
-            float* const hs = BWD ? a.scratch + na.row0 * a.Nc : nullptr;   // this net's scratch rows
+            const float* cnet = cst + net * NCA_CONST_NET_FLOATS;
+            const float* cwin = cnet;
+            const float* cfour = cnet + NCA_CONST_WIN;
+            const float* lat = y.T > 0 ? cnet + NCA_CONST_WIN + NCA_CONST_FOUR + phc * y.T : nullptr;
+            float* const hs = BWD ? tbase + na.row0 * 32 : nullptr;          // this net's rows, this lane's column (+4h rows)
+            float* const hc = BWD ? tcol + na.row0 * 32 : nullptr;           // same without the lane-half row offset
 
             f32x16 hprev[MT];
 #pragma unroll
@@ -270,18 +323,9 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
             // ================= forward (recompute) ==========================================
             for (int jj = 0; jj < y.NL; ++jj) {
                 const NcaLayerL& l = y.layer[jj];
-                // prefetch the next image into registers
+                // DMA the next image into the other buffer while this layer computes
                 const int nsi = (si + 1 == a.nstages) ? 0 : si + 1;
-                uint4 pf[PF];
-                {
-                    const uint4* src = reinterpret_cast<const uint4*>(a.stage[nsi].ptr);
-                    const int n16 = (int)(a.stage[nsi].bytes >> 4);
-#pragma unroll
-                    for (int i = 0; i < PF; ++i) {
-                        const int idx = tid + i * NCA_NT;
-                        pf[i] = idx < n16 ? src[idx] : make_uint4(0, 0, 0, 0);
-                    }
-                }
+                stage_issue(a.stage[nsi], smem + (cur ^ 1) * BUF, wave, lane);
                 const float* img = reinterpret_cast<const float*>(smem + cur * BUF);
                 const float* imgl = img + lane * MT;
                 const float* tail = img + l.ksteps * 64 * MT;
@@ -293,8 +337,8 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
                     for (int i = 0; i < 16; ++i) acc[m][i] = tail[(lh * MT + m) * 16 + i];
 
                 if (l.kind != NCA_IN_HID) {
-                    float* const henc = hs;   // rows [0, K0rows_pad)
-                    enc_steps(y, p, na.win, na.four, lat, [&](int s, float fa, float fb) {
+                    float* const henc = hc;   // rows [0, K0rows_pad)
+                    enc_steps(y, p, cwin, cfour, lat, [&](int s, float fa, float fb) {
                         const float bop = lh ? fb : fa;
                         float av[MT];
                         load_a<MT>(imgl + s * 64 * MT, av);
@@ -304,26 +348,16 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
                             int ia, ib;
                             nca_enc_pair(y, s, &ia, &ib);
                             const int row = lh ? ib : ia;
-                            if (row >= 0) henc[(int64_t)row * a.Nc + col] = bop;
+                            if (row >= 0) henc[row * 32] = bop;
                         }
                     });
                     if (BWD && jj == 0 && y.P > 0 && tvalid) {
                         // one-hot phase rows: their "weight gradient" is sum_n [phase_n = p] D0[:, n]
-                        for (int pp = lh; pp < y.P; pp += 2) henc[(int64_t)(y.K0 + pp) * a.Nc + col] = (pp == phc) ? 1.f : 0.f;
+                        for (int pp = lh; pp < y.P; pp += 2) henc[(y.K0 + pp) * 32] = (pp == phc) ? 1.f : 0.f;
                     }
                 }
                 if (l.kind != NCA_IN_ENC) {
-                    const float* ih = imgl + l.ksteps_enc * 64 * MT;
-#pragma unroll
-                    for (int t = 0; t < MT; ++t)
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) {
-                            float av[MT];
-                            load_a<MT>(ih + (16 * t + i) * 64 * MT, av);
-                            const float bop = hprev[t][i];
-#pragma unroll
-                            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bop, acc[m], 0, 0, 0);
-                        }
+                    hidden_steps<MT>(imgl + l.ksteps_enc * 64 * MT, hprev, acc);
                 }
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
@@ -332,11 +366,14 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
 
                 if (BWD && jj + 1 < y.NL && tvalid) {
                     // input of layer jj+1, feature-major (waves past the last tile write nothing)
-                    float* hh = hs + (int64_t)(y.K0rows_pad + jj * F) * a.Nc + col;
+                    float* hh = hs + (y.K0rows_pad + jj * F) * 32;
 #pragma unroll
-                    for (int m = 0; m < MT; ++m)
+                    for (int m = 0; m < MT; ++m) {
+                        float* q = hh + m * 1024;            // 32 rows x 32 columns
+                        asm volatile("" : "+v"(q));          // opaque base: rows become small immediate offsets
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) hh[(int64_t)(32 * m + nca_rho(i) + 4 * lh) * a.Nc] = hprev[m][i];
+                        for (int i = 0; i < 16; ++i) q[nca_rho(i) * 32] = hprev[m][i];
+                    }
                 }
 
                 if (jj == y.NL - 1) {
@@ -363,78 +400,66 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
                             g = a.g_raw[n];
                         }
                         if (!valid) g = 0.f;
-                        // dWo[f] = sum_n g H[f][n] : reduce-scatter over the 32 lanes of each half
-                        float v[MT * 16];
-#pragma unroll
-                        for (int m = 0; m < MT; ++m)
-#pragma unroll
-                            for (int i = 0; i < 16; ++i) v[m * 16 + i] = g * hprev[m][i];
+                        // dWo[f] = sum_n g H[f][n]: reduce-scatter over the 32 lanes of each wave half, at most 32
+                        // values at a time (two row tiles), so that lane lj ends up owning flat index lj*per+e
                         {
-                            constexpr int NV = MT * 16;
-                            int cnt = NV;
-#pragma unroll
-                            for (int d = 16; d >= 1; d >>= 1) {
-                                if (cnt >= 2) {
-                                    const int hn = cnt / 2;
-                                    const bool up = (lj & d) != 0;
-#pragma unroll
-                                    for (int i = 0; i < NV / 2; ++i) {
-                                        if (i < hn) {
-                                            const float keep = up ? v[i + hn] : v[i];
-                                            const float send = up ? v[i] : v[i + hn];
-                                            v[i] = keep + __shfl_xor(send, d);
-                                        }
-                                    }
-                                    cnt = hn;
-                                } else {
-                                    v[0] += __shfl_xor(v[0], d);
-                                }
-                            }
-                            // lane now owns `per` consecutive flat indices starting at lane-dependent base
-                            constexpr int per = NV >= 32 ? NV / 32 : 1;
                             float* orow = osum + (wave * 2 + net) * (F + 1);
-                            if (NV >= 32) {
+                            constexpr int GM = MT >= 2 ? 2 : 1;          // row tiles per pass
+                            constexpr int NV = GM * 16;
 #pragma unroll
-                                for (int e = 0; e < per; ++e) {
-                                    const int idx = lj * per + e;
-                                    const int f = 32 * (idx >> 4) + nca_rho(idx & 15) + 4 * lh;
-                                    orow[f] += v[e];
+                            for (int m0 = 0; m0 < MT; m0 += GM) {
+                                float v[NV];
+#pragma unroll
+                                for (int q = 0; q < NV; ++q) v[q] = g * hprev[m0 + (q >> 4)][q & 15];
+                                int cnt = NV;
+#pragma unroll
+                                for (int d = 16; d >= 1; d >>= 1) {
+                                    if (cnt >= 2) {
+                                        const int hn = cnt / 2;
+                                        const bool up = (lj & d) != 0;
+#pragma unroll
+                                        for (int i = 0; i < NV / 2; ++i) {
+                                            if (i < hn) {
+                                                // both halves in named registers first: otherwise the select is folded
+                                                // into a lane-varying index into v[] (a 32-way compare/select chain)
+                                                float lo = v[i], hi = v[i + hn];
+                                                asm volatile("" : "+v"(lo), "+v"(hi));
+                                                const float keep = up ? hi : lo;
+                                                const float send = up ? lo : hi;
+                                                v[i] = keep + __shfl_xor(send, d);
+                                            }
+                                        }
+                                        cnt = hn;
+                                    } else {
+                                        v[0] += __shfl_xor(v[0], d);
+                                    }
                                 }
-                            } else {
-                                // NV == 16 (F = 32): after 4 halvings lanes (lj>>1) own index lj>>1, fully summed after d=1
-                                if ((lj & 1) == 0) {
-                                    const int idx = lj >> 1;
-                                    const int f = nca_rho(idx & 15) + 4 * lh;
-                                    orow[f] += v[0];
+                                if (NV == 32) {
+                                    orow[32 * (m0 + (lj >> 4)) + nca_rho(lj & 15) + 4 * lh] += v[0];
+                                } else if ((lj & 1) == 0) {          // NV == 16: index lj>>1, complete in both lanes of a pair
+                                    orow[32 * m0 + nca_rho((lj >> 1) & 15) + 4 * lh] += v[0];
                                 }
                             }
                             const float gsum = half_sum(lh == 0 ? g : 0.f);
                             if (lane == 0) orow[F] += gsum;
                         }
                         // D_{NL-1} = Wo * g masked by ReLU
-                        float* dd = hs + (int64_t)(y.K0rows_pad + (y.NL - 1) * F + (y.NL - 1) * F) * a.Nc + col;
+                        float* dd = hs + (y.K0rows_pad + (y.NL - 1) * F + (y.NL - 1) * F) * 32;
 #pragma unroll
-                        for (int m = 0; m < MT; ++m)
+                        for (int m = 0; m < MT; ++m) {
+                            float* q = dd + m * 1024;
+                            asm volatile("" : "+v"(q));
 #pragma unroll
                             for (int i = 0; i < 16; ++i) {
                                 const float dv = hprev[m][i] > 0.f ? wo[(lh * MT + m) * 16 + i] * g : 0.f;
                                 hprev[m][i] = dv;
-                                if (tvalid) dd[(int64_t)(32 * m + nca_rho(i) + 4 * lh) * a.Nc] = dv;
+                                if (tvalid) q[nca_rho(i) * 32] = dv;
                             }
+                        }
                     }
                 }
 
-                // publish the prefetched image into the other buffer
-                {
-                    uint4* dst = reinterpret_cast<uint4*>(smem + (cur ^ 1) * BUF);
-                    const int n16 = (int)(a.stage[nsi].bytes >> 4);
-#pragma unroll
-                    for (int i = 0; i < PF; ++i) {
-                        const int idx = tid + i * NCA_NT;
-                        if (idx < n16) dst[idx] = pf[i];
-                    }
-                }
-                __syncthreads();
+                stage_publish();
                 cur ^= 1;
                 si = nsi;
             }
@@ -444,52 +469,28 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
                 // hprev holds D_{NL-1}.  For jj = NL-1 .. 1:  D_{jj-1} = relu'(H_jj) .* (W_jj^T D_jj)
                 for (int jj = y.NL - 1; jj >= 1; --jj) {
                     const int nsi = (si + 1 == a.nstages) ? 0 : si + 1;
-                    uint4 pf[PF];
-                    {
-                        const uint4* src = reinterpret_cast<const uint4*>(a.stage[nsi].ptr);
-                        const int n16 = (int)(a.stage[nsi].bytes >> 4);
-#pragma unroll
-                        for (int i = 0; i < PF; ++i) {
-                            const int idx = tid + i * NCA_NT;
-                            pf[i] = idx < n16 ? src[idx] : make_uint4(0, 0, 0, 0);
-                        }
-                    }
+                    stage_issue(a.stage[nsi], smem + (cur ^ 1) * BUF, wave, lane);
                     const float* imgl = reinterpret_cast<const float*>(smem + cur * BUF) + lane * MT;
                     f32x16 acc[MT];
 #pragma unroll
                     for (int m = 0; m < MT; ++m) acc[m] = (f32x16)(0.f);
-#pragma unroll
-                    for (int t = 0; t < MT; ++t)
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) {
-                            float av[MT];
-                            load_a<MT>(imgl + (16 * t + i) * 64 * MT, av);
-                            const float bop = hprev[t][i];
-#pragma unroll
-                            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bop, acc[m], 0, 0, 0);
-                        }
+                    hidden_steps<MT>(imgl, hprev, acc);
                     // mask with the stored input of layer jj (= output of layer jj-1), store D_{jj-1}
-                    const float* hh = hs + (int64_t)(y.K0rows_pad + (jj - 1) * F) * a.Nc + col;
-                    float* dd = hs + (int64_t)(y.K0rows_pad + (y.NL - 1) * F + (jj - 1) * F) * a.Nc + col;
+                    const float* hh = hs + (y.K0rows_pad + (jj - 1) * F) * 32;
+                    float* dd = hs + (y.K0rows_pad + (y.NL - 1) * F + (jj - 1) * F) * 32;
 #pragma unroll
-                    for (int m = 0; m < MT; ++m)
+                    for (int m = 0; m < MT; ++m) {
+                        const float* qh = hh + m * 1024;
+                        float* qd = dd + m * 1024;
+                        asm volatile("" : "+v"(qh), "+v"(qd));
 #pragma unroll
                         for (int i = 0; i < 16; ++i) {
-                            const int64_t ro = (int64_t)(32 * m + nca_rho(i) + 4 * lh) * a.Nc;
-                            const float dv = hh[ro] > 0.f ? acc[m][i] : 0.f;
+                            const float dv = qh[nca_rho(i) * 32] > 0.f ? acc[m][i] : 0.f;
                             hprev[m][i] = dv;
-                            if (tvalid) dd[ro] = dv;
-                        }
-                    {
-                        uint4* dst = reinterpret_cast<uint4*>(smem + (cur ^ 1) * BUF);
-                        const int n16 = (int)(a.stage[nsi].bytes >> 4);
-#pragma unroll
-                        for (int i = 0; i < PF; ++i) {
-                            const int idx = tid + i * NCA_NT;
-                            if (idx < n16) dst[idx] = pf[i];
+                            if (tvalid) qd[nca_rho(i) * 32] = dv;
                         }
                     }
-                    __syncthreads();
+                    stage_publish();
                     cur ^= 1;
                     si = nsi;
                 }
@@ -546,10 +547,11 @@ __global__ __launch_bounds__(256) void nca_wgrad_f32(const NcaWgradArgs a) {
     const int F = job.F, MT = F / 32;
     const int brows = job.b_rows_pad;                            // multiple of 32, <= 128
     const int CT = brows / 32;
-    const float* __restrict__ Ag = a.scratch + (int64_t)job.d_row0 * a.Nc;
-    const float* __restrict__ Bg = a.scratch + (int64_t)job.b_row0 * a.Nc;
+    const float* __restrict__ Ag = a.scratch + job.d_row0 * 32;      // + tile * rows_total * 32
+    const float* __restrict__ Bg = a.scratch + job.b_row0 * 32;
+    const int64_t tstride = a.rows_total * 32;
 
-    const int64_t ntile = a.Nc / 32;
+    const int64_t ntile = a.ntiles;
     const int64_t per = (ntile + gridDim.x - 1) / gridDim.x;
     const int64_t t0 = (int64_t)q * per, t1 = (t0 + per < ntile) ? t0 + per : ntile;
 
@@ -561,12 +563,14 @@ __global__ __launch_bounds__(256) void nca_wgrad_f32(const NcaWgradArgs a) {
     const int lrow = tid >> 3, lc4 = tid & 7;                    // loader: rows lrow + 32 i, float4 chunk lc4
     float4 pa[4], pb[4];
     auto issue = [&](int64_t t) {
-        const int64_t c0 = t * 32 + lc4 * 4;
+        // an operand tile is ONE contiguous block of rows x 128 B
+        const float* at = Ag + t * tstride + lrow * 32 + lc4 * 4;
+        const float* bt = Bg + t * tstride + lrow * 32 + lc4 * 4;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = lrow + 32 * i;
-            pa[i] = r < F ? *reinterpret_cast<const float4*>(Ag + (int64_t)r * a.Nc + c0) : make_float4(0, 0, 0, 0);
-            pb[i] = r < brows ? *reinterpret_cast<const float4*>(Bg + (int64_t)r * a.Nc + c0) : make_float4(0, 0, 0, 0);
+            pa[i] = r < F ? *reinterpret_cast<const float4*>(at + i * 1024) : make_float4(0, 0, 0, 0);
+            pb[i] = r < brows ? *reinterpret_cast<const float4*>(bt + i * 1024) : make_float4(0, 0, 0, 0);
         }
     };
     auto commit = [&](int buf) {
@@ -684,7 +688,7 @@ __global__ void nca_pix_f32(int64_t R, int nchunk, const float* __restrict__ I0,
 // ------------------------------------------------------------------------------------------
 template <int F>
 static hipError_t launch_fused_t(const NcaFusedArgs& a, bool bwd, int grid, hipStream_t st) {
-    const size_t lds = 2 * FusedCfg<F>::BUF_BYTES + (bwd ? NCA_WAVES * 2 * (F + 1) * sizeof(float) : 0);
+    const size_t lds = 2 * FusedCfg<F>::BUF_BYTES + NCA_CONST_BYTES + (bwd ? NCA_WAVES * 2 * (F + 1) * sizeof(float) : 0);
     if (bwd) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_fused_f32<F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((nca_fused_f32<F, true>), dim3(grid), dim3(NCA_NT), lds, st, a);

@@ -117,7 +117,7 @@ inline int nca_build_layout(const NcaNet& n, NcaLayout* out, const char** why) {
         l.b_off = off; off += y.F;
         l.img_off = boff;
         l.img_bytes = nca_img_w_bytes(l.ksteps, y.MT) + nca_img_tail_bytes(y.MT) + (j == y.NL - 1 ? nca_img_tail_bytes(y.MT) + 16u : 0u);
-        boff += (l.img_bytes + 255u) & ~255u;
+        boff += (l.img_bytes + 1023u) & ~1023u;   // images are DMA'd to LDS in 1 KiB pieces
         if (l.img_bytes > maxb) maxb = l.img_bytes;
     }
     for (int j = 0; j < y.NL; ++j) {
@@ -125,7 +125,7 @@ inline int nca_build_layout(const NcaNet& n, NcaLayout* out, const char** why) {
         if (l.kind == NCA_IN_ENC) { l.imgT_off = 0; l.imgT_bytes = 0; continue; }
         l.imgT_off = boff;
         l.imgT_bytes = nca_img_w_bytes(y.F / 2, y.MT);
-        boff += (l.imgT_bytes + 255u) & ~255u;
+        boff += (l.imgT_bytes + 1023u) & ~1023u;
         if (l.imgT_bytes > maxb) maxb = l.imgT_bytes;
     }
     y.wo_off = off; off += y.F;

@@ -47,7 +47,6 @@ class FieldBinding:
         self.prec = prec
         self.flat: Optional[torch.Tensor] = None
         self.packed: Optional[torch.Tensor] = None
-        self._packed_key = None
         self._offsets: List[int] = []
         self.reflatten()
 
@@ -77,7 +76,6 @@ class FieldBinding:
                 off += n
         self.flat = flat
         self.packed = None
-        self._packed_key = None
 
     def _is_flat(self) -> bool:
         if self.flat is None:
@@ -89,21 +87,20 @@ class FieldBinding:
         return True
 
     def ensure_packed(self) -> torch.Tensor:
+        """Re-order the current parameters into the kernels' weight images.  Done on EVERY forward:
+        optimisers update parameters in place without a reliable change signal (fused Adam does not
+        bump tensor version counters), and the pack kernel costs ~10 us."""
         if not self._is_flat():
             self.reflatten()
         _require_cuda(self.flat, "network parameters")
-        key = (self.flat.data_ptr(), self.flat._version, tuple(p._version for p in self.params()))
-        if self.packed is None or key != self._packed_key:
-            lib = _capi.lib()
-            expect = lib.nca_param_count(C.byref(self.net))
-            check(expect)
+        lib = _capi.lib()
+        if self.packed is None or self.packed.device != self.flat.device:
+            expect = check(lib.nca_param_count(C.byref(self.net)))
             if expect != self.flat.numel():
                 raise _capi.NcaError(f"parameter count mismatch: module has {self.flat.numel()}, descriptor expects {expect}")
             nbytes = check(lib.nca_packed_bytes(C.byref(self.net), self.prec))
-            if self.packed is None or self.packed.numel() != nbytes or self.packed.device != self.flat.device:
-                self.packed = torch.empty(nbytes, dtype=torch.uint8, device=self.flat.device)
-            check(lib.nca_pack_weights(C.byref(self.net), ptr(self.flat), ptr(self.packed), self.prec, _stream()))
-            self._packed_key = key
+            self.packed = torch.empty(nbytes, dtype=torch.uint8, device=self.flat.device)
+        check(lib.nca_pack_weights(C.byref(self.net), ptr(self.flat), ptr(self.packed), self.prec, _stream()))
         return self.packed
 
     def split_grads(self, gflat: torch.Tensor) -> List[torch.Tensor]:
@@ -180,7 +177,6 @@ class _RenderFn(torch.autograd.Function):
                                  ptr(pix), ptr(sig_s), ptr(sig_d), ptr(work), wbytes, _stream()))
         ctx.batch, ctx.bs, ctx.bd = batch, bs, bd
         ctx.keep = (packed_s, packed_d, win_s, four_s, win_d, four_d)
-        ctx.flat_versions = (bs.flat._version, bd.flat._version if bd is not None else 0)
         if not batch.f64:
             pix = pix.to(torch.float32)
         if bd is None:
@@ -192,8 +188,6 @@ class _RenderFn(torch.autograd.Function):
         lib = _capi.lib()
         batch, bs, bd = ctx.batch, ctx.bs, ctx.bd
         packed_s, packed_d, win_s, four_s, win_d, four_d = ctx.keep
-        if (bs.flat._version, bd.flat._version if bd is not None else 0) != ctx.flat_versions:
-            raise _capi.NcaError("network parameters were modified between forward and backward")
         dev = batch.o.device
         gp = torch.zeros(batch.R, dtype=torch.float64, device=dev) if g_pix is None else g_pix.detach().to(torch.float64).contiguous()
         gs, gd = _f32c(g_sig_s), _f32c(g_sig_d)
@@ -245,7 +239,6 @@ class _PointsFn(torch.autograd.Function):
         check(lib.nca_mlp_fwd(C.byref(binding.net), binding.prec, ptr(packed), ptr(win), ptr(four), ptr(binding.flat), N,
                               ptr(pts), ptr(phase), ptr(raw), _stream()))
         ctx.binding, ctx.keep = binding, (packed, win, four, pts, phase)
-        ctx.flat_version = binding.flat._version
         return raw.view(N, 1)
 
     @staticmethod
@@ -253,8 +246,6 @@ class _PointsFn(torch.autograd.Function):
         lib = _capi.lib()
         binding = ctx.binding
         packed, win, four, pts, phase = ctx.keep
-        if binding.flat._version != ctx.flat_version:
-            raise _capi.NcaError("network parameters were modified between forward and backward")
         N = pts.shape[0]
         g = _f32c(g_raw).reshape(-1)
         grads = torch.empty(binding.flat.numel(), dtype=torch.float32, device=pts.device)
