@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--rays", type=int, default=65536, help="rays per step per GPU (one full 256^2 detector)")
     ap.add_argument("--det", type=int, default=256)
     ap.add_argument("--samples", type=int, default=192)
-    ap.add_argument("--prec", default="f32", choices=["f32"])
+    ap.add_argument("--prec", default="f32", choices=["f32", "bf16"])
     ap.add_argument("--cpu-rays", type=int, default=2048, help="rays per step of the CPU baseline sample")
     ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -105,6 +105,7 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
+    import nerfca_amd
     from nerfca_amd import _capi, synthetic
     from nerfca_amd.model.CPPN import CPPN
     from nerfca_amd.model.Temporal import Temporal
@@ -116,6 +117,7 @@ def main():
     torch.manual_seed(1)
     sdef, tdef = synthetic.net_definitions(dev)
     s, t = CPPN(sdef).to(dev), Temporal(tdef).to(dev)
+    nerfca_amd.set_precision(args.prec, s, t)
     cfg = TrainConfig(depth_samples_per_ray_coarse=args.samples, img_sample_size=args.rays * world)
     tr = CompositeTrainer(cfg, s, t, data, dev, rank=rank, world=world, seed=0)
 

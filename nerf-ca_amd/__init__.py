@@ -4,6 +4,6 @@ Import as ``nerfca_amd`` (see ``nerfca_amd.py`` at the repository root: the dire
 hyphen).  ``model/`` and ``train/`` mirror the reference's packages of the same names.
 """
 from . import _capi  # noqa: F401
-from .fused import render_rays, eval_points  # noqa: F401
+from .fused import render_rays, eval_points, set_precision  # noqa: F401
 
-__all__ = ["render_rays", "eval_points"]
+__all__ = ["render_rays", "eval_points", "set_precision"]

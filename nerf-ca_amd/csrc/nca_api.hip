@@ -107,10 +107,15 @@ extern "C" int nca_timing_read(int32_t kind, double* total_ms, int64_t* launches
 extern "C" int nca_abi_version(void) { return NCA_ABI_VERSION; }
 extern "C" const char* nca_last_error(void) { return g_err; }
 
-static int layout_of(const NcaNet* net, NcaLayout* y) {
+static int check_prec(int32_t prec) {
+    if (prec != NCA_PREC_F32 && prec != NCA_PREC_BF16) return fail(NCA_E_UNSUPPORTED, "unknown precision %d", prec);
+    return NCA_OK;
+}
+
+static int layout_of(const NcaNet* net, NcaLayout* y, int32_t prec = NCA_PREC_F32) {
     if (!net) return fail(NCA_E_INVALID, "net is NULL");
     const char* why = "";
-    int rc = nca_build_layout(*net, y, &why);
+    int rc = prec == NCA_PREC_BF16 ? nca_build_layout_bf16(*net, y, &why) : nca_build_layout(*net, y, &why);
     if (rc != NCA_OK) return fail(rc, "%s", why);
     return NCA_OK;
 }
@@ -123,20 +128,23 @@ extern "C" int64_t nca_param_count(const NcaNet* net) {
 
 extern "C" int64_t nca_packed_bytes(const NcaNet* net, int32_t prec) {
     NcaLayout y;
-    int rc = layout_of(net, &y);
+    int rc = check_prec(prec);
+    if (rc) return rc;
+    rc = layout_of(net, &y, prec);
     if (rc != NCA_OK) return rc;
-    if (prec != NCA_PREC_F32) return fail(NCA_E_UNSUPPORTED, "precision %d not built", prec);
     return y.packed_bytes;
 }
 
 extern "C" int nca_pack_weights(const NcaNet* net, const float* params, void* packed, int32_t prec, void* stream) {
     NcaLayout y;
-    int rc = layout_of(net, &y);
+    int rc = check_prec(prec);
+    if (rc) return rc;
+    rc = layout_of(net, &y, prec);
     if (rc != NCA_OK) return rc;
-    if (prec != NCA_PREC_F32) return fail(NCA_E_UNSUPPORTED, "precision %d not built", prec);
     if (!params || !packed) return fail(NCA_E_INVALID, "params/packed is NULL");
     Span sp(NCA_K_PACK, (hipStream_t)stream);
-    HIPCHK(nca_launch_pack_f32(y, params, packed, (hipStream_t)stream));
+    if (prec == NCA_PREC_BF16) HIPCHK(nca_launch_pack_bf16(y, params, packed, (hipStream_t)stream));
+    else HIPCHK(nca_launch_pack_f32(y, params, packed, (hipStream_t)stream));
     return NCA_OK;
 }
 
@@ -147,8 +155,8 @@ struct NetBind {
     const NcaNet* net; const void* packed; const float* win; const float* four; const float* params;
 };
 
-static int fill_net(const NetBind& b, NcaNetArgs* na) {
-    int rc = layout_of(b.net, &na->lay);
+static int fill_net(const NetBind& b, NcaNetArgs* na, int32_t prec) {
+    int rc = layout_of(b.net, &na->lay, prec);
     if (rc != NCA_OK) return rc;
     if (!b.packed) return fail(NCA_E_INVALID, "packed weights pointer is NULL");
     if (na->lay.enc_mode == NCA_ENC_BANDS && !b.win) return fail(NCA_E_INVALID, "band window is NULL");
@@ -187,8 +195,6 @@ static int build_stages(NcaFusedArgs* a, const NetBind* binds, bool bwd) {
     return NCA_OK;
 }
 
-static int64_t scratch_rows(const NcaLayout& y) { return y.K0rows_pad + (int64_t)(y.NL - 1) * y.F + (int64_t)y.NL * y.F; }
-
 static int check_rays(const NcaRays* r) {
     if (!r) return fail(NCA_E_INVALID, "rays is NULL");
     if (r->R <= 0 || r->S <= 0) return fail(NCA_E_INVALID, "empty ray batch (R=%lld, S=%d)", (long long)r->R, r->S);
@@ -197,10 +203,12 @@ static int check_rays(const NcaRays* r) {
     return NCA_OK;
 }
 
-static void rays_to_args(const NcaRays* r, NcaFusedArgs* a) {
+static inline int tile_samples(int32_t prec) { return prec == NCA_PREC_BF16 ? 64 : 32; }
+
+static void rays_to_args(const NcaRays* r, NcaFusedArgs* a, int32_t prec) {
     a->mode = NCA_MODE_RAYS;
     a->S = r->S;
-    a->nchunk = (r->S + 31) / 32;
+    a->nchunk = (r->S + tile_samples(prec) - 1) / tile_samples(prec);
     a->ray_is_f64 = r->ray_is_f64;
     a->act = r->act;
     a->single = r->single_field;
@@ -229,7 +237,8 @@ extern "C" int nca_render_fwd(const NcaRays* rays, int32_t prec,
                               double* pix, float* sig_s, float* sig_d, void* work, int64_t work_bytes, void* stream) {
     int rc = check_rays(rays);
     if (rc) return rc;
-    if (prec != NCA_PREC_F32) return fail(NCA_E_UNSUPPORTED, "precision %d not built", prec);
+    rc = check_prec(prec);
+    if (rc) return rc;
     if (!pix || !sig_s || (!rays->single_field && !sig_d)) return fail(NCA_E_INVALID, "an output pointer is NULL");
     if (!rays->single_field && !net_d) return fail(NCA_E_INVALID, "composite render needs the dynamic net");
     const int64_t need = nca_render_fwd_workspace(rays);
@@ -237,11 +246,11 @@ extern "C" int nca_render_fwd(const NcaRays* rays, int32_t prec,
 
     static thread_local NcaFusedArgs a;
     memset(&a, 0, sizeof(a));
-    rays_to_args(rays, &a);
+    rays_to_args(rays, &a, prec);
     a.nnets = rays->single_field ? 1 : 2;
     NetBind binds[2] = {{net_s, packed_s, win_s, four_s, nullptr}, {net_d, packed_d, win_d, four_d, latents_d}};
     for (int n = 0; n < a.nnets; ++n) {
-        rc = fill_net(binds[n], &a.net[n]);
+        rc = fill_net(binds[n], &a.net[n], prec);
         if (rc) return rc;
     }
     if (a.net[0].lay.T > 0 && !rays->single_field) return fail(NCA_E_INVALID, "first net of a composite render must be static (T == 0)");
@@ -260,29 +269,34 @@ extern "C" int nca_render_fwd(const NcaRays* rays, int32_t prec,
     hipStream_t st = (hipStream_t)stream;
     {
         Span sp(NCA_K_FWD, st);
-        HIPCHK(nca_launch_fused_f32(a.net[0].lay.F, a, false, grid, st));
+        if (prec == NCA_PREC_BF16) HIPCHK(nca_launch_fused_bf16(a.net[0].lay.F, a, false, grid, st));
+        else HIPCHK(nca_launch_fused_f32(a.net[0].lay.F, a, false, grid, st));
     }
     HIPCHK(nca_launch_pix_f32(rays->R, a.nchunk, rays->I0, a.part, pix, st));
     return NCA_OK;
 }
 
 // ---------------------------------------------------------------------------------- backward
+// A "unit" is what the batch is chunked by: one ray (rays mode) or one wave tile of points.
 struct BwdPlan {
-    int64_t rows;          // scratch rows over all nets
+    int64_t tile_stride;   // f32: scratch rows per 32-sample tile; bf16: BYTES per 32-sample tile (all nets)
     int64_t slab_stride;   // floats per split slab
     int n_split, njobs, grid;
-    int64_t units_per_chunk;   // rays (or 32-point tiles) per launch
-    int64_t tiles_per_unit;
-    int64_t bytes_fixed, bytes_total;
+    int64_t units_per_chunk;
+    int64_t tiles_per_unit;    // wave tiles (32 samples f32 / 64 samples bf16) per unit
+    int64_t bytes_total;
     int64_t off_slab, off_oslab, off_scratch;
 };
 
-static int plan_bwd(const NcaLayout* lays, int nnets, int64_t units, int64_t tiles_per_unit, int64_t budget, BwdPlan* p) {
-    p->rows = 0;
+static int64_t scratch_rows(const NcaLayout& y) { return y.K0rows_pad + (int64_t)(y.NL - 1) * y.F + (int64_t)y.NL * y.F; }
+
+static int plan_bwd(const NcaLayout* lays, int nnets, int32_t prec, int64_t units, int64_t tiles_per_unit, int64_t budget, BwdPlan* p) {
+    const bool bf = prec == NCA_PREC_BF16;
+    p->tile_stride = 0;
     p->slab_stride = 0;
     p->njobs = 0;
     for (int n = 0; n < nnets; ++n) {
-        p->rows += scratch_rows(lays[n]);
+        p->tile_stride += bf ? nca_bf_tile_bytes(lays[n]) : scratch_rows(lays[n]);
         p->slab_stride += lays[n].n_params;
         for (int j = 0; j < lays[n].NL; ++j) p->njobs += lays[n].layer[j].kind == NCA_IN_SKIP ? 2 : 1;
     }
@@ -292,35 +306,36 @@ static int plan_bwd(const NcaLayout* lays, int nnets, int64_t units, int64_t til
     const int cus = num_cus();
     p->tiles_per_unit = tiles_per_unit;
     const int F = lays[0].F;
-    // fixed parts sized for the largest possible launch geometry
-    const int64_t max_grid = cus;
-    int nsplit = (2 * cus + p->njobs - 1) / p->njobs;
+    // f32 wgrad: 256-thread workgroups, two per CU.  bf16 wgrad: one wave per (job, split), four per CU.
+    int nsplit = ((bf ? 4 : 2) * cus + p->njobs - 1) / p->njobs;
     if (nsplit < 1) nsplit = 1;
     const int64_t slab_bytes = align_up((int64_t)nsplit * p->slab_stride * 4, 256);
-    const int64_t oslab_bytes = align_up(max_grid * 2 * (F + 1) * 4, 256);
-    p->bytes_fixed = slab_bytes + oslab_bytes;
-    const int64_t per_unit = p->rows * tiles_per_unit * 32 * 4;
+    const int64_t oslab_bytes = align_up((int64_t)cus * 2 * (F + 1) * 4, 256);
+    const int64_t fixed = slab_bytes + oslab_bytes;
+    // scratch bytes per unit: f32 rows*32 floats per 32-sample tile; bf16 two 32-sample tiles per wave tile
+    const int64_t per_unit = bf ? p->tile_stride * 2 * tiles_per_unit : p->tile_stride * tiles_per_unit * 32 * 4;
     int64_t upc = units;
     if (budget > 0) {
-        int64_t avail = budget - p->bytes_fixed;
+        int64_t avail = budget - fixed;
         int64_t fit = avail > 0 ? avail / per_unit : 0;
         if (fit < 1) fit = 1;
         if (fit < upc) upc = fit;
     }
     p->units_per_chunk = upc;
     const int64_t tiles = upc * tiles_per_unit;
-    if ((int64_t)nsplit > tiles) nsplit = (int)tiles;
+    const int64_t ktiles = bf ? tiles * 2 : tiles;       // 32-sample tiles the wgrad splits over
+    if ((int64_t)nsplit > ktiles) nsplit = (int)ktiles;
     p->n_split = nsplit;
     const int64_t ngroups = (tiles + NCA_WAVES - 1) / NCA_WAVES;
     p->grid = (int)(ngroups < cus ? ngroups : cus);
     p->off_slab = 0;
     p->off_oslab = slab_bytes;
-    p->off_scratch = slab_bytes + oslab_bytes;
+    p->off_scratch = fixed;
     p->bytes_total = p->off_scratch + align_up(per_unit * upc, 256);
     return NCA_OK;
 }
 
-static int add_jobs(NcaWgradArgs* w, const NcaLayout& y, int64_t row0, int64_t slab_off, int64_t onehot_off) {
+static void add_jobs_f32(NcaWgradArgs* w, const NcaLayout& y, int64_t row0, int64_t slab_off, int64_t onehot_off) {
     const int64_t hrow0 = row0 + y.K0rows_pad;                    // inputs of layers 1..NL-1
     const int64_t drow0 = hrow0 + (int64_t)(y.NL - 1) * y.F;      // D_0 .. D_{NL-1}
     for (int j = 0; j < y.NL; ++j) {
@@ -356,15 +371,45 @@ static int add_jobs(NcaWgradArgs* w, const NcaLayout& y, int64_t row0, int64_t s
             g.bias_off = bias_done ? -1 : slab_off + l.b_off;
         }
     }
-    return NCA_OK;
 }
 
-static int run_bwd(NcaFusedArgs& a, const NetBind* binds, int64_t units, int64_t tiles_per_unit, float* const* grads,
+static void add_jobs_bf16(NcaWgradArgs* w, const NcaLayout& y, int64_t net_off, int64_t slab_off, int64_t onehot_off) {
+    const int64_t EB = 32 * (int64_t)NCA_BF_ENCROWS * 2, HB = 32 * (int64_t)y.F * 2;
+    for (int j = 0; j < y.NL; ++j) {
+        const NcaLayerL& l = y.layer[j];
+        NcaWgradJob& g = w->job[w->njobs++];
+        g.F = y.F;
+        g.d_row0 = net_off + EB + (int64_t)(y.NL - 1) * HB + (int64_t)j * HB;
+        g.out_off = slab_off + l.w_off;
+        g.out_ld = l.K;
+        g.out_col0 = 0;
+        g.bias_off = slab_off + l.b_off;
+        g.onehot_off = onehot_off;
+        if (j == 0) {
+            g.is_enc = 1;
+            g.b_row0 = net_off;
+            g.b_row_bytes = NCA_BF_ENCROWS * 2;
+            g.ncols_w = y.Kenc;
+            g.T = y.T;
+            g.P = y.P;
+        } else {
+            g.is_enc = 0;
+            g.b_row0 = net_off + EB + (int64_t)(j - 1) * HB;
+            g.b_row_bytes = y.F * 2;
+            g.ncols_w = y.F;
+            g.T = 0;
+            g.P = 0;
+        }
+    }
+}
+
+static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t units, int64_t tiles_per_unit, float* const* grads,
                    void* work, int64_t work_bytes, hipStream_t st) {
+    const bool bf = prec == NCA_PREC_BF16;
     NcaLayout lays[2];
     for (int n = 0; n < a.nnets; ++n) lays[n] = a.net[n].lay;
     BwdPlan p;
-    int rc = plan_bwd(lays, a.nnets, units, tiles_per_unit, work_bytes, &p);
+    int rc = plan_bwd(lays, a.nnets, prec, units, tiles_per_unit, work_bytes, &p);
     if (rc) return rc;
     if (!work || work_bytes < p.bytes_total) return fail(NCA_E_WORKSPACE, "backward workspace %lld < %lld bytes", (long long)work_bytes, (long long)p.bytes_total);
     char* wb = static_cast<char*>(work);
@@ -374,15 +419,18 @@ static int run_bwd(NcaFusedArgs& a, const NetBind* binds, int64_t units, int64_t
 
     rc = build_stages(&a, binds, true);
     if (rc) return rc;
-    int64_t row = 0, soff = 0;
-    for (int n = 0; n < a.nnets; ++n) { a.net[n].row0 = row; row += scratch_rows(lays[n]); }
+    int64_t off = 0, soff = 0;
+    for (int n = 0; n < a.nnets; ++n) { a.net[n].row0 = off; off += bf ? nca_bf_tile_bytes(lays[n]) : scratch_rows(lays[n]); }
     int64_t slab_off[2] = {0, 0}, onehot_off[2] = {0, 0};
     for (int n = 0; n < a.nnets; ++n) { slab_off[n] = soff; soff += lays[n].n_params; }
     for (int n = 0; n < a.nnets; ++n) { onehot_off[n] = soff; soff += (int64_t)lays[n].F * lays[n].P; }
 
     static thread_local NcaWgradArgs w;
     memset(&w, 0, sizeof(w));
-    for (int n = 0; n < a.nnets; ++n) add_jobs(&w, lays[n], a.net[n].row0, slab_off[n], onehot_off[n]);
+    for (int n = 0; n < a.nnets; ++n) {
+        if (bf) add_jobs_bf16(&w, lays[n], a.net[n].row0, slab_off[n], onehot_off[n]);
+        else add_jobs_f32(&w, lays[n], a.net[n].row0, slab_off[n], onehot_off[n]);
+    }
     w.scratch = scratch;
     w.slab = slab;
     w.slab_stride = p.slab_stride;
@@ -390,23 +438,26 @@ static int run_bwd(NcaFusedArgs& a, const NetBind* binds, int64_t units, int64_t
     a.scratch = scratch;
     a.oslab = oslab;
     const int F = lays[0].F;
+    const int wave_samples = tile_samples(prec);
     int chunk = 0;
     for (int64_t u0 = 0; u0 < units; u0 += p.units_per_chunk, ++chunk) {
         const int64_t nu = (u0 + p.units_per_chunk <= units) ? p.units_per_chunk : units - u0;
         a.ntiles = nu * tiles_per_unit;
-        a.rows_total = p.rows;
+        a.rows_total = p.tile_stride;
         a.accumulate = chunk > 0;
-        if (a.mode == NCA_MODE_RAYS) a.ray0 = u0; else a.n0 = u0 * 32;
+        if (a.mode == NCA_MODE_RAYS) a.ray0 = u0; else a.n0 = u0 * wave_samples;
         {
             Span sp(NCA_K_BWD_DGRAD, st);
-            HIPCHK(nca_launch_fused_f32(F, a, true, p.grid, st));
+            if (bf) HIPCHK(nca_launch_fused_bf16(F, a, true, p.grid, st));
+            else HIPCHK(nca_launch_fused_f32(F, a, true, p.grid, st));
         }
-        w.rows_total = p.rows;
-        w.ntiles = a.ntiles;
+        w.rows_total = p.tile_stride;
+        w.ntiles = bf ? a.ntiles * 2 : a.ntiles;
         w.accumulate = chunk > 0;
         {
             Span sp(NCA_K_BWD_WGRAD, st);
-            HIPCHK(nca_launch_wgrad_f32(w, p.n_split, st));
+            if (bf) HIPCHK(nca_launch_wgrad_bf16(F, w, p.n_split, st));
+            else HIPCHK(nca_launch_wgrad_f32(w, p.n_split, st));
         }
     }
     NcaReduceArgs r;
@@ -440,14 +491,16 @@ static int run_bwd(NcaFusedArgs& a, const NetBind* binds, int64_t units, int64_t
 extern "C" int64_t nca_render_bwd_workspace(const NcaRays* rays, const NcaNet* net_s, const NcaNet* net_d, int32_t prec, int64_t max_bytes) {
     int rc = check_rays(rays);
     if (rc) return rc;
-    if (prec != NCA_PREC_F32) return fail(NCA_E_UNSUPPORTED, "precision %d not built", prec);
+    rc = check_prec(prec);
+    if (rc) return rc;
     NcaLayout lays[2];
     int nn = rays->single_field ? 1 : 2;
-    rc = layout_of(net_s, &lays[0]);
+    rc = layout_of(net_s, &lays[0], prec);
     if (rc) return rc;
-    if (nn == 2) { rc = layout_of(net_d, &lays[1]); if (rc) return rc; }
+    if (nn == 2) { rc = layout_of(net_d, &lays[1], prec); if (rc) return rc; }
     BwdPlan p;
-    rc = plan_bwd(lays, nn, rays->R, (rays->S + 31) / 32, max_bytes, &p);
+    const int ts = tile_samples(prec);
+    rc = plan_bwd(lays, nn, prec, rays->R, (rays->S + ts - 1) / ts, max_bytes, &p);
     if (rc) return rc;
     return p.bytes_total;
 }
@@ -459,17 +512,18 @@ extern "C" int nca_render_bwd(const NcaRays* rays, int32_t prec,
                               float* grads_s, float* grads_d, void* work, int64_t work_bytes, void* stream) {
     int rc = check_rays(rays);
     if (rc) return rc;
-    if (prec != NCA_PREC_F32) return fail(NCA_E_UNSUPPORTED, "precision %d not built", prec);
+    rc = check_prec(prec);
+    if (rc) return rc;
     if (!g_pix) return fail(NCA_E_INVALID, "g_pix is NULL");
     if (!grads_s || (!rays->single_field && !grads_d)) return fail(NCA_E_INVALID, "a gradient output pointer is NULL");
     if (!params_s || (!rays->single_field && !params_d)) return fail(NCA_E_INVALID, "natural parameters are required");
     static thread_local NcaFusedArgs a;
     memset(&a, 0, sizeof(a));
-    rays_to_args(rays, &a);
+    rays_to_args(rays, &a, prec);
     a.nnets = rays->single_field ? 1 : 2;
     NetBind binds[2] = {{net_s, packed_s, win_s, four_s, params_s}, {net_d, packed_d, win_d, four_d, params_d}};
     for (int n = 0; n < a.nnets; ++n) {
-        rc = fill_net(binds[n], &a.net[n]);
+        rc = fill_net(binds[n], &a.net[n], prec);
         if (rc) return rc;
     }
     if (a.nnets == 2 && a.net[0].lay.F != a.net[1].lay.F) return fail(NCA_E_UNSUPPORTED, "static and dynamic nets must have the same num_filters");
@@ -479,13 +533,14 @@ extern "C" int nca_render_bwd(const NcaRays* rays, int32_t prec,
     a.g_sig_s = g_sig_s;
     a.g_sig_d = g_sig_d;
     float* grads[2] = {grads_s, grads_d};
-    return run_bwd(a, binds, rays->R, a.nchunk, grads, work, work_bytes, (hipStream_t)stream);
+    return run_bwd(a, prec, binds, rays->R, a.nchunk, grads, work, work_bytes, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------- point path
 extern "C" int nca_mlp_fwd(const NcaNet* net, int32_t prec, const void* packed, const float* win, const float* four,
                            const float* params, int64_t N, const float* pts, const int32_t* phase, float* raw, void* stream) {
-    if (prec != NCA_PREC_F32) return fail(NCA_E_UNSUPPORTED, "precision %d not built", prec);
+    int rc = check_prec(prec);
+    if (rc) return rc;
     if (N <= 0) return fail(NCA_E_INVALID, "empty point batch");
     if (!pts || !raw) return fail(NCA_E_INVALID, "pts/raw is NULL");
     static thread_local NcaFusedArgs a;
@@ -493,32 +548,36 @@ extern "C" int nca_mlp_fwd(const NcaNet* net, int32_t prec, const void* packed, 
     a.mode = NCA_MODE_POINTS;
     a.nnets = 1;
     NetBind binds[2] = {{net, packed, win, four, params}, {}};
-    int rc = fill_net(binds[0], &a.net[0]);
+    rc = fill_net(binds[0], &a.net[0], prec);
     if (rc) return rc;
     if (a.net[0].lay.T > 0 && !phase) return fail(NCA_E_INVALID, "dynamic net needs phase ids");
     rc = build_stages(&a, binds, false);
     if (rc) return rc;
+    const int ts = tile_samples(prec);
     a.N = N;
     a.n0 = 0;
     a.pts = pts;
     a.phase = phase;
     a.raw_out = raw;
-    a.ntiles = (N + 31) / 32;
+    a.ntiles = (N + ts - 1) / ts;
     const int64_t ngroups = (a.ntiles + NCA_WAVES - 1) / NCA_WAVES;
     const int grid = (int)(ngroups < num_cus() ? ngroups : num_cus());
     Span sp(NCA_K_FWD, (hipStream_t)stream);
-    HIPCHK(nca_launch_fused_f32(a.net[0].lay.F, a, false, grid, (hipStream_t)stream));
+    if (prec == NCA_PREC_BF16) HIPCHK(nca_launch_fused_bf16(a.net[0].lay.F, a, false, grid, (hipStream_t)stream));
+    else HIPCHK(nca_launch_fused_f32(a.net[0].lay.F, a, false, grid, (hipStream_t)stream));
     return NCA_OK;
 }
 
 extern "C" int64_t nca_mlp_bwd_workspace(const NcaNet* net, int32_t prec, int64_t N, int64_t max_bytes) {
-    if (prec != NCA_PREC_F32) return fail(NCA_E_UNSUPPORTED, "precision %d not built", prec);
+    int rc = check_prec(prec);
+    if (rc) return rc;
     if (N <= 0) return fail(NCA_E_INVALID, "empty point batch");
     NcaLayout lay;
-    int rc = layout_of(net, &lay);
+    rc = layout_of(net, &lay, prec);
     if (rc) return rc;
     BwdPlan p;
-    rc = plan_bwd(&lay, 1, (N + 31) / 32, 1, max_bytes, &p);
+    const int ts = tile_samples(prec);
+    rc = plan_bwd(&lay, 1, prec, (N + ts - 1) / ts, 1, max_bytes, &p);
     if (rc) return rc;
     return p.bytes_total;
 }
@@ -526,7 +585,8 @@ extern "C" int64_t nca_mlp_bwd_workspace(const NcaNet* net, int32_t prec, int64_
 extern "C" int nca_mlp_bwd(const NcaNet* net, int32_t prec, const void* packed, const float* win, const float* four,
                            const float* params, int64_t N, const float* pts, const int32_t* phase, const float* g_raw,
                            float* grads, void* work, int64_t work_bytes, void* stream) {
-    if (prec != NCA_PREC_F32) return fail(NCA_E_UNSUPPORTED, "precision %d not built", prec);
+    int rc = check_prec(prec);
+    if (rc) return rc;
     if (N <= 0) return fail(NCA_E_INVALID, "empty point batch");
     if (!pts || !g_raw || !grads || !params) return fail(NCA_E_INVALID, "a pointer is NULL");
     static thread_local NcaFusedArgs a;
@@ -534,7 +594,7 @@ extern "C" int nca_mlp_bwd(const NcaNet* net, int32_t prec, const void* packed, 
     a.mode = NCA_MODE_POINTS;
     a.nnets = 1;
     NetBind binds[2] = {{net, packed, win, four, params}, {}};
-    int rc = fill_net(binds[0], &a.net[0]);
+    rc = fill_net(binds[0], &a.net[0], prec);
     if (rc) return rc;
     if (a.net[0].lay.T > 0 && !phase) return fail(NCA_E_INVALID, "dynamic net needs phase ids");
     a.N = N;
@@ -542,5 +602,6 @@ extern "C" int nca_mlp_bwd(const NcaNet* net, int32_t prec, const void* packed, 
     a.phase = phase;
     a.g_raw = g_raw;
     float* gr[2] = {grads, nullptr};
-    return run_bwd(a, binds, (N + 31) / 32, 1, gr, work, work_bytes, (hipStream_t)stream);
+    const int ts = tile_samples(prec);
+    return run_bwd(a, prec, binds, (N + ts - 1) / ts, 1, gr, work, work_bytes, (hipStream_t)stream);
 }

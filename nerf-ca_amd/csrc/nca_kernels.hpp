@@ -51,7 +51,7 @@ struct NcaFusedArgs {
     const float* g_sig_d;
     const float* g_raw;
     float* scratch;      // [tile][rows_total][32]: layer inputs H and output gradients D of each 32-sample tile
-    int64_t rows_total;  // scratch rows per tile over all nets
+    int64_t rows_total;  // f32: scratch rows per 32-sample tile over all nets;  bf16: BYTES per 32-sample tile
     float* oslab;        // [grid][2][F+1] output-layer gradient partials
     int32_t accumulate;  // add to oslab instead of overwriting (ray chunks after the first)
     int32_t nstages;
@@ -69,6 +69,8 @@ struct NcaWgradJob {
     int32_t out_ld, out_col0;
     int64_t onehot_off;   // slab offset of the [F][P] one-hot block
     int64_t bias_off;     // slab offset of the bias gradient, or -1
+    int32_t b_row_bytes;  // bf16 path: bytes of one sample row of the H block (d_row0/b_row0 are BYTE offsets in a tile there)
+    int32_t is_enc, T, pad;
 };
 
 struct NcaWgradArgs {
@@ -104,4 +106,7 @@ hipError_t nca_launch_pack_f32(const NcaLayout& y, const float* prm, void* out, 
 hipError_t nca_launch_fused_f32(int F, const NcaFusedArgs& a, bool bwd, int grid, hipStream_t st);
 hipError_t nca_launch_wgrad_f32(const NcaWgradArgs& a, int nsplit, hipStream_t st);
 hipError_t nca_launch_reduce_f32(const NcaReduceArgs& a, hipStream_t st);
+hipError_t nca_launch_pack_bf16(const NcaLayout& y, const float* prm, void* out, hipStream_t st);
+hipError_t nca_launch_fused_bf16(int F, const NcaFusedArgs& a, bool bwd, int grid, hipStream_t st);
+hipError_t nca_launch_wgrad_bf16(int F, const NcaWgradArgs& a, int nsplit, hipStream_t st);
 hipError_t nca_launch_pix_f32(int64_t R, int nchunk, const float* I0, const double* part, double* pix, hipStream_t st);

@@ -1,0 +1,719 @@
+// nca_kernels_bf16.hip -- gfx950 kernels of the bf16 (throughput) path: bf16 MFMA operands
+// (v_mfma_f32_32x32x16_bf16), f32 accumulation, f32 master weights, f32 encoding arithmetic.
+//
+//   nca_pack_bf16        natural flat f32 parameters -> bf16 MFMA-ordered LDS images (+ f32 bias tails)
+//   nca_fused_bf16<F,BWD>  a wave owns 64 consecutive samples of one ray: lane = sample for the
+//         encoding, then two 32-column tiles for the MFMAs (v_permlane32_swap builds both operand
+//         tiles from the per-lane features).  Layers run row-tile-outer: the 32x32 accumulator pair of
+//         row tile m is finished, ReLU'd, packed pairwise to bf16 and becomes k-steps 2m, 2m+1 of the
+//         next layer's B operand while row tile m+1's MFMAs issue -- activations never leave registers.
+//         BWD=true adds the recompute stores (sample-major bf16 blocks), output-layer gradients and
+//         the dgrad sweep.
+//   nca_wgrad_bf16       dW = D * H^T over samples with NO LDS: sample-major operand tiles are loaded
+//         straight into A-operand fragments, transposed by MFMAs against identity fragments into
+//         accumulator layout (rows = samples), and those tiles feed the weight-gradient MFMAs as A
+//         (X^T form) and B operands; dW of a whole layer stays in 256 accumulator registers.
+#include <hip/hip_runtime.h>
+#include "nca_kernels.hpp"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+    bf16x2 v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float bf_lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bf_hi(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+__device__ __forceinline__ bf16x8 frag(u32x4 x) { return __builtin_bit_cast(bf16x8, x); }
+__device__ __forceinline__ float relu1(float x) {
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// pack
+// ------------------------------------------------------------------------------------------
+__global__ void nca_pack_bf16(NcaLayout y, const float* __restrict__ prm, unsigned* __restrict__ out) {
+    const uint32_t total = y.packed_bytes / 4u;
+    for (uint32_t wd = blockIdx.x * blockDim.x + threadIdx.x; wd < total; wd += gridDim.x * blockDim.x) {
+        unsigned v = 0u;
+        const uint32_t byte = wd * 4u;
+        for (int j = 0; j < y.NL; ++j) {
+            const NcaLayerL& l = y.layer[j];
+            if (byte >= l.img_off && byte < l.img_off + l.img_bytes) {
+                const uint32_t wbytes = (uint32_t)y.MT * (uint32_t)l.ksteps * 1024u;
+                const uint32_t off = byte - l.img_off;
+                const uint32_t tail = 2u * (uint32_t)y.MT * 16u;   // floats
+                if (off < wbytes) {
+                    float two[2];
+                    for (int e2 = 0; e2 < 2; ++e2) {
+                        const uint32_t e = off / 2u + e2;            // bf16 element index
+                        const int jj = e % 8, lane = (e / 8) % 64, ks = (e / 512) % l.ksteps, m = e / (512 * l.ksteps);
+                        const int r = lane & 31, h = lane >> 5;
+                        int k;
+                        if (j == 0) k = nca_bf_slot_to_nat(y, 16 * ks + 8 * h + jj);
+                        else k = nca_bf_kidx_hidden(ks, h, jj);
+                        two[e2] = k >= 0 ? prm[l.w_off + (32 * m + r) * l.K + k] : 0.f;
+                    }
+                    v = pack2(two[0], two[1]);
+                } else {
+                    uint32_t q = (off - wbytes) / 4u;
+                    float f = 0.f;
+                    if (q < tail) {
+                        const int i = q % 16, m = (q / 16) % y.MT, h = q / (16 * y.MT);
+                        f = prm[l.b_off + 32 * m + nca_rho(i) + 4 * h];
+                    } else if (j == y.NL - 1) {
+                        q -= tail;
+                        if (q < tail) {
+                            const int i = q % 16, m = (q / 16) % y.MT, h = q / (16 * y.MT);
+                            f = prm[y.wo_off + 32 * m + nca_rho(i) + 4 * h];
+                        } else if (q == tail) {
+                            f = prm[y.bo_off];
+                        }
+                    }
+                    v = __builtin_bit_cast(unsigned, f);
+                }
+            }
+            if (l.imgT_bytes && byte >= l.imgT_off && byte < l.imgT_off + l.imgT_bytes) {
+                const uint32_t off = byte - l.imgT_off;
+                const int KS = y.F / 16;
+                float two[2];
+                for (int e2 = 0; e2 < 2; ++e2) {
+                    const uint32_t e = off / 2u + e2;
+                    const int jj = e % 8, lane = (e / 8) % 64, ks = (e / 512) % KS, m = e / (512 * KS);
+                    const int r = lane & 31, h = lane >> 5;
+                    two[e2] = prm[l.w_off + nca_bf_kidx_hidden(ks, h, jj) * l.K + 32 * m + r];
+                }
+                v = pack2(two[0], two[1]);
+            }
+        }
+        out[wd] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// shared device helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float act_fwd_b(int act, float x) {
+    if (act == NCA_ACT_SIGMOID) return 1.f / (1.f + expf(-x));
+    float sp = x > 20.f ? x : log1pf(expf(x));
+    if (act == NCA_ACT_CLAMP) sp = fminf(fmaxf(sp, 0.f), 1.f);
+    return sp;
+}
+__device__ __forceinline__ float act_bwd_b(int act, float x) {
+    if (act == NCA_ACT_SIGMOID) { float s = 1.f / (1.f + expf(-x)); return s * (1.f - s); }
+    float d;
+    if (x > 20.f) d = 1.f; else { float z = expf(x); d = z / (z + 1.f); }
+    if (act == NCA_ACT_CLAMP) {
+        float sp = x > 20.f ? x : log1pf(expf(x));
+        if (!(sp > 0.f && sp < 1.f)) d = 0.f;
+    }
+    return d;
+}
+__device__ __forceinline__ float half_sum_b(float v) {
+    v += __shfl_xor(v, 16); v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_b(double v) {
+    v += __shfl_xor(v, 32); v += __shfl_xor(v, 16); v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+    return v;
+}
+
+template <int F>
+struct BfCfg {
+    static constexpr int MT = F / 32;
+    static constexpr int KS = F / 16;
+    static constexpr int KS0 = NCA_BF_K0SLOTS / 16;
+    static constexpr int KSMAX = KS > KS0 ? KS : KS0;
+    static constexpr int IMG_MAX = KSMAX * MT * 1024 + 2 * (2 * MT * 16 * 4) + 16;
+    static constexpr int BUF_BYTES = (IMG_MAX + 1023) & ~1023;
+};
+
+#define NCA_CONST_WIN 16
+#define NCA_CONST_FOUR 48
+#define NCA_CONST_LAT 2048
+#define NCA_CONST_NET_FLOATS (NCA_CONST_WIN + NCA_CONST_FOUR + NCA_CONST_LAT)
+#define NCA_CONST_BYTES (2 * NCA_CONST_NET_FLOATS * 4)
+
+__device__ __forceinline__ void stage_issue_b(const NcaStage& st, char* dst, int wave, int lane) {
+    const int npiece = (int)(st.bytes >> 10);
+    const char* src = reinterpret_cast<const char*>(st.ptr) + lane * 16;
+    for (int c = wave; c < npiece; c += NCA_WAVES) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)c * 1024),
+                                         (__attribute__((address_space(3))) void*)(dst + c * 1024), 16, 0, 0);
+    }
+}
+__device__ __forceinline__ void stage_publish_b() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+// acc0/acc1 += A(row tile image) * B over NKS k-steps; A fragments are read one step ahead
+template <int NKS, int NB>
+__device__ __forceinline__ void mma_rowtile(const char* imgm, const u32x4 (&B)[2][NB], f32x16& acc0, f32x16& acc1) {
+    u32x4 A[2];
+    A[0] = *reinterpret_cast<const u32x4*>(imgm);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        if (ks + 1 < NKS) A[(ks + 1) & 1] = *reinterpret_cast<const u32x4*>(imgm + (ks + 1) * 1024);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(A[ks & 1]), frag(B[0][ks]), acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(A[ks & 1]), frag(B[1][ks]), acc1, 0, 0, 0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// fused forward / backward-dgrad kernel
+// ------------------------------------------------------------------------------------------
+template <int F, bool BWD>
+__global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a) {
+    constexpr int MT = BfCfg<F>::MT, KS = BfCfg<F>::KS, KS0 = BfCfg<F>::KS0, KSMAX = BfCfg<F>::KSMAX;
+    constexpr int BUF = BfCfg<F>::BUF_BYTES;
+    constexpr int HB = 32 * F * 2;                          // bytes of one hidden scratch block (32 samples x F)
+    constexpr int EB = 32 * NCA_BF_ENCROWS * 2;             // bytes of the input block
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* cst = reinterpret_cast<float*>(smem + 2 * BUF);
+    float* osum = reinterpret_cast<float*>(smem + 2 * BUF + NCA_CONST_BYTES);
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+
+    for (int net = 0; net < a.nnets; ++net) {
+        const NcaNetArgs& na = a.net[net];
+        float* c = cst + net * NCA_CONST_NET_FLOATS;
+        if (na.win) for (int i = tid; i < na.lay.L; i += NCA_NT) c[i] = na.win[i];
+        if (na.lat) for (int i = tid; i < na.lay.P * na.lay.T; i += NCA_NT) c[NCA_CONST_WIN + NCA_CONST_FOUR + i] = na.lat[i];
+    }
+    if (BWD) for (int i = tid; i < NCA_WAVES * 2 * (F + 1); i += NCA_NT) osum[i] = 0.f;
+    __syncthreads();
+    stage_issue_b(a.stage[0], smem, wave, lane);
+    stage_publish_b();
+    int cur = 0, si = 0;
+
+    const int64_t ngroups = (a.ntiles + NCA_WAVES - 1) / NCA_WAVES;
+    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int64_t tile = grp * NCA_WAVES + wave;           // 64-sample tile
+        const bool tvalid = tile < a.ntiles;
+        const int64_t tl = tvalid ? tile : a.ntiles - 1;
+
+        // ---- per-lane sample (lane = sample) --------------------------------------------------------
+        int64_t ray = 0, n = 0;
+        int smp = 0;
+        bool valid;
+        float p[3];
+        if (a.mode == NCA_MODE_RAYS) {
+            ray = a.ray0 + tl / a.nchunk;
+            smp = (int)(tl % a.nchunk) * 64 + lane;
+            valid = tvalid && smp < a.S;
+            if (smp >= a.S) smp = a.S - 1;
+            n = ray * a.S + smp;
+            const float zz = a.z[ray * a.zs_r + smp];
+            if (a.ray_is_f64) {
+                const double* o = reinterpret_cast<const double*>(a.origins) + ray * 3;
+                const double* d = reinterpret_cast<const double*>(a.dirs) + ray * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) p[c] = (float)__dadd_rn(o[c], __dmul_rn(d[c], (double)zz));
+            } else {
+                const float* o = reinterpret_cast<const float*>(a.origins) + ray * 3;
+                const float* d = reinterpret_cast<const float*>(a.dirs) + ray * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) p[c] = __fadd_rn(o[c], __fmul_rn(d[c], zz));
+            }
+        } else {
+            n = a.n0 + tl * 64 + lane;
+            valid = tvalid && n < a.N;
+            if (n >= a.N) n = a.N - 1;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) p[c] = a.pts[n * 3 + c];
+        }
+        int ph = 0;
+        if (a.phase) ph = a.mode == NCA_MODE_RAYS ? a.phase[ray * a.ps_r + (int64_t)smp * a.ps_s] : a.phase[n];
+
+        // backward scratch: two 32-sample tiles per wave, sample-major blocks (see nca_bf_tile_bytes)
+        char* const t32 = BWD ? reinterpret_cast<char*>(a.scratch) + (tl * 2) * a.rows_total : nullptr;   // rows_total = bytes per 32-sample tile
+
+        float raw[2] = {0.f, 0.f};
+
+#pragma unroll
+        for (int net = 0; net < 2; ++net) {
+            if (net >= a.nnets) break;
+            const NcaNetArgs& na = a.net[net];
+            const NcaLayout& y = na.lay;
+            const int phc = ph < 0 ? 0 : (ph >= y.P ? y.P - 1 : ph);
+            const float* cnet = cst + net * NCA_CONST_NET_FLOATS;
+            char* const nb = BWD ? t32 + na.row0 : nullptr;   // this net's bytes inside a tile (row0 = byte offset)
+
+            // ================= encoding, lane = sample ===================================================
+            u32x4 B[2][KSMAX];
+            {
+                float fe[NCA_BF_K0SLOTS];
+#pragma unroll
+                for (int i = 0; i < NCA_BF_K0SLOTS; ++i) fe[i] = 0.f;
+                fe[0] = p[0]; fe[1] = p[1]; fe[2] = p[2];
+                if (y.enc_mode == NCA_ENC_BANDS) {
+                    float sn[3], cs[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) sincosf(p[c], &sn[c], &cs[c]);
+#pragma unroll
+                    for (int k = 0; k < 15; ++k) {
+                        if (k < y.L) {
+                            const float w = cnet[k];
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) {
+                                fe[3 + 6 * k + c] = w * sn[c];
+                                fe[6 + 6 * k + c] = w * cs[c];
+                                const float s2 = 2.f * sn[c] * cs[c];
+                                const float c2 = 1.f - 2.f * sn[c] * sn[c];
+                                sn[c] = s2; cs[c] = c2;
+                            }
+                        }
+                    }
+                }
+                if (y.T > 0) {
+                    const float* lat = cnet + NCA_CONST_WIN + NCA_CONST_FOUR + phc * y.T;
+#pragma unroll
+                    for (int t = 0; t < 16; ++t)
+                        if (t < y.T) fe[NCA_BF_LAT_SLOT + t] = lat[t];
+                }
+                unsigned fp[NCA_BF_K0SLOTS / 2];
+#pragma unroll
+                for (int w = 0; w < NCA_BF_K0SLOTS / 2; ++w) fp[w] = pack2(fe[2 * w], fe[2 * w + 1]);
+
+                if (BWD && tvalid) {
+                    // input block row of this sample: 96 slots + 16 one-hot phase slots
+                    char* row = nb + (lane >> 5) * a.rows_total + (lane & 31) * (NCA_BF_ENCROWS * 2);
+#pragma unroll
+                    for (int q = 0; q < NCA_BF_K0SLOTS / 8; ++q) {
+                        u32x4 v = {fp[4 * q], fp[4 * q + 1], fp[4 * q + 2], fp[4 * q + 3]};
+                        *reinterpret_cast<u32x4*>(row + q * 16) = v;
+                    }
+                    unsigned hot[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const unsigned lo = (y.P > 0 && phc == 2 * q) ? 0x3f80u : 0u;
+                        const unsigned hi = (y.P > 0 && phc == 2 * q + 1) ? 0x3f800000u : 0u;
+                        hot[q] = lo | hi;
+                    }
+                    u32x4 h0 = {hot[0], hot[1], hot[2], hot[3]}, h1 = {hot[4], hot[5], hot[6], hot[7]};
+                    *reinterpret_cast<u32x4*>(row + NCA_BF_HOT_SLOT * 2) = h0;
+                    *reinterpret_cast<u32x4*>(row + NCA_BF_HOT_SLOT * 2 + 16) = h1;
+                }
+                // per k-step: words 8s..8s+3 = k-half 0, 8s+4..8s+7 = k-half 1 of MY sample.  One
+                // half-swap per word yields the operand of tile 0 (samples 0..31) and tile 1 (32..63).
+#pragma unroll
+                for (int s = 0; s < KS0; ++s)
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        auto r = __builtin_amdgcn_permlane32_swap(fp[8 * s + w], fp[8 * s + 4 + w], false, false);
+                        B[0][s][w] = r[0];
+                        B[1][s][w] = r[1];
+                    }
+            }
+
+            // ================= layers (forward / recompute) ===============================================
+            float part[2] = {0.f, 0.f};       // output-layer partial dot per column tile
+            for (int jj = 0; jj < y.NL; ++jj) {
+                const NcaLayerL& l = y.layer[jj];
+                const int nsi = (si + 1 == a.nstages) ? 0 : si + 1;
+                stage_issue_b(a.stage[nsi], smem + (cur ^ 1) * BUF, wave, lane);
+                const char* img = smem + cur * BUF;
+                const int nks = l.ksteps;
+                const float* tail = reinterpret_cast<const float*>(img + MT * nks * 1024);
+                const bool last = jj == y.NL - 1;
+                const bool store_h = BWD && tvalid && !last;
+                char* const hblk = BWD ? nb + EB + jj * HB : nullptr;            // input block of layer jj+1
+                u32x4 Bn[2][2 * MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    f32x16 acc0, acc1;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { const float b = tail[(lh * MT + m) * 16 + i]; acc0[i] = b; acc1[i] = b; }
+                    const char* imgm = img + m * nks * 1024 + lane * 16;
+                    if (jj == 0) mma_rowtile<KS0, KSMAX>(imgm, B, acc0, acc1);
+                    else mma_rowtile<KS, KSMAX>(imgm, B, acc0, acc1);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { acc0[i] = relu1(acc0[i]); acc1[i] = relu1(acc1[i]); }
+                    if (last) {
+                        const float* wo = tail + 2 * MT * 16;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const float w = wo[(lh * MT + m) * 16 + i];
+                            part[0] = fmaf(w, acc0[i], part[0]);
+                            part[1] = fmaf(w, acc1[i], part[1]);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        Bn[0][2 * m][u] = pack2(acc0[2 * u], acc0[2 * u + 1]);
+                        Bn[0][2 * m + 1][u] = pack2(acc0[8 + 2 * u], acc0[8 + 2 * u + 1]);
+                        Bn[1][2 * m][u] = pack2(acc1[2 * u], acc1[2 * u + 1]);
+                        Bn[1][2 * m + 1][u] = pack2(acc1[8 + 2 * u], acc1[8 + 2 * u + 1]);
+                    }
+                    if (store_h) {
+                        // rows rho(4q..4q+3) + 4h = 8q + 4h + {0..3}: four consecutive features = 8 bytes
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            char* rowp = hblk + c * a.rows_total + lr * (F * 2) + (32 * m + 4 * lh) * 2;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                u32x2 v = {Bn[c][2 * m + (q >> 1)][2 * (q & 1)], Bn[c][2 * m + (q >> 1)][2 * (q & 1) + 1]};
+                                *reinterpret_cast<u32x2*>(rowp + q * 16) = v;
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int k = 0; k < 2 * MT; ++k) B[c][k] = Bn[c][k];
+
+                if (last) {
+                    const float* wo = tail + 2 * MT * 16;
+                    const float bo = wo[2 * MT * 16];
+                    // column tile c of lane (r,h) is sample 32c + r: sum the two halves, then lane = sample picks its tile
+                    const float r0 = part[0] + __shfl_xor(part[0], 32) + bo;
+                    const float r1 = part[1] + __shfl_xor(part[1], 32) + bo;
+                    raw[net] = lh ? r1 : r0;
+                }
+
+                if (BWD && last) {
+                    // ---------- gradient wrt the raw output, output-layer parameter gradients, D_{NL-1} ----------
+                    float g;
+                    if (a.mode == NCA_MODE_RAYS) {
+                        const float* gs = net == 0 ? a.g_sig_s : a.g_sig_d;
+                        const double gsig = gs ? (double)gs[n] : 0.0;
+                        const double gp = a.g_pix[ray] * a.dists[smp];
+                        const double dsig = a.single ? (gsig - gp * (double)a.scale) : (gsig - gp) * (double)a.scale;
+                        g = (float)dsig * act_bwd_b(a.act, raw[net]);
+                    } else {
+                        g = a.g_raw[n];
+                    }
+                    if (!valid) g = 0.f;
+                    // g of tile c for BOTH lane halves: [g.lower|g.lower] and [g.upper|g.upper]
+                    const float gc[2] = {__shfl(g, lr), __shfl(g, lr + 32)};
+                    const float* wo = tail + 2 * MT * 16;
+                    float* orow = osum + (wave * 2 + net) * (F + 1);
+                    char* const dblk = nb + EB + (y.NL - 1) * HB + (y.NL - 1) * HB;
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        // H_last of this row tile back to f32 (both column tiles), in accumulator register order
+                        float hv[2][16];
+#pragma unroll
+                        for (int c = 0; c < 2; ++c)
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                hv[c][2 * u] = bf_lo(B[c][2 * m][u]);          hv[c][2 * u + 1] = bf_hi(B[c][2 * m][u]);
+                                hv[c][8 + 2 * u] = bf_lo(B[c][2 * m + 1][u]);  hv[c][8 + 2 * u + 1] = bf_hi(B[c][2 * m + 1][u]);
+                            }
+                        // dWo[f] = sum_n g H[f][n]: reduce-scatter the 16 values over the 32 lanes of each half
+                        float v[16];
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) v[i] = gc[0] * hv[0][i] + gc[1] * hv[1][i];
+                        int cnt = 16;
+#pragma unroll
+                        for (int d = 16; d >= 1; d >>= 1) {
+                            if (cnt >= 2) {
+                                const int hn = cnt / 2;
+                                const bool up = (lr & d) != 0;
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) {
+                                    if (i < hn) {
+                                        float lo = v[i], hi = v[i + hn];
+                                        asm volatile("" : "+v"(lo), "+v"(hi));
+                                        const float keep = up ? hi : lo;
+                                        const float send = up ? lo : hi;
+                                        v[i] = keep + __shfl_xor(send, d);
+                                    }
+                                }
+                                cnt = hn;
+                            } else {
+                                v[0] += __shfl_xor(v[0], d);
+                            }
+                        }
+                        if ((lr & 1) == 0) orow[32 * m + nca_rho((lr >> 1) & 15) + 4 * lh] += v[0];
+                        // D_{NL-1} = relu'(H_last) * Wo * g, packed as the dgrad B operand, stored sample-major
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            float dv[16];
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) dv[i] = hv[c][i] > 0.f ? wo[(lh * MT + m) * 16 + i] * gc[c] : 0.f;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                Bn[c][2 * m][u] = pack2(dv[2 * u], dv[2 * u + 1]);
+                                Bn[c][2 * m + 1][u] = pack2(dv[8 + 2 * u], dv[8 + 2 * u + 1]);
+                            }
+                            if (tvalid) {
+                                char* rowp = dblk + c * a.rows_total + lr * (F * 2) + (32 * m + 4 * lh) * 2;
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    u32x2 w2 = {Bn[c][2 * m + (q >> 1)][2 * (q & 1)], Bn[c][2 * m + (q >> 1)][2 * (q & 1) + 1]};
+                                    *reinterpret_cast<u32x2*>(rowp + q * 16) = w2;
+                                }
+                            }
+                        }
+                    }
+                    const float gsum = half_sum_b(g) ;            // sum over the 32 lanes of each half
+                    const float gtot = gsum + __shfl_xor(gsum, 32);
+                    if (lane == 0) orow[F] += gtot;
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int k = 0; k < 2 * MT; ++k) B[c][k] = Bn[c][k];
+                }
+
+                stage_publish_b();
+                cur ^= 1;
+                si = nsi;
+            }
+
+            // ================= backward sweep (dgrad) =====================================================
+            if (BWD) {
+                for (int jj = y.NL - 1; jj >= 1; --jj) {
+                    const int nsi = (si + 1 == a.nstages) ? 0 : si + 1;
+                    stage_issue_b(a.stage[nsi], smem + (cur ^ 1) * BUF, wave, lane);
+                    const char* img = smem + cur * BUF;
+                    const char* const hblk = nb + EB + (jj - 1) * HB;                       // input of layer jj (mask)
+                    char* const dblk = nb + EB + (y.NL - 1) * HB + (jj - 1) * HB;           // D_{jj-1}
+                    u32x4 Bn[2][2 * MT];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        f32x16 acc0, acc1;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+                        mma_rowtile<KS, KSMAX>(img + m * KS * 1024 + lane * 16, B, acc0, acc1);
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            const char* hp = hblk + c * a.rows_total + lr * (F * 2) + (32 * m + 4 * lh) * 2;
+                            char* dp = dblk + c * a.rows_total + lr * (F * 2) + (32 * m + 4 * lh) * 2;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const u32x2 hw = *reinterpret_cast<const u32x2*>(hp + q * 16);   // features 8q+4h .. +3
+                                float dv[4];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const unsigned bits = (e & 1) ? (hw[e >> 1] >> 16) : (hw[e >> 1] & 0xffffu);
+                                    const float av = c == 0 ? acc0[4 * q + e] : acc1[4 * q + e];
+                                    dv[e] = ((short)bits > 0) ? av : 0.f;
+                                }
+                                const unsigned w0 = pack2(dv[0], dv[1]), w1 = pack2(dv[2], dv[3]);
+                                Bn[c][2 * m + (q >> 1)][2 * (q & 1)] = w0;
+                                Bn[c][2 * m + (q >> 1)][2 * (q & 1) + 1] = w1;
+                                if (tvalid) { u32x2 o2 = {w0, w1}; *reinterpret_cast<u32x2*>(dp + q * 16) = o2; }
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int k = 0; k < 2 * MT; ++k) B[c][k] = Bn[c][k];
+                    stage_publish_b();
+                    cur ^= 1;
+                    si = nsi;
+                }
+            }
+        }  // nets
+
+        // ================= epilogue (lane = sample) =========================================================
+        if (!BWD) {
+            if (a.mode == NCA_MODE_RAYS) {
+                double term;
+                if (a.single) {
+                    const float sa = act_fwd_b(a.act, raw[0]);
+                    if (valid) a.sig_s[n] = sa;
+                    term = ((double)sa * a.dists[smp]) * (double)a.scale;
+                } else {
+                    const float ss = __fmul_rn(act_fwd_b(a.act, raw[0]), a.scale);
+                    const float sd = __fmul_rn(act_fwd_b(a.act, raw[1]), a.scale);
+                    if (valid) { a.sig_s[n] = ss; a.sig_d[n] = sd; }
+                    term = (double)__fadd_rn(ss, sd) * a.dists[smp];
+                }
+                if (!valid) term = 0.0;
+                term = wave_sum_b(term);
+                if (lane == 0 && tvalid) a.part[tile] = term;
+            } else {
+                if (valid) a.raw_out[n] = raw[0];
+            }
+        }
+    }  // tile groups
+
+    if (BWD) {
+        __syncthreads();
+        for (int i = tid; i < 2 * (F + 1); i += NCA_NT) {
+            float s = 0.f;
+            for (int w = 0; w < NCA_WAVES; ++w) s += osum[(w * 2) * (F + 1) + i];
+            float* dst = a.oslab + (int64_t)blockIdx.x * 2 * (F + 1) + i;
+            *dst = a.accumulate ? *dst + s : s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// wgrad, no LDS.  One wave = one (job, split): dW of the whole layer in accumulators.
+// ------------------------------------------------------------------------------------------
+// identity fragment of k-step s for the transposing product Z = X^T * E: element j of lane (c,h) is
+// E[k = 16s + 8h + j][column c of the 32-wide output tile tcol] = 1 iff 32*tcol + c == that k.
+__device__ __forceinline__ u32x4 ident_frag(int kbase, int lc) {
+    // kbase = 16s + 8h - 32*tcol ; element j is 1 when kbase + j == lc
+    u32x4 r;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const unsigned lo = (kbase + 2 * w == lc) ? 0x3f80u : 0u;
+        const unsigned hi = (kbase + 2 * w + 1 == lc) ? 0x3f800000u : 0u;
+        r[w] = lo | hi;
+    }
+    return r;
+}
+
+// transpose a [32 samples][32*NT features] sample-major bf16 block (already loaded as A fragments:
+// lane (r = sample, h), k-step s: features 16s+8h..+7) into NT accumulator tiles with rows = samples,
+// column = feature on the lane, packed as two k-steps (16 samples each) of MFMA operands.
+template <int NT>
+__device__ __forceinline__ void transpose_block(const u32x4 (&X)[2 * NT], int lc, int lh, u32x4 (&T)[NT][2], float (*colsum)[NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        f32x16 z;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) z[i] = 0.f;
+        // features of tile t live in k-steps 2t and 2t+1 of X
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const u32x4 E = ident_frag(16 * s + 8 * lh, lc);
+            z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(X[2 * t + s]), frag(E), z, 0, 0, 0);
+        }
+        if (colsum) {
+            float cs = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) cs += z[i];
+            (*colsum)[t] += cs;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            T[t][0][u] = pack2(z[2 * u], z[2 * u + 1]);
+            T[t][1][u] = pack2(z[8 + 2 * u], z[8 + 2 * u + 1]);
+        }
+    }
+}
+
+template <int F, int NTB>   // NTB = 32-column tiles of the H block (F/32 for hidden inputs, 4 for the 112-wide input block)
+__device__ __forceinline__ void wgrad_job(const NcaWgradArgs& a, const NcaWgradJob& job, int q, int nsplit, int lane) {
+    constexpr int MT = F / 32;
+    const int lc = lane & 31, lh = lane >> 5;
+    const int64_t per = (a.ntiles + nsplit - 1) / nsplit;
+    const int64_t t0 = (int64_t)q * per, t1 = (t0 + per < a.ntiles) ? t0 + per : a.ntiles;
+    const char* base = reinterpret_cast<const char*>(a.scratch);
+    const int drow = F * 2, brow = job.b_row_bytes;
+    f32x16 acc[MT][NTB];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int c = 0; c < NTB; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][c][i] = 0.f;
+    float bsum[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) bsum[m] = 0.f;
+
+    for (int64_t t = t0; t < t1; ++t) {
+        const char* tb = base + t * a.rows_total;            // rows_total = bytes per 32-sample tile
+        const char* dp = tb + job.d_row0 + lc * drow + lh * 16;
+        const char* bp = tb + job.b_row0 + lc * brow + lh * 16;
+        u32x4 XD[2 * MT], XH[2 * NTB];
+#pragma unroll
+        for (int s = 0; s < 2 * MT; ++s) XD[s] = *reinterpret_cast<const u32x4*>(dp + s * 32);
+#pragma unroll
+        for (int s = 0; s < 2 * NTB; ++s) XH[s] = (s * 32 + 32 <= brow) ? *reinterpret_cast<const u32x4*>(bp + s * 32) : (u32x4){0, 0, 0, 0};
+        u32x4 TD[MT][2], TH[NTB][2];
+        transpose_block<MT>(XD, lc, lh, TD, &bsum);
+        transpose_block<NTB>(XH, lc, lh, TH, nullptr);
+        // dW[o][i] += sum_n D^T-form[o][n] * H-form[n][i]: both operands are accumulator-layout tiles
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int c = 0; c < NTB; ++c)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+                    acc[m][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(TD[m][s]), frag(TH[c][s]), acc[m][c], 0, 0, 0);
+    }
+
+    float* slab = a.slab + (int64_t)q * a.slab_stride;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int c = 0; c < NTB; ++c) {
+            const int slot = 32 * c + lc;                      // H column (layer-0 slot or hidden feature)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int o = 32 * m + nca_rho(i) + 4 * lh;
+                float* dst = nullptr;
+                if (job.is_enc) {
+                    if (slot < job.ncols_w) dst = slab + job.out_off + (int64_t)o * job.out_ld + slot;
+                    else if (slot >= NCA_BF_LAT_SLOT && slot < NCA_BF_LAT_SLOT + job.T) dst = slab + job.out_off + (int64_t)o * job.out_ld + job.ncols_w + (slot - NCA_BF_LAT_SLOT);
+                    else if (slot >= NCA_BF_HOT_SLOT && slot < NCA_BF_HOT_SLOT + job.P) dst = slab + job.onehot_off + o * job.P + (slot - NCA_BF_HOT_SLOT);
+                } else if (slot < job.ncols_w) {
+                    dst = slab + job.out_off + (int64_t)o * job.out_ld + slot;
+                }
+                if (dst) *dst = a.accumulate ? *dst + acc[m][c][i] : acc[m][c][i];
+            }
+        }
+        if (job.bias_off >= 0) {
+            // column sums of the transposed D tile = sum over samples; the two lane halves hold disjoint samples
+            const float b = bsum[m] + __shfl_xor(bsum[m], 32);
+            if (lh == 0) {
+                float* dst = slab + job.bias_off + 32 * m + lc;
+                *dst = a.accumulate ? *dst + b : b;
+            }
+        }
+    }
+}
+
+template <int F>
+__global__ __launch_bounds__(64, 1) void nca_wgrad_bf16(const NcaWgradArgs a) {
+    const NcaWgradJob job = a.job[blockIdx.y];
+    if (job.is_enc) wgrad_job<F, 4>(a, job, blockIdx.x, gridDim.x, threadIdx.x);
+    else wgrad_job<F, F / 32>(a, job, blockIdx.x, gridDim.x, threadIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+template <int F>
+static hipError_t launch_fused_bf(const NcaFusedArgs& a, bool bwd, int grid, hipStream_t st) {
+    const size_t lds = 2 * BfCfg<F>::BUF_BYTES + NCA_CONST_BYTES + (bwd ? NCA_WAVES * 2 * (F + 1) * sizeof(float) : 0);
+    if (bwd) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_fused_bf16<F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((nca_fused_bf16<F, true>), dim3(grid), dim3(NCA_NT), lds, st, a);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_fused_bf16<F, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((nca_fused_bf16<F, false>), dim3(grid), dim3(NCA_NT), lds, st, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t nca_launch_fused_bf16(int F, const NcaFusedArgs& a, bool bwd, int grid, hipStream_t st) {
+    switch (F) {
+        case 32: return launch_fused_bf<32>(a, bwd, grid, st);
+        case 64: return launch_fused_bf<64>(a, bwd, grid, st);
+        case 128: return launch_fused_bf<128>(a, bwd, grid, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t nca_launch_pack_bf16(const NcaLayout& y, const float* prm, void* out, hipStream_t st) {
+    const int total = (int)(y.packed_bytes / 4u);
+    const int grid = (total + 255) / 256;
+    hipLaunchKernelGGL(nca_pack_bf16, dim3(grid > 1024 ? 1024 : grid), dim3(256), 0, st, y, prm, reinterpret_cast<unsigned*>(out));
+    return hipGetLastError();
+}
+
+hipError_t nca_launch_wgrad_bf16(int F, const NcaWgradArgs& a, int nsplit, hipStream_t st) {
+    switch (F) {
+        case 32: hipLaunchKernelGGL(nca_wgrad_bf16<32>, dim3(nsplit, a.njobs), dim3(64), 0, st, a); break;
+        case 64: hipLaunchKernelGGL(nca_wgrad_bf16<64>, dim3(nsplit, a.njobs), dim3(64), 0, st, a); break;
+        case 128: hipLaunchKernelGGL(nca_wgrad_bf16<128>, dim3(nsplit, a.njobs), dim3(64), 0, st, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}

@@ -136,3 +136,64 @@ inline int nca_build_layout(const NcaNet& n, NcaLayout* out, const char** why) {
     *out = y;
     return NCA_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// bf16 path (v_mfma_f32_32x32x16_bf16): a k-step is 16 features, a wave owns 64 samples (two 32-column
+// tiles).  The encoded input of layer 0 lives in fixed SLOTS so that every register index in the
+// kernel is a compile-time constant:
+//     slot 0..Kenc-1   encoded coordinates in natural order        (Kenc <= 80 with latents, <= 96 without)
+//     slot 80..80+T-1  time latents                                (T <= 16)
+//     slot 96..96+P-1  one-hot phase rows (backward scratch only)  (P <= 16)
+// Hidden layers read the previous accumulator tiles as B operands: k-step 2t+s, element j of lane
+// half h is feature 32t + 16s + 8(j>>2) + 4h + (j&3).
+// ------------------------------------------------------------------------------------------
+#define NCA_BF_K0SLOTS 96      // layer-0 input slots fed to the MFMAs (6 k-steps)
+#define NCA_BF_ENCROWS 112     // slots of the stored input block (adds the one-hot rows)
+#define NCA_BF_LAT_SLOT 80
+#define NCA_BF_HOT_SLOT 96
+
+NCA_HD inline int nca_bf_kidx_hidden(int ks, int h, int j) { return 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3); }
+// natural input index of a layer-0 slot (-1: padding)
+NCA_HD inline int nca_bf_slot_to_nat(const NcaLayout& y, int slot) {
+    if (slot < y.Kenc) return slot;
+    if (slot >= NCA_BF_LAT_SLOT && slot < NCA_BF_LAT_SLOT + y.T) return y.Kenc + (slot - NCA_BF_LAT_SLOT);
+    return -1;
+}
+
+inline int nca_build_layout_bf16(const NcaNet& n, NcaLayout* out, const char** why) {
+    int rc = nca_build_layout(n, out, why);
+    if (rc != NCA_OK) return rc;
+    NcaLayout& y = *out;
+    if (n.n_late > 0) { *why = "bf16 path: skip/late layers are not implemented (use the f32 path)"; return NCA_E_UNSUPPORTED; }
+    if (n.enc_mode == NCA_ENC_FOURIER) { *why = "bf16 path: fourier encoding is not implemented (use the f32 path)"; return NCA_E_UNSUPPORTED; }
+    if (n.T > 16 || y.P > 16) { *why = "bf16 path: num_time_dim and phases must be <= 16"; return NCA_E_UNSUPPORTED; }
+    if (y.Kenc > (n.T > 0 ? NCA_BF_LAT_SLOT : NCA_BF_K0SLOTS)) { *why = "bf16 path: encoded input too wide (pos_enc_basis <= 12 with latents, <= 15 without)"; return NCA_E_UNSUPPORTED; }
+    uint32_t boff = 0, maxb = 0;
+    const uint32_t tail = nca_img_tail_bytes(y.MT);
+    for (int j = 0; j < y.NL; ++j) {
+        NcaLayerL& l = y.layer[j];
+        l.ksteps = (j == 0) ? NCA_BF_K0SLOTS / 16 : y.F / 16;
+        l.ksteps_enc = (j == 0) ? l.ksteps : 0;
+        l.img_off = boff;
+        l.img_bytes = (uint32_t)y.MT * (uint32_t)l.ksteps * 1024u + tail + (j == y.NL - 1 ? tail + 16u : 0u);
+        boff += (l.img_bytes + 1023u) & ~1023u;
+        if (l.img_bytes > maxb) maxb = l.img_bytes;
+    }
+    for (int j = 0; j < y.NL; ++j) {
+        NcaLayerL& l = y.layer[j];
+        if (j == 0) { l.imgT_off = 0; l.imgT_bytes = 0; continue; }
+        l.imgT_off = boff;
+        l.imgT_bytes = (uint32_t)y.MT * (uint32_t)(y.F / 16) * 1024u;
+        boff += l.imgT_bytes;
+        if (l.imgT_bytes > maxb) maxb = l.imgT_bytes;
+    }
+    y.packed_bytes = boff;
+    y.max_img_bytes = maxb;
+    return NCA_OK;
+}
+
+// bytes of one 32-sample tile of the bf16 backward scratch for this net:
+//   [input block 32 x 112][inputs of layers 1..NL-1: 32 x F each][output gradients D_0..D_{NL-1}: 32 x F each]
+NCA_HD inline int64_t nca_bf_tile_bytes(const NcaLayout& y) {
+    return 32 * (int64_t)NCA_BF_ENCROWS * 2 + (int64_t)(2 * y.NL - 1) * 32 * y.F * 2;
+}

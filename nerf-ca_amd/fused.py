@@ -23,6 +23,20 @@ _ACT = {"softplus": _capi.ACT_SOFTPLUS, "clamp": _capi.ACT_CLAMP}  # anything el
 # upper bound on the backward workspace (layer inputs + output gradients of one ray chunk)
 BWD_WORKSPACE_BYTES = 6 << 30
 
+_PREC = {"f32": _capi.PREC_F32, "fp32": _capi.PREC_F32, "bf16": _capi.PREC_BF16}
+
+
+def set_precision(prec: str, *models) -> None:
+    """Select the arithmetic of the MLP contractions for the given drop-in models: ``"f32"`` (parity
+    mode: f32 MFMA, 1e-5 vs the reference) or ``"bf16"`` (throughput mode: bf16 MFMA operands, f32
+    accumulation and f32 master weights; PSNR-gated, not 1e-5-gated)."""
+    code = _PREC[prec]
+    for m in models:
+        b = m._binding
+        if b.prec != code:
+            b.prec = code
+            b.packed = None
+
 
 def act_code(name: str) -> int:
     return _ACT.get(name, _capi.ACT_SIGMOID)

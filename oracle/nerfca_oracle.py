@@ -52,6 +52,7 @@ class NetSpec:
     fourier_coefficients: Optional[Tensor] = None  # gaussian * sigma, shape [C * L]
     num_time_dim: int = 0  # 0 -> static net (CPPN); >0 -> dynamic net (Temporal)
     num_phases: int = 10  # Temporal.py:25 fixed_frame_ids = arange(0, 10)
+    emulate_bf16: bool = False  # NOT reference behaviour: round where the bf16 HIP path rounds (see _q)
 
     @property
     def enc_features(self) -> int:
@@ -182,8 +183,24 @@ def encode(x: Tensor, spec: NetSpec, window: Optional[Tensor]) -> Tensor:
 # --------------------------------------------------------------------------------------
 
 
+def _q(x: Tensor) -> Tensor:
+    """Straight-through bf16 rounding (value rounded, gradient passed through)."""
+    return x + (x.to(torch.bfloat16).to(x.dtype) - x).detach()
+
+
 def mlp(params: Dict[str, Tensor], spec: NetSpec, feats: Tensor) -> Tensor:
-    """Shared body of CPPN.forward (CPPN.py:98-110) and Temporal.query_time (Temporal.py:125-134)."""
+    """Shared body of CPPN.forward (CPPN.py:98-110) and Temporal.query_time (Temporal.py:125-134).
+
+    With ``spec.emulate_bf16`` (used only to test the bf16 HIP kernels) the MFMA operands are rounded
+    to bf16 exactly where the kernel rounds them: layer inputs (encoded features, ReLU outputs) and
+    weights of the F-wide layers; biases, accumulation and the F->1 output layer stay f32."""
+    if spec.emulate_bf16:
+        if spec.num_late_layers > 0:
+            raise NotImplementedError
+        h = feats
+        for i in range(spec.num_early_layers + 1):
+            h = torch.relu(TF.linear(_q(h), _q(params[f"early_pts_layers.{2 * i}.weight"]), params[f"early_pts_layers.{2 * i}.bias"]))
+        return TF.linear(h, params["output_linear.0.weight"], params["output_linear.0.bias"])
     h = feats
     for i in range(spec.num_early_layers + 1):
         h = torch.relu(TF.linear(h, params[f"early_pts_layers.{2 * i}.weight"], params[f"early_pts_layers.{2 * i}.bias"]))

@@ -255,3 +255,110 @@ def test_backward_is_linear_in_upstream_gradient(dev):
         ((pix * cp).sum() + (a * cs).sum() * 50 + (b * cd).sum() * 50).backward()
         flat.append(torch.cat([p.grad.flatten() for p in list(s.parameters()) + list(t.parameters())]).double().cpu())
     assert rel_err(flat[2], flat[0] + flat[1]) < 2e-6
+
+
+# ------------------------------------------------------------------------------------------
+# bf16 throughput mode: bf16 MFMA operands, f32 accumulate, f32 master weights.  It is NOT a 1e-5 mode
+# (PSNR-gated).  To test the KERNELS rather than the quantisation, the oracle is run with
+# emulate_bf16=True: it rounds (straight-through) exactly what the kernel rounds in the forward -- layer
+# inputs and weights of the F-wide layers.  What remains un-emulated is the bf16 rounding of the
+# back-propagated deltas (2^-9 relative, random) and the f32 (not f64) sin/cos recurrence, so:
+#   outputs  <= 2e-3 of max-norm (measured ~1.5e-4),  gradients <= 5e-2 (measured 2e-3 .. 2e-2).
+# A structural error (wrong k order, transposed tile, lost bias) shows up as O(1).
+# ------------------------------------------------------------------------------------------
+BF_OUT, BF_GRAD = 2e-3, 5e-2
+
+
+@pytest.mark.parametrize("F,early", [(32, 0), (32, 4), (64, 4), (128, 0), (128, 4)])
+def test_bf16_points_vs_emulating_oracle(golden, dev, F, early):
+    from nerfca_amd import set_precision
+    g = golden("mlps")
+    tag = f"F{F}_e{early}_l0"
+    ps, pd = g.prefixed(f"s_{tag}_p_"), g.prefixed(f"d_{tag}_p_")
+    ss = O.NetSpec(num_filters=F, num_early_layers=early, emulate_bf16=True)
+    sd = O.NetSpec(num_filters=F, num_early_layers=early, num_time_dim=8, emulate_bf16=True)
+    win = O.freq_mask_alpha(12, 60000, 150000, 1)[0]
+    pso = {k: v.clone().requires_grad_(True) for k, v in ps.items()}
+    pdo = {k: v.clone().requires_grad_(True) for k, v in pd.items()}
+    ys_o = O.static_forward(pso, ss, g["x"], win)
+    yd_o = O.dynamic_forward(pdo, sd, g["x"], g["ts"], win)
+    ((ys_o + yd_o) * g["gout"]).sum().backward()
+    s = make_static(ps, dev, F=F, early=early, late=0)
+    t = make_dynamic(pd, dev, F=F, early=early, late=0, T=8)
+    set_precision("bf16", s, t)
+    for m in (s, t):
+        m.update_freq_mask_alpha(60000, 150000)
+    x = g["x"].to(dev)
+    ys, yd = s(x), t.forward_composite(x, g["ts"].to(dev))
+    assert rel_err(ys.cpu(), ys_o) < BF_OUT and rel_err(yd.cpu(), yd_o) < BF_OUT
+    # and the quantised result stays close to the reference's f32 result
+    assert rel_err(ys.cpu(), g[f"s_{tag}_y"]) < 3e-2 and rel_err(yd.cpu(), g[f"d_{tag}_y"]) < 3e-2
+    ((ys + yd) * g["gout"].to(dev)).sum().backward()
+    gs, gd = grads_of(s), grads_of(t)
+    for k in pso:
+        assert rel_err(gs[k], pso[k].grad) < BF_GRAD, ("static", k)
+    for k in pdo:
+        assert rel_err(gd[k], pdo[k].grad) < BF_GRAD, ("dynamic", k)
+
+
+def _oracle_render_grads_bf16(ps, ss, pd, sd, win, o, d, ph, I0, z, cp, cs, cd):
+    import dataclasses
+    return _oracle_render_grads(ps, dataclasses.replace(ss, emulate_bf16=True), pd, dataclasses.replace(sd, emulate_bf16=True),
+                                win, o, d, ph, I0, z, cp, cs, cd, torch.float32)
+
+
+@pytest.mark.parametrize("R,S,F", [(8, 16, 32), (33, 50, 64), (64, 192, 128), (7, 500, 128)])
+def test_bf16_render_vs_emulating_oracle(dev, R, S, F):
+    from nerfca_amd import render_rays, set_precision
+    gen = torch.Generator().manual_seed(4321 + R + S)
+    ss = O.NetSpec(num_filters=F, num_early_layers=3, num_time_dim=0)
+    sd = O.NetSpec(num_filters=F, num_early_layers=3, num_time_dim=8)
+    ps, pd = O.init_params(ss, gen), O.init_params(sd, gen)
+    win = O.freq_mask_alpha(12, 75000, 150000, 1)[0]
+    o = (torch.rand(R, 3, generator=gen) * 0.2 + torch.tensor([3.0, -2.0, 2.5])).double()
+    d = (torch.rand(R, 3, generator=gen) - 0.5).double()
+    d = d / d.norm(dim=-1, keepdim=True) * 1.001
+    ph = torch.randint(0, 10, (R,), generator=gen)
+    z = O.stratified_depths(O.depth_values(3.4259, 5.5741, S), torch.rand(S, generator=gen))
+    I0 = torch.full((R,), 2.15991)
+    cp, cs, cd = torch.randn(R, generator=gen).double(), torch.randn(R, S, generator=gen), torch.randn(R, S, generator=gen)
+    pix, a, b, dists, pse, pde = _oracle_render_grads_bf16(ps, ss, pd, sd, win, o, d, ph, I0, z, cp, cs, cd)
+    s = make_static(ps, dev, F=F, early=3, late=0)
+    t = make_dynamic(pd, dev, F=F, early=3, late=0, T=8)
+    set_precision("bf16", s, t)
+    s.update_freq_mask_alpha(75000, 150000)
+    t.update_freq_mask_alpha(75000, 150000)
+    pix2, a2, b2 = render_rays(s, t, o.to(dev), d.to(dev), ph.to(dev), I0.to(dev), z.to(dev), dists.to(dev))
+    assert pix2.dtype == torch.float64 and tuple(a2.shape) == (R, S)
+    assert rel_err(a2.cpu(), a) < BF_OUT and rel_err(b2.cpu(), b) < BF_OUT
+    assert rel_err((I0.double() - pix2.cpu()), (I0.double() - pix)) < BF_OUT          # the ray sums themselves
+    ((pix2 * cp.to(dev)).sum() + (a2 * cs.to(dev)).sum() * 50 + (b2 * cd.to(dev)).sum() * 50).backward()
+    for name, got, pe in (("static", grads_of(s), pse), ("dynamic", grads_of(t), pde)):
+        for k in pe:
+            assert rel_err(got[k], pe[k].grad) < BF_GRAD, (name, k)
+
+
+def test_bf16_backward_is_deterministic(dev):
+    from nerfca_amd import render_rays, set_precision
+    gen = torch.Generator().manual_seed(5)
+    ss, sd = O.NetSpec(num_filters=128), O.NetSpec(num_filters=128, num_time_dim=8)
+    s = make_static(O.init_params(ss, gen), dev, F=128, early=4, late=0)
+    t = make_dynamic(O.init_params(sd, gen), dev, F=128, early=4, late=0, T=8)
+    set_precision("bf16", s, t)
+    for m in (s, t):
+        m.update_freq_mask_alpha(75000, 150000)
+    R, S = 300, 192
+    o = (torch.rand(R, 3, generator=gen) + 2).double().to(dev)
+    d = (torch.rand(R, 3, generator=gen) - 0.5).double().to(dev)
+    ph = torch.randint(0, 10, (R,), generator=gen).to(dev)
+    z = O.depth_values(3.4, 5.6, S).to(dev)
+    dists = O.ray_dists(z.cpu(), torch.float64).to(dev)
+    I0 = torch.full((R,), 2.0, device=dev)
+    outs = []
+    for _ in range(2):
+        for m in (s, t):
+            m.zero_grad()
+        pix, a, b = render_rays(s, t, o, d, ph, I0, z, dists)
+        (pix.sum() + a.sum() + 2 * b.sum()).backward()
+        outs.append(torch.cat([p.grad.flatten() for p in list(s.parameters()) + list(t.parameters())]).clone())
+    assert torch.equal(outs[0], outs[1])
