@@ -307,7 +307,9 @@ static int plan_bwd(const NcaLayout* lays, int nnets, int32_t prec, int64_t unit
     p->tiles_per_unit = tiles_per_unit;
     const int F = lays[0].F;
     // f32 wgrad: 256-thread workgroups, two per CU.  bf16 wgrad: one wave per (job, split), four per CU.
-    int nsplit = ((bf ? 4 : 2) * cus + p->njobs - 1) / p->njobs;
+    // all (split, job) blocks must be co-resident in ONE round: floor, never ceil (6 stragglers of 1030
+    // blocks on 1024 slots double the kernel time)
+    int nsplit = ((bf ? 4 : 2) * cus) / p->njobs;
     if (nsplit < 1) nsplit = 1;
     const int64_t slab_bytes = align_up((int64_t)nsplit * p->slab_stride * 4, 256);
     const int64_t oslab_bytes = align_up((int64_t)cus * 2 * (F + 1) * 4, 256);
@@ -437,6 +439,13 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
 
     a.scratch = scratch;
     a.oslab = oslab;
+    // bf16: keep the ReLU masks of the recomputed layers in LDS when they fit (8 KiB per layer per workgroup)
+    a.mask_layers = 0;
+    if (bf) {
+        int ml = 0;
+        for (int n = 0; n < a.nnets; ++n) if (lays[n].NL - 1 > ml) ml = lays[n].NL - 1;
+        if (ml > 0 && ml <= 6) a.mask_layers = ml;
+    }
     const int F = lays[0].F;
     const int wave_samples = tile_samples(prec);
     int chunk = 0;

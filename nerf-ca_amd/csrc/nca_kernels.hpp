@@ -55,6 +55,8 @@ struct NcaFusedArgs {
     float* oslab;        // [grid][2][F+1] output-layer gradient partials
     int32_t accumulate;  // add to oslab instead of overwriting (ray chunks after the first)
     int32_t nstages;
+    int32_t mask_layers; // bf16 backward: ReLU masks of this many layers per wave are kept in LDS (0: re-read H)
+    int32_t pad0;
     NcaNetArgs net[2];
     NcaStage stage[NCA_MAX_STAGES];
 };

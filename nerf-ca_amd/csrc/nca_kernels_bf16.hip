@@ -152,6 +152,16 @@ __device__ __forceinline__ void stage_publish_b() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 }
+// Backward stages issue exactly NST scratch stores AFTER the weight DMA of the stage.  VMEM operations
+// retire in issue order, so waiting until NST remain outstanding waits for the DMA (and everything
+// older) but not for those stores.  The raw barrier avoids the vmcnt(0) a __syncthreads() would add.
+template <int NST>
+__device__ __forceinline__ void stage_publish_counted(bool stores_issued) {
+    if (stores_issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
 
 // acc0/acc1 += A(row tile image) * B over NKS k-steps; A fragments are read one step ahead
 template <int NKS, int NB>
@@ -178,6 +188,8 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* cst = reinterpret_cast<float*>(smem + 2 * BUF);
     float* osum = reinterpret_cast<float*>(smem + 2 * BUF + NCA_CONST_BYTES);
+    // ReLU masks of the recomputed layers: [wave][layer][lane][16 B] (2 bits per packed bf16 pair)
+    char* const maskbase = smem + 2 * BUF + NCA_CONST_BYTES + NCA_WAVES * 2 * (F + 1) * 4;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
 
@@ -245,6 +257,8 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
             const int phc = ph < 0 ? 0 : (ph >= y.P ? y.P - 1 : ph);
             const float* cnet = cst + net * NCA_CONST_NET_FLOATS;
             char* const nb = BWD ? t32 + na.row0 : nullptr;   // this net's bytes inside a tile (row0 = byte offset)
+            const bool lds_mask = BWD && a.mask_layers >= y.NL - 1;
+            char* const mwave = maskbase + (wave * a.mask_layers) * 1024 + lane * 16;
 
             // ================= encoding, lane = sample ===================================================
             u32x4 B[2][KSMAX];
@@ -282,25 +296,6 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
 #pragma unroll
                 for (int w = 0; w < NCA_BF_K0SLOTS / 2; ++w) fp[w] = pack2(fe[2 * w], fe[2 * w + 1]);
 
-                if (BWD && tvalid) {
-                    // input block row of this sample: 96 slots + 16 one-hot phase slots
-                    char* row = nb + (lane >> 5) * a.rows_total + (lane & 31) * (NCA_BF_ENCROWS * 2);
-#pragma unroll
-                    for (int q = 0; q < NCA_BF_K0SLOTS / 8; ++q) {
-                        u32x4 v = {fp[4 * q], fp[4 * q + 1], fp[4 * q + 2], fp[4 * q + 3]};
-                        *reinterpret_cast<u32x4*>(row + q * 16) = v;
-                    }
-                    unsigned hot[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const unsigned lo = (y.P > 0 && phc == 2 * q) ? 0x3f80u : 0u;
-                        const unsigned hi = (y.P > 0 && phc == 2 * q + 1) ? 0x3f800000u : 0u;
-                        hot[q] = lo | hi;
-                    }
-                    u32x4 h0 = {hot[0], hot[1], hot[2], hot[3]}, h1 = {hot[4], hot[5], hot[6], hot[7]};
-                    *reinterpret_cast<u32x4*>(row + NCA_BF_HOT_SLOT * 2) = h0;
-                    *reinterpret_cast<u32x4*>(row + NCA_BF_HOT_SLOT * 2 + 16) = h1;
-                }
                 // per k-step: words 8s..8s+3 = k-half 0, 8s+4..8s+7 = k-half 1 of MY sample.  One
                 // half-swap per word yields the operand of tile 0 (samples 0..31) and tile 1 (32..63).
 #pragma unroll
@@ -311,6 +306,25 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                         B[0][s][w] = r[0];
                         B[1][s][w] = r[1];
                     }
+                if (BWD && tvalid) {
+                    // input block of both column tiles, fragment-major [k-step][lane][16 B]: the layer-0
+                    // operands as they sit in registers, then one k-step of one-hot phase slots
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        char* blk = nb + c * a.rows_total + lane * 16;
+#pragma unroll
+                        for (int s = 0; s < KS0; ++s) *reinterpret_cast<u32x4*>(blk + s * 1024) = B[c][s];
+                        const int pc = __shfl(phc, 32 * c + lr);          // phase of sample 32c + r
+                        u32x4 hot;
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            const unsigned lo = (y.P > 0 && pc == 8 * lh + 2 * w) ? 0x3f80u : 0u;
+                            const unsigned hi = (y.P > 0 && pc == 8 * lh + 2 * w + 1) ? 0x3f800000u : 0u;
+                            hot[w] = lo | hi;
+                        }
+                        *reinterpret_cast<u32x4*>(blk + KS0 * 1024) = hot;
+                    }
+                }
             }
 
             // ================= layers (forward / recompute) ===============================================
@@ -326,6 +340,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                 const bool store_h = BWD && tvalid && !last;
                 char* const hblk = BWD ? nb + EB + jj * HB : nullptr;            // input block of layer jj+1
                 u32x4 Bn[2][2 * MT];
+                unsigned mw[2][2] = {{0u, 0u}, {0u, 0u}};     // mask words: [column tile][row-tile pair]
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
                     f32x16 acc0, acc1;
@@ -352,16 +367,29 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                         Bn[1][2 * m][u] = pack2(acc1[2 * u], acc1[2 * u + 1]);
                         Bn[1][2 * m + 1][u] = pack2(acc1[8 + 2 * u], acc1[8 + 2 * u + 1]);
                     }
-                    if (store_h) {
-                        // rows rho(4q..4q+3) + 4h = 8q + 4h + {0..3}: four consecutive features = 8 bytes
+                    if (BWD && !last) {
+                        // bit k / 16+k of a field: low / high bf16 of packed word k (k = 4*(fragment&1) + u) is > 0.
+                        // ReLU output is >= 0, so "nonzero" is (x + 0x7fff) >> 15 per 16-bit half.
 #pragma unroll
                         for (int c = 0; c < 2; ++c) {
-                            char* rowp = hblk + c * a.rows_total + lr * (F * 2) + (32 * m + 4 * lh) * 2;
+                            unsigned fld = 0u;
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                u32x2 v = {Bn[c][2 * m + (q >> 1)][2 * (q & 1)], Bn[c][2 * m + (q >> 1)][2 * (q & 1) + 1]};
-                                *reinterpret_cast<u32x2*>(rowp + q * 16) = v;
+                            for (int k = 0; k < 8; ++k) {
+                                const unsigned w = Bn[c][2 * m + (k >> 2)][k & 3];
+                                fld |= (((w + 0x7fff7fffu) >> 15) & 0x00010001u) << k;
                             }
+                            mw[c][m >> 1] |= fld << (8 * (m & 1));
+                        }
+                    }
+                    if (store_h) {
+                        // the next layer's B-operand fragments exactly as they sit in registers: 1 KiB per
+                        // wave instruction, [k-step][lane][16 B] (feature order inside a tile is the
+                        // accumulator->operand order; the wgrad un-permutes when it writes dW)
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            char* fp2 = hblk + c * a.rows_total + lane * 16;
+                            *reinterpret_cast<u32x4*>(fp2 + (2 * m) * 1024) = Bn[c][2 * m];
+                            *reinterpret_cast<u32x4*>(fp2 + (2 * m + 1) * 1024) = Bn[c][2 * m + 1];
                         }
                     }
                 }
@@ -369,6 +397,10 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
                     for (int k = 0; k < 2 * MT; ++k) B[c][k] = Bn[c][k];
+                if (lds_mask && !last) {
+                    u32x4 mv = {mw[0][0], mw[0][1], mw[1][0], mw[1][1]};
+                    *reinterpret_cast<u32x4*>(mwave + jj * 1024) = mv;
+                }
 
                 if (last) {
                     const float* wo = tail + 2 * MT * 16;
@@ -446,12 +478,9 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                                 Bn[c][2 * m + 1][u] = pack2(dv[8 + 2 * u], dv[8 + 2 * u + 1]);
                             }
                             if (tvalid) {
-                                char* rowp = dblk + c * a.rows_total + lr * (F * 2) + (32 * m + 4 * lh) * 2;
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) {
-                                    u32x2 w2 = {Bn[c][2 * m + (q >> 1)][2 * (q & 1)], Bn[c][2 * m + (q >> 1)][2 * (q & 1) + 1]};
-                                    *reinterpret_cast<u32x2*>(rowp + q * 16) = w2;
-                                }
+                                char* fp2 = dblk + c * a.rows_total + lane * 16;
+                                *reinterpret_cast<u32x4*>(fp2 + (2 * m) * 1024) = Bn[c][2 * m];
+                                *reinterpret_cast<u32x4*>(fp2 + (2 * m + 1) * 1024) = Bn[c][2 * m + 1];
                             }
                         }
                     }
@@ -464,7 +493,8 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                         for (int k = 0; k < 2 * MT; ++k) B[c][k] = Bn[c][k];
                 }
 
-                stage_publish_b();
+                if (BWD) stage_publish_counted<4 * MT>(tvalid);     // H stores (or D_{NL-1} stores on the last layer)
+                else stage_publish_b();
                 cur ^= 1;
                 si = nsi;
             }
@@ -478,6 +508,8 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                     const char* const hblk = nb + EB + (jj - 1) * HB;                       // input of layer jj (mask)
                     char* const dblk = nb + EB + (y.NL - 1) * HB + (jj - 1) * HB;           // D_{jj-1}
                     u32x4 Bn[2][2 * MT];
+                    u32x4 mv = {0u, 0u, 0u, 0u};
+                    if (lds_mask) mv = *reinterpret_cast<const u32x4*>(mwave + (jj - 1) * 1024);
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
                         f32x16 acc0, acc1;
@@ -486,22 +518,25 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                         mma_rowtile<KS, KSMAX>(img + m * KS * 1024 + lane * 16, B, acc0, acc1);
 #pragma unroll
                         for (int c = 0; c < 2; ++c) {
-                            const char* hp = hblk + c * a.rows_total + lr * (F * 2) + (32 * m + 4 * lh) * 2;
-                            char* dp = dblk + c * a.rows_total + lr * (F * 2) + (32 * m + 4 * lh) * 2;
+                            const char* hp = hblk + c * a.rows_total + lane * 16;
+                            char* dp = dblk + c * a.rows_total + lane * 16;
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const u32x2 hw = *reinterpret_cast<const u32x2*>(hp + q * 16);   // features 8q+4h .. +3
-                                float dv[4];
+                            for (int s2 = 0; s2 < 2; ++s2) {
+                                // word u of fragment 2m+s2 holds accumulator registers 8 s2 + 2u, +1
+                                u32x4 hw = {0u, 0u, 0u, 0u};
+                                if (!lds_mask) hw = *reinterpret_cast<const u32x4*>(hp + (2 * m + s2) * 1024);
+                                const unsigned fld = mv[2 * c + (m >> 1)] >> (8 * (m & 1));
+                                u32x4 dw;
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    const unsigned bits = (e & 1) ? (hw[e >> 1] >> 16) : (hw[e >> 1] & 0xffffu);
-                                    const float av = c == 0 ? acc0[4 * q + e] : acc1[4 * q + e];
-                                    dv[e] = ((short)bits > 0) ? av : 0.f;
+                                for (int u = 0; u < 4; ++u) {
+                                    const float a0 = c == 0 ? acc0[8 * s2 + 2 * u] : acc1[8 * s2 + 2 * u];
+                                    const float a1 = c == 0 ? acc0[8 * s2 + 2 * u + 1] : acc1[8 * s2 + 2 * u + 1];
+                                    const bool p0 = lds_mask ? ((fld >> (4 * s2 + u)) & 1u) != 0u : (short)(hw[u] & 0xffffu) > 0;
+                                    const bool p1 = lds_mask ? ((fld >> (16 + 4 * s2 + u)) & 1u) != 0u : (short)(hw[u] >> 16) > 0;
+                                    dw[u] = pack2(p0 ? a0 : 0.f, p1 ? a1 : 0.f);
                                 }
-                                const unsigned w0 = pack2(dv[0], dv[1]), w1 = pack2(dv[2], dv[3]);
-                                Bn[c][2 * m + (q >> 1)][2 * (q & 1)] = w0;
-                                Bn[c][2 * m + (q >> 1)][2 * (q & 1) + 1] = w1;
-                                if (tvalid) { u32x2 o2 = {w0, w1}; *reinterpret_cast<u32x2*>(dp + q * 16) = o2; }
+                                Bn[c][2 * m + s2] = dw;
+                                if (tvalid) *reinterpret_cast<u32x4*>(dp + (2 * m + s2) * 1024) = dw;
                             }
                         }
                     }
@@ -509,7 +544,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                     for (int c = 0; c < 2; ++c)
 #pragma unroll
                         for (int k = 0; k < 2 * MT; ++k) B[c][k] = Bn[c][k];
-                    stage_publish_b();
+                    stage_publish_counted<4 * MT>(tvalid);             // D stores
                     cur ^= 1;
                     si = nsi;
                 }
@@ -604,7 +639,7 @@ __device__ __forceinline__ void wgrad_job(const NcaWgradArgs& a, const NcaWgradJ
     const int64_t per = (a.ntiles + nsplit - 1) / nsplit;
     const int64_t t0 = (int64_t)q * per, t1 = (t0 + per < a.ntiles) ? t0 + per : a.ntiles;
     const char* base = reinterpret_cast<const char*>(a.scratch);
-    const int drow = F * 2, brow = job.b_row_bytes;
+    const int brow = job.b_row_bytes;
     f32x16 acc[MT][NTB];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -616,15 +651,23 @@ __device__ __forceinline__ void wgrad_job(const NcaWgradArgs& a, const NcaWgradJ
 #pragma unroll
     for (int m = 0; m < MT; ++m) bsum[m] = 0.f;
 
-    for (int64_t t = t0; t < t1; ++t) {
+    // blocks are fragment-major [k-step][lane][16 B]: one coalesced 1 KiB load per fragment.  The next
+    // tile's fragments are requested before this tile's MFMAs so that ~32 KiB per wave stay in flight
+    // (this kernel is HBM-bound: 16 KiB of operands per 48 MFMAs).
+    u32x4 XD[2 * MT], XH[2 * NTB];
+    auto load_tile = [&](int64_t t, u32x4 (&xd)[2 * MT], u32x4 (&xh)[2 * NTB]) {
         const char* tb = base + t * a.rows_total;            // rows_total = bytes per 32-sample tile
-        const char* dp = tb + job.d_row0 + lc * drow + lh * 16;
-        const char* bp = tb + job.b_row0 + lc * brow + lh * 16;
-        u32x4 XD[2 * MT], XH[2 * NTB];
+        const char* dp = tb + job.d_row0 + lane * 16;
+        const char* bp = tb + job.b_row0 + lane * 16;
 #pragma unroll
-        for (int s = 0; s < 2 * MT; ++s) XD[s] = *reinterpret_cast<const u32x4*>(dp + s * 32);
+        for (int s = 0; s < 2 * MT; ++s) xd[s] = *reinterpret_cast<const u32x4*>(dp + s * 1024);
 #pragma unroll
-        for (int s = 0; s < 2 * NTB; ++s) XH[s] = (s * 32 + 32 <= brow) ? *reinterpret_cast<const u32x4*>(bp + s * 32) : (u32x4){0, 0, 0, 0};
+        for (int s = 0; s < 2 * NTB; ++s) xh[s] = (s * 32 + 32 <= brow) ? *reinterpret_cast<const u32x4*>(bp + s * 1024) : (u32x4){0, 0, 0, 0};
+    };
+    if (t0 < t1) load_tile(t0, XD, XH);
+    for (int64_t t = t0; t < t1; ++t) {
+        u32x4 ND[2 * MT], NH[2 * NTB];
+        if (t + 1 < t1) load_tile(t + 1, ND, NH);
         u32x4 TD[MT][2], TH[NTB][2];
         transpose_block<MT>(XD, lc, lh, TD, &bsum);
         transpose_block<NTB>(XH, lc, lh, TH, nullptr);
@@ -636,17 +679,26 @@ __device__ __forceinline__ void wgrad_job(const NcaWgradArgs& a, const NcaWgradJ
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
                     acc[m][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(TD[m][s]), frag(TH[c][s]), acc[m][c], 0, 0, 0);
+        if (t + 1 < t1) {
+#pragma unroll
+            for (int s = 0; s < 2 * MT; ++s) XD[s] = ND[s];
+#pragma unroll
+            for (int s = 0; s < 2 * NTB; ++s) XH[s] = NH[s];
+        }
     }
 
+    // Hidden blocks hold features in accumulator->operand order: position c = 16s+8a+4b+e of a 32-wide
+    // tile is feature 16s+8b+4a+e (bits 3 and 2 swapped).  The input block is in natural slot order.
+    auto unperm = [](int c) { return (c & 0x13) | ((c & 8) >> 1) | ((c & 4) << 1); };
     float* slab = a.slab + (int64_t)q * a.slab_stride;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
 #pragma unroll
         for (int c = 0; c < NTB; ++c) {
-            const int slot = 32 * c + lc;                      // H column (layer-0 slot or hidden feature)
+            const int slot = job.is_enc ? 32 * c + lc : 32 * c + unperm(lc);      // H column (layer-0 slot or hidden feature)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int o = 32 * m + nca_rho(i) + 4 * lh;
+                const int o = 32 * m + unperm(nca_rho(i) + 4 * lh);
                 float* dst = nullptr;
                 if (job.is_enc) {
                     if (slot < job.ncols_w) dst = slab + job.out_off + (int64_t)o * job.out_ld + slot;
@@ -662,7 +714,7 @@ __device__ __forceinline__ void wgrad_job(const NcaWgradArgs& a, const NcaWgradJ
             // column sums of the transposed D tile = sum over samples; the two lane halves hold disjoint samples
             const float b = bsum[m] + __shfl_xor(bsum[m], 32);
             if (lh == 0) {
-                float* dst = slab + job.bias_off + 32 * m + lc;
+                float* dst = slab + job.bias_off + 32 * m + unperm(lc);
                 *dst = a.accumulate ? *dst + b : b;
             }
         }
@@ -681,7 +733,7 @@ __global__ __launch_bounds__(64, 1) void nca_wgrad_bf16(const NcaWgradArgs a) {
 // ------------------------------------------------------------------------------------------
 template <int F>
 static hipError_t launch_fused_bf(const NcaFusedArgs& a, bool bwd, int grid, hipStream_t st) {
-    const size_t lds = 2 * BfCfg<F>::BUF_BYTES + NCA_CONST_BYTES + (bwd ? NCA_WAVES * 2 * (F + 1) * sizeof(float) : 0);
+    const size_t lds = 2 * BfCfg<F>::BUF_BYTES + NCA_CONST_BYTES + (bwd ? NCA_WAVES * 2 * (F + 1) * sizeof(float) + (size_t)NCA_WAVES * a.mask_layers * 1024 : 0);
     if (bwd) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_fused_bf16<F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((nca_fused_bf16<F, true>), dim3(grid), dim3(NCA_NT), lds, st, a);

@@ -658,20 +658,45 @@ __global__ void nca_reduce_f32(const NcaReduceArgs a) {
         return;
     }
     if (le < rn.lat_count) {
-        // time_latents[p][t]: dL = sum_f W0[f][Kenc+t] * sum_q Dsum_q[f][p]
+        // time_latents[p][t] = sum_f W0[f][Kenc+t] * Dsum[f][p]; Dsum was reduced over the splits into
+        // slab 0 by nca_onehot_sum_f32 (launched before this kernel)
         const int pp = (int)(le / rn.T), t = (int)(le % rn.T);
         float s = 0.f;
-        for (int f = 0; f < rn.F; ++f) {
-            float d = 0.f;
-            for (int q = 0; q < a.n_split; ++q) d += a.slab[(int64_t)q * a.slab_stride + rn.onehot_off + f * rn.P + pp];
-            s = fmaf(rn.params[rn.w0_off + f * rn.K0 + rn.Kenc + t], d, s);
-        }
+        for (int f = 0; f < rn.F; ++f)
+            s = fmaf(rn.params[rn.w0_off + f * rn.K0 + rn.Kenc + t], a.slab[rn.onehot_off + f * rn.P + pp], s);
         *out = s;
         return;
     }
-    float s = 0.f;
-    for (int q = 0; q < a.n_split; ++q) s += a.slab[(int64_t)q * a.slab_stride + rn.slab_off + le];
-    *out = s;
+    // four independent partial sums (splits q, q+1, q+2, q+3 mod 4) keep several loads in flight;
+    // the combination order is fixed, so the result is still bit-reproducible
+    float s4[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* sp = a.slab + rn.slab_off + le;
+    int q = 0;
+    for (; q + 4 <= a.n_split; q += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s4[u] += sp[(int64_t)(q + u) * a.slab_stride];
+    }
+    for (; q < a.n_split; ++q) s4[0] += sp[(int64_t)q * a.slab_stride];
+    *out = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+}
+
+// Dsum[f][p] = sum over splits of the one-hot block, written in place into slab 0 (fixed order)
+__global__ void nca_onehot_sum_f32(const NcaReduceArgs a) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int net = 0; net < 2; ++net) {
+        const NcaReduceNet& rn = a.net[net];
+        const int64_t cnt = (int64_t)rn.F * rn.P;
+        if (e >= cnt || !rn.grads) continue;
+        float* p0 = const_cast<float*>(a.slab) + rn.onehot_off + e;
+        float s4[4] = {0.f, 0.f, 0.f, 0.f};
+        int q = 0;
+        for (; q + 4 <= a.n_split; q += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s4[u] += p0[(int64_t)(q + u) * a.slab_stride];
+        }
+        for (; q < a.n_split; ++q) s4[0] += p0[(int64_t)q * a.slab_stride];
+        *p0 = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+    }
 }
 
 // pix[r] = I0[r] - sum_c part[r][c]   (model_helpers.py:82 / 95)
@@ -723,6 +748,9 @@ hipError_t nca_launch_wgrad_f32(const NcaWgradArgs& a, int nsplit, hipStream_t s
 }
 
 hipError_t nca_launch_reduce_f32(const NcaReduceArgs& a, hipStream_t st) {
+    int64_t hot = 0;
+    for (int n = 0; n < 2; ++n) if (a.net[n].grads && (int64_t)a.net[n].F * a.net[n].P > hot) hot = (int64_t)a.net[n].F * a.net[n].P;
+    if (hot > 0) hipLaunchKernelGGL(nca_onehot_sum_f32, dim3((int)((hot + 255) / 256)), dim3(256), 0, st, a);
     const int grid = (int)((a.n_total + 255) / 256);
     hipLaunchKernelGGL(nca_reduce_f32, dim3(grid), dim3(256), 0, st, a);
     return hipGetLastError();
