@@ -38,11 +38,13 @@ def parse():
     ap.add_argument("--rays", type=int, default=65536, help="rays per step per GPU (one full 256^2 detector)")
     ap.add_argument("--det", type=int, default=256)
     ap.add_argument("--samples", type=int, default=192)
-    ap.add_argument("--prec", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--prec", default="bf16", choices=["f32", "bf16"],
+                    help="bf16 = BASELINE configs[1] (bf16 MFMA operands, f32 accumulate/master weights, PSNR-gated); f32 = parity mode")
     ap.add_argument("--cpu-rays", type=int, default=2048, help="rays per step of the CPU baseline sample")
     ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--views", type=int, default=4)
+    ap.add_argument("--torch-losses", action="store_true", help="losses + autograd in torch ops instead of the fused loss kernel")
     return ap.parse_args()
 
 
@@ -119,7 +121,7 @@ def main():
     s, t = CPPN(sdef).to(dev), Temporal(tdef).to(dev)
     nerfca_amd.set_precision(args.prec, s, t)
     cfg = TrainConfig(depth_samples_per_ray_coarse=args.samples, img_sample_size=args.rays * world)
-    tr = CompositeTrainer(cfg, s, t, data, dev, rank=rank, world=world, seed=0)
+    tr = CompositeTrainer(cfg, s, t, data, dev, rank=rank, world=world, seed=0, fused_loss=not args.torch_losses)
 
     def barrier():
         torch.cuda.synchronize()
@@ -147,7 +149,7 @@ def main():
     if rank == 0:
         n_samp = args.rays * args.samples * args.steps               # per GPU over the timed region
         kern = {}
-        for name, flop in (("fwd", FLOP_FWD), ("bwd_dgrad", FLOP_DGRAD), ("bwd_wgrad", FLOP_WGRAD), ("bwd_reduce", 0), ("pack", 0)):
+        for name, flop in (("fwd", FLOP_FWD), ("bwd_dgrad", FLOP_DGRAD), ("bwd_wgrad", FLOP_WGRAD), ("bwd_reduce", 0), ("loss", 0), ("pack", 0)):
             ms, n = _capi.timing_read(name)
             kern[name] = {"ms_total": ms, "launches": n, "avg_ms": ms / n if n else None,
                           "tflops": (flop * n_samp / (ms * 1e-3) / 1e12) if ms > 0 and flop else None}

@@ -101,8 +101,7 @@ int64_t nca_param_count(const NcaNet* net);
 /* Bytes of the MFMA-ordered weight image produced by nca_pack_weights. */
 int64_t nca_packed_bytes(const NcaNet* net, int32_t prec);
 /* Re-order the flat natural parameters into the LDS images the kernels stream
- * (run once per optimiser step).  `window` = per-band weights f32[L] (freq_mask_alpha /
- * windowed_pos_enc, model/CPPN.py:137-159; ones when un-windowed), `fourier` = f32[3L] or NULL. */
+ * (run before every forward: optimisers update the parameters in place). */
 int nca_pack_weights(const NcaNet* net, const float* params, void* packed, int32_t prec, void* stream);
 
 /* ---- ray path: replaces obtain_train_predictions_iter/_static + get_predictions_* +
@@ -140,8 +139,30 @@ int nca_mlp_bwd(const NcaNet* net, int32_t prec, const void* packed, const float
                 const float* params, int64_t N, const float* pts, const int32_t* phase, const float* g_raw /*[N]*/,
                 float* grads, void* work, int64_t work_bytes, void* stream);
 
+/* ---- losses: replaces weighted_MSELoss + compute_losses + the loss assembly and their autograd
+ *      (train/model_helpers.py:189-262, 284-288; train/run_composite.py:276-292) ------------------ */
+typedef struct NcaLoss {
+    int64_t R;               /* rays of this batch (this rank's slice under data parallelism)          */
+    int32_t S;
+    int32_t use_weighting;   /* entro_use_weighting                                                     */
+    double skew;             /* skewness_val                                                            */
+    double mask_thre;        /* entro_mask_thre                                                         */
+    double weighted_thresh;  /* entro_weighted_thresh                                                   */
+    double w_favor, w_dent, w_occl, w_l1;  /* this step's weights (linear_param_decay, run_composite.py:276-279) */
+    double inv_R;            /* 1 / GLOBAL ray count: mean-type terms are sums over local rays times this */
+} NcaLoss;
+enum { NCA_T_LOSS = 0, NCA_T_PIXEL, NCA_T_BLENDW, NCA_T_SIG_S_MAX, NCA_T_SIG_D_MAX, NCA_T_FAVOR, NCA_T_S_ENTROPY, NCA_T_S_SUM,
+       NCA_T_D_ENTROPY, NCA_T_D_SUM, NCA_T_OCCL, NCA_T_L1, NCA_T_L2, NCA_T_COUNT };
+int64_t nca_loss_workspace(int64_t R);
+/* terms f64[NCA_T_COUNT]; gradients g_pix f64[R], g_sig_s/g_sig_d f32[R,S] (all three NULL = values only).
+ * pix, gt, wpix are f64[R]; sig_s, sig_d f32[R,S]; dists f64[S]. */
+int nca_loss_fwd_bwd(const NcaLoss* desc, const double* pix, const double* gt, const double* wpix,
+                     const float* sig_s, const float* sig_d, const double* dists,
+                     double* terms, double* g_pix, float* g_sig_s, float* g_sig_d,
+                     void* work, int64_t work_bytes, void* stream);
+
 /* ---- in-library kernel timing (HIP events on the launch stream), used by bench.py -------- */
-enum { NCA_K_PACK = 0, NCA_K_FWD = 1, NCA_K_BWD_DGRAD = 2, NCA_K_BWD_WGRAD = 3, NCA_K_BWD_REDUCE = 4, NCA_K_COUNT = 5 };
+enum { NCA_K_PACK = 0, NCA_K_FWD = 1, NCA_K_BWD_DGRAD = 2, NCA_K_BWD_WGRAD = 3, NCA_K_BWD_REDUCE = 4, NCA_K_LOSS = 5, NCA_K_COUNT = 6 };
 int nca_timing_enable(int32_t on);
 /* Synchronises the recorded events and returns accumulated milliseconds and launch count. */
 int nca_timing_read(int32_t kind, double* total_ms, int64_t* launches);

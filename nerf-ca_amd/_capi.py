@@ -15,8 +15,11 @@ LIB_PATH = os.path.join(_HERE, "lib", "libnerfca_hip.so")
 ENC_NONE, ENC_BANDS, ENC_FOURIER = 0, 1, 2
 ACT_SIGMOID, ACT_SOFTPLUS, ACT_CLAMP = 0, 1, 2
 PREC_F32, PREC_BF16 = 0, 1
-K_PACK, K_FWD, K_BWD_DGRAD, K_BWD_WGRAD, K_BWD_REDUCE = 0, 1, 2, 3, 4
-KERNEL_KINDS = {"pack": K_PACK, "fwd": K_FWD, "bwd_dgrad": K_BWD_DGRAD, "bwd_wgrad": K_BWD_WGRAD, "bwd_reduce": K_BWD_REDUCE}
+K_PACK, K_FWD, K_BWD_DGRAD, K_BWD_WGRAD, K_BWD_REDUCE, K_LOSS = 0, 1, 2, 3, 4, 5
+KERNEL_KINDS = {"pack": K_PACK, "fwd": K_FWD, "bwd_dgrad": K_BWD_DGRAD, "bwd_wgrad": K_BWD_WGRAD, "bwd_reduce": K_BWD_REDUCE,
+                "loss": K_LOSS}
+TERM_NAMES = ["loss", "pixel", "blendw", "sigma_s_max", "sigma_d_max", "favor_s", "s_entropy", "s_entropy_sum", "d_entropy",
+              "d_entropy_sum", "d_occl", "s_l1", "s_l2"]
 
 
 class NcaNet(C.Structure):
@@ -31,6 +34,12 @@ class NcaRays(C.Structure):
                 ("z", C.c_void_p), ("z_stride_r", C.c_int64),
                 ("dists", C.c_void_p), ("I0", C.c_void_p),
                 ("act", C.c_int32), ("single_field", C.c_int32), ("scale", C.c_float), ("reserved", C.c_int32)]
+
+
+class NcaLoss(C.Structure):
+    _fields_ = [("R", C.c_int64), ("S", C.c_int32), ("use_weighting", C.c_int32), ("skew", C.c_double), ("mask_thre", C.c_double),
+                ("weighted_thresh", C.c_double), ("w_favor", C.c_double), ("w_dent", C.c_double), ("w_occl", C.c_double),
+                ("w_l1", C.c_double), ("inv_R", C.c_double)]
 
 
 class NcaError(RuntimeError):
@@ -56,6 +65,8 @@ SYMBOLS = {
     "nca_mlp_fwd": (C.c_int, [C.POINTER(NcaNet), _I32, _P, _P, _P, _P, _I64, _P, _P, _P, _P]),
     "nca_mlp_bwd_workspace": (_I64, [C.POINTER(NcaNet), _I32, _I64, _I64]),
     "nca_mlp_bwd": (C.c_int, [C.POINTER(NcaNet), _I32, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _I64, _P]),
+    "nca_loss_workspace": (_I64, [_I64]),
+    "nca_loss_fwd_bwd": (C.c_int, [C.POINTER(NcaLoss), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "nca_timing_enable": (C.c_int, [_I32]),
     "nca_timing_read": (C.c_int, [_I32, C.POINTER(C.c_double), C.POINTER(_I64)]),
     "nca_timing_reset": (C.c_int, []),

@@ -614,3 +614,32 @@ extern "C" int nca_mlp_bwd(const NcaNet* net, int32_t prec, const void* packed, 
     const int ts = tile_samples(prec);
     return run_bwd(a, prec, binds, (N + ts - 1) / ts, 1, gr, work, work_bytes, (hipStream_t)stream);
 }
+
+// ---------------------------------------------------------------------------------- losses
+extern "C" int64_t nca_loss_workspace(int64_t R) {
+    if (R <= 0) return fail(NCA_E_INVALID, "empty ray batch");
+    return align_up(nca_loss_partials_bytes(R), 256);
+}
+
+extern "C" int nca_loss_fwd_bwd(const NcaLoss* d, const double* pix, const double* gt, const double* wpix,
+                                const float* sig_s, const float* sig_d, const double* dists,
+                                double* terms, double* g_pix, float* g_sig_s, float* g_sig_d,
+                                void* work, int64_t work_bytes, void* stream) {
+    if (!d) return fail(NCA_E_INVALID, "loss descriptor is NULL");
+    if (d->R <= 0 || d->S <= 0) return fail(NCA_E_INVALID, "empty ray batch");
+    if (!pix || !gt || !wpix || !sig_s || !sig_d || !dists || !terms) return fail(NCA_E_INVALID, "a loss input pointer is NULL");
+    const bool any = g_pix || g_sig_s || g_sig_d;
+    if (any && !(g_pix && g_sig_s && g_sig_d)) return fail(NCA_E_INVALID, "give all three gradient outputs or none");
+    const int64_t need = nca_loss_workspace(d->R);
+    if (!work || work_bytes < need) return fail(NCA_E_WORKSPACE, "loss workspace %lld < %lld bytes", (long long)work_bytes, (long long)need);
+    NcaLossArgs a;
+    a.R = d->R; a.S = d->S; a.use_weighting = d->use_weighting;
+    a.skew = d->skew; a.mask_thre = d->mask_thre; a.weighted_thresh = d->weighted_thresh;
+    a.w_favor = d->w_favor; a.w_dent = d->w_dent; a.w_occl = d->w_occl; a.w_l1 = d->w_l1; a.inv_R = d->inv_R;
+    a.pix = pix; a.gt = gt; a.wpix = wpix; a.sig_s = sig_s; a.sig_d = sig_d; a.dists = dists;
+    a.terms = terms; a.g_pix = g_pix; a.g_sig_s = g_sig_s; a.g_sig_d = g_sig_d;
+    a.partials = static_cast<double*>(work);
+    Span sp(NCA_K_LOSS, (hipStream_t)stream);
+    HIPCHK(nca_launch_loss(a, (hipStream_t)stream));
+    return NCA_OK;
+}

@@ -104,6 +104,19 @@ struct NcaReduceArgs {
     NcaReduceNet net[2];
 };
 
+struct NcaLossArgs {
+    int64_t R;
+    int32_t S, use_weighting;
+    double skew, mask_thre, weighted_thresh;
+    double w_favor, w_dent, w_occl, w_l1, inv_R;
+    const double* pix; const double* gt; const double* wpix;
+    const float* sig_s; const float* sig_d; const double* dists;
+    double* terms; double* g_pix; float* g_sig_s; float* g_sig_d;
+    double* partials;
+};
+hipError_t nca_launch_loss(const NcaLossArgs& a, hipStream_t st);
+int64_t nca_loss_partials_bytes(int64_t R);
+
 hipError_t nca_launch_pack_f32(const NcaLayout& y, const float* prm, void* out, hipStream_t st);
 hipError_t nca_launch_fused_f32(int F, const NcaFusedArgs& a, bool bwd, int grid, hipStream_t st);
 hipError_t nca_launch_wgrad_f32(const NcaWgradArgs& a, int nsplit, hipStream_t st);

@@ -1,0 +1,194 @@
+// nca_kernels_loss.hip -- pixel loss + D2NeRF-style regularisers of train/model_helpers.py:189-262 and
+// the loss assembly of train/run_composite.py:287-292, forward AND gradient in one pass per ray:
+//
+//   terms[]  = loss, pixel, blendw mean, sigma maxima, favor, static/dynamic ray entropy + ray sums,
+//              occlusion, l1, l2                                  (the reference's 11-tuple + loss)
+//   g_pix[r], g_sig_s[r,s], g_sig_d[r,s] = d loss / d (pix, sigma_s, sigma_d)
+//
+// One wave per ray (a ray's S samples are strided over the 64 lanes); three wave reductions per ray.
+// Arithmetic follows the reference's dtypes: the blend-weight entropy runs in f32 (sigma is f32), every
+// term that touches `dists` runs in f64.  Sums over rays: per-wave values -> per-block partials ->
+// one finishing block, all in fixed order (bit-reproducible, no atomics).
+#include <hip/hip_runtime.h>
+#include "nca_kernels.hpp"
+
+#define LOSS_WAVES 4
+#define LOSS_NT (64 * LOSS_WAVES)
+enum { T_LOSS = 0, T_PIXEL, T_BLENDW, T_SMAX, T_DMAX, T_FAVOR, T_SENT, T_SSUM, T_DENT, T_DSUM, T_OCCL, T_L1, T_L2, T_COUNT };
+#define NPART 12   // per-block partial sums (maxima handled separately)
+
+__device__ __forceinline__ double wsum(double v) {
+    v += __shfl_xor(v, 32); v += __shfl_xor(v, 16); v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+    return v;
+}
+__device__ __forceinline__ float wmax(float v) {
+    v = fmaxf(v, __shfl_xor(v, 32)); v = fmaxf(v, __shfl_xor(v, 16)); v = fmaxf(v, __shfl_xor(v, 8));
+    v = fmaxf(v, __shfl_xor(v, 4)); v = fmaxf(v, __shfl_xor(v, 2)); v = fmaxf(v, __shfl_xor(v, 1));
+    return v;
+}
+
+__global__ __launch_bounds__(LOSS_NT) void nca_loss_rays(const NcaLossArgs a) {
+    __shared__ double sh[LOSS_WAVES][NPART];
+    __shared__ float shm[LOSS_WAVES][2];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * LOSS_WAVES + wave;
+    double part[NPART];
+#pragma unroll
+    for (int i = 0; i < NPART; ++i) part[i] = 0.0;
+    float mx_s = 0.f, mx_d = 0.f;
+
+    if (r < a.R) {
+        const float* ss = a.sig_s + r * a.S;
+        const float* sd = a.sig_d + r * a.S;
+        const float skew = (float)a.skew;
+        // ---- pass 1: ray sums, favor entropy, l2, maxima -------------------------------------------------
+        double Ms = 0.0, Md = 0.0, l2 = 0.0, fav = 0.0, bwsum = 0.0;
+        for (int s = lane; s < a.S; s += 64) {
+            const float vs = ss[s], vd = sd[s];
+            const double dl = a.dists[s];
+            const double ms = (double)vs * dl, md = (double)vd * dl;
+            Ms += ms; Md += md; l2 += ms * ms;
+            mx_s = fmaxf(mx_s, vs); mx_d = fmaxf(mx_d, vd);
+            // compute_ratio / compute_blendw_loss in f32 (model_helpers.py:189-204)
+            const float bw = vd / (vs + vd + 1e-10f);
+            bwsum += (double)bw;
+            float b = skew == 1.f ? bw : powf(bw, skew);
+            b = fminf(fmaxf(b, 1e-19f), 1.f - 1e-19f);
+            const float rb = fmaxf(1.f - b, 1e-19f);
+            fav += (double)(-(b * logf(b) + rb * logf(rb)));
+        }
+        Ms = wsum(Ms); Md = wsum(Md); l2 = wsum(l2); fav = wsum(fav); bwsum = wsum(bwsum);
+        // ---- pass 2: ray entropies (compute_sigma_s_ray_loss, model_helpers.py:206-224) ------------------
+        const double Mcs = fmax(Ms, 1e-19), Mcd = fmax(Md, 1e-19);
+        double es = 0.0, ed = 0.0, qp = 0.0;
+        for (int s = lane; s < a.S; s += 64) {
+            const double dl = a.dists[s];
+            const double ps = (double)ss[s] * dl / Mcs, pd = (double)sd[s] * dl / Mcd;
+            es += ps * log(ps + 1e-10);
+            const double lg = log(pd + 1e-10);
+            ed += pd * lg;
+            qp += (lg + pd / (pd + 1e-10)) * pd;
+        }
+        es = wsum(es); ed = wsum(ed); qp = wsum(qp);
+        const double wr = a.wpix[r];
+        const int mask_s = Ms < a.mask_thre ? 0 : 1;
+        int mask_d = Md < a.mask_thre ? 0 : 1;
+        if (a.use_weighting && wr > 1.0 + a.weighted_thresh) mask_d = 1;
+        const double diff = a.pix[r] - a.gt[r];
+        // ---- gradients ------------------------------------------------------------------------------------
+        if (a.g_pix && lane == 0) a.g_pix[r] = 2.0 * wr * diff * a.inv_R;
+        if (a.g_sig_s) {
+            float* gs = a.g_sig_s + r * a.S;
+            float* gd = a.g_sig_d + r * a.S;
+            const float fscale = (float)(a.w_favor * a.inv_R / (double)a.S);
+            const double escale = a.w_dent * a.inv_R * (double)mask_d / Mcd;
+            const bool unclipped = Md >= 1e-19;      // d clip(M)/dM
+            for (int s = lane; s < a.S; s += 64) {
+                const float vs = ss[s], vd = sd[s];
+                const double dl = a.dists[s];
+                // favor: F = -(b ln b + rb ln rb), b = clip(bw^skew), rb = clip(1 - b)
+                const float T = vs + vd + 1e-10f;
+                const float bw = vd / T;
+                const float braw = skew == 1.f ? bw : powf(bw, skew);
+                float dFdbw = 0.f;
+                if (braw >= 1e-19f && braw <= 1.f - 1e-19f) {
+                    const float b = braw;
+                    const float rbraw = 1.f - b;
+                    float dF = -(logf(b) + 1.f);
+                    if (rbraw >= 1e-19f) dF += logf(rbraw) + 1.f;
+                    const float dbdbw = skew == 1.f ? 1.f : skew * powf(bw, skew - 1.f);
+                    dFdbw = dF * dbdbw;
+                }
+                const float gf = fscale * dFdbw;
+                const float g_s_f = gf * (-vd / (T * T));
+                const float g_d_f = gf * ((T - vd) / (T * T));
+                // dynamic ray entropy: E = -sum p ln(p+eps); dE/dm_j = (-q_j + [unclipped] sum_s q_s p_s) / M
+                const double pd = (double)vd * dl / Mcd;
+                const double q = log(pd + 1e-10) + pd / (pd + 1e-10);
+                const double g_d_e = escale * dl * (-q + (unclipped ? qp : 0.0));
+                const double g_d_o = a.w_occl * a.inv_R * dl;
+                const double g_s_l = a.w_l1 * (dl + 2.0 * (double)vs * dl * dl);
+                gs[s] = g_s_f + (float)g_s_l;
+                gd[s] = g_d_f + (float)(g_d_e + g_d_o);
+            }
+        }
+        if (lane == 0) {
+            part[0] = wr * diff * diff;                 // pixel (sum over rays; scaled by inv_R at the end)
+            part[1] = bwsum / (double)a.S;              // mean_s blendw
+            part[2] = fav / (double)a.S;                // mean_s entropy
+            part[3] = (double)mask_s * -es;
+            part[4] = Ms;
+            part[5] = (double)mask_d * -ed;
+            part[6] = Md;
+            part[7] = Md;                               // occlusion with the all-ones mask = ray sum
+            part[8] = Ms;                               // l1
+            part[9] = l2;
+        }
+    }
+    mx_s = wmax(mx_s); mx_d = wmax(mx_d);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NPART; ++i) sh[wave][i] = part[i];
+        shm[wave][0] = mx_s; shm[wave][1] = mx_d;
+    }
+    __syncthreads();
+    if (threadIdx.x < NPART) {
+        double s = 0.0;
+        for (int w = 0; w < LOSS_WAVES; ++w) s += sh[w][threadIdx.x];
+        a.partials[(int64_t)blockIdx.x * (NPART + 2) + threadIdx.x] = s;
+    } else if (threadIdx.x < NPART + 2) {
+        const int k = threadIdx.x - NPART;
+        float m = 0.f;
+        for (int w = 0; w < LOSS_WAVES; ++w) m = fmaxf(m, shm[w][k]);
+        a.partials[(int64_t)blockIdx.x * (NPART + 2) + threadIdx.x] = (double)m;
+    }
+}
+
+__global__ __launch_bounds__(256) void nca_loss_finish(const NcaLossArgs a, int nblocks) {
+    __shared__ double sh[256];
+    double res[NPART + 2];
+    for (int k = 0; k < NPART + 2; ++k) {
+        double v = 0.0;
+        for (int b = threadIdx.x; b < nblocks; b += 256) {
+            const double x = a.partials[(int64_t)b * (NPART + 2) + k];
+            v = k < NPART ? v + x : fmax(v, x);
+        }
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (threadIdx.x < st) sh[threadIdx.x] = k < NPART ? sh[threadIdx.x] + sh[threadIdx.x + st] : fmax(sh[threadIdx.x], sh[threadIdx.x + st]);
+            __syncthreads();
+        }
+        res[k] = sh[0];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double iR = a.inv_R;
+        double* t = a.terms;
+        t[T_PIXEL] = res[0] * iR;
+        t[T_BLENDW] = res[1] * iR;
+        t[T_FAVOR] = res[2] * iR;
+        t[T_SENT] = res[3] * iR;
+        t[T_SSUM] = res[4] * iR;
+        t[T_DENT] = res[5] * iR;
+        t[T_DSUM] = res[6] * iR;
+        t[T_OCCL] = res[7] * iR;
+        t[T_L1] = res[8];
+        t[T_L2] = res[9];
+        t[T_SMAX] = res[NPART];
+        t[T_DMAX] = res[NPART + 1];
+        t[T_LOSS] = t[T_PIXEL] + a.w_favor * t[T_FAVOR] + a.w_dent * t[T_DENT] + a.w_occl * t[T_OCCL] + a.w_l1 * t[T_L2] + a.w_l1 * t[T_L1];
+    }
+}
+
+hipError_t nca_launch_loss(const NcaLossArgs& a, hipStream_t st) {
+    const int nblocks = (int)((a.R + LOSS_WAVES - 1) / LOSS_WAVES);
+    hipLaunchKernelGGL(nca_loss_rays, dim3(nblocks), dim3(LOSS_NT), 0, st, a);
+    hipLaunchKernelGGL(nca_loss_finish, dim3(1), dim3(256), 0, st, a, nblocks);
+    return hipGetLastError();
+}
+
+int64_t nca_loss_partials_bytes(int64_t R) {
+    const int64_t nblocks = (R + LOSS_WAVES - 1) / LOSS_WAVES;
+    return nblocks * (NPART + 2) * (int64_t)sizeof(double);
+}

@@ -166,31 +166,57 @@ class _RayBatch:
                        single_field=self.single, scale=self.scale, reserved=0)
 
 
+def render_forward_raw(batch: _RayBatch, bs: FieldBinding, bd: Optional[FieldBinding]):
+    """Fused forward without autograd: returns (pix f64[R], sigma_s, sigma_d | None, keep) where ``keep``
+    pins the packed weights / encoding buffers the matching backward must see."""
+    lib = _capi.lib()
+    dev = batch.o.device
+    packed_s = bs.ensure_packed()
+    packed_d = bd.ensure_packed() if bd is not None else None
+    win_s, four_s = bs.module._enc_buffers()
+    win_d, four_d = bd.module._enc_buffers() if bd is not None else (None, None)
+    R, S = batch.R, batch.S
+    pix = torch.empty(R, dtype=torch.float64, device=dev)
+    sig_s = torch.empty((R, S), dtype=torch.float32, device=dev)
+    sig_d = torch.empty((R, S), dtype=torch.float32, device=dev) if bd is not None else None
+    desc = batch.desc()
+    wbytes = check(lib.nca_render_fwd_workspace(C.byref(desc)))
+    work = torch.empty(wbytes, dtype=torch.uint8, device=dev)
+    check(lib.nca_render_fwd(C.byref(desc), bs.prec,
+                             C.byref(bs.net), ptr(packed_s), ptr(win_s), ptr(four_s),
+                             C.byref(bd.net) if bd is not None else None, ptr(packed_d), ptr(win_d), ptr(four_d),
+                             ptr(bd.flat) if bd is not None else None,
+                             ptr(pix), ptr(sig_s), ptr(sig_d), ptr(work), wbytes, _stream()))
+    return pix, sig_s, sig_d, (packed_s, packed_d, win_s, four_s, win_d, four_d)
+
+
+def render_backward_raw(batch: _RayBatch, bs: FieldBinding, bd: Optional[FieldBinding], keep, g_pix, g_sig_s, g_sig_d):
+    """Fused backward (recompute + dgrad + wgrad + reduce): returns flat f32 gradients per net."""
+    lib = _capi.lib()
+    packed_s, packed_d, win_s, four_s, win_d, four_d = keep
+    dev = batch.o.device
+    gp = torch.zeros(batch.R, dtype=torch.float64, device=dev) if g_pix is None else g_pix.detach().to(torch.float64).contiguous()
+    gs, gd = _f32c(g_sig_s), _f32c(g_sig_d)
+    grads_s = torch.empty(bs.flat.numel(), dtype=torch.float32, device=dev)
+    grads_d = torch.empty(bd.flat.numel(), dtype=torch.float32, device=dev) if bd is not None else None
+    desc = batch.desc()
+    net_d = C.byref(bd.net) if bd is not None else None
+    wbytes = check(lib.nca_render_bwd_workspace(C.byref(desc), C.byref(bs.net), net_d, bs.prec, BWD_WORKSPACE_BYTES))
+    work = torch.empty(wbytes, dtype=torch.uint8, device=dev)
+    check(lib.nca_render_bwd(C.byref(desc), bs.prec,
+                             C.byref(bs.net), ptr(packed_s), ptr(win_s), ptr(four_s), ptr(bs.flat),
+                             net_d, ptr(packed_d), ptr(win_d), ptr(four_d), ptr(bd.flat) if bd is not None else None,
+                             ptr(gp), ptr(gs), ptr(gd), ptr(grads_s), ptr(grads_d), ptr(work), wbytes, _stream()))
+    return grads_s, grads_d
+
+
 class _RenderFn(torch.autograd.Function):
     """pix, sigma_s, sigma_d = fused(rays; params_s, params_d)."""
 
     @staticmethod
     def forward(ctx, batch: _RayBatch, bs: FieldBinding, bd: Optional[FieldBinding], n_s: int, *params):
-        lib = _capi.lib()
-        dev = batch.o.device
-        packed_s = bs.ensure_packed()
-        packed_d = bd.ensure_packed() if bd is not None else None
-        win_s, four_s = bs.module._enc_buffers()
-        win_d, four_d = bd.module._enc_buffers() if bd is not None else (None, None)
-        R, S = batch.R, batch.S
-        pix = torch.empty(R, dtype=torch.float64, device=dev)
-        sig_s = torch.empty((R, S), dtype=torch.float32, device=dev)
-        sig_d = torch.empty((R, S), dtype=torch.float32, device=dev) if bd is not None else None
-        desc = batch.desc()
-        wbytes = check(lib.nca_render_fwd_workspace(C.byref(desc)))
-        work = torch.empty(wbytes, dtype=torch.uint8, device=dev)
-        check(lib.nca_render_fwd(C.byref(desc), bs.prec,
-                                 C.byref(bs.net), ptr(packed_s), ptr(win_s), ptr(four_s),
-                                 C.byref(bd.net) if bd is not None else None, ptr(packed_d), ptr(win_d), ptr(four_d),
-                                 ptr(bd.flat) if bd is not None else None,
-                                 ptr(pix), ptr(sig_s), ptr(sig_d), ptr(work), wbytes, _stream()))
-        ctx.batch, ctx.bs, ctx.bd = batch, bs, bd
-        ctx.keep = (packed_s, packed_d, win_s, four_s, win_d, four_d)
+        pix, sig_s, sig_d, keep = render_forward_raw(batch, bs, bd)
+        ctx.batch, ctx.bs, ctx.bd, ctx.keep = batch, bs, bd, keep
         if not batch.f64:
             pix = pix.to(torch.float32)
         if bd is None:
@@ -199,28 +225,45 @@ class _RenderFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_pix, g_sig_s, g_sig_d=None):
-        lib = _capi.lib()
-        batch, bs, bd = ctx.batch, ctx.bs, ctx.bd
-        packed_s, packed_d, win_s, four_s, win_d, four_d = ctx.keep
-        dev = batch.o.device
-        gp = torch.zeros(batch.R, dtype=torch.float64, device=dev) if g_pix is None else g_pix.detach().to(torch.float64).contiguous()
-        gs, gd = _f32c(g_sig_s), _f32c(g_sig_d)
-        grads_s = torch.empty(bs.flat.numel(), dtype=torch.float32, device=dev)
-        grads_d = torch.empty(bd.flat.numel(), dtype=torch.float32, device=dev) if bd is not None else None
-        desc = batch.desc()
-        net_d = C.byref(bd.net) if bd is not None else None
-        wbytes = check(lib.nca_render_bwd_workspace(C.byref(desc), C.byref(bs.net), net_d, bs.prec, BWD_WORKSPACE_BYTES))
-        work = torch.empty(wbytes, dtype=torch.uint8, device=dev)
-        check(lib.nca_render_bwd(C.byref(desc), bs.prec,
-                                 C.byref(bs.net), ptr(packed_s), ptr(win_s), ptr(four_s), ptr(bs.flat),
-                                 net_d, ptr(packed_d), ptr(win_d), ptr(four_d), ptr(bd.flat) if bd is not None else None,
-                                 ptr(gp), ptr(gs), ptr(gd), ptr(grads_s), ptr(grads_d), ptr(work), wbytes, _stream()))
+        bs, bd = ctx.bs, ctx.bd
+        grads_s, grads_d = render_backward_raw(ctx.batch, bs, bd, ctx.keep, g_pix, g_sig_s, g_sig_d)
         bs.last_grad = grads_s
         out = bs.split_grads(grads_s)
         if bd is not None:
             bd.last_grad = grads_d
             out = out + bd.split_grads(grads_d)
         return (None, None, None, None, *out)
+
+
+def fused_losses(pix, gt, wpix, sig_s, sig_d, dists, run_args, weights, inv_R=None, want_grads=True):
+    """weighted MSE + compute_losses + the loss assembly of run_composite.py:287-292 in one HIP pass.
+
+    ``weights`` = (favor_s_weight, dynamic_entro_weight, occl_weight, l1_weight) of this step.
+    Returns ``(terms f64[13] on device, g_pix f64[R], g_sigma_s f32[R,S], g_sigma_d f32[R,S])``; see
+    ``_capi.TERM_NAMES`` for the order of ``terms``.  ``inv_R`` = 1 / global ray count (default 1/R).
+    """
+    lib = _capi.lib()
+    _require_cuda(sig_s, "sigma")
+    dev = sig_s.device
+    R, S = sig_s.shape
+    f64 = lambda t: t.detach().to(device=dev, dtype=torch.float64).contiguous()
+    pix, gt, wpix, dists = f64(pix), f64(gt), f64(wpix), f64(dists)
+    ss, sd = _f32c(sig_s), _f32c(sig_d)
+    desc = _capi.NcaLoss(R=R, S=S, use_weighting=1 if run_args.entro_use_weighting else 0, skew=float(run_args.skewness_val),
+                         mask_thre=float(run_args.entro_mask_thre), weighted_thresh=float(run_args.entro_weighted_thresh),
+                         w_favor=float(weights[0]), w_dent=float(weights[1]), w_occl=float(weights[2]), w_l1=float(weights[3]),
+                         inv_R=float(inv_R if inv_R is not None else 1.0 / R))
+    terms = torch.empty(len(_capi.TERM_NAMES), dtype=torch.float64, device=dev)
+    g_pix = g_s = g_d = None
+    if want_grads:
+        g_pix = torch.empty(R, dtype=torch.float64, device=dev)
+        g_s = torch.empty((R, S), dtype=torch.float32, device=dev)
+        g_d = torch.empty((R, S), dtype=torch.float32, device=dev)
+    wbytes = check(lib.nca_loss_workspace(R))
+    work = torch.empty(wbytes, dtype=torch.uint8, device=dev)
+    check(lib.nca_loss_fwd_bwd(C.byref(desc), ptr(pix), ptr(gt), ptr(wpix), ptr(ss), ptr(sd), ptr(dists), ptr(terms),
+                               ptr(g_pix), ptr(g_s), ptr(g_d), ptr(work), wbytes, _stream()))
+    return terms, g_pix, g_s, g_d
 
 
 def render_rays(static_model, temp_model, origins, directions, phases, I0, z, dists, act="softplus", single=False, scale=1e-2):

@@ -69,8 +69,13 @@ def make_dataset(n_det: int, S: int, device, views=None, n_phases: int = 10, tea
         torch.manual_seed(teacher_seed)
         sdef, tdef = net_definitions(device, F=F, pos_enc="vanilla")
         ts, tt = CPPN(sdef).to(device), Temporal(tdef).to(device)
-        with torch.no_grad():                       # make the phantom less flat than a default-init net
+        with torch.no_grad():
+            # a default-init net renders an almost constant image; give the phantom contrast in space
+            # (output gains) and over the cardiac phase (latent gain) so that PSNR means something
             tt.time_latents.mul_(2.0)
+            for m, gain, bias in ((ts, 40.0, -1.0), (tt, 60.0, -2.0)):
+                m.output_linear[0].weight.mul_(gain)
+                m.output_linear[0].bias.fill_(bias)
     else:
         ts, tt = teacher
     z = create_depth_values(geo["near_thresh"], geo["far_thresh"], S, device)

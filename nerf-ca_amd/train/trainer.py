@@ -57,9 +57,10 @@ class TrainConfig:
 
 class CompositeTrainer:
     def __init__(self, cfg: TrainConfig, static_model, temp_model, data, device, rank: int = 0, world: int = 1,
-                 seed: int = 0, render: Optional[Callable] = None, fused_adam: Optional[bool] = None):
+                 seed: int = 0, render: Optional[Callable] = None, fused_adam: Optional[bool] = None, fused_loss: bool = False):
         self.cfg, self.s, self.t, self.data, self.device = cfg, static_model, temp_model, data, device
         self.rank, self.world, self.seed = rank, world, seed
+        self.fused_loss = fused_loss and render is None
         self.render = render or MH._fused.render_rays
         self.params = list(temp_model.parameters()) + list(static_model.parameters())   # run_composite.py:192
         kw = {}
@@ -127,6 +128,8 @@ class CompositeTrainer:
         return loss, pixel, terms
 
     def step(self, n_iter: int):
+        if self.fused_loss:
+            return self.step_fused(n_iter)
         self.update_windows(n_iter)
         ids = self.draw_ray_ids(n_iter)
         loss, pixel, terms = self.local_loss(n_iter, ids, self.draw_jitter(n_iter))
@@ -137,6 +140,39 @@ class CompositeTrainer:
         self.opt.step()
         self.sched.step()
         return loss.detach(), pixel.detach(), terms
+
+    def step_fused(self, n_iter: int):
+        """Same step without an autograd graph: fused forward -> fused loss kernel (values + d loss/d(pix,
+        sigma)) -> fused backward -> (all-reduce) -> Adam.  Returns (loss, pixel, terms f64[13]) on device;
+        the entries of ``terms`` are this rank's share of the global value (they sum over ranks)."""
+        from ..fused import _RayBatch, fused_losses, render_backward_raw, render_forward_raw
+        c = self.cfg
+        self.update_windows(n_iter)
+        ids = self.draw_ray_ids(n_iter)
+        R = len(ids)
+        lo, hi = (R * self.rank) // self.world, (R * (self.rank + 1)) // self.world
+        my = torch.as_tensor(ids[lo:hi], device=self.device)
+        rays = self.data.rays_train.index_select(0, my)
+        phases = self.data.phases_train.index_select(0, my)
+        o, d, gt, w = rays[:, 0, :], rays[:, 1, :], rays[:, 2, 0], rays[:, 3, 0]
+        z = MH.randomize_depth(self.depth, self.device, self.draw_jitter(n_iter))
+        dists = MH._interval_lengths(z, d)
+        bs, bd = self.s._binding, self.t._binding
+        batch = _RayBatch(o, d, phases, self.I0[: hi - lo], z, dists, c.output_activation, False, 1e-2)
+        pix, sig_s, sig_d, keep = render_forward_raw(batch, bs, bd)
+        terms, g_pix, g_s, g_d = fused_losses(pix, gt, w, sig_s, sig_d, dists, c, self.loss_weights(n_iter), inv_R=1.0 / R)
+        grads_s, grads_d = render_backward_raw(batch, bs, bd, keep, g_pix, g_s, g_d)
+        if self.world > 1:
+            flat = torch.cat([grads_d, grads_s])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            grads_d, grads_s = flat[: grads_d.numel()], flat[grads_d.numel():]
+        for p, g in zip(self.t.parameters(), bd.split_grads(grads_d)):
+            p.grad = g
+        for p, g in zip(self.s.parameters(), bs.split_grads(grads_s)):
+            p.grad = g
+        self.opt.step()
+        self.sched.step()
+        return terms[0], terms[1], terms
 
     def allreduce_grads(self) -> None:
         """ONE all-reduce(SUM) over a flat f32 buffer of every gradient (152 914 floats by default)."""

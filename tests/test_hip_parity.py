@@ -362,3 +362,98 @@ def test_bf16_backward_is_deterministic(dev):
         (pix.sum() + a.sum() + 2 * b.sum()).backward()
         outs.append(torch.cat([p.grad.flatten() for p in list(s.parameters()) + list(t.parameters())]).clone())
     assert torch.equal(outs[0], outs[1])
+
+
+def _train_psnr(dev, prec, steps, det=32, S=64, R=2048, seed=3):
+    """Short training run on a synthetic phantom; returns held-out-view PSNR (of the MSE)."""
+    import nerfca_amd
+    from nerfca_amd import synthetic
+    from nerfca_amd.model.CPPN import CPPN
+    from nerfca_amd.model.Temporal import Temporal
+    from nerfca_amd.train.trainer import CompositeTrainer, TrainConfig
+    data = _train_psnr.cache.get((det, S))
+    if data is None:
+        data = synthetic.make_dataset(det, S, dev, views=synthetic.TRAIN_VIEWS, n_phases=4, F=64)
+        _train_psnr.cache[(det, S)] = data
+    torch.manual_seed(seed)
+    sdef, tdef = synthetic.net_definitions(dev, F=64)
+    s, t = CPPN(sdef).to(dev), Temporal(tdef).to(dev)
+    nerfca_amd.set_precision(prec, s, t)
+    cfg = TrainConfig(depth_samples_per_ray_coarse=S, img_sample_size=R, static_pos_enc_window_decay_steps=steps,
+                      temp_pos_enc_window_decay_steps=steps, lr_decay_steps=steps)
+    tr = CompositeTrainer(cfg, s, t, data, dev, seed=seed)
+    tr.update_windows(0)
+    p0 = float(tr.evaluate(0)["test_psnr_mse"])
+    for it in range(steps):
+        tr.step(it)
+    return p0, float(tr.evaluate(steps)["test_psnr_mse"])
+
+
+_train_psnr.cache = {}
+
+
+def test_bf16_training_matches_f32_psnr(dev):
+    """The gate for the throughput mode: after equal steps from identical initial weights,
+    batches and jitter, the held-out-view PSNR of bf16 training is within 0.5 dB of f32 training, and both
+    have clearly learned the phantom (>= 8 dB above the untrained nets)."""
+    i32, p32 = _train_psnr(dev, "f32", 400)
+    i16, p16 = _train_psnr(dev, "bf16", 400)
+    print(f"held-out PSNR: untrained {i32:.2f} dB; after 400 steps f32 {p32:.2f} dB, bf16 {p16:.2f} dB")
+    assert p32 - i32 > 8.0 and p16 - i16 > 8.0
+    assert abs(p32 - p16) < 0.5
+
+
+@pytest.mark.parametrize("dtn", ["f64", "f32"])
+def test_fused_loss_kernel_vs_reference(golden, dev, dtn):
+    """nca_loss_fwd_bwd: the reference's 11-tuple, the assembled loss and d loss / d sigma on the golden
+    inputs (which include rays below the entropy mask threshold and weighted pixels)."""
+    from types import SimpleNamespace
+    from nerfca_amd import _capi
+    from nerfca_amd.fused import fused_losses
+    g = golden("losses")
+    args = SimpleNamespace(favor_s_opt=None, skewness_val=1.0, entro_mask_thre=1e-4, entro_use_weighting=True,
+                           entro_weighted_thresh=0.03, occl_reg_perc=0.2)
+    a, b = g[f"{dtn}_sig_s"], g[f"{dtn}_sig_d"]
+    dists, wpix = g[f"{dtn}_dists"], g[f"{dtn}_wpix"]
+    R = a.shape[0]
+    gen = torch.Generator().manual_seed(0)
+    pix, gt = torch.randn(R, generator=gen).double(), torch.randn(R, generator=gen).double()
+    weights = (0.7, 0.9, 0.5, 0.25)
+    # oracle: same assembly as run_composite.py:287-292
+    ao, bo, po = a.clone().requires_grad_(True), b.clone().requires_grad_(True), pix.clone().requires_grad_(True)
+    t = O.compute_losses(ao, bo, dists, wpix, O.LossArgs())
+    pixel = O.weighted_mse(po, gt, wpix.double()).mean()
+    loss = pixel + weights[0] * t[3] + weights[1] * t[6] + weights[2] * t[8] + weights[3] * t[10] + weights[3] * t[9]
+    loss.backward()
+    terms, g_pix, g_s, g_d = fused_losses(pix.to(dev), gt.to(dev), wpix.to(dev), a.to(dev), b.to(dev), dists.to(dev), args, weights)
+    got = dict(zip(_capi.TERM_NAMES, terms.cpu().tolist()))
+    ref = {"loss": loss, "pixel": pixel, "blendw": t[0], "sigma_s_max": t[1], "sigma_d_max": t[2], "favor_s": t[3], "s_entropy": t[4],
+           "s_entropy_sum": t[5], "d_entropy": t[6], "d_entropy_sum": t[7], "d_occl": t[8], "s_l1": t[9], "s_l2": t[10]}
+    for k, v in ref.items():
+        assert abs(got[k] - float(v)) <= 2e-6 * abs(float(v)) + 1e-12, (k, got[k], float(v))
+    assert rel_err(g_pix.cpu(), po.grad) < 1e-9
+    assert rel_err(g_s.cpu(), ao.grad) < TOL and rel_err(g_d.cpu(), bo.grad) < TOL
+
+
+def test_fused_step_equals_autograd_step(dev):
+    """CompositeTrainer.step_fused (no autograd graph) and the autograd step produce the same update."""
+    from nerfca_amd import synthetic
+    from nerfca_amd.model.CPPN import CPPN
+    from nerfca_amd.model.Temporal import Temporal
+    from nerfca_amd.train.trainer import CompositeTrainer, TrainConfig
+    data = synthetic.make_dataset(16, 48, dev, views=synthetic.TRAIN_VIEWS[:2], n_phases=3, F=32)
+    outs = []
+    for fused in (False, True):
+        torch.manual_seed(9)
+        sdef, tdef = synthetic.net_definitions(dev, F=64)
+        s, t = CPPN(sdef).to(dev), Temporal(tdef).to(dev)
+        cfg = TrainConfig(depth_samples_per_ray_coarse=48, img_sample_size=512, favor_s_weight_delay_steps=0,
+                          l1_weight_start=1e-3, l1_weight_end=1e-3, occl_weight_start=1e-2, dynamic_entro_weight_start=1e-3,
+                          favor_s_weight_start=1e-3, entro_mask_thre=1e-6)
+        tr = CompositeTrainer(cfg, s, t, data, dev, seed=5, fused_loss=fused)
+        loss = None
+        for it in range(3):
+            loss = tr.step(1000 + it)[0]
+        outs.append((float(loss), torch.cat([p.detach().flatten() for p in tr.params]).cpu()))
+    assert abs(outs[0][0] - outs[1][0]) <= 1e-6 * abs(outs[0][0])
+    assert rel_err(outs[1][1], outs[0][1]) < 1e-5
