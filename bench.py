@@ -61,6 +61,22 @@ def host_cores() -> int:
     return n
 
 
+def measured_traffic(args, kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01_*_pmc_traffic.json:
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE doubled as the
+    gfx950 guide prescribes).  Only reported for the exact configuration those passes were taken on."""
+    path = os.path.join(ROOT, "profiles", f"r01_{args.prec}_pmc_traffic.json")
+    try:
+        rec = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    cfg = rec.get("config", {})
+    if cfg.get("rays_per_step") != args.rays or cfg.get("samples_per_ray") != args.samples or cfg.get("prec") != args.prec:
+        return None
+    k = rec.get("kernels", {}).get(kernel)
+    return k["hbm_bytes_per_launch"] if k else None
+
+
 def cpu_baseline(args, data, cfg_kwargs):
     """Reference-equivalent CPU path (oracle) on a bounded sample of the same workload."""
     from oracle import nerfca_oracle as O
@@ -102,7 +118,8 @@ def main():
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_pg = world > 1 or os.environ.get("NERFCA_FORCE_PG") == "1"   # the env switch lets a 1-GPU box exercise RCCL
+    if use_pg:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
@@ -122,10 +139,11 @@ def main():
     nerfca_amd.set_precision(args.prec, s, t)
     cfg = TrainConfig(depth_samples_per_ray_coarse=args.samples, img_sample_size=args.rays * world)
     tr = CompositeTrainer(cfg, s, t, data, dev, rank=rank, world=world, seed=0, fused_loss=not args.torch_losses)
+    tr.always_allreduce = use_pg
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_pg:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -141,7 +159,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     _capi.timing_enable(False)
-    if world > 1:
+    if use_pg:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -156,7 +174,7 @@ def main():
         dom = max(("fwd", "bwd_dgrad", "bwd_wgrad"), key=lambda k: kern[k]["ms_total"])
         peak = PEAK_TFLOPS[args.prec]
         roof = {"bound": "mfma", "kernel": dom, "achieved": kern[dom]["tflops"], "peak": peak, "unit": "TFLOP/s",
-                "frac": kern[dom]["tflops"] / peak if kern[dom]["tflops"] else None, "traffic": None,
+                "frac": kern[dom]["tflops"] / peak if kern[dom]["tflops"] else None, "traffic": measured_traffic(args, dom),
                 "avg_launch_ms": kern[dom]["avg_ms"], "launches": kern[dom]["launches"],
                 "kernel_time_share": kern[dom]["ms_total"] / (dt * 1e3), "all_kernels": kern}
         out = {"metric": "training rays/sec (256^2 det, 192 samples/ray)", "value": args.rays * world * args.steps / dt, "unit": "rays/s",
@@ -169,7 +187,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, data, None)
         print(json.dumps(out))
-    if world > 1:
+    if use_pg:
         torch.distributed.destroy_process_group()
 
 

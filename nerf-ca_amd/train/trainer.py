@@ -61,6 +61,8 @@ class CompositeTrainer:
         self.cfg, self.s, self.t, self.data, self.device = cfg, static_model, temp_model, data, device
         self.rank, self.world, self.seed = rank, world, seed
         self.fused_loss = fused_loss and render is None
+        self.always_allreduce = False      # all-reduce even with one rank (exercises the collective path)
+        self._dev_gen = None
         self.render = render or MH._fused.render_rays
         self.params = list(temp_model.parameters()) + list(static_model.parameters())   # run_composite.py:192
         kw = {}
@@ -95,6 +97,25 @@ class CompositeTrainer:
             return ids
         return rng.integers(low=0, high=d.rays_train.shape[0], size=c.img_sample_size)
 
+    def draw_ray_ids_device(self, n_iter: int) -> torch.Tensor:
+        """The same importance sampling (run_composite.py:250-260) drawn ON the GPU with a per-step seeded
+        device generator: identical stream on every rank, no host RNG / shuffle / H2D copy per step.
+        ``choice`` with replacement = uniform integer indices into the id tables; shuffle = randperm."""
+        c, d, dev = self.cfg, self.data, self.device
+        if self._dev_gen is None:
+            self._dev_gen = torch.Generator(device=dev)
+            self._var_dev = torch.as_tensor(d.var_ray_ids, device=dev)
+            self._non_var_dev = torch.as_tensor(d.non_var_ray_ids, device=dev)
+        g = self._dev_gen
+        g.manual_seed(self.seed * 1000003 + n_iter)
+        n = c.img_sample_size
+        if c.var_sample_perc > 0 and len(d.var_ray_ids) > 0:
+            a = self._non_var_dev[torch.randint(len(d.non_var_ray_ids), (n - self.n_var,), generator=g, device=dev)]
+            b = self._var_dev[torch.randint(len(d.var_ray_ids), (self.n_var,), generator=g, device=dev)]
+            ids = torch.cat([a, b])
+            return ids[torch.randperm(n, generator=g, device=dev)]
+        return torch.randint(0, d.rays_train.shape[0], (n,), generator=g, device=dev)
+
     def draw_jitter(self, n_iter: int) -> torch.Tensor:
         g = torch.Generator().manual_seed(self.seed * 1000003 + n_iter)
         return torch.rand(self.depth.shape, generator=g)
@@ -112,7 +133,7 @@ class CompositeTrainer:
         c = self.cfg
         R = len(ids)
         lo, hi = (R * self.rank) // self.world, (R * (self.rank + 1)) // self.world
-        my = torch.as_tensor(ids[lo:hi], device=self.device)
+        my = ids[lo:hi] if torch.is_tensor(ids) else torch.as_tensor(ids[lo:hi], device=self.device)
         rays = self.data.rays_train.index_select(0, my)                  # f64 [r,4,3]  (run_composite.py:262)
         phases = self.data.phases_train.index_select(0, my)
         o, d, gt, w = rays[:, 0, :], rays[:, 1, :], rays[:, 2, 0], rays[:, 3, 0]
@@ -131,11 +152,12 @@ class CompositeTrainer:
         if self.fused_loss:
             return self.step_fused(n_iter)
         self.update_windows(n_iter)
-        ids = self.draw_ray_ids(n_iter)
+        on_gpu = torch.device(self.device).type == "cuda"
+        ids = self.draw_ray_ids_device(n_iter) if on_gpu else self.draw_ray_ids(n_iter)
         loss, pixel, terms = self.local_loss(n_iter, ids, self.draw_jitter(n_iter))
         self.opt.zero_grad(set_to_none=True)
         loss.backward()
-        if self.world > 1:
+        if self.world > 1 or self.always_allreduce:
             self.allreduce_grads()
         self.opt.step()
         self.sched.step()
@@ -148,10 +170,10 @@ class CompositeTrainer:
         from ..fused import _RayBatch, fused_losses, render_backward_raw, render_forward_raw
         c = self.cfg
         self.update_windows(n_iter)
-        ids = self.draw_ray_ids(n_iter)
-        R = len(ids)
+        ids = self.draw_ray_ids_device(n_iter)
+        R = ids.shape[0]
         lo, hi = (R * self.rank) // self.world, (R * (self.rank + 1)) // self.world
-        my = torch.as_tensor(ids[lo:hi], device=self.device)
+        my = ids[lo:hi]
         rays = self.data.rays_train.index_select(0, my)
         phases = self.data.phases_train.index_select(0, my)
         o, d, gt, w = rays[:, 0, :], rays[:, 1, :], rays[:, 2, 0], rays[:, 3, 0]
@@ -162,7 +184,7 @@ class CompositeTrainer:
         pix, sig_s, sig_d, keep = render_forward_raw(batch, bs, bd)
         terms, g_pix, g_s, g_d = fused_losses(pix, gt, w, sig_s, sig_d, dists, c, self.loss_weights(n_iter), inv_R=1.0 / R)
         grads_s, grads_d = render_backward_raw(batch, bs, bd, keep, g_pix, g_s, g_d)
-        if self.world > 1:
+        if self.world > 1 or self.always_allreduce:
             flat = torch.cat([grads_d, grads_s])
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
             grads_d, grads_s = flat[: grads_d.numel()], flat[grads_d.numel():]
