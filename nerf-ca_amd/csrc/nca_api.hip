@@ -185,6 +185,10 @@ static int build_stages(NcaFusedArgs* a, const NetBind* binds, bool bwd) {
         for (int j = 0; j < y.NL; ++j) {
             int rc = add_stage(a, binds[n].packed, y.layer[j].img_off, y.layer[j].img_bytes);
             if (rc) return rc;
+            if (y.layer[j].img2_bytes) {            // second stage of a skip layer
+                rc = add_stage(a, binds[n].packed, y.layer[j].img2_off, y.layer[j].img2_bytes);
+                if (rc) return rc;
+            }
         }
         if (bwd)
             for (int j = y.NL - 1; j >= 1; --j) {

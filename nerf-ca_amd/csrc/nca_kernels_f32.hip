@@ -32,9 +32,29 @@ __global__ void nca_pack_f32(NcaLayout y, const float* __restrict__ prm, float* 
         const uint32_t byte = e * 4u;
         for (int j = 0; j < y.NL; ++j) {
             const NcaLayerL& l = y.layer[j];
+            const bool skip = l.kind == NCA_IN_SKIP;
+            if (skip && byte >= l.img2_off && byte < l.img2_off + l.img2_bytes) {
+                // second stage of a skip layer: hidden-part k-steps, then (last layer) Wo and bo
+                uint32_t q = (byte - l.img2_off) / 4u;
+                const uint32_t wcount = (uint32_t)(l.ksteps - l.ksteps_enc) * 64u * (uint32_t)y.MT;
+                const uint32_t tail = 2u * (uint32_t)y.MT * 16u;
+                if (q < wcount) {
+                    int m = q % y.MT, lane = (q / y.MT) % 64, s = q / (y.MT * 64);
+                    int r = lane & 31, h = lane >> 5;
+                    v = prm[l.w_off + (32 * m + r) * l.K + y.K0 + nca_kidx_hidden(s, h)];
+                } else if (j == y.NL - 1) {
+                    q -= wcount;
+                    if (q < tail) {
+                        int i = q % 16, m = (q / 16) % y.MT, h = q / (16 * y.MT);
+                        v = prm[y.wo_off + 32 * m + nca_rho(i) + 4 * h];
+                    } else if (q == tail) {
+                        v = prm[y.bo_off];
+                    }
+                }
+            }
             if (byte >= l.img_off && byte < l.img_off + l.img_bytes) {
                 uint32_t q = (byte - l.img_off) / 4u;
-                const uint32_t wcount = (uint32_t)l.ksteps * 64u * (uint32_t)y.MT;
+                const uint32_t wcount = (uint32_t)(skip ? l.ksteps_enc : l.ksteps) * 64u * (uint32_t)y.MT;
                 const uint32_t tail = 2u * (uint32_t)y.MT * 16u;
                 if (q < wcount) {
                     int m = q % y.MT, lane = (q / y.MT) % 64, s = q / (y.MT * 64);
@@ -51,7 +71,7 @@ __global__ void nca_pack_f32(NcaLayout y, const float* __restrict__ prm, float* 
                     q -= wcount;
                     int i = q % 16, m = (q / 16) % y.MT, h = q / (16 * y.MT);
                     v = prm[l.b_off + 32 * m + nca_rho(i) + 4 * h];
-                } else if (j == y.NL - 1) {
+                } else if (j == y.NL - 1 && !skip) {
                     q -= wcount + tail;
                     if (q < tail) {
                         int i = q % 16, m = (q / 16) % y.MT, h = q / (16 * y.MT);
@@ -325,10 +345,13 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
                 const NcaLayerL& l = y.layer[jj];
                 // DMA the next image into the other buffer while this layer computes
                 const int nsi = (si + 1 == a.nstages) ? 0 : si + 1;
+                int nsi_final = nsi;
                 stage_issue(a.stage[nsi], smem + (cur ^ 1) * BUF, wave, lane);
                 const float* img = reinterpret_cast<const float*>(smem + cur * BUF);
                 const float* imgl = img + lane * MT;
-                const float* tail = img + l.ksteps * 64 * MT;
+                // bias tail: behind the k-steps of this image (a skip layer's first image holds only its encoded part)
+                const float* tail = img + (l.kind == NCA_IN_SKIP ? l.ksteps_enc : l.ksteps) * 64 * MT;
+                const float* wo_tail = tail + 2 * MT * 16;     // Wo, bo (last layer); re-pointed for skip layers below
 
                 f32x16 acc[MT];
 #pragma unroll
@@ -356,8 +379,19 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
                         for (int pp = lh; pp < y.P; pp += 2) henc[(y.K0 + pp) * 32] = (pp == phc) ? 1.f : 0.f;
                     }
                 }
-                if (l.kind != NCA_IN_ENC) {
-                    hidden_steps<MT>(imgl + l.ksteps_enc * 64 * MT, hprev, acc);
+                if (l.kind == NCA_IN_SKIP) {
+                    // second stage of the skip layer: publish the hidden-part image, prefetch the one after it
+                    stage_publish();
+                    cur ^= 1;
+                    si = nsi;
+                    const int nsi2 = (si + 1 == a.nstages) ? 0 : si + 1;
+                    stage_issue(a.stage[nsi2], smem + (cur ^ 1) * BUF, wave, lane);
+                    const float* img2 = reinterpret_cast<const float*>(smem + cur * BUF);
+                    hidden_steps<MT>(img2 + lane * MT, hprev, acc);
+                    wo_tail = img2 + (l.ksteps - l.ksteps_enc) * 64 * MT;
+                    nsi_final = nsi2;
+                } else if (l.kind != NCA_IN_ENC) {
+                    hidden_steps<MT>(imgl, hprev, acc);
                 }
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
@@ -378,7 +412,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
 
                 if (jj == y.NL - 1) {
                     // output layer F -> 1 from the image tail (model/CPPN.py:108)
-                    const float* wo = tail + 2 * MT * 16;
+                    const float* wo = wo_tail;
                     float part = 0.f;
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
@@ -461,7 +495,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
 
                 stage_publish();
                 cur ^= 1;
-                si = nsi;
+                si = nsi_final;
             }
 
             // ================= backward sweep (dgrad) =======================================

@@ -36,6 +36,8 @@ struct NcaLayerL {
     uint32_t img_bytes;  // incl. bias tail (and Wo/bo tail on the last layer)
     uint32_t imgT_off;   // transposed image for dgrad (hidden part only); 0 bytes on layer 0
     uint32_t imgT_bytes;
+    uint32_t img2_off;   // SKIP layers stream in two stages: `img` = encoded part + bias tail, `img2` = hidden part (+ Wo tail)
+    uint32_t img2_bytes;
 };
 
 struct NcaLayout {
@@ -112,12 +114,23 @@ inline int nca_build_layout(const NcaNet& n, NcaLayout* out, const char** why) {
         if (j == 0) { l.kind = NCA_IN_ENC; l.K = y.K0; l.ksteps_enc = y.enc_steps; l.ksteps = y.enc_steps; }
         else if (n.n_late > 0 && j == 1 + n.n_hidden) { l.kind = NCA_IN_SKIP; l.K = y.K0 + y.F; l.ksteps_enc = y.enc_steps; l.ksteps = y.enc_steps + y.F / 2; }
         else { l.kind = NCA_IN_HID; l.K = y.F; l.ksteps_enc = 0; l.ksteps = y.F / 2; }
-        if (l.ksteps > NCA_MAX_KSTEPS) { *why = "a layer needs more than 64 MFMA k-steps (encoded input too wide for this num_filters)"; return NCA_E_UNSUPPORTED; }
+        if (l.ksteps_enc > NCA_MAX_KSTEPS || l.ksteps - l.ksteps_enc > NCA_MAX_KSTEPS) { *why = "a layer stage needs more than 64 MFMA k-steps (encoded input too wide)"; return NCA_E_UNSUPPORTED; }
         l.w_off = off; off += y.F * l.K;
         l.b_off = off; off += y.F;
+        const uint32_t wo_tail = (j == y.NL - 1) ? nca_img_tail_bytes(y.MT) + 16u : 0u;
         l.img_off = boff;
-        l.img_bytes = nca_img_w_bytes(l.ksteps, y.MT) + nca_img_tail_bytes(y.MT) + (j == y.NL - 1 ? nca_img_tail_bytes(y.MT) + 16u : 0u);
-        boff += (l.img_bytes + 1023u) & ~1023u;   // images are DMA'd to LDS in 1 KiB pieces
+        if (l.kind == NCA_IN_SKIP) {
+            l.img_bytes = nca_img_w_bytes(l.ksteps_enc, y.MT) + nca_img_tail_bytes(y.MT);                 // encoded part + bias
+            boff += (l.img_bytes + 1023u) & ~1023u;
+            l.img2_off = boff;
+            l.img2_bytes = nca_img_w_bytes(l.ksteps - l.ksteps_enc, y.MT) + wo_tail;                       // hidden part (+ Wo, bo)
+            boff += (l.img2_bytes + 1023u) & ~1023u;
+            if (l.img2_bytes > maxb) maxb = l.img2_bytes;
+        } else {
+            l.img_bytes = nca_img_w_bytes(l.ksteps, y.MT) + nca_img_tail_bytes(y.MT) + wo_tail;
+            boff += (l.img_bytes + 1023u) & ~1023u;   // images are DMA'd to LDS in 1 KiB pieces
+            l.img2_off = 0; l.img2_bytes = 0;
+        }
         if (l.img_bytes > maxb) maxb = l.img_bytes;
     }
     for (int j = 0; j < y.NL; ++j) {

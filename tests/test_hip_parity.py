@@ -488,3 +488,19 @@ def test_fine_pass_vs_reference(golden, dev, R, S, dtn):
         # (model_helpers.py:139, 182-185): a 1e-7 change of a coarse sigma moves a fine depth by ~1e-5.
         # That ill-conditioning is the reference's; the fine outputs are therefore held to 2e-3.
         assert rel_err(v.cpu(), ref) < (TOL if n.endswith("_c") else 2e-3), n
+
+
+@pytest.mark.parametrize("F,early", [(F, e) for F in (32, 64, 128) for e in (0, 4)])
+def test_points_static_skip_layers_vs_reference(golden, dev, F, early):
+    """CPPN with num_late_layers=2: the skip layer relu(W [enc, h]) streams as two LDS stages
+    (model/CPPN.py:52-62, 102-106)."""
+    g = golden("mlps")
+    tag = f"F{F}_e{early}_l2"
+    m = make_static(g.prefixed(f"s_{tag}_p_"), dev, F=F, early=early, late=2)
+    m.update_freq_mask_alpha(60000, 150000)
+    y = m(g["x"].to(dev))
+    assert rel_err(y.cpu(), g[f"s_{tag}_y"]) < TOL
+    (y * g["gout"].to(dev)).sum().backward()
+    got = grads_of(m)
+    for k, ref in g.prefixed(f"s_{tag}_g_").items():
+        assert rel_err(got[k], ref) < TOL, k
