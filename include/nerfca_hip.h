@@ -139,6 +139,17 @@ int nca_mlp_bwd(const NcaNet* net, int32_t prec, const void* packed, const float
                 const float* params, int64_t N, const float* pts, const int32_t* phase, const float* g_raw /*[N]*/,
                 float* grads, void* work, int64_t work_bytes, void* stream);
 
+/* ---- stand-alone compositing of raw fields: render_volume_density_composite / render_volume_density
+ *      (train/model_helpers.py:72-97), as the reference's evaluation code calls them
+ *      (train/run_composite.py:361, 407-413).  raw_* f32[R,S]; `single_field`, `act`, `scale` as in NcaRays. */
+int nca_composite_fwd(int64_t R, int32_t S, int32_t act, int32_t single_field, float scale,
+                      const float* raw_s, const float* raw_d, const float* I0, const double* dists,
+                      double* pix, float* sig_s, float* sig_d, void* stream);
+int nca_composite_bwd(int64_t R, int32_t S, int32_t act, int32_t single_field, float scale,
+                      const float* raw_s, const float* raw_d, const double* dists,
+                      const double* g_pix, const float* g_sig_s, const float* g_sig_d,
+                      float* g_raw_s, float* g_raw_d, void* stream);
+
 /* ---- losses: replaces weighted_MSELoss + compute_losses + the loss assembly and their autograd
  *      (train/model_helpers.py:189-262, 284-288; train/run_composite.py:276-292) ------------------ */
 typedef struct NcaLoss {

@@ -647,3 +647,32 @@ extern "C" int nca_loss_fwd_bwd(const NcaLoss* d, const double* pix, const doubl
     HIPCHK(nca_launch_loss(a, (hipStream_t)stream));
     return NCA_OK;
 }
+
+// ---------------------------------------------------------------------------------- stand-alone compositing
+extern "C" int nca_composite_fwd(int64_t R, int32_t S, int32_t act, int32_t single_field, float scale,
+                                 const float* raw_s, const float* raw_d, const float* I0, const double* dists,
+                                 double* pix, float* sig_s, float* sig_d, void* stream) {
+    if (R <= 0 || S <= 0) return fail(NCA_E_INVALID, "empty ray batch");
+    if (act < 0 || act > 2) return fail(NCA_E_INVALID, "unknown activation %d", act);
+    if (!raw_s || !I0 || !dists || !pix || !sig_s || (!single_field && (!raw_d || !sig_d))) return fail(NCA_E_INVALID, "a pointer is NULL");
+    NcaCompositeArgs a{};
+    a.R = R; a.S = S; a.act = act; a.single = single_field; a.scale = scale;
+    a.raw_s = raw_s; a.raw_d = raw_d; a.I0 = I0; a.dists = dists; a.pix = pix; a.sig_s = sig_s; a.sig_d = sig_d;
+    HIPCHK(nca_launch_composite(a, false, (hipStream_t)stream));
+    return NCA_OK;
+}
+
+extern "C" int nca_composite_bwd(int64_t R, int32_t S, int32_t act, int32_t single_field, float scale,
+                                 const float* raw_s, const float* raw_d, const double* dists,
+                                 const double* g_pix, const float* g_sig_s, const float* g_sig_d,
+                                 float* g_raw_s, float* g_raw_d, void* stream) {
+    if (R <= 0 || S <= 0) return fail(NCA_E_INVALID, "empty ray batch");
+    if (act < 0 || act > 2) return fail(NCA_E_INVALID, "unknown activation %d", act);
+    if (!raw_s || !dists || !g_raw_s || (!single_field && (!raw_d || !g_raw_d))) return fail(NCA_E_INVALID, "a pointer is NULL");
+    NcaCompositeArgs a{};
+    a.R = R; a.S = S; a.act = act; a.single = single_field; a.scale = scale;
+    a.raw_s = raw_s; a.raw_d = raw_d; a.dists = dists;
+    a.g_pix = g_pix; a.g_sig_s = g_sig_s; a.g_sig_d = g_sig_d; a.g_raw_s = g_raw_s; a.g_raw_d = g_raw_d;
+    HIPCHK(nca_launch_composite(a, true, (hipStream_t)stream));
+    return NCA_OK;
+}

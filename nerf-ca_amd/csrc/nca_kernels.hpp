@@ -114,6 +114,15 @@ struct NcaLossArgs {
     double* terms; double* g_pix; float* g_sig_s; float* g_sig_d;
     double* partials;
 };
+struct NcaCompositeArgs {
+    int64_t R;
+    int32_t S, act, single;
+    float scale;
+    const float* raw_s; const float* raw_d; const float* I0; const double* dists;
+    double* pix; float* sig_s; float* sig_d;
+    const double* g_pix; const float* g_sig_s; const float* g_sig_d; float* g_raw_s; float* g_raw_d;
+};
+hipError_t nca_launch_composite(const NcaCompositeArgs& a, bool bwd, hipStream_t st);
 hipError_t nca_launch_loss(const NcaLossArgs& a, hipStream_t st);
 int64_t nca_loss_partials_bytes(int64_t R);
 

@@ -192,3 +192,73 @@ int64_t nca_loss_partials_bytes(int64_t R) {
     const int64_t nblocks = (R + LOSS_WAVES - 1) / LOSS_WAVES;
     return nblocks * (NPART + 2) * (int64_t)sizeof(double);
 }
+
+// ------------------------------------------------------------------------------------------
+// stand-alone compositing of raw fields the caller already holds: render_volume_density_composite /
+// render_volume_density (train/model_helpers.py:72-97), one wave per ray, forward and backward
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float cact_fwd(int act, float x) {
+    if (act == NCA_ACT_SIGMOID) return 1.f / (1.f + expf(-x));
+    float sp = x > 20.f ? x : log1pf(expf(x));
+    if (act == NCA_ACT_CLAMP) sp = fminf(fmaxf(sp, 0.f), 1.f);
+    return sp;
+}
+__device__ __forceinline__ float cact_bwd(int act, float x) {
+    if (act == NCA_ACT_SIGMOID) { float s = 1.f / (1.f + expf(-x)); return s * (1.f - s); }
+    float d;
+    if (x > 20.f) d = 1.f; else { float z = expf(x); d = z / (z + 1.f); }
+    if (act == NCA_ACT_CLAMP) {
+        float sp = x > 20.f ? x : log1pf(expf(x));
+        if (!(sp > 0.f && sp < 1.f)) d = 0.f;
+    }
+    return d;
+}
+
+__global__ __launch_bounds__(LOSS_NT) void nca_composite_fwd_k(const NcaCompositeArgs a) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * LOSS_WAVES + wave;
+    if (r >= a.R) return;
+    double acc = 0.0;
+    for (int s = lane; s < a.S; s += 64) {
+        const int64_t n = r * a.S + s;
+        if (a.single) {
+            const float sa = cact_fwd(a.act, a.raw_s[n]);
+            a.sig_s[n] = sa;                                           // un-scaled (model_helpers.py:90)
+            acc += ((double)sa * a.dists[s]) * (double)a.scale;
+        } else {
+            const float ss = __fmul_rn(cact_fwd(a.act, a.raw_s[n]), a.scale);
+            const float sd = __fmul_rn(cact_fwd(a.act, a.raw_d[n]), a.scale);
+            a.sig_s[n] = ss;
+            a.sig_d[n] = sd;
+            acc += (double)__fadd_rn(ss, sd) * a.dists[s];
+        }
+    }
+    acc = wsum(acc);
+    if (lane == 0) a.pix[r] = (double)a.I0[r] - acc;
+}
+
+__global__ __launch_bounds__(256) void nca_composite_bwd_k(const NcaCompositeArgs a) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= a.R * a.S) return;
+    const int64_t r = n / a.S;
+    const int s = (int)(n % a.S);
+    const double gp = (a.g_pix ? a.g_pix[r] : 0.0) * a.dists[s];
+    const double gs = a.g_sig_s ? (double)a.g_sig_s[n] : 0.0;
+    if (a.single) {
+        a.g_raw_s[n] = (float)(gs - gp * (double)a.scale) * cact_bwd(a.act, a.raw_s[n]);
+    } else {
+        const double gd = a.g_sig_d ? (double)a.g_sig_d[n] : 0.0;
+        a.g_raw_s[n] = (float)((gs - gp) * (double)a.scale) * cact_bwd(a.act, a.raw_s[n]);
+        a.g_raw_d[n] = (float)((gd - gp) * (double)a.scale) * cact_bwd(a.act, a.raw_d[n]);
+    }
+}
+
+hipError_t nca_launch_composite(const NcaCompositeArgs& a, bool bwd, hipStream_t st) {
+    if (bwd) {
+        const int64_t n = a.R * a.S;
+        hipLaunchKernelGGL(nca_composite_bwd_k, dim3((int)((n + 255) / 256)), dim3(256), 0, st, a);
+    } else {
+        hipLaunchKernelGGL(nca_composite_fwd_k, dim3((int)((a.R + LOSS_WAVES - 1) / LOSS_WAVES)), dim3(LOSS_NT), 0, st, a);
+    }
+    return hipGetLastError();
+}

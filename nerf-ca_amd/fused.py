@@ -325,3 +325,44 @@ def eval_points(model, pts: torch.Tensor, phase: Optional[torch.Tensor] = None) 
     if phase is not None:
         ph = phase.detach().flatten().to(device=p.device, dtype=torch.int32).contiguous()
     return _PointsFn.apply(binding, p, ph, *binding.params())
+
+
+class _CompositeFn(torch.autograd.Function):
+    """render_volume_density[_composite] on raw fields (model_helpers.py:72-97) as one HIP kernel each way."""
+
+    @staticmethod
+    def forward(ctx, raw_s, raw_d, I0, dists, act: int, single: bool, scale: float, f64_out: bool):
+        lib = _capi.lib()
+        R, S = raw_s.shape
+        dev = raw_s.device
+        rs = _f32c(raw_s)
+        rd = _f32c(raw_d) if raw_d is not None else None
+        pix = torch.empty(R, dtype=torch.float64, device=dev)
+        sig_s = torch.empty((R, S), dtype=torch.float32, device=dev)
+        sig_d = torch.empty((R, S), dtype=torch.float32, device=dev) if not single else None
+        i0 = I0.detach().to(device=dev, dtype=torch.float32).expand(R).contiguous()
+        dd = dists.detach().to(device=dev, dtype=torch.float64).contiguous()
+        check(lib.nca_composite_fwd(R, S, act, 1 if single else 0, scale, ptr(rs), ptr(rd), ptr(i0), ptr(dd), ptr(pix), ptr(sig_s),
+                                    ptr(sig_d), _stream()))
+        ctx.keep = (rs, rd, dd, act, single, scale)
+        if not f64_out:
+            pix = pix.to(torch.float32)
+        return (pix, sig_s) if single else (pix, sig_s, sig_d)
+
+    @staticmethod
+    def backward(ctx, g_pix, g_sig_s, g_sig_d=None):
+        lib = _capi.lib()
+        rs, rd, dd, act, single, scale = ctx.keep
+        R, S = rs.shape
+        gp = g_pix.detach().to(torch.float64).contiguous() if g_pix is not None else None
+        gs, gd = _f32c(g_sig_s), _f32c(g_sig_d)
+        g_rs = torch.empty_like(rs)
+        g_rd = torch.empty_like(rd) if rd is not None else None
+        check(lib.nca_composite_bwd(R, S, act, 1 if single else 0, scale, ptr(rs), ptr(rd), ptr(dd), ptr(gp), ptr(gs), ptr(gd),
+                                    ptr(g_rs), ptr(g_rd), _stream()))
+        return g_rs, g_rd, None, None, None, None, None, None
+
+
+def composite_raw(raw_s, raw_d, I0, dists, act: str, single: bool, scale: float, f64_out: bool):
+    """HIP compositing of raw fields [R,S]; returns (pix, sigma_s[, sigma_d])."""
+    return _CompositeFn.apply(raw_s, raw_d, I0, dists, act_code(act), single, float(scale), f64_out)

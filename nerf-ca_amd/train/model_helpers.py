@@ -70,9 +70,19 @@ def _interval_lengths(depth_values, like):
     return torch.cat((depth_values[..., 1:] - depth_values[..., :-1], tail), dim=-1)
 
 
+def _hip_composable(field, depth_values):
+    """The stand-alone compositing kernels take one depth vector shared by all rays and [R,S,C] fields on the GPU."""
+    return field.is_cuda and field.dim() == 3 and depth_values.dim() == 1
+
+
 def render_volume_density_composite(static_radiance_field, temp_radiance_field, initial_intensities, ray_directions, depth_values,
                                     output_activation="softplus", scale_value=1e-2):
     dists = _interval_lengths(depth_values, ray_directions)
+    if _hip_composable(static_radiance_field, depth_values):
+        f64 = ray_directions.dtype == torch.float64
+        pix, ss, sd = _fused.composite_raw(static_radiance_field[..., -1], temp_radiance_field[..., -1], initial_intensities, dists,
+                                           output_activation, False, scale_value, f64)
+        return pix, ss, sd, dists
     f = get_activation_func(output_activation)
     static_sigma = f(static_radiance_field[..., -1]) * scale_value
     temp_sigma = f(temp_radiance_field[..., -1]) * scale_value
@@ -82,6 +92,10 @@ def render_volume_density_composite(static_radiance_field, temp_radiance_field, 
 
 def render_volume_density(radiance_field, initial_intensities, ray_directions, depth_values, output_activation="softplus", scale_value=1e-2):
     dists = _interval_lengths(depth_values, ray_directions)
+    if _hip_composable(radiance_field, depth_values):
+        f64 = ray_directions.dtype == torch.float64
+        pix, sa = _fused.composite_raw(radiance_field[..., -1], None, initial_intensities, dists, output_activation, True, scale_value, f64)
+        return pix, sa, dists
     sigma_a = get_activation_func(output_activation)(radiance_field[..., -1])
     int_map = initial_intensities - (sigma_a * dists * scale_value).sum(dim=-1)
     return int_map, sigma_a, dists
