@@ -29,6 +29,8 @@ __device__ __forceinline__ unsigned pack2(float lo, float hi) {
 __device__ __forceinline__ float bf_lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
 __device__ __forceinline__ float bf_hi(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
 __device__ __forceinline__ bf16x8 frag(u32x4 x) { return __builtin_bit_cast(bf16x8, x); }
+// scratch blocks are written once and read once by another kernel: stream them past the caches
+__device__ __forceinline__ void store_nt(char* p, u32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p)); }
 __device__ __forceinline__ float relu1(float x) {
     float r;
     asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                     for (int c = 0; c < 2; ++c) {
                         char* blk = nb + c * a.rows_total + lane * 16;
 #pragma unroll
-                        for (int s = 0; s < KS0; ++s) *reinterpret_cast<u32x4*>(blk + s * 1024) = B[c][s];
+                        for (int s = 0; s < KS0; ++s) store_nt(blk + s * 1024, B[c][s]);
                         const int pc = __shfl(phc, 32 * c + lr);          // phase of sample 32c + r
                         u32x4 hot;
 #pragma unroll
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                             const unsigned hi = (y.P > 0 && pc == 8 * lh + 2 * w + 1) ? 0x3f800000u : 0u;
                             hot[w] = lo | hi;
                         }
-                        *reinterpret_cast<u32x4*>(blk + KS0 * 1024) = hot;
+                        store_nt(blk + KS0 * 1024, hot);
                     }
                 }
             }
@@ -388,8 +390,8 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
 #pragma unroll
                         for (int c = 0; c < 2; ++c) {
                             char* fp2 = hblk + c * a.rows_total + lane * 16;
-                            *reinterpret_cast<u32x4*>(fp2 + (2 * m) * 1024) = Bn[c][2 * m];
-                            *reinterpret_cast<u32x4*>(fp2 + (2 * m + 1) * 1024) = Bn[c][2 * m + 1];
+                            store_nt(fp2 + (2 * m) * 1024, Bn[c][2 * m]);
+                            store_nt(fp2 + (2 * m + 1) * 1024, Bn[c][2 * m + 1]);
                         }
                     }
                 }
@@ -479,8 +481,8 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                             }
                             if (tvalid) {
                                 char* fp2 = dblk + c * a.rows_total + lane * 16;
-                                *reinterpret_cast<u32x4*>(fp2 + (2 * m) * 1024) = Bn[c][2 * m];
-                                *reinterpret_cast<u32x4*>(fp2 + (2 * m + 1) * 1024) = Bn[c][2 * m + 1];
+                                store_nt(fp2 + (2 * m) * 1024, Bn[c][2 * m]);
+                                store_nt(fp2 + (2 * m + 1) * 1024, Bn[c][2 * m + 1]);
                             }
                         }
                     }
@@ -536,7 +538,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                                     dw[u] = pack2(p0 ? a0 : 0.f, p1 ? a1 : 0.f);
                                 }
                                 Bn[c][2 * m + s2] = dw;
-                                if (tvalid) *reinterpret_cast<u32x4*>(dp + (2 * m + s2) * 1024) = dw;
+                                if (tvalid) store_nt(dp + (2 * m + s2) * 1024, dw);
                             }
                         }
                     }
@@ -660,9 +662,9 @@ __device__ __forceinline__ void wgrad_job(const NcaWgradArgs& a, const NcaWgradJ
         const char* dp = tb + job.d_row0 + lane * 16;
         const char* bp = tb + job.b_row0 + lane * 16;
 #pragma unroll
-        for (int s = 0; s < 2 * MT; ++s) xd[s] = *reinterpret_cast<const u32x4*>(dp + s * 1024);
+        for (int s = 0; s < 2 * MT; ++s) xd[s] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(dp + s * 1024));
 #pragma unroll
-        for (int s = 0; s < 2 * NTB; ++s) xh[s] = (s * 32 + 32 <= brow) ? *reinterpret_cast<const u32x4*>(bp + s * 1024) : (u32x4){0, 0, 0, 0};
+        for (int s = 0; s < 2 * NTB; ++s) xh[s] = (s * 32 + 32 <= brow) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(bp + s * 1024)) : (u32x4){0, 0, 0, 0};
     };
     if (t0 < t1) load_tile(t0, XD, XH);
     for (int64_t t = t0; t < t1; ++t) {

@@ -17,6 +17,7 @@
 #include "nca_kernels.hpp"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4e __attribute__((ext_vector_type(4)));
 
 #define NCA_HALF_PI_F 1.57079637050628662109375f   // fl32(0.5 * pi), the constant the reference adds
 #define NCA_HALF_PI_D 1.57079632679489661923
@@ -603,8 +604,10 @@ __global__ __launch_bounds__(256) void nca_wgrad_f32(const NcaWgradArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = lrow + 32 * i;
-            pa[i] = r < F ? *reinterpret_cast<const float4*>(at + i * 1024) : make_float4(0, 0, 0, 0);
-            pb[i] = r < brows ? *reinterpret_cast<const float4*>(bt + i * 1024) : make_float4(0, 0, 0, 0);
+            const f32x4e va = r < F ? __builtin_nontemporal_load(reinterpret_cast<const f32x4e*>(at + i * 1024)) : (f32x4e){0.f, 0.f, 0.f, 0.f};
+            const f32x4e vb = r < brows ? __builtin_nontemporal_load(reinterpret_cast<const f32x4e*>(bt + i * 1024)) : (f32x4e){0.f, 0.f, 0.f, 0.f};
+            pa[i] = make_float4(va[0], va[1], va[2], va[3]);
+            pb[i] = make_float4(vb[0], vb[1], vb[2], vb[3]);
         }
     };
     auto commit = [&](int buf) {
