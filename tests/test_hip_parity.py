@@ -529,3 +529,72 @@ def test_standalone_render_helpers_on_gpu(golden, dev, dtn, dt, act):
     single = MH.render_volume_density(g["raw_s"].to(dev), g["I0"].to(dev), dirs, g["z"].to(dev), act)
     for v, n in zip(single, ("pix", "sig", "dists")):
         assert rel_err(v.cpu(), g[f"single_{dtn}_{act}_{n}"]) < TOL, n
+
+
+@pytest.mark.parametrize("fused_loss", [False, True])
+def test_full_training_steps_vs_reference(golden, dev, fused_loss):
+    """End to end against the reference's own trajectory (tests/golden/full_step.npz: 3 steps of
+    run_composite.py's loop body on 64 rays x 48 samples, F=64): loss and pixel loss of every step, all
+    parameter gradients of step 0, and every parameter after 3 Adam + LinearLR steps.  f32 path; losses
+    either through torch autograd on the HIP render or through the fused loss kernel (graph-free)."""
+    from types import SimpleNamespace
+    from nerfca_amd import fused as FZ
+    from nerfca_amd.schedules import linear_param_decay
+    from nerfca_amd.train import model_helpers as MH
+    g = golden("full_step")
+    s = make_static(g.prefixed("init_sp_"), dev, F=64, early=4, late=0)
+    t = make_dynamic(g.prefixed("init_dp_"), dev, F=64, early=4, late=0, T=8)
+    params = list(t.parameters()) + list(s.parameters())                      # run_composite.py:192
+    opt = torch.optim.Adam([{"params": params, "lr": 1e-3}], lr=1e-3)
+    sched = torch.optim.lr_scheduler.LinearLR(opt, start_factor=1, end_factor=0.01, total_iters=150000)
+    args = SimpleNamespace(favor_s_opt=None, skewness_val=1.0, entro_mask_thre=1e-4, entro_use_weighting=True,
+                           entro_weighted_thresh=0.03, occl_reg_perc=0.2)
+    o, d, gt, w = g["o"].to(dev), g["d"].to(dev), g["gt"].to(dev), g["wpix"].to(dev)
+    S = g["z"].shape[0]
+    phs = g["ph"][:, None].repeat(1, S).to(dev)
+    I0, z0 = g["I0"].to(dev), g["z"].to(dev)
+    base = int(g["base_iter"])
+    for k in range(3):
+        n_iter = base + k
+        s.update_freq_mask_alpha(n_iter, 150000)
+        t.update_freq_mask_alpha(n_iter, 150000)
+        fw = linear_param_decay(n_iter, 1e-12, 1e-10, 100000, 40000)
+        ew = linear_param_decay(n_iter, 1e-10, 1e-8, 100000)
+        ow = linear_param_decay(n_iter, 1e-8, 1e-4, 100000, 40000)
+        lw = linear_param_decay(n_iter, 1e-8, 1e-15, 100000)
+        assert np.array_equal(np.array([fw, ew, ow, lw]), g.np(f"step{k}_weights"))
+        opt.zero_grad()
+        if fused_loss:
+            zj = MH.randomize_depth(z0, dev, g[f"step{k}_t_rand"])
+            dists = MH._interval_lengths(zj, d)
+            batch = FZ._RayBatch(o, d, phs, I0, zj, dists, "softplus", False, 1e-2)
+            pix, ss, sd, keep = FZ.render_forward_raw(batch, s._binding, t._binding)
+            terms, g_pix, g_s, g_d = FZ.fused_losses(pix, gt, w, ss, sd, dists, args, (fw, ew, ow, lw))
+            gs_flat, gd_flat = FZ.render_backward_raw(batch, s._binding, t._binding, keep, g_pix, g_s, g_d)
+            for p, gr in zip(s.parameters(), s._binding.split_grads(gs_flat)):
+                p.grad = gr
+            for p, gr in zip(t.parameters(), t._binding.split_grads(gd_flat)):
+                p.grad = gr
+            loss, pixel = terms[0], terms[1]
+        else:
+            res = MH.obtain_train_predictions_iter(s, t, None, None, o, d, phs, I0, z0, "softplus", 32768, 0, dev, t_rand=g[f"step{k}_t_rand"])
+            pix, ss, sd, dists = res[:4]
+            pixel = MH.weighted_MSELoss()(pix, gt, w).mean()
+            L = MH.compute_losses(ss, sd, dists, w, args)
+            loss = pixel + fw * L[3] + ew * L[6] + ow * L[8] + lw * L[10] + lw * L[9]
+            loss.backward()
+        assert rel_err(loss.detach().cpu(), g[f"step{k}_loss"]) < TOL
+        assert rel_err(pixel.detach().cpu(), g[f"step{k}_pixel"]) < TOL
+        if k == 0:
+            gs_, gd_ = grads_of(s), grads_of(t)
+            for name, ref in g.prefixed("step0_sg_").items():
+                assert rel_err(gs_[name], ref) < TOL, ("static", name)
+            for name, ref in g.prefixed("step0_dg_").items():
+                assert rel_err(gd_[name], ref) < TOL, ("dynamic", name)
+        opt.step()
+        sched.step()
+    # Adam divides by sqrt(v): parameters whose gradient is ~0 amplify rounding noise, hence 1e-4 here
+    for name, ref in g.prefixed("final_sp_").items():
+        assert rel_err(s.state_dict()[name].cpu(), ref) < 1e-4, ("static", name)
+    for name, ref in g.prefixed("final_dp_").items():
+        assert rel_err(t.state_dict()[name].cpu(), ref) < 1e-4, ("dynamic", name)
