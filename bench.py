@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--prec", default="bf16", choices=["f32", "bf16"],
                     help="bf16 = BASELINE configs[1] (bf16 MFMA operands, f32 accumulate/master weights, PSNR-gated); f32 = parity mode")
     ap.add_argument("--cpu-rays", type=int, default=2048, help="rays per step of the CPU baseline sample")
-    ap.add_argument("--cpu-steps", type=int, default=5)
+    ap.add_argument("--cpu-steps", type=int, default=5, help="timed CPU steps (plus one warm-up): ~20 s of CPU work at the defaults")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--views", type=int, default=4)
     ap.add_argument("--torch-losses", action="store_true", help="losses + autograd in torch ops instead of the fused loss kernel")

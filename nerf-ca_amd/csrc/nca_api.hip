@@ -398,6 +398,7 @@ static void add_jobs_bf16(NcaWgradArgs* w, const NcaLayout& y, int64_t net_off, 
             g.ncols_w = y.Kenc;
             g.T = y.T;
             g.P = y.P;
+            g.fourier_L = y.enc_mode == NCA_ENC_FOURIER ? y.L : 0;
         } else {
             g.is_enc = 0;
             g.b_row0 = net_off + EB + (int64_t)(j - 1) * HB;

@@ -72,7 +72,8 @@ struct NcaWgradJob {
     int64_t onehot_off;   // slab offset of the [F][P] one-hot block
     int64_t bias_off;     // slab offset of the bias gradient, or -1
     int32_t b_row_bytes;  // bf16 path: bytes of one sample row of the H block (d_row0/b_row0 are BYTE offsets in a tile there)
-    int32_t is_enc, T, pad;
+    int32_t is_enc, T;
+    int32_t fourier_L;    // bf16 input block of a fourier net: slots are (sin_i, cos_i) interleaved; 0 otherwise
 };
 
 struct NcaWgradArgs {

@@ -199,6 +199,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
         const NcaNetArgs& na = a.net[net];
         float* c = cst + net * NCA_CONST_NET_FLOATS;
         if (na.win) for (int i = tid; i < na.lay.L; i += NCA_NT) c[i] = na.win[i];
+        if (na.four) for (int i = tid; i < 3 * na.lay.L; i += NCA_NT) c[NCA_CONST_WIN + i] = na.four[i];
         if (na.lat) for (int i = tid; i < na.lay.P * na.lay.T; i += NCA_NT) c[NCA_CONST_WIN + NCA_CONST_FOUR + i] = na.lat[i];
     }
     if (BWD) for (int i = tid; i < NCA_WAVES * 2 * (F + 1); i += NCA_NT) osum[i] = 0.f;
@@ -268,7 +269,20 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                 float fe[NCA_BF_K0SLOTS];
 #pragma unroll
                 for (int i = 0; i < NCA_BF_K0SLOTS; ++i) fe[i] = 0.f;
-                fe[0] = p[0]; fe[1] = p[1]; fe[2] = p[2];
+                if (y.enc_mode == NCA_ENC_FOURIER) {
+                    // [sin(2 pi x g_i), cos(2 pi x g_i)] interleaved into slots 2i, 2i+1 (model/CPPN.py:115-118)
+#pragma unroll
+                    for (int i = 0; i < NCA_BF_K0SLOTS / 2; ++i) {
+                        if (i < 3 * y.L) {
+                            const int c = i % 3;
+                            const float pc = c == 0 ? p[0] : (c == 1 ? p[1] : p[2]);
+                            const float v = __fmul_rn(__fmul_rn(6.283185482025146484375f, pc), cnet[NCA_CONST_WIN + i]);
+                            sincosf(v, &fe[2 * i], &fe[2 * i + 1]);
+                        }
+                    }
+                } else {
+                    fe[0] = p[0]; fe[1] = p[1]; fe[2] = p[2];
+                }
                 if (y.enc_mode == NCA_ENC_BANDS) {
                     float sn[3], cs[3];
 #pragma unroll
@@ -703,7 +717,7 @@ __device__ __forceinline__ void wgrad_job(const NcaWgradArgs& a, const NcaWgradJ
                 const int o = 32 * m + unperm(nca_rho(i) + 4 * lh);
                 float* dst = nullptr;
                 if (job.is_enc) {
-                    if (slot < job.ncols_w) dst = slab + job.out_off + (int64_t)o * job.out_ld + slot;
+                    if (slot < job.ncols_w) dst = slab + job.out_off + (int64_t)o * job.out_ld + (job.fourier_L ? ((slot & 1) ? 3 * job.fourier_L + (slot >> 1) : (slot >> 1)) : slot);
                     else if (slot >= NCA_BF_LAT_SLOT && slot < NCA_BF_LAT_SLOT + job.T) dst = slab + job.out_off + (int64_t)o * job.out_ld + job.ncols_w + (slot - NCA_BF_LAT_SLOT);
                     else if (slot >= NCA_BF_HOT_SLOT && slot < NCA_BF_HOT_SLOT + job.P) dst = slab + job.onehot_off + o * job.P + (slot - NCA_BF_HOT_SLOT);
                 } else if (slot < job.ncols_w) {

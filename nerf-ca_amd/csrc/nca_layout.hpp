@@ -154,7 +154,8 @@ inline int nca_build_layout(const NcaNet& n, NcaLayout* out, const char** why) {
 // bf16 path (v_mfma_f32_32x32x16_bf16): a k-step is 16 features, a wave owns 64 samples (two 32-column
 // tiles).  The encoded input of layer 0 lives in fixed SLOTS so that every register index in the
 // kernel is a compile-time constant:
-//     slot 0..Kenc-1   encoded coordinates in natural order        (Kenc <= 80 with latents, <= 96 without)
+//     slot 0..Kenc-1   encoded coordinates in natural order        (Kenc <= 80 with latents, <= 96 without;
+//                      fourier: slot 2i = sin_i, 2i+1 = cos_i)
 //     slot 80..80+T-1  time latents                                (T <= 16)
 //     slot 96..96+P-1  one-hot phase rows (backward scratch only)  (P <= 16)
 // Hidden layers read the previous accumulator tiles as B operands: k-step 2t+s, element j of lane
@@ -168,6 +169,7 @@ inline int nca_build_layout(const NcaNet& n, NcaLayout* out, const char** why) {
 NCA_HD inline int nca_bf_kidx_hidden(int ks, int h, int j) { return 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3); }
 // natural input index of a layer-0 slot (-1: padding)
 NCA_HD inline int nca_bf_slot_to_nat(const NcaLayout& y, int slot) {
+    if (y.enc_mode == NCA_ENC_FOURIER && slot < y.Kenc) return (slot & 1) ? 3 * y.L + (slot >> 1) : (slot >> 1);   // (sin_i, cos_i) interleaved
     if (slot < y.Kenc) return slot;
     if (slot >= NCA_BF_LAT_SLOT && slot < NCA_BF_LAT_SLOT + y.T) return y.Kenc + (slot - NCA_BF_LAT_SLOT);
     return -1;
@@ -178,7 +180,6 @@ inline int nca_build_layout_bf16(const NcaNet& n, NcaLayout* out, const char** w
     if (rc != NCA_OK) return rc;
     NcaLayout& y = *out;
     if (n.n_late > 0) { *why = "bf16 path: skip/late layers are not implemented (use the f32 path)"; return NCA_E_UNSUPPORTED; }
-    if (n.enc_mode == NCA_ENC_FOURIER) { *why = "bf16 path: fourier encoding is not implemented (use the f32 path)"; return NCA_E_UNSUPPORTED; }
     if (n.T > 16 || y.P > 16) { *why = "bf16 path: num_time_dim and phases must be <= 16"; return NCA_E_UNSUPPORTED; }
     if (y.Kenc > (n.T > 0 ? NCA_BF_LAT_SLOT : NCA_BF_K0SLOTS)) { *why = "bf16 path: encoded input too wide (pos_enc_basis <= 12 with latents, <= 15 without)"; return NCA_E_UNSUPPORTED; }
     uint32_t boff = 0, maxb = 0;

@@ -598,3 +598,35 @@ def test_full_training_steps_vs_reference(golden, dev, fused_loss):
         assert rel_err(s.state_dict()[name].cpu(), ref) < 1e-4, ("static", name)
     for name, ref in g.prefixed("final_dp_").items():
         assert rel_err(t.state_dict()[name].cpu(), ref) < 1e-4, ("dynamic", name)
+
+
+@pytest.mark.parametrize("enc", ["none", "vanilla", "nerfies_windowed", "fourier"])
+def test_bf16_other_encodings_vs_emulating_oracle(golden, dev, enc):
+    from nerfca_amd import set_precision
+    g = golden("mlps")
+    L = 0 if enc == "none" else 6
+    gauss = g["enc_fourier_gauss"] if enc == "fourier" else None
+    coef = gauss * 3 if enc == "fourier" else None
+    win = O.nerfies_window(L, float(g["enc_nerfies_alpha"])) if enc == "nerfies_windowed" else None
+    ss = O.NetSpec(num_filters=64, num_early_layers=2, pos_enc=enc, pos_enc_basis=L, fourier_coefficients=coef, emulate_bf16=True)
+    sd = O.NetSpec(num_filters=64, num_early_layers=2, pos_enc=enc, pos_enc_basis=L, fourier_coefficients=coef, num_time_dim=4, emulate_bf16=True)
+    ps, pd = g.prefixed(f"enc_{enc}_sp_"), g.prefixed(f"enc_{enc}_dp_")
+    pso = {k: v.clone().requires_grad_(True) for k, v in ps.items()}
+    pdo = {k: v.clone().requires_grad_(True) for k, v in pd.items()}
+    ys_o, yd_o = O.static_forward(pso, ss, g["x"], win), O.dynamic_forward(pdo, sd, g["x"], g["ts"], win)
+    ((ys_o + yd_o) * g["gout"]).sum().backward()
+    s = make_static(ps, dev, F=64, early=2, late=0, pos_enc=enc, L=L, gauss=gauss, sigma=3)
+    t = make_dynamic(pd, dev, F=64, early=2, late=0, pos_enc=enc, L=L, T=4, gauss=gauss, sigma=3)
+    set_precision("bf16", s, t)
+    if enc == "nerfies_windowed":
+        s.update_windowed_alpha(30000, 100000)
+        t.update_windowed_alpha(30000, 100000)
+    x = g["x"].to(dev)
+    ys, yd = s(x), t.forward_composite(x, g["ts"].to(dev))
+    assert rel_err(ys.cpu(), ys_o) < BF_OUT and rel_err(yd.cpu(), yd_o) < BF_OUT
+    ((ys + yd) * g["gout"].to(dev)).sum().backward()
+    gs, gd = grads_of(s), grads_of(t)
+    for k in pso:
+        assert rel_err(gs[k], pso[k].grad) < BF_GRAD, ("static", k)
+    for k in pdo:
+        assert rel_err(gd[k], pdo[k].grad) < BF_GRAD, ("dynamic", k)
