@@ -228,6 +228,8 @@ static void rays_to_args(const NcaRays* r, NcaFusedArgs* a, int32_t prec) {
 }
 
 // ---------------------------------------------------------------------------------- forward
+extern "C" int nca_composite_fwd(int64_t, int32_t, int32_t, int32_t, float, const float*, const float*, const float*, const double*, double*, float*, float*, void*);
+extern "C" int nca_composite_bwd(int64_t, int32_t, int32_t, int32_t, float, const float*, const float*, const double*, const double*, const float*, const float*, float*, float*, void*);
 extern "C" int64_t nca_render_fwd_workspace(const NcaRays* rays) {
     int rc = check_rays(rays);
     if (rc) return rc;
@@ -258,19 +260,38 @@ extern "C" int nca_render_fwd(const NcaRays* rays, int32_t prec,
         if (rc) return rc;
     }
     if (a.net[0].lay.T > 0 && !rays->single_field) return fail(NCA_E_INVALID, "first net of a composite render must be static (T == 0)");
-    if (a.nnets == 2 && a.net[0].lay.F != a.net[1].lay.F) return fail(NCA_E_UNSUPPORTED, "static and dynamic nets must have the same num_filters (%d vs %d)", a.net[0].lay.F, a.net[1].lay.F);
     for (int n = 0; n < a.nnets; ++n)
         if (a.net[n].lay.T > 0 && !rays->phase) return fail(NCA_E_INVALID, "dynamic net needs phase ids");
-    rc = build_stages(&a, binds, false);
-    if (rc) return rc;
     a.ntiles = rays->R * a.nchunk;
     a.ray0 = 0;
-    a.part = static_cast<double*>(work);
-    a.sig_s = sig_s;
-    a.sig_d = sig_d;
     const int64_t ngroups = (a.ntiles + NCA_WAVES - 1) / NCA_WAVES;
     const int grid = (int)(ngroups < num_cus() ? ngroups : num_cus());
     hipStream_t st = (hipStream_t)stream;
+    if (a.nnets == 2 && a.net[0].lay.F != a.net[1].lay.F) {
+        // nets of different width: one fused launch per net writes the raw field into its sigma buffer,
+        // then the stand-alone compositing kernel turns both into sigmas + pix in place
+        float* outs[2] = {sig_s, sig_d};
+        for (int n = 0; n < 2; ++n) {
+            static thread_local NcaFusedArgs one;
+            one = a;
+            one.nnets = 1;
+            one.net[0] = a.net[n];
+            one.raw_only = 1;
+            one.raw_out = outs[n];
+            NetBind b1[2] = {binds[n], {}};
+            rc = build_stages(&one, b1, false);
+            if (rc) return rc;
+            Span sp(NCA_K_FWD, st);
+            if (prec == NCA_PREC_BF16) HIPCHK(nca_launch_fused_bf16(one.net[0].lay.F, one, false, grid, st));
+            else HIPCHK(nca_launch_fused_f32(one.net[0].lay.F, one, false, grid, st));
+        }
+        return nca_composite_fwd(rays->R, rays->S, rays->act, 0, rays->scale, sig_s, sig_d, rays->I0, rays->dists, pix, sig_s, sig_d, stream);
+    }
+    rc = build_stages(&a, binds, false);
+    if (rc) return rc;
+    a.part = static_cast<double*>(work);
+    a.sig_s = sig_s;
+    a.sig_d = sig_d;
     {
         Span sp(NCA_K_FWD, st);
         if (prec == NCA_PREC_BF16) HIPCHK(nca_launch_fused_bf16(a.net[0].lay.F, a, false, grid, st));
@@ -514,6 +535,18 @@ extern "C" int64_t nca_render_bwd_workspace(const NcaRays* rays, const NcaNet* n
     if (nn == 2) { rc = layout_of(net_d, &lays[1], prec); if (rc) return rc; }
     BwdPlan p;
     const int ts = tile_samples(prec);
+    if (nn == 2 && lays[0].F != lays[1].F) {
+        // nets of different width run their backward one after the other in the same region; four [R,S] f32
+        // arrays (raw_s, raw_d, g_raw_s, g_raw_d) sit behind it
+        const int64_t extra = 4 * align_up(rays->R * (int64_t)rays->S * 4, 256);
+        int64_t most = 0;
+        for (int n = 0; n < 2; ++n) {
+            rc = plan_bwd(&lays[n], 1, prec, rays->R, (rays->S + ts - 1) / ts, max_bytes > extra ? max_bytes - extra : 1, &p);
+            if (rc) return rc;
+            if (p.bytes_total > most) most = p.bytes_total;
+        }
+        return most + extra;
+    }
     rc = plan_bwd(lays, nn, prec, rays->R, (rays->S + ts - 1) / ts, max_bytes, &p);
     if (rc) return rc;
     return p.bytes_total;
@@ -540,14 +573,56 @@ extern "C" int nca_render_bwd(const NcaRays* rays, int32_t prec,
         rc = fill_net(binds[n], &a.net[n], prec);
         if (rc) return rc;
     }
-    if (a.nnets == 2 && a.net[0].lay.F != a.net[1].lay.F) return fail(NCA_E_UNSUPPORTED, "static and dynamic nets must have the same num_filters");
     for (int n = 0; n < a.nnets; ++n)
         if (a.net[n].lay.T > 0 && !rays->phase) return fail(NCA_E_INVALID, "dynamic net needs phase ids");
+    float* grads[2] = {grads_s, grads_d};
+    hipStream_t st = (hipStream_t)stream;
+    if (a.nnets == 2 && a.net[0].lay.F != a.net[1].lay.F) {
+        // different widths: recompute both raw fields, push (g_pix, g_sigma) through the compositing chain rule
+        // once, then run each net's backward on its own with the per-sample raw gradient
+        const int64_t arr = align_up(rays->R * (int64_t)rays->S * 4, 256);
+        if (!work || work_bytes < 4 * arr) return fail(NCA_E_WORKSPACE, "backward workspace too small");
+        const int64_t region = work_bytes - 4 * arr;
+        char* tailp = static_cast<char*>(work) + region;
+        float* raw[2] = {reinterpret_cast<float*>(tailp), reinterpret_cast<float*>(tailp + arr)};
+        float* graw[2] = {reinterpret_cast<float*>(tailp + 2 * arr), reinterpret_cast<float*>(tailp + 3 * arr)};
+        a.ntiles = rays->R * a.nchunk;
+        const int64_t ngroups = (a.ntiles + NCA_WAVES - 1) / NCA_WAVES;
+        const int grid = (int)(ngroups < num_cus() ? ngroups : num_cus());
+        for (int n = 0; n < 2; ++n) {
+            static thread_local NcaFusedArgs one;
+            one = a;
+            one.nnets = 1;
+            one.net[0] = a.net[n];
+            one.raw_only = 1;
+            one.raw_out = raw[n];
+            NetBind b1[2] = {binds[n], {}};
+            rc = build_stages(&one, b1, false);
+            if (rc) return rc;
+            Span sp(NCA_K_FWD, st);
+            if (prec == NCA_PREC_BF16) HIPCHK(nca_launch_fused_bf16(one.net[0].lay.F, one, false, grid, st));
+            else HIPCHK(nca_launch_fused_f32(one.net[0].lay.F, one, false, grid, st));
+        }
+        rc = nca_composite_bwd(rays->R, rays->S, rays->act, 0, rays->scale, raw[0], raw[1], rays->dists, g_pix, g_sig_s, g_sig_d,
+                               graw[0], graw[1], stream);
+        if (rc) return rc;
+        for (int n = 0; n < 2; ++n) {
+            static thread_local NcaFusedArgs one;
+            one = a;
+            one.nnets = 1;
+            one.net[0] = a.net[n];
+            one.g_raw = graw[n];
+            NetBind b1[2] = {binds[n], {}};
+            float* g1[2] = {grads[n], nullptr};
+            rc = run_bwd(one, prec, b1, rays->R, a.nchunk, g1, work, region, st);
+            if (rc) return rc;
+        }
+        return NCA_OK;
+    }
     a.g_pix = g_pix;
     a.g_sig_s = g_sig_s;
     a.g_sig_d = g_sig_d;
-    float* grads[2] = {grads_s, grads_d};
-    return run_bwd(a, prec, binds, rays->R, a.nchunk, grads, work, work_bytes, (hipStream_t)stream);
+    return run_bwd(a, prec, binds, rays->R, a.nchunk, grads, work, work_bytes, st);
 }
 
 // ---------------------------------------------------------------------------------- point path

@@ -56,7 +56,8 @@ struct NcaFusedArgs {
     int32_t accumulate;  // add to oslab instead of overwriting (ray chunks after the first)
     int32_t nstages;
     int32_t mask_layers; // bf16 backward: ReLU masks of this many layers per wave are kept in LDS (0: re-read H)
-    int32_t pad0;
+    int32_t raw_only;    // rays mode, forward: write the raw net output to raw_out[n] instead of compositing
+                         // (rays mode, backward: a non-null g_raw replaces the compositing chain rule)
     NcaNetArgs net[2];
     NcaStage stage[NCA_MAX_STAGES];
 };

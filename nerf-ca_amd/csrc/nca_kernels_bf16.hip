@@ -430,7 +430,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                 if (BWD && last) {
                     // ---------- gradient wrt the raw output, output-layer parameter gradients, D_{NL-1} ----------
                     float g;
-                    if (a.mode == NCA_MODE_RAYS) {
+                    if (a.mode == NCA_MODE_RAYS && !a.g_raw) {
                         const float* gs = net == 0 ? a.g_sig_s : a.g_sig_d;
                         const double gsig = gs ? (double)gs[n] : 0.0;
                         const double gp = a.g_pix[ray] * a.dists[smp];
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
 
         // ================= epilogue (lane = sample) =========================================================
         if (!BWD) {
-            if (a.mode == NCA_MODE_RAYS) {
+            if (a.mode == NCA_MODE_RAYS && !a.raw_only) {
                 double term;
                 if (a.single) {
                     const float sa = act_fwd_b(a.act, raw[0]);

@@ -425,7 +425,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
                     if (BWD) {
                         // gradient wrt the raw output of this net
                         float g;
-                        if (a.mode == NCA_MODE_RAYS) {
+                        if (a.mode == NCA_MODE_RAYS && !a.g_raw) {
                             const float* gs = net == 0 ? a.g_sig_s : a.g_sig_d;
                             const double gsig = gs ? (double)gs[n] : 0.0;
                             const double gp = a.g_pix[ray] * a.dists[smp];
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
 
         // ================= epilogue =========================================================
         if (!BWD) {
-            if (a.mode == NCA_MODE_RAYS) {
+            if (a.mode == NCA_MODE_RAYS && !a.raw_only) {
                 // render_volume_density[_composite] (model_helpers.py:72-97)
                 double term;
                 if (a.single) {

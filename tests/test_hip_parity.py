@@ -630,3 +630,38 @@ def test_bf16_other_encodings_vs_emulating_oracle(golden, dev, enc):
         assert rel_err(gs[k], pso[k].grad) < BF_GRAD, ("static", k)
     for k in pdo:
         assert rel_err(gd[k], pdo[k].grad) < BF_GRAD, ("dynamic", k)
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_nets_of_different_width(dev, prec):
+    """static_num_filters != temp_num_filters: per-net fused launches + compositing kernel; outputs and all
+    gradients against the oracle (bf16: the emulating oracle)."""
+    import dataclasses
+    from nerfca_amd import render_rays, set_precision
+    gen = torch.Generator().manual_seed(77)
+    emu = prec == "bf16"
+    ss = O.NetSpec(num_filters=64, num_early_layers=2, num_time_dim=0, emulate_bf16=emu)
+    sd = O.NetSpec(num_filters=128, num_early_layers=3, num_time_dim=8, emulate_bf16=emu)
+    ps, pd = O.init_params(ss, gen), O.init_params(sd, gen)
+    win = O.freq_mask_alpha(12, 75000, 150000, 1)[0]
+    R, S = 21, 80
+    o = (torch.rand(R, 3, generator=gen) * 0.2 + torch.tensor([3.0, -2.0, 2.5])).double()
+    d = (torch.rand(R, 3, generator=gen) - 0.5).double()
+    ph = torch.randint(0, 10, (R,), generator=gen)
+    z = O.stratified_depths(O.depth_values(3.4259, 5.5741, S), torch.rand(S, generator=gen))
+    I0 = torch.full((R,), 2.15991)
+    cp, cs, cd = torch.randn(R, generator=gen).double(), torch.randn(R, S, generator=gen), torch.randn(R, S, generator=gen)
+    pix, a, b, dists, pso, pdo = _oracle_render_grads(ps, ss, pd, sd, win, o, d, ph, I0, z, cp, cs, cd, torch.float32)
+    s = make_static(ps, dev, F=64, early=2, late=0)
+    t = make_dynamic(pd, dev, F=128, early=3, late=0, T=8)
+    set_precision(prec, s, t)
+    s.update_freq_mask_alpha(75000, 150000)
+    t.update_freq_mask_alpha(75000, 150000)
+    pix2, a2, b2 = render_rays(s, t, o.to(dev), d.to(dev), ph.to(dev), I0.to(dev), z.to(dev), dists.to(dev))
+    tol_o, tol_g = (BF_OUT, BF_GRAD) if emu else (TOL, 3e-5)
+    assert rel_err(a2.cpu(), a) < tol_o and rel_err(b2.cpu(), b) < tol_o
+    assert rel_err(I0.double() - pix2.cpu(), I0.double() - pix) < tol_o
+    ((pix2 * cp.to(dev)).sum() + (a2 * cs.to(dev)).sum() * 50 + (b2 * cd.to(dev)).sum() * 50).backward()
+    for name, got, pe in (("static", grads_of(s), pso), ("dynamic", grads_of(t), pdo)):
+        for k in pe:
+            assert rel_err(got[k], pe[k].grad) < tol_g, (name, k)
