@@ -278,6 +278,8 @@ def render_rays(static_model, temp_model, origins, directions, phases, I0, z, di
     bd: Optional[FieldBinding] = temp_model._binding if temp_model is not None else None
     if single and bd is not None:
         raise ValueError("single-field render takes exactly one network")
+    if bd is not None and bd.prec != bs.prec:
+        raise _capi.NcaError("static and dynamic networks must use the same precision (see set_precision)")
     batch = _RayBatch(origins, directions, phases, I0, z, dists, act, single or bd is None, scale)
     params = bs.params() + (bd.params() if bd is not None else [])
     return _RenderFn.apply(batch, bs, bd, len(bs.params()), *params)

@@ -223,3 +223,20 @@ def test_sample_pdf_matches_oracle():
     w = torch.rand(6, 14, generator=gen)
     u = torch.rand(6, 9, generator=gen)
     assert torch.equal(MH.sample_pdf(bins, w, 9, "cpu", u=u), O.sample_pdf(bins, w, u))
+
+
+def test_precision_switch_is_per_model_pair():
+    import nerfca_amd
+    from nerfca_amd import _capi
+    from nerfca_amd.model.CPPN import CPPN
+    from nerfca_amd.model.Temporal import Temporal
+    s, t = CPPN(model_def(F=32, early=1)), Temporal(model_def(F=32, early=1, T=4))
+    assert s._binding.prec == _capi.PREC_F32
+    nerfca_amd.set_precision("bf16", s, t)
+    assert s._binding.prec == t._binding.prec == _capi.PREC_BF16
+    lib = _capi.lib()
+    assert lib.nca_packed_bytes(C.byref(s._binding.net), _capi.PREC_BF16) > 0
+    # configurations the bf16 kernels do not implement are explicit errors, not fallbacks
+    late = CPPN(model_def(F=32, early=1, late=2))
+    assert lib.nca_packed_bytes(C.byref(late._binding.net), _capi.PREC_BF16) == -2 and b"bf16" in lib.nca_last_error()
+    assert lib.nca_packed_bytes(C.byref(late._binding.net), _capi.PREC_F32) > 0
