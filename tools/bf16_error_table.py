@@ -1,3 +1,5 @@
+"""Developer aid (GPU box): per-tensor error table of the fused render (outputs and every gradient) against
+the oracle.  usage: python tools/bf16_error_table.py R S F [bf16|f32]   (bf16 compares with the emulating oracle)"""
 import sys, os
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo"); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
