@@ -43,6 +43,10 @@ def parse():
     ap.add_argument("--cpu-rays", type=int, default=2048, help="rays per step of the CPU baseline sample")
     ap.add_argument("--cpu-steps", type=int, default=5, help="timed CPU steps (plus one warm-up): ~20 s of CPU work at the defaults")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph (library Adam+LinearLR); "
+                    "per-kernel timings then come from a short eager pass after the timed region")
+    ap.add_argument("--unfused-gpu-rays", type=int, default=0, help="also time the unfused torch path on cuda:0 with this many rays/step")
+    ap.add_argument("--unfused-gpu-steps", type=int, default=5)
     ap.add_argument("--views", type=int, default=4)
     ap.add_argument("--torch-losses", action="store_true", help="losses + autograd in torch ops instead of the fused loss kernel")
     return ap.parse_args()
@@ -77,35 +81,67 @@ def measured_traffic(args, kernel):
     return k["hbm_bytes_per_launch"] if k else None
 
 
-def cpu_baseline(args, data, cfg_kwargs):
-    """Reference-equivalent CPU path (oracle) on a bounded sample of the same workload."""
+def _oracle_leg(args, data, R, steps, device):
+    """`steps` reference-equivalent training steps (the oracle: plain torch ops + autograd + torch Adam) of R rays on
+    `device`; returns seconds.  On cuda this is the unfused PyTorch-ROCm path of SURVEY.md 8(d)(ii)."""
     from oracle import nerfca_oracle as O
-    cores = host_cores()
-    torch.set_num_threads(cores)
-    R, S = args.cpu_rays, args.samples
+    S = args.samples
     gen = torch.Generator().manual_seed(0)
     ss, sd = O.NetSpec(num_filters=128), O.NetSpec(num_filters=128, num_time_dim=8)
-    tr = O.OracleTrainer(O.init_params(ss, gen), ss, O.init_params(sd, gen), sd)
+    on = lambda t: None if t is None else t.to(device)
+    ps = {k: on(v) for k, v in O.init_params(ss, gen).items()}
+    pd = {k: on(v) for k, v in O.init_params(sd, gen).items()}
+
+    class Trainer(O.OracleTrainer):
+        def windows(self, n_iter):
+            return tuple(on(w) for w in super().windows(n_iter))
+
     ids = torch.randint(0, data.rays_train.shape[0], (R,), generator=gen)
     rays = data.rays_train.cpu().index_select(0, ids)
     ph = data.phases_train.cpu().index_select(0, ids)
-    o, d, gt, w = rays[:, 0, :], rays[:, 1, :], rays[:, 2, 0], rays[:, 3, 0]
-    I0 = torch.full((R,), float(data.geo["max_pixel_value"]))
+    o, d, gt, w = (on(t) for t in (rays[:, 0, :], rays[:, 1, :], rays[:, 2, 0], rays[:, 3, 0]))
+    I0 = torch.full((R,), float(data.geo["max_pixel_value"]), device=device)
     z0 = O.depth_values(data.geo["near_thresh"], data.geo["far_thresh"], S)
-    phs = ph[:, None].repeat(1, S)
+    phs = on(ph[:, None].repeat(1, S))
+    sync = torch.cuda.synchronize if torch.device(device).type == "cuda" else (lambda: None)
+    prev = torch.get_default_device()
+    torch.set_default_device(device)           # the oracle builds its small constants on the default device
+    try:
+        tr = Trainer(ps, ss, pd, sd)
 
-    def one(i):
-        zj = O.stratified_depths(z0, torch.rand(S, generator=gen))
-        tr.step(75000 + i, o, d, phs, I0, zj, gt, w)
+        def one(i):
+            zj = on(O.stratified_depths(z0.cpu(), torch.rand(S, generator=gen, device="cpu")))
+            tr.step(75000 + i, o, d, phs, I0, zj, gt, w)
 
-    one(0)
-    t0 = time.perf_counter()
-    for i in range(args.cpu_steps):
-        one(1 + i)
-    dt = time.perf_counter() - t0
+        one(0)
+        sync()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            one(1 + i)
+        sync()
+        return time.perf_counter() - t0
+    finally:
+        torch.set_default_device(prev)
+
+
+def cpu_baseline(args, data, cfg_kwargs):
+    """Reference-equivalent CPU path (oracle) on a bounded sample of the same workload."""
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    R, S = args.cpu_rays, args.samples
+    dt = _oracle_leg(args, data, R, args.cpu_steps, "cpu")
     return {"value": R * args.cpu_steps / dt, "unit": "rays/s", "cores": cores, "kind": "port",
             "sample": f"{args.cpu_steps} full training steps of {R} rays x {S} samples (same nets, losses, Adam) with torch CPU ops, "
                       f"{dt:.1f} s"}
+
+
+def unfused_gpu_baseline(args, data):
+    """Opt-in (--unfused-gpu-rays): the same reference-equivalent torch path run op by op on cuda:0 in f32 — what
+    the reference itself does on a GPU.  The chunk loop of the reference is not needed for memory on 288 GB."""
+    R, steps = args.unfused_gpu_rays, args.unfused_gpu_steps
+    dt = _oracle_leg(args, data, R, steps, "cuda:0")
+    return {"value": R * steps / dt, "unit": "rays/s", "dtype": "f32",
+            "sample": f"{steps} full training steps of {R} rays x {args.samples} samples with unfused PyTorch-ROCm ops, {dt:.2f} s"}
 
 
 def main():
@@ -148,16 +184,25 @@ def main():
         torch.cuda.synchronize()
 
     base_iter = 75000    # steady state: half of the frequency bands open
+    step = tr.step_graph if args.graph else tr.step
     for i in range(args.warmup):
-        tr.step(base_iter + i)
+        step(base_iter + i)
     barrier()
     _capi.timing_reset()
-    _capi.timing_enable(True)
+    _capi.timing_enable(not args.graph)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        loss, _, _ = tr.step(base_iter + args.warmup + i)
+        loss, _, _ = step(base_iter + args.warmup + i)
     barrier()
     dt = time.perf_counter() - t0
+    loss = float(loss)
+    timed_steps = args.steps
+    if args.graph:       # events cannot be recorded inside a replayed graph: time the same kernels eagerly, outside dt
+        timed_steps = min(args.steps, 4)
+        _capi.timing_enable(True)
+        for i in range(timed_steps):
+            tr.step(base_iter + i)
+        barrier()
     _capi.timing_enable(False)
     if use_pg:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -165,7 +210,7 @@ def main():
         dt = float(tmax.item())
 
     if rank == 0:
-        n_samp = args.rays * args.samples * args.steps               # per GPU over the timed region
+        n_samp = args.rays * args.samples * timed_steps               # per GPU over the span the kernel timers covered
         kern = {}
         for name, flop in (("fwd", FLOP_FWD), ("bwd_dgrad", FLOP_DGRAD), ("bwd_wgrad", FLOP_WGRAD), ("bwd_reduce", 0), ("loss", 0), ("pack", 0)):
             ms, n = _capi.timing_read(name)
@@ -182,10 +227,12 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.prec, "data": "synthetic",
                "config": {"workload": f"run_composite XCAT {args.views}-view x 10 phases, {args.det}^2 detector x {args.samples} samples/ray, "
                                       f"{args.rays} rays/step/GPU (one full detector), F=128 x 4 hidden layers x 2 nets, L=12, fwd+losses+bwd+Adam",
-                          "rays_per_step_per_gpu": args.rays, "samples_per_ray": args.samples, "parallelism": f"ray-sharded dp{world}"},
+                          "rays_per_step_per_gpu": args.rays, "samples_per_ray": args.samples, "parallelism": f"ray-sharded dp{world}", "hip_graph": bool(args.graph)},
                "roofline": roof, "final_loss": float(loss)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, data, None)
+        if world == 1 and args.unfused_gpu_rays > 0:
+            out["unfused_gpu_baseline"] = unfused_gpu_baseline(args, data)
         print(json.dumps(out))
     if use_pg:
         torch.distributed.destroy_process_group()

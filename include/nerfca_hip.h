@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NCA_ABI_VERSION 1
+#define NCA_ABI_VERSION 2
 
 enum {
     NCA_OK = 0,
@@ -161,6 +161,8 @@ typedef struct NcaLoss {
     double weighted_thresh;  /* entro_weighted_thresh                                                   */
     double w_favor, w_dent, w_occl, w_l1;  /* this step's weights (linear_param_decay, run_composite.py:276-279) */
     double inv_R;            /* 1 / GLOBAL ray count: mean-type terms are sums over local rays times this */
+    const double* weights_dev; /* NULL, or DEVICE f64[4] = {w_favor, w_dent, w_occl, w_l1} read by the kernels instead of
+                                  the four fields above: a captured HIP graph can be replayed with new weights          */
 } NcaLoss;
 enum { NCA_T_LOSS = 0, NCA_T_PIXEL, NCA_T_BLENDW, NCA_T_SIG_S_MAX, NCA_T_SIG_D_MAX, NCA_T_FAVOR, NCA_T_S_ENTROPY, NCA_T_S_SUM,
        NCA_T_D_ENTROPY, NCA_T_D_SUM, NCA_T_OCCL, NCA_T_L1, NCA_T_L2, NCA_T_COUNT };
@@ -172,8 +174,24 @@ int nca_loss_fwd_bwd(const NcaLoss* desc, const double* pix, const double* gt, c
                      double* terms, double* g_pix, float* g_sig_s, float* g_sig_d,
                      void* work, int64_t work_bytes, void* stream);
 
+/* ---- optimiser: torch.optim.Adam(lr) + LinearLR(start_factor=1, end_factor, total_iters) of
+ *      train/run_composite.py:209-215, 307-308, as one launch over up to NCA_ADAM_MAX_SEG flat buffers.
+ *      `step` is a DEVICE counter = optimiser steps taken so far: the kernel uses t = *step + 1 for the
+ *      bias corrections and lr = cfg.lr * factor(*step) (the scheduler is stepped after the optimiser
+ *      in the reference), then increments it, so a captured graph replays the whole schedule. -------- */
+enum { NCA_ADAM_MAX_SEG = 4 };
+typedef struct NcaAdam {
+    double lr;               /* base learning rate                                              */
+    double beta1, beta2, eps;/* torch defaults 0.9, 0.999, 1e-8; no weight decay, no amsgrad    */
+    double lr_end_factor;    /* LinearLR end_factor (1.0 = constant lr)                         */
+    int64_t lr_total_iters;  /* LinearLR total_iters                                            */
+} NcaAdam;
+/* n, params, grads, exp_avg, exp_avg_sq: HOST arrays of n_seg entries (device pointers, f32). */
+int nca_adam_step(const NcaAdam* cfg, int32_t n_seg, const int64_t* n, float* const* params, const float* const* grads,
+                  float* const* exp_avg, float* const* exp_avg_sq, int64_t* step, void* stream);
+
 /* ---- in-library kernel timing (HIP events on the launch stream), used by bench.py -------- */
-enum { NCA_K_PACK = 0, NCA_K_FWD = 1, NCA_K_BWD_DGRAD = 2, NCA_K_BWD_WGRAD = 3, NCA_K_BWD_REDUCE = 4, NCA_K_LOSS = 5, NCA_K_COUNT = 6 };
+enum { NCA_K_PACK = 0, NCA_K_FWD = 1, NCA_K_BWD_DGRAD = 2, NCA_K_BWD_WGRAD = 3, NCA_K_BWD_REDUCE = 4, NCA_K_LOSS = 5, NCA_K_ADAM = 6, NCA_K_COUNT = 7 };
 int nca_timing_enable(int32_t on);
 /* Synchronises the recorded events and returns accumulated milliseconds and launch count. */
 int nca_timing_read(int32_t kind, double* total_ms, int64_t* launches);

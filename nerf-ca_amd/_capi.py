@@ -15,9 +15,9 @@ LIB_PATH = os.path.join(_HERE, "lib", "libnerfca_hip.so")
 ENC_NONE, ENC_BANDS, ENC_FOURIER = 0, 1, 2
 ACT_SIGMOID, ACT_SOFTPLUS, ACT_CLAMP = 0, 1, 2
 PREC_F32, PREC_BF16 = 0, 1
-K_PACK, K_FWD, K_BWD_DGRAD, K_BWD_WGRAD, K_BWD_REDUCE, K_LOSS = 0, 1, 2, 3, 4, 5
+K_PACK, K_FWD, K_BWD_DGRAD, K_BWD_WGRAD, K_BWD_REDUCE, K_LOSS, K_ADAM = 0, 1, 2, 3, 4, 5, 6
 KERNEL_KINDS = {"pack": K_PACK, "fwd": K_FWD, "bwd_dgrad": K_BWD_DGRAD, "bwd_wgrad": K_BWD_WGRAD, "bwd_reduce": K_BWD_REDUCE,
-                "loss": K_LOSS}
+                "loss": K_LOSS, "adam": K_ADAM}
 TERM_NAMES = ["loss", "pixel", "blendw", "sigma_s_max", "sigma_d_max", "favor_s", "s_entropy", "s_entropy_sum", "d_entropy",
               "d_entropy_sum", "d_occl", "s_l1", "s_l2"]
 
@@ -39,7 +39,12 @@ class NcaRays(C.Structure):
 class NcaLoss(C.Structure):
     _fields_ = [("R", C.c_int64), ("S", C.c_int32), ("use_weighting", C.c_int32), ("skew", C.c_double), ("mask_thre", C.c_double),
                 ("weighted_thresh", C.c_double), ("w_favor", C.c_double), ("w_dent", C.c_double), ("w_occl", C.c_double),
-                ("w_l1", C.c_double), ("inv_R", C.c_double)]
+                ("w_l1", C.c_double), ("inv_R", C.c_double), ("weights_dev", C.c_void_p)]
+
+
+class NcaAdam(C.Structure):
+    _fields_ = [("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
+                ("lr_end_factor", C.c_double), ("lr_total_iters", C.c_int64)]
 
 
 class NcaError(RuntimeError):
@@ -69,6 +74,8 @@ SYMBOLS = {
     "nca_composite_bwd": (C.c_int, [_I64, _I32, _I32, _I32, C.c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "nca_loss_workspace": (_I64, [_I64]),
     "nca_loss_fwd_bwd": (C.c_int, [C.POINTER(NcaLoss), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
+    "nca_adam_step": (C.c_int, [C.POINTER(NcaAdam), _I32, C.POINTER(_I64), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P),
+                                _P, _P]),
     "nca_timing_enable": (C.c_int, [_I32]),
     "nca_timing_read": (C.c_int, [_I32, C.POINTER(C.c_double), C.POINTER(_I64)]),
     "nca_timing_reset": (C.c_int, []),
@@ -87,7 +94,7 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.nca_abi_version() != 1:
+        if handle.nca_abi_version() != 2:
             raise NcaError("libnerfca_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -47,6 +47,10 @@ struct Span {
     Span(int k, hipStream_t s) : kind(k), st(s) {
         std::lock_guard<std::mutex> lk(g_tmu);
         on = g_timing;
+        if (on) {       // events recorded into a stream capture become graph nodes and cannot be timed: skip them
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) on = false;
+        }
         if (on) { a = get_event(); b = get_event(); if (a && b) hipEventRecord(a, st); else on = false; }
     }
     ~Span() {
@@ -716,11 +720,32 @@ extern "C" int nca_loss_fwd_bwd(const NcaLoss* d, const double* pix, const doubl
     a.R = d->R; a.S = d->S; a.use_weighting = d->use_weighting;
     a.skew = d->skew; a.mask_thre = d->mask_thre; a.weighted_thresh = d->weighted_thresh;
     a.w_favor = d->w_favor; a.w_dent = d->w_dent; a.w_occl = d->w_occl; a.w_l1 = d->w_l1; a.inv_R = d->inv_R;
+    a.weights_dev = d->weights_dev;
     a.pix = pix; a.gt = gt; a.wpix = wpix; a.sig_s = sig_s; a.sig_d = sig_d; a.dists = dists;
     a.terms = terms; a.g_pix = g_pix; a.g_sig_s = g_sig_s; a.g_sig_d = g_sig_d;
     a.partials = static_cast<double*>(work);
     Span sp(NCA_K_LOSS, (hipStream_t)stream);
     HIPCHK(nca_launch_loss(a, (hipStream_t)stream));
+    return NCA_OK;
+}
+
+// ---------------------------------------------------------------------------------- optimiser
+extern "C" int nca_adam_step(const NcaAdam* cfg, int32_t n_seg, const int64_t* n, float* const* params, const float* const* grads,
+                             float* const* exp_avg, float* const* exp_avg_sq, int64_t* step, void* stream) {
+    if (!cfg || !n || !params || !grads || !exp_avg || !exp_avg_sq || !step) return fail(NCA_E_INVALID, "an Adam argument is NULL");
+    if (n_seg < 1 || n_seg > NCA_ADAM_MAX_SEG) return fail(NCA_E_INVALID, "n_seg %d outside 1..%d", n_seg, (int)NCA_ADAM_MAX_SEG);
+    if (!(cfg->lr >= 0.0) || !(cfg->beta1 >= 0.0 && cfg->beta1 < 1.0) || !(cfg->beta2 >= 0.0 && cfg->beta2 < 1.0) || !(cfg->eps >= 0.0))
+        return fail(NCA_E_INVALID, "Adam hyper-parameters out of range");
+    NcaAdamArgs a{};
+    a.lr = cfg->lr; a.beta1 = cfg->beta1; a.beta2 = cfg->beta2; a.eps = cfg->eps;
+    a.lr_end_factor = cfg->lr_end_factor; a.lr_total_iters = cfg->lr_total_iters;
+    a.n_seg = n_seg; a.step = step;
+    for (int s = 0; s < n_seg; ++s) {
+        if (n[s] <= 0 || !params[s] || !grads[s] || !exp_avg[s] || !exp_avg_sq[s]) return fail(NCA_E_INVALID, "Adam segment %d is empty or NULL", s);
+        a.n[s] = n[s]; a.params[s] = params[s]; a.grads[s] = grads[s]; a.exp_avg[s] = exp_avg[s]; a.exp_avg_sq[s] = exp_avg_sq[s];
+    }
+    Span sp(NCA_K_ADAM, (hipStream_t)stream);
+    HIPCHK(nca_launch_adam(a, (hipStream_t)stream));
     return NCA_OK;
 }
 

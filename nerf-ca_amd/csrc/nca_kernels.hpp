@@ -111,6 +111,7 @@ struct NcaLossArgs {
     int32_t S, use_weighting;
     double skew, mask_thre, weighted_thresh;
     double w_favor, w_dent, w_occl, w_l1, inv_R;
+    const double* weights_dev;
     const double* pix; const double* gt; const double* wpix;
     const float* sig_s; const float* sig_d; const double* dists;
     double* terms; double* g_pix; float* g_sig_s; float* g_sig_d;
@@ -126,6 +127,15 @@ struct NcaCompositeArgs {
 };
 hipError_t nca_launch_composite(const NcaCompositeArgs& a, bool bwd, hipStream_t st);
 hipError_t nca_launch_loss(const NcaLossArgs& a, hipStream_t st);
+struct NcaAdamArgs {
+    double lr, beta1, beta2, eps, lr_end_factor;
+    int64_t lr_total_iters;
+    int32_t n_seg;
+    int64_t n[4];
+    float* params[4]; const float* grads[4]; float* exp_avg[4]; float* exp_avg_sq[4];
+    int64_t* step;
+};
+hipError_t nca_launch_adam(const NcaAdamArgs& a, hipStream_t st);
 int64_t nca_loss_partials_bytes(int64_t R);
 
 hipError_t nca_launch_pack_f32(const NcaLayout& y, const float* prm, void* out, hipStream_t st);

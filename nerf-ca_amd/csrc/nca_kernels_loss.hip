@@ -37,6 +37,9 @@ __global__ __launch_bounds__(LOSS_NT) void nca_loss_rays(const NcaLossArgs a) {
     for (int i = 0; i < NPART; ++i) part[i] = 0.0;
     float mx_s = 0.f, mx_d = 0.f;
 
+    // this step's weights: by value, or from the device vector a graph replay refreshes
+    const double w_favor = a.weights_dev ? a.weights_dev[0] : a.w_favor, w_dent = a.weights_dev ? a.weights_dev[1] : a.w_dent;
+    const double w_occl = a.weights_dev ? a.weights_dev[2] : a.w_occl, w_l1 = a.weights_dev ? a.weights_dev[3] : a.w_l1;
     if (r < a.R) {
         const float* ss = a.sig_s + r * a.S;
         const float* sd = a.sig_d + r * a.S;
@@ -80,8 +83,8 @@ __global__ __launch_bounds__(LOSS_NT) void nca_loss_rays(const NcaLossArgs a) {
         if (a.g_sig_s) {
             float* gs = a.g_sig_s + r * a.S;
             float* gd = a.g_sig_d + r * a.S;
-            const float fscale = (float)(a.w_favor * a.inv_R / (double)a.S);
-            const double escale = a.w_dent * a.inv_R * (double)mask_d / Mcd;
+            const float fscale = (float)(w_favor * a.inv_R / (double)a.S);
+            const double escale = w_dent * a.inv_R * (double)mask_d / Mcd;
             const bool unclipped = Md >= 1e-19;      // d clip(M)/dM
             for (int s = lane; s < a.S; s += 64) {
                 const float vs = ss[s], vd = sd[s];
@@ -106,8 +109,8 @@ __global__ __launch_bounds__(LOSS_NT) void nca_loss_rays(const NcaLossArgs a) {
                 const double pd = (double)vd * dl / Mcd;
                 const double q = log(pd + 1e-10) + pd / (pd + 1e-10);
                 const double g_d_e = escale * dl * (-q + (unclipped ? qp : 0.0));
-                const double g_d_o = a.w_occl * a.inv_R * dl;
-                const double g_s_l = a.w_l1 * (dl + 2.0 * (double)vs * dl * dl);
+                const double g_d_o = w_occl * a.inv_R * dl;
+                const double g_s_l = w_l1 * (dl + 2.0 * (double)vs * dl * dl);
                 gs[s] = g_s_f + (float)g_s_l;
                 gd[s] = g_d_f + (float)(g_d_e + g_d_o);
             }
@@ -177,7 +180,9 @@ __global__ __launch_bounds__(256) void nca_loss_finish(const NcaLossArgs a, int 
         t[T_L2] = res[9];
         t[T_SMAX] = res[NPART];
         t[T_DMAX] = res[NPART + 1];
-        t[T_LOSS] = t[T_PIXEL] + a.w_favor * t[T_FAVOR] + a.w_dent * t[T_DENT] + a.w_occl * t[T_OCCL] + a.w_l1 * t[T_L2] + a.w_l1 * t[T_L1];
+        const double w_favor = a.weights_dev ? a.weights_dev[0] : a.w_favor, w_dent = a.weights_dev ? a.weights_dev[1] : a.w_dent;
+        const double w_occl = a.weights_dev ? a.weights_dev[2] : a.w_occl, w_l1 = a.weights_dev ? a.weights_dev[3] : a.w_l1;
+        t[T_LOSS] = t[T_PIXEL] + w_favor * t[T_FAVOR] + w_dent * t[T_DENT] + w_occl * t[T_OCCL] + w_l1 * t[T_L2] + w_l1 * t[T_L1];
     }
 }
 
@@ -260,5 +265,43 @@ hipError_t nca_launch_composite(const NcaCompositeArgs& a, bool bwd, hipStream_t
     } else {
         hipLaunchKernelGGL(nca_composite_fwd_k, dim3((int)((a.R + LOSS_WAVES - 1) / LOSS_WAVES)), dim3(LOSS_NT), 0, st, a);
     }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Adam + LinearLR (train/run_composite.py:209-215, 307-308): the element-wise update of torch.optim.Adam's
+// default path (lerp, addcmul, sqrt/ bias-correction, addcdiv) with the step-dependent scalars derived from
+// a device-resident step counter, so the launch can sit in a captured graph.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nca_adam_k(const NcaAdamArgs a) {
+    const int64_t done = *a.step;                                  // optimiser steps taken before this one
+    const double t = (double)(done + 1);
+    const double bc1 = 1.0 - pow(a.beta1, t), bc2 = 1.0 - pow(a.beta2, t);
+    const double frac = a.lr_total_iters > 0 ? fmin((double)done, (double)a.lr_total_iters) / (double)a.lr_total_iters : 1.0;
+    const double lr = a.lr * (1.0 + (a.lr_end_factor - 1.0) * frac);  // LinearLR, start_factor = 1, closed form
+    const float step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2), eps = (float)a.eps;
+    const float w1 = (float)(1.0 - a.beta1), b2 = (float)a.beta2, w2 = (float)(1.0 - a.beta2);
+    const int seg = blockIdx.y;
+    float* __restrict__ p = a.params[seg];
+    const float* __restrict__ g = a.grads[seg];
+    float* __restrict__ m = a.exp_avg[seg];
+    float* __restrict__ v = a.exp_avg_sq[seg];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n[seg]; i += (int64_t)gridDim.x * 256) {
+        const float gi = g[i];
+        const float mi = m[i] + w1 * (gi - m[i]);
+        const float vi = v[i] * b2 + w2 * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] = p[i] - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+    }
+}
+__global__ void nca_adam_tick(int64_t* step) { *step += 1; }
+
+hipError_t nca_launch_adam(const NcaAdamArgs& a, hipStream_t st) {
+    int64_t nmax = 0;
+    for (int s = 0; s < a.n_seg; ++s) nmax = a.n[s] > nmax ? a.n[s] : nmax;
+    int gx = (int)((nmax + 255) / 256);
+    gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
+    hipLaunchKernelGGL(nca_adam_k, dim3(gx, a.n_seg), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(nca_adam_tick, dim3(1), dim3(1), 0, st, a.step);
     return hipGetLastError();
 }

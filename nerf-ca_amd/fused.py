@@ -61,6 +61,7 @@ class FieldBinding:
         self.prec = prec
         self.flat: Optional[torch.Tensor] = None
         self.packed: Optional[torch.Tensor] = None
+        self.static_window: Optional[torch.Tensor] = None   # device f32[L] that overrides the module's band window
         self._offsets: List[int] = []
         self.reflatten()
 
@@ -235,12 +236,14 @@ class _RenderFn(torch.autograd.Function):
         return (None, None, None, None, *out)
 
 
-def fused_losses(pix, gt, wpix, sig_s, sig_d, dists, run_args, weights, inv_R=None, want_grads=True):
+def fused_losses(pix, gt, wpix, sig_s, sig_d, dists, run_args, weights, inv_R=None, want_grads=True, weights_dev=None):
     """weighted MSE + compute_losses + the loss assembly of run_composite.py:287-292 in one HIP pass.
 
     ``weights`` = (favor_s_weight, dynamic_entro_weight, occl_weight, l1_weight) of this step.
     Returns ``(terms f64[13] on device, g_pix f64[R], g_sigma_s f32[R,S], g_sigma_d f32[R,S])``; see
     ``_capi.TERM_NAMES`` for the order of ``terms``.  ``inv_R`` = 1 / global ray count (default 1/R).
+    ``weights_dev`` (device f64[4]) replaces ``weights`` with values the kernels read at run time, which is
+    what a captured HIP graph needs.
     """
     lib = _capi.lib()
     _require_cuda(sig_s, "sigma")
@@ -252,7 +255,11 @@ def fused_losses(pix, gt, wpix, sig_s, sig_d, dists, run_args, weights, inv_R=No
     desc = _capi.NcaLoss(R=R, S=S, use_weighting=1 if run_args.entro_use_weighting else 0, skew=float(run_args.skewness_val),
                          mask_thre=float(run_args.entro_mask_thre), weighted_thresh=float(run_args.entro_weighted_thresh),
                          w_favor=float(weights[0]), w_dent=float(weights[1]), w_occl=float(weights[2]), w_l1=float(weights[3]),
-                         inv_R=float(inv_R if inv_R is not None else 1.0 / R))
+                         inv_R=float(inv_R if inv_R is not None else 1.0 / R), weights_dev=None)
+    if weights_dev is not None:
+        if weights_dev.dtype != torch.float64 or weights_dev.numel() != 4 or not weights_dev.is_cuda or not weights_dev.is_contiguous():
+            raise _capi.NcaError("weights_dev must be a contiguous device f64[4]")
+        desc.weights_dev = ptr(weights_dev)
     terms = torch.empty(len(_capi.TERM_NAMES), dtype=torch.float64, device=dev)
     g_pix = g_s = g_d = None
     if want_grads:
@@ -264,6 +271,37 @@ def fused_losses(pix, gt, wpix, sig_s, sig_d, dists, run_args, weights, inv_R=No
     check(lib.nca_loss_fwd_bwd(C.byref(desc), ptr(pix), ptr(gt), ptr(wpix), ptr(ss), ptr(sd), ptr(dists), ptr(terms),
                                ptr(g_pix), ptr(g_s), ptr(g_d), ptr(work), wbytes, _stream()))
     return terms, g_pix, g_s, g_d
+
+
+class FusedAdam:
+    """torch.optim.Adam(lr) + LinearLR(1 -> end_factor over total_iters) of run_composite.py:209-215 as ONE library
+    launch over the flat parameter buffers of the given models (order as given).  The step counter lives on the
+    device, so the launch can be captured in a HIP graph and replayed; ``grads`` are flat f32 tensors per model."""
+
+    def __init__(self, models: Sequence[torch.nn.Module], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, end_factor=1.0, total_iters=0):
+        self.bindings = [m._binding for m in models]
+        for b in self.bindings:
+            if not b._is_flat():
+                b.reflatten()
+            _require_cuda(b.flat, "network parameters")
+        dev = self.bindings[0].flat.device
+        self.cfg = _capi.NcaAdam(lr=float(lr), beta1=float(betas[0]), beta2=float(betas[1]), eps=float(eps),
+                                 lr_end_factor=float(end_factor), lr_total_iters=int(total_iters))
+        self.exp_avg = [torch.zeros_like(b.flat) for b in self.bindings]
+        self.exp_avg_sq = [torch.zeros_like(b.flat) for b in self.bindings]
+        self.step_count = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def step(self, grads: Sequence[torch.Tensor]) -> None:
+        k = len(self.bindings)
+        if len(grads) != k:
+            raise ValueError("one flat gradient per model")
+        for b, g in zip(self.bindings, grads):
+            if g.numel() != b.flat.numel() or g.dtype != torch.float32 or not g.is_contiguous() or g.device != b.flat.device:
+                raise _capi.NcaError("gradient must be a contiguous f32 tensor matching the flat parameters")
+        arr = lambda ts: (C.c_void_p * k)(*[t.data_ptr() for t in ts])
+        n = (C.c_int64 * k)(*[b.flat.numel() for b in self.bindings])
+        check(_capi.lib().nca_adam_step(C.byref(self.cfg), k, n, arr([b.flat for b in self.bindings]), arr(grads), arr(self.exp_avg),
+                                        arr(self.exp_avg_sq), ptr(self.step_count), _stream()))
 
 
 def render_rays(static_model, temp_model, origins, directions, phases, I0, z, dists, act="softplus", single=False, scale=1e-2):

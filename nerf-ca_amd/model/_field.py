@@ -113,6 +113,9 @@ class FieldBase(nn.Module):
         dev = self._param_device()
         b = self._binding.net
         if b.enc_mode == _capi.ENC_BANDS:
+            pinned = self._binding.static_window      # a persistent device vector owned by a graph-captured step
+            if pinned is not None:
+                return pinned, None
             w = self._band_window()
             key = (w.data_ptr(), w._version, dev)
             if self._win_cache is None or self._win_cache[0] != key:

@@ -196,6 +196,123 @@ class CompositeTrainer:
         self.sched.step()
         return terms[0], terms[1], terms
 
+    # -- the same step as a replayed HIP graph ---------------------------------------------------
+    def _graph_setup(self) -> None:
+        """Capture gather -> jitter -> fused forward -> loss kernel -> fused backward (-> all-reduce) -> Adam+LinearLR
+        once.  Everything that changes from step to step reaches the kernels through device memory: the ray ids,
+        one small host-pinned record (depth jitter, the two band windows, the four loss weights) copied per step,
+        and the optimiser's device-side step counter."""
+        from ..fused import FusedAdam, _RayBatch, fused_losses, render_backward_raw, render_forward_raw
+        c, dev = self.cfg, self.device
+        S = self.depth.shape[0]
+        Ls, Ld = self.s.pos_enc_basis, self.t.pos_enc_basis
+        nf = S + Ls + Ld
+        off64 = (4 * nf + 7) // 8 * 8
+        self._rec_layout = (S, Ls, Ld, off64)
+        self._rec_host = [torch.empty(off64 + 32, dtype=torch.uint8).pin_memory() for _ in range(4)]
+        self._rec_done = [None] * 4
+        self._rec_dev = torch.zeros(off64 + 32, dtype=torch.uint8, device=dev)
+        rec32 = self._rec_dev[: 4 * nf].view(torch.float32)
+        rec64 = self._rec_dev[off64:].view(torch.float64)
+        R = c.img_sample_size
+        lo, hi = (R * self.rank) // self.world, (R * (self.rank + 1)) // self.world
+        self._slice = (lo, hi)
+        self._ids_buf = torch.zeros(hi - lo, dtype=torch.int64, device=dev)
+        tail = torch.tensor([1e-10], dtype=self.data.rays_train.dtype, device=dev)   # model_helpers.py:73
+        self.adam = FusedAdam([self.t, self.s], lr=c.lr, end_factor=c.lr_end_factor, total_iters=c.lr_decay_steps)
+        bs, bd = self.s._binding, self.t._binding
+        split = self.world > 1 or self.always_allreduce
+        out = {}
+
+        def front():
+            rays = self.data.rays_train.index_select(0, self._ids_buf)
+            phases = self.data.phases_train.index_select(0, self._ids_buf)
+            o, d, gt, w = rays[:, 0, :], rays[:, 1, :], rays[:, 2, 0], rays[:, 3, 0]
+            z = MH.randomize_depth(self.depth, dev, rec32[:S])
+            dists = torch.cat((z[1:] - z[:-1], tail))
+            batch = _RayBatch(o, d, phases, self.I0[: hi - lo], z, dists, c.output_activation, False, 1e-2)
+            pix, sig_s, sig_d, keep = render_forward_raw(batch, bs, bd)
+            terms, g_pix, g_s, g_d = fused_losses(pix, gt, w, sig_s, sig_d, dists, c, (0.0, 0.0, 0.0, 0.0), inv_R=1.0 / R,
+                                                  weights_dev=rec64)
+            grads_s, grads_d = render_backward_raw(batch, bs, bd, keep, g_pix, g_s, g_d)
+            out["terms"] = terms
+            out["flat"] = torch.cat([grads_d, grads_s])
+
+        def back():
+            nd = bd.flat.numel()
+            self.adam.step([out["flat"][:nd], out["flat"][nd:]])
+
+        bs.static_window = rec32[S:S + Ls] if Ls > 0 else None
+        bd.static_window = rec32[S + Ls:S + Ls + Ld] if Ld > 0 else None
+        try:
+            self._write_record(0)
+            saved = [b.flat.clone() for b in (bd, bs)]
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):          # eager warm-up on the capture stream's allocator pool
+                front()
+                back()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            for b, keep_flat in zip((bd, bs), saved):      # undo the warm-up's optimiser step
+                b.flat.copy_(keep_flat)
+            for t in self.adam.exp_avg + self.adam.exp_avg_sq:
+                t.zero_()
+            self.adam.step_count.zero_()
+            self._graphs = []
+            g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                front()
+                if not split:
+                    back()
+            self._graphs.append(g1)
+            if split:
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2, pool=g1.pool()):
+                    back()
+                self._graphs.append(g2)
+        finally:
+            bs.static_window = bd.static_window = None
+        self._graph_out = out
+
+    def _write_record(self, n_iter: int) -> None:
+        """Fill the next pinned record with this step's host-side scalars and enqueue its copy to the device."""
+        S, Ls, Ld, off64 = self._rec_layout
+        k = n_iter % len(self._rec_host)
+        if self._rec_done[k] is not None:
+            self._rec_done[k].synchronize()          # the copy that last used this pinned buffer has run
+        host = self._rec_host[k]
+        h32 = host[: 4 * (S + Ls + Ld)].view(torch.float32)
+        h32[:S] = self.draw_jitter(n_iter)
+        if Ls > 0:
+            h32[S:S + Ls] = self.s._band_window()
+        if Ld > 0:
+            h32[S + Ls:S + Ls + Ld] = self.t._band_window()
+        host[off64:].view(torch.float64).copy_(torch.tensor([float(x) for x in self.loss_weights(n_iter)], dtype=torch.float64))
+        self._rec_dev.copy_(host, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._rec_done[k] = ev
+
+    def step_graph(self, n_iter: int):
+        """``step_fused`` with the device work replayed from a captured HIP graph and the library's Adam + LinearLR
+        (its own moment buffers: do not interleave with ``step``/``step_fused`` in one run).  Per step the host only
+        draws the ray ids, fills one pinned record and launches the graph.  Returns (loss, pixel, terms) as
+        ``step_fused`` does; the tensors are overwritten by the next call."""
+        self.update_windows(n_iter)
+        if getattr(self, "_graphs", None) is None:
+            self._graph_setup()
+        lo, hi = self._slice
+        self._ids_buf.copy_(self.draw_ray_ids_device(n_iter)[lo:hi])
+        self._write_record(n_iter)
+        self._graphs[0].replay()
+        if len(self._graphs) > 1:
+            if self.world > 1 or self.always_allreduce:
+                dist.all_reduce(self._graph_out["flat"], op=dist.ReduceOp.SUM)
+            self._graphs[1].replay()
+        terms = self._graph_out["terms"]
+        return terms[0], terms[1], terms
+
     def allreduce_grads(self) -> None:
         """ONE all-reduce(SUM) over a flat f32 buffer of every gradient (152 914 floats by default)."""
         grads = [p.grad for p in self.params]

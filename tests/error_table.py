@@ -1,7 +1,7 @@
 """Developer aid (GPU box): per-tensor error table of the fused render (outputs and every gradient) against
-the oracle.  usage: python tools/bf16_error_table.py R S F [bf16|f32]   (bf16 compares with the emulating oracle)"""
+the oracle.  usage: python tests/error_table.py R S F [bf16|f32]   (bf16 compares with the emulating oracle)"""
 import sys, os
-ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo"); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+HERE = os.path.dirname(os.path.abspath(__file__)); ROOT = os.path.dirname(HERE); sys.path[:0] = [ROOT, HERE]
 import torch
 from oracle import nerfca_oracle as O
 from test_hip_parity import make_static, make_dynamic, _oracle_render_grads, grads_of

@@ -52,7 +52,7 @@ def grads_of(model):
 # ------------------------------------------------------------------------------------------
 def test_library_loaded():
     from nerfca_amd import _capi
-    assert _capi.lib().nca_abi_version() == 1
+    assert _capi.lib().nca_abi_version() == 2
 
 
 @pytest.mark.parametrize("F,early", [(F, e) for F in (32, 64, 128) for e in (0, 4)])
@@ -728,3 +728,87 @@ def test_error_paths_are_explicit(dev):
     assert s(torch.zeros(0, 3, device=dev)).shape == (0, 1)             # empty point batch: empty result, no launch
     bad = _capi.NcaNet(F=256, n_hidden=4, n_late=0, enc_mode=1, L=12, T=0, P=0, reserved=0)
     assert _capi.lib().nca_packed_bytes(C.byref(bad), 0) == -2
+
+
+# ----------------------------------------------------------------------------- optimiser + graph-replayed step
+def test_library_adam_matches_torch(dev):
+    """nca_adam_step == torch.optim.Adam + LinearLR (run_composite.py:209-215) over a schedule that crosses
+    total_iters, on the flat parameter buffers of a model pair."""
+    from nerfca_amd import synthetic
+    from nerfca_amd.fused import FusedAdam
+    from nerfca_amd.model.CPPN import CPPN
+    from nerfca_amd.model.Temporal import Temporal
+    torch.manual_seed(3)
+    sdef, tdef = synthetic.net_definitions(dev, F=32)
+    s, t = CPPN(sdef).to(dev), Temporal(tdef).to(dev)
+    ref = [p.detach().clone().requires_grad_(True) for p in list(t.parameters()) + list(s.parameters())]
+    opt = torch.optim.Adam([{"params": ref, "lr": 1e-2}], lr=1e-2)
+    sched = torch.optim.lr_scheduler.LinearLR(opt, start_factor=1, end_factor=0.1, total_iters=4)
+    adam = FusedAdam([t, s], lr=1e-2, end_factor=0.1, total_iters=4)
+    gen = torch.Generator(device=dev).manual_seed(1)
+    for it in range(7):
+        flat = [torch.randn(b.flat.numel(), generator=gen, device=dev) * (10.0 ** (it - 3)) for b in adam.bindings]
+        off = 0
+        for p in ref[: len(list(t.parameters()))]:
+            p.grad = flat[0][off:off + p.numel()].view(p.shape).clone(); off += p.numel()
+        off = 0
+        for p in ref[len(list(t.parameters())):]:
+            p.grad = flat[1][off:off + p.numel()].view(p.shape).clone(); off += p.numel()
+        opt.step(); sched.step()
+        adam.step(flat)
+    assert int(adam.step_count.item()) == 7
+    got = torch.cat([p.detach().flatten() for p in list(t.parameters()) + list(s.parameters())])
+    want = torch.cat([p.detach().flatten() for p in ref])
+    assert rel_err(got.cpu(), want.cpu()) < 2e-6
+
+
+def test_loss_weights_from_device_memory(golden, dev):
+    """The loss kernel gives bit-identical results whether this step's weights arrive by value or through the
+    device vector a graph replay refreshes."""
+    from types import SimpleNamespace
+    from nerfca_amd.fused import fused_losses
+    g = golden("losses")
+    args = SimpleNamespace(favor_s_opt=None, skewness_val=1.0, entro_mask_thre=1e-4, entro_use_weighting=True,
+                           entro_weighted_thresh=0.03, occl_reg_perc=0.2)
+    a, b, dists, wpix = (g[f"f64_{k}"].to(dev) for k in ("sig_s", "sig_d", "dists", "wpix"))
+    R = a.shape[0]
+    gen = torch.Generator().manual_seed(0)
+    pix, gt = torch.randn(R, generator=gen).double().to(dev), torch.randn(R, generator=gen).double().to(dev)
+    w = (0.7, 0.9, 0.5, 0.25)
+    one = fused_losses(pix, gt, wpix, a, b, dists, args, w)
+    two = fused_losses(pix, gt, wpix, a, b, dists, args, (0.0, 0.0, 0.0, 0.0), weights_dev=torch.tensor(w, dtype=torch.float64, device=dev))
+    for x, y in zip(one, two):
+        assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_graph_step_matches_eager_step(dev, prec):
+    """CompositeTrainer.step_graph (captured HIP graph + library Adam/LinearLR, per-step scalars through device
+    memory) follows the same trajectory as the eager fused step with torch.optim.Adam: same loss every step
+    (so ids, jitter, band windows, loss weights and lr all advance inside the replay), same parameters."""
+    from nerfca_amd import set_precision, synthetic
+    from nerfca_amd.model.CPPN import CPPN
+    from nerfca_amd.model.Temporal import Temporal
+    from nerfca_amd.train.trainer import CompositeTrainer, TrainConfig
+    data = synthetic.make_dataset(16, 48, dev, views=synthetic.TRAIN_VIEWS[:2], n_phases=3, F=32)
+    outs = []
+    for graph in (False, True):
+        torch.manual_seed(9)
+        sdef, tdef = synthetic.net_definitions(dev, F=64)
+        s, t = CPPN(sdef).to(dev), Temporal(tdef).to(dev)
+        set_precision(prec, s, t)
+        cfg = TrainConfig(depth_samples_per_ray_coarse=48, img_sample_size=512, favor_s_weight_delay_steps=0,
+                          l1_weight_start=1e-3, l1_weight_end=1e-5, occl_weight_start=1e-2, occl_weight_end=1e-4,
+                          dynamic_entro_weight_start=1e-3, favor_s_weight_start=1e-3, entro_mask_thre=1e-6,
+                          hyperparam_decay_steps=40, lr=5e-3, lr_decay_steps=6, lr_end_factor=0.1,
+                          static_pos_enc_window_decay_steps=40, temp_pos_enc_window_decay_steps=40)
+        tr = CompositeTrainer(cfg, s, t, data, dev, seed=5, fused_loss=True)
+        losses = []
+        for it in range(8):
+            out = tr.step_graph(3 * it) if graph else tr.step_fused(3 * it)
+            losses.append(float(out[0]))
+        outs.append((losses, torch.cat([p.detach().flatten() for p in tr.params]).cpu()))
+    tol = 1e-5 if prec == "f32" else 1e-3
+    for a, b in zip(*[o[0] for o in outs]):
+        assert abs(a - b) <= tol * abs(a), (outs[0][0], outs[1][0])
+    assert rel_err(outs[1][1], outs[0][1]) < (1e-5 if prec == "f32" else 1e-3)
