@@ -178,6 +178,36 @@ __device__ __forceinline__ void mma_rowtile(const char* imgm, const u32x4 (&B)[2
     }
 }
 
+// The same contraction with the A fragments of a whole layer image streamed through a ring of registers:
+// the image is [row tile][k-step][lane][16 B], i.e. contiguous in the global step g = m * NKS + ks, so the read
+// of step g + PF is issued while step g multiplies -- also across row-tile boundaries, where the ReLU/pack
+// epilogue then hides the LDS latency of the next row tile's first fragments.
+#ifndef NCA_BF_PF
+#define NCA_BF_PF 3
+#endif
+constexpr int NCA_BF_RING = 4;
+static_assert(NCA_BF_PF >= 1 && NCA_BF_PF < NCA_BF_RING, "prefetch distance must fit the ring");
+template <int NKS, int MTOT>
+__device__ __forceinline__ void ring_prime(const char* imgl, u32x4 (&A)[NCA_BF_RING]) {
+#pragma unroll
+    for (int g = 0; g < NCA_BF_PF; ++g)
+        if (g < MTOT * NKS) A[g % NCA_BF_RING] = *reinterpret_cast<const u32x4*>(imgl + g * 1024);
+}
+template <int NKS, int MTOT, int NB>
+__device__ __forceinline__ void mma_rowtile_ring(const char* imgl, int m, u32x4 (&A)[NCA_BF_RING], const u32x4 (&B)[2][NB],
+                                                 f32x16& acc0, f32x16& acc1) {
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        const int g = m * NKS + ks, nx = g + NCA_BF_PF;
+        if (nx < MTOT * NKS) A[nx % NCA_BF_RING] = *reinterpret_cast<const u32x4*>(imgl + nx * 1024);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(A[g % NCA_BF_RING]), frag(B[0][ks]), acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(A[g % NCA_BF_RING]), frag(B[1][ks]), acc1, 0, 0, 0);
+        // keep every LDS read and MFMA inside its own step (the scheduler otherwise sinks the reads next to their
+        // use and the prefetch distance is lost); vector/scalar ALU and global memory instructions may still move
+        __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x10 | 0x400);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // fused forward / backward-dgrad kernel
 // ------------------------------------------------------------------------------------------
@@ -357,14 +387,17 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                 char* const hblk = BWD ? nb + EB + jj * HB : nullptr;            // input block of layer jj+1
                 u32x4 Bn[2][2 * MT];
                 unsigned mw[2][2] = {{0u, 0u}, {0u, 0u}};     // mask words: [column tile][row-tile pair]
+                u32x4 A[NCA_BF_RING];
+                const char* imgl = img + lane * 16;
+                if (jj == 0) ring_prime<KS0, MT>(imgl, A);
+                else ring_prime<KS, MT>(imgl, A);
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
                     f32x16 acc0, acc1;
 #pragma unroll
                     for (int i = 0; i < 16; ++i) { const float b = tail[(lh * MT + m) * 16 + i]; acc0[i] = b; acc1[i] = b; }
-                    const char* imgm = img + m * nks * 1024 + lane * 16;
-                    if (jj == 0) mma_rowtile<KS0, KSMAX>(imgm, B, acc0, acc1);
-                    else mma_rowtile<KS, KSMAX>(imgm, B, acc0, acc1);
+                    if (jj == 0) mma_rowtile_ring<KS0, MT, KSMAX>(imgl, m, A, B, acc0, acc1);
+                    else mma_rowtile_ring<KS, MT, KSMAX>(imgl, m, A, B, acc0, acc1);
 #pragma unroll
                     for (int i = 0; i < 16; ++i) { acc0[i] = relu1(acc0[i]); acc1[i] = relu1(acc1[i]); }
                     if (last) {
@@ -526,12 +559,15 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                     u32x4 Bn[2][2 * MT];
                     u32x4 mv = {0u, 0u, 0u, 0u};
                     if (lds_mask) mv = *reinterpret_cast<const u32x4*>(mwave + (jj - 1) * 1024);
+                    u32x4 A[NCA_BF_RING];
+                    const char* imgl = img + lane * 16;
+                    ring_prime<KS, MT>(imgl, A);
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
                         f32x16 acc0, acc1;
 #pragma unroll
                         for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-                        mma_rowtile<KS, KSMAX>(img + m * KS * 1024 + lane * 16, B, acc0, acc1);
+                        mma_rowtile_ring<KS, MT, KSMAX>(imgl, m, A, B, acc0, acc1);
 #pragma unroll
                         for (int c = 0; c < 2; ++c) {
                             const char* hp = hblk + c * a.rows_total + lane * 16;
