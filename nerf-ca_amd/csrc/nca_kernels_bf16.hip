@@ -14,6 +14,7 @@
 //         accumulator layout (rows = samples), and those tiles feed the weight-gradient MFMAs as A
 //         (X^T form) and B operands; dW of a whole layer stays in 256 accumulator registers.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "nca_kernels.hpp"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -31,11 +32,10 @@ __device__ __forceinline__ float bf_hi(unsigned w) { return __builtin_bit_cast(f
 __device__ __forceinline__ bf16x8 frag(u32x4 x) { return __builtin_bit_cast(bf16x8, x); }
 // scratch blocks are written once and read once by another kernel: stream them past the caches
 __device__ __forceinline__ void store_nt(char* p, u32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p)); }
-__device__ __forceinline__ float relu1(float x) {
-    float r;
-    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
-    return r;
-}
+// ReLU as ONE integer max on the bit pattern (negative floats and -0 are negative integers): no canonicalising
+// v_max x,x,x in front as fmaxf would get, and -- unlike an inline-asm v_max_f32 -- visible to the compiler's hazard
+// recogniser, which must put the wait states between an MFMA and the first VALU read of its result.
+__device__ __forceinline__ float relu1(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
 
 // ------------------------------------------------------------------------------------------
 // pack
@@ -387,17 +387,19 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                 char* const hblk = BWD ? nb + EB + jj * HB : nullptr;            // input block of layer jj+1
                 u32x4 Bn[2][2 * MT];
                 unsigned mw[2][2] = {{0u, 0u}, {0u, 0u}};     // mask words: [column tile][row-tile pair]
-                u32x4 A[NCA_BF_RING];
                 const char* imgl = img + lane * 16;
-                if (jj == 0) ring_prime<KS0, MT>(imgl, A);
-                else ring_prime<KS, MT>(imgl, A);
+                // one instantiation per k-step count (encoded layer / hidden layers): no control-flow join inside the
+                // row-tile loop, so accumulators and ring registers are never copied at a merge point
+                auto rowtiles = [&](auto nks_c) __attribute__((always_inline)) {
+                constexpr int NKS = decltype(nks_c)::value;
+                u32x4 A[NCA_BF_RING];
+                ring_prime<NKS, MT>(imgl, A);
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
                     f32x16 acc0, acc1;
 #pragma unroll
                     for (int i = 0; i < 16; ++i) { const float b = tail[(lh * MT + m) * 16 + i]; acc0[i] = b; acc1[i] = b; }
-                    if (jj == 0) mma_rowtile_ring<KS0, MT, KSMAX>(imgl, m, A, B, acc0, acc1);
-                    else mma_rowtile_ring<KS, MT, KSMAX>(imgl, m, A, B, acc0, acc1);
+                    mma_rowtile_ring<NKS, MT, KSMAX>(imgl, m, A, B, acc0, acc1);
 #pragma unroll
                     for (int i = 0; i < 16; ++i) { acc0[i] = relu1(acc0[i]); acc1[i] = relu1(acc1[i]); }
                     if (last) {
@@ -442,6 +444,9 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                         }
                     }
                 }
+                };
+                if (jj == 0) rowtiles(std::integral_constant<int, KS0>{});
+                else rowtiles(std::integral_constant<int, KS>{});
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
