@@ -338,6 +338,69 @@ class CompositeTrainer:
         return {"test_mse": mse, "test_psnr_mse": -10.0 * torch.log10(mse), "pred": pred}
 
 
+class StaticTrainer:
+    """The static-only loop of train/run_nerf.py:186-231 (BASELINE configs[0]) around the fused single-field render:
+    loss = weighted MSE + occl_weight_start * sum(compute_occl_loss(sigma, dists, occl_reg_perc)); Adam + LinearLR.
+    Ray sharding and the gradient all-reduce work as in ``CompositeTrainer``."""
+
+    def __init__(self, cfg: TrainConfig, static_model, data, device, rank: int = 0, world: int = 1, seed: int = 0,
+                 fused_adam: Optional[bool] = None):
+        self.cfg, self.s, self.data, self.device = cfg, static_model, data, device
+        self.rank, self.world, self.seed = rank, world, seed
+        self.params = [p for _, p in static_model.named_parameters()]          # run_nerf.py:159-161
+        kw = {}
+        if fused_adam is None:
+            fused_adam = torch.device(device).type == "cuda"
+        if fused_adam:
+            kw["fused"] = True
+        self.opt = torch.optim.Adam([{"params": self.params, "lr": cfg.lr}], lr=cfg.lr, **kw)
+        self.sched = torch.optim.lr_scheduler.LinearLR(self.opt, start_factor=1, end_factor=cfg.lr_end_factor, total_iters=cfg.lr_decay_steps)
+        self.depth = MH_depth(data.geo, cfg.depth_samples_per_ray_coarse, device)
+        self.I0 = torch.full((cfg.img_sample_size,), data.geo["max_pixel_value"], dtype=torch.float32, device=device)
+        self.n_var = int((cfg.var_sample_perc / 100.0) * cfg.img_sample_size) if cfg.var_sample_perc > 0 else 0
+        self._dev_gen = None
+
+    def update_window(self, n_iter: int) -> None:
+        """run_nerf.py:191-197."""
+        c = self.cfg
+        if c.static_pos_enc == "nerfies_windowed" and n_iter > 0:
+            self.s.update_windowed_alpha(n_iter, c.static_pos_enc_window_decay_steps)
+        elif c.static_pos_enc == "free_windowed":
+            self.s.update_freq_mask_alpha(n_iter, c.static_pos_enc_window_decay_steps)
+
+    draw_ray_ids = CompositeTrainer.draw_ray_ids
+    draw_ray_ids_device = CompositeTrainer.draw_ray_ids_device
+    draw_jitter = CompositeTrainer.draw_jitter
+
+    def loss_on(self, n_iter: int, origins, directions, I0, gt, w, t_rand, share: float = 1.0):
+        """Loss of one ray set (run_nerf.py:218-226); ``share`` = local / global ray count under sharding."""
+        c = self.cfg
+        pix, sigma, dists = MH.obtain_train_predictions_static(self.s, origins, directions, I0, self.depth, c.output_activation,
+                                                               c.batch_size, self.device, t_rand=t_rand)
+        pixel = MH.weighted_MSELoss()(pix, gt, w).mean() * share
+        occl = torch.sum(MH.compute_occl_loss(sigma, dists, c.occl_reg_perc)) * share
+        return pixel + c.occl_weight_start * occl, pixel, occl, pix
+
+    def step(self, n_iter: int):
+        c = self.cfg
+        self.update_window(n_iter)
+        on_gpu = torch.device(self.device).type == "cuda"
+        ids = self.draw_ray_ids_device(n_iter) if on_gpu else self.draw_ray_ids(n_iter)
+        R = len(ids)
+        lo, hi = (R * self.rank) // self.world, (R * (self.rank + 1)) // self.world
+        my = ids[lo:hi] if torch.is_tensor(ids) else torch.as_tensor(ids[lo:hi], device=self.device)
+        rays = self.data.rays_train.index_select(0, my)
+        loss, pixel, occl, _ = self.loss_on(n_iter, rays[:, 0, :], rays[:, 1, :], self.I0[: hi - lo], rays[:, 2, 0], rays[:, 3, 0],
+                                            self.draw_jitter(n_iter), share=(hi - lo) / R)
+        self.opt.zero_grad(set_to_none=True)
+        loss.backward()
+        if self.world > 1:
+            CompositeTrainer.allreduce_grads(self)
+        self.opt.step()
+        self.sched.step()
+        return loss.detach(), pixel.detach(), occl.detach()
+
+
 def MH_depth(geo, n, device):
     from .data_helpers import create_depth_values
     return create_depth_values(geo["near_thresh"], geo["far_thresh"], n, device)

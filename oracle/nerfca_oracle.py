@@ -597,3 +597,41 @@ class OracleTrainer:
         self.opt.step()
         self.sched.step()
         return loss.detach(), pixel.detach(), terms
+
+
+class OracleStaticTrainer:
+    """One reference-equivalent iteration of the static-only loop (train/run_nerf.py:186-231): stratified depths,
+    static render, weighted MSE + occl_weight_start * sum(compute_occl_loss), Adam + LinearLR."""
+
+    def __init__(self, ps, spec, lr=1e-3, lr_end_factor=0.01, lr_decay_steps=150000, occl_weight_start=1e-8, occl_reg_perc=0.2,
+                 act="softplus", window_decay_steps=150000):
+        self.spec = spec
+        self.ps = {k: v.clone().requires_grad_(True) for k, v in ps.items()}
+        plist = list(self.ps.values())
+        self.opt = torch.optim.Adam([{"params": plist, "lr": lr}], lr=lr)
+        self.sched = torch.optim.lr_scheduler.LinearLR(self.opt, start_factor=1, end_factor=lr_end_factor, total_iters=lr_decay_steps)
+        self.occl_weight_start, self.occl_reg_perc, self.act = occl_weight_start, occl_reg_perc, act
+        self.window_decay_steps = window_decay_steps
+
+    def window(self, n_iter):
+        spec = self.spec
+        if spec.pos_enc == "free_windowed":
+            return freq_mask_alpha(spec.pos_enc_basis, n_iter, self.window_decay_steps, spec.pos_enc_window_start)[0]
+        if spec.pos_enc == "nerfies_windowed":
+            return nerfies_window(spec.pos_enc_basis, windowed_alpha(spec.pos_enc_basis, n_iter, self.window_decay_steps))
+        return None
+
+    def loss(self, n_iter, origins, directions, I0, z_jit, gt, wpix):
+        pix, sig, dists = predict_static(self.ps, self.spec, self.window(n_iter), origins, directions, I0, z_jit, self.act)
+        pixel = weighted_mse(pix, gt, wpix).mean()
+        occl = torch.sum(occlusion(sig, dists, self.occl_reg_perc))
+        return pixel + self.occl_weight_start * occl, pixel, occl, pix, sig
+
+    def step(self, n_iter, origins, directions, I0, z_jit, gt, wpix):
+        loss, pixel, occl, _, _ = self.loss(n_iter, origins, directions, I0, z_jit, gt, wpix)
+        self.opt.zero_grad()
+        loss.backward()
+        self.opt.step()
+        self.sched.step()
+        return loss.detach(), pixel.detach(), occl.detach()
+

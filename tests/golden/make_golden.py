@@ -363,6 +363,53 @@ def gen_full_step():
     npz("full_step", **out)
 
 
+
+# ----------------------------------------------------------------------------------- (7b)
+def gen_static_step():
+    """Three iterations of the body of train/run_nerf.py:186-231 (BASELINE configs[0]: static CPPN, 64 samples per
+    ray): obtain_train_predictions_static, weighted MSE + occl_weight_start * occlusion, Adam + LinearLR."""
+    out = {}
+    R, S = 96, 64
+    torch.manual_seed(8000)
+    s = CPPN(static_def(F=64))
+    out.update(sd(s, "init_sp_"))
+    plist = [p for _, p in s.named_parameters()]
+    opt = torch.optim.Adam([{"params": plist, "lr": 1e-3}], lr=1e-3)
+    sched = torch.optim.lr_scheduler.LinearLR(opt, start_factor=1, end_factor=0.01, total_iters=150000)
+    o, d, _ = sample_rays(R, np.float64, 80)
+    rng = np.random.default_rng(81)
+    gt = torch.from_numpy(rng.uniform(0.5, 2.0, R))
+    wpix = torch.from_numpy(1 + rng.uniform(0, 1, R))
+    z = DH.create_depth_values(3.4259, 5.5741, S, DEV)
+    I0 = torch.full((R,), float(np.log(8.670397)))
+    out["o"], out["d"], out["gt"], out["wpix"], out["z"], out["I0"] = o, d, gt, wpix, z, I0
+    occl_w, perc = 1e-2, 0.2          # larger than composite.txt's 1e-8 so the term is visible in the gradients
+    out["occl_weight_start"], out["occl_reg_perc"] = np.array(occl_w), np.array(perc)
+    base_iter = 60000
+    for k in range(3):
+        n_iter = base_iter + k
+        s.update_freq_mask_alpha(n_iter, 150000)
+        seed = 8100 + k
+        torch.manual_seed(seed)
+        pix, sig, dists = MH.obtain_train_predictions_static(s, o, d, I0, z, "softplus", 32768, DEV)
+        torch.manual_seed(seed)
+        out[f"step{k}_t_rand"] = torch.rand(z.shape)
+        pixel = MH.weighted_MSELoss()(pix, gt, wpix).mean()
+        occl = torch.sum(MH.compute_occl_loss(sig, dists, perc))
+        loss = pixel + occl_w * occl
+        opt.zero_grad()
+        loss.backward()
+        out[f"step{k}_loss"], out[f"step{k}_pixel"], out[f"step{k}_occl"], out[f"step{k}_pix"] = loss, pixel, occl, pix
+        if k == 0:
+            out.update(grads(s, "step0_sg_"))
+            out["step0_sigma"] = sig
+        opt.step()
+        sched.step()
+    out.update(sd(s, "final_sp_"))
+    out["base_iter"] = np.array(base_iter)
+    npz("static_step", **out)
+
+
 # ----------------------------------------------------------------------------------- (8)
 def gen_geometry():
     out = {}
@@ -452,6 +499,6 @@ def gen_checkpoint_keys():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["posenc", "mlps", "depth", "predict_iter", "render", "losses", "full_step", "geometry", "schedules", "checkpoint_keys"]
+    which = sys.argv[1:] or ["posenc", "mlps", "depth", "predict_iter", "render", "losses", "full_step", "static_step", "geometry", "schedules", "checkpoint_keys"]
     for w in which:
         globals()["gen_" + w]()

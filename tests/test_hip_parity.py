@@ -812,3 +812,91 @@ def test_graph_step_matches_eager_step(dev, prec):
     for a, b in zip(*[o[0] for o in outs]):
         assert abs(a - b) <= tol * abs(a), (outs[0][0], outs[1][0])
     assert rel_err(outs[1][1], outs[0][1]) < (1e-5 if prec == "f32" else 1e-3)
+
+
+def test_static_training_steps_vs_reference(golden, dev):
+    """BASELINE configs[0] on the GPU: three iterations of the static-only loop (train/run_nerf.py:186-231) through
+    StaticTrainer.loss_on + Adam/LinearLR against the reference's own trajectory (tests/golden/static_step.npz)."""
+    from nerfca_amd.train.trainer import StaticTrainer, TrainConfig
+    g = golden("static_step")
+    s = make_static(g.prefixed("init_sp_"), dev, F=64, early=4, late=0)
+    R, S = g["o"].shape[0], g["z"].shape[0]
+    cfg = TrainConfig(depth_samples_per_ray_coarse=S, img_sample_size=R, occl_weight_start=float(g["occl_weight_start"]),
+                      occl_reg_perc=float(g["occl_reg_perc"]))
+    geo = {"near_thresh": 3.4259, "far_thresh": 5.5741, "max_pixel_value": float(g["I0"][0])}
+    from types import SimpleNamespace
+    tr = StaticTrainer(cfg, s, SimpleNamespace(geo=geo), dev, fused_adam=False)
+    assert torch.equal(tr.depth.cpu(), g["z"])
+    o, d, gt, w, I0 = (g[k].to(dev) for k in ("o", "d", "gt", "wpix", "I0"))
+    base = int(g["base_iter"])
+    for k in range(3):
+        n_iter = base + k
+        tr.update_window(n_iter)
+        loss, pixel, occl, pix = tr.loss_on(n_iter, o, d, I0, gt, w, g[f"step{k}_t_rand"])
+        assert pix.dtype == g[f"step{k}_pix"].dtype
+        assert rel_err(pix.cpu(), g[f"step{k}_pix"]) < TOL
+        assert abs(float(loss.detach()) - float(g[f"step{k}_loss"])) <= TOL * abs(float(g[f"step{k}_loss"]))
+        assert abs(float(occl.detach()) - float(g[f"step{k}_occl"])) <= TOL * abs(float(g[f"step{k}_occl"]))
+        tr.opt.zero_grad()
+        loss.backward()
+        if k == 0:
+            for name, gr in g.prefixed("step0_sg_").items():
+                assert rel_err(dict(s.named_parameters())[name].grad.cpu(), gr) < TOL, name
+        tr.opt.step()
+        tr.sched.step()
+    for name, v in g.prefixed("final_sp_").items():      # Adam amplifies rounding noise of near-zero gradient entries
+        assert rel_err(dict(s.named_parameters())[name].detach().cpu(), v) < 1e-4, name
+
+
+# ----------------------------------------------------------------------------- BASELINE.json full sizes
+@pytest.mark.parametrize("prec,R,S", [("bf16", 65536, 192), ("f32", 16384, 256)])
+def test_full_size_properties(dev, prec, R, S):
+    """configs[1] (one full 256^2 detector x 192 samples, bf16) and configs[3]'s ray shape (256 samples per ray, f32)
+    through properties that do not need the oracle at that size:
+      * checksum: pix == I0 - sum_s fl32(sigma_s + sigma_d) * dists, recomputed from the returned fields;
+      * rays are independent units: rendering a permuted batch gives the permuted outputs BIT for bit, and changing
+        the phase of some rays changes those rays only;
+      * a 1/64 subsample of the rays agrees with the oracle (which finishes those in seconds)."""
+    import dataclasses
+    from nerfca_amd import render_rays, set_precision
+    gen = torch.Generator().manual_seed(21)
+    ss, sd = O.NetSpec(num_filters=128), O.NetSpec(num_filters=128, num_time_dim=8)
+    ps, pd = O.init_params(ss, gen), O.init_params(sd, gen)
+    s = make_static(ps, dev, F=128, early=4, late=0)
+    t = make_dynamic(pd, dev, F=128, early=4, late=0, T=8)
+    set_precision(prec, s, t)
+    for m in (s, t):
+        m.update_freq_mask_alpha(75000, 150000)
+    o = (torch.rand(R, 3, generator=gen) * 0.2 + torch.tensor([3.0, -2.0, 2.5])).double()
+    d = (torch.rand(R, 3, generator=gen) - 0.5).double()
+    ph = torch.randint(0, 10, (R,), generator=gen)
+    z = O.stratified_depths(O.depth_values(3.4259, 5.5741, S), torch.rand(S, generator=gen))
+    dists = O.ray_dists(z, torch.float64)
+    I0 = torch.full((R,), 2.15991)
+    args = [x.to(dev) for x in (o, d, ph, I0, z, dists)]
+    with torch.no_grad():
+        pix, a, b = render_rays(s, t, *args)
+        # checksum of the ray sums
+        chk = args[3].double() - ((a + b).double() * args[5]).sum(-1)
+        assert pix.dtype == torch.float64 and rel_err(pix, chk) < 1e-12
+        # permutation equivariance, bit-exact
+        perm = torch.randperm(R, generator=gen).to(dev)
+        pix_p, a_p, b_p = render_rays(s, t, args[0][perm], args[1][perm], args[2][perm], args[3][perm], args[4], args[5])
+        assert torch.equal(pix_p, pix[perm]) and torch.equal(a_p, a[perm]) and torch.equal(b_p, b[perm])
+        # phases touch the dynamic field of their own rays only
+        ph2 = args[2].clone()
+        ph2[::7] = (ph2[::7] + 3) % 10
+        pix_q, a_q, b_q = render_rays(s, t, args[0], args[1], ph2, args[3], args[4], args[5])
+        keep = torch.ones(R, dtype=torch.bool, device=dev)
+        keep[::7] = False
+        assert torch.equal(a_q, a) and torch.equal(b_q[keep], b[keep]) and torch.equal(pix_q[keep], pix[keep])
+        assert not torch.equal(b_q[~keep], b[~keep])
+    # oracle on a strided subsample
+    sub = slice(0, R, 64)
+    emu = prec == "bf16"
+    sse, sde = dataclasses.replace(ss, emulate_bf16=emu), dataclasses.replace(sd, emulate_bf16=emu)
+    win = O.freq_mask_alpha(12, 75000, 150000, 1)[0]
+    with torch.no_grad():
+        po, ao, bo, _ = O.predict_iter(ps, sse, win, pd, sde, win, o[sub], d[sub], ph[sub][:, None].repeat(1, S), I0[sub], z)[:4]
+    tol = BF_OUT if emu else TOL
+    assert rel_err(pix[sub].cpu(), po) < tol and rel_err(a[sub].cpu(), ao) < tol and rel_err(b[sub].cpu(), bo) < tol

@@ -251,6 +251,33 @@ def test_full_training_steps(golden):
         assert rel_err(tr.pd[name], v) < 1e-5, name
 
 
+def test_static_training_steps(golden):
+    """BASELINE configs[0]: the static-only loop of train/run_nerf.py on the reference's own trajectory."""
+    g = golden("static_step")
+    spec = spec_from(64, 4, 0)
+    tr = O.OracleStaticTrainer(g.prefixed("init_sp_"), spec, occl_weight_start=float(g["occl_weight_start"]),
+                               occl_reg_perc=float(g["occl_reg_perc"]))
+    base = int(g["base_iter"])
+    for k in range(3):
+        n_iter = base + k
+        zj = O.stratified_depths(g["z"], g[f"step{k}_t_rand"])
+        if k == 0:
+            loss, _, _, pix, sig = tr.loss(n_iter, g["o"], g["d"], g["I0"], zj, g["gt"], g["wpix"])
+            loss.backward()
+            assert rel_err(pix, g["step0_pix"]) < 1e-6 and pix.dtype == g["step0_pix"].dtype
+            assert rel_err(sig, g["step0_sigma"]) < 1e-6
+            for name, gr in g.prefixed("step0_sg_").items():
+                assert rel_err(tr.ps[name].grad, gr) < 1e-5, name
+        loss, pixel, occl = tr.step(n_iter, g["o"], g["d"], g["I0"], zj, g["gt"], g["wpix"])
+        assert rel_err(loss, g[f"step{k}_loss"]) < 1e-6
+        assert rel_err(pixel, g[f"step{k}_pixel"]) < 1e-6
+        assert rel_err(occl, g[f"step{k}_occl"]) < 1e-6
+    # after Adam: the normalised step m/sqrt(v) turns rounding noise of near-zero gradient entries (which depends on the
+    # BLAS thread count of the run that made the fixture) into O(lr * 1e-3) parameter differences
+    for name, v in g.prefixed("final_sp_").items():
+        assert rel_err(tr.ps[name], v) < 1e-4, name
+
+
 # ------------------------------------------------------------------------------- (8) geometry
 VIEWS = [[-30, 30], [-30, -30], [60, -30], [60, 30], [-5, 40]]
 
