@@ -321,21 +321,43 @@ class CompositeTrainer:
         for g, r in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
             g.copy_(r)
 
-    # -- held-out view (run_composite.py:346-403) ------------------------------------------------
+    # -- held-out view (run_composite.py:346-413) ------------------------------------------------
     @torch.no_grad()
     def evaluate(self, n_iter: int, chunk_rays: int = 65536):
-        c, d = self.cfg, self.data
-        z = MH.randomize_depth(self.depth, self.device, torch.full(self.depth.shape, 0.5))
+        """The display_every block of the reference: render the held-out view (one fixed depth jitter drawn at set-up,
+        run_composite.py:134), the weighted pixel loss with unit weights, all loss terms and ``test_loss`` with this
+        iteration's weights, ``test_psnr = -10 log10(test_loss)`` (the reference's definition, :391), and the static /
+        dynamic images each field renders on its own (:407-413; un-normalised ``I0 - sum sigma dists``)."""
+        c, d, dev = self.cfg, self.data, self.device
+        if getattr(self, "_test_jitter", None) is None:
+            self._test_jitter = torch.rand(self.depth.shape, generator=torch.Generator().manual_seed(self.seed * 7919 + 1))
+        z = MH.randomize_depth(self.depth, dev, self._test_jitter)
         dists = MH._interval_lengths(z, d.test_directions)
-        out = []
+        pix, sig_s, sig_d = [], [], []
         for i in range(0, d.test_origins.shape[0], chunk_rays):
             o, dd = d.test_origins[i:i + chunk_rays], d.test_directions[i:i + chunk_rays]
-            ph = torch.full((o.shape[0],), d.test_phase, dtype=torch.int32, device=self.device)
-            I0 = torch.full((o.shape[0],), d.geo["max_pixel_value"], dtype=torch.float32, device=self.device)
-            out.append(self.render(self.s, self.t, o, dd, ph, I0, z, dists, act=c.output_activation)[0].float())
-        pred = torch.cat(out)
-        mse = ((pred - d.test_image) ** 2).mean()
-        return {"test_mse": mse, "test_psnr_mse": -10.0 * torch.log10(mse), "pred": pred}
+            ph = torch.full((o.shape[0],), d.test_phase, dtype=torch.int32, device=dev)
+            I0 = torch.full((o.shape[0],), d.geo["max_pixel_value"], dtype=torch.float32, device=dev)
+            p, a, b = self.render(self.s, self.t, o, dd, ph, I0, z, dists, act=c.output_activation)
+            pix.append(p); sig_s.append(a); sig_d.append(b)
+        pix, sig_s, sig_d = torch.cat(pix), torch.cat(sig_s), torch.cat(sig_d)
+        gt = d.test_image.to(pix.dtype)
+        ones = torch.ones_like(gt)
+        pixel = MH.weighted_MSELoss()(pix, gt, ones).mean()
+        terms = LS.all_terms(sig_s, sig_d, dists, ones, c)
+        fav_w, ent_w, occ_w, l1_w = self.loss_weights(n_iter)
+        test_loss = pixel + fav_w * terms[3] + ent_w * terms[6] + occ_w * terms[8] + l1_w * terms[10] + l1_w * terms[9]
+        I0 = d.geo["max_pixel_value"]
+        mse = ((pix.float() - d.test_image) ** 2).mean()
+        return {"test_loss": test_loss, "test_psnr": -10.0 * torch.log10(test_loss), "test_pixel_loss_coarse": pixel,
+                "test_favor_s_loss": terms[3], "test_blendw": terms[0], "test_s_entropy_loss": terms[4], "test_d_entropy_loss": terms[6],
+                "test_mse": mse, "test_psnr_mse": -10.0 * torch.log10(mse), "pred": pix.float(),
+                "pred_static": (I0 - (sig_s.double() * dists).sum(-1)).float(), "pred_dynamic": (I0 - (sig_d.double() * dists).sum(-1)).float()}
+
+
+def normalize_image(img: torch.Tensor) -> torch.Tensor:
+    """(x - min) / (max - min), as the reference does before logging images (run_composite.py:405-413)."""
+    return (img - img.min()) / (img.max() - img.min())
 
 
 class StaticTrainer:

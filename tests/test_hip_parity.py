@@ -900,3 +900,49 @@ def test_full_size_properties(dev, prec, R, S):
         po, ao, bo, _ = O.predict_iter(ps, sse, win, pd, sde, win, o[sub], d[sub], ph[sub][:, None].repeat(1, S), I0[sub], z)[:4]
     tol = BF_OUT if emu else TOL
     assert rel_err(pix[sub].cpu(), po) < tol and rel_err(a[sub].cpu(), ao) < tol and rel_err(b[sub].cpu(), bo) < tol
+
+
+def test_evaluate_matches_reference_display_block(dev):
+    """CompositeTrainer.evaluate = the display_every block of run_composite.py:346-413, checked against the oracle run
+    on the same held-out view: pixel loss, loss terms, test_loss / test_psnr, and the per-field images."""
+    from nerfca_amd import synthetic
+    from nerfca_amd.model.CPPN import CPPN
+    from nerfca_amd.model.Temporal import Temporal
+    from nerfca_amd.train.trainer import CompositeTrainer, TrainConfig
+    S = 48
+    data = synthetic.make_dataset(16, S, dev, views=synthetic.TRAIN_VIEWS[:2], n_phases=3, F=32)
+    torch.manual_seed(4)
+    sdef, tdef = synthetic.net_definitions(dev, F=64)
+    s, t = CPPN(sdef).to(dev), Temporal(tdef).to(dev)
+    cfg = TrainConfig(depth_samples_per_ray_coarse=S, img_sample_size=256, favor_s_weight_delay_steps=0, l1_weight_start=1e-3,
+                      occl_weight_start=1e-2, dynamic_entro_weight_start=1e-3, favor_s_weight_start=1e-3, entro_mask_thre=1e-6)
+    tr = CompositeTrainer(cfg, s, t, data, dev, seed=5)
+    n_iter = 1234
+    tr.update_windows(n_iter)
+    ev = tr.evaluate(n_iter)
+    # oracle on the same inputs
+    ss, sd = O.NetSpec(num_filters=64), O.NetSpec(num_filters=64, num_time_dim=8)
+    ps = {k: v.detach().cpu() for k, v in s.state_dict().items()}
+    pd = {k: v.detach().cpu() for k, v in t.state_dict().items()}
+    win = O.freq_mask_alpha(12, n_iter, 150000, 1)[0]
+    zj = O.stratified_depths(tr.depth.cpu(), tr._test_jitter)
+    o, d = data.test_origins.cpu(), data.test_directions.cpu()
+    R = o.shape[0]
+    ph = torch.full((R, S), data.test_phase)
+    I0 = torch.full((R,), data.geo["max_pixel_value"])
+    with torch.no_grad():
+        pix, a, b, dists = O.predict_iter(ps, ss, win, pd, sd, win, o, d, ph, I0, zj)[:4]
+        gt, ones = data.test_image.cpu().to(pix.dtype), torch.ones(R, dtype=pix.dtype)
+        pixel = O.weighted_mse(pix, gt, ones).mean()
+        terms = O.compute_losses(a, b, dists, ones, O.LossArgs(entro_mask_thre=1e-6))
+        fw, ew, ow, lw = tr.loss_weights(n_iter)
+        loss = pixel + fw * terms[3] + ew * terms[6] + ow * terms[8] + lw * terms[10] + lw * terms[9]
+    assert rel_err(ev["pred"].cpu(), pix.float()) < TOL
+    assert abs(float(ev["test_pixel_loss_coarse"]) - float(pixel)) <= 1e-4 * abs(float(pixel))
+    assert abs(float(ev["test_loss"]) - float(loss)) <= 1e-4 * abs(float(loss))
+    assert abs(float(ev["test_psnr"]) - float(-10.0 * torch.log10(loss))) < 1e-3
+    for key, idx in (("test_blendw", 0), ("test_favor_s_loss", 3), ("test_s_entropy_loss", 4), ("test_d_entropy_loss", 6)):
+        assert abs(float(ev[key]) - float(terms[idx])) <= 1e-4 * abs(float(terms[idx])) + 1e-12, key
+    st = (I0.double() - (a.double() * dists).sum(-1)).float()
+    dy = (I0.double() - (b.double() * dists).sum(-1)).float()
+    assert rel_err(ev["pred_static"].cpu(), st) < TOL and rel_err(ev["pred_dynamic"].cpu(), dy) < TOL
