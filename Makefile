@@ -15,6 +15,7 @@ all: $(OUT)
 	$(HIPCC) $(FLAGS) $(EXTRA) -c $< -o $@
 
 $(OUT): $(OBJS)
+	@mkdir -p $(dir $@)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -o $@
 
 clean:

@@ -131,7 +131,7 @@ def test_render_forward_vs_reference(golden, dev, R, S, dtn):
     assert all(v is None for v in res[4:])
 
 
-def _oracle_render_grads(ps, ss, pd, sd, win, o, d, ph, I0, z, cp, cs, cd, dt):
+def _oracle_render_grads(ps, ss, pd, sd, win, o, d, ph, I0, z, cp, cs, cd, dt, win_d=None):
     """Outputs and all parameter gradients of the oracle evaluated in dtype `dt` (same f32 query points)."""
     S = z.shape[0]
     pso = {k: v.clone().to(dt).requires_grad_(True) for k, v in ps.items()}
@@ -139,7 +139,7 @@ def _oracle_render_grads(ps, ss, pd, sd, win, o, d, ph, I0, z, cp, cs, cd, dt):
     pts = O.query_points(o, d, z).to(dt)
     w = win.to(dt)
     raw_s = O.static_forward(pso, ss, pts, w).reshape(o.shape[0], S, -1)
-    raw_d = O.dynamic_forward(pdo, sd, pts, ph[:, None].repeat(1, S).flatten(), w).reshape(o.shape[0], S, -1)
+    raw_d = O.dynamic_forward(pdo, sd, pts, ph[:, None].repeat(1, S).flatten(), w if win_d is None else win_d.to(dt)).reshape(o.shape[0], S, -1)
     pix, a, b, dists = O.composite(raw_s, raw_d, I0.to(dt), d, z.to(dt))
     ((pix * cp).sum() + (a * cs).sum() * 50 + (b * cd).sum() * 50).backward()
     return pix, a, b, dists, pso, pdo
@@ -301,14 +301,16 @@ def test_bf16_points_vs_emulating_oracle(golden, dev, F, early):
         assert rel_err(gd[k], pdo[k].grad) < BF_GRAD, ("dynamic", k)
 
 
-def _oracle_render_grads_bf16(ps, ss, pd, sd, win, o, d, ph, I0, z, cp, cs, cd):
+def _oracle_render_grads_bf16(ps, ss, pd, sd, win, o, d, ph, I0, z, cp, cs, cd, win_d=None):
     import dataclasses
     return _oracle_render_grads(ps, dataclasses.replace(ss, emulate_bf16=True), pd, dataclasses.replace(sd, emulate_bf16=True),
-                                win, o, d, ph, I0, z, cp, cs, cd, torch.float32)
+                                win, o, d, ph, I0, z, cp, cs, cd, torch.float32, win_d=win_d)
 
 
 @pytest.mark.parametrize("R,S,F", [(8, 16, 32), (33, 50, 64), (64, 192, 128), (7, 500, 128)])
-def test_bf16_render_vs_emulating_oracle(dev, R, S, F):
+@pytest.mark.parametrize("it_d", [75000, 30000])
+def test_bf16_render_vs_emulating_oracle(dev, R, S, F, it_d):
+    """it_d == 75000: both nets use the same band window (the composite.txt default); 30000: a different window per net."""
     from nerfca_amd import render_rays, set_precision
     gen = torch.Generator().manual_seed(4321 + R + S)
     ss = O.NetSpec(num_filters=F, num_early_layers=3, num_time_dim=0)
@@ -322,12 +324,13 @@ def test_bf16_render_vs_emulating_oracle(dev, R, S, F):
     z = O.stratified_depths(O.depth_values(3.4259, 5.5741, S), torch.rand(S, generator=gen))
     I0 = torch.full((R,), 2.15991)
     cp, cs, cd = torch.randn(R, generator=gen).double(), torch.randn(R, S, generator=gen), torch.randn(R, S, generator=gen)
-    pix, a, b, dists, pse, pde = _oracle_render_grads_bf16(ps, ss, pd, sd, win, o, d, ph, I0, z, cp, cs, cd)
+    win_d = O.freq_mask_alpha(12, it_d, 150000, 1)[0]
+    pix, a, b, dists, pse, pde = _oracle_render_grads_bf16(ps, ss, pd, sd, win, o, d, ph, I0, z, cp, cs, cd, win_d=win_d)
     s = make_static(ps, dev, F=F, early=3, late=0)
     t = make_dynamic(pd, dev, F=F, early=3, late=0, T=8)
     set_precision("bf16", s, t)
     s.update_freq_mask_alpha(75000, 150000)
-    t.update_freq_mask_alpha(75000, 150000)
+    t.update_freq_mask_alpha(it_d, 150000)
     pix2, a2, b2 = render_rays(s, t, o.to(dev), d.to(dev), ph.to(dev), I0.to(dev), z.to(dev), dists.to(dev))
     assert pix2.dtype == torch.float64 and tuple(a2.shape) == (R, S)
     assert rel_err(a2.cpu(), a) < BF_OUT and rel_err(b2.cpu(), b) < BF_OUT

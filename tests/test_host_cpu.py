@@ -240,3 +240,15 @@ def test_precision_switch_is_per_model_pair():
     late = CPPN(model_def(F=32, early=1, late=2))
     assert lib.nca_packed_bytes(C.byref(late._binding.net), _capi.PREC_BF16) == -2 and b"bf16" in lib.nca_last_error()
     assert lib.nca_packed_bytes(C.byref(late._binding.net), _capi.PREC_F32) > 0
+
+
+def test_graft_entry_build_contract():
+    """__graft_entry__.build() must succeed here (hipcc cross-compiles without a GPU) and agree with the header's ABI
+    version; the Makefile must create the output directory itself (it is git-ignored, so absent in a fresh clone)."""
+    import __graft_entry__ as G
+    G.build()
+    header = open(os.path.join(ROOT, "include", "nerfca_hip.h")).read()
+    ver = int(re.search(r"#define NCA_ABI_VERSION (\d+)", header).group(1))
+    from nerfca_amd import _capi
+    assert _capi.lib().nca_abi_version() == ver
+    assert "mkdir -p" in open(os.path.join(ROOT, "Makefile")).read()
