@@ -55,7 +55,8 @@ struct NcaFusedArgs {
     float* oslab;        // [grid][2][F+1] output-layer gradient partials
     int32_t accumulate;  // add to oslab instead of overwriting (ray chunks after the first)
     int32_t nstages;
-    int32_t mask_layers; // bf16 backward: ReLU masks of this many layers per wave are kept in LDS (0: re-read H)
+    int32_t mask_layers; // backward: ReLU masks of this many layers per wave are kept in LDS (0: re-read H)
+    int32_t const_net_floats; // f32 kernels: floats per net of the LDS constant area (window, fourier, latents), set by the launcher
     int32_t raw_only;    // rays mode, forward: write the raw net output to raw_out[n] instead of compositing
                          // (rays mode, backward: a non-null g_raw replaces the compositing chain rule)
     NcaNetArgs net[2];

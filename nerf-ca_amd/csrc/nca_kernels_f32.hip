@@ -253,14 +253,17 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
     constexpr int BUF = FusedCfg<F>::BUF_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // [buf0][buf1][constants of both nets][per-wave output-layer gradient sums: WAVES x 2 nets x (F+1)]
+    // [buf0][buf1][constants of both nets][per-wave output-layer gradient sums][per-wave ReLU masks: 8 B per lane and layer]
     float* cst = reinterpret_cast<float*>(smem + 2 * BUF);
-    float* osum = reinterpret_cast<float*>(smem + 2 * BUF + NCA_CONST_BYTES);
+    const int cnf = a.const_net_floats;
+    float* osum = cst + 2 * cnf;
+    char* const maskbase = reinterpret_cast<char*>(osum + NCA_WAVES * 2 * (F + 1));
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lj = lane & 31, lh = lane >> 5;
 
     for (int net = 0; net < a.nnets; ++net) {
         const NcaNetArgs& na = a.net[net];
-        float* c = cst + net * NCA_CONST_NET_FLOATS;
+        float* c = cst + net * cnf;
         if (na.win) for (int i = tid; i < na.lay.L; i += NCA_NT) c[i] = na.win[i];
         if (na.four) for (int i = tid; i < 3 * na.lay.L; i += NCA_NT) c[NCA_CONST_WIN + i] = na.four[i];
         if (na.lat) for (int i = tid; i < na.lay.P * na.lay.T; i += NCA_NT) c[NCA_CONST_WIN + NCA_CONST_FOUR + i] = na.lat[i];
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
             const NcaNetArgs& na = a.net[net];
             const NcaLayout& y = na.lay;
             int phc = ph < 0 ? 0 : (ph >= y.P ? y.P - 1 : ph);
-            const float* cnet = cst + net * NCA_CONST_NET_FLOATS;
+            const float* cnet = cst + net * cnf;
             const float* cwin = cnet;
             const float* cfour = cnet + NCA_CONST_WIN;
             const float* lat = y.T > 0 ? cnet + NCA_CONST_WIN + NCA_CONST_FOUR + phc * y.T : nullptr;
@@ -399,6 +402,15 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) hprev[m][i] = fmaxf(acc[m][i], 0.f);
 
+                if (BWD && a.mask_layers > 0 && jj + 1 < y.NL) {
+                    // ReLU mask of this layer's output for the dgrad sweep: bit 16 (m & 1) + i of word m >> 1 <-> acc[m][i]
+                    unsigned mw[2] = {0u, 0u};
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) mw[m >> 1] |= (hprev[m][i] > 0.f ? 1u : 0u) << (16 * (m & 1) + i);
+                    *reinterpret_cast<uint2*>(maskbase + ((wave * a.mask_layers + jj) * 64 + lane) * 8) = make_uint2(mw[0], mw[1]);
+                }
                 if (BWD && jj + 1 < y.NL && tvalid) {
                     // input of layer jj+1, feature-major (waves past the last tile write nothing)
                     float* hh = hs + (y.K0rows_pad + jj * F) * 32;
@@ -513,16 +525,32 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
                     // mask with the stored input of layer jj (= output of layer jj-1), store D_{jj-1}
                     const float* hh = hs + (y.K0rows_pad + (jj - 1) * F) * 32;
                     float* dd = hs + (y.K0rows_pad + (y.NL - 1) * F + (jj - 1) * F) * 32;
+                    if (a.mask_layers > 0) {
+                        const uint2 mv = *reinterpret_cast<const uint2*>(maskbase + ((wave * a.mask_layers + (jj - 1)) * 64 + lane) * 8);
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) {
-                        const float* qh = hh + m * 1024;
-                        float* qd = dd + m * 1024;
-                        asm volatile("" : "+v"(qh), "+v"(qd));
+                        for (int m = 0; m < MT; ++m) {
+                            float* qd = dd + m * 1024;
+                            asm volatile("" : "+v"(qd));
+                            const unsigned fld = ((m >> 1) ? mv.y : mv.x) >> (16 * (m & 1));
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) {
-                            const float dv = qh[nca_rho(i) * 32] > 0.f ? acc[m][i] : 0.f;
-                            hprev[m][i] = dv;
-                            if (tvalid) qd[nca_rho(i) * 32] = dv;
+                            for (int i = 0; i < 16; ++i) {
+                                const float dv = ((fld >> i) & 1u) ? acc[m][i] : 0.f;
+                                hprev[m][i] = dv;
+                                if (tvalid) qd[nca_rho(i) * 32] = dv;
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) {
+                            const float* qh = hh + m * 1024;
+                            float* qd = dd + m * 1024;
+                            asm volatile("" : "+v"(qh), "+v"(qd));
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) {
+                                const float dv = qh[nca_rho(i) * 32] > 0.f ? acc[m][i] : 0.f;
+                                hprev[m][i] = dv;
+                                if (tvalid) qd[nca_rho(i) * 32] = dv;
+                            }
                         }
                     }
                     stage_publish();
@@ -749,8 +777,23 @@ __global__ void nca_pix_f32(int64_t R, int nchunk, const float* __restrict__ I0,
 // launchers (called from nca_api.cpp)
 // ------------------------------------------------------------------------------------------
 template <int F>
-static hipError_t launch_fused_t(const NcaFusedArgs& a, bool bwd, int grid, hipStream_t st) {
-    const size_t lds = 2 * FusedCfg<F>::BUF_BYTES + NCA_CONST_BYTES + (bwd ? NCA_WAVES * 2 * (F + 1) * sizeof(float) : 0);
+static hipError_t launch_fused_t(const NcaFusedArgs& a_in, bool bwd, int grid, hipStream_t st) {
+    NcaFusedArgs a = a_in;
+    // constant area sized to the latents actually present (the cap of 2048 floats per net is rarely needed) ...
+    int lat = 0;
+    for (int n = 0; n < a.nnets; ++n) { const int v = a.net[n].lay.P * a.net[n].lay.T; lat = v > lat ? v : lat; }
+    if (lat > NCA_CONST_LAT) return hipErrorInvalidValue;
+    a.const_net_floats = NCA_CONST_WIN + NCA_CONST_FOUR + ((lat + 15) & ~15);
+    size_t lds = 2 * FusedCfg<F>::BUF_BYTES + 2 * (size_t)a.const_net_floats * 4 + (bwd ? NCA_WAVES * 2 * (F + 1) * sizeof(float) : 0);
+    // ... which leaves room for the ReLU masks of the recomputed layers (8 B per lane and layer): the dgrad sweep
+    // then reads no H back from the scratch.  If they do not fit, it falls back to re-reading H.
+    a.mask_layers = 0;
+    if (bwd) {
+        int ml = 0;
+        for (int n = 0; n < a.nnets; ++n) ml = a.net[n].lay.NL - 1 > ml ? a.net[n].lay.NL - 1 : ml;
+        const size_t need = (size_t)NCA_WAVES * ml * 512;
+        if (ml > 0 && lds + need <= 160 * 1024) { a.mask_layers = ml; lds += need; }
+    }
     if (bwd) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_fused_f32<F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((nca_fused_f32<F, true>), dim3(grid), dim3(NCA_NT), lds, st, a);

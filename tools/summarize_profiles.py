@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/prof_<prec>/ (written by tools/collect_profiles.sh on the GPU box) into the committed summaries:
+    profiles/<tag>_<prec>_bench.json, _bench_under_rocprof.json, _bench_kernel_stats.csv,
+    _pmc_FETCH_SIZE.csv / _pmc_WRITE_SIZE.csv (rows of this library's kernels), _pmc_traffic.json, _pmc_sq.json
+usage: python tools/summarize_profiles.py bf16 [tag=r01]"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+prec = sys.argv[1]
+tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
+src = os.path.join(ROOT, "gpurun_out", f"prof_{prec}")
+dst = os.path.join(ROOT, "profiles")
+KERNELS = {"fwd": f"nca_fused_{prec}<128, false>", "bwd_dgrad": f"nca_fused_{prec}<128, true>",
+           "bwd_wgrad": "nca_wgrad_bf16<128>" if prec == "bf16" else "nca_wgrad_f32", "bwd_reduce": "nca_reduce_f32",
+           "loss": "nca_loss_rays"}
+
+
+def last_json_line(path):
+    lines = [l for l in open(path).read().splitlines() if l.startswith("{")]
+    return json.loads(lines[-1])
+
+
+def find(pattern):
+    hits = glob.glob(os.path.join(src, pattern), recursive=True)
+    if not hits:
+        raise SystemExit(f"missing {pattern} under {src}")
+    return hits[0]
+
+
+bench = last_json_line(os.path.join(src, "bench.json"))
+json.dump(bench, open(os.path.join(dst, f"{tag}_{prec}_bench.json"), "w"))
+json.dump(last_json_line(os.path.join(src, "bench_under_rocprof.json")), open(os.path.join(dst, f"{tag}_{prec}_bench_under_rocprof.json"), "w"))
+with open(find("stats/**/*kernel_stats.csv")) as f, open(os.path.join(dst, f"{tag}_{prec}_bench_kernel_stats.csv"), "w") as g:
+    g.write(f.read())
+
+
+def per_kernel(counter_dir, keep_rows_to=None):
+    rows = list(csv.DictReader(open(find(f"{counter_dir}/**/*counter_collection.csv"))))
+    ours = [r for r in rows if "nca_" in r["Kernel_Name"]]
+    if keep_rows_to:
+        with open(keep_rows_to, "w", newline="") as g:
+            w = csv.DictWriter(g, fieldnames=list(rows[0].keys()))
+            w.writeheader()
+            w.writerows(ours)
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in ours:
+        agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return agg
+
+
+def mean_last(v, n=20):
+    v = v[-n:]
+    return sum(v) / len(v)
+
+
+fetch = per_kernel("pmc_FETCH_SIZE", os.path.join(dst, f"{tag}_{prec}_pmc_FETCH_SIZE.csv"))
+write = per_kernel("pmc_WRITE_SIZE", os.path.join(dst, f"{tag}_{prec}_pmc_WRITE_SIZE.csv"))
+traffic = {"how": "rocprofv3 --pmc FETCH_SIZE (and, in a second run, --pmc WRITE_SIZE) --kernel-trace --output-format csv -- python3 bench.py "
+                  "--steps 2 --warmup 1 --no-cpu-baseline; per-kernel mean over the last <=20 dispatches; bytes = counter * 1024; FETCH_SIZE "
+                  "doubled (gfx950 reports half of a wide coalesced stream, MI355X_MICROARCH.md section HBM); WRITE_SIZE as is",
+           "config": {"prec": prec, "rays_per_step": bench["config"]["rays_per_step_per_gpu"], "samples_per_ray": bench["config"]["samples_per_ray"],
+                      "ray_chunks_per_step": bench["roofline"]["all_kernels"]["bwd_dgrad"]["launches"] // bench["steps"]},
+           "kernels": {}}
+for key, name in KERNELS.items():
+    fk = [k for k in fetch if name in k]
+    wk = [k for k in write if name in k]
+    if not fk or not wk:
+        continue
+    rd = mean_last(fetch[fk[0]]["FETCH_SIZE"]) * 1024 * 2
+    wr = mean_last(write[wk[0]]["WRITE_SIZE"]) * 1024
+    traffic["kernels"][key] = {"kernel": name, "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr}
+json.dump(traffic, open(os.path.join(dst, f"{tag}_{prec}_pmc_traffic.json"), "w"), indent=1)
+
+sq = per_kernel("pmc_SQ")
+out = {"how": "one rocprofv3 --pmc pass (8 SQ counters + GRBM_GUI_ACTIVE) --kernel-trace over bench.py --steps 2 --warmup 1; means per dispatch. "
+              "mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs); wait/active fractions are of SQ_WAVE_CYCLES",
+       "kernels": {}}
+for key, name in KERNELS.items():
+    ks = [k for k in sq if name in k]
+    if not ks:
+        continue
+    d = {c: sum(v) / len(v) for c, v in sq[ks[0]].items()}
+    cyc = d["GRBM_GUI_ACTIVE"] / 8
+    out["kernels"][key] = {"kernel": name, "dispatches": len(sq[ks[0]]["SQ_WAVE_CYCLES"]), "gpu_cycles_per_xcd": cyc,
+                           "mfma_busy": d["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / cyc,
+                           "wait_any": d["SQ_WAIT_ANY"] / d["SQ_WAVE_CYCLES"], "wait_inst_any": d["SQ_WAIT_INST_ANY"] / d["SQ_WAVE_CYCLES"],
+                           "active_inst_any": d["SQ_ACTIVE_INST_ANY"] / d["SQ_WAVE_CYCLES"], "wait_inst_lds": d["SQ_WAIT_INST_LDS"] / d["SQ_WAVE_CYCLES"],
+                           "lds_bank_conflict_cycles": d["SQ_LDS_BANK_CONFLICT"]}
+json.dump(out, open(os.path.join(dst, f"{tag}_{prec}_pmc_sq.json"), "w"), indent=1)
+print(json.dumps({k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items() if kk != "kernel"} for k, v in out["kernels"].items()}, indent=1))
+print({k: round(v["hbm_bytes_per_launch"] / 1e9, 3) for k, v in traffic["kernels"].items()})
+print(bench["value"], bench["ms_per_step"], bench["roofline"]["frac"], bench.get("cpu_baseline", {}).get("value"))
