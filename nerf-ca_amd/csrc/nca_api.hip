@@ -392,6 +392,7 @@ static void add_jobs_f32(NcaWgradArgs* w, const NcaLayout& y, int64_t row0, int6
             g.F = y.F;
             g.d_row0 = drow0 + (int64_t)j * y.F;
             g.b_row0 = hrow0 + (int64_t)(j - 1) * y.F;
+            g.b_frag = 1;
             g.ncols_w = y.F;
             g.P = 0;
             g.b_rows_pad = y.F;

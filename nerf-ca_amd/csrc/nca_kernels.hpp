@@ -66,6 +66,7 @@ struct NcaFusedArgs {
 struct NcaWgradJob {
     int32_t F;            // rows of D
     int32_t b_rows_pad;   // rows of H rounded up to 32
+    int32_t b_frag;       // f32: the H block is in the fused kernel's register order (hidden blocks), not row-major (input block)
     int64_t d_row0, b_row0;
     int32_t ncols_w;      // H rows that are real weight columns
     int32_t P;            // further H rows that are one-hot phase rows

@@ -246,6 +246,16 @@ __device__ __forceinline__ void stage_publish() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 }
+// Backward stages of hidden layers issue exactly NST scratch stores AFTER the weight DMA of the stage (and every load
+// issued in between has been consumed by then).  VMEM operations retire in issue order, so waiting until NST remain
+// outstanding waits for the DMA but not for those stores: the 16 KiB a wave writes per layer drain under the next layer.
+template <int NST>
+__device__ __forceinline__ void stage_publish_counted(bool stores_issued) {
+    if (stores_issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
 
 template <int F, bool BWD>
 __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a) {
@@ -322,7 +332,6 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
         // backward scratch is tile-major: scratch[tile][row][32 columns].  A wave owns one tile, so every
         // row it touches sits at a compile-time offset (row * 128 B) from one per-lane base; lane-half h
         // owns rows rho(i)+4h and carries those 4 rows in its base.
-        float* const tbase = BWD ? a.scratch + (tl * a.rows_total + 4 * lh) * 32 + lj : nullptr;
         float* const tcol = BWD ? a.scratch + tl * a.rows_total * 32 + lj : nullptr;
 
         float raw[2] = {0.f, 0.f};
@@ -337,8 +346,10 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
             const float* cwin = cnet;
             const float* cfour = cnet + NCA_CONST_WIN;
             const float* lat = y.T > 0 ? cnet + NCA_CONST_WIN + NCA_CONST_FOUR + phc * y.T : nullptr;
-            float* const hs = BWD ? tbase + na.row0 * 32 : nullptr;          // this net's rows, this lane's column (+4h rows)
-            float* const hc = BWD ? tcol + na.row0 * 32 : nullptr;           // same without the lane-half row offset
+            float* const hc = BWD ? tcol + na.row0 * 32 : nullptr;           // the row-major input block: this lane's column
+            // hidden blocks (H, D) are stored as the accumulators sit in registers: [row tile][register quad][lane][4 floats],
+            // quad g of lane (r, h) = rows 32 m + 8 g + 4 h + 0..3 of sample r -- one 1 KiB store per wave instruction
+            float* const hf = BWD ? a.scratch + (tl * a.rows_total + na.row0) * 32 + lane * 4 : nullptr;
 
             f32x16 hprev[MT];
 #pragma unroll
@@ -413,14 +424,13 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
                 }
                 if (BWD && jj + 1 < y.NL && tvalid) {
                     // input of layer jj+1, feature-major (waves past the last tile write nothing)
-                    float* hh = hs + (y.K0rows_pad + jj * F) * 32;
+                    float* hh = hf + (y.K0rows_pad + jj * F) * 32;
+                    asm volatile("" : "+v"(hh));             // opaque base: quads become small immediate offsets
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) {
-                        float* q = hh + m * 1024;            // 32 rows x 32 columns
-                        asm volatile("" : "+v"(q));          // opaque base: rows become small immediate offsets
+                    for (int m = 0; m < MT; ++m)
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) q[nca_rho(i) * 32] = hprev[m][i];
-                    }
+                        for (int g = 0; g < 4; ++g)
+                            *reinterpret_cast<float4*>(hh + (m * 4 + g) * 256) = make_float4(hprev[m][4 * g], hprev[m][4 * g + 1], hprev[m][4 * g + 2], hprev[m][4 * g + 3]);
                 }
 
                 if (jj == y.NL - 1) {
@@ -491,22 +501,23 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
                             if (lane == 0) orow[F] += gsum;
                         }
                         // D_{NL-1} = Wo * g masked by ReLU
-                        float* dd = hs + (y.K0rows_pad + (y.NL - 1) * F + (y.NL - 1) * F) * 32;
+                        float* dd = hf + (y.K0rows_pad + (y.NL - 1) * F + (y.NL - 1) * F) * 32;
+                        asm volatile("" : "+v"(dd));
 #pragma unroll
                         for (int m = 0; m < MT; ++m) {
-                            float* q = dd + m * 1024;
-                            asm volatile("" : "+v"(q));
 #pragma unroll
-                            for (int i = 0; i < 16; ++i) {
-                                const float dv = hprev[m][i] > 0.f ? wo[(lh * MT + m) * 16 + i] * g : 0.f;
-                                hprev[m][i] = dv;
-                                if (tvalid) q[nca_rho(i) * 32] = dv;
+                            for (int i = 0; i < 16; ++i) hprev[m][i] = hprev[m][i] > 0.f ? wo[(lh * MT + m) * 16 + i] * g : 0.f;
+                            if (tvalid) {
+#pragma unroll
+                                for (int q = 0; q < 4; ++q)
+                                    *reinterpret_cast<float4*>(dd + (m * 4 + q) * 256) = make_float4(hprev[m][4 * q], hprev[m][4 * q + 1], hprev[m][4 * q + 2], hprev[m][4 * q + 3]);
                             }
                         }
                     }
                 }
 
-                stage_publish();
+                if (BWD && l.kind == NCA_IN_HID) stage_publish_counted<4 * MT>(tvalid);   // H stores (D_{NL-1} stores on the last layer)
+                else stage_publish();
                 cur ^= 1;
                 si = nsi_final;
             }
@@ -523,37 +534,28 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
                     for (int m = 0; m < MT; ++m) acc[m] = (f32x16)(0.f);
                     hidden_steps<MT>(imgl, hprev, acc);
                     // mask with the stored input of layer jj (= output of layer jj-1), store D_{jj-1}
-                    const float* hh = hs + (y.K0rows_pad + (jj - 1) * F) * 32;
-                    float* dd = hs + (y.K0rows_pad + (y.NL - 1) * F + (jj - 1) * F) * 32;
-                    if (a.mask_layers > 0) {
-                        const uint2 mv = *reinterpret_cast<const uint2*>(maskbase + ((wave * a.mask_layers + (jj - 1)) * 64 + lane) * 8);
+                    const float* hh = hf + (y.K0rows_pad + (jj - 1) * F) * 32;
+                    float* dd = hf + (y.K0rows_pad + (y.NL - 1) * F + (jj - 1) * F) * 32;
+                    asm volatile("" : "+v"(hh), "+v"(dd));
+                    uint2 mv = make_uint2(0u, 0u);
+                    if (a.mask_layers > 0) mv = *reinterpret_cast<const uint2*>(maskbase + ((wave * a.mask_layers + (jj - 1)) * 64 + lane) * 8);
 #pragma unroll
-                        for (int m = 0; m < MT; ++m) {
-                            float* qd = dd + m * 1024;
-                            asm volatile("" : "+v"(qd));
-                            const unsigned fld = ((m >> 1) ? mv.y : mv.x) >> (16 * (m & 1));
+                    for (int m = 0; m < MT; ++m) {
+                        const unsigned fld = ((m >> 1) ? mv.y : mv.x) >> (16 * (m & 1));
 #pragma unroll
-                            for (int i = 0; i < 16; ++i) {
-                                const float dv = ((fld >> i) & 1u) ? acc[m][i] : 0.f;
-                                hprev[m][i] = dv;
-                                if (tvalid) qd[nca_rho(i) * 32] = dv;
-                            }
-                        }
-                    } else {
+                        for (int q = 0; q < 4; ++q) {
+                            float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if (a.mask_layers == 0) hv = *reinterpret_cast<const float4*>(hh + (m * 4 + q) * 256);     // fallback: masks did not fit in LDS
+                            const bool on[4] = {a.mask_layers > 0 ? ((fld >> (4 * q)) & 1u) != 0u : hv.x > 0.f,
+                                                a.mask_layers > 0 ? ((fld >> (4 * q + 1)) & 1u) != 0u : hv.y > 0.f,
+                                                a.mask_layers > 0 ? ((fld >> (4 * q + 2)) & 1u) != 0u : hv.z > 0.f,
+                                                a.mask_layers > 0 ? ((fld >> (4 * q + 3)) & 1u) != 0u : hv.w > 0.f};
 #pragma unroll
-                        for (int m = 0; m < MT; ++m) {
-                            const float* qh = hh + m * 1024;
-                            float* qd = dd + m * 1024;
-                            asm volatile("" : "+v"(qh), "+v"(qd));
-#pragma unroll
-                            for (int i = 0; i < 16; ++i) {
-                                const float dv = qh[nca_rho(i) * 32] > 0.f ? acc[m][i] : 0.f;
-                                hprev[m][i] = dv;
-                                if (tvalid) qd[nca_rho(i) * 32] = dv;
-                            }
+                            for (int k = 0; k < 4; ++k) hprev[m][4 * q + k] = on[k] ? acc[m][4 * q + k] : 0.f;
+                            if (tvalid) *reinterpret_cast<float4*>(dd + (m * 4 + q) * 256) = make_float4(hprev[m][4 * q], hprev[m][4 * q + 1], hprev[m][4 * q + 2], hprev[m][4 * q + 3]);
                         }
                     }
-                    stage_publish();
+                    stage_publish_counted<4 * MT>(tvalid);        // D stores
                     cur ^= 1;
                     si = nsi;
                 }
@@ -625,29 +627,36 @@ __global__ __launch_bounds__(256) void nca_wgrad_f32(const NcaWgradArgs a) {
 
     const int lrow = tid >> 3, lc4 = tid & 7;                    // loader: rows lrow + 32 i, float4 chunk lc4
     float4 pa[4], pb[4];
+    // An operand tile is ONE contiguous block of rows x 128 B, read as 256 threads x float4 per 32 rows.  Hidden blocks
+    // (every D, every H but the encoded input) are in the fused kernel's register order: float4 #(4 m + g) * 64 + l
+    // holds rows 32 m + 8 g + 4 (l >> 5) + 0..3 of sample l & 31; the encoded-input block is row-major [row][32].
+    const bool bfrag = job.b_frag != 0;
     auto issue = [&](int64_t t) {
-        // an operand tile is ONE contiguous block of rows x 128 B
-        const float* at = Ag + t * tstride + lrow * 32 + lc4 * 4;
-        const float* bt = Bg + t * tstride + lrow * 32 + lc4 * 4;
+        const float* at = Ag + t * tstride + tid * 4;
+        const float* bt = Bg + t * tstride + tid * 4;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int r = lrow + 32 * i;
-            const f32x4e va = r < F ? __builtin_nontemporal_load(reinterpret_cast<const f32x4e*>(at + i * 1024)) : (f32x4e){0.f, 0.f, 0.f, 0.f};
-            const f32x4e vb = r < brows ? __builtin_nontemporal_load(reinterpret_cast<const f32x4e*>(bt + i * 1024)) : (f32x4e){0.f, 0.f, 0.f, 0.f};
+            const f32x4e va = 32 * i < F ? __builtin_nontemporal_load(reinterpret_cast<const f32x4e*>(at + i * 1024)) : (f32x4e){0.f, 0.f, 0.f, 0.f};
+            const f32x4e vb = 32 * i < brows ? __builtin_nontemporal_load(reinterpret_cast<const f32x4e*>(bt + i * 1024)) : (f32x4e){0.f, 0.f, 0.f, 0.f};
             pa[i] = make_float4(va[0], va[1], va[2], va[3]);
             pb[i] = make_float4(vb[0], vb[1], vb[2], vb[3]);
         }
     };
+    const int fr = 8 * (tid >> 6) + 4 * ((tid >> 5) & 1), fc = tid & 31;      // fragment layout: first row within the row tile, sample
     auto commit = [&](int buf) {
         float* ad = As + buf * 128 * WG_PITCH;
         float* bd = Bs + buf * 128 * WG_PITCH;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int r = lrow + 32 * i;
-            float* x = ad + r * WG_PITCH + lc4 * 4;
-            x[0] = pa[i].x; x[1] = pa[i].y; x[2] = pa[i].z; x[3] = pa[i].w;
-            float* z = bd + r * WG_PITCH + lc4 * 4;
-            z[0] = pb[i].x; z[1] = pb[i].y; z[2] = pb[i].z; z[3] = pb[i].w;
+            float* x = ad + (32 * i + fr) * WG_PITCH + fc;
+            x[0] = pa[i].x; x[WG_PITCH] = pa[i].y; x[2 * WG_PITCH] = pa[i].z; x[3 * WG_PITCH] = pa[i].w;
+            if (bfrag) {
+                float* z = bd + (32 * i + fr) * WG_PITCH + fc;
+                z[0] = pb[i].x; z[WG_PITCH] = pb[i].y; z[2 * WG_PITCH] = pb[i].z; z[3 * WG_PITCH] = pb[i].w;
+            } else {
+                float* z = bd + (lrow + 32 * i) * WG_PITCH + lc4 * 4;
+                z[0] = pb[i].x; z[1] = pb[i].y; z[2] = pb[i].z; z[3] = pb[i].w;
+            }
         }
     };
 
