@@ -144,14 +144,22 @@ __device__ __forceinline__ double half_sum(double v) {
 // operands are the previous layer's accumulator registers.  The A fragment of step s+1 is read
 // while step s's MFMAs issue; the scheduling barrier keeps the compiler from hoisting dozens of LDS
 // reads (and their registers) to the top of the unrolled loop.
+// Backward: the B operands are also what the weight-gradient kernel needs (a layer input H or an output gradient D), and
+// they sit untouched in registers for the whole contraction -- so their 4 MT quad stores (1 KiB each) are issued here,
+// one every fourth k-step, and drain under the MFMAs instead of in a burst of all eight waves before the layer barrier.
 template <int MT>
-__device__ __forceinline__ void hidden_steps(const float* __restrict__ ih, const f32x16 (&b)[MT], f32x16 (&acc)[MT]) {
+__device__ __forceinline__ void hidden_steps(const float* __restrict__ ih, const f32x16 (&b)[MT], f32x16 (&acc)[MT],
+                                             float* st = nullptr, bool do_store = false) {
     constexpr int NS = 16 * MT;
     float av[2][MT];
     load_a<MT>(ih, av[0]);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         if (s + 1 < NS) load_a<MT>(ih + (s + 1) * 64 * MT, av[(s + 1) & 1]);
+        if ((s & 3) == 0 && do_store) {
+            const int qd = s >> 2, m = qd >> 2, g = qd & 3;       // quad g of row tile m: registers 4g .. 4g+3
+            *reinterpret_cast<float4*>(st + qd * 256) = make_float4(b[m][4 * g], b[m][4 * g + 1], b[m][4 * g + 2], b[m][4 * g + 3]);
+        }
         const float bop = b[s >> 4][s & 15];
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][m], bop, acc[m], 0, 0, 0);
@@ -402,11 +410,11 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
                     const int nsi2 = (si + 1 == a.nstages) ? 0 : si + 1;
                     stage_issue(a.stage[nsi2], smem + (cur ^ 1) * BUF, wave, lane);
                     const float* img2 = reinterpret_cast<const float*>(smem + cur * BUF);
-                    hidden_steps<MT>(img2 + lane * MT, hprev, acc);
+                    hidden_steps<MT>(img2 + lane * MT, hprev, acc, hf + (y.K0rows_pad + (jj - 1) * F) * 32, BWD && tvalid);   // stores H_{jj-1}
                     wo_tail = img2 + (l.ksteps - l.ksteps_enc) * 64 * MT;
                     nsi_final = nsi2;
                 } else if (l.kind != NCA_IN_ENC) {
-                    hidden_steps<MT>(imgl, hprev, acc);
+                    hidden_steps<MT>(imgl, hprev, acc, hf + (y.K0rows_pad + (jj - 1) * F) * 32, BWD && tvalid);            // stores H_{jj-1}
                 }
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
@@ -422,17 +430,6 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
                         for (int i = 0; i < 16; ++i) mw[m >> 1] |= (hprev[m][i] > 0.f ? 1u : 0u) << (16 * (m & 1) + i);
                     *reinterpret_cast<uint2*>(maskbase + ((wave * a.mask_layers + jj) * 64 + lane) * 8) = make_uint2(mw[0], mw[1]);
                 }
-                if (BWD && jj + 1 < y.NL && tvalid) {
-                    // input of layer jj+1, feature-major (waves past the last tile write nothing)
-                    float* hh = hf + (y.K0rows_pad + jj * F) * 32;
-                    asm volatile("" : "+v"(hh));             // opaque base: quads become small immediate offsets
-#pragma unroll
-                    for (int m = 0; m < MT; ++m)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            *reinterpret_cast<float4*>(hh + (m * 4 + g) * 256) = make_float4(hprev[m][4 * g], hprev[m][4 * g + 1], hprev[m][4 * g + 2], hprev[m][4 * g + 3]);
-                }
-
                 if (jj == y.NL - 1) {
                     // output layer F -> 1 from the image tail (model/CPPN.py:108)
                     const float* wo = wo_tail;
@@ -501,22 +498,16 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
                             if (lane == 0) orow[F] += gsum;
                         }
                         // D_{NL-1} = Wo * g masked by ReLU
-                        float* dd = hf + (y.K0rows_pad + (y.NL - 1) * F + (y.NL - 1) * F) * 32;
-                        asm volatile("" : "+v"(dd));
+                        // (stored by the dgrad sweep, under the contraction that consumes it)
 #pragma unroll
                         for (int m = 0; m < MT; ++m) {
 #pragma unroll
                             for (int i = 0; i < 16; ++i) hprev[m][i] = hprev[m][i] > 0.f ? wo[(lh * MT + m) * 16 + i] * g : 0.f;
-                            if (tvalid) {
-#pragma unroll
-                                for (int q = 0; q < 4; ++q)
-                                    *reinterpret_cast<float4*>(dd + (m * 4 + q) * 256) = make_float4(hprev[m][4 * q], hprev[m][4 * q + 1], hprev[m][4 * q + 2], hprev[m][4 * q + 3]);
-                            }
                         }
                     }
                 }
 
-                if (BWD && l.kind == NCA_IN_HID) stage_publish_counted<4 * MT>(tvalid);   // H stores (D_{NL-1} stores on the last layer)
+                if (BWD && l.kind == NCA_IN_HID) stage_publish_counted<4 * MT>(tvalid);   // the H_{jj-1} stores issued inside the contraction
                 else stage_publish();
                 cur ^= 1;
                 si = nsi_final;
@@ -532,11 +523,10 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
                     f32x16 acc[MT];
 #pragma unroll
                     for (int m = 0; m < MT; ++m) acc[m] = (f32x16)(0.f);
-                    hidden_steps<MT>(imgl, hprev, acc);
-                    // mask with the stored input of layer jj (= output of layer jj-1), store D_{jj-1}
+                    hidden_steps<MT>(imgl, hprev, acc, hf + (y.K0rows_pad + (y.NL - 1) * F + jj * F) * 32, tvalid);         // stores D_jj
+                    // mask with the ReLU pattern of layer jj's input (= output of layer jj-1)
                     const float* hh = hf + (y.K0rows_pad + (jj - 1) * F) * 32;
-                    float* dd = hf + (y.K0rows_pad + (y.NL - 1) * F + (jj - 1) * F) * 32;
-                    asm volatile("" : "+v"(hh), "+v"(dd));
+                    asm volatile("" : "+v"(hh));
                     uint2 mv = make_uint2(0u, 0u);
                     if (a.mask_layers > 0) mv = *reinterpret_cast<const uint2*>(maskbase + ((wave * a.mask_layers + (jj - 1)) * 64 + lane) * 8);
 #pragma unroll
@@ -552,12 +542,20 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
                                                 a.mask_layers > 0 ? ((fld >> (4 * q + 3)) & 1u) != 0u : hv.w > 0.f};
 #pragma unroll
                             for (int k = 0; k < 4; ++k) hprev[m][4 * q + k] = on[k] ? acc[m][4 * q + k] : 0.f;
-                            if (tvalid) *reinterpret_cast<float4*>(dd + (m * 4 + q) * 256) = make_float4(hprev[m][4 * q], hprev[m][4 * q + 1], hprev[m][4 * q + 2], hprev[m][4 * q + 3]);
                         }
                     }
-                    stage_publish_counted<4 * MT>(tvalid);        // D stores
+                    stage_publish_counted<4 * MT>(tvalid);        // D_jj stores
                     cur ^= 1;
                     si = nsi;
+                }
+                if (tvalid) {     // D_0 has no consumer in this kernel: stored here, drains under the next net / tile
+                    float* dd = hf + (y.K0rows_pad + (y.NL - 1) * F) * 32;
+                    asm volatile("" : "+v"(dd));
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            *reinterpret_cast<float4*>(dd + (m * 4 + q) * 256) = make_float4(hprev[m][4 * q], hprev[m][4 * q + 1], hprev[m][4 * q + 2], hprev[m][4 * q + 3]);
                 }
             }
         }  // nets
