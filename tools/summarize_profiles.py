@@ -29,7 +29,7 @@ def find(pattern):
     hits = glob.glob(os.path.join(src, pattern), recursive=True)
     if not hits:
         raise SystemExit(f"missing {pattern} under {src}")
-    return hits[0]
+    return max(hits, key=os.path.getmtime)        # gpurun merges runs into the same directory: take the newest
 
 
 bench = last_json_line(os.path.join(src, "bench.json"))
