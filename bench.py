@@ -222,7 +222,7 @@ def main():
                 "frac": kern[dom]["tflops"] / peak if kern[dom]["tflops"] else None, "traffic": measured_traffic(args, dom),
                 "avg_launch_ms": kern[dom]["avg_ms"], "launches": kern[dom]["launches"],
                 "kernel_time_share": kern[dom]["ms_total"] / (dt * 1e3), "all_kernels": kern}
-        out = {"metric": "training rays/sec (256^2 det, 192 samples/ray)", "value": args.rays * world * args.steps / dt, "unit": "rays/s",
+        out = {"metric": f"training rays/sec ({args.det}^2 det, {args.samples} samples/ray)", "value": args.rays * world * args.steps / dt, "unit": "rays/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.prec, "data": "synthetic",
                "config": {"workload": f"run_composite XCAT {args.views}-view x 10 phases, {args.det}^2 detector x {args.samples} samples/ray, "
