@@ -949,3 +949,29 @@ def test_evaluate_matches_reference_display_block(dev):
     st = (I0.double() - (a.double() * dists).sum(-1)).float()
     dy = (I0.double() - (b.double() * dists).sum(-1)).float()
     assert rel_err(ev["pred_static"].cpu(), st) < TOL and rel_err(ev["pred_dynamic"].cpu(), dy) < TOL
+
+
+def test_density_volume_export(golden, dev):
+    """export.density_volume (the 4-D reconstruction: one static volume + one dynamic volume per phase) against the
+    oracle evaluated on the same grid."""
+    from nerfca_amd.export import density_volume
+    g = golden("mlps")
+    tag = "F64_e4_l0"
+    ps, pd = g.prefixed(f"s_{tag}_p_"), g.prefixed(f"d_{tag}_p_")
+    s = make_static(ps, dev, F=64, early=4, late=0)
+    t = make_dynamic(pd, dev, F=64, early=4, late=0, T=8)
+    for m in (s, t):
+        m.update_freq_mask_alpha(60000, 150000)
+    res, bounds = (9, 8, 7), ((-1.0, 1.0), (-0.5, 0.75), (0.0, 1.0))
+    vs, vd = density_volume(s, t, phase=3, resolution=res, bounds=bounds, chunk_points=100)
+    assert tuple(vs.shape) == res and tuple(vd.shape) == res
+    axes = [torch.linspace(lo, hi, n) for (lo, hi), n in zip(bounds, res)]
+    grid = torch.stack(torch.meshgrid(*axes, indexing="ij"), dim=-1).reshape(-1, 3)
+    win = O.freq_mask_alpha(12, 60000, 150000, 1)[0]
+    ss, sd = O.NetSpec(num_filters=64), O.NetSpec(num_filters=64, num_time_dim=8)
+    with torch.no_grad():
+        ref_s = torch.nn.functional.softplus(O.static_forward(ps, ss, grid, win)[:, 0]) * 1e-2
+        ref_d = torch.nn.functional.softplus(O.dynamic_forward(pd, sd, grid, torch.full((grid.shape[0],), 3), win)[:, 0]) * 1e-2
+    assert rel_err(vs.cpu().flatten(), ref_s) < TOL and rel_err(vd.cpu().flatten(), ref_d) < TOL
+    only_s, none = density_volume(s, None, phase=None, resolution=(4, 4, 4))
+    assert none is None and tuple(only_s.shape) == (4, 4, 4)

@@ -252,3 +252,24 @@ def test_graft_entry_build_contract():
     from nerfca_amd import _capi
     assert _capi.lib().nca_abi_version() == ver
     assert "mkdir -p" in open(os.path.join(ROOT, "Makefile")).read()
+
+
+def test_checkpoint_round_trip(tmp_path):
+    """export.load_checkpoint rebuilds what CPPN.save / Temporal.save wrote (the reference has no loader): same class,
+    same state dict, same window state, training_information passed through."""
+    from nerfca_amd.export import load_checkpoint
+    from nerfca_amd.model.CPPN import CPPN
+    from nerfca_amd.model.Temporal import Temporal
+    for cls, kw in ((CPPN, {}), (Temporal, {"T": 8})):
+        torch.manual_seed(3)
+        m = cls(model_def(**kw))
+        m.update_freq_mask_alpha(1234, 5000)
+        path = tmp_path / f"{cls.__name__}.pth"
+        m.save(str(path), {"n_iter": 1234})
+        back, info = load_checkpoint(str(path))
+        assert type(back) is cls and info == {"n_iter": 1234}
+        assert list(back.state_dict().keys()) == list(m.state_dict().keys())
+        for (k, a), b in zip(m.state_dict().items(), back.state_dict().values()):
+            assert torch.equal(a, b), k
+        assert torch.equal(back.freq_mask_alpha, m.freq_mask_alpha)      # what save() keeps for free_windowed
+        assert back._binding._is_flat()          # the loaded parameters are views of one flat buffer again
