@@ -50,7 +50,8 @@ struct NcaFusedArgs {
     const float* g_sig_s;
     const float* g_sig_d;
     const float* g_raw;
-    float* scratch;      // [tile][rows_total][32]: layer inputs H and output gradients D of each 32-sample tile
+    float* scratch;      // [tile][rows_total x 32 floats]: layer inputs H and output gradients D of each 32-sample tile
+                         // (f32: input block row-major [row][32], hidden blocks [row tile][quad][lane][4]; bf16: see nca_bf_tile_bytes)
     int64_t rows_total;  // f32: scratch rows per 32-sample tile over all nets;  bf16: BYTES per 32-sample tile
     float* oslab;        // [grid][2][F+1] output-layer gradient partials
     int32_t accumulate;  // add to oslab instead of overwriting (ray chunks after the first)

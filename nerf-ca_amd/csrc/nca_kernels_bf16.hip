@@ -165,20 +165,8 @@ __device__ __forceinline__ void stage_publish_counted(bool stores_issued) {
     __builtin_amdgcn_s_barrier();
 }
 
-// acc0/acc1 += A(row tile image) * B over NKS k-steps; A fragments are read one step ahead
-template <int NKS, int NB>
-__device__ __forceinline__ void mma_rowtile(const char* imgm, const u32x4 (&B)[2][NB], f32x16& acc0, f32x16& acc1) {
-    u32x4 A[2];
-    A[0] = *reinterpret_cast<const u32x4*>(imgm);
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-        if (ks + 1 < NKS) A[(ks + 1) & 1] = *reinterpret_cast<const u32x4*>(imgm + (ks + 1) * 1024);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(A[ks & 1]), frag(B[0][ks]), acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(A[ks & 1]), frag(B[1][ks]), acc1, 0, 0, 0);
-    }
-}
-
-// The same contraction with the A fragments of a whole layer image streamed through a ring of registers:
+// acc0/acc1 += A(row tile m of the layer image) * B, with the A fragments of the whole layer image streamed through a
+// ring of registers:
 // the image is [row tile][k-step][lane][16 B], i.e. contiguous in the global step g = m * NKS + ks, so the read
 // of step g + PF is issued while step g multiplies -- also across row-tile boundaries, where the ReLU/pack
 // epilogue then hides the LDS latency of the next row tile's first fragments.

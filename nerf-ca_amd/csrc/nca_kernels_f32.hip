@@ -4,8 +4,10 @@
 //   nca_fused_f32<F,BWD>  one pass over ray-ordered samples:
 //         BWD=false: query point -> positional encoding -> static MLP -> dynamic MLP ->
 //                    activation -> per-ray partial sums            (model_helpers.py:115-129)
-//         BWD=true : the same recompute, then the backward sweep (dgrad) of each net; layer
-//                    inputs H and output gradients D are written feature-major for the wgrad
+//         BWD=true : the same recompute, then the backward sweep (dgrad) of each net; hidden layer
+//                    inputs H and output gradients D go to the scratch in register order (quads of
+//                    four rows per lane, 1 KiB per store, issued inside the contraction that consumes
+//                    them), the encoded input row-major; ReLU masks stay in LDS
 //   nca_wgrad_f32     dW = D * H^T over the sample axis (split over workgroups), bias sums
 //   nca_reduce_f32    fixed-order sum of the split slabs -> natural flat gradients
 //   nca_pix_f32       pix = I0 - sum of the per-tile partial ray sums
