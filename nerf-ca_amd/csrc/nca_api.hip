@@ -51,13 +51,14 @@ struct Span {
             hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
             if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) on = false;
         }
-        if (on) { a = get_event(); b = get_event(); if (a && b) hipEventRecord(a, st); else on = false; }
+        if (on) { a = get_event(); b = get_event(); on = a && b && hipEventRecord(a, st) == hipSuccess; }
     }
     ~Span() {
         if (!on) return;
-        hipEventRecord(b, st);
+        const bool ok = hipEventRecord(b, st) == hipSuccess;
         std::lock_guard<std::mutex> lk(g_tmu);
-        g_spans.push_back({a, b, kind});
+        if (ok) g_spans.push_back({a, b, kind});
+        else { g_free.push_back(a); g_free.push_back(b); }
     }
 };
 
