@@ -174,6 +174,15 @@ int nca_loss_fwd_bwd(const NcaLoss* desc, const double* pix, const double* gt, c
                      double* terms, double* g_pix, float* g_sig_s, float* g_sig_d,
                      void* work, int64_t work_bytes, void* stream);
 
+/* ---- fine-pass depths: the sampling half of the hierarchical pass of obtain_train_predictions_iter
+ *      (train/model_helpers.py:131-148) with sample_pdf (:162-187): weights = |jump of sigma_s + sigma_d| / batch-wide
+ *      max, inverse-transform sampling of n_fine depths per ray from the injected uniform draws u[R, n_fine], and
+ *      sort(cat[fine, coarse]).  sig_d may be NULL (single field).  z f32[S] is the coarse depth vector shared by
+ *      all rays (ascending); z_all f32[R, S + n_fine].  Needs S >= 3. ------------------------------------ */
+int64_t nca_fine_depths_workspace(int64_t R);
+int nca_fine_depths(int64_t R, int32_t S, int32_t n_fine, const float* sig_s, const float* sig_d, const float* z,
+                    const float* u, float* z_all, void* work, int64_t work_bytes, void* stream);
+
 /* ---- optimiser: torch.optim.Adam(lr) + LinearLR(start_factor=1, end_factor, total_iters) of
  *      train/run_composite.py:209-215, 307-308, as one launch over up to NCA_ADAM_MAX_SEG flat buffers.
  *      `step` is a DEVICE counter = optimiser steps taken so far: the kernel uses t = *step + 1 for the

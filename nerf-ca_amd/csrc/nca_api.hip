@@ -731,6 +731,32 @@ extern "C" int nca_loss_fwd_bwd(const NcaLoss* d, const double* pix, const doubl
     return NCA_OK;
 }
 
+// ---------------------------------------------------------------------------------- fine-pass depths
+extern "C" int64_t nca_fine_depths_workspace(int64_t R) {
+    if (R <= 0) return fail(NCA_E_INVALID, "empty ray batch");
+    return align_up((nca_fine_partials(R) + 1) * (int64_t)sizeof(float), 256);
+}
+
+extern "C" int nca_fine_depths(int64_t R, int32_t S, int32_t n_fine, const float* sig_s, const float* sig_d, const float* z,
+                               const float* u, float* z_all, void* work, int64_t work_bytes, void* stream) {
+    if (R <= 0) return fail(NCA_E_INVALID, "empty ray batch");
+    if (S < 3) return fail(NCA_E_INVALID, "fine sampling needs at least 3 coarse samples per ray (got %d)", S);
+    if (n_fine < 1) return fail(NCA_E_INVALID, "n_fine must be positive");
+    if (!sig_s || !z || !u || !z_all) return fail(NCA_E_INVALID, "a pointer is NULL");
+    int npad = 64;
+    while (npad < n_fine) npad <<= 1;
+    if (4 * (int64_t)((S - 1) + npad + S) * 4 > 160 * 1024) return fail(NCA_E_UNSUPPORTED, "S + n_fine too large for the LDS-resident sampler");
+    const int64_t need = nca_fine_depths_workspace(R);
+    if (!work || work_bytes < need) return fail(NCA_E_WORKSPACE, "fine-depth workspace %lld < %lld bytes", (long long)work_bytes, (long long)need);
+    NcaFineArgs a{};
+    a.R = R; a.S = S; a.n_fine = n_fine;
+    a.sig_s = sig_s; a.sig_d = sig_d; a.z = z; a.u = u; a.z_all = z_all;
+    a.partial_max = static_cast<float*>(work);
+    a.jmax = a.partial_max + nca_fine_partials(R);
+    HIPCHK(nca_launch_fine(a, (hipStream_t)stream));
+    return NCA_OK;
+}
+
 // ---------------------------------------------------------------------------------- optimiser
 extern "C" int nca_adam_step(const NcaAdam* cfg, int32_t n_seg, const int64_t* n, float* const* params, const float* const* grads,
                              float* const* exp_avg, float* const* exp_avg_sq, int64_t* step, void* stream) {

@@ -139,6 +139,16 @@ struct NcaAdamArgs {
     int64_t* step;
 };
 hipError_t nca_launch_adam(const NcaAdamArgs& a, hipStream_t st);
+struct NcaFineArgs {
+    int64_t R;
+    int32_t S, n_fine;
+    const float* sig_s; const float* sig_d; const float* z; const float* u;
+    float* z_all;
+    float* partial_max;   // [ceil(R / 4)]
+    float* jmax;          // [1]
+};
+hipError_t nca_launch_fine(const NcaFineArgs& a, hipStream_t st);
+int64_t nca_fine_partials(int64_t R);
 int64_t nca_loss_partials_bytes(int64_t R);
 
 hipError_t nca_launch_pack_f32(const NcaLayout& y, const float* prm, void* out, hipStream_t st);

@@ -305,3 +305,148 @@ hipError_t nca_launch_adam(const NcaAdamArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(nca_adam_tick, dim3(1), dim3(1), 0, st, a.step);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------
+// Fine-pass depths (train/model_helpers.py:131-148 + sample_pdf 162-187): per ray, the jump of the total density
+// between neighbouring coarse samples -- normalised by the BATCH-wide maximum (:139) -- is the weight of the bin
+// between their mid-points; n_fine depths are drawn by inverse-transform sampling of that piecewise-constant pdf and
+// merged with the coarse depths into one sorted vector.  One wave per ray: wave prefix scan for the CDF, binary
+// search in LDS for searchsorted(right=True), bitonic sort of the draws, rank merge with the (sorted) coarse depths.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fine_total(const NcaFineArgs& a, int64_t r, int k) {
+    const float s = a.sig_s[r * a.S + k];
+    return a.sig_d ? __fadd_rn(s, a.sig_d[r * a.S + k]) : s;
+}
+
+// pass 1: maximum jump per block (the leading 1e-10 of every ray's weight vector is folded into the finishing step)
+__global__ __launch_bounds__(LOSS_NT) void nca_fine_max_k(const NcaFineArgs a) {
+    __shared__ float sh[LOSS_WAVES];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * LOSS_WAVES + wave;
+    float m = 0.f;
+    if (r < a.R)
+        for (int k = 1 + lane; k < a.S; k += 64) m = fmaxf(m, fabsf(__fsub_rn(fine_total(a, r, k), fine_total(a, r, k - 1))));
+    m = wmax(m);
+    if (lane == 0) sh[wave] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float v = sh[0];
+        for (int w = 1; w < LOSS_WAVES; ++w) v = fmaxf(v, sh[w]);
+        a.partial_max[blockIdx.x] = v;
+    }
+}
+__global__ __launch_bounds__(256) void nca_fine_max_finish_k(const NcaFineArgs a, int nblocks) {
+    __shared__ float sh[256];
+    float v = 1e-10f;
+    for (int b = threadIdx.x; b < nblocks; b += 256) v = fmaxf(v, a.partial_max[b]);
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) sh[threadIdx.x] = fmaxf(sh[threadIdx.x], sh[threadIdx.x + st]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *a.jmax = sh[0];
+}
+
+__device__ __forceinline__ float wscan_incl(float v, int lane) {     // inclusive prefix sum over the 64 lanes
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const float o = __shfl_up(v, d);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// pass 2: one wave per ray.  LDS per wave: cdf[S-1] | draws[npad] | zc[S]
+__global__ __launch_bounds__(LOSS_NT) void nca_fine_sample_k(const NcaFineArgs a, int npad) {
+    extern __shared__ __attribute__((aligned(16))) char fsm[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * LOSS_WAVES + wave;
+    if (r >= a.R) return;                                   // no block-wide barrier below: waves are independent
+    const int S = a.S, NF = a.n_fine, NB = S - 1;            // NB bins (mid-points) = length of the cdf
+    float* cdf = reinterpret_cast<float*>(fsm) + (size_t)wave * (NB + npad + S);
+    float* dr = cdf + NB;
+    float* zc = dr + npad;
+    const float jmax = *a.jmax;
+    for (int k = lane; k < S; k += 64) zc[k] = a.z[k];
+
+    // weights of bins 1 .. S-2 (weights[..., 1:-1]) + 1e-5, their sum
+    float sum = 0.f;
+    for (int j = lane; j < S - 2; j += 64) {
+        const float w = __fadd_rn(__fdiv_rn(fabsf(__fsub_rn(fine_total(a, r, j + 1), fine_total(a, r, j))), jmax), 1e-5f);
+        cdf[j + 1] = w;                                      // staged in place
+        sum += w;
+    }
+    sum = (float)wsum((double)sum);
+    __builtin_amdgcn_wave_barrier();
+    // cdf = [0, cumsum(w / sum)]
+    float carry = 0.f;
+    for (int base = 0; base < S - 2; base += 64) {
+        const int j = base + lane;
+        const float p = j < S - 2 ? __fdiv_rn(cdf[j + 1], sum) : 0.f;
+        const float inc = wscan_incl(p, lane) + carry;
+        if (j < S - 2) cdf[j + 1] = inc;
+        carry = __shfl(inc, 63);
+    }
+    if (lane == 0) cdf[0] = 0.f;
+    __builtin_amdgcn_wave_barrier();
+
+    // inverse-transform sampling (searchsorted(right=True): number of cdf entries <= u)
+    for (int j = lane; j < npad; j += 64) {
+        float smp = __int_as_float(0x7f800000);              // +inf padding sorts to the end
+        if (j < NF) {
+            const float u = a.u[r * NF + j];
+            int lo = 0, hi = NB;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdf[mid] <= u) lo = mid + 1; else hi = mid; }
+            const int below = lo - 1 < 0 ? 0 : lo - 1, above = lo > NB - 1 ? NB - 1 : lo;
+            const float c0 = cdf[below], c1 = cdf[above];
+            const float b0 = 0.5f * (zc[below + 1] + zc[below]), b1 = 0.5f * (zc[above + 1] + zc[above]);
+            float den = c1 - c0;
+            if (den < 1e-5f) den = 1.f;
+            smp = b0 + (u - c0) / den * (b1 - b0);
+        }
+        dr[j] = smp;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // bitonic sort of the draws (npad = power of two >= 64)
+    for (int k = 2; k <= npad; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = lane; i < npad; i += 64) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const float x = dr[i], y = dr[l];
+                    const bool up = (i & k) == 0;
+                    if ((x > y) == up) { dr[i] = y; dr[l] = x; }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    // rank merge; torch.sort of cat([draws, coarse]) is stable, so a draw precedes an equal coarse depth
+    float* out = a.z_all + r * (int64_t)(S + NF);
+    for (int i = lane; i < S; i += 64) {
+        const float v = zc[i];
+        int lo = 0, hi = NF;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (dr[mid] <= v) lo = mid + 1; else hi = mid; }
+        out[i + lo] = v;
+    }
+    for (int j = lane; j < NF; j += 64) {
+        const float v = dr[j];
+        int lo = 0, hi = S;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (zc[mid] < v) lo = mid + 1; else hi = mid; }
+        out[j + lo] = v;
+    }
+}
+
+int64_t nca_fine_partials(int64_t R) { return (R + LOSS_WAVES - 1) / LOSS_WAVES; }
+
+hipError_t nca_launch_fine(const NcaFineArgs& a, hipStream_t st) {
+    const int nblocks = (int)nca_fine_partials(a.R);
+    int npad = 64;
+    while (npad < a.n_fine) npad <<= 1;
+    const size_t lds = (size_t)LOSS_WAVES * ((a.S - 1) + npad + a.S) * sizeof(float);
+    hipLaunchKernelGGL(nca_fine_max_k, dim3(nblocks), dim3(LOSS_NT), 0, st, a);
+    hipLaunchKernelGGL(nca_fine_max_finish_k, dim3(1), dim3(256), 0, st, a, nblocks);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_fine_sample_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(nca_fine_sample_k, dim3(nblocks), dim3(LOSS_NT), lds, st, a, npad);
+    return hipGetLastError();
+}

@@ -273,6 +273,29 @@ def fused_losses(pix, gt, wpix, sig_s, sig_d, dists, run_args, weights, inv_R=No
     return terms, g_pix, g_s, g_d
 
 
+def fine_depths(sig_s: torch.Tensor, sig_d: Optional[torch.Tensor], z: torch.Tensor, u: torch.Tensor) -> torch.Tensor:
+    """The sampling half of the hierarchical pass (model_helpers.py:131-148 + sample_pdf): returns the merged, sorted
+    depths f32[R, S + n_fine] for coarse fields ``sig_*`` f32[R, S], the shared coarse depths ``z`` f32[S] and the
+    uniform draws ``u`` f32[R, n_fine].  One HIP launch sequence; no gradient flows through the depths (the reference
+    detaches the coarse depths and the weights only steer where samples go)."""
+    _require_cuda(sig_s, "sigma")
+    dev = sig_s.device
+    R, S = sig_s.shape
+    ss = _f32c(sig_s)
+    sd = _f32c(sig_d) if sig_d is not None else None
+    zz = z.detach().to(device=dev, dtype=torch.float32).contiguous()
+    uu = u.detach().to(device=dev, dtype=torch.float32).contiguous()
+    if zz.dim() != 1 or zz.shape[0] != S or uu.dim() != 2 or uu.shape[0] != R:
+        raise _capi.NcaError("fine_depths takes z[S] shared by all rays and u[R, n_fine]")
+    n_fine = uu.shape[1]
+    out = torch.empty((R, S + n_fine), dtype=torch.float32, device=dev)
+    lib = _capi.lib()
+    wbytes = check(lib.nca_fine_depths_workspace(R))
+    work = torch.empty(wbytes, dtype=torch.uint8, device=dev)
+    check(lib.nca_fine_depths(R, S, n_fine, ptr(ss), ptr(sd), ptr(zz), ptr(uu), ptr(out), ptr(work), wbytes, _stream()))
+    return out
+
+
 class FusedAdam:
     """torch.optim.Adam(lr) + LinearLR(1 -> end_factor over total_iters) of run_composite.py:209-215 as ONE library
     launch over the flat parameter buffers of the given models (order as given).  The step counter lives on the

@@ -122,13 +122,10 @@ def obtain_train_predictions_iter(static_model_coarse, temp_model_coarse, static
     pix_f = sig_s_f = sig_d_f = dists_f = None
     if depth_samples_per_ray_fine > 0:
         R, n_coarse = pix_c.shape[0], z.shape[0]
-        total = sig_s_c + sig_d_c
-        jump = torch.cat([torch.full_like(total[:, :1], 1e-10), (total[:, 1:] - total[:, :-1]).abs()], dim=-1)
-        jump = jump / jump.max()                                   # batch-wide max (model_helpers.py:139)
-        z_rows = z[None, :].repeat(R, 1)
-        mids = 0.5 * (z_rows[..., 1:] + z_rows[..., :-1])
-        z_new = sample_pdf(mids, jump[..., 1:-1], depth_samples_per_ray_fine, device, u=u_fine)
-        z_all, _ = torch.sort(torch.cat([z_new, z_rows.detach()], -1), -1)
+        if u_fine is None:                                         # the draw comes from the CPU generator, as in the reference
+            u_fine = torch.rand(R, depth_samples_per_ray_fine)
+        # weights (batch-wide max, :139), sample_pdf and sort(cat[fine, coarse]) in one HIP pass per ray
+        z_all = _fused.fine_depths(sig_s_c, sig_d_c, z, u_fine)
         z0 = z_all[0, :]                                           # dists of ray 0 for every ray (model_helpers.py:150)
         dists_f = _interval_lengths(z0, batch_directions)
         phase_per_ray = batch_phases[:, 0] if batch_phases.dim() > 1 else batch_phases

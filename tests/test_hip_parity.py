@@ -975,3 +975,38 @@ def test_density_volume_export(golden, dev):
     assert rel_err(vs.cpu().flatten(), ref_s) < TOL and rel_err(vd.cpu().flatten(), ref_d) < TOL
     only_s, none = density_volume(s, None, phase=None, resolution=(4, 4, 4))
     assert none is None and tuple(only_s.shape) == (4, 4, 4)
+
+
+@pytest.mark.parametrize("R,S,NF", [(5, 3, 4), (33, 16, 7), (64, 192, 32), (17, 500, 128), (3, 64, 300)])
+def test_fine_depths_kernel_vs_oracle(dev, R, S, NF):
+    """nca_fine_depths (weights with the batch-wide maximum, sample_pdf, sort(cat[fine, coarse])) against the oracle's
+    restatement of model_helpers.py:131-148, 162-187 on the same coarse fields and draws.  The rows must be sorted and
+    contain the coarse depths BIT for bit; the drawn depths are held to 2e-4 of the depth range (the inverse CDF
+    divides by increments as small as 1e-5, so f32 summation order shows), and draws that land exactly on coarse
+    depths (u = 0 / ties) are exercised."""
+    from nerfca_amd.fused import fine_depths
+    gen = torch.Generator().manual_seed(100 + R + S)
+    z = O.stratified_depths(O.depth_values(3.4259, 5.5741, S), torch.rand(S, generator=gen))
+    a = torch.rand(R, S, generator=gen) * 0.02
+    b = torch.rand(R, S, generator=gen) * 0.01
+    a[:, S // 3: S // 3 + 2] += 0.5                 # a sharp structure: most of the mass in few bins
+    if R > 2:
+        a[1] = 0.25; b[1] = 0.0                      # a flat ray: all weights equal 1e-5
+    u = torch.rand(R, NF, generator=gen)
+    u[0, 0] = 0.0
+    u[-1, -1] = 0.999999
+    total = a + b
+    w = torch.cat([torch.full((R, 1), 1e-10), (total[:, 1:] - total[:, :-1]).abs()], -1)
+    w = w / w.max()
+    zr = z[None, :].repeat(R, 1)
+    mids = 0.5 * (zr[:, 1:] + zr[:, :-1])
+    ref, _ = torch.sort(torch.cat([O.sample_pdf(mids, w[:, 1:-1], u), zr], -1), -1)
+    got = fine_depths(a.to(dev), b.to(dev), z.to(dev), u.to(dev)).cpu()
+    assert tuple(got.shape) == (R, S + NF) and got.dtype == torch.float32
+    assert torch.all(got[:, 1:] >= got[:, :-1])
+    for r in range(R):                               # every coarse depth is present, bit for bit
+        assert torch.isin(z, got[r]).all()
+    assert (got - ref).abs().max() <= 2e-4 * (5.5741 - 3.4259)
+    # single field (sig_d = None) = the same with b folded into a
+    got1 = fine_depths((a + b).to(dev), None, z.to(dev), u.to(dev)).cpu()
+    assert torch.equal(got1, got)
