@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NCA_ABI_VERSION 2
+#define NCA_ABI_VERSION 3
 
 enum {
     NCA_OK = 0,
@@ -110,15 +110,23 @@ int nca_pack_weights(const NcaNet* net, const float* params, void* packed, int32
 /* Forward.  net_d/packed_d/win_d may be NULL when rays->single_field == 1.
  *   pix   f64[R]    = I0 - sum_s (sigma_s + sigma_d) * dists
  *   sig_s f32[R,S], sig_d f32[R,S]  (activation * scale; un-scaled in single_field mode)
- *   work  scratch of nca_render_fwd_workspace() bytes. */
+ *   work  scratch of nca_render_fwd_workspace() bytes.
+ *   store NULL, or a caller-owned buffer of nca_render_store_bytes() bytes: the forward then also leaves every layer
+ *         input, the ReLU masks and the raw outputs there (what the reference's autograd graph keeps,
+ *         train/run_composite.py:306), and nca_render_bwd given the same buffer does not recompute the layers.
+ *         nca_render_store_bytes() returns 0 where this is not available (f32 path, nets of different width, nets
+ *         without a hidden layer): pass NULL there. */
 int64_t nca_render_fwd_workspace(const NcaRays* rays);
+int64_t nca_render_store_bytes(const NcaRays* rays, const NcaNet* net_s, const NcaNet* net_d, int32_t prec);
 int nca_render_fwd(const NcaRays* rays, int32_t prec,
                    const NcaNet* net_s, const void* packed_s, const float* win_s, const float* four_s,
                    const NcaNet* net_d, const void* packed_d, const float* win_d, const float* four_d,
                    const float* latents_d, /* = params_d (time_latents are its first P*T floats) */
-                   double* pix, float* sig_s, float* sig_d, void* work, int64_t work_bytes, void* stream);
+                   double* pix, float* sig_s, float* sig_d, void* work, int64_t work_bytes,
+                   void* store, int64_t store_bytes, void* stream);
 
-/* Backward with recompute.  Upstream gradients g_pix f64[R], g_sig_s/g_sig_d f32[R,S] (NULL = 0).
+/* Backward: with recompute (store == NULL), or from the store the forward of the SAME rays, weights and windows left.
+ * Upstream gradients g_pix f64[R], g_sig_s/g_sig_d f32[R,S] (NULL = 0).
  * Writes (overwrites) grads_s / grads_d, flat f32 in the natural parameter order.
  * `params_*` are the natural flat parameters (needed for the latent gradient). */
 int64_t nca_render_bwd_workspace(const NcaRays* rays, const NcaNet* net_s, const NcaNet* net_d, int32_t prec,
@@ -127,7 +135,8 @@ int nca_render_bwd(const NcaRays* rays, int32_t prec,
                    const NcaNet* net_s, const void* packed_s, const float* win_s, const float* four_s, const float* params_s,
                    const NcaNet* net_d, const void* packed_d, const float* win_d, const float* four_d, const float* params_d,
                    const double* g_pix, const float* g_sig_s, const float* g_sig_d,
-                   float* grads_s, float* grads_d, void* work, int64_t work_bytes, void* stream);
+                   float* grads_s, float* grads_d, void* work, int64_t work_bytes,
+                   const void* store, int64_t store_bytes, void* stream);
 
 /* ---- point path: replaces CPPN.forward / Temporal.forward_composite on arbitrary points
  *      (model/CPPN.py:88-110, model/Temporal.py:138-151) ---------------------------------- */

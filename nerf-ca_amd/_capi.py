@@ -62,11 +62,12 @@ SYMBOLS = {
     "nca_packed_bytes": (_I64, [C.POINTER(NcaNet), _I32]),
     "nca_pack_weights": (C.c_int, [C.POINTER(NcaNet), _P, _P, _I32, _P]),
     "nca_render_fwd_workspace": (_I64, [C.POINTER(NcaRays)]),
+    "nca_render_store_bytes": (_I64, [C.POINTER(NcaRays), C.POINTER(NcaNet), C.POINTER(NcaNet), _I32]),
     "nca_render_fwd": (C.c_int, [C.POINTER(NcaRays), _I32, C.POINTER(NcaNet), _P, _P, _P, C.POINTER(NcaNet), _P, _P, _P, _P,
-                                 _P, _P, _P, _P, _I64, _P]),
+                                 _P, _P, _P, _P, _I64, _P, _I64, _P]),
     "nca_render_bwd_workspace": (_I64, [C.POINTER(NcaRays), C.POINTER(NcaNet), C.POINTER(NcaNet), _I32, _I64]),
     "nca_render_bwd": (C.c_int, [C.POINTER(NcaRays), _I32, C.POINTER(NcaNet), _P, _P, _P, _P, C.POINTER(NcaNet), _P, _P, _P, _P,
-                                 _P, _P, _P, _P, _P, _P, _I64, _P]),
+                                 _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _P]),
     "nca_mlp_fwd": (C.c_int, [C.POINTER(NcaNet), _I32, _P, _P, _P, _P, _I64, _P, _P, _P, _P]),
     "nca_mlp_bwd_workspace": (_I64, [C.POINTER(NcaNet), _I32, _I64, _I64]),
     "nca_mlp_bwd": (C.c_int, [C.POINTER(NcaNet), _I32, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _I64, _P]),
@@ -96,7 +97,7 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.nca_abi_version() != 2:
+        if handle.nca_abi_version() != 3:
             raise NcaError("libnerfca_hip.so ABI version mismatch")
         _lib = handle
     return _lib

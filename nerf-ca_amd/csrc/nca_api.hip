@@ -183,11 +183,11 @@ static int add_stage(NcaFusedArgs* a, const void* base, uint32_t off, uint32_t b
     return NCA_OK;
 }
 
-static int build_stages(NcaFusedArgs* a, const NetBind* binds, bool bwd) {
+static int build_stages(NcaFusedArgs* a, const NetBind* binds, bool bwd, bool stored = false) {
     a->nstages = 0;
     for (int n = 0; n < a->nnets; ++n) {
         const NcaLayout& y = a->net[n].lay;
-        for (int j = 0; j < y.NL; ++j) {
+        for (int j = 0; !stored && j < y.NL; ++j) {
             int rc = add_stage(a, binds[n].packed, y.layer[j].img_off, y.layer[j].img_bytes);
             if (rc) return rc;
             if (y.layer[j].img2_bytes) {            // second stage of a skip layer
@@ -235,6 +235,43 @@ static void rays_to_args(const NcaRays* r, NcaFusedArgs* a, int32_t prec) {
 // ---------------------------------------------------------------------------------- forward
 extern "C" int nca_composite_fwd(int64_t, int32_t, int32_t, int32_t, float, const float*, const float*, const float*, const double*, double*, float*, float*, void*);
 extern "C" int nca_composite_bwd(int64_t, int32_t, int32_t, int32_t, float, const float*, const float*, const double*, const double*, const float*, const float*, float*, float*, void*);
+// The store a bf16 forward can leave behind for its backward (so that the backward does not recompute the layers):
+//   H region  [32-sample tile][net][input block | NL layer outputs]      (the recompute backward's H blocks + the last one)
+//   masks     [wave tile][2][max(NL) - 1][1 KiB]                          ReLU bit masks of the hidden layers
+//   raw       [wave tile][2][64] f32                                      raw net outputs
+struct StorePlan {
+    int64_t h_stride, row0[2], off_m, off_r, bytes;
+    int32_t mask_layers;
+};
+static bool store_plan(const NcaLayout* lays, int nnets, int64_t wave_tiles, StorePlan* sp) {
+    if (nnets == 2 && lays[0].F != lays[1].F) return false;
+    memset(sp, 0, sizeof(*sp));
+    for (int n = 0; n < nnets; ++n) {
+        if (lays[n].NL < 2) return false;                 // no hidden layer: nothing worth storing
+        sp->row0[n] = sp->h_stride;
+        sp->h_stride += 32 * (int64_t)NCA_BF_ENCROWS * 2 + (int64_t)lays[n].NL * 32 * lays[n].F * 2;
+        if (lays[n].NL - 1 > sp->mask_layers) sp->mask_layers = lays[n].NL - 1;
+    }
+    sp->off_m = align_up(wave_tiles * 2 * sp->h_stride, 1024);
+    sp->off_r = sp->off_m + wave_tiles * 2 * sp->mask_layers * 1024;
+    sp->bytes = align_up(sp->off_r + wave_tiles * 2 * 64 * 4, 256);
+    return true;
+}
+
+extern "C" int64_t nca_render_store_bytes(const NcaRays* rays, const NcaNet* net_s, const NcaNet* net_d, int32_t prec) {
+    int rc = check_rays(rays);
+    if (rc) return rc;
+    if (prec != NCA_PREC_BF16) return 0;
+    NcaLayout lays[2];
+    const int nn = rays->single_field ? 1 : 2;
+    rc = layout_of(net_s, &lays[0], prec);
+    if (rc) return rc;
+    if (nn == 2) { rc = layout_of(net_d, &lays[1], prec); if (rc) return rc; }
+    StorePlan sp;
+    if (!store_plan(lays, nn, rays->R * ((rays->S + 63) / 64), &sp)) return 0;
+    return sp.bytes;
+}
+
 extern "C" int64_t nca_render_fwd_workspace(const NcaRays* rays) {
     int rc = check_rays(rays);
     if (rc) return rc;
@@ -245,7 +282,8 @@ extern "C" int nca_render_fwd(const NcaRays* rays, int32_t prec,
                               const NcaNet* net_s, const void* packed_s, const float* win_s, const float* four_s,
                               const NcaNet* net_d, const void* packed_d, const float* win_d, const float* four_d,
                               const float* latents_d,
-                              double* pix, float* sig_s, float* sig_d, void* work, int64_t work_bytes, void* stream) {
+                              double* pix, float* sig_s, float* sig_d, void* work, int64_t work_bytes,
+                              void* store, int64_t store_bytes, void* stream) {
     int rc = check_rays(rays);
     if (rc) return rc;
     rc = check_prec(prec);
@@ -273,6 +311,7 @@ extern "C" int nca_render_fwd(const NcaRays* rays, int32_t prec,
     const int grid = (int)(ngroups < num_cus() ? ngroups : num_cus());
     hipStream_t st = (hipStream_t)stream;
     if (a.nnets == 2 && a.net[0].lay.F != a.net[1].lay.F) {
+        if (store) return fail(NCA_E_UNSUPPORTED, "a forward store needs nets of one width");
         // nets of different width: one fused launch per net writes the raw field into its sigma buffer,
         // then the stand-alone compositing kernel turns both into sigmas + pix in place
         float* outs[2] = {sig_s, sig_d};
@@ -297,9 +336,25 @@ extern "C" int nca_render_fwd(const NcaRays* rays, int32_t prec,
     a.part = static_cast<double*>(work);
     a.sig_s = sig_s;
     a.sig_d = sig_d;
+    int kmode = NCA_KM_FWD;
+    if (store) {
+        NcaLayout lays[2] = {a.net[0].lay, a.net[1].lay};
+        StorePlan spl;
+        if (prec != NCA_PREC_BF16 || !store_plan(lays, a.nnets, a.ntiles, &spl))
+            return fail(NCA_E_UNSUPPORTED, "a forward store needs the bf16 path, nets of one width and at least one hidden layer");
+        if (store_bytes < spl.bytes) return fail(NCA_E_WORKSPACE, "forward store %lld < %lld bytes", (long long)store_bytes, (long long)spl.bytes);
+        kmode = NCA_KM_FWD_STORE;
+        a.scratch = static_cast<float*>(store);
+        a.rows_total = spl.h_stride;
+        for (int n = 0; n < a.nnets; ++n) a.net[n].row0 = spl.row0[n];
+        a.tile0 = 0;
+        a.mstore = static_cast<char*>(store) + spl.off_m;
+        a.rstore = reinterpret_cast<float*>(static_cast<char*>(store) + spl.off_r);
+        a.mstore_layers = spl.mask_layers;
+    }
     {
         Span sp(NCA_K_FWD, st);
-        if (prec == NCA_PREC_BF16) HIPCHK(nca_launch_fused_bf16(a.net[0].lay.F, a, false, grid, st));
+        if (prec == NCA_PREC_BF16) HIPCHK(nca_launch_fused_bf16(a.net[0].lay.F, a, kmode, grid, st));
         else HIPCHK(nca_launch_fused_f32(a.net[0].lay.F, a, false, grid, st));
     }
     HIPCHK(nca_launch_pix_f32(rays->R, a.nchunk, rays->I0, a.part, pix, st));
@@ -320,13 +375,15 @@ struct BwdPlan {
 
 static int64_t scratch_rows(const NcaLayout& y) { return y.K0rows_pad + (int64_t)(y.NL - 1) * y.F + (int64_t)y.NL * y.F; }
 
-static int plan_bwd(const NcaLayout* lays, int nnets, int32_t prec, int64_t units, int64_t tiles_per_unit, int64_t budget, BwdPlan* p) {
+static int plan_bwd(const NcaLayout* lays, int nnets, int32_t prec, int64_t units, int64_t tiles_per_unit, int64_t budget, BwdPlan* p,
+                    bool stored = false) {
     const bool bf = prec == NCA_PREC_BF16;
     p->tile_stride = 0;
     p->slab_stride = 0;
     p->njobs = 0;
     for (int n = 0; n < nnets; ++n) {
-        p->tile_stride += bf ? nca_bf_tile_bytes(lays[n]) : scratch_rows(lays[n]);
+        if (stored) p->tile_stride += (int64_t)lays[n].NL * 32 * lays[n].F * 2;       // only the D blocks live in the chunk scratch
+        else p->tile_stride += bf ? nca_bf_tile_bytes(lays[n]) : scratch_rows(lays[n]);
         p->slab_stride += lays[n].n_params;
         for (int j = 0; j < lays[n].NL; ++j) p->njobs += lays[n].layer[j].kind == NCA_IN_SKIP ? 2 : 1;
     }
@@ -406,13 +463,14 @@ static void add_jobs_f32(NcaWgradArgs* w, const NcaLayout& y, int64_t row0, int6
     }
 }
 
-static void add_jobs_bf16(NcaWgradArgs* w, const NcaLayout& y, int64_t net_off, int64_t slab_off, int64_t onehot_off) {
+// net_off: byte offset of the net's input/H blocks in a tile of the H region; d_off: of its D blocks in a tile of the D region
+static void add_jobs_bf16(NcaWgradArgs* w, const NcaLayout& y, int64_t net_off, int64_t d_off, int64_t slab_off, int64_t onehot_off) {
     const int64_t EB = 32 * (int64_t)NCA_BF_ENCROWS * 2, HB = 32 * (int64_t)y.F * 2;
     for (int j = 0; j < y.NL; ++j) {
         const NcaLayerL& l = y.layer[j];
         NcaWgradJob& g = w->job[w->njobs++];
         g.F = y.F;
-        g.d_row0 = net_off + EB + (int64_t)(y.NL - 1) * HB + (int64_t)j * HB;
+        g.d_row0 = d_off + (int64_t)j * HB;
         g.out_off = slab_off + l.w_off;
         g.out_ld = l.K;
         g.out_col0 = 0;
@@ -438,12 +496,19 @@ static void add_jobs_bf16(NcaWgradArgs* w, const NcaLayout& y, int64_t net_off, 
 }
 
 static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t units, int64_t tiles_per_unit, float* const* grads,
-                   void* work, int64_t work_bytes, hipStream_t st) {
+                   void* work, int64_t work_bytes, hipStream_t st, const void* store = nullptr, int64_t store_bytes = 0) {
     const bool bf = prec == NCA_PREC_BF16;
     NcaLayout lays[2];
     for (int n = 0; n < a.nnets; ++n) lays[n] = a.net[n].lay;
+    // a store left by the forward of the SAME batch: no recompute, the chunk scratch holds the D blocks only
+    StorePlan spl;
+    const bool stored = store != nullptr;
+    if (stored) {
+        if (!bf || !store_plan(lays, a.nnets, units * tiles_per_unit, &spl)) return fail(NCA_E_UNSUPPORTED, "no forward store exists for this configuration");
+        if (store_bytes < spl.bytes) return fail(NCA_E_WORKSPACE, "forward store %lld < %lld bytes", (long long)store_bytes, (long long)spl.bytes);
+    }
     BwdPlan p;
-    int rc = plan_bwd(lays, a.nnets, prec, units, tiles_per_unit, work_bytes, &p);
+    int rc = plan_bwd(lays, a.nnets, prec, units, tiles_per_unit, work_bytes, &p, stored);
     if (rc) return rc;
     if (!work || work_bytes < p.bytes_total) return fail(NCA_E_WORKSPACE, "backward workspace %lld < %lld bytes", (long long)work_bytes, (long long)p.bytes_total);
     char* wb = static_cast<char*>(work);
@@ -451,10 +516,21 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     float* oslab = reinterpret_cast<float*>(wb + p.off_oslab);
     float* scratch = reinterpret_cast<float*>(wb + p.off_scratch);
 
-    rc = build_stages(&a, binds, true);
+    rc = build_stages(&a, binds, true, stored);
     if (rc) return rc;
     int64_t off = 0, soff = 0;
     for (int n = 0; n < a.nnets; ++n) { a.net[n].row0 = off; off += bf ? nca_bf_tile_bytes(lays[n]) : scratch_rows(lays[n]); }
+    if (bf) {     // where each net's D blocks start inside a tile of the D region
+        int64_t doff = 0;
+        for (int n = 0; n < a.nnets; ++n) {
+            const int64_t EB = 32 * (int64_t)NCA_BF_ENCROWS * 2, HB = 32 * (int64_t)lays[n].F * 2;
+            if (stored) { a.net[n].row0 = spl.row0[n]; a.net[n].drow0 = doff; doff += (int64_t)lays[n].NL * HB; }
+            else a.net[n].drow0 = a.net[n].row0 + EB + (int64_t)(lays[n].NL - 1) * HB;
+            // [bias | Wo | bo] tail behind the k-steps of the last layer's forward image
+            const NcaLayerL& ll = lays[n].layer[lays[n].NL - 1];
+            a.net[n].wo_src = reinterpret_cast<const float*>(static_cast<const char*>(binds[n].packed) + ll.img_off + (int64_t)lays[n].MT * ll.ksteps * 1024) + 2 * lays[n].MT * 16;
+        }
+    }
     int64_t slab_off[2] = {0, 0}, onehot_off[2] = {0, 0};
     for (int n = 0; n < a.nnets; ++n) { slab_off[n] = soff; soff += lays[n].n_params; }
     for (int n = 0; n < a.nnets; ++n) { onehot_off[n] = soff; soff += (int64_t)lays[n].F * lays[n].P; }
@@ -462,18 +538,27 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     static thread_local NcaWgradArgs w;
     memset(&w, 0, sizeof(w));
     for (int n = 0; n < a.nnets; ++n) {
-        if (bf) add_jobs_bf16(&w, lays[n], a.net[n].row0, slab_off[n], onehot_off[n]);
+        if (bf) add_jobs_bf16(&w, lays[n], a.net[n].row0, a.net[n].drow0, slab_off[n], onehot_off[n]);
         else add_jobs_f32(&w, lays[n], a.net[n].row0, slab_off[n], onehot_off[n]);
     }
     w.scratch = scratch;
     w.slab = slab;
     w.slab_stride = p.slab_stride;
+    w.scratch_b = stored ? static_cast<const float*>(store) : scratch;
+    w.rows_total_b = stored ? spl.h_stride : p.tile_stride;
 
-    a.scratch = scratch;
+    a.scratch = stored ? const_cast<float*>(static_cast<const float*>(store)) : scratch;
+    a.dscratch = reinterpret_cast<char*>(scratch);
+    a.d_total = p.tile_stride;
+    if (stored) {
+        a.mstore = const_cast<char*>(static_cast<const char*>(store)) + spl.off_m;
+        a.rstore = reinterpret_cast<float*>(const_cast<char*>(static_cast<const char*>(store)) + spl.off_r);
+        a.mstore_layers = spl.mask_layers;
+    }
     a.oslab = oslab;
     // bf16: keep the ReLU masks of the recomputed layers in LDS when they fit (8 KiB per layer per workgroup)
     a.mask_layers = 0;
-    if (bf) {
+    if (bf && !stored) {
         int ml = 0;
         for (int n = 0; n < a.nnets; ++n) if (lays[n].NL - 1 > ml) ml = lays[n].NL - 1;
         if (ml > 0 && ml <= 6) a.mask_layers = ml;
@@ -484,15 +569,17 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     for (int64_t u0 = 0; u0 < units; u0 += p.units_per_chunk, ++chunk) {
         const int64_t nu = (u0 + p.units_per_chunk <= units) ? p.units_per_chunk : units - u0;
         a.ntiles = nu * tiles_per_unit;
-        a.rows_total = p.tile_stride;
+        a.rows_total = stored ? spl.h_stride : p.tile_stride;
+        a.tile0 = stored ? u0 * tiles_per_unit : 0;       // position of this chunk in the store of the whole batch
         a.accumulate = chunk > 0;
         if (a.mode == NCA_MODE_RAYS) a.ray0 = u0; else a.n0 = u0 * wave_samples;
         {
             Span sp(NCA_K_BWD_DGRAD, st);
-            if (bf) HIPCHK(nca_launch_fused_bf16(F, a, true, p.grid, st));
+            if (bf) HIPCHK(nca_launch_fused_bf16(F, a, stored ? NCA_KM_BWD_STORED : NCA_KM_BWD, p.grid, st));
             else HIPCHK(nca_launch_fused_f32(F, a, true, p.grid, st));
         }
         w.rows_total = p.tile_stride;
+        w.tile0_b = stored ? u0 * tiles_per_unit * 2 : 0;
         w.ntiles = bf ? a.ntiles * 2 : a.ntiles;
         w.accumulate = chunk > 0;
         {
@@ -562,7 +649,8 @@ extern "C" int nca_render_bwd(const NcaRays* rays, int32_t prec,
                               const NcaNet* net_s, const void* packed_s, const float* win_s, const float* four_s, const float* params_s,
                               const NcaNet* net_d, const void* packed_d, const float* win_d, const float* four_d, const float* params_d,
                               const double* g_pix, const float* g_sig_s, const float* g_sig_d,
-                              float* grads_s, float* grads_d, void* work, int64_t work_bytes, void* stream) {
+                              float* grads_s, float* grads_d, void* work, int64_t work_bytes,
+                              const void* store, int64_t store_bytes, void* stream) {
     int rc = check_rays(rays);
     if (rc) return rc;
     rc = check_prec(prec);
@@ -584,6 +672,7 @@ extern "C" int nca_render_bwd(const NcaRays* rays, int32_t prec,
     float* grads[2] = {grads_s, grads_d};
     hipStream_t st = (hipStream_t)stream;
     if (a.nnets == 2 && a.net[0].lay.F != a.net[1].lay.F) {
+        if (store) return fail(NCA_E_UNSUPPORTED, "a forward store needs nets of one width");
         // different widths: recompute both raw fields, push (g_pix, g_sigma) through the compositing chain rule
         // once, then run each net's backward on its own with the per-sample raw gradient
         const int64_t arr = align_up(rays->R * (int64_t)rays->S * 4, 256);
@@ -628,7 +717,7 @@ extern "C" int nca_render_bwd(const NcaRays* rays, int32_t prec,
     a.g_pix = g_pix;
     a.g_sig_s = g_sig_s;
     a.g_sig_d = g_sig_d;
-    return run_bwd(a, prec, binds, rays->R, a.nchunk, grads, work, work_bytes, st);
+    return run_bwd(a, prec, binds, rays->R, a.nchunk, grads, work, work_bytes, st, store, store_bytes);
 }
 
 // ---------------------------------------------------------------------------------- point path

@@ -19,8 +19,16 @@ struct NcaNetArgs {
     const float* win;    // f32[L] band weights
     const float* four;   // f32[3L] fourier coefficients (or null)
     const float* lat;    // f32[P*T] time latents (or null)
-    int64_t row0;        // first scratch row of this net (backward only)
+    int64_t row0;        // first scratch row of this net (backward only); bf16: BYTE offset of its input/H blocks in a tile
+    int64_t drow0;       // bf16: byte offset of its output-gradient (D) blocks in a tile of the D region
+    const float* wo_src; // bf16 stored-forward backward: the [Wo | bo] tail of the packed last-layer image (global)
 };
+
+// kernel modes of nca_fused_bf16
+enum { NCA_KM_FWD = 0,          // forward
+       NCA_KM_BWD = 1,          // recompute + output-layer gradients + dgrad; H, D and the input block go to ONE scratch
+       NCA_KM_FWD_STORE = 2,    // forward that also writes the input block, every layer input, ReLU masks and raw outputs
+       NCA_KM_BWD_STORED = 3 }; // output-layer gradients + dgrad from that store (no recompute); D to the chunk scratch
 
 struct NcaFusedArgs {
     int32_t mode, nnets;
@@ -53,6 +61,13 @@ struct NcaFusedArgs {
     float* scratch;      // [tile][rows_total x 32 floats]: layer inputs H and output gradients D of each 32-sample tile
                          // (f32: input block row-major [row][32], hidden blocks [row tile][quad][lane][4]; bf16: see nca_bf_tile_bytes)
     int64_t rows_total;  // f32: scratch rows per 32-sample tile over all nets;  bf16: BYTES per 32-sample tile
+    // bf16 two-region addressing (NCA_KM_BWD: dscratch == scratch, d_total == rows_total, tile0 == 0)
+    char* dscratch;      // D region of this launch: [local tile][d_total bytes]
+    int64_t d_total;     // bytes per 32-sample tile of the D region
+    int64_t tile0;       // wave-tile index of this launch's first tile inside the H region (stored forward: global)
+    char* mstore;        // stored forward: ReLU masks [wave tile][net][layer][1 KiB]
+    float* rstore;       // stored forward: raw outputs [wave tile][net][64]
+    int32_t mstore_layers; // layers per net in mstore
     float* oslab;        // [grid][2][F+1] output-layer gradient partials
     int32_t accumulate;  // add to oslab instead of overwriting (ray chunks after the first)
     int32_t nstages;
@@ -81,8 +96,11 @@ struct NcaWgradJob {
 };
 
 struct NcaWgradArgs {
-    const float* scratch;   // [tile][rows_total][32]
+    const float* scratch;   // [tile][rows_total][32]   (bf16: the D region, bytes)
     int64_t rows_total, ntiles;
+    const float* scratch_b; // bf16: the region of the H / input blocks (== scratch in recompute mode) ...
+    int64_t rows_total_b;   // ... its bytes per 32-sample tile ...
+    int64_t tile0_b;        // ... and the 32-sample-tile index of this launch's first tile inside it
     float* slab;
     int64_t slab_stride;
     int32_t accumulate, njobs;
@@ -156,6 +174,6 @@ hipError_t nca_launch_fused_f32(int F, const NcaFusedArgs& a, bool bwd, int grid
 hipError_t nca_launch_wgrad_f32(const NcaWgradArgs& a, int nsplit, hipStream_t st);
 hipError_t nca_launch_reduce_f32(const NcaReduceArgs& a, hipStream_t st);
 hipError_t nca_launch_pack_bf16(const NcaLayout& y, const float* prm, void* out, hipStream_t st);
-hipError_t nca_launch_fused_bf16(int F, const NcaFusedArgs& a, bool bwd, int grid, hipStream_t st);
+hipError_t nca_launch_fused_bf16(int F, const NcaFusedArgs& a, int kmode, int grid, hipStream_t st);
 hipError_t nca_launch_wgrad_bf16(int F, const NcaWgradArgs& a, int nsplit, hipStream_t st);
 hipError_t nca_launch_pix_f32(int64_t R, int nchunk, const float* I0, const double* part, double* pix, hipStream_t st);

@@ -32,6 +32,7 @@ __device__ __forceinline__ float bf_hi(unsigned w) { return __builtin_bit_cast(f
 __device__ __forceinline__ bf16x8 frag(u32x4 x) { return __builtin_bit_cast(bf16x8, x); }
 // scratch blocks are written once and read once by another kernel: stream them past the caches
 __device__ __forceinline__ void store_nt(char* p, u32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p)); }
+__device__ __forceinline__ u32x4 load_nt(const char* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)); }
 // ReLU as ONE integer max on the bit pattern (negative floats and -0 are negative integers): no canonicalising
 // v_max x,x,x in front as fmaxf would get, and -- unlike an inline-asm v_max_f32 -- visible to the compiler's hazard
 // recogniser, which must put the wait states between an MFMA and the first VALU read of its result.
@@ -199,8 +200,12 @@ __device__ __forceinline__ void mma_rowtile_ring(const char* imgl, int m, u32x4 
 // ------------------------------------------------------------------------------------------
 // fused forward / backward-dgrad kernel
 // ------------------------------------------------------------------------------------------
-template <int F, bool BWD>
+template <int F, int MODE>
 __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a) {
+    constexpr bool BWD = MODE == NCA_KM_BWD || MODE == NCA_KM_BWD_STORED;     // output-layer gradients + dgrad sweep
+    constexpr bool STORE = MODE == NCA_KM_BWD || MODE == NCA_KM_FWD_STORE;    // writes the input block and the layer inputs
+    constexpr bool RECOMP = MODE != NCA_KM_BWD_STORED;                        // runs the forward layers
+    constexpr bool FSTORE = MODE == NCA_KM_FWD_STORE, STORED = MODE == NCA_KM_BWD_STORED;
     constexpr int MT = BfCfg<F>::MT, KS = BfCfg<F>::KS, KS0 = BfCfg<F>::KS0, KSMAX = BfCfg<F>::KSMAX;
     constexpr int BUF = BfCfg<F>::BUF_BYTES;
     constexpr int HB = 32 * F * 2;                          // bytes of one hidden scratch block (32 samples x F)
@@ -210,6 +215,9 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
     float* osum = reinterpret_cast<float*>(smem + 2 * BUF + NCA_CONST_BYTES);
     // ReLU masks of the recomputed layers: [wave][layer][lane][16 B] (2 bits per packed bf16 pair)
     char* const maskbase = smem + 2 * BUF + NCA_CONST_BYTES + NCA_WAVES * 2 * (F + 1) * 4;
+    // stored backward: no recompute, hence no last-layer image in LDS -- its [Wo | bo] tails are copied here once
+    float* const wos = reinterpret_cast<float*>(maskbase);            // [net][2 MT 16 + 16]
+    constexpr int WOS = 2 * MT * 16 + 16;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
 
@@ -221,6 +229,9 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
         if (na.lat) for (int i = tid; i < na.lay.P * na.lay.T; i += NCA_NT) c[NCA_CONST_WIN + NCA_CONST_FOUR + i] = na.lat[i];
     }
     if (BWD) for (int i = tid; i < NCA_WAVES * 2 * (F + 1); i += NCA_NT) osum[i] = 0.f;
+    if (STORED)
+        for (int net = 0; net < a.nnets; ++net)
+            for (int i = tid; i < 2 * MT * 16 + 1; i += NCA_NT) wos[net * WOS + i] = a.net[net].wo_src[i];
     __syncthreads();
     stage_issue_b(a.stage[0], smem, wave, lane);
     stage_publish_b();
@@ -243,8 +254,10 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
             valid = tvalid && smp < a.S;
             if (smp >= a.S) smp = a.S - 1;
             n = ray * a.S + smp;
-            const float zz = a.z[ray * a.zs_r + smp];
-            if (a.ray_is_f64) {
+            const float zz = RECOMP ? a.z[ray * a.zs_r + smp] : 0.f;
+            if (!RECOMP) {
+                p[0] = p[1] = p[2] = 0.f;
+            } else if (a.ray_is_f64) {
                 const double* o = reinterpret_cast<const double*>(a.origins) + ray * 3;
                 const double* d = reinterpret_cast<const double*>(a.dirs) + ray * 3;
 #pragma unroll
@@ -260,13 +273,17 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
             valid = tvalid && n < a.N;
             if (n >= a.N) n = a.N - 1;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) p[c] = a.pts[n * 3 + c];
+            for (int c = 0; c < 3; ++c) p[c] = RECOMP ? a.pts[n * 3 + c] : 0.f;
         }
         int ph = 0;
-        if (a.phase) ph = a.mode == NCA_MODE_RAYS ? a.phase[ray * a.ps_r + (int64_t)smp * a.ps_s] : a.phase[n];
+        if (RECOMP && a.phase) ph = a.mode == NCA_MODE_RAYS ? a.phase[ray * a.ps_r + (int64_t)smp * a.ps_s] : a.phase[n];
 
-        // backward scratch: two 32-sample tiles per wave, sample-major blocks (see nca_bf_tile_bytes)
-        char* const t32 = BWD ? reinterpret_cast<char*>(a.scratch) + (tl * 2) * a.rows_total : nullptr;   // rows_total = bytes per 32-sample tile
+        // Scratch: two 32-sample tiles per wave, fragment-major blocks (see nca_bf_tile_bytes).  The input block and the
+        // layer inputs live in the H region (indexed by the tile's position in the whole batch when a stored forward
+        // wrote it), the output gradients in the D region of this launch; the recompute backward uses one for both.
+        const int64_t tg = tl + a.tile0;
+        char* const t32 = (BWD || STORE) ? reinterpret_cast<char*>(a.scratch) + (tg * 2) * a.rows_total : nullptr;   // rows_total = bytes per 32-sample tile
+        char* const d32 = BWD ? a.dscratch + (tl * 2) * a.d_total : nullptr;
 
         float raw[2] = {0.f, 0.f};
 
@@ -277,13 +294,17 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
             const NcaLayout& y = na.lay;
             const int phc = ph < 0 ? 0 : (ph >= y.P ? y.P - 1 : ph);
             const float* cnet = cst + net * NCA_CONST_NET_FLOATS;
-            char* const nb = BWD ? t32 + na.row0 : nullptr;   // this net's bytes inside a tile (row0 = byte offset)
-            const bool lds_mask = BWD && a.mask_layers >= y.NL - 1;
+            char* const nb = (BWD || STORE) ? t32 + na.row0 : nullptr;   // this net's input/H blocks inside a tile (byte offset)
+            char* const db = BWD ? d32 + na.drow0 : nullptr;             // this net's D blocks
+            const bool lds_mask = MODE == NCA_KM_BWD && a.mask_layers >= y.NL - 1;
             char* const mwave = maskbase + (wave * a.mask_layers) * 1024 + lane * 16;
+            // stored forward: masks [wave tile][net][layer][lane][16 B], raw outputs [wave tile][net][lane]
+            char* const mglob = (FSTORE || STORED) ? a.mstore + ((tg * 2 + net) * a.mstore_layers) * 1024 + lane * 16 : nullptr;
+            float* const rglob = (FSTORE || STORED) ? a.rstore + (tg * 2 + net) * 64 + lane : nullptr;
 
             // ================= encoding, lane = sample ===================================================
             u32x4 B[2][KSMAX];
-            {
+            if (RECOMP) {
                 float fe[NCA_BF_K0SLOTS];
 #pragma unroll
                 for (int i = 0; i < NCA_BF_K0SLOTS; ++i) fe[i] = 0.f;
@@ -340,7 +361,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                         B[0][s][w] = r[0];
                         B[1][s][w] = r[1];
                     }
-                if (BWD && tvalid) {
+                if (STORE && tvalid) {
                     // input block of both column tiles, fragment-major [k-step][lane][16 B]: the layer-0
                     // operands as they sit in registers, then one k-step of one-hot phase slots
 #pragma unroll
@@ -361,99 +382,9 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                 }
             }
 
-            // ================= layers (forward / recompute) ===============================================
-            float part[2] = {0.f, 0.f};       // output-layer partial dot per column tile
-            for (int jj = 0; jj < y.NL; ++jj) {
-                const NcaLayerL& l = y.layer[jj];
-                const int nsi = (si + 1 == a.nstages) ? 0 : si + 1;
-                stage_issue_b(a.stage[nsi], smem + (cur ^ 1) * BUF, wave, lane);
-                const char* img = smem + cur * BUF;
-                const int nks = l.ksteps;
-                const float* tail = reinterpret_cast<const float*>(img + MT * nks * 1024);
-                const bool last = jj == y.NL - 1;
-                const bool store_h = BWD && tvalid && !last;
-                char* const hblk = BWD ? nb + EB + jj * HB : nullptr;            // input block of layer jj+1
-                u32x4 Bn[2][2 * MT];
-                unsigned mw[2][2] = {{0u, 0u}, {0u, 0u}};     // mask words: [column tile][row-tile pair]
-                const char* imgl = img + lane * 16;
-                // one instantiation per k-step count (encoded layer / hidden layers): no control-flow join inside the
-                // row-tile loop, so accumulators and ring registers are never copied at a merge point
-                auto rowtiles = [&](auto nks_c) __attribute__((always_inline)) {
-                constexpr int NKS = decltype(nks_c)::value;
-                u32x4 A[NCA_BF_RING];
-                ring_prime<NKS, MT>(imgl, A);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    f32x16 acc0, acc1;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) { const float b = tail[(lh * MT + m) * 16 + i]; acc0[i] = b; acc1[i] = b; }
-                    mma_rowtile_ring<NKS, MT, KSMAX>(imgl, m, A, B, acc0, acc1);
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) { acc0[i] = relu1(acc0[i]); acc1[i] = relu1(acc1[i]); }
-                    if (last) {
-                        const float* wo = tail + 2 * MT * 16;
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) {
-                            const float w = wo[(lh * MT + m) * 16 + i];
-                            part[0] = fmaf(w, acc0[i], part[0]);
-                            part[1] = fmaf(w, acc1[i], part[1]);
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        Bn[0][2 * m][u] = pack2(acc0[2 * u], acc0[2 * u + 1]);
-                        Bn[0][2 * m + 1][u] = pack2(acc0[8 + 2 * u], acc0[8 + 2 * u + 1]);
-                        Bn[1][2 * m][u] = pack2(acc1[2 * u], acc1[2 * u + 1]);
-                        Bn[1][2 * m + 1][u] = pack2(acc1[8 + 2 * u], acc1[8 + 2 * u + 1]);
-                    }
-                    if (BWD && !last) {
-                        // bit k / 16+k of a field: low / high bf16 of packed word k (k = 4*(fragment&1) + u) is > 0.
-                        // ReLU output is >= 0, so "nonzero" is (x + 0x7fff) >> 15 per 16-bit half.
-#pragma unroll
-                        for (int c = 0; c < 2; ++c) {
-                            unsigned fld = 0u;
-#pragma unroll
-                            for (int k = 0; k < 8; ++k) {
-                                const unsigned w = Bn[c][2 * m + (k >> 2)][k & 3];
-                                fld |= (((w + 0x7fff7fffu) >> 15) & 0x00010001u) << k;
-                            }
-                            mw[c][m >> 1] |= fld << (8 * (m & 1));
-                        }
-                    }
-                    if (store_h) {
-                        // the next layer's B-operand fragments exactly as they sit in registers: 1 KiB per
-                        // wave instruction, [k-step][lane][16 B] (feature order inside a tile is the
-                        // accumulator->operand order; the wgrad un-permutes when it writes dW)
-#pragma unroll
-                        for (int c = 0; c < 2; ++c) {
-                            char* fp2 = hblk + c * a.rows_total + lane * 16;
-                            store_nt(fp2 + (2 * m) * 1024, Bn[c][2 * m]);
-                            store_nt(fp2 + (2 * m + 1) * 1024, Bn[c][2 * m + 1]);
-                        }
-                    }
-                }
-                };
-                if (jj == 0) rowtiles(std::integral_constant<int, KS0>{});
-                else rowtiles(std::integral_constant<int, KS>{});
-#pragma unroll
-                for (int c = 0; c < 2; ++c)
-#pragma unroll
-                    for (int k = 0; k < 2 * MT; ++k) B[c][k] = Bn[c][k];
-                if (lds_mask && !last) {
-                    u32x4 mv = {mw[0][0], mw[0][1], mw[1][0], mw[1][1]};
-                    *reinterpret_cast<u32x4*>(mwave + jj * 1024) = mv;
-                }
-
-                if (last) {
-                    const float* wo = tail + 2 * MT * 16;
-                    const float bo = wo[2 * MT * 16];
-                    // column tile c of lane (r,h) is sample 32c + r: sum the two halves, then lane = sample picks its tile
-                    const float r0 = part[0] + __shfl_xor(part[0], 32) + bo;
-                    const float r1 = part[1] + __shfl_xor(part[1], 32) + bo;
-                    raw[net] = lh ? r1 : r0;
-                }
-
-                if (BWD && last) {
+            // ---------- gradient wrt the raw output, output-layer parameter gradients, D_{NL-1}: expects the last layer's
+            // packed output in B and its raw output in raw[net]; leaves D_{NL-1} in B.  `wo` = [Wo | bo] in LDS
+            auto last_layer_grads = [&](const float* wo) __attribute__((always_inline)) {
                     // ---------- gradient wrt the raw output, output-layer parameter gradients, D_{NL-1} ----------
                     float g;
                     if (a.mode == NCA_MODE_RAYS && !a.g_raw) {
@@ -468,9 +399,9 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                     if (!valid) g = 0.f;
                     // g of tile c for BOTH lane halves: [g.lower|g.lower] and [g.upper|g.upper]
                     const float gc[2] = {__shfl(g, lr), __shfl(g, lr + 32)};
-                    const float* wo = tail + 2 * MT * 16;
                     float* orow = osum + (wave * 2 + net) * (F + 1);
-                    char* const dblk = nb + EB + (y.NL - 1) * HB + (y.NL - 1) * HB;
+                    char* const dblk = db + (y.NL - 1) * HB;
+                    u32x4 Bn[2][2 * MT];
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
                         // H_last of this row tile back to f32 (both column tiles), in accumulator register order
@@ -520,7 +451,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                                 Bn[c][2 * m + 1][u] = pack2(dv[8 + 2 * u], dv[8 + 2 * u + 1]);
                             }
                             if (tvalid) {
-                                char* fp2 = dblk + c * a.rows_total + lane * 16;
+                                char* fp2 = dblk + c * a.d_total + lane * 16;
                                 store_nt(fp2 + (2 * m) * 1024, Bn[c][2 * m]);
                                 store_nt(fp2 + (2 * m + 1) * 1024, Bn[c][2 * m + 1]);
                             }
@@ -533,12 +464,126 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                     for (int c = 0; c < 2; ++c)
 #pragma unroll
                         for (int k = 0; k < 2 * MT; ++k) B[c][k] = Bn[c][k];
+            };
+
+            // ================= layers (forward / recompute) ===============================================
+            float part[2] = {0.f, 0.f};       // output-layer partial dot per column tile
+            for (int jj = 0; RECOMP && jj < y.NL; ++jj) {
+                const NcaLayerL& l = y.layer[jj];
+                const int nsi = (si + 1 == a.nstages) ? 0 : si + 1;
+                stage_issue_b(a.stage[nsi], smem + (cur ^ 1) * BUF, wave, lane);
+                const char* img = smem + cur * BUF;
+                const int nks = l.ksteps;
+                const float* tail = reinterpret_cast<const float*>(img + MT * nks * 1024);
+                const bool last = jj == y.NL - 1;
+                // every layer input goes to the store; the stored forward also keeps the last layer's output (the
+                // backward without recompute needs it for the output-layer gradients)
+                const bool store_h = STORE && tvalid && (!last || FSTORE);
+                char* const hblk = STORE ? nb + EB + jj * HB : nullptr;          // input block of layer jj+1
+                u32x4 Bn[2][2 * MT];
+                unsigned mw[2][2] = {{0u, 0u}, {0u, 0u}};     // mask words: [column tile][row-tile pair]
+                const char* imgl = img + lane * 16;
+                // one instantiation per k-step count (encoded layer / hidden layers): no control-flow join inside the
+                // row-tile loop, so accumulators and ring registers are never copied at a merge point
+                auto rowtiles = [&](auto nks_c) __attribute__((always_inline)) {
+                constexpr int NKS = decltype(nks_c)::value;
+                u32x4 A[NCA_BF_RING];
+                ring_prime<NKS, MT>(imgl, A);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    f32x16 acc0, acc1;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { const float b = tail[(lh * MT + m) * 16 + i]; acc0[i] = b; acc1[i] = b; }
+                    mma_rowtile_ring<NKS, MT, KSMAX>(imgl, m, A, B, acc0, acc1);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { acc0[i] = relu1(acc0[i]); acc1[i] = relu1(acc1[i]); }
+                    if (last) {
+                        const float* wo = tail + 2 * MT * 16;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const float w = wo[(lh * MT + m) * 16 + i];
+                            part[0] = fmaf(w, acc0[i], part[0]);
+                            part[1] = fmaf(w, acc1[i], part[1]);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        Bn[0][2 * m][u] = pack2(acc0[2 * u], acc0[2 * u + 1]);
+                        Bn[0][2 * m + 1][u] = pack2(acc0[8 + 2 * u], acc0[8 + 2 * u + 1]);
+                        Bn[1][2 * m][u] = pack2(acc1[2 * u], acc1[2 * u + 1]);
+                        Bn[1][2 * m + 1][u] = pack2(acc1[8 + 2 * u], acc1[8 + 2 * u + 1]);
+                    }
+                    if (STORE && !last) {
+                        // bit k / 16+k of a field: low / high bf16 of packed word k (k = 4*(fragment&1) + u) is > 0.
+                        // ReLU output is >= 0, so "nonzero" is (x + 0x7fff) >> 15 per 16-bit half.
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            unsigned fld = 0u;
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) {
+                                const unsigned w = Bn[c][2 * m + (k >> 2)][k & 3];
+                                fld |= (((w + 0x7fff7fffu) >> 15) & 0x00010001u) << k;
+                            }
+                            mw[c][m >> 1] |= fld << (8 * (m & 1));
+                        }
+                    }
+                    if (store_h) {
+                        // the next layer's B-operand fragments exactly as they sit in registers: 1 KiB per
+                        // wave instruction, [k-step][lane][16 B] (feature order inside a tile is the
+                        // accumulator->operand order; the wgrad un-permutes when it writes dW)
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            char* fp2 = hblk + c * a.rows_total + lane * 16;
+                            store_nt(fp2 + (2 * m) * 1024, Bn[c][2 * m]);
+                            store_nt(fp2 + (2 * m + 1) * 1024, Bn[c][2 * m + 1]);
+                        }
+                    }
+                }
+                };
+                if (jj == 0) rowtiles(std::integral_constant<int, KS0>{});
+                else rowtiles(std::integral_constant<int, KS>{});
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int k = 0; k < 2 * MT; ++k) B[c][k] = Bn[c][k];
+                if (lds_mask && !last) {
+                    u32x4 mv = {mw[0][0], mw[0][1], mw[1][0], mw[1][1]};
+                    *reinterpret_cast<u32x4*>(mwave + jj * 1024) = mv;
+                }
+                if (FSTORE && !last && tvalid) {
+                    u32x4 mv = {mw[0][0], mw[0][1], mw[1][0], mw[1][1]};
+                    store_nt(mglob + jj * 1024, mv);
                 }
 
-                if (BWD) stage_publish_counted<4 * MT>(tvalid);     // H stores (or D_{NL-1} stores on the last layer)
+                if (last) {
+                    const float* wo = tail + 2 * MT * 16;
+                    const float bo = wo[2 * MT * 16];
+                    // column tile c of lane (r,h) is sample 32c + r: sum the two halves, then lane = sample picks its tile
+                    const float r0 = part[0] + __shfl_xor(part[0], 32) + bo;
+                    const float r1 = part[1] + __shfl_xor(part[1], 32) + bo;
+                    raw[net] = lh ? r1 : r0;
+                    if (FSTORE && tvalid) *rglob = raw[net];
+                }
+
+                if (MODE == NCA_KM_BWD && last) last_layer_grads(tail + 2 * MT * 16);
+
+                // at least 4 MT stores follow the weight DMA of every storing stage (H, or D_{NL-1} on the last layer of the
+                // recompute backward; the stored forward adds a mask or raw store on top, which it then also waits for)
+                if (STORE) stage_publish_counted<4 * MT>(tvalid);
                 else stage_publish_b();
                 cur ^= 1;
                 si = nsi;
+            }
+
+            if (STORED) {
+                // the forward state comes from the store: raw output, the last layer's packed output as it sat in registers
+                raw[net] = *rglob;
+                const char* hl = nb + EB + (y.NL - 1) * HB + lane * 16;
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int k = 0; k < 2 * MT; ++k) B[c][k] = load_nt(hl + c * a.rows_total + k * 1024);
+                last_layer_grads(wos + net * WOS);
             }
 
             // ================= backward sweep (dgrad) =====================================================
@@ -548,10 +593,12 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                     stage_issue_b(a.stage[nsi], smem + (cur ^ 1) * BUF, wave, lane);
                     const char* img = smem + cur * BUF;
                     const char* const hblk = nb + EB + (jj - 1) * HB;                       // input of layer jj (mask)
-                    char* const dblk = nb + EB + (y.NL - 1) * HB + (jj - 1) * HB;           // D_{jj-1}
+                    char* const dblk = db + (jj - 1) * HB;                                  // D_{jj-1}
                     u32x4 Bn[2][2 * MT];
                     u32x4 mv = {0u, 0u, 0u, 0u};
                     if (lds_mask) mv = *reinterpret_cast<const u32x4*>(mwave + (jj - 1) * 1024);
+                    if (STORED) mv = load_nt(mglob + (jj - 1) * 1024);
+                    const bool bits = lds_mask || STORED;         // mask bits at hand (else: re-read the layer input)
                     u32x4 A[NCA_BF_RING];
                     const char* imgl = img + lane * 16;
                     ring_prime<KS, MT>(imgl, A);
@@ -564,20 +611,20 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
 #pragma unroll
                         for (int c = 0; c < 2; ++c) {
                             const char* hp = hblk + c * a.rows_total + lane * 16;
-                            char* dp = dblk + c * a.rows_total + lane * 16;
+                            char* dp = dblk + c * a.d_total + lane * 16;
 #pragma unroll
                             for (int s2 = 0; s2 < 2; ++s2) {
                                 // word u of fragment 2m+s2 holds accumulator registers 8 s2 + 2u, +1
                                 u32x4 hw = {0u, 0u, 0u, 0u};
-                                if (!lds_mask) hw = *reinterpret_cast<const u32x4*>(hp + (2 * m + s2) * 1024);
+                                if (!bits) hw = *reinterpret_cast<const u32x4*>(hp + (2 * m + s2) * 1024);
                                 const unsigned fld = mv[2 * c + (m >> 1)] >> (8 * (m & 1));
                                 u32x4 dw;
 #pragma unroll
                                 for (int u = 0; u < 4; ++u) {
                                     const float a0 = c == 0 ? acc0[8 * s2 + 2 * u] : acc1[8 * s2 + 2 * u];
                                     const float a1 = c == 0 ? acc0[8 * s2 + 2 * u + 1] : acc1[8 * s2 + 2 * u + 1];
-                                    const bool p0 = lds_mask ? ((fld >> (4 * s2 + u)) & 1u) != 0u : (short)(hw[u] & 0xffffu) > 0;
-                                    const bool p1 = lds_mask ? ((fld >> (16 + 4 * s2 + u)) & 1u) != 0u : (short)(hw[u] >> 16) > 0;
+                                    const bool p0 = bits ? ((fld >> (4 * s2 + u)) & 1u) != 0u : (short)(hw[u] & 0xffffu) > 0;
+                                    const bool p1 = bits ? ((fld >> (16 + 4 * s2 + u)) & 1u) != 0u : (short)(hw[u] >> 16) > 0;
                                     dw[u] = pack2(p0 ? a0 : 0.f, p1 ? a1 : 0.f);
                                 }
                                 Bn[c][2 * m + s2] = dw;
@@ -683,7 +730,8 @@ __device__ __forceinline__ void wgrad_job(const NcaWgradArgs& a, const NcaWgradJ
     const int lc = lane & 31, lh = lane >> 5;
     const int64_t per = (a.ntiles + nsplit - 1) / nsplit;
     const int64_t t0 = (int64_t)q * per, t1 = (t0 + per < a.ntiles) ? t0 + per : a.ntiles;
-    const char* base = reinterpret_cast<const char*>(a.scratch);
+    const char* base = reinterpret_cast<const char*>(a.scratch);          // D region of this launch
+    const char* base_b = reinterpret_cast<const char*>(a.scratch_b);      // region of the input / H blocks (may be the same)
     const int brow = job.b_row_bytes;
     f32x16 acc[MT][NTB];
 #pragma unroll
@@ -701,9 +749,8 @@ __device__ __forceinline__ void wgrad_job(const NcaWgradArgs& a, const NcaWgradJ
     // (this kernel is HBM-bound: 16 KiB of operands per 48 MFMAs).
     u32x4 XD[2 * MT], XH[2 * NTB];
     auto load_tile = [&](int64_t t, u32x4 (&xd)[2 * MT], u32x4 (&xh)[2 * NTB]) {
-        const char* tb = base + t * a.rows_total;            // rows_total = bytes per 32-sample tile
-        const char* dp = tb + job.d_row0 + lane * 16;
-        const char* bp = tb + job.b_row0 + lane * 16;
+        const char* dp = base + t * a.rows_total + job.d_row0 + lane * 16;            // rows_total = bytes per 32-sample tile
+        const char* bp = base_b + (t + a.tile0_b) * a.rows_total_b + job.b_row0 + lane * 16;
 #pragma unroll
         for (int s = 0; s < 2 * MT; ++s) xd[s] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(dp + s * 1024));
 #pragma unroll
@@ -776,24 +823,33 @@ __global__ __launch_bounds__(64, 1) void nca_wgrad_bf16(const NcaWgradArgs a) {
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-template <int F>
-static hipError_t launch_fused_bf(const NcaFusedArgs& a, bool bwd, int grid, hipStream_t st) {
-    const size_t lds = 2 * BfCfg<F>::BUF_BYTES + NCA_CONST_BYTES + (bwd ? NCA_WAVES * 2 * (F + 1) * sizeof(float) + (size_t)NCA_WAVES * a.mask_layers * 1024 : 0);
-    if (bwd) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_fused_bf16<F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((nca_fused_bf16<F, true>), dim3(grid), dim3(NCA_NT), lds, st, a);
-    } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_fused_bf16<F, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((nca_fused_bf16<F, false>), dim3(grid), dim3(NCA_NT), lds, st, a);
-    }
+template <int F, int MODE>
+static hipError_t launch_fused_bf_mode(const NcaFusedArgs& a, int grid, hipStream_t st) {
+    constexpr bool bwd = MODE == NCA_KM_BWD || MODE == NCA_KM_BWD_STORED;
+    size_t lds = 2 * BfCfg<F>::BUF_BYTES + NCA_CONST_BYTES;
+    if (bwd) lds += NCA_WAVES * 2 * (F + 1) * sizeof(float);
+    if (MODE == NCA_KM_BWD) lds += (size_t)NCA_WAVES * a.mask_layers * 1024;
+    if (MODE == NCA_KM_BWD_STORED) lds += 2 * (2 * BfCfg<F>::MT * 16 + 16) * sizeof(float);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_fused_bf16<F, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((nca_fused_bf16<F, MODE>), dim3(grid), dim3(NCA_NT), lds, st, a);
     return hipGetLastError();
 }
+template <int F>
+static hipError_t launch_fused_bf(const NcaFusedArgs& a, int kmode, int grid, hipStream_t st) {
+    switch (kmode) {
+        case NCA_KM_FWD: return launch_fused_bf_mode<F, NCA_KM_FWD>(a, grid, st);
+        case NCA_KM_BWD: return launch_fused_bf_mode<F, NCA_KM_BWD>(a, grid, st);
+        case NCA_KM_FWD_STORE: return launch_fused_bf_mode<F, NCA_KM_FWD_STORE>(a, grid, st);
+        case NCA_KM_BWD_STORED: return launch_fused_bf_mode<F, NCA_KM_BWD_STORED>(a, grid, st);
+    }
+    return hipErrorInvalidValue;
+}
 
-hipError_t nca_launch_fused_bf16(int F, const NcaFusedArgs& a, bool bwd, int grid, hipStream_t st) {
+hipError_t nca_launch_fused_bf16(int F, const NcaFusedArgs& a, int kmode, int grid, hipStream_t st) {
     switch (F) {
-        case 32: return launch_fused_bf<32>(a, bwd, grid, st);
-        case 64: return launch_fused_bf<64>(a, bwd, grid, st);
-        case 128: return launch_fused_bf<128>(a, bwd, grid, st);
+        case 32: return launch_fused_bf<32>(a, kmode, grid, st);
+        case 64: return launch_fused_bf<64>(a, kmode, grid, st);
+        case 128: return launch_fused_bf<128>(a, kmode, grid, st);
     }
     return hipErrorInvalidValue;
 }

@@ -167,9 +167,16 @@ class _RayBatch:
                        single_field=self.single, scale=self.scale, reserved=0)
 
 
-def render_forward_raw(batch: _RayBatch, bs: FieldBinding, bd: Optional[FieldBinding]):
+# A bf16 forward that will be followed by a backward leaves every layer input, the ReLU masks and the raw outputs in a
+# store (what the reference's autograd graph keeps); the backward then skips the recompute.  ~3 KB per sample: the
+# store is used when it fits under this limit, otherwise the backward recomputes (set to 0 to always recompute).
+STORE_FORWARD_LIMIT_BYTES = 96 << 30
+
+
+def render_forward_raw(batch: _RayBatch, bs: FieldBinding, bd: Optional[FieldBinding], for_backward: bool = False):
     """Fused forward without autograd: returns (pix f64[R], sigma_s, sigma_d | None, keep) where ``keep``
-    pins the packed weights / encoding buffers the matching backward must see."""
+    pins the packed weights / encoding buffers (and, with ``for_backward``, the forward store) the matching
+    backward must see."""
     lib = _capi.lib()
     dev = batch.o.device
     packed_s = bs.ensure_packed()
@@ -183,18 +190,24 @@ def render_forward_raw(batch: _RayBatch, bs: FieldBinding, bd: Optional[FieldBin
     desc = batch.desc()
     wbytes = check(lib.nca_render_fwd_workspace(C.byref(desc)))
     work = torch.empty(wbytes, dtype=torch.uint8, device=dev)
+    store = None
+    if for_backward and STORE_FORWARD_LIMIT_BYTES > 0:
+        sbytes = check(lib.nca_render_store_bytes(C.byref(desc), C.byref(bs.net), C.byref(bd.net) if bd is not None else None, bs.prec))
+        if 0 < sbytes <= STORE_FORWARD_LIMIT_BYTES:
+            store = torch.empty(sbytes, dtype=torch.uint8, device=dev)
     check(lib.nca_render_fwd(C.byref(desc), bs.prec,
                              C.byref(bs.net), ptr(packed_s), ptr(win_s), ptr(four_s),
                              C.byref(bd.net) if bd is not None else None, ptr(packed_d), ptr(win_d), ptr(four_d),
                              ptr(bd.flat) if bd is not None else None,
-                             ptr(pix), ptr(sig_s), ptr(sig_d), ptr(work), wbytes, _stream()))
-    return pix, sig_s, sig_d, (packed_s, packed_d, win_s, four_s, win_d, four_d)
+                             ptr(pix), ptr(sig_s), ptr(sig_d), ptr(work), wbytes,
+                             ptr(store), store.numel() if store is not None else 0, _stream()))
+    return pix, sig_s, sig_d, (packed_s, packed_d, win_s, four_s, win_d, four_d, store)
 
 
 def render_backward_raw(batch: _RayBatch, bs: FieldBinding, bd: Optional[FieldBinding], keep, g_pix, g_sig_s, g_sig_d):
     """Fused backward (recompute + dgrad + wgrad + reduce): returns flat f32 gradients per net."""
     lib = _capi.lib()
-    packed_s, packed_d, win_s, four_s, win_d, four_d = keep
+    packed_s, packed_d, win_s, four_s, win_d, four_d, store = keep
     dev = batch.o.device
     gp = torch.zeros(batch.R, dtype=torch.float64, device=dev) if g_pix is None else g_pix.detach().to(torch.float64).contiguous()
     gs, gd = _f32c(g_sig_s), _f32c(g_sig_d)
@@ -207,7 +220,8 @@ def render_backward_raw(batch: _RayBatch, bs: FieldBinding, bd: Optional[FieldBi
     check(lib.nca_render_bwd(C.byref(desc), bs.prec,
                              C.byref(bs.net), ptr(packed_s), ptr(win_s), ptr(four_s), ptr(bs.flat),
                              net_d, ptr(packed_d), ptr(win_d), ptr(four_d), ptr(bd.flat) if bd is not None else None,
-                             ptr(gp), ptr(gs), ptr(gd), ptr(grads_s), ptr(grads_d), ptr(work), wbytes, _stream()))
+                             ptr(gp), ptr(gs), ptr(gd), ptr(grads_s), ptr(grads_d), ptr(work), wbytes,
+                             ptr(store), store.numel() if store is not None else 0, _stream()))
     return grads_s, grads_d
 
 
@@ -216,7 +230,8 @@ class _RenderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, batch: _RayBatch, bs: FieldBinding, bd: Optional[FieldBinding], n_s: int, *params):
-        pix, sig_s, sig_d, keep = render_forward_raw(batch, bs, bd)
+        needs_grad = any(p.requires_grad for p in params)      # (autograd.Function.forward itself runs under no_grad)
+        pix, sig_s, sig_d, keep = render_forward_raw(batch, bs, bd, for_backward=needs_grad)
         ctx.batch, ctx.bs, ctx.bd, ctx.keep = batch, bs, bd, keep
         if not batch.f64:
             pix = pix.to(torch.float32)

@@ -181,7 +181,7 @@ class CompositeTrainer:
         dists = MH._interval_lengths(z, d)
         bs, bd = self.s._binding, self.t._binding
         batch = _RayBatch(o, d, phases, self.I0[: hi - lo], z, dists, c.output_activation, False, 1e-2)
-        pix, sig_s, sig_d, keep = render_forward_raw(batch, bs, bd)
+        pix, sig_s, sig_d, keep = render_forward_raw(batch, bs, bd, for_backward=True)
         terms, g_pix, g_s, g_d = fused_losses(pix, gt, w, sig_s, sig_d, dists, c, self.loss_weights(n_iter), inv_R=1.0 / R)
         grads_s, grads_d = render_backward_raw(batch, bs, bd, keep, g_pix, g_s, g_d)
         if self.world > 1 or self.always_allreduce:
@@ -231,7 +231,7 @@ class CompositeTrainer:
             z = MH.randomize_depth(self.depth, dev, rec32[:S])
             dists = torch.cat((z[1:] - z[:-1], tail))
             batch = _RayBatch(o, d, phases, self.I0[: hi - lo], z, dists, c.output_activation, False, 1e-2)
-            pix, sig_s, sig_d, keep = render_forward_raw(batch, bs, bd)
+            pix, sig_s, sig_d, keep = render_forward_raw(batch, bs, bd, for_backward=True)
             terms, g_pix, g_s, g_d = fused_losses(pix, gt, w, sig_s, sig_d, dists, c, (0.0, 0.0, 0.0, 0.0), inv_R=1.0 / R,
                                                   weights_dev=rec64)
             grads_s, grads_d = render_backward_raw(batch, bs, bd, keep, g_pix, g_s, g_d)

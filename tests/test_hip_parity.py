@@ -52,7 +52,7 @@ def grads_of(model):
 # ------------------------------------------------------------------------------------------
 def test_library_loaded():
     from nerfca_amd import _capi
-    assert _capi.lib().nca_abi_version() == 2
+    assert _capi.lib().nca_abi_version() == 3
 
 
 @pytest.mark.parametrize("F,early", [(F, e) for F in (32, 64, 128) for e in (0, 4)])
@@ -1010,3 +1010,47 @@ def test_fine_depths_kernel_vs_oracle(dev, R, S, NF):
     # single field (sig_d = None) = the same with b folded into a
     got1 = fine_depths((a + b).to(dev), None, z.to(dev), u.to(dev)).cpu()
     assert torch.equal(got1, got)
+
+
+@pytest.mark.parametrize("R,S,F,early", [(8, 16, 32, 1), (33, 50, 64, 3), (64, 192, 128, 4), (300, 70, 128, 2)])
+def test_bf16_stored_forward_backward_equals_recompute(dev, R, S, F, early):
+    """The bf16 backward from the forward's store (layer inputs, ReLU masks, raw outputs kept by the forward, no
+    recompute) performs the same arithmetic on the same values as the recompute backward: outputs and every gradient
+    must be BIT-identical, also when the batch is cut into several ray chunks (small workspace)."""
+    from nerfca_amd import fused, render_rays, set_precision
+    gen = torch.Generator().manual_seed(77 + R)
+    ss = O.NetSpec(num_filters=F, num_early_layers=early, num_time_dim=0)
+    sd = O.NetSpec(num_filters=F, num_early_layers=early, num_time_dim=8)
+    s = make_static(O.init_params(ss, gen), dev, F=F, early=early, late=0)
+    t = make_dynamic(O.init_params(sd, gen), dev, F=F, early=early, late=0, T=8)
+    set_precision("bf16", s, t)
+    s.update_freq_mask_alpha(75000, 150000)
+    t.update_freq_mask_alpha(40000, 150000)
+    o = (torch.rand(R, 3, generator=gen) * 0.2 + torch.tensor([3.0, -2.0, 2.5])).double().to(dev)
+    d = (torch.rand(R, 3, generator=gen) - 0.5).double().to(dev)
+    ph = torch.randint(0, 10, (R,), generator=gen).to(dev)
+    z = O.stratified_depths(O.depth_values(3.4259, 5.5741, S), torch.rand(S, generator=gen))
+    dists = O.ray_dists(z, torch.float64).to(dev)
+    z = z.to(dev)
+    I0 = torch.full((R,), 2.15991, device=dev)
+    cp, cs, cd = torch.randn(R, generator=gen).double().to(dev), torch.randn(R, S, generator=gen).to(dev), torch.randn(R, S, generator=gen).to(dev)
+    outs = []
+    saved = fused.STORE_FORWARD_LIMIT_BYTES, fused.BWD_WORKSPACE_BYTES
+    try:
+        for limit, ws in ((0, 6 << 30), (96 << 30, 6 << 30), (96 << 30, 24 << 20)):
+            fused.STORE_FORWARD_LIMIT_BYTES, fused.BWD_WORKSPACE_BYTES = limit, ws
+            for m in (s, t):
+                m.zero_grad()
+            pix, a, b = render_rays(s, t, o, d, ph, I0, z, dists)
+            ((pix * cp).sum() + (a * cs).sum() * 50 + (b * cd).sum() * 50).backward()
+            outs.append([pix.detach().clone(), a.detach().clone(), b.detach().clone()] + [p.grad.clone() for p in list(s.parameters()) + list(t.parameters())])
+    finally:
+        fused.STORE_FORWARD_LIMIT_BYTES, fused.BWD_WORKSPACE_BYTES = saved
+    for other in outs[1:2]:
+        for x, y in zip(outs[0], other):
+            assert torch.equal(x, y)
+    # several ray chunks change the order in which per-chunk slabs are summed: equal up to f32 summation rounding
+    for x, y in zip(outs[0][:3], outs[2][:3]):
+        assert torch.equal(x, y)
+    for x, y in zip(outs[0][3:], outs[2][3:]):
+        assert rel_err(y, x) < 2e-6

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in nerfca_hip.h but not exported"
     assert declared == set(_capi.SYMBOLS), "ctypes table and header disagree"
-    assert _capi.lib().nca_abi_version() == 2
+    assert _capi.lib().nca_abi_version() == 3
 
 
 def test_param_count_and_packed_size_match_reference_nets():
