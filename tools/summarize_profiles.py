@@ -15,9 +15,21 @@ prec = sys.argv[1]
 tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
 src = os.path.join(ROOT, "gpurun_out", f"prof_{prec}")
 dst = os.path.join(ROOT, "profiles")
-KERNELS = {"fwd": f"nca_fused_{prec}<128, false>", "bwd_dgrad": f"nca_fused_{prec}<128, true>",
-           "bwd_wgrad": "nca_wgrad_bf16<128>" if prec == "bf16" else "nca_wgrad_f32", "bwd_reduce": "nca_reduce_f32",
-           "loss": "nca_loss_rays"}
+# candidate kernel names per role, most specific first (bf16 kernel modes: 0 forward, 1 recompute backward, 2 storing
+# forward, 3 backward from the store; the f32 kernels are templated on a bool)
+KERNELS = {"fwd": [f"nca_fused_{prec}<128, 2>", f"nca_fused_{prec}<128, 0>", f"nca_fused_{prec}<128, false>"],
+           "bwd_dgrad": [f"nca_fused_{prec}<128, 3>", f"nca_fused_{prec}<128, 1>", f"nca_fused_{prec}<128, true>"],
+           "bwd_wgrad": ["nca_wgrad_bf16<128>" if prec == "bf16" else "nca_wgrad_f32"], "bwd_reduce": ["nca_reduce_f32"],
+           "loss": ["nca_loss_rays"]}
+
+
+def pick(table, names):
+    """(kernel key in `table`, matched name) for the first candidate that occurs."""
+    for name in names:
+        ks = [k for k in table if name in k]
+        if ks:
+            return ks[0], name
+    return None, None
 
 
 def last_json_line(path):
@@ -66,13 +78,13 @@ traffic = {"how": "rocprofv3 --pmc FETCH_SIZE (and, in a second run, --pmc WRITE
            "config": {"prec": prec, "rays_per_step": bench["config"]["rays_per_step_per_gpu"], "samples_per_ray": bench["config"]["samples_per_ray"],
                       "ray_chunks_per_step": bench["roofline"]["all_kernels"]["bwd_dgrad"]["launches"] // bench["steps"]},
            "kernels": {}}
-for key, name in KERNELS.items():
-    fk = [k for k in fetch if name in k]
-    wk = [k for k in write if name in k]
-    if not fk or not wk:
+for key, names in KERNELS.items():
+    fk, name = pick(fetch, names)
+    wk, _ = pick(write, names)
+    if fk is None or wk is None:
         continue
-    rd = mean_last(fetch[fk[0]]["FETCH_SIZE"]) * 1024 * 2
-    wr = mean_last(write[wk[0]]["WRITE_SIZE"]) * 1024
+    rd = mean_last(fetch[fk]["FETCH_SIZE"]) * 1024 * 2
+    wr = mean_last(write[wk]["WRITE_SIZE"]) * 1024
     traffic["kernels"][key] = {"kernel": name, "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr}
 json.dump(traffic, open(os.path.join(dst, f"{tag}_{prec}_pmc_traffic.json"), "w"), indent=1)
 
@@ -80,10 +92,11 @@ sq = per_kernel("pmc_SQ")
 out = {"how": "one rocprofv3 --pmc pass (8 SQ counters + GRBM_GUI_ACTIVE) --kernel-trace over bench.py --steps 2 --warmup 1; means per dispatch. "
               "mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs); wait/active fractions are of SQ_WAVE_CYCLES",
        "kernels": {}}
-for key, name in KERNELS.items():
-    ks = [k for k in sq if name in k]
-    if not ks:
+for key, names in KERNELS.items():
+    k0, name = pick(sq, names)
+    if k0 is None:
         continue
+    ks = [k0]
     d = {c: sum(v) / len(v) for c, v in sq[ks[0]].items()}
     cyc = d["GRBM_GUI_ACTIVE"] / 8
     out["kernels"][key] = {"kernel": name, "dispatches": len(sq[ks[0]]["SQ_WAVE_CYCLES"]), "gpu_cycles_per_xcd": cyc,
