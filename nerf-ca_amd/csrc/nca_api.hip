@@ -240,35 +240,47 @@ extern "C" int nca_composite_bwd(int64_t, int32_t, int32_t, int32_t, float, cons
 //   masks     [wave tile][2][max(NL) - 1][1 KiB]                          ReLU bit masks of the hidden layers
 //   raw       [wave tile][2][64] f32                                      raw net outputs
 struct StorePlan {
-    int64_t h_stride, row0[2], off_m, off_r, bytes;
+    int64_t h_stride;     // per 32-sample tile of the H region: bytes (bf16) / rows of 32 floats (f32)
+    int64_t row0[2], off_m, off_r, bytes;
     int32_t mask_layers;
 };
-static bool store_plan(const NcaLayout* lays, int nnets, int64_t wave_tiles, StorePlan* sp) {
+// wave_tiles: 64-sample tiles (bf16) / 32-sample tiles (f32)
+static bool store_plan(const NcaLayout* lays, int nnets, int32_t prec, int64_t wave_tiles, StorePlan* sp) {
     if (nnets == 2 && lays[0].F != lays[1].F) return false;
+    const bool bf = prec == NCA_PREC_BF16;
     memset(sp, 0, sizeof(*sp));
     for (int n = 0; n < nnets; ++n) {
         if (lays[n].NL < 2) return false;                 // no hidden layer: nothing worth storing
         sp->row0[n] = sp->h_stride;
-        sp->h_stride += 32 * (int64_t)NCA_BF_ENCROWS * 2 + (int64_t)lays[n].NL * 32 * lays[n].F * 2;
+        if (bf) sp->h_stride += 32 * (int64_t)NCA_BF_ENCROWS * 2 + (int64_t)lays[n].NL * 32 * lays[n].F * 2;
+        else sp->h_stride += lays[n].K0rows_pad + (int64_t)lays[n].NL * lays[n].F;
         if (lays[n].NL - 1 > sp->mask_layers) sp->mask_layers = lays[n].NL - 1;
     }
-    sp->off_m = align_up(wave_tiles * 2 * sp->h_stride, 1024);
-    sp->off_r = sp->off_m + wave_tiles * 2 * sp->mask_layers * 1024;
-    sp->bytes = align_up(sp->off_r + wave_tiles * 2 * 64 * 4, 256);
+    if (bf) {
+        sp->off_m = align_up(wave_tiles * 2 * sp->h_stride, 1024);
+        sp->off_r = sp->off_m + wave_tiles * 2 * sp->mask_layers * 1024;
+        sp->bytes = align_up(sp->off_r + wave_tiles * 2 * 64 * 4, 256);
+    } else {
+        sp->off_m = align_up(wave_tiles * sp->h_stride * 32 * 4, 1024);
+        sp->off_r = sp->off_m + wave_tiles * 2 * sp->mask_layers * 512;
+        sp->bytes = align_up(sp->off_r + wave_tiles * 2 * 32 * 4, 256);
+    }
     return true;
 }
 
 extern "C" int64_t nca_render_store_bytes(const NcaRays* rays, const NcaNet* net_s, const NcaNet* net_d, int32_t prec) {
     int rc = check_rays(rays);
     if (rc) return rc;
-    if (prec != NCA_PREC_BF16) return 0;
+    rc = check_prec(prec);
+    if (rc) return rc;
     NcaLayout lays[2];
     const int nn = rays->single_field ? 1 : 2;
     rc = layout_of(net_s, &lays[0], prec);
     if (rc) return rc;
     if (nn == 2) { rc = layout_of(net_d, &lays[1], prec); if (rc) return rc; }
     StorePlan sp;
-    if (!store_plan(lays, nn, rays->R * ((rays->S + 63) / 64), &sp)) return 0;
+    const int ts = tile_samples(prec);
+    if (!store_plan(lays, nn, prec, rays->R * ((rays->S + ts - 1) / ts), &sp)) return 0;
     return sp.bytes;
 }
 
@@ -340,8 +352,8 @@ extern "C" int nca_render_fwd(const NcaRays* rays, int32_t prec,
     if (store) {
         NcaLayout lays[2] = {a.net[0].lay, a.net[1].lay};
         StorePlan spl;
-        if (prec != NCA_PREC_BF16 || !store_plan(lays, a.nnets, a.ntiles, &spl))
-            return fail(NCA_E_UNSUPPORTED, "a forward store needs the bf16 path, nets of one width and at least one hidden layer");
+        if (!store_plan(lays, a.nnets, prec, a.ntiles, &spl))
+            return fail(NCA_E_UNSUPPORTED, "a forward store needs nets of one width with at least one hidden layer");
         if (store_bytes < spl.bytes) return fail(NCA_E_WORKSPACE, "forward store %lld < %lld bytes", (long long)store_bytes, (long long)spl.bytes);
         kmode = NCA_KM_FWD_STORE;
         a.scratch = static_cast<float*>(store);
@@ -355,7 +367,7 @@ extern "C" int nca_render_fwd(const NcaRays* rays, int32_t prec,
     {
         Span sp(NCA_K_FWD, st);
         if (prec == NCA_PREC_BF16) HIPCHK(nca_launch_fused_bf16(a.net[0].lay.F, a, kmode, grid, st));
-        else HIPCHK(nca_launch_fused_f32(a.net[0].lay.F, a, false, grid, st));
+        else HIPCHK(nca_launch_fused_f32(a.net[0].lay.F, a, kmode, grid, st));
     }
     HIPCHK(nca_launch_pix_f32(rays->R, a.nchunk, rays->I0, a.part, pix, st));
     return NCA_OK;
@@ -382,7 +394,7 @@ static int plan_bwd(const NcaLayout* lays, int nnets, int32_t prec, int64_t unit
     p->slab_stride = 0;
     p->njobs = 0;
     for (int n = 0; n < nnets; ++n) {
-        if (stored) p->tile_stride += (int64_t)lays[n].NL * 32 * lays[n].F * 2;       // only the D blocks live in the chunk scratch
+        if (stored) p->tile_stride += bf ? (int64_t)lays[n].NL * 32 * lays[n].F * 2 : (int64_t)lays[n].NL * lays[n].F;   // only the D blocks live in the chunk scratch
         else p->tile_stride += bf ? nca_bf_tile_bytes(lays[n]) : scratch_rows(lays[n]);
         p->slab_stride += lays[n].n_params;
         for (int j = 0; j < lays[n].NL; ++j) p->njobs += lays[n].layer[j].kind == NCA_IN_SKIP ? 2 : 1;
@@ -424,9 +436,9 @@ static int plan_bwd(const NcaLayout* lays, int nnets, int32_t prec, int64_t unit
     return NCA_OK;
 }
 
-static void add_jobs_f32(NcaWgradArgs* w, const NcaLayout& y, int64_t row0, int64_t slab_off, int64_t onehot_off) {
+// row0: first row of the net's input block in a tile of the H region; drow0: of its D_0 in a tile of the D region
+static void add_jobs_f32(NcaWgradArgs* w, const NcaLayout& y, int64_t row0, int64_t drow0, int64_t slab_off, int64_t onehot_off) {
     const int64_t hrow0 = row0 + y.K0rows_pad;                    // inputs of layers 1..NL-1
-    const int64_t drow0 = hrow0 + (int64_t)(y.NL - 1) * y.F;      // D_0 .. D_{NL-1}
     for (int j = 0; j < y.NL; ++j) {
         const NcaLayerL& l = y.layer[j];
         bool bias_done = false;
@@ -504,7 +516,7 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     StorePlan spl;
     const bool stored = store != nullptr;
     if (stored) {
-        if (!bf || !store_plan(lays, a.nnets, units * tiles_per_unit, &spl)) return fail(NCA_E_UNSUPPORTED, "no forward store exists for this configuration");
+        if (!store_plan(lays, a.nnets, prec, units * tiles_per_unit, &spl)) return fail(NCA_E_UNSUPPORTED, "no forward store exists for this configuration");
         if (store_bytes < spl.bytes) return fail(NCA_E_WORKSPACE, "forward store %lld < %lld bytes", (long long)store_bytes, (long long)spl.bytes);
     }
     BwdPlan p;
@@ -520,15 +532,25 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     if (rc) return rc;
     int64_t off = 0, soff = 0;
     for (int n = 0; n < a.nnets; ++n) { a.net[n].row0 = off; off += bf ? nca_bf_tile_bytes(lays[n]) : scratch_rows(lays[n]); }
-    if (bf) {     // where each net's D blocks start inside a tile of the D region
+    {     // where each net's D blocks start inside a tile of the D region; where the [Wo | bo] tail of its last image is
         int64_t doff = 0;
         for (int n = 0; n < a.nnets; ++n) {
-            const int64_t EB = 32 * (int64_t)NCA_BF_ENCROWS * 2, HB = 32 * (int64_t)lays[n].F * 2;
-            if (stored) { a.net[n].row0 = spl.row0[n]; a.net[n].drow0 = doff; doff += (int64_t)lays[n].NL * HB; }
-            else a.net[n].drow0 = a.net[n].row0 + EB + (int64_t)(lays[n].NL - 1) * HB;
-            // [bias | Wo | bo] tail behind the k-steps of the last layer's forward image
-            const NcaLayerL& ll = lays[n].layer[lays[n].NL - 1];
-            a.net[n].wo_src = reinterpret_cast<const float*>(static_cast<const char*>(binds[n].packed) + ll.img_off + (int64_t)lays[n].MT * ll.ksteps * 1024) + 2 * lays[n].MT * 16;
+            const NcaLayout& y = lays[n];
+            const NcaLayerL& ll = y.layer[y.NL - 1];
+            const char* pk = static_cast<const char*>(binds[n].packed);
+            if (bf) {
+                const int64_t EB = 32 * (int64_t)NCA_BF_ENCROWS * 2, HB = 32 * (int64_t)y.F * 2;
+                if (stored) { a.net[n].row0 = spl.row0[n]; a.net[n].drow0 = doff; doff += (int64_t)y.NL * HB; }
+                else a.net[n].drow0 = a.net[n].row0 + EB + (int64_t)(y.NL - 1) * HB;
+                a.net[n].wo_src = reinterpret_cast<const float*>(pk + ll.img_off + (int64_t)y.MT * ll.ksteps * 1024) + 2 * y.MT * 16;
+            } else {
+                if (stored) { a.net[n].row0 = spl.row0[n]; a.net[n].drow0 = doff; doff += (int64_t)y.NL * y.F; }
+                else a.net[n].drow0 = a.net[n].row0 + y.K0rows_pad + (int64_t)(y.NL - 1) * y.F;
+                // f32 images: [k-steps x 64 x MT floats][bias 2 MT 16][Wo 2 MT 16][bo]; a last layer that is a skip
+                // layer keeps [Wo | bo] behind the k-steps of its second (hidden-part) image
+                if (ll.kind == NCA_IN_SKIP) a.net[n].wo_src = reinterpret_cast<const float*>(pk + ll.img2_off) + (int64_t)(ll.ksteps - ll.ksteps_enc) * 64 * y.MT;
+                else a.net[n].wo_src = reinterpret_cast<const float*>(pk + ll.img_off) + (int64_t)ll.ksteps * 64 * y.MT + 2 * y.MT * 16;
+            }
         }
     }
     int64_t slab_off[2] = {0, 0}, onehot_off[2] = {0, 0};
@@ -539,7 +561,7 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     memset(&w, 0, sizeof(w));
     for (int n = 0; n < a.nnets; ++n) {
         if (bf) add_jobs_bf16(&w, lays[n], a.net[n].row0, a.net[n].drow0, slab_off[n], onehot_off[n]);
-        else add_jobs_f32(&w, lays[n], a.net[n].row0, slab_off[n], onehot_off[n]);
+        else add_jobs_f32(&w, lays[n], a.net[n].row0, a.net[n].drow0, slab_off[n], onehot_off[n]);
     }
     w.scratch = scratch;
     w.slab = slab;
@@ -576,10 +598,10 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
         {
             Span sp(NCA_K_BWD_DGRAD, st);
             if (bf) HIPCHK(nca_launch_fused_bf16(F, a, stored ? NCA_KM_BWD_STORED : NCA_KM_BWD, p.grid, st));
-            else HIPCHK(nca_launch_fused_f32(F, a, true, p.grid, st));
+            else HIPCHK(nca_launch_fused_f32(F, a, stored ? NCA_KM_BWD_STORED : NCA_KM_BWD, p.grid, st));
         }
         w.rows_total = p.tile_stride;
-        w.tile0_b = stored ? u0 * tiles_per_unit * 2 : 0;
+        w.tile0_b = stored ? u0 * tiles_per_unit * (bf ? 2 : 1) : 0;      // in 32-sample tiles
         w.ntiles = bf ? a.ntiles * 2 : a.ntiles;
         w.accumulate = chunk > 0;
         {

@@ -170,7 +170,7 @@ int64_t nca_fine_partials(int64_t R);
 int64_t nca_loss_partials_bytes(int64_t R);
 
 hipError_t nca_launch_pack_f32(const NcaLayout& y, const float* prm, void* out, hipStream_t st);
-hipError_t nca_launch_fused_f32(int F, const NcaFusedArgs& a, bool bwd, int grid, hipStream_t st);
+hipError_t nca_launch_fused_f32(int F, const NcaFusedArgs& a, int kmode, int grid, hipStream_t st);
 hipError_t nca_launch_wgrad_f32(const NcaWgradArgs& a, int nsplit, hipStream_t st);
 hipError_t nca_launch_reduce_f32(const NcaReduceArgs& a, hipStream_t st);
 hipError_t nca_launch_pack_bf16(const NcaLayout& y, const float* prm, void* out, hipStream_t st);

@@ -274,8 +274,14 @@ __device__ __forceinline__ void stage_publish_counted(bool stores_issued) {
     __builtin_amdgcn_s_barrier();
 }
 
-template <int F, bool BWD>
+// Kernel modes as in the bf16 kernel (nca_kernels.hpp): 0 forward, 1 recompute backward (one scratch for H and D),
+// 2 forward that also stores the input block / layer inputs / ReLU masks / raw outputs, 3 backward from that store.
+template <int F, int MODE>
 __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a) {
+    constexpr bool BWD = MODE == NCA_KM_BWD || MODE == NCA_KM_BWD_STORED;
+    constexpr bool STORE = MODE == NCA_KM_BWD || MODE == NCA_KM_FWD_STORE;
+    constexpr bool RECOMP = MODE != NCA_KM_BWD_STORED;
+    constexpr bool FSTORE = MODE == NCA_KM_FWD_STORE, STORED = MODE == NCA_KM_BWD_STORED;
     constexpr int MT = FusedCfg<F>::MT;
     constexpr int BUF = FusedCfg<F>::BUF_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -285,6 +291,8 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
     const int cnf = a.const_net_floats;
     float* osum = cst + 2 * cnf;
     char* const maskbase = reinterpret_cast<char*>(osum + NCA_WAVES * 2 * (F + 1));
+    float* const wos = reinterpret_cast<float*>(maskbase);      // mode 3: [Wo | bo] of both nets (no last-layer image in LDS)
+    constexpr int WOS = 2 * MT * 16 + 16;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lj = lane & 31, lh = lane >> 5;
 
@@ -298,6 +306,9 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
     if (BWD) {
         for (int i = tid; i < NCA_WAVES * 2 * (F + 1); i += NCA_NT) osum[i] = 0.f;
     }
+    if (STORED)
+        for (int net = 0; net < a.nnets; ++net)
+            for (int i = tid; i < 2 * MT * 16 + 1; i += NCA_NT) wos[net * WOS + i] = a.net[net].wo_src[i];
     __syncthreads();
 
     // stage 0 -> buffer 0
@@ -323,8 +334,10 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
             valid = tvalid && smp < a.S;
             if (smp >= a.S) smp = a.S - 1;
             n = ray * a.S + smp;
-            const float zz = a.z[ray * a.zs_r + smp];
-            if (a.ray_is_f64) {
+            const float zz = RECOMP ? a.z[ray * a.zs_r + smp] : 0.f;
+            if (!RECOMP) {
+                p[0] = p[1] = p[2] = 0.f;
+            } else if (a.ray_is_f64) {
                 const double* o = reinterpret_cast<const double*>(a.origins) + ray * 3;
                 const double* d = reinterpret_cast<const double*>(a.dirs) + ray * 3;
 #pragma unroll
@@ -340,16 +353,19 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
             valid = tvalid && n < a.N;
             if (n >= a.N) n = a.N - 1;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) p[c] = a.pts[n * 3 + c];
+            for (int c = 0; c < 3; ++c) p[c] = RECOMP ? a.pts[n * 3 + c] : 0.f;
         }
         int ph = 0;
-        if (a.phase) {
+        if (RECOMP && a.phase) {
             ph = a.mode == NCA_MODE_RAYS ? a.phase[ray * a.ps_r + (int64_t)smp * a.ps_s] : a.phase[n];
         }
         // backward scratch is tile-major: scratch[tile][row][32 columns].  A wave owns one tile, so every
         // row it touches sits at a compile-time offset (row * 128 B) from one per-lane base; lane-half h
         // owns rows rho(i)+4h and carries those 4 rows in its base.
-        float* const tcol = BWD ? a.scratch + tl * a.rows_total * 32 + lj : nullptr;
+        // The input block and the layer inputs live in the H region (indexed by the tile's position in the whole batch
+        // when a storing forward wrote it), the output gradients in the D region of this launch (mode 1: the same).
+        const int64_t tg = tl + a.tile0;
+        float* const tcol = STORE ? a.scratch + tg * a.rows_total * 32 + lj : nullptr;
 
         float raw[2] = {0.f, 0.f};
 
@@ -363,94 +379,23 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
             const float* cwin = cnet;
             const float* cfour = cnet + NCA_CONST_WIN;
             const float* lat = y.T > 0 ? cnet + NCA_CONST_WIN + NCA_CONST_FOUR + phc * y.T : nullptr;
-            float* const hc = BWD ? tcol + na.row0 * 32 : nullptr;           // the row-major input block: this lane's column
+            float* const hc = STORE ? tcol + na.row0 * 32 : nullptr;         // the row-major input block: this lane's column
             // hidden blocks (H, D) are stored as the accumulators sit in registers: [row tile][register quad][lane][4 floats],
-            // quad g of lane (r, h) = rows 32 m + 8 g + 4 h + 0..3 of sample r -- one 1 KiB store per wave instruction
-            float* const hf = BWD ? a.scratch + (tl * a.rows_total + na.row0) * 32 + lane * 4 : nullptr;
+            // quad g of lane (r, h) = rows 32 m + 8 g + 4 h + 0..3 of sample r -- one 1 KiB store per wave instruction.
+            // hf: this net's rows of the H region (input block first), df: its D blocks
+            float* const hf = (BWD || STORE) ? a.scratch + (tg * a.rows_total + na.row0) * 32 + lane * 4 : nullptr;
+            float* const df = BWD ? reinterpret_cast<float*>(a.dscratch) + (tl * a.d_total + na.drow0) * 32 + lane * 4 : nullptr;
+            // storing forward / backward from the store: masks [tile][net][layer][lane][8 B], raw outputs [tile][net][32]
+            char* const mglob = (FSTORE || STORED) ? a.mstore + (((tg * 2 + net) * a.mstore_layers) * 64 + lane) * 8 : nullptr;
+            float* const rglob = (FSTORE || STORED) ? a.rstore + (tg * 2 + net) * 32 + lj : nullptr;
 
             f32x16 hprev[MT];
 #pragma unroll
             for (int m = 0; m < MT; ++m) hprev[m] = (f32x16)(0.f);
 
-            // ================= forward (recompute) ==========================================
-            for (int jj = 0; jj < y.NL; ++jj) {
-                const NcaLayerL& l = y.layer[jj];
-                // DMA the next image into the other buffer while this layer computes
-                const int nsi = (si + 1 == a.nstages) ? 0 : si + 1;
-                int nsi_final = nsi;
-                stage_issue(a.stage[nsi], smem + (cur ^ 1) * BUF, wave, lane);
-                const float* img = reinterpret_cast<const float*>(smem + cur * BUF);
-                const float* imgl = img + lane * MT;
-                // bias tail: behind the k-steps of this image (a skip layer's first image holds only its encoded part)
-                const float* tail = img + (l.kind == NCA_IN_SKIP ? l.ksteps_enc : l.ksteps) * 64 * MT;
-                const float* wo_tail = tail + 2 * MT * 16;     // Wo, bo (last layer); re-pointed for skip layers below
-
-                f32x16 acc[MT];
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[m][i] = tail[(lh * MT + m) * 16 + i];
-
-                if (l.kind != NCA_IN_HID) {
-                    float* const henc = hc;   // rows [0, K0rows_pad)
-                    enc_steps(y, p, cwin, cfour, lat, [&](int s, float fa, float fb) {
-                        const float bop = lh ? fb : fa;
-                        float av[MT];
-                        load_a<MT>(imgl + s * 64 * MT, av);
-#pragma unroll
-                        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bop, acc[m], 0, 0, 0);
-                        if (BWD && jj == 0 && tvalid) {
-                            int ia, ib;
-                            nca_enc_pair(y, s, &ia, &ib);
-                            const int row = lh ? ib : ia;
-                            if (row >= 0) __builtin_nontemporal_store(bop, henc + row * 32);
-                        }
-                    });
-                    if (BWD && jj == 0 && y.P > 0 && tvalid) {
-                        // one-hot phase rows: their "weight gradient" is sum_n [phase_n = p] D0[:, n]
-                        for (int pp = lh; pp < y.P; pp += 2) __builtin_nontemporal_store((pp == phc) ? 1.f : 0.f, henc + (y.K0 + pp) * 32);
-                    }
-                }
-                if (l.kind == NCA_IN_SKIP) {
-                    // second stage of the skip layer: publish the hidden-part image, prefetch the one after it
-                    stage_publish();
-                    cur ^= 1;
-                    si = nsi;
-                    const int nsi2 = (si + 1 == a.nstages) ? 0 : si + 1;
-                    stage_issue(a.stage[nsi2], smem + (cur ^ 1) * BUF, wave, lane);
-                    const float* img2 = reinterpret_cast<const float*>(smem + cur * BUF);
-                    hidden_steps<MT>(img2 + lane * MT, hprev, acc, hf + (y.K0rows_pad + (jj - 1) * F) * 32, BWD && tvalid);   // stores H_{jj-1}
-                    wo_tail = img2 + (l.ksteps - l.ksteps_enc) * 64 * MT;
-                    nsi_final = nsi2;
-                } else if (l.kind != NCA_IN_ENC) {
-                    hidden_steps<MT>(imgl, hprev, acc, hf + (y.K0rows_pad + (jj - 1) * F) * 32, BWD && tvalid);            // stores H_{jj-1}
-                }
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) hprev[m][i] = fmaxf(acc[m][i], 0.f);
-
-                if (BWD && a.mask_layers > 0 && jj + 1 < y.NL) {
-                    // ReLU mask of this layer's output for the dgrad sweep: bit 16 (m & 1) + i of word m >> 1 <-> acc[m][i]
-                    unsigned mw[2] = {0u, 0u};
-#pragma unroll
-                    for (int m = 0; m < MT; ++m)
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) mw[m >> 1] |= (hprev[m][i] > 0.f ? 1u : 0u) << (16 * (m & 1) + i);
-                    *reinterpret_cast<uint2*>(maskbase + ((wave * a.mask_layers + jj) * 64 + lane) * 8) = make_uint2(mw[0], mw[1]);
-                }
-                if (jj == y.NL - 1) {
-                    // output layer F -> 1 from the image tail (model/CPPN.py:108)
-                    const float* wo = wo_tail;
-                    float part = 0.f;
-#pragma unroll
-                    for (int m = 0; m < MT; ++m)
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) part = fmaf(wo[(lh * MT + m) * 16 + i], hprev[m][i], part);
-                    part += __shfl_xor(part, 32);
-                    raw[net] = part + wo[2 * MT * 16];
-
-                    if (BWD) {
+            // Gradient wrt the raw output, output-layer parameter gradients and D_{NL-1}: expects the last hidden layer's
+            // output in hprev and this net's raw output in raw[net]; leaves D_{NL-1} in hprev.  `wo` = [Wo | bo] in LDS.
+            auto last_layer_grads = [&](const float* wo) __attribute__((always_inline)) {
                         // gradient wrt the raw output of this net
                         float g;
                         if (a.mode == NCA_MODE_RAYS && !a.g_raw) {
@@ -513,13 +458,121 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
 #pragma unroll
                             for (int i = 0; i < 16; ++i) hprev[m][i] = hprev[m][i] > 0.f ? wo[(lh * MT + m) * 16 + i] * g : 0.f;
                         }
+            };
+
+            // ================= forward (recompute) ==========================================
+            for (int jj = 0; RECOMP && jj < y.NL; ++jj) {
+                const NcaLayerL& l = y.layer[jj];
+                // DMA the next image into the other buffer while this layer computes
+                const int nsi = (si + 1 == a.nstages) ? 0 : si + 1;
+                int nsi_final = nsi;
+                stage_issue(a.stage[nsi], smem + (cur ^ 1) * BUF, wave, lane);
+                const float* img = reinterpret_cast<const float*>(smem + cur * BUF);
+                const float* imgl = img + lane * MT;
+                // bias tail: behind the k-steps of this image (a skip layer's first image holds only its encoded part)
+                const float* tail = img + (l.kind == NCA_IN_SKIP ? l.ksteps_enc : l.ksteps) * 64 * MT;
+                const float* wo_tail = tail + 2 * MT * 16;     // Wo, bo (last layer); re-pointed for skip layers below
+
+                f32x16 acc[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[m][i] = tail[(lh * MT + m) * 16 + i];
+
+                if (l.kind != NCA_IN_HID) {
+                    float* const henc = hc;   // rows [0, K0rows_pad)
+                    enc_steps(y, p, cwin, cfour, lat, [&](int s, float fa, float fb) {
+                        const float bop = lh ? fb : fa;
+                        float av[MT];
+                        load_a<MT>(imgl + s * 64 * MT, av);
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bop, acc[m], 0, 0, 0);
+                        if (STORE && jj == 0 && tvalid) {
+                            int ia, ib;
+                            nca_enc_pair(y, s, &ia, &ib);
+                            const int row = lh ? ib : ia;
+                            if (row >= 0) __builtin_nontemporal_store(bop, henc + row * 32);
+                        }
+                    });
+                    if (STORE && jj == 0 && y.P > 0 && tvalid) {
+                        // one-hot phase rows: their "weight gradient" is sum_n [phase_n = p] D0[:, n]
+                        for (int pp = lh; pp < y.P; pp += 2) __builtin_nontemporal_store((pp == phc) ? 1.f : 0.f, henc + (y.K0 + pp) * 32);
                     }
                 }
+                if (l.kind == NCA_IN_SKIP) {
+                    // second stage of the skip layer: publish the hidden-part image, prefetch the one after it
+                    stage_publish();
+                    cur ^= 1;
+                    si = nsi;
+                    const int nsi2 = (si + 1 == a.nstages) ? 0 : si + 1;
+                    stage_issue(a.stage[nsi2], smem + (cur ^ 1) * BUF, wave, lane);
+                    const float* img2 = reinterpret_cast<const float*>(smem + cur * BUF);
+                    hidden_steps<MT>(img2 + lane * MT, hprev, acc, hf + (y.K0rows_pad + (jj - 1) * F) * 32, STORE && tvalid); // stores H_{jj-1}
+                    wo_tail = img2 + (l.ksteps - l.ksteps_enc) * 64 * MT;
+                    nsi_final = nsi2;
+                } else if (l.kind != NCA_IN_ENC) {
+                    hidden_steps<MT>(imgl, hprev, acc, hf + (y.K0rows_pad + (jj - 1) * F) * 32, STORE && tvalid);          // stores H_{jj-1}
+                }
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) hprev[m][i] = fmaxf(acc[m][i], 0.f);
 
-                if (BWD && l.kind == NCA_IN_HID) stage_publish_counted<4 * MT>(tvalid);   // the H_{jj-1} stores issued inside the contraction
+                if (((MODE == NCA_KM_BWD && a.mask_layers > 0) || FSTORE) && jj + 1 < y.NL) {
+                    // ReLU mask of this layer's output for the dgrad sweep: bit 16 (m & 1) + i of word m >> 1 <-> acc[m][i]
+                    unsigned mw[2] = {0u, 0u};
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) mw[m >> 1] |= (hprev[m][i] > 0.f ? 1u : 0u) << (16 * (m & 1) + i);
+                    if (FSTORE) { if (tvalid) __builtin_nontemporal_store(((unsigned long long)mw[1] << 32) | mw[0], reinterpret_cast<unsigned long long*>(mglob + jj * 512)); }
+                    else *reinterpret_cast<uint2*>(maskbase + ((wave * a.mask_layers + jj) * 64 + lane) * 8) = make_uint2(mw[0], mw[1]);
+                }
+                if (jj == y.NL - 1) {
+                    // output layer F -> 1 from the image tail (model/CPPN.py:108)
+                    const float* wo = wo_tail;
+                    float part = 0.f;
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) part = fmaf(wo[(lh * MT + m) * 16 + i], hprev[m][i], part);
+                    part += __shfl_xor(part, 32);
+                    raw[net] = part + wo[2 * MT * 16];
+                    if (FSTORE && tvalid) {
+                        // what the backward from the store cannot get from a later contraction: the last hidden layer's
+                        // output (block NL-1 of the H region) and the raw output
+                        float* hl = hf + (y.K0rows_pad + (y.NL - 1) * F) * 32;
+                        asm volatile("" : "+v"(hl));
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) store_quad(hl + (m * 4 + q) * 256, hprev[m][4 * q], hprev[m][4 * q + 1], hprev[m][4 * q + 2], hprev[m][4 * q + 3]);
+                        if (lh == 0) __builtin_nontemporal_store(raw[net], rglob);
+                    }
+
+                    if (MODE == NCA_KM_BWD) last_layer_grads(wo);
+                }
+
+                // hidden layers of the storing modes: at least 4 MT stores (H_{jj-1}, inside the contraction) follow the DMA
+                if (STORE && l.kind == NCA_IN_HID) stage_publish_counted<4 * MT>(tvalid);
                 else stage_publish();
                 cur ^= 1;
                 si = nsi_final;
+            }
+
+            if (STORED) {
+                // the forward state comes from the store: raw output and the last hidden layer's output in register order
+                raw[net] = *rglob;
+                const float* hl = hf + (y.K0rows_pad + (y.NL - 1) * F) * 32;
+                asm volatile("" : "+v"(hl));
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4e v = __builtin_nontemporal_load(reinterpret_cast<const f32x4e*>(hl + (m * 4 + q) * 256));
+                        hprev[m][4 * q] = v[0]; hprev[m][4 * q + 1] = v[1]; hprev[m][4 * q + 2] = v[2]; hprev[m][4 * q + 3] = v[3];
+                    }
+                last_layer_grads(wos + net * WOS);
             }
 
             // ================= backward sweep (dgrad) =======================================
@@ -532,23 +585,29 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
                     f32x16 acc[MT];
 #pragma unroll
                     for (int m = 0; m < MT; ++m) acc[m] = (f32x16)(0.f);
-                    hidden_steps<MT>(imgl, hprev, acc, hf + (y.K0rows_pad + (y.NL - 1) * F + jj * F) * 32, tvalid);         // stores D_jj
+                    hidden_steps<MT>(imgl, hprev, acc, df + jj * F * 32, tvalid);         // stores D_jj
                     // mask with the ReLU pattern of layer jj's input (= output of layer jj-1)
                     const float* hh = hf + (y.K0rows_pad + (jj - 1) * F) * 32;
                     asm volatile("" : "+v"(hh));
                     uint2 mv = make_uint2(0u, 0u);
-                    if (a.mask_layers > 0) mv = *reinterpret_cast<const uint2*>(maskbase + ((wave * a.mask_layers + (jj - 1)) * 64 + lane) * 8);
+                    const bool bits = STORED || a.mask_layers > 0;           // mask bits at hand (else: re-read the layer input)
+                    if (STORED) {
+                        const unsigned long long w = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(mglob + (jj - 1) * 512));
+                        mv = make_uint2((unsigned)w, (unsigned)(w >> 32));
+                    } else if (a.mask_layers > 0) {
+                        mv = *reinterpret_cast<const uint2*>(maskbase + ((wave * a.mask_layers + (jj - 1)) * 64 + lane) * 8);
+                    }
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
                         const unsigned fld = ((m >> 1) ? mv.y : mv.x) >> (16 * (m & 1));
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
-                            if (a.mask_layers == 0) hv = *reinterpret_cast<const float4*>(hh + (m * 4 + q) * 256);     // fallback: masks did not fit in LDS
-                            const bool on[4] = {a.mask_layers > 0 ? ((fld >> (4 * q)) & 1u) != 0u : hv.x > 0.f,
-                                                a.mask_layers > 0 ? ((fld >> (4 * q + 1)) & 1u) != 0u : hv.y > 0.f,
-                                                a.mask_layers > 0 ? ((fld >> (4 * q + 2)) & 1u) != 0u : hv.z > 0.f,
-                                                a.mask_layers > 0 ? ((fld >> (4 * q + 3)) & 1u) != 0u : hv.w > 0.f};
+                            if (!bits) hv = *reinterpret_cast<const float4*>(hh + (m * 4 + q) * 256);     // fallback: masks did not fit in LDS
+                            const bool on[4] = {bits ? ((fld >> (4 * q)) & 1u) != 0u : hv.x > 0.f,
+                                                bits ? ((fld >> (4 * q + 1)) & 1u) != 0u : hv.y > 0.f,
+                                                bits ? ((fld >> (4 * q + 2)) & 1u) != 0u : hv.z > 0.f,
+                                                bits ? ((fld >> (4 * q + 3)) & 1u) != 0u : hv.w > 0.f};
 #pragma unroll
                             for (int k = 0; k < 4; ++k) hprev[m][4 * q + k] = on[k] ? acc[m][4 * q + k] : 0.f;
                         }
@@ -558,7 +617,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
                     si = nsi;
                 }
                 if (tvalid) {     // D_0 has no consumer in this kernel: stored here, drains under the next net / tile
-                    float* dd = hf + (y.K0rows_pad + (y.NL - 1) * F) * 32;
+                    float* dd = df;
                     asm volatile("" : "+v"(dd));
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
@@ -619,9 +678,11 @@ __global__ __launch_bounds__(256) void nca_wgrad_f32(const NcaWgradArgs a) {
     const int F = job.F, MT = F / 32;
     const int brows = job.b_rows_pad;                            // multiple of 32, <= 128
     const int CT = brows / 32;
+    // D blocks come from the D region of this launch, H / input blocks from the H region (the same buffer in the
+    // recompute backward; the whole batch's store after a storing forward)
     const float* __restrict__ Ag = a.scratch + job.d_row0 * 32;      // + tile * rows_total * 32
-    const float* __restrict__ Bg = a.scratch + job.b_row0 * 32;
-    const int64_t tstride = a.rows_total * 32;
+    const float* __restrict__ Bg = a.scratch_b + (a.tile0_b * a.rows_total_b + job.b_row0) * 32;
+    const int64_t tstride = a.rows_total * 32, tstride_b = a.rows_total_b * 32;
 
     const int64_t ntile = a.ntiles;
     const int64_t per = (ntile + gridDim.x - 1) / gridDim.x;
@@ -640,7 +701,7 @@ __global__ __launch_bounds__(256) void nca_wgrad_f32(const NcaWgradArgs a) {
     const bool bfrag = job.b_frag != 0;
     auto issue = [&](int64_t t) {
         const float* at = Ag + t * tstride + tid * 4;
-        const float* bt = Bg + t * tstride + tid * 4;
+        const float* bt = Bg + t * tstride_b + tid * 4;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const f32x4e va = 32 * i < F ? __builtin_nontemporal_load(reinterpret_cast<const f32x4e*>(at + i * 1024)) : (f32x4e){0.f, 0.f, 0.f, 0.f};
@@ -792,8 +853,9 @@ __global__ void nca_pix_f32(int64_t R, int nchunk, const float* __restrict__ I0,
 // ------------------------------------------------------------------------------------------
 // launchers (called from nca_api.cpp)
 // ------------------------------------------------------------------------------------------
-template <int F>
-static hipError_t launch_fused_t(const NcaFusedArgs& a_in, bool bwd, int grid, hipStream_t st) {
+template <int F, int MODE>
+static hipError_t launch_fused_mode(const NcaFusedArgs& a_in, int grid, hipStream_t st) {
+    constexpr bool bwd = MODE == NCA_KM_BWD || MODE == NCA_KM_BWD_STORED;
     NcaFusedArgs a = a_in;
     // constant area sized to the latents actually present (the cap of 2048 floats per net is rarely needed) ...
     int lat = 0;
@@ -804,27 +866,33 @@ static hipError_t launch_fused_t(const NcaFusedArgs& a_in, bool bwd, int grid, h
     // ... which leaves room for the ReLU masks of the recomputed layers (8 B per lane and layer): the dgrad sweep
     // then reads no H back from the scratch.  If they do not fit, it falls back to re-reading H.
     a.mask_layers = 0;
-    if (bwd) {
+    if (MODE == NCA_KM_BWD) {
         int ml = 0;
         for (int n = 0; n < a.nnets; ++n) ml = a.net[n].lay.NL - 1 > ml ? a.net[n].lay.NL - 1 : ml;
         const size_t need = (size_t)NCA_WAVES * ml * 512;
         if (ml > 0 && lds + need <= 160 * 1024) { a.mask_layers = ml; lds += need; }
     }
-    if (bwd) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_fused_f32<F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((nca_fused_f32<F, true>), dim3(grid), dim3(NCA_NT), lds, st, a);
-    } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_fused_f32<F, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((nca_fused_f32<F, false>), dim3(grid), dim3(NCA_NT), lds, st, a);
-    }
+    if (MODE == NCA_KM_BWD_STORED) lds += 2 * (2 * FusedCfg<F>::MT * 16 + 16) * sizeof(float);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_fused_f32<F, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((nca_fused_f32<F, MODE>), dim3(grid), dim3(NCA_NT), lds, st, a);
     return hipGetLastError();
 }
+template <int F>
+static hipError_t launch_fused_t(const NcaFusedArgs& a, int kmode, int grid, hipStream_t st) {
+    switch (kmode) {
+        case NCA_KM_FWD: return launch_fused_mode<F, NCA_KM_FWD>(a, grid, st);
+        case NCA_KM_BWD: return launch_fused_mode<F, NCA_KM_BWD>(a, grid, st);
+        case NCA_KM_FWD_STORE: return launch_fused_mode<F, NCA_KM_FWD_STORE>(a, grid, st);
+        case NCA_KM_BWD_STORED: return launch_fused_mode<F, NCA_KM_BWD_STORED>(a, grid, st);
+    }
+    return hipErrorInvalidValue;
+}
 
-hipError_t nca_launch_fused_f32(int F, const NcaFusedArgs& a, bool bwd, int grid, hipStream_t st) {
+hipError_t nca_launch_fused_f32(int F, const NcaFusedArgs& a, int kmode, int grid, hipStream_t st) {
     switch (F) {
-        case 32: return launch_fused_t<32>(a, bwd, grid, st);
-        case 64: return launch_fused_t<64>(a, bwd, grid, st);
-        case 128: return launch_fused_t<128>(a, bwd, grid, st);
+        case 32: return launch_fused_t<32>(a, kmode, grid, st);
+        case 64: return launch_fused_t<64>(a, kmode, grid, st);
+        case 128: return launch_fused_t<128>(a, kmode, grid, st);
     }
     return hipErrorInvalidValue;
 }
