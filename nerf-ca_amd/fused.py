@@ -173,6 +173,12 @@ class _RayBatch:
 STORE_FORWARD_LIMIT_BYTES = 96 << 30
 
 
+def forward_store_bytes(batch: _RayBatch, bs: FieldBinding, bd: Optional[FieldBinding]) -> int:
+    """Bytes a storing forward of this ray batch would leave for its backward (0: no store for this configuration)."""
+    desc = batch.desc()
+    return check(_capi.lib().nca_render_store_bytes(C.byref(desc), C.byref(bs.net), C.byref(bd.net) if bd is not None else None, bs.prec))
+
+
 def render_forward_raw(batch: _RayBatch, bs: FieldBinding, bd: Optional[FieldBinding], for_backward: bool = False):
     """Fused forward without autograd: returns (pix f64[R], sigma_s, sigma_d | None, keep) where ``keep``
     pins the packed weights / encoding buffers (and, with ``for_backward``, the forward store) the matching

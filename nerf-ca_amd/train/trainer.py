@@ -180,10 +180,32 @@ class CompositeTrainer:
         z = MH.randomize_depth(self.depth, self.device, self.draw_jitter(n_iter))
         dists = MH._interval_lengths(z, d)
         bs, bd = self.s._binding, self.t._binding
-        batch = _RayBatch(o, d, phases, self.I0[: hi - lo], z, dists, c.output_activation, False, 1e-2)
-        pix, sig_s, sig_d, keep = render_forward_raw(batch, bs, bd, for_backward=True)
-        terms, g_pix, g_s, g_d = fused_losses(pix, gt, w, sig_s, sig_d, dists, c, self.loss_weights(n_iter), inv_R=1.0 / R)
-        grads_s, grads_d = render_backward_raw(batch, bs, bd, keep, g_pix, g_s, g_d)
+        # Rays are independent given the weights and every loss term is a sum over rays (times the GLOBAL 1/R), so the
+        # step may run over ray micro-batches and add up: that keeps the forward store (the tensors autograd would keep)
+        # under fused.STORE_FORWARD_LIMIT_BYTES at any batch size instead of falling back to the recompute backward.
+        from .. import fused as FU
+        n_loc = hi - lo
+        whole = _RayBatch(o, d, phases, self.I0[:n_loc], z, dists, c.output_activation, False, 1e-2)
+        need = FU.forward_store_bytes(whole, bs, bd)
+        limit = FU.STORE_FORWARD_LIMIT_BYTES
+        micro = n_loc if need <= limit or need == 0 or limit <= 0 else max(1, int(n_loc * (limit / need)))
+        weights = self.loss_weights(n_iter)
+        terms = grads_s = grads_d = None
+        for m0 in range(0, n_loc, micro):
+            m1 = min(n_loc, m0 + micro)
+            batch = whole if micro == n_loc else _RayBatch(o[m0:m1], d[m0:m1], phases[m0:m1], self.I0[: m1 - m0], z, dists, c.output_activation, False, 1e-2)
+            pix, sig_s, sig_d, keep = render_forward_raw(batch, bs, bd, for_backward=True)
+            t_m, g_pix, g_s, g_d = fused_losses(pix, gt[m0:m1], w[m0:m1], sig_s, sig_d, dists, c, weights, inv_R=1.0 / R)
+            gs_m, gd_m = render_backward_raw(batch, bs, bd, keep, g_pix, g_s, g_d)
+            del keep
+            if terms is None:
+                terms, grads_s, grads_d = t_m, gs_m, gd_m
+            else:       # sums, except the two logged maxima
+                mx = torch.maximum(terms[3:5], t_m[3:5])
+                terms = terms + t_m
+                terms[3:5] = mx
+                grads_s += gs_m
+                grads_d += gd_m
         if self.world > 1 or self.always_allreduce:
             flat = torch.cat([grads_d, grads_s])
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)

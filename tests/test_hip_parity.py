@@ -1056,3 +1056,36 @@ def test_stored_forward_backward_equals_recompute(dev, prec, R, S, F, early):
         assert torch.equal(x, y)
     for x, y in zip(outs[0][3:], outs[2][3:]):
         assert rel_err(y, x) < 2e-6
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_fused_step_over_ray_micro_batches(dev, prec):
+    """When the forward store of the whole batch would exceed fused.STORE_FORWARD_LIMIT_BYTES, step_fused runs the batch as
+    ray micro-batches (forward with store -> loss kernel with the GLOBAL 1/R -> backward) and adds up gradients and
+    loss terms: same loss, same terms, same parameters after the optimiser steps as the single-batch step."""
+    from nerfca_amd import fused, set_precision, synthetic
+    from nerfca_amd.model.CPPN import CPPN
+    from nerfca_amd.model.Temporal import Temporal
+    from nerfca_amd.train.trainer import CompositeTrainer, TrainConfig
+    data = synthetic.make_dataset(16, 48, dev, views=synthetic.TRAIN_VIEWS[:2], n_phases=3, F=32)
+    outs = []
+    saved = fused.STORE_FORWARD_LIMIT_BYTES
+    try:
+        for limit in (96 << 30, 1 << 20):        # 512 rays x 48 samples need ~3 MB (bf16) / ~6 MB (f32) of store
+            fused.STORE_FORWARD_LIMIT_BYTES = limit
+            torch.manual_seed(9)
+            sdef, tdef = synthetic.net_definitions(dev, F=64)
+            s, t = CPPN(sdef).to(dev), Temporal(tdef).to(dev)
+            set_precision(prec, s, t)
+            cfg = TrainConfig(depth_samples_per_ray_coarse=48, img_sample_size=512, favor_s_weight_delay_steps=0,
+                              l1_weight_start=1e-3, l1_weight_end=1e-3, occl_weight_start=1e-2, dynamic_entro_weight_start=1e-3,
+                              favor_s_weight_start=1e-3, entro_mask_thre=1e-6)
+            tr = CompositeTrainer(cfg, s, t, data, dev, seed=5, fused_loss=True)
+            rec = [tr.step_fused(1000 + it)[2].cpu().clone() for it in range(3)]
+            outs.append((rec, torch.cat([p.detach().flatten() for p in tr.params]).cpu()))
+    finally:
+        fused.STORE_FORWARD_LIMIT_BYTES = saved
+    tol = 1e-5 if prec == "f32" else 1e-3
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert torch.allclose(a, b, rtol=tol, atol=1e-12), (a, b)
+    assert rel_err(outs[1][1], outs[0][1]) < tol
