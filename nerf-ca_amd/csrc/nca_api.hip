@@ -183,11 +183,13 @@ static int add_stage(NcaFusedArgs* a, const void* base, uint32_t off, uint32_t b
     return NCA_OK;
 }
 
-static int build_stages(NcaFusedArgs* a, const NetBind* binds, bool bwd, bool stored = false) {
+// stored: 0 = all forward images (+ dgrad images when bwd); 1 = backward from a store that holds everything (f32: dgrad
+// images only); 2 = backward from a store without the last layer's output (bf16: the last forward image, then dgrad images)
+static int build_stages(NcaFusedArgs* a, const NetBind* binds, bool bwd, int stored = 0) {
     a->nstages = 0;
     for (int n = 0; n < a->nnets; ++n) {
         const NcaLayout& y = a->net[n].lay;
-        for (int j = 0; !stored && j < y.NL; ++j) {
+        for (int j = stored == 2 ? y.NL - 1 : 0; stored != 1 && j < y.NL; ++j) {
             int rc = add_stage(a, binds[n].packed, y.layer[j].img_off, y.layer[j].img_bytes);
             if (rc) return rc;
             if (y.layer[j].img2_bytes) {            // second stage of a skip layer
@@ -236,9 +238,10 @@ static void rays_to_args(const NcaRays* r, NcaFusedArgs* a, int32_t prec) {
 extern "C" int nca_composite_fwd(int64_t, int32_t, int32_t, int32_t, float, const float*, const float*, const float*, const double*, double*, float*, float*, void*);
 extern "C" int nca_composite_bwd(int64_t, int32_t, int32_t, int32_t, float, const float*, const float*, const double*, const double*, const float*, const float*, float*, float*, void*);
 // The store a bf16 forward can leave behind for its backward (so that the backward does not recompute the layers):
-//   H region  [32-sample tile][net][input block | NL layer outputs]      (the recompute backward's H blocks + the last one)
-//   masks     [wave tile][2][max(NL) - 1][1 KiB]                          ReLU bit masks of the hidden layers
-//   raw       [wave tile][2][64] f32                                      raw net outputs
+//   H region  [32-sample tile][net][input block | layer outputs]         bf16: the inputs of all NL layers (the backward
+//                                                                          recomputes the last layer); f32: + the last output
+//   masks     [wave tile][2][max(NL) - 1][1 KiB | 512 B]                  ReLU bit masks of the hidden layers
+//   raw       [wave tile][2][32] f32                                      raw net outputs (f32 only)
 struct StorePlan {
     int64_t h_stride;     // per 32-sample tile of the H region: bytes (bf16) / rows of 32 floats (f32)
     int64_t row0[2], off_m, off_r, bytes;
@@ -252,14 +255,14 @@ static bool store_plan(const NcaLayout* lays, int nnets, int32_t prec, int64_t w
     for (int n = 0; n < nnets; ++n) {
         if (lays[n].NL < 2) return false;                 // no hidden layer: nothing worth storing
         sp->row0[n] = sp->h_stride;
-        if (bf) sp->h_stride += 32 * (int64_t)NCA_BF_ENCROWS * 2 + (int64_t)lays[n].NL * 32 * lays[n].F * 2;
+        if (bf) sp->h_stride += 32 * (int64_t)NCA_BF_ENCROWS * 2 + (int64_t)(lays[n].NL - 1) * 32 * lays[n].F * 2;   // inputs of layers 0 .. NL-1
         else sp->h_stride += lays[n].K0rows_pad + (int64_t)lays[n].NL * lays[n].F;
         if (lays[n].NL - 1 > sp->mask_layers) sp->mask_layers = lays[n].NL - 1;
     }
     if (bf) {
         sp->off_m = align_up(wave_tiles * 2 * sp->h_stride, 1024);
-        sp->off_r = sp->off_m + wave_tiles * 2 * sp->mask_layers * 1024;
-        sp->bytes = align_up(sp->off_r + wave_tiles * 2 * 64 * 4, 256);
+        sp->off_r = sp->off_m + wave_tiles * 2 * sp->mask_layers * 1024;       // (no raw outputs: the bf16 backward recomputes the last layer)
+        sp->bytes = align_up(sp->off_r, 256);
     } else {
         sp->off_m = align_up(wave_tiles * sp->h_stride * 32 * 4, 1024);
         sp->off_r = sp->off_m + wave_tiles * 2 * sp->mask_layers * 512;
@@ -528,7 +531,7 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     float* oslab = reinterpret_cast<float*>(wb + p.off_oslab);
     float* scratch = reinterpret_cast<float*>(wb + p.off_scratch);
 
-    rc = build_stages(&a, binds, true, stored);
+    rc = build_stages(&a, binds, true, stored ? (bf ? 2 : 1) : 0);
     if (rc) return rc;
     int64_t off = 0, soff = 0;
     for (int n = 0; n < a.nnets; ++n) { a.net[n].row0 = off; off += bf ? nca_bf_tile_bytes(lays[n]) : scratch_rows(lays[n]); }

@@ -215,9 +215,6 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
     float* osum = reinterpret_cast<float*>(smem + 2 * BUF + NCA_CONST_BYTES);
     // ReLU masks of the recomputed layers: [wave][layer][lane][16 B] (2 bits per packed bf16 pair)
     char* const maskbase = smem + 2 * BUF + NCA_CONST_BYTES + NCA_WAVES * 2 * (F + 1) * 4;
-    // stored backward: no recompute, hence no last-layer image in LDS -- its [Wo | bo] tails are copied here once
-    float* const wos = reinterpret_cast<float*>(maskbase);            // [net][2 MT 16 + 16]
-    constexpr int WOS = 2 * MT * 16 + 16;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
 
@@ -229,9 +226,6 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
         if (na.lat) for (int i = tid; i < na.lay.P * na.lay.T; i += NCA_NT) c[NCA_CONST_WIN + NCA_CONST_FOUR + i] = na.lat[i];
     }
     if (BWD) for (int i = tid; i < NCA_WAVES * 2 * (F + 1); i += NCA_NT) osum[i] = 0.f;
-    if (STORED)
-        for (int net = 0; net < a.nnets; ++net)
-            for (int i = tid; i < 2 * MT * 16 + 1; i += NCA_NT) wos[net * WOS + i] = a.net[net].wo_src[i];
     __syncthreads();
     stage_issue_b(a.stage[0], smem, wave, lane);
     stage_publish_b();
@@ -298,9 +292,8 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
             char* const db = BWD ? d32 + na.drow0 : nullptr;             // this net's D blocks
             const bool lds_mask = MODE == NCA_KM_BWD && a.mask_layers >= y.NL - 1;
             char* const mwave = maskbase + (wave * a.mask_layers) * 1024 + lane * 16;
-            // stored forward: masks [wave tile][net][layer][lane][16 B], raw outputs [wave tile][net][lane]
+            // stored forward: ReLU masks [wave tile][net][layer][lane][16 B]
             char* const mglob = (FSTORE || STORED) ? a.mstore + ((tg * 2 + net) * a.mstore_layers) * 1024 + lane * 16 : nullptr;
-            float* const rglob = (FSTORE || STORED) ? a.rstore + (tg * 2 + net) * 64 + lane : nullptr;
 
             // ================= encoding, lane = sample ===================================================
             u32x4 B[2][KSMAX];
@@ -468,7 +461,16 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
 
             // ================= layers (forward / recompute) ===============================================
             float part[2] = {0.f, 0.f};       // output-layer partial dot per column tile
-            for (int jj = 0; RECOMP && jj < y.NL; ++jj) {
+            if (STORED) {
+                // the backward from the store recomputes ONE layer, the last: its input is in the store anyway (the wgrad
+                // reads it too), which saves the forward from writing that layer's output and the raw outputs
+                const char* hl = nb + EB + (y.NL - 2) * HB + lane * 16;
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int k = 0; k < 2 * MT; ++k) B[c][k] = load_nt(hl + c * a.rows_total + k * 1024);
+            }
+            for (int jj = STORED ? y.NL - 1 : 0; jj < y.NL; ++jj) {
                 const NcaLayerL& l = y.layer[jj];
                 const int nsi = (si + 1 == a.nstages) ? 0 : si + 1;
                 stage_issue_b(a.stage[nsi], smem + (cur ^ 1) * BUF, wave, lane);
@@ -476,9 +478,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                 const int nks = l.ksteps;
                 const float* tail = reinterpret_cast<const float*>(img + MT * nks * 1024);
                 const bool last = jj == y.NL - 1;
-                // every layer input goes to the store; the stored forward also keeps the last layer's output (the
-                // backward without recompute needs it for the output-layer gradients)
-                const bool store_h = STORE && tvalid && (!last || FSTORE);
+                const bool store_h = STORE && tvalid && !last;
                 char* const hblk = STORE ? nb + EB + jj * HB : nullptr;          // input block of layer jj+1
                 u32x4 Bn[2][2 * MT];
                 unsigned mw[2][2] = {{0u, 0u}, {0u, 0u}};     // mask words: [column tile][row-tile pair]
@@ -562,28 +562,17 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                     const float r0 = part[0] + __shfl_xor(part[0], 32) + bo;
                     const float r1 = part[1] + __shfl_xor(part[1], 32) + bo;
                     raw[net] = lh ? r1 : r0;
-                    if (FSTORE && tvalid) *rglob = raw[net];
                 }
 
-                if (MODE == NCA_KM_BWD && last) last_layer_grads(tail + 2 * MT * 16);
+                if (BWD && last) last_layer_grads(tail + 2 * MT * 16);
 
-                // at least 4 MT stores follow the weight DMA of every storing stage (H, or D_{NL-1} on the last layer of the
-                // recompute backward; the stored forward adds a mask or raw store on top, which it then also waits for)
-                if (STORE) stage_publish_counted<4 * MT>(tvalid);
+                // at least 4 MT stores follow the weight DMA of every storing stage: H (plus a mask store in the storing
+                // forward, which it then also waits for), or D_{NL-1} on the last layer of both backward modes; the last
+                // layer of the storing forward stores nothing
+                if ((STORE && !last) || (BWD && last)) stage_publish_counted<4 * MT>(tvalid);
                 else stage_publish_b();
                 cur ^= 1;
                 si = nsi;
-            }
-
-            if (STORED) {
-                // the forward state comes from the store: raw output, the last layer's packed output as it sat in registers
-                raw[net] = *rglob;
-                const char* hl = nb + EB + (y.NL - 1) * HB + lane * 16;
-#pragma unroll
-                for (int c = 0; c < 2; ++c)
-#pragma unroll
-                    for (int k = 0; k < 2 * MT; ++k) B[c][k] = load_nt(hl + c * a.rows_total + k * 1024);
-                last_layer_grads(wos + net * WOS);
             }
 
             // ================= backward sweep (dgrad) =====================================================
@@ -829,7 +818,6 @@ static hipError_t launch_fused_bf_mode(const NcaFusedArgs& a, int grid, hipStrea
     size_t lds = 2 * BfCfg<F>::BUF_BYTES + NCA_CONST_BYTES;
     if (bwd) lds += NCA_WAVES * 2 * (F + 1) * sizeof(float);
     if (MODE == NCA_KM_BWD) lds += (size_t)NCA_WAVES * a.mask_layers * 1024;
-    if (MODE == NCA_KM_BWD_STORED) lds += 2 * (2 * BfCfg<F>::MT * 16 + 16) * sizeof(float);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_fused_bf16<F, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((nca_fused_bf16<F, MODE>), dim3(grid), dim3(NCA_NT), lds, st, a);
     return hipGetLastError();
