@@ -236,8 +236,9 @@ class _RenderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, batch: _RayBatch, bs: FieldBinding, bd: Optional[FieldBinding], n_s: int, *params):
-        needs_grad = any(p.requires_grad for p in params)      # (autograd.Function.forward itself runs under no_grad)
-        pix, sig_s, sig_d, keep = render_forward_raw(batch, bs, bd, for_backward=needs_grad)
+        # batch.record: autograd is recording this call (see render_rays) -- only then will a backward follow and only
+        # then is the forward asked to keep its layer inputs
+        pix, sig_s, sig_d, keep = render_forward_raw(batch, bs, bd, for_backward=getattr(batch, "record", False))
         ctx.batch, ctx.bs, ctx.bd, ctx.keep = batch, bs, bd, keep
         if not batch.f64:
             pix = pix.to(torch.float32)
@@ -364,6 +365,8 @@ def render_rays(static_model, temp_model, origins, directions, phases, I0, z, di
         raise _capi.NcaError("static and dynamic networks must use the same precision (see set_precision)")
     batch = _RayBatch(origins, directions, phases, I0, z, dists, act, single or bd is None, scale)
     params = bs.params() + (bd.params() if bd is not None else [])
+    # (inside autograd.Function.forward grad mode is always off and needs_input_grad ignores torch.no_grad(): decide here)
+    batch.record = torch.is_grad_enabled() and any(p.requires_grad for p in params)
     return _RenderFn.apply(batch, bs, bd, len(bs.params()), *params)
 
 

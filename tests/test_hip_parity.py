@@ -1089,3 +1089,33 @@ def test_fused_step_over_ray_micro_batches(dev, prec):
     for a, b in zip(outs[0][0], outs[1][0]):
         assert torch.allclose(a, b, rtol=tol, atol=1e-12), (a, b)
     assert rel_err(outs[1][1], outs[0][1]) < tol
+
+
+def test_no_forward_store_without_autograd(dev):
+    """Under torch.no_grad() (evaluation) the autograd entry point must not ask the forward for a store: same outputs,
+    and no store-sized allocation."""
+    from nerfca_amd import fused, render_rays, set_precision
+    gen = torch.Generator().manual_seed(3)
+    ss, sd = O.NetSpec(num_filters=64, num_early_layers=2), O.NetSpec(num_filters=64, num_early_layers=2, num_time_dim=8)
+    s = make_static(O.init_params(ss, gen), dev, F=64, early=2, late=0)
+    t = make_dynamic(O.init_params(sd, gen), dev, F=64, early=2, late=0, T=8)
+    set_precision("bf16", s, t)
+    for m in (s, t):
+        m.update_freq_mask_alpha(75000, 150000)
+    R, S = 256, 64
+    o = (torch.rand(R, 3, generator=gen) * 0.2 + torch.tensor([3.0, -2.0, 2.5])).double().to(dev)
+    d = (torch.rand(R, 3, generator=gen) - 0.5).double().to(dev)
+    ph = torch.randint(0, 10, (R,), generator=gen).to(dev)
+    z = O.stratified_depths(O.depth_values(3.4259, 5.5741, S), torch.rand(S, generator=gen))
+    dists = O.ray_dists(z, torch.float64).to(dev)
+    I0 = torch.full((R,), 2.15991, device=dev)
+    calls = []
+    orig = fused.render_forward_raw
+    fused.render_forward_raw = lambda *a, **k: (calls.append(k.get("for_backward", False)), orig(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            p0 = render_rays(s, t, o, d, ph, I0, z.to(dev), dists)[0]
+        p1 = render_rays(s, t, o, d, ph, I0, z.to(dev), dists)[0]
+    finally:
+        fused.render_forward_raw = orig
+    assert calls == [False, True] and torch.equal(p0, p1.detach())
