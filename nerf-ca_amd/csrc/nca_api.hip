@@ -242,22 +242,39 @@ extern "C" int nca_composite_bwd(int64_t, int32_t, int32_t, int32_t, float, cons
 //                                                                          recomputes the last layer); f32: + the last output
 //   masks     [wave tile][2][max(NL) - 1][1 KiB | 512 B]                  ReLU bit masks of the hidden layers
 //   raw       [wave tile][2][32] f32                                      raw net outputs (f32 only)
+// bf16, static + dynamic net of one width with the same encoding (mode, bands, the SAME window / coefficient vectors):
+// the dynamic net's input block is a superset of the static one's and is stored once
+static bool can_share_enc(const NcaFusedArgs& a, int32_t prec) {
+    if (prec != NCA_PREC_BF16 || a.nnets != 2) return false;
+    const NcaLayout& s = a.net[0].lay;
+    const NcaLayout& d = a.net[1].lay;
+    return s.T == 0 && s.F == d.F && s.enc_mode == d.enc_mode && s.L == d.L && s.Kenc == d.Kenc && a.net[0].win == a.net[1].win &&
+           a.net[0].four == a.net[1].four;
+}
+
 struct StorePlan {
     int64_t h_stride;     // per 32-sample tile of the H region: bytes (bf16) / rows of 32 floats (f32)
     int64_t row0[2], off_m, off_r, bytes;
     int32_t mask_layers;
 };
 // wave_tiles: 64-sample tiles (bf16) / 32-sample tiles (f32)
-static bool store_plan(const NcaLayout* lays, int nnets, int32_t prec, int64_t wave_tiles, StorePlan* sp) {
+static bool store_plan(const NcaLayout* lays, int nnets, int32_t prec, int64_t wave_tiles, StorePlan* sp, bool share_enc = false) {
     if (nnets == 2 && lays[0].F != lays[1].F) return false;
     const bool bf = prec == NCA_PREC_BF16;
+    const int64_t EB = 32 * (int64_t)NCA_BF_ENCROWS * 2;
     memset(sp, 0, sizeof(*sp));
     for (int n = 0; n < nnets; ++n) {
         if (lays[n].NL < 2) return false;                 // no hidden layer: nothing worth storing
         sp->row0[n] = sp->h_stride;
-        if (bf) sp->h_stride += 32 * (int64_t)NCA_BF_ENCROWS * 2 + (int64_t)(lays[n].NL - 1) * 32 * lays[n].F * 2;   // inputs of layers 0 .. NL-1
+        if (bf) sp->h_stride += EB + (int64_t)(lays[n].NL - 1) * 32 * lays[n].F * 2;   // inputs of layers 0 .. NL-1
         else sp->h_stride += lays[n].K0rows_pad + (int64_t)lays[n].NL * lays[n].F;
         if (lays[n].NL - 1 > sp->mask_layers) sp->mask_layers = lays[n].NL - 1;
+    }
+    if (share_enc) {      // [dynamic: input block + hidden blocks][static: hidden blocks only]
+        const int64_t dyn = EB + (int64_t)(lays[1].NL - 1) * 32 * lays[1].F * 2;
+        sp->row0[1] = 0;
+        sp->row0[0] = dyn - EB;       // so that row0 + EB is where the static net's first hidden block starts
+        sp->h_stride -= EB;
     }
     if (bf) {
         sp->off_m = align_up(wave_tiles * 2 * sp->h_stride, 1024);
@@ -355,7 +372,8 @@ extern "C" int nca_render_fwd(const NcaRays* rays, int32_t prec,
     if (store) {
         NcaLayout lays[2] = {a.net[0].lay, a.net[1].lay};
         StorePlan spl;
-        if (!store_plan(lays, a.nnets, prec, a.ntiles, &spl))
+        a.share_enc = can_share_enc(a, prec) ? 1 : 0;
+        if (!store_plan(lays, a.nnets, prec, a.ntiles, &spl, a.share_enc != 0))
             return fail(NCA_E_UNSUPPORTED, "a forward store needs nets of one width with at least one hidden layer");
         if (store_bytes < spl.bytes) return fail(NCA_E_WORKSPACE, "forward store %lld < %lld bytes", (long long)store_bytes, (long long)spl.bytes);
         kmode = NCA_KM_FWD_STORE;
@@ -479,7 +497,7 @@ static void add_jobs_f32(NcaWgradArgs* w, const NcaLayout& y, int64_t row0, int6
 }
 
 // net_off: byte offset of the net's input/H blocks in a tile of the H region; d_off: of its D blocks in a tile of the D region
-static void add_jobs_bf16(NcaWgradArgs* w, const NcaLayout& y, int64_t net_off, int64_t d_off, int64_t slab_off, int64_t onehot_off) {
+static void add_jobs_bf16(NcaWgradArgs* w, const NcaLayout& y, int64_t net_off, int64_t d_off, int64_t slab_off, int64_t onehot_off, int64_t enc_off) {
     const int64_t EB = 32 * (int64_t)NCA_BF_ENCROWS * 2, HB = 32 * (int64_t)y.F * 2;
     for (int j = 0; j < y.NL; ++j) {
         const NcaLayerL& l = y.layer[j];
@@ -493,7 +511,7 @@ static void add_jobs_bf16(NcaWgradArgs* w, const NcaLayout& y, int64_t net_off, 
         g.onehot_off = onehot_off;
         if (j == 0) {
             g.is_enc = 1;
-            g.b_row0 = net_off;
+            g.b_row0 = enc_off;          // the input block (the other net's when it is shared)
             g.b_row_bytes = NCA_BF_ENCROWS * 2;
             g.ncols_w = y.Kenc;
             g.T = y.T;
@@ -519,7 +537,8 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     StorePlan spl;
     const bool stored = store != nullptr;
     if (stored) {
-        if (!store_plan(lays, a.nnets, prec, units * tiles_per_unit, &spl)) return fail(NCA_E_UNSUPPORTED, "no forward store exists for this configuration");
+        a.share_enc = can_share_enc(a, prec) ? 1 : 0;        // the same decision the storing forward took (same nets, same vectors)
+        if (!store_plan(lays, a.nnets, prec, units * tiles_per_unit, &spl, a.share_enc != 0)) return fail(NCA_E_UNSUPPORTED, "no forward store exists for this configuration");
         if (store_bytes < spl.bytes) return fail(NCA_E_WORKSPACE, "forward store %lld < %lld bytes", (long long)store_bytes, (long long)spl.bytes);
     }
     BwdPlan p;
@@ -563,7 +582,7 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     static thread_local NcaWgradArgs w;
     memset(&w, 0, sizeof(w));
     for (int n = 0; n < a.nnets; ++n) {
-        if (bf) add_jobs_bf16(&w, lays[n], a.net[n].row0, a.net[n].drow0, slab_off[n], onehot_off[n]);
+        if (bf) add_jobs_bf16(&w, lays[n], a.net[n].row0, a.net[n].drow0, slab_off[n], onehot_off[n], stored && a.share_enc && n == 0 ? a.net[1].row0 : a.net[n].row0);
         else add_jobs_f32(&w, lays[n], a.net[n].row0, a.net[n].drow0, slab_off[n], onehot_off[n]);
     }
     w.scratch = scratch;

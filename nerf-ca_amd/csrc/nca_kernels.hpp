@@ -61,6 +61,9 @@ struct NcaFusedArgs {
     float* scratch;      // [tile][rows_total x 32 floats]: layer inputs H and output gradients D of each 32-sample tile
                          // (f32: input block row-major [row][32], hidden blocks [row tile][quad][lane][4]; bf16: see nca_bf_tile_bytes)
     int64_t rows_total;  // f32: scratch rows per 32-sample tile over all nets;  bf16: BYTES per 32-sample tile
+    int32_t share_enc;   // bf16, two nets with the same encoding (mode, bands, the SAME window / coefficient vectors): net 0 (static)
+                         // does not store its input block -- net 1's is a superset (+ latents, one-hot phase slots) and net 0's
+                         // layer-0 weight-gradient job reads that one
     // bf16 two-region addressing (NCA_KM_BWD: dscratch == scratch, d_total == rows_total, tile0 == 0)
     char* dscratch;      // D region of this launch: [local tile][d_total bytes]
     int64_t d_total;     // bytes per 32-sample tile of the D region

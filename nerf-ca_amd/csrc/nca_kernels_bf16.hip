@@ -354,7 +354,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                         B[0][s][w] = r[0];
                         B[1][s][w] = r[1];
                     }
-                if (STORE && tvalid) {
+                if (STORE && tvalid && !(a.share_enc && net == 0)) {
                     // input block of both column tiles, fragment-major [k-step][lane][16 B]: the layer-0
                     // operands as they sit in registers, then one k-step of one-hot phase slots
 #pragma unroll

@@ -173,6 +173,16 @@ class _RayBatch:
 STORE_FORWARD_LIMIT_BYTES = 96 << 30
 
 
+def _same_window(bs: FieldBinding, bd: FieldBinding) -> bool:
+    """Both nets use the same band encoding with equal window VALUES this step (the composite.txt default)."""
+    if bs.net.enc_mode != _capi.ENC_BANDS or bd.net.enc_mode != _capi.ENC_BANDS or bs.net.L != bd.net.L:
+        return False
+    if bs.static_window is not None or bd.static_window is not None:
+        return False       # graph-owned vectors: the owner decides (pointer equality is fixed at capture)
+    a, b = bs.module._band_window(), bd.module._band_window()
+    return (not a.is_cuda) and (not b.is_cuda) and a.shape == b.shape and bool(torch.equal(a, b))
+
+
 def forward_store_bytes(batch: _RayBatch, bs: FieldBinding, bd: Optional[FieldBinding]) -> int:
     """Bytes a storing forward of this ray batch would leave for its backward (0: no store for this configuration)."""
     desc = batch.desc()
@@ -189,6 +199,8 @@ def render_forward_raw(batch: _RayBatch, bs: FieldBinding, bd: Optional[FieldBin
     packed_d = bd.ensure_packed() if bd is not None else None
     win_s, four_s = bs.module._enc_buffers()
     win_d, four_d = bd.module._enc_buffers() if bd is not None else (None, None)
+    if bd is not None and win_s is not None and win_d is not None and win_s.data_ptr() != win_d.data_ptr() and _same_window(bs, bd):
+        win_d = win_s      # one vector for both nets: the library then stores the encoded input once (see share_enc)
     R, S = batch.R, batch.S
     pix = torch.empty(R, dtype=torch.float64, device=dev)
     sig_s = torch.empty((R, S), dtype=torch.float32, device=dev)

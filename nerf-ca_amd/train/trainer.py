@@ -266,6 +266,9 @@ class CompositeTrainer:
 
         bs.static_window = rec32[S:S + Ls] if Ls > 0 else None
         bd.static_window = rec32[S + Ls:S + Ls + Ld] if Ld > 0 else None
+        if (Ls == Ld and Ls > 0 and c.static_pos_enc == c.temp_pos_enc and c.static_pos_enc_window_decay_steps == c.temp_pos_enc_window_decay_steps
+                and getattr(self.s, "pos_enc_window_start", None) == getattr(self.t, "pos_enc_window_start", None)):
+            bd.static_window = bs.static_window     # identical schedules: one vector, the encoded input is stored once
         try:
             self._write_record(0)
             saved = [b.flat.clone() for b in (bd, bs)]
