@@ -577,6 +577,10 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
 
             // ================= backward sweep (dgrad) =====================================================
             if (BWD) {
+                // masks from the store are requested one layer ahead of their use (a load issued at the top of its own
+                // layer would be needed after one row tile, ~0.25 us later: an exposed HBM latency per layer)
+                u32x4 mnext = {0u, 0u, 0u, 0u};
+                if (STORED && y.NL >= 2) mnext = load_nt(mglob + (y.NL - 2) * 1024);
                 for (int jj = y.NL - 1; jj >= 1; --jj) {
                     const int nsi = (si + 1 == a.nstages) ? 0 : si + 1;
                     stage_issue_b(a.stage[nsi], smem + (cur ^ 1) * BUF, wave, lane);
@@ -586,7 +590,10 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                     u32x4 Bn[2][2 * MT];
                     u32x4 mv = {0u, 0u, 0u, 0u};
                     if (lds_mask) mv = *reinterpret_cast<const u32x4*>(mwave + (jj - 1) * 1024);
-                    if (STORED) mv = load_nt(mglob + (jj - 1) * 1024);
+                    if (STORED) {
+                        mv = mnext;
+                        if (jj >= 2) mnext = load_nt(mglob + (jj - 2) * 1024);
+                    }
                     const bool bits = lds_mask || STORED;         // mask bits at hand (else: re-read the layer input)
                     u32x4 A[NCA_BF_RING];
                     const char* imgl = img + lane * 16;
