@@ -221,6 +221,8 @@ def main():
         roof = {"bound": "mfma", "kernel": dom, "achieved": kern[dom]["tflops"], "peak": peak, "unit": "TFLOP/s",
                 "frac": kern[dom]["tflops"] / peak if kern[dom]["tflops"] else None, "traffic": measured_traffic(args, dom),
                 "avg_launch_ms": kern[dom]["avg_ms"], "launches": kern[dom]["launches"],
+                # the staged (non-algorithmic) HBM traffic of that kernel per second of its run time: what it is bound by in practice
+                "staging_TBps": (measured_traffic(args, dom) / (kern[dom]["avg_ms"] * 1e-3) / 1e12) if measured_traffic(args, dom) and kern[dom]["avg_ms"] else None,
                 "kernel_time_share": kern[dom]["ms_total"] / (dt * 1e3), "all_kernels": kern}
         out = {"metric": f"training rays/sec ({args.det}^2 det, {args.samples} samples/ray)", "value": args.rays * world * args.steps / dt, "unit": "rays/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
