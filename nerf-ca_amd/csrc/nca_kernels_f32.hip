@@ -791,35 +791,47 @@ __global__ void nca_reduce_f32(const NcaReduceArgs a) {
     const int64_t le = net == 0 ? e : e - a.n_params[0];
     const NcaReduceNet& rn = a.net[net];
     float* out = rn.grads + le;
-    if (le >= rn.wo_off) {
-        // Wo / bo: sum the fused kernel's per-workgroup partials
-        const int k = (int)(le - rn.wo_off);   // 0..F (F = bias)
-        float s = 0.f;
-        for (int w = 0; w < a.n_wg; ++w) s += a.oslab[(int64_t)w * a.oslab_stride + net * (rn.F + 1) + k];
-        *out = s;
-        return;
-    }
-    if (le < rn.lat_count) {
-        // time_latents[p][t] = sum_f W0[f][Kenc+t] * Dsum[f][p]; Dsum was reduced over the splits into
-        // slab 0 by nca_onehot_sum_f32 (launched before this kernel)
-        const int pp = (int)(le / rn.T), t = (int)(le % rn.T);
-        float s = 0.f;
-        for (int f = 0; f < rn.F; ++f)
-            s = fmaf(rn.params[rn.w0_off + f * rn.K0 + rn.Kenc + t], a.slab[rn.onehot_off + f * rn.P + pp], s);
-        *out = s;
-        return;
-    }
-    // four independent partial sums (splits q, q+1, q+2, q+3 mod 4) keep several loads in flight;
+    if (le >= rn.wo_off || le < rn.lat_count) return;       // Wo / bo and the latents: nca_reduce_small_f32 (long sums, few outputs)
+    // eight independent partial sums (splits q .. q+7 mod 8) keep several loads in flight;
     // the combination order is fixed, so the result is still bit-reproducible
-    float s4[4] = {0.f, 0.f, 0.f, 0.f};
+    float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const float* sp = a.slab + rn.slab_off + le;
     int q = 0;
-    for (; q + 4 <= a.n_split; q += 4) {
+    for (; q + 8 <= a.n_split; q += 8) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) s4[u] += sp[(int64_t)(q + u) * a.slab_stride];
+        for (int u = 0; u < 8; ++u) s8[u] += sp[(int64_t)(q + u) * a.slab_stride];
     }
-    for (; q < a.n_split; ++q) s4[0] += sp[(int64_t)q * a.slab_stride];
-    *out = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+    for (; q < a.n_split; ++q) s8[0] += sp[(int64_t)q * a.slab_stride];
+    *out = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+}
+
+// The few outputs with long sums -- Wo / bo (over the fused kernel's per-workgroup partials) and the time latents (over
+// the F rows of the one-hot block) -- one WAVE per output: lane-strided partial sums, then a fixed xor tree.
+__global__ __launch_bounds__(256) void nca_reduce_small_f32(const NcaReduceArgs a) {
+    const int lane = threadIdx.x & 63;
+    int64_t id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (int net = 0; net < 2; ++net) {
+        const NcaReduceNet& rn = a.net[net];
+        if (!rn.grads) continue;
+        const int64_t cnt = rn.lat_count + rn.F + 1;
+        if (id >= cnt) { id -= cnt; continue; }
+        float s = 0.f;
+        float* out;
+        if (id < rn.lat_count) {
+            // time_latents[p][t] = sum_f W0[f][Kenc+t] * Dsum[f][p]; Dsum was reduced over the splits into slab 0 by
+            // nca_onehot_sum_f32 (launched before this kernel)
+            const int pp = (int)(id / rn.T), t = (int)(id % rn.T);
+            for (int f = lane; f < rn.F; f += 64) s = fmaf(rn.params[rn.w0_off + f * rn.K0 + rn.Kenc + t], a.slab[rn.onehot_off + f * rn.P + pp], s);
+            out = rn.grads + id;
+        } else {
+            const int k = (int)(id - rn.lat_count);           // 0..F (F = bias)
+            for (int w = lane; w < a.n_wg; w += 64) s += a.oslab[(int64_t)w * a.oslab_stride + net * (rn.F + 1) + k];
+            out = rn.grads + rn.wo_off + k;
+        }
+        s += __shfl_xor(s, 32); s += __shfl_xor(s, 16); s += __shfl_xor(s, 8); s += __shfl_xor(s, 4); s += __shfl_xor(s, 2); s += __shfl_xor(s, 1);
+        if (lane == 0) *out = s;
+        return;
+    }
 }
 
 // Dsum[f][p] = sum over splits of the one-hot block, written in place into slab 0 (fixed order)
@@ -917,6 +929,9 @@ hipError_t nca_launch_reduce_f32(const NcaReduceArgs& a, hipStream_t st) {
     if (hot > 0) hipLaunchKernelGGL(nca_onehot_sum_f32, dim3((int)((hot + 255) / 256)), dim3(256), 0, st, a);
     const int grid = (int)((a.n_total + 255) / 256);
     hipLaunchKernelGGL(nca_reduce_f32, dim3(grid), dim3(256), 0, st, a);
+    int64_t small = 0;
+    for (int n = 0; n < 2; ++n) if (a.net[n].grads) small += a.net[n].lat_count + a.net[n].F + 1;
+    if (small > 0) hipLaunchKernelGGL(nca_reduce_small_f32, dim3((int)((small + 3) / 4)), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
