@@ -1120,3 +1120,46 @@ def test_no_forward_store_without_autograd(dev):
     finally:
         fused.render_forward_raw = orig
     assert calls == [False, True] and torch.equal(p0, p1.detach())
+
+
+@pytest.mark.parametrize("late", [1, 2])
+def test_f32_store_with_skip_layers(dev, late):
+    """f32 render of a static net WITH a skip connection (num_late_layers > 0: two LDS stages per skip layer, a last
+    layer whose [Wo | bo] tail sits behind its second image when late == 1) beside a plain dynamic net: forward and all
+    gradients against the oracle, and the backward from the forward's store bit-identical to the recompute backward."""
+    from nerfca_amd import fused, render_rays
+    gen = torch.Generator().manual_seed(500 + late)
+    F, early, R, S = 64, 2, 37, 40
+    ss = O.NetSpec(num_filters=F, num_early_layers=early, num_late_layers=late, num_time_dim=0)
+    sd = O.NetSpec(num_filters=F, num_early_layers=early, num_time_dim=8)
+    ps, pd = O.init_params(ss, gen), O.init_params(sd, gen)
+    s = make_static(ps, dev, F=F, early=early, late=late)
+    t = make_dynamic(pd, dev, F=F, early=early, late=0, T=8)
+    for m in (s, t):
+        m.update_freq_mask_alpha(75000, 150000)
+    win = O.freq_mask_alpha(12, 75000, 150000, 1)[0]
+    o = (torch.rand(R, 3, generator=gen) * 0.2 + torch.tensor([3.0, -2.0, 2.5])).double()
+    d = (torch.rand(R, 3, generator=gen) - 0.5).double()
+    ph = torch.randint(0, 10, (R,), generator=gen)
+    z = O.stratified_depths(O.depth_values(3.4259, 5.5741, S), torch.rand(S, generator=gen))
+    I0 = torch.full((R,), 2.15991)
+    cp, cs, cd = torch.randn(R, generator=gen).double(), torch.randn(R, S, generator=gen), torch.randn(R, S, generator=gen)
+    pix, a, b, dists, pso, pdo = _oracle_render_grads(ps, ss, pd, sd, win, o, d, ph, I0, z, cp, cs, cd, torch.float32)
+    outs = []
+    saved = fused.STORE_FORWARD_LIMIT_BYTES
+    try:
+        for limit in (0, 96 << 30):
+            fused.STORE_FORWARD_LIMIT_BYTES = limit
+            for m in (s, t):
+                m.zero_grad()
+            p2, a2, b2 = render_rays(s, t, o.to(dev), d.to(dev), ph.to(dev), I0.to(dev), z.to(dev), dists.to(dev))
+            ((p2 * cp.to(dev)).sum() + (a2 * cs.to(dev)).sum() * 50 + (b2 * cd.to(dev)).sum() * 50).backward()
+            outs.append([p2.detach().clone(), a2.detach().clone(), b2.detach().clone()] + [p.grad.clone() for p in list(s.parameters()) + list(t.parameters())])
+    finally:
+        fused.STORE_FORWARD_LIMIT_BYTES = saved
+    for x, y in zip(outs[0], outs[1]):
+        assert torch.equal(x, y)
+    assert rel_err(outs[1][0].cpu(), pix) < TOL and rel_err(outs[1][1].cpu(), a) < TOL and rel_err(outs[1][2].cpu(), b) < TOL
+    for name, got, pe in (("static", grads_of(s), pso), ("dynamic", grads_of(t), pdo)):
+        for k in pe:
+            assert rel_err(got[k], pe[k].grad) < TOL, (name, k)
