@@ -212,7 +212,10 @@ def render_forward_raw(batch: _RayBatch, bs: FieldBinding, bd: Optional[FieldBin
     if for_backward and STORE_FORWARD_LIMIT_BYTES > 0:
         sbytes = check(lib.nca_render_store_bytes(C.byref(desc), C.byref(bs.net), C.byref(bd.net) if bd is not None else None, bs.prec))
         if 0 < sbytes <= STORE_FORWARD_LIMIT_BYTES:
-            store = torch.empty(sbytes, dtype=torch.uint8, device=dev)
+            try:
+                store = torch.empty(sbytes, dtype=torch.uint8, device=dev)
+            except torch.cuda.OutOfMemoryError:        # not enough free HBM for the store: the backward recomputes instead
+                store = None
     check(lib.nca_render_fwd(C.byref(desc), bs.prec,
                              C.byref(bs.net), ptr(packed_s), ptr(win_s), ptr(four_s),
                              C.byref(bd.net) if bd is not None else None, ptr(packed_d), ptr(win_d), ptr(four_d),
