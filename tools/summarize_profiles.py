@@ -87,6 +87,14 @@ for key, names in KERNELS.items():
     wr = mean_last(write[wk]["WRITE_SIZE"]) * 1024
     traffic["kernels"][key] = {"kernel": name, "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr}
 json.dump(traffic, open(os.path.join(dst, f"{tag}_{prec}_pmc_traffic.json"), "w"), indent=1)
+# bench.py reads roofline.traffic from the traffic file that was committed when it ran; the bench line kept here gets the
+# figure of THIS collection (same box, same build) instead
+dom = bench["roofline"]["kernel"]
+if dom in traffic["kernels"]:
+    t = traffic["kernels"][dom]["hbm_bytes_per_launch"]
+    bench["roofline"]["traffic"] = t
+    bench["roofline"]["staging_TBps"] = t / (bench["roofline"]["avg_launch_ms"] * 1e-3) / 1e12
+    json.dump(bench, open(os.path.join(dst, f"{tag}_{prec}_bench.json"), "w"))
 
 sq = per_kernel("pmc_SQ")
 out = {"how": "one rocprofv3 --pmc pass (8 SQ counters + GRBM_GUI_ACTIVE) --kernel-trace over bench.py --steps 2 --warmup 1; means per dispatch. "
