@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include <mutex>
 #include <vector>
 #include "nca_kernels.hpp"
@@ -609,6 +610,7 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     }
     const int F = lays[0].F;
     const int wave_samples = tile_samples(prec);
+    static const bool per_net_launch = getenv("NCA_PER_NET") != nullptr;     // experiment switch
     int chunk = 0;
     for (int64_t u0 = 0; u0 < units; u0 += p.units_per_chunk, ++chunk) {
         const int64_t nu = (u0 + p.units_per_chunk <= units) ? p.units_per_chunk : units - u0;
@@ -617,7 +619,21 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
         a.tile0 = stored ? u0 * tiles_per_unit : 0;       // position of this chunk in the store of the whole batch
         a.accumulate = chunk > 0;
         if (a.mode == NCA_MODE_RAYS) a.ray0 = u0; else a.n0 = u0 * wave_samples;
-        {
+        if (bf && stored && a.nnets == 2 && per_net_launch) {
+            // one launch per net (nets are independent once the upstream gradients are known)
+            for (int n = 0; n < 2; ++n) {
+                static thread_local NcaFusedArgs one;
+                one = a;
+                one.nnets = 1;
+                one.net[0] = a.net[n];
+                one.net_base = n;
+                NetBind b1[2] = {binds[n], {}};
+                rc = build_stages(&one, b1, true, 2);
+                if (rc) return rc;
+                Span sp(NCA_K_BWD_DGRAD, st);
+                HIPCHK(nca_launch_fused_bf16(F, one, NCA_KM_BWD_STORED, p.grid, st));
+            }
+        } else {
             Span sp(NCA_K_BWD_DGRAD, st);
             if (bf) HIPCHK(nca_launch_fused_bf16(F, a, stored ? NCA_KM_BWD_STORED : NCA_KM_BWD, p.grid, st));
             else HIPCHK(nca_launch_fused_f32(F, a, stored ? NCA_KM_BWD_STORED : NCA_KM_BWD, p.grid, st));

@@ -61,6 +61,8 @@ struct NcaFusedArgs {
     float* scratch;      // [tile][rows_total x 32 floats]: layer inputs H and output gradients D of each 32-sample tile
                          // (f32: input block row-major [row][32], hidden blocks [row tile][quad][lane][4]; bf16: see nca_bf_tile_bytes)
     int64_t rows_total;  // f32: scratch rows per 32-sample tile over all nets;  bf16: BYTES per 32-sample tile
+    int32_t net_base;    // a launch that carries ONE net of a two-net render (nnets == 1): its index (0 static, 1 dynamic) for
+                         // the per-net upstream gradient, mask region and output-layer partial slot
     int32_t share_enc;   // bf16, two nets with the same encoding (mode, bands, the SAME window / coefficient vectors): net 0 (static)
                          // does not store its input block -- net 1's is a superset (+ latents, one-hot phase slots) and net 0's
                          // layer-0 weight-gradient job reads that one

@@ -293,7 +293,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
             const bool lds_mask = MODE == NCA_KM_BWD && a.mask_layers >= y.NL - 1;
             char* const mwave = maskbase + (wave * a.mask_layers) * 1024 + lane * 16;
             // stored forward: ReLU masks [wave tile][net][layer][lane][16 B]
-            char* const mglob = (FSTORE || STORED) ? a.mstore + ((tg * 2 + net) * a.mstore_layers) * 1024 + lane * 16 : nullptr;
+            char* const mglob = (FSTORE || STORED) ? a.mstore + ((tg * 2 + net + a.net_base) * a.mstore_layers) * 1024 + lane * 16 : nullptr;
 
             // ================= encoding, lane = sample ===================================================
             u32x4 B[2][KSMAX];
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                     // ---------- gradient wrt the raw output, output-layer parameter gradients, D_{NL-1} ----------
                     float g;
                     if (a.mode == NCA_MODE_RAYS && !a.g_raw) {
-                        const float* gs = net == 0 ? a.g_sig_s : a.g_sig_d;
+                        const float* gs = net + a.net_base == 0 ? a.g_sig_s : a.g_sig_d;
                         const double gsig = gs ? (double)gs[n] : 0.0;
                         const double gp = a.g_pix[ray] * a.dists[smp];
                         const double dsig = a.single ? (gsig - gp * (double)a.scale) : (gsig - gp) * (double)a.scale;
@@ -664,10 +664,10 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
 
     if (BWD) {
         __syncthreads();
-        for (int i = tid; i < 2 * (F + 1); i += NCA_NT) {
+        for (int i = tid; i < a.nnets * (F + 1); i += NCA_NT) {
             float s = 0.f;
             for (int w = 0; w < NCA_WAVES; ++w) s += osum[(w * 2) * (F + 1) + i];
-            float* dst = a.oslab + (int64_t)blockIdx.x * 2 * (F + 1) + i;
+            float* dst = a.oslab + (int64_t)blockIdx.x * 2 * (F + 1) + a.net_base * (F + 1) + i;
             *dst = a.accumulate ? *dst + s : s;
         }
     }
