@@ -404,13 +404,14 @@ struct BwdPlan {
     int64_t units_per_chunk;
     int64_t tiles_per_unit;    // wave tiles (32 samples f32 / 64 samples bf16) per unit
     int64_t bytes_total;
-    int64_t off_slab, off_oslab, off_scratch;
+    int64_t off_slab, off_oslab, off_wslab, off_scratch;
+    int64_t wslab_stride;
 };
 
 static int64_t scratch_rows(const NcaLayout& y) { return y.K0rows_pad + (int64_t)(y.NL - 1) * y.F + (int64_t)y.NL * y.F; }
 
 static int plan_bwd(const NcaLayout* lays, int nnets, int32_t prec, int64_t units, int64_t tiles_per_unit, int64_t budget, BwdPlan* p,
-                    bool stored = false) {
+                    bool stored = false, bool onchip = false) {
     const bool bf = prec == NCA_PREC_BF16;
     p->tile_stride = 0;
     p->slab_stride = 0;
@@ -420,6 +421,7 @@ static int plan_bwd(const NcaLayout* lays, int nnets, int32_t prec, int64_t unit
         else p->tile_stride += bf ? nca_bf_tile_bytes(lays[n]) : scratch_rows(lays[n]);
         p->slab_stride += lays[n].n_params;
         for (int j = 0; j < lays[n].NL; ++j) p->njobs += lays[n].layer[j].kind == NCA_IN_SKIP ? 2 : 1;
+        if (onchip) p->njobs -= 1;                    // the last hidden layer's weight gradient stays in the dgrad kernel
     }
     for (int n = 0; n < nnets; ++n) p->slab_stride += (int64_t)lays[n].F * lays[n].P;
     p->slab_stride = align_up(p->slab_stride, 64);
@@ -434,7 +436,9 @@ static int plan_bwd(const NcaLayout* lays, int nnets, int32_t prec, int64_t unit
     if (nsplit < 1) nsplit = 1;
     const int64_t slab_bytes = align_up((int64_t)nsplit * p->slab_stride * 4, 256);
     const int64_t oslab_bytes = align_up((int64_t)cus * 2 * (F + 1) * 4, 256);
-    const int64_t fixed = slab_bytes + oslab_bytes;
+    p->wslab_stride = (int64_t)F * F + F;                                               // on-chip layer: dW and db per workgroup
+    const int64_t wslab_bytes = bf ? align_up((int64_t)cus * 2 * p->wslab_stride * 4, 256) : 0;
+    const int64_t fixed = slab_bytes + oslab_bytes + wslab_bytes;
     // scratch bytes per unit: f32 rows*32 floats per 32-sample tile; bf16 two 32-sample tiles per wave tile
     const int64_t per_unit = bf ? p->tile_stride * 2 * tiles_per_unit : p->tile_stride * tiles_per_unit * 32 * 4;
     int64_t upc = units;
@@ -453,6 +457,7 @@ static int plan_bwd(const NcaLayout* lays, int nnets, int32_t prec, int64_t unit
     p->grid = (int)(ngroups < cus ? ngroups : cus);
     p->off_slab = 0;
     p->off_oslab = slab_bytes;
+    p->off_wslab = slab_bytes + oslab_bytes;
     p->off_scratch = fixed;
     p->bytes_total = p->off_scratch + align_up(per_unit * upc, 256);
     return NCA_OK;
@@ -498,9 +503,11 @@ static void add_jobs_f32(NcaWgradArgs* w, const NcaLayout& y, int64_t row0, int6
 }
 
 // net_off: byte offset of the net's input/H blocks in a tile of the H region; d_off: of its D blocks in a tile of the D region
-static void add_jobs_bf16(NcaWgradArgs* w, const NcaLayout& y, int64_t net_off, int64_t d_off, int64_t slab_off, int64_t onehot_off, int64_t enc_off) {
+static void add_jobs_bf16(NcaWgradArgs* w, const NcaLayout& y, int64_t net_off, int64_t d_off, int64_t slab_off, int64_t onehot_off, int64_t enc_off,
+                          int skip_layer = -1) {
     const int64_t EB = 32 * (int64_t)NCA_BF_ENCROWS * 2, HB = 32 * (int64_t)y.F * 2;
     for (int j = 0; j < y.NL; ++j) {
+        if (j == skip_layer) continue;            // accumulated on chip by the dgrad kernel
         const NcaLayerL& l = y.layer[j];
         NcaWgradJob& g = w->job[w->njobs++];
         g.F = y.F;
@@ -542,8 +549,12 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
         if (!store_plan(lays, a.nnets, prec, units * tiles_per_unit, &spl, a.share_enc != 0)) return fail(NCA_E_UNSUPPORTED, "no forward store exists for this configuration");
         if (store_bytes < spl.bytes) return fail(NCA_E_WORKSPACE, "forward store %lld < %lld bytes", (long long)store_bytes, (long long)spl.bytes);
     }
+    // bf16 backward from a store: the weight gradient of the last hidden layer stays on chip (one launch per net)
+    static const bool onchip_off = getenv("NCA_ONCHIP") != nullptr && getenv("NCA_ONCHIP")[0] == '0';     // NCA_ONCHIP=0: A/B switch
+    const bool onchip = !onchip_off && bf && stored;
+    const bool per_net_launch = onchip;
     BwdPlan p;
-    int rc = plan_bwd(lays, a.nnets, prec, units, tiles_per_unit, work_bytes, &p, stored);
+    int rc = plan_bwd(lays, a.nnets, prec, units, tiles_per_unit, work_bytes, &p, stored, onchip);
     if (rc) return rc;
     if (!work || work_bytes < p.bytes_total) return fail(NCA_E_WORKSPACE, "backward workspace %lld < %lld bytes", (long long)work_bytes, (long long)p.bytes_total);
     char* wb = static_cast<char*>(work);
@@ -583,7 +594,8 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     static thread_local NcaWgradArgs w;
     memset(&w, 0, sizeof(w));
     for (int n = 0; n < a.nnets; ++n) {
-        if (bf) add_jobs_bf16(&w, lays[n], a.net[n].row0, a.net[n].drow0, slab_off[n], onehot_off[n], stored && a.share_enc && n == 0 ? a.net[1].row0 : a.net[n].row0);
+        if (bf) add_jobs_bf16(&w, lays[n], a.net[n].row0, a.net[n].drow0, slab_off[n], onehot_off[n], stored && a.share_enc && n == 0 ? a.net[1].row0 : a.net[n].row0,
+                              onchip ? lays[n].NL - 1 : -1);
         else add_jobs_f32(&w, lays[n], a.net[n].row0, a.net[n].drow0, slab_off[n], onehot_off[n]);
     }
     w.scratch = scratch;
@@ -610,7 +622,7 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     }
     const int F = lays[0].F;
     const int wave_samples = tile_samples(prec);
-    static const bool per_net_launch = getenv("NCA_PER_NET") != nullptr;     // experiment switch
+
     int chunk = 0;
     for (int64_t u0 = 0; u0 < units; u0 += p.units_per_chunk, ++chunk) {
         const int64_t nu = (u0 + p.units_per_chunk <= units) ? p.units_per_chunk : units - u0;
@@ -619,19 +631,22 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
         a.tile0 = stored ? u0 * tiles_per_unit : 0;       // position of this chunk in the store of the whole batch
         a.accumulate = chunk > 0;
         if (a.mode == NCA_MODE_RAYS) a.ray0 = u0; else a.n0 = u0 * wave_samples;
-        if (bf && stored && a.nnets == 2 && per_net_launch) {
+        if (bf && stored && per_net_launch) {
             // one launch per net (nets are independent once the upstream gradients are known)
-            for (int n = 0; n < 2; ++n) {
+            for (int n = 0; n < a.nnets; ++n) {
                 static thread_local NcaFusedArgs one;
                 one = a;
                 one.nnets = 1;
                 one.net[0] = a.net[n];
                 one.net_base = n;
+                one.onchip = onchip ? 1 : 0;
+                one.wslab = reinterpret_cast<float*>(wb + p.off_wslab) + (int64_t)n * num_cus() * p.wslab_stride;
+                one.wslab_stride = p.wslab_stride;
                 NetBind b1[2] = {binds[n], {}};
                 rc = build_stages(&one, b1, true, 2);
                 if (rc) return rc;
                 Span sp(NCA_K_BWD_DGRAD, st);
-                HIPCHK(nca_launch_fused_bf16(F, one, NCA_KM_BWD_STORED, p.grid, st));
+                HIPCHK(nca_launch_fused_bf16(F, one, onchip ? NCA_KM_BWD_ONCHIP : NCA_KM_BWD_STORED, p.grid, st));
             }
         } else {
             Span sp(NCA_K_BWD_DGRAD, st);
@@ -668,6 +683,12 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
         rn.w0_off = lays[n].layer[0].w_off;
         rn.lat_count = (int64_t)lays[n].P * lays[n].T;
         rn.wo_off = lays[n].wo_off;
+        if (onchip) {
+            rn.wslab = reinterpret_cast<const float*>(wb + p.off_wslab) + (int64_t)n * num_cus() * p.wslab_stride;
+            rn.wslab_stride = p.wslab_stride;
+            rn.oc_w_off = lays[n].layer[lays[n].NL - 1].w_off;
+            rn.oc_b_off = lays[n].layer[lays[n].NL - 1].b_off;
+        }
     }
     {
         Span sp(NCA_K_BWD_REDUCE, st);
@@ -702,7 +723,13 @@ extern "C" int64_t nca_render_bwd_workspace(const NcaRays* rays, const NcaNet* n
     }
     rc = plan_bwd(lays, nn, prec, rays->R, (rays->S + ts - 1) / ts, max_bytes, &p);
     if (rc) return rc;
-    return p.bytes_total;
+    int64_t need = p.bytes_total;
+    if (prec == NCA_PREC_BF16) {       // the on-chip variant of the backward from a store runs fewer jobs over more splits (more slabs)
+        rc = plan_bwd(lays, nn, prec, rays->R, (rays->S + ts - 1) / ts, max_bytes, &p, true, true);
+        if (rc) return rc;
+        if (p.bytes_total > need) need = p.bytes_total;
+    }
+    return need;
 }
 
 extern "C" int nca_render_bwd(const NcaRays* rays, int32_t prec,

@@ -28,7 +28,8 @@ struct NcaNetArgs {
 enum { NCA_KM_FWD = 0,          // forward
        NCA_KM_BWD = 1,          // recompute + output-layer gradients + dgrad; H, D and the input block go to ONE scratch
        NCA_KM_FWD_STORE = 2,    // forward that also writes the input block, every layer input, ReLU masks and raw outputs
-       NCA_KM_BWD_STORED = 3 }; // output-layer gradients + dgrad from that store (no recompute); D to the chunk scratch
+       NCA_KM_BWD_STORED = 3,   // output-layer gradients + dgrad from that store (no recompute); D to the chunk scratch
+       NCA_KM_BWD_ONCHIP = 4 }; // mode 3 for one net, with the last hidden layer's weight gradient accumulated on chip
 
 struct NcaFusedArgs {
     int32_t mode, nnets;
@@ -61,6 +62,11 @@ struct NcaFusedArgs {
     float* scratch;      // [tile][rows_total x 32 floats]: layer inputs H and output gradients D of each 32-sample tile
                          // (f32: input block row-major [row][32], hidden blocks [row tile][quad][lane][4]; bf16: see nca_bf_tile_bytes)
     int64_t rows_total;  // f32: scratch rows per 32-sample tile over all nets;  bf16: BYTES per 32-sample tile
+    int32_t onchip;      // bf16 backward from the store, one net per launch: the weight gradient of the last hidden layer is
+                         // accumulated in registers (8 waves share the F x F blocks, operand tiles exchanged through LDS)
+                         // and written to wslab at the end; its D block is not stored and the wgrad kernel skips that layer
+    float* wslab;        // [workgroup][F*F + F] f32: dW and db of that layer per workgroup (summed by the reduce kernel)
+    int64_t wslab_stride;
     int32_t net_base;    // a launch that carries ONE net of a two-net render (nnets == 1): its index (0 static, 1 dynamic) for
                          // the per-net upstream gradient, mask region and output-layer partial slot
     int32_t share_enc;   // bf16, two nets with the same encoding (mode, bands, the SAME window / coefficient vectors): net 0 (static)
@@ -115,6 +121,9 @@ struct NcaWgradArgs {
 struct NcaReduceNet {
     float* grads;
     const float* params;
+    const float* wslab;   // on-chip layer: per-workgroup [F*F + F] partials (or null)
+    int64_t wslab_stride;
+    int64_t oc_w_off, oc_b_off;   // natural offsets of that layer's W (F*F) and b (F)
     int64_t slab_off;     // where this net's natural block starts inside a slab
     int64_t onehot_off;
     int32_t F, T, P, K0, Kenc, w0_off;

@@ -166,6 +166,13 @@ __device__ __forceinline__ void stage_publish_counted(bool stores_issued) {
     __builtin_amdgcn_s_barrier();
 }
 
+// workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain the wave's global stores / loads
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // acc0/acc1 += A(row tile m of the layer image) * B, with the A fragments of the whole layer image streamed through a
 // ring of registers:
 // the image is [row tile][k-step][lane][16 B], i.e. contiguous in the global step g = m * NKS + ks, so the read
@@ -197,15 +204,61 @@ __device__ __forceinline__ void mma_rowtile_ring(const char* imgl, int m, u32x4 
     }
 }
 
+// identity fragment of k-step s for the transposing product Z = X^T * E: element j of lane (c,h) is
+// E[k = 16s + 8h + j][column c of the 32-wide output tile tcol] = 1 iff 32*tcol + c == that k.
+__device__ __forceinline__ u32x4 ident_frag(int kbase, int lc) {
+    // kbase = 16s + 8h - 32*tcol ; element j is 1 when kbase + j == lc
+    u32x4 r;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const unsigned lo = (kbase + 2 * w == lc) ? 0x3f80u : 0u;
+        const unsigned hi = (kbase + 2 * w + 1 == lc) ? 0x3f800000u : 0u;
+        r[w] = lo | hi;
+    }
+    return r;
+}
+
+// transpose a [32 samples][32*NT features] sample-major bf16 block (already loaded as A fragments:
+// lane (r = sample, h), k-step s: features 16s+8h..+7) into NT accumulator tiles with rows = samples,
+// column = feature on the lane, packed as two k-steps (16 samples each) of MFMA operands.
+template <int NT>
+__device__ __forceinline__ void transpose_block(const u32x4 (&X)[2 * NT], int lc, int lh, u32x4 (&T)[NT][2], float (*colsum)[NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        f32x16 z;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) z[i] = 0.f;
+        // features of tile t live in k-steps 2t and 2t+1 of X
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const u32x4 E = ident_frag(16 * s + 8 * lh, lc);
+            z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(X[2 * t + s]), frag(E), z, 0, 0, 0);
+        }
+        if (colsum) {
+            float cs = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) cs += z[i];
+            (*colsum)[t] += cs;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            T[t][0][u] = pack2(z[2 * u], z[2 * u + 1]);
+            T[t][1][u] = pack2(z[8 + 2 * u], z[8 + 2 * u + 1]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // fused forward / backward-dgrad kernel
 // ------------------------------------------------------------------------------------------
 template <int F, int MODE>
 __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a) {
-    constexpr bool BWD = MODE == NCA_KM_BWD || MODE == NCA_KM_BWD_STORED;     // output-layer gradients + dgrad sweep
+    constexpr bool ONCHIP = MODE == NCA_KM_BWD_ONCHIP;                        // mode 3 + on-chip dW of the last hidden layer
+    constexpr bool STORED = MODE == NCA_KM_BWD_STORED || ONCHIP;
+    constexpr bool BWD = MODE == NCA_KM_BWD || STORED;                        // output-layer gradients + dgrad sweep
     constexpr bool STORE = MODE == NCA_KM_BWD || MODE == NCA_KM_FWD_STORE;    // writes the input block and the layer inputs
-    constexpr bool RECOMP = MODE != NCA_KM_BWD_STORED;                        // runs the forward layers
-    constexpr bool FSTORE = MODE == NCA_KM_FWD_STORE, STORED = MODE == NCA_KM_BWD_STORED;
+    constexpr bool RECOMP = !STORED;                                          // runs the forward layers
+    constexpr bool FSTORE = MODE == NCA_KM_FWD_STORE;
     constexpr int MT = BfCfg<F>::MT, KS = BfCfg<F>::KS, KS0 = BfCfg<F>::KS0, KSMAX = BfCfg<F>::KSMAX;
     constexpr int BUF = BfCfg<F>::BUF_BYTES;
     constexpr int HB = 32 * F * 2;                          // bytes of one hidden scratch block (32 samples x F)
@@ -230,6 +283,20 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
     stage_issue_b(a.stage[0], smem, wave, lane);
     stage_publish_b();
     int cur = 0, si = 0;
+
+    // On-chip weight gradient of the last hidden layer (mode 3, one net per launch): the MT x MT blocks of dW are shared
+    // by the 8 waves (BPW blocks each, same output-row tile), accumulated over every tile this workgroup processes.
+    // Between the exchange phases the accumulators are PARKED in the wave's own slice of the exchange area (it is idle
+    // then): kept in registers they push the dgrad loops over the register budget, and a spill reload that misses the
+    // caches under this kernel's streaming traffic costs microseconds.
+    constexpr int BPW = (MT * MT + NCA_WAVES - 1) / NCA_WAVES;
+    constexpr int XS = 2 * MT * 1024 > BPW * 16 * 256 ? 2 * MT * 1024 : BPW * 16 * 256;     // bytes of a wave's slice (exchange / parking)
+    char* const xch = maskbase;          // exchange area [wave][2 MT fragments][lane][16 B] (the masks live in the store in mode 3)
+    float* const park = reinterpret_cast<float*>(xch + wave * XS) + lane;      // [BPW * 16][64 lanes] floats <= 8 KiB
+    if (ONCHIP) {
+#pragma unroll
+        for (int q = 0; q < BPW * 16; ++q) park[q * 64] = 0.f;
+    }
 
     const int64_t ngroups = (a.ntiles + NCA_WAVES - 1) / NCA_WAVES;
     for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
@@ -443,7 +510,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                                 Bn[c][2 * m][u] = pack2(dv[2 * u], dv[2 * u + 1]);
                                 Bn[c][2 * m + 1][u] = pack2(dv[8 + 2 * u], dv[8 + 2 * u + 1]);
                             }
-                            if (tvalid) {
+                            if (tvalid && !ONCHIP) {
                                 char* fp2 = dblk + c * a.d_total + lane * 16;
                                 store_nt(fp2 + (2 * m) * 1024, Bn[c][2 * m]);
                                 store_nt(fp2 + (2 * m + 1) * 1024, Bn[c][2 * m + 1]);
@@ -566,10 +633,103 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
 
                 if (BWD && last) last_layer_grads(tail + 2 * MT * 16);
 
+                if (ONCHIP && last) {
+                    // dW_L += D_L * H_{L-1}^T over this workgroup's 8 x 64 samples.  B holds D_L; the layer's input fragments
+                    // (consumed by the recompute above) are read once more.  Both are transposed into rows = samples by
+                    // identity MFMAs (as the wgrad kernel does) and handed round 16 samples per wave at a time.
+                    const char* hl = nb + EB + (y.NL - 2) * HB + lane * 16;
+                    const int b0 = wave * BPW;                       // my blocks b0 .. b0 + BPW - 1 of the MT x MT grid
+                    const int mo = b0 / MT, i0 = b0 % MT;
+                    const bool own = b0 < MT * MT;
+                    f32x16 accW[BPW];
+                    // one 32-feature tile (fragments x0, x1) transposed to rows = samples; returns the packed half `s2`
+                    // (16 samples) as an MFMA operand and, if asked, adds the tile's column sums (bias gradient)
+                    const u32x4 E0 = ident_frag(8 * lh, lr), E1 = ident_frag(16 + 8 * lh, lr);      // identity operands, once per phase
+                    auto tr_half = [&](const u32x4& x0, const u32x4& x1, int s2, float& colsum) __attribute__((always_inline)) {
+                        f32x16 zt;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) zt[i] = 0.f;
+                        // the two halves of a tile come from the SAME products, recomputed on purpose: opaque copies of the
+                        // identity operands keep the compiler from merging them and carrying 16 registers per tile across a round
+                        u32x4 e0 = E0, e1 = E1;
+                        asm volatile("" : "+v"(e0), "+v"(e1));
+                        zt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(x0), frag(e0), zt, 0, 0, 0);
+                        zt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(x1), frag(e1), zt, 0, 0, 0);
+                        colsum = 0.f;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) colsum += zt[i];
+                        u32x4 r;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) r[u] = s2 ? pack2(zt[8 + 2 * u], zt[8 + 2 * u + 1]) : pack2(zt[2 * u], zt[2 * u + 1]);
+                        return r;
+                    };
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        // this column tile's input fragments (one request per tile, issued before its rounds)
+                        u32x4 XHc[2 * MT];
+#pragma unroll
+                        for (int k = 0; k < 2 * MT; ++k) XHc[k] = *reinterpret_cast<const u32x4*>(hl + c * a.rows_total + k * 1024);
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) {
+                            if (c == 0 && s2 == 0) {
+                                // un-park the accumulators (behind a scheduling fence: loaded any earlier they would sit on top of
+                                // the recompute's live registers), then free the slices for the exchange
+                                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                                for (int j = 0; j < BPW; ++j)
+#pragma unroll
+                                    for (int i = 0; i < 16; ++i) accW[j][i] = park[(j * 16 + i) * 64];
+                                asm volatile("" ::: "memory");        // the fragment stores below reuse the parked slice (other types: keep the order)
+                            }
+                            if (c + s2 > 0) lds_barrier();            // the previous round has been read by everyone (round 0 only touches
+                                                                      // the wave's own slice, which nobody reads before the next barrier)
+                            // nothing of this round may be scheduled above this point: the transposes depend on registers only and
+                            // would otherwise all be hoisted to the top of the phase (4 rounds x 2 MT results alive at once)
+                            __builtin_amdgcn_sched_barrier(0);
+                            char* my = xch + wave * XS + lane * 16;
+#pragma unroll
+                            for (int m = 0; m < MT; ++m) {
+                                // (the transposes run once per half: keeping both halves of all tiles alive costs ~100 registers)
+                                float cs;
+                                *reinterpret_cast<u32x4*>(my + m * 1024) = tr_half(B[c][2 * m], B[c][2 * m + 1], s2, cs);
+                                if (s2 == 0) {
+                                    // bias gradient: column sums of the transposed D tile, kept in the (unused) second-net slot of
+                                    // this wave's output-layer scratch -- another four live registers push the dgrad loops over
+                                    const float bcol = cs + __shfl_xor(cs, 32);
+                                    if (lh == 0) osum[(wave * 2 + 1) * (F + 1) + 32 * m + lr] += bcol;
+                                }
+                            }
+#pragma unroll
+                            for (int m = 0; m < MT; ++m) {
+                                float unused;
+                                *reinterpret_cast<u32x4*>(my + (MT + m) * 1024) = tr_half(XHc[2 * m], XHc[2 * m + 1], s2, unused);
+                            }
+                            lds_barrier();
+                            if (own) {
+#pragma unroll
+                                for (int src = 0; src < NCA_WAVES; ++src) {
+                                    const char* sp = xch + src * XS + lane * 16;
+                                    const u32x4 A = *reinterpret_cast<const u32x4*>(sp + mo * 1024);
+#pragma unroll
+                                    for (int j = 0; j < BPW; ++j) {
+                                        const u32x4 Bf = *reinterpret_cast<const u32x4*>(sp + (MT + i0 + j) * 1024);
+                                        accW[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(A), frag(Bf), accW[j], 0, 0, 0);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    lds_barrier();                                    // the last round has been read: the slices are free again
+#pragma unroll
+                    for (int j = 0; j < BPW; ++j)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) park[(j * 16 + i) * 64] = accW[j][i];
+                }
+
                 // at least 4 MT stores follow the weight DMA of every storing stage: H (plus a mask store in the storing
                 // forward, which it then also waits for), or D_{NL-1} on the last layer of both backward modes; the last
                 // layer of the storing forward stores nothing
-                if ((STORE && !last) || (BWD && last)) stage_publish_counted<4 * MT>(tvalid);
+                if ((STORE && !last) || (BWD && last && !ONCHIP)) stage_publish_counted<4 * MT>(tvalid);
                 else stage_publish_b();
                 cur ^= 1;
                 si = nsi;
@@ -662,6 +822,35 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
         }
     }  // tile groups
 
+    if (ONCHIP) {
+        // dW blocks and bias sums of the on-chip layer -> this workgroup's slab, natural [o][i] order (both indices of a
+        // hidden block are in accumulator->operand order: un-permute them as the wgrad kernel does)
+        auto unperm = [](int c) { return (c & 0x13) | ((c & 8) >> 1) | ((c & 4) << 1); };
+        float* ws = a.wslab + (int64_t)blockIdx.x * a.wslab_stride;
+        const int b0 = wave * BPW;
+        if (b0 < MT * MT) {
+            const int mo = b0 / MT, i0 = b0 % MT;
+#pragma unroll
+            for (int j = 0; j < BPW; ++j) {
+                const int col = 32 * (i0 + j) + unperm(lr);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int o = 32 * mo + unperm(nca_rho(i) + 4 * lh);
+                    const float v = park[(j * 16 + i) * 64];
+                    float* dst = ws + (int64_t)o * F + col;
+                    *dst = a.accumulate ? *dst + v : v;
+                }
+            }
+        }
+        // bias: per-wave column sums -> LDS -> sum over the waves
+        __syncthreads();
+        for (int f = tid; f < F; f += NCA_NT) {          // position f of the accumulator order is feature 32 (f / 32) + unperm(f % 32)
+            float sb = 0.f;
+            for (int w = 0; w < NCA_WAVES; ++w) sb += osum[(w * 2 + 1) * (F + 1) + f];
+            float* dst = ws + (int64_t)F * F + 32 * (f >> 5) + unperm(f & 31);
+            *dst = a.accumulate ? *dst + sb : sb;
+        }
+    }
     if (BWD) {
         __syncthreads();
         for (int i = tid; i < a.nnets * (F + 1); i += NCA_NT) {
@@ -676,50 +865,6 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
 // ------------------------------------------------------------------------------------------
 // wgrad, no LDS.  One wave = one (job, split): dW of the whole layer in accumulators.
 // ------------------------------------------------------------------------------------------
-// identity fragment of k-step s for the transposing product Z = X^T * E: element j of lane (c,h) is
-// E[k = 16s + 8h + j][column c of the 32-wide output tile tcol] = 1 iff 32*tcol + c == that k.
-__device__ __forceinline__ u32x4 ident_frag(int kbase, int lc) {
-    // kbase = 16s + 8h - 32*tcol ; element j is 1 when kbase + j == lc
-    u32x4 r;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        const unsigned lo = (kbase + 2 * w == lc) ? 0x3f80u : 0u;
-        const unsigned hi = (kbase + 2 * w + 1 == lc) ? 0x3f800000u : 0u;
-        r[w] = lo | hi;
-    }
-    return r;
-}
-
-// transpose a [32 samples][32*NT features] sample-major bf16 block (already loaded as A fragments:
-// lane (r = sample, h), k-step s: features 16s+8h..+7) into NT accumulator tiles with rows = samples,
-// column = feature on the lane, packed as two k-steps (16 samples each) of MFMA operands.
-template <int NT>
-__device__ __forceinline__ void transpose_block(const u32x4 (&X)[2 * NT], int lc, int lh, u32x4 (&T)[NT][2], float (*colsum)[NT]) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        f32x16 z;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) z[i] = 0.f;
-        // features of tile t live in k-steps 2t and 2t+1 of X
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const u32x4 E = ident_frag(16 * s + 8 * lh, lc);
-            z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(X[2 * t + s]), frag(E), z, 0, 0, 0);
-        }
-        if (colsum) {
-            float cs = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) cs += z[i];
-            (*colsum)[t] += cs;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            T[t][0][u] = pack2(z[2 * u], z[2 * u + 1]);
-            T[t][1][u] = pack2(z[8 + 2 * u], z[8 + 2 * u + 1]);
-        }
-    }
-}
-
 template <int F, int NTB>   // NTB = 32-column tiles of the H block (F/32 for hidden inputs, 4 for the 112-wide input block)
 __device__ __forceinline__ void wgrad_job(const NcaWgradArgs& a, const NcaWgradJob& job, int q, int nsplit, int lane) {
     constexpr int MT = F / 32;
@@ -821,10 +966,14 @@ __global__ __launch_bounds__(64, 1) void nca_wgrad_bf16(const NcaWgradArgs a) {
 // ------------------------------------------------------------------------------------------
 template <int F, int MODE>
 static hipError_t launch_fused_bf_mode(const NcaFusedArgs& a, int grid, hipStream_t st) {
-    constexpr bool bwd = MODE == NCA_KM_BWD || MODE == NCA_KM_BWD_STORED;
+    constexpr bool bwd = MODE == NCA_KM_BWD || MODE == NCA_KM_BWD_STORED || MODE == NCA_KM_BWD_ONCHIP;
     size_t lds = 2 * BfCfg<F>::BUF_BYTES + NCA_CONST_BYTES;
     if (bwd) lds += NCA_WAVES * 2 * (F + 1) * sizeof(float);
     if (MODE == NCA_KM_BWD) lds += (size_t)NCA_WAVES * a.mask_layers * 1024;
+    if (MODE == NCA_KM_BWD_ONCHIP) {      // exchange / parking area: the larger of 2 MT fragments and the wave's parked accumulators
+        constexpr int MT = BfCfg<F>::MT, BPW = (MT * MT + NCA_WAVES - 1) / NCA_WAVES;
+        lds += (size_t)NCA_WAVES * (2 * MT * 1024 > BPW * 16 * 256 ? 2 * MT * 1024 : BPW * 16 * 256);
+    }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_fused_bf16<F, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((nca_fused_bf16<F, MODE>), dim3(grid), dim3(NCA_NT), lds, st, a);
     return hipGetLastError();
@@ -836,6 +985,7 @@ static hipError_t launch_fused_bf(const NcaFusedArgs& a, int kmode, int grid, hi
         case NCA_KM_BWD: return launch_fused_bf_mode<F, NCA_KM_BWD>(a, grid, st);
         case NCA_KM_FWD_STORE: return launch_fused_bf_mode<F, NCA_KM_FWD_STORE>(a, grid, st);
         case NCA_KM_BWD_STORED: return launch_fused_bf_mode<F, NCA_KM_BWD_STORED>(a, grid, st);
+        case NCA_KM_BWD_ONCHIP: return launch_fused_bf_mode<F, NCA_KM_BWD_ONCHIP>(a, grid, st);
     }
     return hipErrorInvalidValue;
 }

@@ -796,12 +796,20 @@ __global__ void nca_reduce_f32(const NcaReduceArgs a) {
     // the combination order is fixed, so the result is still bit-reproducible
     float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const float* sp = a.slab + rn.slab_off + le;
-    int q = 0;
-    for (; q + 8 <= a.n_split; q += 8) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s8[u] += sp[(int64_t)(q + u) * a.slab_stride];
+    int64_t stride = a.slab_stride;
+    int nsum = a.n_split;
+    if (rn.wslab) {
+        // the layer whose weight gradient the dgrad kernel accumulated on chip: one partial per workgroup
+        const int64_t F2 = (int64_t)rn.F * rn.F;
+        if (le >= rn.oc_w_off && le < rn.oc_w_off + F2) { sp = rn.wslab + (le - rn.oc_w_off); stride = rn.wslab_stride; nsum = a.n_wg; }
+        else if (le >= rn.oc_b_off && le < rn.oc_b_off + rn.F) { sp = rn.wslab + F2 + (le - rn.oc_b_off); stride = rn.wslab_stride; nsum = a.n_wg; }
     }
-    for (; q < a.n_split; ++q) s8[0] += sp[(int64_t)q * a.slab_stride];
+    int q = 0;
+    for (; q + 8 <= nsum; q += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s8[u] += sp[(int64_t)(q + u) * stride];
+    }
+    for (; q < nsum; ++q) s8[0] += sp[(int64_t)q * stride];
     *out = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
 }
 

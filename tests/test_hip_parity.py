@@ -1049,9 +1049,15 @@ def test_stored_forward_backward_equals_recompute(dev, prec, it_d, R, S, F, earl
             outs.append([pix.detach().clone(), a.detach().clone(), b.detach().clone()] + [p.grad.clone() for p in list(s.parameters()) + list(t.parameters())])
     finally:
         fused.STORE_FORWARD_LIMIT_BYTES, fused.BWD_WORKSPACE_BYTES = saved
-    for other in outs[1:2]:
-        for x, y in zip(outs[0], other):
-            assert torch.equal(x, y)
+    # f32: bit for bit.  bf16 from the store: the weight gradient of the LAST hidden layer is accumulated on chip by the dgrad
+    # kernel and the wgrad kernel then spreads its remaining jobs over more sample splits -- the same products in another
+    # (still fixed) summation order: outputs bit for bit, gradients to f32 summation rounding
+    names = ["pix", "sigma_s", "sigma_d"] + ["s." + k for k, _ in s.named_parameters()] + ["t." + k for k, _ in t.named_parameters()]
+    for i, (name, x, y) in enumerate(zip(names, outs[0], outs[1])):
+        if prec == "bf16" and i >= 3:
+            assert rel_err(y, x) < 2e-6, name
+        else:
+            assert torch.equal(x, y), name
     # several ray chunks change the order in which per-chunk slabs are summed: equal up to f32 summation rounding
     for x, y in zip(outs[0][:3], outs[2][:3]):
         assert torch.equal(x, y)
