@@ -183,21 +183,23 @@ __device__ __forceinline__ void lds_barrier() {
 #endif
 constexpr int NCA_BF_RING = 4;
 static_assert(NCA_BF_PF >= 1 && NCA_BF_PF < NCA_BF_RING, "prefetch distance must fit the ring");
-template <int NKS, int MTOT>
-__device__ __forceinline__ void ring_prime(const char* imgl, u32x4 (&A)[NCA_BF_RING]) {
+// RING registers, prefetch distance RING - 1 (the default ring of 4 for the MFMA-bound modes; the on-chip backward, which is
+// bound by its stores and short of registers, uses a ring of 2)
+template <int NKS, int MTOT, int RING>
+__device__ __forceinline__ void ring_prime(const char* imgl, u32x4 (&A)[RING]) {
 #pragma unroll
-    for (int g = 0; g < NCA_BF_PF; ++g)
-        if (g < MTOT * NKS) A[g % NCA_BF_RING] = *reinterpret_cast<const u32x4*>(imgl + g * 1024);
+    for (int g = 0; g < RING - 1; ++g)
+        if (g < MTOT * NKS) A[g % RING] = *reinterpret_cast<const u32x4*>(imgl + g * 1024);
 }
-template <int NKS, int MTOT, int NB>
-__device__ __forceinline__ void mma_rowtile_ring(const char* imgl, int m, u32x4 (&A)[NCA_BF_RING], const u32x4 (&B)[2][NB],
+template <int NKS, int MTOT, int NB, int RING>
+__device__ __forceinline__ void mma_rowtile_ring(const char* imgl, int m, u32x4 (&A)[RING], const u32x4 (&B)[2][NB],
                                                  f32x16& acc0, f32x16& acc1) {
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
-        const int g = m * NKS + ks, nx = g + NCA_BF_PF;
-        if (nx < MTOT * NKS) A[nx % NCA_BF_RING] = *reinterpret_cast<const u32x4*>(imgl + nx * 1024);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(A[g % NCA_BF_RING]), frag(B[0][ks]), acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(A[g % NCA_BF_RING]), frag(B[1][ks]), acc1, 0, 0, 0);
+        const int g = m * NKS + ks, nx = g + RING - 1;
+        if (nx < MTOT * NKS) A[nx % RING] = *reinterpret_cast<const u32x4*>(imgl + nx * 1024);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(A[g % RING]), frag(B[0][ks]), acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(A[g % RING]), frag(B[1][ks]), acc1, 0, 0, 0);
         // keep every LDS read and MFMA inside its own step (the scheduler otherwise sinks the reads next to their
         // use and the prefetch distance is lost); vector/scalar ALU and global memory instructions may still move
         __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x10 | 0x400);
@@ -254,6 +256,7 @@ __device__ __forceinline__ void transpose_block(const u32x4 (&X)[2 * NT], int lc
 template <int F, int MODE>
 __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a) {
     constexpr bool ONCHIP = MODE == NCA_KM_BWD_ONCHIP;                        // mode 3 + on-chip dW of the last hidden layer
+    constexpr int RINGK = ONCHIP ? 2 : NCA_BF_RING;                           // A-fragment ring of the layer contractions
     constexpr bool STORED = MODE == NCA_KM_BWD_STORED || ONCHIP;
     constexpr bool BWD = MODE == NCA_KM_BWD || STORED;                        // output-layer gradients + dgrad sweep
     constexpr bool STORE = MODE == NCA_KM_BWD || MODE == NCA_KM_FWD_STORE;    // writes the input block and the layer inputs
@@ -554,14 +557,14 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                 // row-tile loop, so accumulators and ring registers are never copied at a merge point
                 auto rowtiles = [&](auto nks_c) __attribute__((always_inline)) {
                 constexpr int NKS = decltype(nks_c)::value;
-                u32x4 A[NCA_BF_RING];
-                ring_prime<NKS, MT>(imgl, A);
+                u32x4 A[RINGK];
+                ring_prime<NKS, MT, RINGK>(imgl, A);
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
                     f32x16 acc0, acc1;
 #pragma unroll
                     for (int i = 0; i < 16; ++i) { const float b = tail[(lh * MT + m) * 16 + i]; acc0[i] = b; acc1[i] = b; }
-                    mma_rowtile_ring<NKS, MT, KSMAX>(imgl, m, A, B, acc0, acc1);
+                    mma_rowtile_ring<NKS, MT, KSMAX, RINGK>(imgl, m, A, B, acc0, acc1);
 #pragma unroll
                     for (int i = 0; i < 16; ++i) { acc0[i] = relu1(acc0[i]); acc1[i] = relu1(acc1[i]); }
                     if (last) {
@@ -755,15 +758,15 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                         if (jj >= 2) mnext = load_nt(mglob + (jj - 2) * 1024);
                     }
                     const bool bits = lds_mask || STORED;         // mask bits at hand (else: re-read the layer input)
-                    u32x4 A[NCA_BF_RING];
+                    u32x4 A[RINGK];
                     const char* imgl = img + lane * 16;
-                    ring_prime<KS, MT>(imgl, A);
+                    ring_prime<KS, MT, RINGK>(imgl, A);
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
                         f32x16 acc0, acc1;
 #pragma unroll
                         for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-                        mma_rowtile_ring<KS, MT, KSMAX>(imgl, m, A, B, acc0, acc1);
+                        mma_rowtile_ring<KS, MT, KSMAX, RINGK>(imgl, m, A, B, acc0, acc1);
 #pragma unroll
                         for (int c = 0; c < 2; ++c) {
                             const char* hp = hblk + c * a.rows_total + lane * 16;
