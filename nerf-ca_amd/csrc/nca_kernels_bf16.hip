@@ -538,7 +538,8 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
-                    for (int k = 0; k < 2 * MT; ++k) B[c][k] = load_nt(hl + c * a.rows_total + k * 1024);
+                    for (int k = 0; k < 2 * MT; ++k)      // (on chip: plain loads -- the fragments are read again ~40 us later, let the caches keep them)
+                        B[c][k] = ONCHIP ? *reinterpret_cast<const u32x4*>(hl + c * a.rows_total + k * 1024) : load_nt(hl + c * a.rows_total + k * 1024);
             }
             for (int jj = STORED ? y.NL - 1 : 0; jj < y.NL; ++jj) {
                 const NcaLayerL& l = y.layer[jj];
