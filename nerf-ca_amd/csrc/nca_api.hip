@@ -551,7 +551,9 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     }
     // bf16 backward from a store: the weight gradient of the last hidden layer stays on chip (one launch per net)
     static const bool onchip_off = getenv("NCA_ONCHIP") != nullptr && getenv("NCA_ONCHIP")[0] == '0';     // NCA_ONCHIP=0: A/B switch
-    const bool onchip = !onchip_off && bf && stored;
+    // (worth it only when every workgroup sees enough tiles to amortise the per-net launches and the exchange: at the
+    // reference's default batch of 1024 rays x 500 samples -- 4 tile groups per workgroup -- it costs 3.6 %)
+    const bool onchip = !onchip_off && bf && stored && units * tiles_per_unit >= (int64_t)8 * NCA_WAVES * num_cus();
     const bool per_net_launch = onchip;
     BwdPlan p;
     int rc = plan_bwd(lays, a.nnets, prec, units, tiles_per_unit, work_bytes, &p, stored, onchip);
