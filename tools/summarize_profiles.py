@@ -76,7 +76,8 @@ traffic = {"how": "rocprofv3 --pmc FETCH_SIZE (and, in a second run, --pmc WRITE
                   "--steps 2 --warmup 1 --no-cpu-baseline; per-kernel mean over the last <=20 dispatches; bytes = counter * 1024; FETCH_SIZE "
                   "doubled (gfx950 reports half of a wide coalesced stream, MI355X_MICROARCH.md section HBM); WRITE_SIZE as is",
            "config": {"prec": prec, "rays_per_step": bench["config"]["rays_per_step_per_gpu"], "samples_per_ray": bench["config"]["samples_per_ray"],
-                      "ray_chunks_per_step": bench["roofline"]["all_kernels"]["bwd_dgrad"]["launches"] // bench["steps"]},
+                      "ray_chunks_per_step": bench["roofline"]["all_kernels"]["bwd_wgrad"]["launches"] // bench["steps"],
+                      "dgrad_launches_per_step": bench["roofline"]["all_kernels"]["bwd_dgrad"]["launches"] // bench["steps"]},
            "kernels": {}}
 for key, names in KERNELS.items():
     fk, name = pick(fetch, names)
