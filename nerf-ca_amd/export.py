@@ -10,8 +10,8 @@ from typing import Optional, Sequence, Tuple
 
 import torch
 
+from . import fused as _fused
 from .fused import eval_points
-from .train.model_helpers import get_activation_func
 
 
 def load_checkpoint(filename, device=None):
@@ -51,14 +51,23 @@ def density_volume(static_model, temp_model, phase: Optional[int], resolution: S
     dev = next(static_model.parameters()).device
     axes = [torch.linspace(lo, hi, n, device=dev) for (lo, hi), n in zip(bounds, resolution)]
     grid = torch.stack(torch.meshgrid(*axes, indexing="ij"), dim=-1).reshape(-1, 3)
-    act = get_activation_func(output_activation)
     out_s = torch.empty(grid.shape[0], dtype=torch.float32, device=dev)
     out_d = torch.empty_like(out_s) if temp_model is not None else None
+    line = 256                                                   # grid points are handed to the compositing kernel as rows of 256
+    i0 = torch.zeros(1, dtype=torch.float32, device=dev)
+    dz = torch.zeros(line, dtype=torch.float64, device=dev)      # only the activation is wanted here, not the line integral
     for i in range(0, grid.shape[0], chunk_points):
         pts = grid[i:i + chunk_points]
-        out_s[i:i + pts.shape[0]] = act(eval_points(static_model, pts)[:, 0]) * scale_value
+        n = pts.shape[0]
+        pad = (-n) % line
+        raw_s = torch.nn.functional.pad(eval_points(static_model, pts)[:, 0], (0, pad)).reshape(-1, line)
         if temp_model is not None:
-            ph = torch.full((pts.shape[0],), int(phase), dtype=torch.int32, device=dev)
-            out_d[i:i + pts.shape[0]] = act(eval_points(temp_model, pts, ph)[:, 0]) * scale_value
+            ph = torch.full((n,), int(phase), dtype=torch.int32, device=dev)
+            raw_d = torch.nn.functional.pad(eval_points(temp_model, pts, ph)[:, 0], (0, pad)).reshape(-1, line)
+            _, ss, sd = _fused.composite_raw(raw_s, raw_d, i0, dz, output_activation, False, scale_value, False)
+            out_d[i:i + n] = sd.reshape(-1)[:n]
+        else:                                                    # one field: the kernel's single mode returns sigma un-scaled,
+            _, ss, _ = _fused.composite_raw(raw_s, raw_s, i0, dz, output_activation, False, scale_value, False)   # so use the scaled pair mode
+        out_s[i:i + n] = ss.reshape(-1)[:n]
     shape = tuple(int(n) for n in resolution)
     return out_s.reshape(shape), (out_d.reshape(shape) if out_d is not None else None)

@@ -70,35 +70,36 @@ def _interval_lengths(depth_values, like):
     return torch.cat((depth_values[..., 1:] - depth_values[..., :-1], tail), dim=-1)
 
 
-def _hip_composable(field, depth_values):
-    """The stand-alone compositing kernels take one depth vector shared by all rays and [R,S,C] fields on the GPU."""
-    return field.is_cuda and field.dim() == 3 and depth_values.dim() == 1
+def _require_composable(field, depth_values, what):
+    """The stand-alone compositing kernels take [R,S,C] raw fields on the GPU and ONE depth vector shared by all rays (how
+    the reference calls them, run_composite.py:361, 407-413).  Anything else is an explicit error: there is no torch
+    implementation behind these functions."""
+    _fused._require_cuda(field, what)
+    if field.dim() != 3 or depth_values.dim() != 1 or field.shape[-2] != depth_values.shape[0]:
+        raise _fused._capi.NcaError(f"{what}: expected a raw field [R,S,C] and depth values [S], got {tuple(field.shape)} and "
+                                    f"{tuple(depth_values.shape)} (per-ray depth values are only supported by the fused "
+                                    f"obtain_train_predictions_* path)")
 
 
 def render_volume_density_composite(static_radiance_field, temp_radiance_field, initial_intensities, ray_directions, depth_values,
                                     output_activation="softplus", scale_value=1e-2):
+    """model_helpers.py:72-84 as one HIP kernel (nca_composite_fwd / _bwd under autograd)."""
+    _require_composable(static_radiance_field, depth_values, "render_volume_density_composite")
+    _fused._require_cuda(temp_radiance_field, "render_volume_density_composite")
     dists = _interval_lengths(depth_values, ray_directions)
-    if _hip_composable(static_radiance_field, depth_values):
-        f64 = ray_directions.dtype == torch.float64
-        pix, ss, sd = _fused.composite_raw(static_radiance_field[..., -1], temp_radiance_field[..., -1], initial_intensities, dists,
-                                           output_activation, False, scale_value, f64)
-        return pix, ss, sd, dists
-    f = get_activation_func(output_activation)
-    static_sigma = f(static_radiance_field[..., -1]) * scale_value
-    temp_sigma = f(temp_radiance_field[..., -1]) * scale_value
-    int_map = initial_intensities - ((static_sigma + temp_sigma) * dists).sum(dim=-1)
-    return int_map, static_sigma, temp_sigma, dists
+    f64 = ray_directions.dtype == torch.float64
+    pix, ss, sd = _fused.composite_raw(static_radiance_field[..., -1], temp_radiance_field[..., -1], initial_intensities, dists,
+                                       output_activation, False, scale_value, f64)
+    return pix, ss, sd, dists
 
 
 def render_volume_density(radiance_field, initial_intensities, ray_directions, depth_values, output_activation="softplus", scale_value=1e-2):
+    """model_helpers.py:86-97 (returns the UN-scaled sigma) as one HIP kernel."""
+    _require_composable(radiance_field, depth_values, "render_volume_density")
     dists = _interval_lengths(depth_values, ray_directions)
-    if _hip_composable(radiance_field, depth_values):
-        f64 = ray_directions.dtype == torch.float64
-        pix, sa = _fused.composite_raw(radiance_field[..., -1], None, initial_intensities, dists, output_activation, True, scale_value, f64)
-        return pix, sa, dists
-    sigma_a = get_activation_func(output_activation)(radiance_field[..., -1])
-    int_map = initial_intensities - (sigma_a * dists * scale_value).sum(dim=-1)
-    return int_map, sigma_a, dists
+    f64 = ray_directions.dtype == torch.float64
+    pix, sa = _fused.composite_raw(radiance_field[..., -1], None, initial_intensities, dists, output_activation, True, scale_value, f64)
+    return pix, sa, dists
 
 
 def obtain_train_predictions_static(static_model, batch_origins, batch_directions, batch_initial_intensities, depth_values,

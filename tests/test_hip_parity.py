@@ -729,6 +729,12 @@ def test_error_paths_are_explicit(dev):
     with pytest.raises(_capi.NcaError, match="GPU"):
         render_rays(s, t, o.cpu(), o.cpu(), torch.zeros(4, dtype=torch.int64), torch.ones(4), z.cpu(), dists.cpu())
     assert s(torch.zeros(0, 3, device=dev)).shape == (0, 1)             # empty point batch: empty result, no launch
+    from nerfca_amd.train import model_helpers as MH
+    raw = torch.zeros(4, 8, 1, device=dev)
+    with pytest.raises(_capi.NcaError, match="per-ray depth"):         # the stand-alone compositing kernels share one depth vector
+        MH.render_volume_density(raw, torch.ones(4, device=dev), o, z[None, :].repeat(4, 1))
+    with pytest.raises(_capi.NcaError, match="GPU"):
+        MH.render_volume_density_composite(raw.cpu(), raw.cpu(), torch.ones(4), o.cpu(), z.cpu())
     bad = _capi.NcaNet(F=256, n_hidden=4, n_late=0, enc_mode=1, L=12, T=0, P=0, reserved=0)
     assert _capi.lib().nca_packed_bytes(C.byref(bad), 0) == -2
 

@@ -201,18 +201,19 @@ def test_losses_match_reference(golden, dtn):
     assert rel_err(MH.compute_occl_loss(b, g[f"{dtn}_dists"], 0.2, use_back=True), g[f"{dtn}_occl_back"]) < 1e-6
 
 
-@pytest.mark.parametrize("act", ["softplus", "clamp", "Softplus"])
-def test_render_helpers_match_reference(golden, act):
+def test_render_helpers_refuse_cpu_tensors(golden):
+    """render_volume_density[_composite] are HIP kernels (values: tests/test_hip_parity.py against the same goldens); there
+    is no torch implementation behind them, so CPU tensors are an explicit error."""
+    from nerfca_amd._capi import NcaError
     from nerfca_amd.train import model_helpers as MH
     g = golden("render")
-    for dtn, dt in (("f64", torch.float64), ("f32", torch.float32)):
-        dirs = torch.zeros(12, 3, dtype=dt)
-        out = MH.render_volume_density_composite(g["raw_s"], g["raw_d"], g["I0"], dirs, g["z"], act)
-        for v, n in zip(out, ("pix", "sig_s", "sig_d", "dists")):
-            assert torch.equal(v, g[f"comp_{dtn}_{act}_{n}"]), n
-        out = MH.render_volume_density(g["raw_s"], g["I0"], dirs, g["z"], act)
-        for v, n in zip(out, ("pix", "sig", "dists")):
-            assert torch.equal(v, g[f"single_{dtn}_{act}_{n}"]), n
+    dirs = torch.zeros(12, 3, dtype=torch.float64)
+    with pytest.raises(NcaError, match="GPU"):
+        MH.render_volume_density_composite(g["raw_s"], g["raw_d"], g["I0"], dirs, g["z"], "softplus")
+    with pytest.raises(NcaError, match="GPU"):
+        MH.render_volume_density(g["raw_s"], g["I0"], dirs, g["z"], "softplus")
+    assert torch.equal(MH._interval_lengths(g["z"], dirs), g["comp_f64_softplus_dists"])      # the one piece of host arithmetic
+    assert torch.equal(MH._interval_lengths(g["z"], dirs.float()), g["comp_f32_softplus_dists"])
 
 
 def test_sample_pdf_matches_oracle():
