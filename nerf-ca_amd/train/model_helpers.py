@@ -115,7 +115,14 @@ def obtain_train_predictions_static(static_model, batch_origins, batch_direction
 def obtain_train_predictions_iter(static_model_coarse, temp_model_coarse, static_model_fine, temp_model_fine, batch_origins,
                                   batch_directions, batch_phases, batch_initial_intensities, depth_values, output_activation,
                                   batch_size, depth_samples_per_ray_fine, device, t_rand=None, u_fine=None):
-    """model_helpers.py:115-160 -> the reference's 8-tuple; the coarse pass is one fused launch."""
+    """model_helpers.py:115-160 -> the reference's 8-tuple; the coarse pass is one fused launch.
+
+    Fine pass (``depth_samples_per_ray_fine > 0``, off in the reference's configs): all eight outputs equal the reference's
+    (goldens with injected draws).  KNOWN DEVIATION in the backward: the reference never detaches the sampled depths, so its
+    autograd also differentiates the fine losses through ``sample_pdf`` / ``sort`` / the query points / the positional
+    encoding back into the COARSE nets (and through the ray-0 ``dists``).  Here the fine depths are constants of the step, as
+    in NeRF's own hierarchical sampling: coarse nets learn from the coarse terms, fine nets from the fine terms.  ``u_fine``
+    injects the uniform draw of ``sample_pdf``."""
     z = randomize_depth(depth_values, device, t_rand)
     dists_c = _interval_lengths(z, batch_directions)
     pix_c, sig_s_c, sig_d_c = _fused.render_rays(static_model_coarse, temp_model_coarse, batch_origins, batch_directions, batch_phases,

@@ -57,10 +57,13 @@ class TrainConfig:
 
 class CompositeTrainer:
     def __init__(self, cfg: TrainConfig, static_model, temp_model, data, device, rank: int = 0, world: int = 1,
-                 seed: int = 0, render: Optional[Callable] = None, fused_adam: Optional[bool] = None, fused_loss: bool = False):
+                 seed: int = 0, render: Optional[Callable] = None, fused_adam: Optional[bool] = None, fused_loss: Optional[bool] = None):
         self.cfg, self.s, self.t, self.data, self.device = cfg, static_model, temp_model, data, device
         self.rank, self.world, self.seed = rank, world, seed
-        self.fused_loss = fused_loss and render is None
+        on_cuda = device.type == "cuda" if isinstance(device, torch.device) else str(device).startswith("cuda")
+        if fused_loss is None:             # default on the GPU: the autograd-free step with the HIP loss kernel (step_fused);
+            fused_loss = on_cuda           # fused_loss=False keeps the reference's torch loss functions under autograd
+        self.fused_loss = bool(fused_loss) and render is None
         self.always_allreduce = False      # all-reduce even with one rank (exercises the collective path)
         self._dev_gen = None
         self.render = render or MH._fused.render_rays
