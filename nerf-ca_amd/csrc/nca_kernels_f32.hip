@@ -16,6 +16,7 @@
 // of one ray (lane&31 = sample, lane>>5 = k-half), a 32x32 accumulator tile per 32 features.  A
 // layer's output registers are the next layer's B operand in place (see nca_layout.hpp).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "nca_kernels.hpp"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -782,6 +783,199 @@ __global__ __launch_bounds__(256) void nca_wgrad_f32(const NcaWgradArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// wgrad, f32 accuracy on the bf16 matrix cores.  Every f32 operand x is split EXACTLY into three bf16 pieces
+// x = x1 + x2 + x3 (8 + 8 + 8 significant bits, by truncation and exact subtraction), and D * H^T is accumulated in f32
+// from the six piece products of weight <= 2^-16 (x1 y1, x1 y2, x2 y1, x1 y3, x3 y1, x2 y2); the dropped ones are below
+// 2^-24 of |x||y|, i.e. under the rounding of an f32 FMA chain (measured against f64 on random data: 6e-8 vs 4e-7 for
+// plain f32).  Products of bf16 pieces are exact in f32, so the result does not depend on bf16 rounding anywhere.
+// Six 32-cycle v_mfma_f32_32x32x16_bf16 replace eight 64-cycle v_mfma_f32_32x32x2_f32: 2.7x less matrix-pipe time.
+// The split happens once per element while the operand tile is staged into LDS (three bf16 planes [feature][sample],
+// 80 B pitch = conflict-free 16 B fragment reads); same jobs, slabs and tile walk as nca_wgrad_f32.
+// ------------------------------------------------------------------------------------------
+typedef __bf16 w3_bf16x8 __attribute__((ext_vector_type(8)));
+#define W3_PITCH 80
+#define W3_PLANE (128 * W3_PITCH)
+#define W3_OPER (3 * W3_PLANE)
+
+typedef float w3_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 w3_bf16x2 __attribute__((ext_vector_type(2)));
+// two f32 -> three bf16x2 dwords, x = x1 + x2 + x3 exactly: round to bf16 (v_cvt_pk_bf16_f32), subtract exactly
+// (v_pk_add_f32; the residual of a rounding is representable), twice; the third residual has <= 8 significant bits
+__device__ __forceinline__ void split3(w3_f32x2 v, uint32_t (&p)[3]) {
+    const w3_bf16x2 q1 = __builtin_convertvector(v, w3_bf16x2);
+    const w3_f32x2 r1 = v - __builtin_convertvector(q1, w3_f32x2);
+    const w3_bf16x2 q2 = __builtin_convertvector(r1, w3_bf16x2);
+    const w3_f32x2 r2 = r1 - __builtin_convertvector(q2, w3_f32x2);
+    const w3_bf16x2 q3 = __builtin_convertvector(r2, w3_bf16x2);
+    p[0] = __builtin_bit_cast(uint32_t, q1);
+    p[1] = __builtin_bit_cast(uint32_t, q2);
+    p[2] = __builtin_bit_cast(uint32_t, q3);
+}
+
+// the value of lane ^ 1 (DPP quad_perm [1,0,3,2])
+__device__ __forceinline__ float lane_xor1(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+
+template <int CT>      // 32-row tiles of the H block: one instantiation each keeps the MFMA section free of branches
+__device__ __forceinline__ void wgrad3_body(const NcaWgradArgs& a, const NcaWgradJob& job, char* smem) {
+    char* As = smem;                       // D tile: 3 planes [128 features][32 samples] bf16
+    char* Bs = smem + W3_OPER;             // H tile
+    const int q = blockIdx.x;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+    const int F = job.F, MT = F / 32;
+    const float* __restrict__ Ag = a.scratch + job.d_row0 * 32;
+    const float* __restrict__ Bg = a.scratch_b + (a.tile0_b * a.rows_total_b + job.b_row0) * 32;
+    const int64_t tstride = a.rows_total * 32, tstride_b = a.rows_total_b * 32;
+
+    const int64_t ntile = a.ntiles;
+    const int64_t per = (ntile + gridDim.x - 1) / gridDim.x;
+    const int64_t t0 = (int64_t)q * per, t1 = (t0 + per < ntile) ? t0 + per : ntile;
+
+    f32x16 acc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc[c] = (f32x16)(0.f);
+    float bs[4][4];                        // bias gradient: this thread's four rows of every row tile, summed over its sample
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { bs[i][0] = bs[i][1] = bs[i][2] = bs[i][3] = 0.f; }
+
+    // Loader (as nca_wgrad_f32): 256 threads x float4 per 32 rows, 1 KiB contiguous per wave instruction.  Hidden blocks
+    // (every D, every H but the encoded input) are in the fused kernels' register order: float4 #(4 m + g) * 64 + l holds
+    // rows 32 m + 8 g + 4 (l >> 5) + 0..3 of sample l & 31; the encoded-input block is row-major [row][32].
+    const int lrow = tid >> 3, lc4 = tid & 7;
+    const bool bfrag = job.b_frag != 0;
+    struct Regs { f32x4e a[4], b[4]; };
+    Regs R0;
+    auto issue = [&](int64_t t, Regs& r) {
+        const float* at = Ag + t * tstride + tid * 4;
+        const float* bt = Bg + t * tstride_b + tid * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < MT) r.a[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4e*>(at + i * 1024));
+            if (i < CT) r.b[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4e*>(bt + i * 1024));
+        }
+    };
+    // fragment order: this thread holds rows fr + 0..3 (of row tile i) of sample fc.  Neighbouring lanes swap halves so
+    // that each holds TWO rows of TWO neighbouring samples = one bf16x2 dword per plane and row.
+    const int fr = 8 * (tid >> 6) + 4 * ((tid >> 5) & 1), fc = tid & 31, odd = tid & 1;
+    auto put_frag = [&](char* base, int i, const f32x4e& v) {
+        const float s0 = odd ? v[0] : v[2], s1 = odd ? v[1] : v[3];
+        const float r0 = lane_xor1(s0), r1 = lane_xor1(s1);
+        char* dst = base + (32 * i + fr + 2 * odd) * W3_PITCH + (fc & ~1) * 2;
+        uint32_t p0[3], p1[3];
+        split3((w3_f32x2){odd ? r0 : v[0], odd ? v[2] : r0}, p0);
+        split3((w3_f32x2){odd ? r1 : v[1], odd ? v[3] : r1}, p1);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            *reinterpret_cast<uint32_t*>(dst + pl * W3_PLANE) = p0[pl];
+            *reinterpret_cast<uint32_t*>(dst + pl * W3_PLANE + W3_PITCH) = p1[pl];
+        }
+    };
+    auto put_rows = [&](char* base, int i, const f32x4e& v) {     // row lrow + 32 i, samples 4 lc4 + 0..3
+        uint32_t pl[3], ph[3];
+        split3((w3_f32x2){v[0], v[1]}, pl);
+        split3((w3_f32x2){v[2], v[3]}, ph);
+        char* dst = base + (lrow + 32 * i) * W3_PITCH + lc4 * 8;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(dst + p * W3_PLANE) = make_uint2(pl[p], ph[p]);
+    };
+    auto commit = [&](const Regs& r) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < MT) {
+                bs[i][0] += r.a[i][0]; bs[i][1] += r.a[i][1]; bs[i][2] += r.a[i][2]; bs[i][3] += r.a[i][3];
+                put_frag(As, i, r.a[i]);
+            }
+            if (i < CT) {
+                if (bfrag) put_frag(Bs, i, r.b[i]);
+                else put_rows(Bs, i, r.b[i]);
+            }
+        }
+    };
+    auto compute = [&]() {
+        if (wave < MT) {
+            const char* ar = As + (32 * wave + lr) * W3_PITCH + lh * 16;
+            const char* br = Bs + lr * W3_PITCH + lh * 16;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                w3_bf16x8 A[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) A[p] = *reinterpret_cast<const w3_bf16x8*>(ar + p * W3_PLANE + ks * 32);
+#pragma unroll
+                for (int c0 = 0; c0 < CT; c0 += 2) {          // two column tiles at a time: consecutive MFMAs alternate accumulators
+                    w3_bf16x8 B[2][3];
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int p = 0; p < 3; ++p)
+                            if (c0 + c < CT) B[c][p] = *reinterpret_cast<const w3_bf16x8*>(br + p * W3_PLANE + (c0 + c) * 32 * W3_PITCH + ks * 32);
+                    // small products first
+#define W3_MMA(I, J)                                                                                                   \
+                    _Pragma("unroll") for (int c = 0; c < 2; ++c)                                                   \
+                        if (c0 + c < CT) acc[c0 + c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[I], B[c][J], acc[c0 + c], 0, 0, 0);
+                    W3_MMA(1, 1) W3_MMA(2, 0) W3_MMA(0, 2) W3_MMA(1, 0) W3_MMA(0, 1) W3_MMA(0, 0)
+#undef W3_MMA
+                }
+            }
+        }
+    };
+
+    // tile t sits in LDS while t + 1 is in flight (two tiles in flight were measured: no gain, the kernel is bound by
+    // the SIMDs' MFMA + VALU issue time, not by latency)
+    if (t0 < t1) { issue(t0, R0); commit(R0); }
+    __syncthreads();
+    for (int64_t t = t0; t < t1; ++t) {
+        const bool more = t + 1 < t1;
+        if (more) issue(t + 1, R0);
+        compute();
+        __syncthreads();                 // every wave is done with the planes
+        if (more) commit(R0);
+        __syncthreads();
+    }
+
+    if (wave < MT) {
+        float* slab = a.slab + (int64_t)q * a.slab_stride;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const int colb = 32 * c + lr;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int o = 32 * wave + nca_rho(i) + 4 * lh;
+                float* dst = nullptr;
+                if (colb < job.ncols_w) dst = slab + job.out_off + (int64_t)o * job.out_ld + job.out_col0 + colb;
+                else if (colb < job.ncols_w + job.P) dst = slab + job.onehot_off + o * job.P + (colb - job.ncols_w);
+                if (dst) *dst = a.accumulate ? *dst + acc[c][i] : acc[c][i];
+            }
+        }
+    }
+    if (job.bias_off >= 0) {
+        float* slab = a.slab + (int64_t)q * a.slab_stride;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float sum = half_sum(bs[i][j]);          // over the 32 samples (lanes of one wave half)
+                if (fc == 0 && i < MT) {
+                    float* dst = slab + job.bias_off + 32 * i + fr + j;
+                    *dst = a.accumulate ? *dst + sum : sum;
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void nca_wgrad_f32x3(const NcaWgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const NcaWgradJob job = a.job[blockIdx.y];
+    switch (job.b_rows_pad / 32) {
+        case 1: wgrad3_body<1>(a, job, smem); break;
+        case 2: wgrad3_body<2>(a, job, smem); break;
+        case 3: wgrad3_body<3>(a, job, smem); break;
+        default: wgrad3_body<4>(a, job, smem); break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // reduce: natural flat gradients from the split slabs (fixed summation order)
 // ------------------------------------------------------------------------------------------
 __global__ void nca_reduce_f32(const NcaReduceArgs a) {
@@ -925,6 +1119,13 @@ hipError_t nca_launch_pack_f32(const NcaLayout& y, const float* prm, void* out, 
 }
 
 hipError_t nca_launch_wgrad_f32(const NcaWgradArgs& a, int nsplit, hipStream_t st) {
+    static const bool plain = getenv("NCA_WGRAD_F32") != nullptr && getenv("NCA_WGRAD_F32")[0] == 'p';   // NCA_WGRAD_F32=plain: A/B switch
+    if (!plain) {
+        const size_t lds3 = 2 * W3_OPER;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_wgrad_f32x3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+        hipLaunchKernelGGL(nca_wgrad_f32x3, dim3(nsplit, a.njobs), dim3(256), lds3, st, a);
+        return hipGetLastError();
+    }
     const size_t lds = 4 * 128 * WG_PITCH * sizeof(float);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_wgrad_f32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(nca_wgrad_f32, dim3(nsplit, a.njobs), dim3(256), lds, st, a);
