@@ -812,11 +812,6 @@ __device__ __forceinline__ void split3(w3_f32x2 v, uint32_t (&p)[3]) {
     p[2] = __builtin_bit_cast(uint32_t, q3);
 }
 
-// the value of lane ^ 1 (DPP quad_perm [1,0,3,2])
-__device__ __forceinline__ float lane_xor1(float v) {
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
-}
-
 template <int CT>      // 32-row tiles of the H block: one instantiation each keeps the MFMA section free of branches
 __device__ __forceinline__ void wgrad3_body(const NcaWgradArgs& a, const NcaWgradJob& job, char* smem) {
     char* As = smem;                       // D tile: 3 planes [128 features][32 samples] bf16
@@ -839,45 +834,56 @@ __device__ __forceinline__ void wgrad3_body(const NcaWgradArgs& a, const NcaWgra
 #pragma unroll
     for (int i = 0; i < 4; ++i) { bs[i][0] = bs[i][1] = bs[i][2] = bs[i][3] = 0.f; }
 
-    // Loader (as nca_wgrad_f32): 256 threads x float4 per 32 rows, 1 KiB contiguous per wave instruction.  Hidden blocks
-    // (every D, every H but the encoded input) are in the fused kernels' register order: float4 #(4 m + g) * 64 + l holds
-    // rows 32 m + 8 g + 4 (l >> 5) + 0..3 of sample l & 31; the encoded-input block is row-major [row][32].
-    const int lrow = tid >> 3, lc4 = tid & 7;
+    // Loader: 256 threads x float4 per 32 rows, 1 KiB per wave instruction.  Hidden blocks (every D, every H but the
+    // encoded input) are in the fused kernels' register order: float4 #(4 m + g) * 64 + l holds rows 32 m + 8 g + 4 (l >> 5)
+    // + 0..3 of sample l & 31; the encoded-input block is row-major [row][32 samples].
+    // Samples are paired (s, s + 16) into bf16x2 dwords -- the contraction index may be permuted as long as both operands
+    // agree -- because the partners then sit in lanes l and l + 32 and ONE v_permlane32_swap moves two registers; and the
+    // lanes of one half (0..15 / 16..31) are given rows 4 apart, which with the 80 B pitch lands their dwords in disjoint
+    // bank halves (rows 2 apart, as a lane ^ 1 exchange would give, cost 11 % of the kernel in bank conflicts).
     const bool bfrag = job.b_frag != 0;
+    const int up = lane >> 5;                                   // 0: keeps rows +0, +1 / samples 4c, 4c + 1; 1: rows +2, +3 / ...
+    const int hq = (lane >> 4) & 1, fj = lane & 15;             // fragment order: row half, sample pair (fj, fj + 16)
+    const int frag_src = (wave * 64 + 32 * hq + fj + 16 * up) * 4;              // floats inside a 32-row tile
+    const int frag_dst = (8 * wave + 4 * hq + 2 * up) * W3_PITCH + fj * 4;      // bytes inside a plane
+    const int rc = lane & 3, rrow = 8 * wave + ((lane >> 2) & 7);              // row-major: float4 rc + 4 up of row rrow
+    const int rows_src = (rrow * 8 + rc + 4 * up) * 4;
+    const int rows_dst = rrow * W3_PITCH + (4 * rc + 2 * up) * 4;
     struct Regs { f32x4e a[4], b[4]; };
     Regs R0;
     auto issue = [&](int64_t t, Regs& r) {
-        const float* at = Ag + t * tstride + tid * 4;
-        const float* bt = Bg + t * tstride_b + tid * 4;
+        const float* at = Ag + t * tstride + frag_src;
+        const float* bt = Bg + t * tstride_b + (bfrag ? frag_src : rows_src);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (i < MT) r.a[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4e*>(at + i * 1024));
             if (i < CT) r.b[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4e*>(bt + i * 1024));
         }
     };
-    // fragment order: this thread holds rows fr + 0..3 (of row tile i) of sample fc.  Neighbouring lanes swap halves so
-    // that each holds TWO rows of TWO neighbouring samples = one bf16x2 dword per plane and row.
-    const int fr = 8 * (tid >> 6) + 4 * ((tid >> 5) & 1), fc = tid & 31, odd = tid & 1;
-    auto put_frag = [&](char* base, int i, const f32x4e& v) {
-        const float s0 = odd ? v[0] : v[2], s1 = odd ? v[1] : v[3];
-        const float r0 = lane_xor1(s0), r1 = lane_xor1(s1);
-        char* dst = base + (32 * i + fr + 2 * odd) * W3_PITCH + (fc & ~1) * 2;
+    // (x, z) and (y, w) of this lane's float4 against the partner lane's: lanes < 32 end up with elements 0, 1 of both,
+    // lanes >= 32 with elements 2, 3 -- as (own sample group, the one 16 samples on) in both cases
+    auto swap_split = [&](const f32x4e& v, uint32_t (&p0)[3], uint32_t (&p1)[3]) {
+        const auto s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0]), __float_as_uint(v[2]), false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[1]), __float_as_uint(v[3]), false, false);
+        split3((w3_f32x2){__uint_as_float(s0[0]), __uint_as_float(s0[1])}, p0);
+        split3((w3_f32x2){__uint_as_float(s1[0]), __uint_as_float(s1[1])}, p1);
+    };
+    auto put_frag = [&](char* base, int i, const f32x4e& v) {     // two rows x one sample pair
         uint32_t p0[3], p1[3];
-        split3((w3_f32x2){odd ? r0 : v[0], odd ? v[2] : r0}, p0);
-        split3((w3_f32x2){odd ? r1 : v[1], odd ? v[3] : r1}, p1);
+        swap_split(v, p0, p1);
+        char* dst = base + 32 * i * W3_PITCH + frag_dst;
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
             *reinterpret_cast<uint32_t*>(dst + pl * W3_PLANE) = p0[pl];
             *reinterpret_cast<uint32_t*>(dst + pl * W3_PLANE + W3_PITCH) = p1[pl];
         }
     };
-    auto put_rows = [&](char* base, int i, const f32x4e& v) {     // row lrow + 32 i, samples 4 lc4 + 0..3
-        uint32_t pl[3], ph[3];
-        split3((w3_f32x2){v[0], v[1]}, pl);
-        split3((w3_f32x2){v[2], v[3]}, ph);
-        char* dst = base + (lrow + 32 * i) * W3_PITCH + lc4 * 8;
+    auto put_rows = [&](char* base, int i, const f32x4e& v) {     // one row x two neighbouring sample pairs
+        uint32_t p0[3], p1[3];
+        swap_split(v, p0, p1);
+        char* dst = base + 32 * i * W3_PITCH + rows_dst;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(dst + p * W3_PLANE) = make_uint2(pl[p], ph[p]);
+        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint2*>(dst + pl * W3_PLANE) = make_uint2(p0[pl], p1[pl]);
     };
     auto commit = [&](const Regs& r) {
 #pragma unroll
@@ -954,9 +960,11 @@ __device__ __forceinline__ void wgrad3_body(const NcaWgradArgs& a, const NcaWgra
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float sum = half_sum(bs[i][j]);          // over the 32 samples (lanes of one wave half)
-                if (fc == 0 && i < MT) {
-                    float* dst = slab + job.bias_off + 32 * i + fr + j;
+                float sum = bs[i][j];                          // over the 32 samples: lane bits 0..3 and 5
+                sum += __shfl_xor(sum, 32); sum += __shfl_xor(sum, 8); sum += __shfl_xor(sum, 4);
+                sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 1);
+                if (fj == 0 && up == 0 && i < MT) {
+                    float* dst = slab + job.bias_off + 32 * i + 8 * wave + 4 * hq + j;
                     *dst = a.accumulate ? *dst + sum : sum;
                 }
             }

@@ -274,3 +274,36 @@ def test_checkpoint_round_trip(tmp_path):
             assert torch.equal(a, b), k
         assert torch.equal(back.freq_mask_alpha, m.freq_mask_alpha)      # what save() keeps for free_windowed
         assert back._binding._is_flat()          # the loaded parameters are views of one flat buffer again
+
+
+def test_three_way_bf16_split_is_exact_and_accurate():
+    """The arithmetic claim behind nca_wgrad_f32x3 (nerf-ca_amd/csrc/nca_kernels_f32.hip): x = x1 + x2 + x3 with three bf16
+    pieces obtained by round-to-nearest-even and exact subtraction reproduces every normal f32 exactly, and the six piece
+    products of weight <= 2^-16, summed in wider precision, are at least as close to the exact product sum as an f32 dot
+    product is."""
+    rng = np.random.default_rng(0)
+
+    def rne_bf16(x):
+        b = x.view(np.uint32).astype(np.uint64)
+        b = (b + 0x7FFF + ((b >> 16) & 1)) & 0xFFFF0000
+        return b.astype(np.uint32).view(np.float32)
+
+    def split(x):
+        p1 = rne_bf16(x)
+        r1 = x - p1
+        p2 = rne_bf16(r1)
+        r2 = r1 - p2
+        return p1, p2, rne_bf16(r2), r2
+
+    v = (rng.standard_normal(1_000_000) * np.exp(rng.uniform(-30, 30, 1_000_000))).astype(np.float32)
+    p1, p2, p3, r2 = split(v)
+    assert np.array_equal(p3, r2)                                              # the third residual needs no rounding
+    assert np.array_equal(p1.astype(np.float64) + p2 + p3, v.astype(np.float64))
+    a = rng.standard_normal((2048, 48)).astype(np.float32)
+    b = rng.standard_normal((2048, 48)).astype(np.float32)
+    A, B = split(a)[:3], split(b)[:3]
+    six = sum(A[i].astype(np.float64).T @ B[j].astype(np.float64) for i, j in ((1, 1), (2, 0), (0, 2), (1, 0), (0, 1), (0, 0)))
+    exact = a.astype(np.float64).T @ b.astype(np.float64)
+    err6 = np.abs(six - exact).max() / np.abs(exact).max()
+    err32 = np.abs((a.T @ b).astype(np.float64) - exact).max() / np.abs(exact).max()
+    assert err6 < 2e-7 and err6 <= err32

@@ -14,7 +14,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 be
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -- python3 bench.py --prec $PREC --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_$C.err
 done
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE \
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE \
   --kernel-trace --output-format csv -d $OUT/pmc_SQ -- python3 bench.py --prec $PREC --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_SQ.err
 find $OUT -name "*.csv" | sort
 tail -c 400 $OUT/bench.json

@@ -19,7 +19,7 @@ dst = os.path.join(ROOT, "profiles")
 # 3 backward from the store, 4 the same with the last hidden layer's weight gradient on chip, one launch per net)
 KERNELS = {"fwd": [f"nca_fused_{prec}<128, 2>", f"nca_fused_{prec}<128, 0>", f"nca_fused_{prec}<128, false>"],
            "bwd_dgrad": [f"nca_fused_{prec}<128, 4>", f"nca_fused_{prec}<128, 3>", f"nca_fused_{prec}<128, 1>", f"nca_fused_{prec}<128, true>"],
-           "bwd_wgrad": ["nca_wgrad_bf16<128>" if prec == "bf16" else "nca_wgrad_f32"], "bwd_reduce": ["nca_reduce_f32"],
+           "bwd_wgrad": ["nca_wgrad_bf16<128>"] if prec == "bf16" else ["nca_wgrad_f32x3", "nca_wgrad_f32"], "bwd_reduce": ["nca_reduce_f32"],
            "loss": ["nca_loss_rays"]}
 
 
@@ -99,7 +99,8 @@ if dom in traffic["kernels"]:
 
 sq = per_kernel("pmc_SQ")
 out = {"how": "one rocprofv3 --pmc pass (8 SQ counters + GRBM_GUI_ACTIVE) --kernel-trace over bench.py --steps 2 --warmup 1; means per dispatch. "
-              "mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs); wait/active fractions are of SQ_WAVE_CYCLES",
+              "mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs); valu_busy = SQ_ACTIVE_INST_VALU (quad-cycles, summed over waves; an MFMA counts "
+              "with its issue slot only) * 4 / (1024 SIMDs) / the same cycles = share of SIMD time spent issuing vector ALU work; wait/active fractions are of SQ_WAVE_CYCLES",
        "kernels": {}}
 for key, names in KERNELS.items():
     k0, name = pick(sq, names)
@@ -110,6 +111,7 @@ for key, names in KERNELS.items():
     cyc = d["GRBM_GUI_ACTIVE"] / 8
     out["kernels"][key] = {"kernel": name, "dispatches": len(sq[ks[0]]["SQ_WAVE_CYCLES"]), "gpu_cycles_per_xcd": cyc,
                            "mfma_busy": d["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / cyc,
+                           "valu_busy": d["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / cyc if "SQ_ACTIVE_INST_VALU" in d else None,
                            "wait_any": d["SQ_WAIT_ANY"] / d["SQ_WAVE_CYCLES"], "wait_inst_any": d["SQ_WAIT_INST_ANY"] / d["SQ_WAVE_CYCLES"],
                            "active_inst_any": d["SQ_ACTIVE_INST_ANY"] / d["SQ_WAVE_CYCLES"], "wait_inst_lds": d["SQ_WAIT_INST_LDS"] / d["SQ_WAVE_CYCLES"],
                            "lds_bank_conflict_cycles": d["SQ_LDS_BANK_CONFLICT"]}
