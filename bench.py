@@ -81,6 +81,19 @@ def measured_traffic(args, kernel):
     return k["hbm_bytes_per_launch"] if k else None
 
 
+def measured_issue_share(args, kernel):
+    """(mfma_busy, valu_busy) of `kernel` from the committed SQ counter pass (profiles/r01_*_pmc_sq.json): the shares of
+    SIMD time spent in MFMA and in other vector-ALU instructions -- they do not overlap on gfx950, so
+    their sum is the issue-side utilisation.  Same configuration gate as the traffic figure."""
+    if measured_traffic(args, kernel) is None:
+        return None
+    try:
+        k = json.load(open(os.path.join(ROOT, "profiles", f"r01_{args.prec}_pmc_sq.json")))["kernels"][kernel]
+        return {"mfma_busy": k["mfma_busy"], "valu_busy": k.get("valu_busy")}
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def _oracle_leg(args, data, R, steps, device):
     """`steps` reference-equivalent training steps (the oracle: plain torch ops + autograd + torch Adam) of R rays on
     `device`; returns seconds.  On cuda this is the unfused PyTorch-ROCm path of SURVEY.md 8(d)(ii)."""
@@ -226,6 +239,7 @@ def main():
                 "avg_launch_ms": kern[dom]["avg_ms"], "launches": kern[dom]["launches"],
                 # the staged (non-algorithmic) HBM traffic of that kernel per second of its run time: what it is bound by in practice
                 "staging_TBps": (measured_traffic(args, dom) / (kern[dom]["avg_ms"] * 1e-3) / 1e12) if measured_traffic(args, dom) and kern[dom]["avg_ms"] else None,
+                "simd_issue_share_pmc": measured_issue_share(args, dom),
                 "kernel_time_share": kern[dom]["ms_total"] / (dt * 1e3), "all_kernels": kern}
         out = {"metric": f"training rays/sec ({args.det}^2 det, {args.samples} samples/ray)", "value": args.rays * world * args.steps / dt, "unit": "rays/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,

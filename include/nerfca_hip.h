@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NCA_ABI_VERSION 3
+#define NCA_ABI_VERSION 4
 
 enum {
     NCA_OK = 0,
@@ -191,6 +191,13 @@ int nca_loss_fwd_bwd(const NcaLoss* desc, const double* pix, const double* gt, c
 int64_t nca_fine_depths_workspace(int64_t R);
 int nca_fine_depths(int64_t R, int32_t S, int32_t n_fine, const float* sig_s, const float* sig_d, const float* z,
                     const float* u, float* z_all, void* work, int64_t work_bytes, void* stream);
+/*      The same in two stages for a batch that is sharded over ranks: the weights are normalised by the maximum over
+ *      the WHOLE batch (model_helpers.py:139), so a rank computes the maximum of its rays into the device scalar
+ *      wmax f32[1], all-reduces it (MAX) and samples with the result. */
+int nca_fine_weight_max(int64_t R, int32_t S, const float* sig_s, const float* sig_d, float* wmax, void* work, int64_t work_bytes,
+                        void* stream);
+int nca_fine_depths_given_max(int64_t R, int32_t S, int32_t n_fine, const float* sig_s, const float* sig_d, const float* z,
+                              const float* u, const float* wmax, float* z_all, void* stream);
 
 /* ---- optimiser: torch.optim.Adam(lr) + LinearLR(start_factor=1, end_factor, total_iters) of
  *      train/run_composite.py:209-215, 307-308, as one launch over up to NCA_ADAM_MAX_SEG flat buffers.

@@ -77,6 +77,8 @@ SYMBOLS = {
     "nca_loss_fwd_bwd": (C.c_int, [C.POINTER(NcaLoss), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "nca_fine_depths_workspace": (_I64, [_I64]),
     "nca_fine_depths": (C.c_int, [_I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _I64, _P]),
+    "nca_fine_weight_max": (C.c_int, [_I64, _I32, _P, _P, _P, _P, _I64, _P]),
+    "nca_fine_depths_given_max": (C.c_int, [_I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _P]),
     "nca_adam_step": (C.c_int, [C.POINTER(NcaAdam), _I32, C.POINTER(_I64), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P),
                                 _P, _P]),
     "nca_timing_enable": (C.c_int, [_I32]),
@@ -97,7 +99,7 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.nca_abi_version() != 3:
+        if handle.nca_abi_version() != 4:
             raise NcaError("libnerfca_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -915,15 +915,50 @@ extern "C" int64_t nca_fine_depths_workspace(int64_t R) {
     return align_up((nca_fine_partials(R) + 1) * (int64_t)sizeof(float), 256);
 }
 
-extern "C" int nca_fine_depths(int64_t R, int32_t S, int32_t n_fine, const float* sig_s, const float* sig_d, const float* z,
-                               const float* u, float* z_all, void* work, int64_t work_bytes, void* stream) {
+static int fine_check(int64_t R, int32_t S, int32_t n_fine) {
     if (R <= 0) return fail(NCA_E_INVALID, "empty ray batch");
     if (S < 3) return fail(NCA_E_INVALID, "fine sampling needs at least 3 coarse samples per ray (got %d)", S);
     if (n_fine < 1) return fail(NCA_E_INVALID, "n_fine must be positive");
-    if (!sig_s || !z || !u || !z_all) return fail(NCA_E_INVALID, "a pointer is NULL");
     int npad = 64;
     while (npad < n_fine) npad <<= 1;
     if (4 * (int64_t)((S - 1) + npad + S) * 4 > 160 * 1024) return fail(NCA_E_UNSUPPORTED, "S + n_fine too large for the LDS-resident sampler");
+    return NCA_OK;
+}
+
+extern "C" int nca_fine_weight_max(int64_t R, int32_t S, const float* sig_s, const float* sig_d, float* wmax, void* work, int64_t work_bytes,
+                                   void* stream) {
+    const int rc = fine_check(R, S, 1);
+    if (rc != NCA_OK) return rc;
+    if (!sig_s || !wmax) return fail(NCA_E_INVALID, "a pointer is NULL");
+    const int64_t need = nca_fine_depths_workspace(R);
+    if (!work || work_bytes < need) return fail(NCA_E_WORKSPACE, "fine-depth workspace %lld < %lld bytes", (long long)work_bytes, (long long)need);
+    NcaFineArgs a{};
+    a.R = R; a.S = S; a.n_fine = 1;
+    a.sig_s = sig_s; a.sig_d = sig_d;
+    a.partial_max = static_cast<float*>(work);
+    a.jmax = wmax;
+    HIPCHK(nca_launch_fine_max(a, (hipStream_t)stream));
+    return NCA_OK;
+}
+
+extern "C" int nca_fine_depths_given_max(int64_t R, int32_t S, int32_t n_fine, const float* sig_s, const float* sig_d, const float* z,
+                                         const float* u, const float* wmax, float* z_all, void* stream) {
+    const int rc = fine_check(R, S, n_fine);
+    if (rc != NCA_OK) return rc;
+    if (!sig_s || !z || !u || !z_all || !wmax) return fail(NCA_E_INVALID, "a pointer is NULL");
+    NcaFineArgs a{};
+    a.R = R; a.S = S; a.n_fine = n_fine;
+    a.sig_s = sig_s; a.sig_d = sig_d; a.z = z; a.u = u; a.z_all = z_all;
+    a.jmax = const_cast<float*>(wmax);
+    HIPCHK(nca_launch_fine_sample(a, (hipStream_t)stream));
+    return NCA_OK;
+}
+
+extern "C" int nca_fine_depths(int64_t R, int32_t S, int32_t n_fine, const float* sig_s, const float* sig_d, const float* z,
+                               const float* u, float* z_all, void* work, int64_t work_bytes, void* stream) {
+    const int rc = fine_check(R, S, n_fine);
+    if (rc != NCA_OK) return rc;
+    if (!sig_s || !z || !u || !z_all) return fail(NCA_E_INVALID, "a pointer is NULL");
     const int64_t need = nca_fine_depths_workspace(R);
     if (!work || work_bytes < need) return fail(NCA_E_WORKSPACE, "fine-depth workspace %lld < %lld bytes", (long long)work_bytes, (long long)need);
     NcaFineArgs a{};

@@ -180,6 +180,8 @@ struct NcaFineArgs {
     float* jmax;          // [1]
 };
 hipError_t nca_launch_fine(const NcaFineArgs& a, hipStream_t st);
+hipError_t nca_launch_fine_max(const NcaFineArgs& a, hipStream_t st);
+hipError_t nca_launch_fine_sample(const NcaFineArgs& a, hipStream_t st);
 int64_t nca_fine_partials(int64_t R);
 int64_t nca_loss_partials_bytes(int64_t R);
 

@@ -439,14 +439,24 @@ __global__ __launch_bounds__(LOSS_NT) void nca_fine_sample_k(const NcaFineArgs a
 
 int64_t nca_fine_partials(int64_t R) { return (R + LOSS_WAVES - 1) / LOSS_WAVES; }
 
-hipError_t nca_launch_fine(const NcaFineArgs& a, hipStream_t st) {
+// stage 1: batch-wide maximum of the density jumps -> *a.jmax;  stage 2: sampling with the maximum found at a.jmax
+// (a caller that shards the batch over ranks all-reduces MAX between the two)
+hipError_t nca_launch_fine_max(const NcaFineArgs& a, hipStream_t st) {
+    const int nblocks = (int)nca_fine_partials(a.R);
+    hipLaunchKernelGGL(nca_fine_max_k, dim3(nblocks), dim3(LOSS_NT), 0, st, a);
+    hipLaunchKernelGGL(nca_fine_max_finish_k, dim3(1), dim3(256), 0, st, a, nblocks);
+    return hipGetLastError();
+}
+hipError_t nca_launch_fine_sample(const NcaFineArgs& a, hipStream_t st) {
     const int nblocks = (int)nca_fine_partials(a.R);
     int npad = 64;
     while (npad < a.n_fine) npad <<= 1;
     const size_t lds = (size_t)LOSS_WAVES * ((a.S - 1) + npad + a.S) * sizeof(float);
-    hipLaunchKernelGGL(nca_fine_max_k, dim3(nblocks), dim3(LOSS_NT), 0, st, a);
-    hipLaunchKernelGGL(nca_fine_max_finish_k, dim3(1), dim3(256), 0, st, a, nblocks);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_fine_sample_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(nca_fine_sample_k, dim3(nblocks), dim3(LOSS_NT), lds, st, a, npad);
     return hipGetLastError();
+}
+hipError_t nca_launch_fine(const NcaFineArgs& a, hipStream_t st) {
+    hipError_t e = nca_launch_fine_max(a, st);
+    return e != hipSuccess ? e : nca_launch_fine_sample(a, st);
 }

@@ -324,11 +324,15 @@ def fused_losses(pix, gt, wpix, sig_s, sig_d, dists, run_args, weights, inv_R=No
     return terms, g_pix, g_s, g_d
 
 
-def fine_depths(sig_s: torch.Tensor, sig_d: Optional[torch.Tensor], z: torch.Tensor, u: torch.Tensor) -> torch.Tensor:
+def fine_depths(sig_s: torch.Tensor, sig_d: Optional[torch.Tensor], z: torch.Tensor, u: torch.Tensor, reduce_max=None) -> torch.Tensor:
     """The sampling half of the hierarchical pass (model_helpers.py:131-148 + sample_pdf): returns the merged, sorted
     depths f32[R, S + n_fine] for coarse fields ``sig_*`` f32[R, S], the shared coarse depths ``z`` f32[S] and the
-    uniform draws ``u`` f32[R, n_fine].  One HIP launch sequence; no gradient flows through the depths (the reference
-    detaches the coarse depths and the weights only steer where samples go)."""
+    uniform draws ``u`` f32[R, n_fine].  The depths are constants of the step here (no gradient flows through them; see
+    the deviation note in train/model_helpers.obtain_train_predictions_iter).
+
+    ``reduce_max``: for a batch sharded over ranks.  The weights are normalised by the maximum over the WHOLE batch
+    (model_helpers.py:139), so the kernel sequence is split: this rank's maximum lands in a device scalar, ``reduce_max``
+    (e.g. ``lambda t: dist.all_reduce(t, op=dist.ReduceOp.MAX)``) makes it global in place, and sampling uses the result."""
     _require_cuda(sig_s, "sigma")
     dev = sig_s.device
     R, S = sig_s.shape
@@ -343,7 +347,13 @@ def fine_depths(sig_s: torch.Tensor, sig_d: Optional[torch.Tensor], z: torch.Ten
     lib = _capi.lib()
     wbytes = check(lib.nca_fine_depths_workspace(R))
     work = torch.empty(wbytes, dtype=torch.uint8, device=dev)
-    check(lib.nca_fine_depths(R, S, n_fine, ptr(ss), ptr(sd), ptr(zz), ptr(uu), ptr(out), ptr(work), wbytes, _stream()))
+    if reduce_max is None:
+        check(lib.nca_fine_depths(R, S, n_fine, ptr(ss), ptr(sd), ptr(zz), ptr(uu), ptr(out), ptr(work), wbytes, _stream()))
+        return out
+    wmax = torch.zeros(1, dtype=torch.float32, device=dev)
+    check(lib.nca_fine_weight_max(R, S, ptr(ss), ptr(sd), ptr(wmax), ptr(work), wbytes, _stream()))
+    reduce_max(wmax)
+    check(lib.nca_fine_depths_given_max(R, S, n_fine, ptr(ss), ptr(sd), ptr(zz), ptr(uu), ptr(wmax), ptr(out), _stream()))
     return out
 
 

@@ -24,6 +24,7 @@ from . import model_helpers as MH
 class TrainConfig:
     """The hot-path keys of train/composite.txt (defaults = that file)."""
     depth_samples_per_ray_coarse: int = 500
+    depth_samples_per_ray_fine: int = 0            # composite.txt:26; > 0 needs the fine model pair (run_composite.py:194-207)
     img_sample_size: int = 1024
     batch_size: int = 32768
     lr: float = 1e-3
@@ -57,17 +58,25 @@ class TrainConfig:
 
 class CompositeTrainer:
     def __init__(self, cfg: TrainConfig, static_model, temp_model, data, device, rank: int = 0, world: int = 1,
-                 seed: int = 0, render: Optional[Callable] = None, fused_adam: Optional[bool] = None, fused_loss: Optional[bool] = None):
+                 seed: int = 0, render: Optional[Callable] = None, fused_adam: Optional[bool] = None, fused_loss: Optional[bool] = None,
+                 static_model_fine=None, temp_model_fine=None, fine_sampler: Optional[Callable] = None):
         self.cfg, self.s, self.t, self.data, self.device = cfg, static_model, temp_model, data, device
+        self.s_fine, self.t_fine = static_model_fine, temp_model_fine
+        self.n_fine = int(cfg.depth_samples_per_ray_fine)
+        if self.n_fine > 0 and (static_model_fine is None or temp_model_fine is None):
+            raise ValueError("depth_samples_per_ray_fine > 0 needs static_model_fine and temp_model_fine (run_composite.py:194-205)")
+        self.fine_sampler = fine_sampler or MH._fused.fine_depths      # (sig_s, sig_d, z, u, reduce_max=) -> z_all[R, S + n_fine]
         self.rank, self.world, self.seed = rank, world, seed
         on_cuda = device.type == "cuda" if isinstance(device, torch.device) else str(device).startswith("cuda")
         if fused_loss is None:             # default on the GPU: the autograd-free step with the HIP loss kernel (step_fused);
             fused_loss = on_cuda           # fused_loss=False keeps the reference's torch loss functions under autograd
-        self.fused_loss = bool(fused_loss) and render is None
+        self.fused_loss = bool(fused_loss) and render is None and self.n_fine == 0   # the fine pass runs under autograd (step)
         self.always_allreduce = False      # all-reduce even with one rank (exercises the collective path)
         self._dev_gen = None
         self.render = render or MH._fused.render_rays
         self.params = list(temp_model.parameters()) + list(static_model.parameters())   # run_composite.py:192
+        if self.n_fine > 0:
+            self.params += list(temp_model_fine.parameters()) + list(static_model_fine.parameters())             # :207
         kw = {}
         if fused_adam is None:
             fused_adam = device.type == "cuda" if isinstance(device, torch.device) else str(device).startswith("cuda")
@@ -82,8 +91,10 @@ class CompositeTrainer:
     # -- per-step host work (identical on every rank) ------------------------------------------
     def update_windows(self, n_iter: int) -> None:
         c = self.cfg
-        for m, enc, steps in ((self.s, c.static_pos_enc, c.static_pos_enc_window_decay_steps),
-                              (self.t, c.temp_pos_enc, c.temp_pos_enc_window_decay_steps)):
+        nets = [(self.s, c.static_pos_enc, c.static_pos_enc_window_decay_steps), (self.t, c.temp_pos_enc, c.temp_pos_enc_window_decay_steps)]
+        if self.n_fine > 0:                # run_composite.py:241-247
+            nets += [(self.s_fine, c.static_pos_enc, c.static_pos_enc_window_decay_steps), (self.t_fine, c.temp_pos_enc, c.temp_pos_enc_window_decay_steps)]
+        for m, enc, steps in nets:
             if enc == "nerfies_windowed":
                 m.update_windowed_alpha(n_iter, steps)
             elif enc == "free_windowed":
@@ -123,6 +134,12 @@ class CompositeTrainer:
         g = torch.Generator().manual_seed(self.seed * 1000003 + n_iter)
         return torch.rand(self.depth.shape, generator=g)
 
+    def draw_fine_u(self, n_iter: int) -> torch.Tensor:
+        """sample_pdf's uniform draw for the GLOBAL batch (model_helpers.py:170), from a per-step seeded CPU generator so
+        that every rank draws the same table and takes its rows."""
+        g = torch.Generator().manual_seed(self.seed * 1000003 + n_iter + 500009)
+        return torch.rand((self.cfg.img_sample_size, self.n_fine), generator=g)
+
     def loss_weights(self, n_iter: int):
         c = self.cfg
         return (linear_param_decay(n_iter, c.favor_s_weight_start, c.favor_s_weight_end, c.hyperparam_decay_steps, c.favor_s_weight_delay_steps),
@@ -149,6 +166,24 @@ class CompositeTrainer:
         fav_w, ent_w, occ_w, l1_w = self.loss_weights(n_iter)
         favor, d_ent, occl, l1, l2 = terms[3], terms[6], terms[8], terms[9], terms[10]
         loss = pixel + fav_w * favor * share + ent_w * d_ent * share + occ_w * occl * share + l1_w * l2 + l1_w * l1
+        if self.n_fine > 0:
+            # hierarchical pass (model_helpers.py:131-158, run_composite.py:294-301).  The weights are normalised by the
+            # maximum over the GLOBAL batch (:139) -> MAX all-reduce inside the sampler; the fine rendering takes its
+            # interval lengths from ray 0 of the GLOBAL batch (:150) -> broadcast from rank 0.  The sampled depths are
+            # constants of the step (see the note in model_helpers.obtain_train_predictions_iter).
+            sharded = self.world > 1
+            red = (lambda t: dist.all_reduce(t, op=dist.ReduceOp.MAX)) if sharded else None
+            u = self.draw_fine_u(n_iter)[lo:hi].to(self.device)
+            z_all = self.fine_sampler(sig_s.detach(), sig_d.detach(), z, u, reduce_max=red)
+            z0 = z_all[0, :].clone()
+            if sharded:
+                dist.broadcast(z0, src=0)
+            dists_f = MH._interval_lengths(z0, d)
+            pix_f, sig_sf, sig_df = self.render(self.s_fine, self.t_fine, o, d, phases, self.I0[: hi - lo], z_all, dists_f,
+                                                act=c.output_activation)
+            pixel_f = MH.weighted_MSELoss()(pix_f, gt, torch.ones_like(w)).mean() * share       # weighted_pixs_ones (:297)
+            tf = LS.all_terms(sig_sf, sig_df, dists_f, w, c)
+            loss = loss + pixel_f + fav_w * tf[3] * share + ent_w * tf[6] * share + occ_w * tf[8] * share + l1_w * tf[10] + l1_w * tf[9]
         return loss, pixel, terms
 
     def step(self, n_iter: int):
@@ -170,6 +205,8 @@ class CompositeTrainer:
         """Same step without an autograd graph: fused forward -> fused loss kernel (values + d loss/d(pix,
         sigma)) -> fused backward -> (all-reduce) -> Adam.  Returns (loss, pixel, terms f64[13]) on device;
         the entries of ``terms`` are this rank's share of the global value (they sum over ranks)."""
+        if self.n_fine > 0:
+            raise NotImplementedError("step_fused covers the coarse pass only; use step() with depth_samples_per_ray_fine > 0")
         from ..fused import _RayBatch, fused_losses, render_backward_raw, render_forward_raw
         c = self.cfg
         self.update_windows(n_iter)
@@ -327,6 +364,8 @@ class CompositeTrainer:
         (its own moment buffers: do not interleave with ``step``/``step_fused`` in one run).  Per step the host only
         draws the ray ids, fills one pinned record and launches the graph.  Returns (loss, pixel, terms) as
         ``step_fused`` does; the tensors are overwritten by the next call."""
+        if self.n_fine > 0:
+            raise NotImplementedError("the graph-replayed step covers the coarse pass only; use step() with depth_samples_per_ray_fine > 0")
         self.update_windows(n_iter)
         if getattr(self, "_graphs", None) is None:
             self._graph_setup()

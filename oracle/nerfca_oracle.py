@@ -330,7 +330,8 @@ def predict_iter(ps, spec_s, win_s, pd, spec_d, win_d, origins, directions, phas
     """obtain_train_predictions_iter minus the RNG draws (model_helpers.py:115-160).
 
     ``phases`` is [R, S] (run_composite.py:265).  ``fine`` is None or a dict with keys
-    ps, spec_s, win_s, pd, spec_d, win_d, n_fine, u (the injected sample_pdf draw [R, n_fine]).
+    ps, spec_s, win_s, pd, spec_d, win_d, n_fine, u (the injected sample_pdf draw [R, n_fine]) and optionally
+    detach_depths (see below).
     Returns the reference's 8-tuple.
     """
     R, S = origins.shape[0], z_jit.shape[0]
@@ -351,6 +352,12 @@ def predict_iter(ps, spec_s, win_s, pd, spec_d, win_d, origins, directions, phas
         mid = 0.5 * (zb[..., 1:] + zb[..., :-1])
         zf = sample_pdf(mid, w[..., 1:-1], fine["u"])
         z_all, _ = torch.sort(torch.cat([zf, zb.detach()], -1), -1)
+        if fine.get("z_all") is not None:     # test hook: depths sampled elsewhere (constants), e.g. by the kernel under test
+            z_all = fine["z_all"]
+        if fine.get("detach_depths", False):
+            # NOT the reference's behaviour (its autograd differentiates through sample_pdf, the sort and the query points
+            # into the coarse nets): only there to quantify the drop-in's documented deviation in the tests.
+            z_all = z_all.detach()
         pts_f = query_points(origins, directions, z_all)
         z0 = z_all[0, :]  # dists from ray 0 only (model_helpers.py:150)
         ph_f = phases[:, 0, None].repeat(1, tot).flatten()

@@ -36,8 +36,28 @@ def oracle_render(s, t, o, d, ph, I0, z, dists, act="softplus", single=False, sc
     raw_s = O.static_forward(dict(s.named_parameters()), spec_of(s, 0), pts, window(s)).reshape(R, S, -1)
     phs = ph.reshape(R, -1)[:, :1].repeat(1, S).flatten()
     raw_d = O.dynamic_forward(dict(t.named_parameters()), spec_of(t, t.num_time_dim), pts, phs, window(t)).reshape(R, S, -1)
-    pix, a, b, _ = O.composite(raw_s, raw_d, I0, d, z, act)
-    return pix, a, b
+    if z.dim() == 1:
+        pix, a, b, _ = O.composite(raw_s, raw_d, I0, d, z, act)
+        return pix, a, b
+    # fine pass: per-ray depths, interval lengths of (global) ray 0 as handed over (model_helpers.py:150)
+    f = O.activation(act)
+    a, b = f(raw_s[..., -1]) * scale, f(raw_d[..., -1]) * scale
+    return I0 - ((a + b) * dists).sum(dim=-1), a, b
+
+
+def oracle_fine_sampler(sig_s, sig_d, z, u, reduce_max=None):
+    """fused.fine_depths signature with the oracle's arithmetic (model_helpers.py:131-148, 162-187)."""
+    from oracle import nerfca_oracle as O
+    R = sig_s.shape[0]
+    tsum = sig_s + sig_d
+    w = torch.cat([torch.full((R, 1), 1e-10), (tsum[:, 1:] - tsum[:, :-1]).abs()], -1)
+    wmax = w.max().reshape(1).clone()
+    if reduce_max is not None:
+        reduce_max(wmax)
+    w = w / wmax
+    zb = z[None, :].repeat(R, 1)
+    mid = 0.5 * (zb[:, 1:] + zb[:, :-1])
+    return torch.sort(torch.cat([O.sample_pdf(mid, w[:, 1:-1], u), zb], -1), -1)[0]
 
 
 def build(seed=0):
@@ -60,9 +80,18 @@ def build(seed=0):
     return cfg, s, t, data, dev, CompositeTrainer
 
 
-def run_steps(rank, world, n_steps=2):
+def run_steps(rank, world, n_steps=2, n_fine=0):
     cfg, s, t, data, dev, CompositeTrainer = build()
-    tr = CompositeTrainer(cfg, s, t, data, dev, rank=rank, world=world, seed=7, render=oracle_render, fused_adam=False)
+    kw = {}
+    if n_fine:
+        from nerfca_amd import synthetic
+        from nerfca_amd.model.CPPN import CPPN
+        from nerfca_amd.model.Temporal import Temporal
+        cfg.depth_samples_per_ray_fine = n_fine
+        sdef, tdef = synthetic.net_definitions(dev, F=32, early=1, L=4, T=4)
+        torch.manual_seed(11)
+        kw = dict(static_model_fine=CPPN(sdef), temp_model_fine=Temporal(tdef), fine_sampler=oracle_fine_sampler)
+    tr = CompositeTrainer(cfg, s, t, data, dev, rank=rank, world=world, seed=7, render=oracle_render, fused_adam=False, **kw)
     grads = None
     for it in range(n_steps):
         tr.step(100 + it)
@@ -72,13 +101,13 @@ def run_steps(rank, world, n_steps=2):
     return grads, params
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, n_fine=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        g, p = run_steps(rank, world)
+        g, p = run_steps(rank, world, n_fine=n_fine)
         torch.save({"g": g, "p": p}, os.path.join(outdir, f"rank{rank}.pt"))
     finally:
         dist.destroy_process_group()
@@ -100,6 +129,23 @@ def test_two_rank_step_equals_one_rank_step(tmp_path):
     # every rank holds the same all-reduced gradient and the same parameters
     assert torch.equal(r0["g"], r1["g"]) and torch.equal(r0["p"], r1["p"])
     # ... and they equal the single-process step up to f32 reduction order
+    gerr = float((r0["g"] - g1).abs().max() / g1.abs().max())
+    perr = float((r0["p"] - p1).abs().max() / p1.abs().max())
+    assert gerr < 1e-5, gerr
+    assert perr < 1e-5, perr
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_step_with_fine_pass_equals_one_rank_step(tmp_path):
+    """The hierarchical pass under sharding: the weight maximum is all-reduced (MAX), the interval lengths come from ray 0
+    of the GLOBAL batch (broadcast), the uniform draws are rows of one global table; four nets in the optimiser."""
+    torch.set_num_threads(2)
+    g1, p1 = run_steps(0, 1, n_fine=6)
+    assert g1.numel() == p1.numel() and float(g1.abs().max()) > 0
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), 6), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "rank0.pt")
+    r1 = torch.load(tmp_path / "rank1.pt")
+    assert torch.equal(r0["g"], r1["g"]) and torch.equal(r0["p"], r1["p"])
     gerr = float((r0["g"] - g1).abs().max() / g1.abs().max())
     perr = float((r0["p"] - p1).abs().max() / p1.abs().max())
     assert gerr < 1e-5, gerr

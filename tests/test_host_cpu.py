@@ -34,7 +34,8 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in nerfca_hip.h but not exported"
     assert declared == set(_capi.SYMBOLS), "ctypes table and header disagree"
-    assert _capi.lib().nca_abi_version() == 3
+    import re as _re
+    assert _capi.lib().nca_abi_version() == int(_re.search(r"#define NCA_ABI_VERSION (\d+)", header).group(1))
 
 
 def test_param_count_and_packed_size_match_reference_nets():
