@@ -114,15 +114,17 @@ def obtain_train_predictions_static(static_model, batch_origins, batch_direction
 
 def obtain_train_predictions_iter(static_model_coarse, temp_model_coarse, static_model_fine, temp_model_fine, batch_origins,
                                   batch_directions, batch_phases, batch_initial_intensities, depth_values, output_activation,
-                                  batch_size, depth_samples_per_ray_fine, device, t_rand=None, u_fine=None):
+                                  batch_size, depth_samples_per_ray_fine, device, t_rand=None, u_fine=None, reduce_max=None):
     """model_helpers.py:115-160 -> the reference's 8-tuple; the coarse pass is one fused launch.
 
     Fine pass (``depth_samples_per_ray_fine > 0``, off in the reference's configs): all eight outputs equal the reference's
     (goldens with injected draws).  KNOWN DEVIATION in the backward: the reference never detaches the sampled depths, so its
     autograd also differentiates the fine losses through ``sample_pdf`` / ``sort`` / the query points / the positional
     encoding back into the COARSE nets (and through the ray-0 ``dists``).  Here the fine depths are constants of the step, as
-    in NeRF's own hierarchical sampling: coarse nets learn from the coarse terms, fine nets from the fine terms.  ``u_fine``
-    injects the uniform draw of ``sample_pdf``."""
+    in NeRF's own hierarchical sampling: coarse nets learn from the coarse terms, fine nets from the fine terms (fine-net
+    gradients equal the reference's; the omitted coarse-net term was measured at ~1e4 times the regular coarse gradient,
+    tests/test_hip_parity.py::test_trainer_with_fine_pass_vs_oracle).  ``u_fine`` injects the uniform draw of ``sample_pdf``;
+    ``reduce_max`` (ray-sharded batches) makes the batch-wide weight maximum global, see ``fused.fine_depths``."""
     z = randomize_depth(depth_values, device, t_rand)
     dists_c = _interval_lengths(z, batch_directions)
     pix_c, sig_s_c, sig_d_c = _fused.render_rays(static_model_coarse, temp_model_coarse, batch_origins, batch_directions, batch_phases,
@@ -133,7 +135,7 @@ def obtain_train_predictions_iter(static_model_coarse, temp_model_coarse, static
         if u_fine is None:                                         # the draw comes from the CPU generator, as in the reference
             u_fine = torch.rand(R, depth_samples_per_ray_fine)
         # weights (batch-wide max, :139), sample_pdf and sort(cat[fine, coarse]) in one HIP pass per ray
-        z_all = _fused.fine_depths(sig_s_c, sig_d_c, z, u_fine)
+        z_all = _fused.fine_depths(sig_s_c, sig_d_c, z, u_fine, reduce_max=reduce_max)
         z0 = z_all[0, :]                                           # dists of ray 0 for every ray (model_helpers.py:150)
         dists_f = _interval_lengths(z0, batch_directions)
         phase_per_ray = batch_phases[:, 0] if batch_phases.dim() > 1 else batch_phases
