@@ -121,7 +121,10 @@ static int check_prec(int32_t prec) {
 static int layout_of(const NcaNet* net, NcaLayout* y, int32_t prec = NCA_PREC_F32) {
     if (!net) return fail(NCA_E_INVALID, "net is NULL");
     const char* why = "";
-    int rc = prec == NCA_PREC_BF16 ? nca_build_layout_bf16(*net, y, &why) : nca_build_layout(*net, y, &why);
+    // f32 path: hidden-width contractions on the bf16 matrix cores from exact 3-way splits (NCA_F32_CHAIN=plain: the
+    // v_mfma_f32_32x32x2_f32 loops, A/B switch)
+    static const bool x3 = !(getenv("NCA_F32_CHAIN") != nullptr && getenv("NCA_F32_CHAIN")[0] == 'p');
+    int rc = prec == NCA_PREC_BF16 ? nca_build_layout_bf16(*net, y, &why) : nca_build_layout(*net, y, &why, x3);
     if (rc != NCA_OK) return fail(rc, "%s", why);
     return NCA_OK;
 }
@@ -202,6 +205,10 @@ static int build_stages(NcaFusedArgs* a, const NetBind* binds, bool bwd, int sto
             for (int j = y.NL - 1; j >= 1; --j) {
                 int rc = add_stage(a, binds[n].packed, y.layer[j].imgT_off, y.layer[j].imgT_bytes);
                 if (rc) return rc;
+                if (y.layer[j].imgT2_bytes) {          // x3: second sub-stage of the transposed image
+                    rc = add_stage(a, binds[n].packed, y.layer[j].imgT2_off, y.layer[j].imgT2_bytes);
+                    if (rc) return rc;
+                }
             }
     }
     return NCA_OK;
@@ -585,6 +592,9 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
                 // f32 images: [k-steps x 64 x MT floats][bias 2 MT 16][Wo 2 MT 16][bo]; a last layer that is a skip
                 // layer keeps [Wo | bo] behind the k-steps of its second (hidden-part) image
                 if (ll.kind == NCA_IN_SKIP) a.net[n].wo_src = reinterpret_cast<const float*>(pk + ll.img2_off) + (int64_t)(ll.ksteps - ll.ksteps_enc) * 64 * y.MT;
+                else if (y.x3 && ll.kind == NCA_IN_HID)   // x3 image: [Wo | bo] follows the fragments of the LAST sub-stage (after the bias if there is only one)
+                    a.net[n].wo_src = ll.img2_bytes ? reinterpret_cast<const float*>(pk + ll.img2_off + nca_x3_sub_bytes(y.F))
+                                                    : reinterpret_cast<const float*>(pk + ll.img_off + nca_x3_sub_bytes(y.F)) + 2 * y.MT * 16;
                 else a.net[n].wo_src = reinterpret_cast<const float*>(pk + ll.img_off) + (int64_t)ll.ksteps * 64 * y.MT + 2 * y.MT * 16;
             }
         }

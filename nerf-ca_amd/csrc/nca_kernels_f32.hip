@@ -26,6 +26,29 @@ typedef float f32x4e __attribute__((ext_vector_type(4)));
 #define NCA_HALF_PI_D 1.57079632679489661923
 #define NCA_TWO_PI_F 6.283185482025146484375f      // fl32(2 * pi)
 
+// x3 split (see the x3 section below): exact three-way bf16 split of f32 values
+typedef float x3_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 x3_bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 x3_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned x3_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void x3_split_pair(float lo, float hi, unsigned& p0, unsigned& p1, unsigned& p2) {
+    const x3_f32x2 v = {lo, hi};
+    const x3_bf16x2 q1 = __builtin_convertvector(v, x3_bf16x2);
+    const x3_f32x2 r1 = v - __builtin_convertvector(q1, x3_f32x2);
+    const x3_bf16x2 q2 = __builtin_convertvector(r1, x3_bf16x2);
+    const x3_f32x2 r2 = r1 - __builtin_convertvector(q2, x3_f32x2);
+    const x3_bf16x2 q3 = __builtin_convertvector(r2, x3_bf16x2);
+    p0 = __builtin_bit_cast(unsigned, q1);
+    p1 = __builtin_bit_cast(unsigned, q2);
+    p2 = __builtin_bit_cast(unsigned, q3);
+}
+// piece p (0..2) of one value, as the pack kernel needs it
+__device__ __forceinline__ unsigned x3_piece(float w, int p) {
+    unsigned a, b, c;
+    x3_split_pair(w, 0.f, a, b, c);
+    return (p == 0 ? a : (p == 1 ? b : c)) & 0xffffu;
+}
+
 // ------------------------------------------------------------------------------------------
 // pack
 // ------------------------------------------------------------------------------------------
@@ -56,6 +79,55 @@ __global__ void nca_pack_f32(NcaLayout y, const float* __restrict__ prm, float* 
                     }
                 }
             }
+            if (y.x3) {
+                // x3 images: A-fragment planes of bf16 pieces (nca_layout.hpp); a dword holds elements j = 2u, 2u + 1
+                const int KH = nca_x3_kh(y.F);                             // k-steps per sub-stage
+                const uint32_t nfr = 3u * y.MT * KH * 256u;                // dwords of fragments in a sub-stage
+                const uint32_t tailn = 2u * (uint32_t)y.MT * 16u;
+                bool done = false;
+                for (int sub = 0; sub < 2 && !done; ++sub) {
+                    for (int tr = 0; tr < 2 && !done; ++tr) {
+                        if (tr == 0 && l.kind != NCA_IN_HID) continue;     // forward images of encoded / skip layers stay f32
+                        if (tr == 1 && l.kind == NCA_IN_ENC) continue;
+                        const uint32_t base = tr ? (sub ? l.imgT2_off : l.imgT_off) : (sub ? l.img2_off : l.img_off);
+                        const uint32_t bytes = tr ? (sub ? l.imgT2_bytes : l.imgT_bytes) : (sub ? l.img2_bytes : l.img_bytes);
+                        if (!bytes || byte < base || byte >= base + bytes) continue;
+                        done = true;
+                        uint32_t q = (byte - base) / 4u;
+                        if (q < nfr) {
+                            const int pc = q / (y.MT * KH * 256), r = q % (y.MT * KH * 256);
+                            const int mm = r / (KH * 256), ks = sub * KH + (r / 256) % KH, ln = (r % 256) / 4, u = r % 4;
+                            const int o = 32 * mm + (ln & 31), h = ln >> 5;
+                            const int k0 = nca_x3_kidx(ks, h, 2 * u), k1 = nca_x3_kidx(ks, h, 2 * u + 1);
+                            float w0, w1;
+                            if (!tr) { w0 = prm[l.w_off + o * l.K + k0]; w1 = prm[l.w_off + o * l.K + k1]; }
+                            else {
+                                const int col0 = l.kind == NCA_IN_SKIP ? y.K0 : 0;
+                                w0 = prm[l.w_off + k0 * l.K + col0 + o]; w1 = prm[l.w_off + k1 * l.K + col0 + o];
+                            }
+                            v = __uint_as_float(x3_piece(w0, pc) | (x3_piece(w1, pc) << 16));
+                        } else if (!tr) {
+                            q -= nfr;
+                            const bool two = y.MT >= 2;
+                            // sub-stage 0: bias tail (then Wo, bo if the layer has ONE sub-stage and is the last); sub-stage 1: Wo, bo
+                            bool want_wo = false;
+                            if (sub == 0) {
+                                if (q < tailn) {
+                                    int i = q % 16, m = (q / 16) % y.MT, h = q / (16 * y.MT);
+                                    v = prm[l.b_off + 32 * m + nca_rho(i) + 4 * h];
+                                } else if (!two && j == y.NL - 1) { q -= tailn; want_wo = true; }
+                            } else if (j == y.NL - 1) want_wo = true;
+                            if (want_wo) {
+                                if (q < tailn) {
+                                    int i = q % 16, m = (q / 16) % y.MT, h = q / (16 * y.MT);
+                                    v = prm[y.wo_off + 32 * m + nca_rho(i) + 4 * h];
+                                } else if (q == tailn) v = prm[y.bo_off];
+                            }
+                        }
+                    }
+                }
+                if (done) continue;
+            }
             if (byte >= l.img_off && byte < l.img_off + l.img_bytes) {
                 uint32_t q = (byte - l.img_off) / 4u;
                 const uint32_t wcount = (uint32_t)(skip ? l.ksteps_enc : l.ksteps) * 64u * (uint32_t)y.MT;
@@ -85,7 +157,7 @@ __global__ void nca_pack_f32(NcaLayout y, const float* __restrict__ prm, float* 
                     }
                 }
             }
-            if (l.imgT_bytes && byte >= l.imgT_off && byte < l.imgT_off + l.imgT_bytes) {
+            if (!y.x3 && l.imgT_bytes && byte >= l.imgT_off && byte < l.imgT_off + l.imgT_bytes) {
                 uint32_t q = (byte - l.imgT_off) / 4u;
                 int m = q % y.MT, lane = (q / y.MT) % 64, s = q / (y.MT * 64);
                 int r = lane & 31, h = lane >> 5;
@@ -152,6 +224,58 @@ __device__ __forceinline__ double half_sum(double v) {
 __device__ __forceinline__ void store_quad(float* p, float a, float b, float c, float d) {
     const f32x4e v = {a, b, c, d};
     __builtin_nontemporal_store(v, reinterpret_cast<f32x4e*>(p));
+}
+
+
+// ------------------------------------------------------------------------------------------
+// x3: hidden-width contractions on the bf16 matrix cores with f32 accuracy (see nca_wgrad_f32x3 below for the
+// arithmetic: x = x1 + x2 + x3 exactly, six piece products of weight >= 2^-16, f32 accumulation).  Here the weights come
+// pre-split from the packed image (three bf16 A-fragment planes per sub-stage, nca_layout.hpp) and the activations are
+// split when they are packed into B fragments: registers 8 s + 2 u, + 1 of row tile t -> word u of k-step 2 t + s.
+// ------------------------------------------------------------------------------------------
+// B fragments of the k-steps [k0, k0 + KH): row tiles k0 / 2 .. of the previous layer's accumulators
+template <int MT, int KH>
+__device__ __forceinline__ void x3_split(const f32x16 (&h)[MT], int k0, x3_u32x4 (&B)[3][KH]) {
+#pragma unroll
+    for (int kk = 0; kk < KH; ++kk) {
+        const int t = (k0 + kk) >> 1, s2 = (k0 + kk) & 1;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            unsigned a, b, c;
+            x3_split_pair(h[t][8 * s2 + 2 * u], h[t][8 * s2 + 2 * u + 1], a, b, c);
+            B[0][kk][u] = a; B[1][kk][u] = b; B[2][kk][u] = c;
+        }
+    }
+}
+// one sub-stage (KH k-steps, all MT row tiles, two row tiles at a time): `sub` = the sub-stage image + lane * 16
+template <int MT, int KH>
+__device__ __forceinline__ void x3_rows(const char* __restrict__ sub, const x3_u32x4 (&B)[3][KH], f32x16 (&acc)[MT]) {
+    constexpr int RG = MT >= 2 ? 2 : 1;
+#pragma unroll
+    for (int m0 = 0; m0 < MT; m0 += RG) {
+#pragma unroll
+        for (int kk = 0; kk < KH; ++kk) {
+            x3_u32x4 A[3][RG];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int mm = 0; mm < RG; ++mm) A[p][mm] = *reinterpret_cast<const x3_u32x4*>(sub + ((p * MT + m0 + mm) * KH + kk) * 1024);
+            // small products first; consecutive MFMAs alternate accumulators
+#define X3_MMA(I, J)                                                                                                       \
+            _Pragma("unroll") for (int mm = 0; mm < RG; ++mm)                                                           \
+                acc[m0 + mm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(x3_bf16x8, A[I][mm]), __builtin_bit_cast(x3_bf16x8, B[J][kk]), acc[m0 + mm], 0, 0, 0);
+            X3_MMA(1, 1) X3_MMA(2, 0) X3_MMA(0, 2) X3_MMA(1, 0) X3_MMA(0, 1) X3_MMA(0, 0)
+#undef X3_MMA
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+template <int MT>
+__device__ __forceinline__ void x3_store_block(float* st, const f32x16 (&h)[MT]) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) store_quad(st + (m * 4 + g) * 256, h[m][4 * g], h[m][4 * g + 1], h[m][4 * g + 2], h[m][4 * g + 3]);
 }
 
 // Backward: the B operands are also what the weight-gradient kernel needs (a layer input H or an output gradient D), and
@@ -277,7 +401,7 @@ __device__ __forceinline__ void stage_publish_counted(bool stores_issued) {
 
 // Kernel modes as in the bf16 kernel (nca_kernels.hpp): 0 forward, 1 recompute backward (one scratch for H and D),
 // 2 forward that also stores the input block / layer inputs / ReLU masks / raw outputs, 3 backward from that store.
-template <int F, int MODE>
+template <int F, int MODE, bool X3>
 __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a) {
     constexpr bool BWD = MODE == NCA_KM_BWD || MODE == NCA_KM_BWD_STORED;
     constexpr bool STORE = MODE == NCA_KM_BWD || MODE == NCA_KM_FWD_STORE;
@@ -471,8 +595,10 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
                 const float* img = reinterpret_cast<const float*>(smem + cur * BUF);
                 const float* imgl = img + lane * MT;
                 // bias tail: behind the k-steps of this image (a skip layer's first image holds only its encoded part)
-                const float* tail = img + (l.kind == NCA_IN_SKIP ? l.ksteps_enc : l.ksteps) * 64 * MT;
-                const float* wo_tail = tail + 2 * MT * 16;     // Wo, bo (last layer); re-pointed for skip layers below
+                const bool x3h = X3 && l.kind == NCA_IN_HID;     // this layer's contraction runs on the bf16 matrix cores (x3)
+                constexpr int X3_SUB = 3 * MT * (MT >= 2 ? MT : 2 * MT) * 256;          // floats of fragments in an x3 sub-stage
+                const float* tail = img + (x3h ? X3_SUB : (l.kind == NCA_IN_SKIP ? l.ksteps_enc : l.ksteps) * 64 * MT);
+                const float* wo_tail = tail + 2 * MT * 16;     // Wo, bo (last layer); re-pointed for two-stage layers below
 
                 f32x16 acc[MT];
 #pragma unroll
@@ -511,6 +637,25 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
                     hidden_steps<MT>(img2 + lane * MT, hprev, acc, hf + (y.K0rows_pad + (jj - 1) * F) * 32, STORE && tvalid); // stores H_{jj-1}
                     wo_tail = img2 + (l.ksteps - l.ksteps_enc) * 64 * MT;
                     nsi_final = nsi2;
+                } else if (x3h) {
+                    constexpr int KH = MT >= 2 ? MT : 2 * MT;          // k-steps per sub-stage
+                    if (STORE && tvalid) x3_store_block<MT>(hf + (y.K0rows_pad + (jj - 1) * F) * 32, hprev);                  // H_{jj-1}
+                    x3_u32x4 Bf[3][KH];
+                    x3_split<MT, KH>(hprev, 0, Bf);
+                    x3_rows<MT, KH>(reinterpret_cast<const char*>(img) + lane * 16, Bf, acc);
+                    if (MT >= 2) {
+                        // second sub-stage (the other half of the k-steps): publish its image, prefetch the one after it
+                        stage_publish();
+                        cur ^= 1;
+                        si = nsi;
+                        const int nsi2 = (si + 1 == a.nstages) ? 0 : si + 1;
+                        stage_issue(a.stage[nsi2], smem + (cur ^ 1) * BUF, wave, lane);
+                        const float* img2 = reinterpret_cast<const float*>(smem + cur * BUF);
+                        x3_split<MT, KH>(hprev, KH, Bf);
+                        x3_rows<MT, KH>(reinterpret_cast<const char*>(img2) + lane * 16, Bf, acc);
+                        wo_tail = img2 + X3_SUB;
+                        nsi_final = nsi2;
+                    }
                 } else if (l.kind != NCA_IN_ENC) {
                     hidden_steps<MT>(imgl, hprev, acc, hf + (y.K0rows_pad + (jj - 1) * F) * 32, STORE && tvalid);          // stores H_{jj-1}
                 }
@@ -555,7 +700,8 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
                 }
 
                 // hidden layers of the storing modes: at least 4 MT stores (H_{jj-1}, inside the contraction) follow the DMA
-                if (STORE && l.kind == NCA_IN_HID) stage_publish_counted<4 * MT>(tvalid);
+                // (x3 layers of two sub-stages issued their last DMA AFTER those stores: plain wait)
+                if (STORE && l.kind == NCA_IN_HID && !(x3h && MT >= 2)) stage_publish_counted<4 * MT>(tvalid);
                 else stage_publish();
                 cur ^= 1;
                 si = nsi_final;
@@ -586,7 +732,25 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
                     f32x16 acc[MT];
 #pragma unroll
                     for (int m = 0; m < MT; ++m) acc[m] = (f32x16)(0.f);
-                    hidden_steps<MT>(imgl, hprev, acc, df + jj * F * 32, tvalid);         // stores D_jj
+                    int nsi_d = nsi;
+                    if (X3) {
+                        constexpr int KH = MT >= 2 ? MT : 2 * MT;
+                        if (tvalid) x3_store_block<MT>(df + jj * F * 32, hprev);                                                // D_jj
+                        x3_u32x4 Bf[3][KH];
+                        x3_split<MT, KH>(hprev, 0, Bf);
+                        x3_rows<MT, KH>(smem + cur * BUF + lane * 16, Bf, acc);
+                        if (MT >= 2) {
+                            stage_publish();
+                            cur ^= 1;
+                            si = nsi;
+                            nsi_d = (si + 1 == a.nstages) ? 0 : si + 1;
+                            stage_issue(a.stage[nsi_d], smem + (cur ^ 1) * BUF, wave, lane);
+                            x3_split<MT, KH>(hprev, KH, Bf);
+                            x3_rows<MT, KH>(smem + cur * BUF + lane * 16, Bf, acc);
+                        }
+                    } else {
+                        hidden_steps<MT>(imgl, hprev, acc, df + jj * F * 32, tvalid);         // stores D_jj
+                    }
                     // mask with the ReLU pattern of layer jj's input (= output of layer jj-1)
                     const float* hh = hf + (y.K0rows_pad + (jj - 1) * F) * 32;
                     asm volatile("" : "+v"(hh));
@@ -613,9 +777,10 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
                             for (int k = 0; k < 4; ++k) hprev[m][4 * q + k] = on[k] ? acc[m][4 * q + k] : 0.f;
                         }
                     }
-                    stage_publish_counted<4 * MT>(tvalid);        // D_jj stores
+                    if (X3 && MT >= 2) stage_publish();           // (the second sub-stage's DMA was issued after the D_jj stores)
+                    else stage_publish_counted<4 * MT>(tvalid);   // D_jj stores
                     cur ^= 1;
-                    si = nsi;
+                    si = nsi_d;
                 }
                 if (tvalid) {     // D_0 has no consumer in this kernel: stored here, drains under the next net / tile
                     float* dd = df;
@@ -1075,7 +1240,7 @@ __global__ void nca_pix_f32(int64_t R, int nchunk, const float* __restrict__ I0,
 // ------------------------------------------------------------------------------------------
 // launchers (called from nca_api.cpp)
 // ------------------------------------------------------------------------------------------
-template <int F, int MODE>
+template <int F, int MODE, bool X3>
 static hipError_t launch_fused_mode(const NcaFusedArgs& a_in, int grid, hipStream_t st) {
     constexpr bool bwd = MODE == NCA_KM_BWD || MODE == NCA_KM_BWD_STORED;
     NcaFusedArgs a = a_in;
@@ -1095,19 +1260,24 @@ static hipError_t launch_fused_mode(const NcaFusedArgs& a_in, int grid, hipStrea
         if (ml > 0 && lds + need <= 160 * 1024) { a.mask_layers = ml; lds += need; }
     }
     if (MODE == NCA_KM_BWD_STORED) lds += 2 * (2 * FusedCfg<F>::MT * 16 + 16) * sizeof(float);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_fused_f32<F, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((nca_fused_f32<F, MODE>), dim3(grid), dim3(NCA_NT), lds, st, a);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_fused_f32<F, MODE, X3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((nca_fused_f32<F, MODE, X3>), dim3(grid), dim3(NCA_NT), lds, st, a);
     return hipGetLastError();
+}
+template <int F, bool X3>
+static hipError_t launch_fused_x(const NcaFusedArgs& a, int kmode, int grid, hipStream_t st) {
+    switch (kmode) {
+        case NCA_KM_FWD: return launch_fused_mode<F, NCA_KM_FWD, X3>(a, grid, st);
+        case NCA_KM_BWD: return launch_fused_mode<F, NCA_KM_BWD, X3>(a, grid, st);
+        case NCA_KM_FWD_STORE: return launch_fused_mode<F, NCA_KM_FWD_STORE, X3>(a, grid, st);
+        case NCA_KM_BWD_STORED: return launch_fused_mode<F, NCA_KM_BWD_STORED, X3>(a, grid, st);
+    }
+    return hipErrorInvalidValue;
 }
 template <int F>
 static hipError_t launch_fused_t(const NcaFusedArgs& a, int kmode, int grid, hipStream_t st) {
-    switch (kmode) {
-        case NCA_KM_FWD: return launch_fused_mode<F, NCA_KM_FWD>(a, grid, st);
-        case NCA_KM_BWD: return launch_fused_mode<F, NCA_KM_BWD>(a, grid, st);
-        case NCA_KM_FWD_STORE: return launch_fused_mode<F, NCA_KM_FWD_STORE>(a, grid, st);
-        case NCA_KM_BWD_STORED: return launch_fused_mode<F, NCA_KM_BWD_STORED>(a, grid, st);
-    }
-    return hipErrorInvalidValue;
+    for (int n = 1; n < a.nnets; ++n) if (a.net[n].lay.x3 != a.net[0].lay.x3) return hipErrorInvalidValue;
+    return a.net[0].lay.x3 ? launch_fused_x<F, true>(a, kmode, grid, st) : launch_fused_x<F, false>(a, kmode, grid, st);
 }
 
 hipError_t nca_launch_fused_f32(int F, const NcaFusedArgs& a, int kmode, int grid, hipStream_t st) {

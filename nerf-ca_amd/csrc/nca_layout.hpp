@@ -37,7 +37,9 @@ struct NcaLayerL {
     uint32_t imgT_off;   // transposed image for dgrad (hidden part only); 0 bytes on layer 0
     uint32_t imgT_bytes;
     uint32_t img2_off;   // SKIP layers stream in two stages: `img` = encoded part + bias tail, `img2` = hidden part (+ Wo tail)
-    uint32_t img2_bytes;
+    uint32_t img2_bytes; // x3 hidden layers of width >= 64 likewise: `img` = first half of the k-steps + bias tail, `img2` = the rest (+ Wo tail)
+    uint32_t imgT2_off;  // x3: second half of the k-steps of the transposed image
+    uint32_t imgT2_bytes;
 };
 
 struct NcaLayout {
@@ -50,6 +52,8 @@ struct NcaLayout {
     int32_t K0rows_pad;         // rounded up to 32
     int32_t lat_off, wo_off, bo_off, n_params;
     uint32_t packed_bytes, max_img_bytes;
+    int32_t x3;                 // f32 path: hidden-width contractions on the bf16 matrix cores from exact 3-way bf16 splits (below)
+    int32_t reserved;
     NcaLayerL layer[NCA_MAX_LAYERS];
 };
 
@@ -84,12 +88,24 @@ NCA_HD inline void nca_enc_pair(const NcaLayout& y, int s, int* ia, int* ib) {
     *ib = (2 * u + 1 < y.T) ? y.Kenc + 2 * u + 1 : -1;
 }
 
+// x3 images (f32 path, hidden-width contractions): weights split EXACTLY into three bf16 pieces w = w1 + w2 + w3 and laid
+// out as A fragments of v_mfma_f32_32x32x16_bf16: [piece][row tile][k-step of the sub-stage][lane][8 bf16].  Lane l of
+// k-step ks holds output row 32 m + (l & 31) and, as element j, the input feature nca_x3_kidx(ks, l >> 5, j) -- the order
+// in which the previous layer's accumulator registers are packed into B fragments (registers 8 (ks & 1) + j of row tile
+// ks >> 1, rows rho(.) + 4 h).  A layer of width >= 64 streams as two sub-stages of HALF THE K-STEPS each (all row
+// tiles), so that an image (3 x 16 KiB + tail at width 128) fits the LDS double buffer and only half of the activations
+// have to sit split in registers at a time.
+NCA_HD inline int nca_x3_kidx(int ks, int h, int j) { return 32 * (ks >> 1) + nca_rho(8 * (ks & 1) + j) + 4 * h; }
+NCA_HD inline int nca_x3_kh(int F) { return F >= 64 ? F / 32 : F / 16; }           // k-steps per sub-stage
+NCA_HD inline uint32_t nca_x3_sub_bytes(int F) { return 3u * (uint32_t)(F / 32) * (uint32_t)nca_x3_kh(F) * 1024u; }
+
 // sizes of the f32 images
 NCA_HD inline uint32_t nca_img_w_bytes(int ksteps, int MT) { return (uint32_t)ksteps * 64u * (uint32_t)MT * 4u; }
 NCA_HD inline uint32_t nca_img_tail_bytes(int MT) { return 2u * (uint32_t)MT * 16u * 4u; }  // bias (or Wo) in accumulator order
 
-inline int nca_build_layout(const NcaNet& n, NcaLayout* out, const char** why) {
+inline int nca_build_layout(const NcaNet& n, NcaLayout* out, const char** why, bool x3 = false) {
     NcaLayout y{};
+    y.x3 = x3 ? 1 : 0;
     if (!(n.F == 32 || n.F == 64 || n.F == 128)) { *why = "num_filters must be 32, 64 or 128"; return NCA_E_UNSUPPORTED; }
     if (n.n_hidden < 0 || n.n_late < 0 || 1 + n.n_hidden + n.n_late > NCA_MAX_LAYERS) { *why = "too many layers"; return NCA_E_UNSUPPORTED; }
     if (n.T < 0 || n.T > 32 || (n.T > 0 && n.P <= 0) || n.P > 64) { *why = "num_time_dim must be in [0,32], phases in [1,64]"; return NCA_E_UNSUPPORTED; }
@@ -126,6 +142,15 @@ inline int nca_build_layout(const NcaNet& n, NcaLayout* out, const char** why) {
             l.img2_bytes = nca_img_w_bytes(l.ksteps - l.ksteps_enc, y.MT) + wo_tail;                       // hidden part (+ Wo, bo)
             boff += (l.img2_bytes + 1023u) & ~1023u;
             if (l.img2_bytes > maxb) maxb = l.img2_bytes;
+        } else if (x3 && l.kind == NCA_IN_HID) {
+            const uint32_t sub = nca_x3_sub_bytes(y.F);
+            const bool two = y.MT >= 2;
+            l.img_bytes = sub + nca_img_tail_bytes(y.MT) + (two ? 0u : wo_tail);                             // first half + bias
+            boff += (l.img_bytes + 1023u) & ~1023u;
+            l.img2_off = two ? boff : 0u;
+            l.img2_bytes = two ? sub + wo_tail : 0u;                                                         // second half (+ Wo, bo)
+            if (two) boff += (l.img2_bytes + 1023u) & ~1023u;
+            if (l.img2_bytes > maxb) maxb = l.img2_bytes;
         } else {
             l.img_bytes = nca_img_w_bytes(l.ksteps, y.MT) + nca_img_tail_bytes(y.MT) + wo_tail;
             boff += (l.img_bytes + 1023u) & ~1023u;   // images are DMA'd to LDS in 1 KiB pieces
@@ -137,8 +162,19 @@ inline int nca_build_layout(const NcaNet& n, NcaLayout* out, const char** why) {
         NcaLayerL& l = y.layer[j];
         if (l.kind == NCA_IN_ENC) { l.imgT_off = 0; l.imgT_bytes = 0; continue; }
         l.imgT_off = boff;
-        l.imgT_bytes = nca_img_w_bytes(y.F / 2, y.MT);
-        boff += (l.imgT_bytes + 1023u) & ~1023u;
+        l.imgT2_off = 0; l.imgT2_bytes = 0;
+        if (x3) {
+            l.imgT_bytes = nca_x3_sub_bytes(y.F);
+            boff += (l.imgT_bytes + 1023u) & ~1023u;
+            if (y.MT >= 2) {
+                l.imgT2_off = boff;
+                l.imgT2_bytes = nca_x3_sub_bytes(y.F);
+                boff += (l.imgT2_bytes + 1023u) & ~1023u;
+            }
+        } else {
+            l.imgT_bytes = nca_img_w_bytes(y.F / 2, y.MT);
+            boff += (l.imgT_bytes + 1023u) & ~1023u;
+        }
         if (l.imgT_bytes > maxb) maxb = l.imgT_bytes;
     }
     y.wo_off = off; off += y.F;

@@ -4,6 +4,8 @@ reference and against the CPU oracle on seeded inputs.
 Tolerance (BASELINE.json north_star): 1e-5 relative in fp32, measured per tensor as
 max|a-b| / max|b|; index bookkeeping exact.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -52,7 +54,9 @@ def grads_of(model):
 # ------------------------------------------------------------------------------------------
 def test_library_loaded():
     from nerfca_amd import _capi
-    assert _capi.lib().nca_abi_version() == 3
+    import re
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "nerfca_hip.h")).read()
+    assert _capi.lib().nca_abi_version() == int(re.search(r"#define NCA_ABI_VERSION (\d+)", header).group(1))
 
 
 @pytest.mark.parametrize("F,early", [(F, e) for F in (32, 64, 128) for e in (0, 4)])
