@@ -233,41 +233,42 @@ __device__ __forceinline__ void store_quad(float* p, float a, float b, float c, 
 // pre-split from the packed image (three bf16 A-fragment planes per sub-stage, nca_layout.hpp) and the activations are
 // split when they are packed into B fragments: registers 8 s + 2 u, + 1 of row tile t -> word u of k-step 2 t + s.
 // ------------------------------------------------------------------------------------------
-// B fragments of the k-steps [k0, k0 + KH): row tiles k0 / 2 .. of the previous layer's accumulators
-template <int MT, int KH>
-__device__ __forceinline__ void x3_split(const f32x16 (&h)[MT], int k0, x3_u32x4 (&B)[3][KH]) {
+// One sub-stage: k-steps [K0, K0 + KH) of the contraction for all MT row tiles.  `sub` = the sub-stage image + lane * 16.
+// The B fragments of ONE k-step are split out of the previous layer's accumulator registers (h) right before their use
+// (12 registers instead of 48 per half, and the split's VALU work is spread between the MFMAs); the A fragments of the
+// next (k-step, row-tile pair) are requested before the current MFMAs issue.
+template <int MT, int KH, int K0>
+__device__ __forceinline__ void x3_sub(const char* __restrict__ sub, const f32x16 (&h)[MT], f32x16 (&acc)[MT]) {
+    constexpr int RG = MT >= 2 ? 2 : 1, NG = MT / RG, NIT = KH * NG;
+    x3_u32x4 A[2][3][RG], B[3];
+    auto load = [&](int it, x3_u32x4 (&a)[3][RG]) {
+        const int kk = it / NG, m0 = (it % NG) * RG;
 #pragma unroll
-    for (int kk = 0; kk < KH; ++kk) {
-        const int t = (k0 + kk) >> 1, s2 = (k0 + kk) & 1;
+        for (int p = 0; p < 3; ++p)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            unsigned a, b, c;
-            x3_split_pair(h[t][8 * s2 + 2 * u], h[t][8 * s2 + 2 * u + 1], a, b, c);
-            B[0][kk][u] = a; B[1][kk][u] = b; B[2][kk][u] = c;
+            for (int mm = 0; mm < RG; ++mm) a[p][mm] = *reinterpret_cast<const x3_u32x4*>(sub + ((p * MT + m0 + mm) * KH + kk) * 1024);
+    };
+    load(0, A[0]);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int kk = it / NG, m0 = (it % NG) * RG;
+        if (it % NG == 0) {
+            const int t = (K0 + kk) >> 1, s2 = (K0 + kk) & 1;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                unsigned b0, b1, b2;
+                x3_split_pair(h[t][8 * s2 + 2 * u], h[t][8 * s2 + 2 * u + 1], b0, b1, b2);
+                B[0][u] = b0; B[1][u] = b1; B[2][u] = b2;
+            }
         }
-    }
-}
-// one sub-stage (KH k-steps, all MT row tiles, two row tiles at a time): `sub` = the sub-stage image + lane * 16
-template <int MT, int KH>
-__device__ __forceinline__ void x3_rows(const char* __restrict__ sub, const x3_u32x4 (&B)[3][KH], f32x16 (&acc)[MT]) {
-    constexpr int RG = MT >= 2 ? 2 : 1;
-#pragma unroll
-    for (int m0 = 0; m0 < MT; m0 += RG) {
-#pragma unroll
-        for (int kk = 0; kk < KH; ++kk) {
-            x3_u32x4 A[3][RG];
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-#pragma unroll
-                for (int mm = 0; mm < RG; ++mm) A[p][mm] = *reinterpret_cast<const x3_u32x4*>(sub + ((p * MT + m0 + mm) * KH + kk) * 1024);
-            // small products first; consecutive MFMAs alternate accumulators
+        if (it + 1 < NIT) load(it + 1, A[(it + 1) & 1]);
+        // small products first; consecutive MFMAs alternate accumulators
 #define X3_MMA(I, J)                                                                                                       \
-            _Pragma("unroll") for (int mm = 0; mm < RG; ++mm)                                                           \
-                acc[m0 + mm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(x3_bf16x8, A[I][mm]), __builtin_bit_cast(x3_bf16x8, B[J][kk]), acc[m0 + mm], 0, 0, 0);
-            X3_MMA(1, 1) X3_MMA(2, 0) X3_MMA(0, 2) X3_MMA(1, 0) X3_MMA(0, 1) X3_MMA(0, 0)
+        _Pragma("unroll") for (int mm = 0; mm < RG; ++mm)                                                               \
+            acc[m0 + mm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(x3_bf16x8, A[it & 1][I][mm]), __builtin_bit_cast(x3_bf16x8, B[J]), acc[m0 + mm], 0, 0, 0);
+        X3_MMA(1, 1) X3_MMA(2, 0) X3_MMA(0, 2) X3_MMA(1, 0) X3_MMA(0, 1) X3_MMA(0, 0)
 #undef X3_MMA
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 template <int MT>
@@ -640,19 +641,18 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
                 } else if (x3h) {
                     constexpr int KH = MT >= 2 ? MT : 2 * MT;          // k-steps per sub-stage
                     if (STORE && tvalid) x3_store_block<MT>(hf + (y.K0rows_pad + (jj - 1) * F) * 32, hprev);                  // H_{jj-1}
-                    x3_u32x4 Bf[3][KH];
-                    x3_split<MT, KH>(hprev, 0, Bf);
-                    x3_rows<MT, KH>(reinterpret_cast<const char*>(img) + lane * 16, Bf, acc);
+                    x3_sub<MT, KH, 0>(reinterpret_cast<const char*>(img) + lane * 16, hprev, acc);
                     if (MT >= 2) {
-                        // second sub-stage (the other half of the k-steps): publish its image, prefetch the one after it
-                        stage_publish();
+                        // second sub-stage (the other half of the k-steps): publish its image, prefetch the one after it.  The
+                        // H stores above are younger than this sub-stage's DMA: wait for the DMA, not for them
+                        if (STORE) stage_publish_counted<4 * MT>(tvalid);
+                        else stage_publish();
                         cur ^= 1;
                         si = nsi;
                         const int nsi2 = (si + 1 == a.nstages) ? 0 : si + 1;
                         stage_issue(a.stage[nsi2], smem + (cur ^ 1) * BUF, wave, lane);
                         const float* img2 = reinterpret_cast<const float*>(smem + cur * BUF);
-                        x3_split<MT, KH>(hprev, KH, Bf);
-                        x3_rows<MT, KH>(reinterpret_cast<const char*>(img2) + lane * 16, Bf, acc);
+                        x3_sub<MT, KH, KH>(reinterpret_cast<const char*>(img2) + lane * 16, hprev, acc);
                         wo_tail = img2 + X3_SUB;
                         nsi_final = nsi2;
                     }
@@ -702,6 +702,11 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
                 // hidden layers of the storing modes: at least 4 MT stores (H_{jj-1}, inside the contraction) follow the DMA
                 // (x3 layers of two sub-stages issued their last DMA AFTER those stores: plain wait)
                 if (STORE && l.kind == NCA_IN_HID && !(x3h && MT >= 2)) stage_publish_counted<4 * MT>(tvalid);
+                else if (FSTORE && x3h && MT >= 2) {
+                    // younger than the second sub-stage's DMA: the mask store, or (last layer) the H_last quads + the raw output
+                    if (jj + 1 < y.NL) stage_publish_counted<1>(tvalid);
+                    else stage_publish_counted<4 * MT + 1>(tvalid);
+                }
                 else stage_publish();
                 cur ^= 1;
                 si = nsi_final;
@@ -736,17 +741,14 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a)
                     if (X3) {
                         constexpr int KH = MT >= 2 ? MT : 2 * MT;
                         if (tvalid) x3_store_block<MT>(df + jj * F * 32, hprev);                                                // D_jj
-                        x3_u32x4 Bf[3][KH];
-                        x3_split<MT, KH>(hprev, 0, Bf);
-                        x3_rows<MT, KH>(smem + cur * BUF + lane * 16, Bf, acc);
+                        x3_sub<MT, KH, 0>(smem + cur * BUF + lane * 16, hprev, acc);
                         if (MT >= 2) {
-                            stage_publish();
+                            stage_publish_counted<4 * MT>(tvalid);      // the D_jj stores are younger than this sub-stage's DMA
                             cur ^= 1;
                             si = nsi;
                             nsi_d = (si + 1 == a.nstages) ? 0 : si + 1;
                             stage_issue(a.stage[nsi_d], smem + (cur ^ 1) * BUF, wave, lane);
-                            x3_split<MT, KH>(hprev, KH, Bf);
-                            x3_rows<MT, KH>(smem + cur * BUF + lane * 16, Bf, acc);
+                            x3_sub<MT, KH, KH>(smem + cur * BUF + lane * 16, hprev, acc);
                         }
                     } else {
                         hidden_steps<MT>(imgl, hprev, acc, df + jj * F * 32, tvalid);         // stores D_jj
