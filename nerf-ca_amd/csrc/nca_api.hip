@@ -260,6 +260,24 @@ static bool can_share_enc(const NcaFusedArgs& a, int32_t prec) {
            a.net[0].four == a.net[1].four;
 }
 
+// bf16 backward from a store: weight-gradient jobs of layers (2p, 2p+1), p < nca_pairs(y), run as pairs that recompute the
+// input of layer 2p+1 and D_{2p} (NcaWgradPair), so the fused kernels do not write those blocks.  The last layer never pairs
+// (its input is what the backward restarts from).  EXPERIMENT, off unless NCA_PAIR=1: it takes 13 GB of stores out of the
+// forward (-0.5 ms) and 13 GB out of each net's backward (-0.6 ms each) and halves the weight-gradient reads, but the pair
+// kernel as built is bound by the latency of its loads (8 KB per wave in flight; registers and LDS are full) and runs
+// 11.2 ms against the 7.3 ms of the plain jobs: 25.6 ms per step instead of 24.1.
+static int nca_pairs(const NcaLayout& y, int32_t prec) {
+    static const bool on = getenv("NCA_PAIR") != nullptr && getenv("NCA_PAIR")[0] == '1';
+    if (!on || prec != NCA_PREC_BF16) return 0;
+    return (y.NL - 1) / 2;
+}
+static void set_skip_bits(NcaNetArgs* na, int32_t prec) {
+    const int np = nca_pairs(na->lay, prec);
+    na->skip_h = 0;
+    na->skip_d = 0;
+    for (int p2 = 0; p2 < np; ++p2) { na->skip_h |= 1 << (2 * p2); na->skip_d |= 1 << (2 * p2); }    // hidden block 2p = input of layer 2p+1; D_{2p}
+}
+
 struct StorePlan {
     int64_t h_stride;     // per 32-sample tile of the H region: bytes (bf16) / rows of 32 floats (f32)
     int64_t row0[2], off_m, off_r, bytes;
@@ -385,6 +403,7 @@ extern "C" int nca_render_fwd(const NcaRays* rays, int32_t prec,
             return fail(NCA_E_UNSUPPORTED, "a forward store needs nets of one width with at least one hidden layer");
         if (store_bytes < spl.bytes) return fail(NCA_E_WORKSPACE, "forward store %lld < %lld bytes", (long long)store_bytes, (long long)spl.bytes);
         kmode = NCA_KM_FWD_STORE;
+        for (int n = 0; n < a.nnets; ++n) set_skip_bits(&a.net[n], prec);
         a.scratch = static_cast<float*>(store);
         a.rows_total = spl.h_stride;
         for (int n = 0; n < a.nnets; ++n) a.net[n].row0 = spl.row0[n];
@@ -510,37 +529,50 @@ static void add_jobs_f32(NcaWgradArgs* w, const NcaLayout& y, int64_t row0, int6
 }
 
 // net_off: byte offset of the net's input/H blocks in a tile of the H region; d_off: of its D blocks in a tile of the D region
-static void add_jobs_bf16(NcaWgradArgs* w, const NcaLayout& y, int64_t net_off, int64_t d_off, int64_t slab_off, int64_t onehot_off, int64_t enc_off,
-                          int skip_layer = -1) {
+static void make_job_bf16(NcaWgradJob& g, const NcaLayout& y, int j, int64_t net_off, int64_t d_off, int64_t slab_off, int64_t onehot_off, int64_t enc_off) {
     const int64_t EB = 32 * (int64_t)NCA_BF_ENCROWS * 2, HB = 32 * (int64_t)y.F * 2;
+    const NcaLayerL& l = y.layer[j];
+    memset(&g, 0, sizeof(g));
+    g.F = y.F;
+    g.d_row0 = d_off + (int64_t)j * HB;
+    g.out_off = slab_off + l.w_off;
+    g.out_ld = l.K;
+    g.out_col0 = 0;
+    g.bias_off = slab_off + l.b_off;
+    g.onehot_off = onehot_off;
+    if (j == 0) {
+        g.is_enc = 1;
+        g.b_row0 = enc_off;          // the input block (the other net's when it is shared)
+        g.b_row_bytes = NCA_BF_ENCROWS * 2;
+        g.ncols_w = y.Kenc;
+        g.T = y.T;
+        g.P = y.P;
+        g.fourier_L = y.enc_mode == NCA_ENC_FOURIER ? y.L : 0;
+    } else {
+        g.is_enc = 0;
+        g.b_row0 = net_off + EB + (int64_t)(j - 1) * HB;
+        g.b_row_bytes = y.F * 2;
+        g.ncols_w = y.F;
+        g.T = 0;
+        g.P = 0;
+    }
+}
+// jobs of layers below 2 * npairs go to `pairs` (two per entry), the others to `w`; skip_layer: accumulated on chip by the dgrad kernel
+static void add_jobs_bf16(NcaWgradArgs* w, NcaWgradPairArgs* pairs, int npairs, int net_index, const void* packed, const NcaLayout& y, int64_t net_off,
+                          int64_t d_off, int64_t slab_off, int64_t onehot_off, int64_t enc_off, int skip_layer = -1) {
     for (int j = 0; j < y.NL; ++j) {
-        if (j == skip_layer) continue;            // accumulated on chip by the dgrad kernel
-        const NcaLayerL& l = y.layer[j];
-        NcaWgradJob& g = w->job[w->njobs++];
-        g.F = y.F;
-        g.d_row0 = d_off + (int64_t)j * HB;
-        g.out_off = slab_off + l.w_off;
-        g.out_ld = l.K;
-        g.out_col0 = 0;
-        g.bias_off = slab_off + l.b_off;
-        g.onehot_off = onehot_off;
-        if (j == 0) {
-            g.is_enc = 1;
-            g.b_row0 = enc_off;          // the input block (the other net's when it is shared)
-            g.b_row_bytes = NCA_BF_ENCROWS * 2;
-            g.ncols_w = y.Kenc;
-            g.T = y.T;
-            g.P = y.P;
-            g.fourier_L = y.enc_mode == NCA_ENC_FOURIER ? y.L : 0;
+        if (j == skip_layer) continue;
+        if (j < 2 * npairs) {
+            NcaWgradPair& pr = pairs->pair[pairs->npairs + j / 2];
+            make_job_bf16((j & 1) ? pr.hi : pr.lo, y, j, net_off, d_off, slab_off, onehot_off, enc_off);
+            const char* pk = static_cast<const char*>(packed);
+            if (j & 1) pr.imgT_hi = pk + y.layer[j].imgT_off;
+            else { pr.img_lo = pk + y.layer[j].img_off; pr.ks_lo = y.layer[j].ksteps; pr.net = net_index; pr.mask_layer = j; }
         } else {
-            g.is_enc = 0;
-            g.b_row0 = net_off + EB + (int64_t)(j - 1) * HB;
-            g.b_row_bytes = y.F * 2;
-            g.ncols_w = y.F;
-            g.T = 0;
-            g.P = 0;
+            make_job_bf16(w->job[w->njobs++], y, j, net_off, d_off, slab_off, onehot_off, enc_off);
         }
     }
+    pairs->npairs += npairs;
 }
 
 static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t units, int64_t tiles_per_unit, float* const* grads,
@@ -604,11 +636,27 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     for (int n = 0; n < a.nnets; ++n) { onehot_off[n] = soff; soff += (int64_t)lays[n].F * lays[n].P; }
 
     static thread_local NcaWgradArgs w;
+    static thread_local NcaWgradPairArgs wp;
     memset(&w, 0, sizeof(w));
+    memset(&wp, 0, sizeof(wp));
     for (int n = 0; n < a.nnets; ++n) {
-        if (bf) add_jobs_bf16(&w, lays[n], a.net[n].row0, a.net[n].drow0, slab_off[n], onehot_off[n], stored && a.share_enc && n == 0 ? a.net[1].row0 : a.net[n].row0,
-                              onchip ? lays[n].NL - 1 : -1);
+        const int np = stored ? nca_pairs(lays[n], prec) : 0;
+        if (stored) set_skip_bits(&a.net[n], prec); else { a.net[n].skip_h = 0; a.net[n].skip_d = 0; }
+        if (wp.npairs + np > NCA_MAX_PAIRS) return fail(NCA_E_UNSUPPORTED, "too many paired wgrad jobs");
+        if (bf) add_jobs_bf16(&w, &wp, np, n, binds[n].packed, lays[n], a.net[n].row0, a.net[n].drow0, slab_off[n], onehot_off[n],
+                              stored && a.share_enc && n == 0 ? a.net[1].row0 : a.net[n].row0, onchip ? lays[n].NL - 1 : -1);
         else add_jobs_f32(&w, lays[n], a.net[n].row0, a.net[n].drow0, slab_off[n], onehot_off[n]);
+    }
+    if (wp.npairs) {
+        wp.dscratch = reinterpret_cast<const char*>(scratch);
+        wp.d_total = p.tile_stride;
+        wp.hstore = static_cast<const char*>(store);
+        wp.h_total = spl.h_stride;
+        wp.mstore = static_cast<const char*>(store) + spl.off_m;
+        wp.mstore_layers = spl.mask_layers;
+        wp.slab = slab;
+        wp.slab_stride = p.slab_stride;
+        wp.nsplit = p.n_split;
     }
     w.scratch = scratch;
     w.slab = slab;
@@ -671,8 +719,15 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
         w.accumulate = chunk > 0;
         {
             Span sp(NCA_K_BWD_WGRAD, st);
-            if (bf) HIPCHK(nca_launch_wgrad_bf16(F, w, p.n_split, st));
-            else HIPCHK(nca_launch_wgrad_f32(w, p.n_split, st));
+            if (bf) {
+                if (wp.npairs) {
+                    wp.ntiles = w.ntiles;
+                    wp.tile0_b = w.tile0_b;
+                    wp.accumulate = w.accumulate;
+                    HIPCHK(nca_launch_wgrad_pair_bf16(F, wp, st));
+                }
+                if (w.njobs) HIPCHK(nca_launch_wgrad_bf16(F, w, p.n_split, st));
+            } else HIPCHK(nca_launch_wgrad_f32(w, p.n_split, st));
         }
     }
     NcaReduceArgs r;

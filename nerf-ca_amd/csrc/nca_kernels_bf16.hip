@@ -549,7 +549,8 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                 const int nks = l.ksteps;
                 const float* tail = reinterpret_cast<const float*>(img + MT * nks * 1024);
                 const bool last = jj == y.NL - 1;
-                const bool store_h = STORE && tvalid && !last;
+                const bool keep_h = last || !((na.skip_h >> jj) & 1);            // a paired wgrad job recomputes a skipped block
+                const bool store_h = STORE && tvalid && !last && keep_h;
                 char* const hblk = STORE ? nb + EB + jj * HB : nullptr;          // input block of layer jj+1
                 u32x4 Bn[2][2 * MT];
                 unsigned mw[2][2] = {{0u, 0u}, {0u, 0u}};     // mask words: [column tile][row-tile pair]
@@ -733,7 +734,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                 // at least 4 MT stores follow the weight DMA of every storing stage: H (plus a mask store in the storing
                 // forward, which it then also waits for), or D_{NL-1} on the last layer of both backward modes; the last
                 // layer of the storing forward stores nothing
-                if ((STORE && !last) || (BWD && last && !ONCHIP)) stage_publish_counted<4 * MT>(tvalid);
+                if ((STORE && !last) || (BWD && last && !ONCHIP)) stage_publish_counted<4 * MT>(tvalid && keep_h);
                 else stage_publish_b();
                 cur ^= 1;
                 si = nsi;
@@ -751,6 +752,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                     const char* img = smem + cur * BUF;
                     const char* const hblk = nb + EB + (jj - 1) * HB;                       // input of layer jj (mask)
                     char* const dblk = db + (jj - 1) * HB;                                  // D_{jj-1}
+                    const bool wr_d = tvalid && !((na.skip_d >> (jj - 1)) & 1);              // a paired wgrad job recomputes a skipped D
                     u32x4 Bn[2][2 * MT];
                     u32x4 mv = {0u, 0u, 0u, 0u};
                     if (lds_mask) mv = *reinterpret_cast<const u32x4*>(mwave + (jj - 1) * 1024);
@@ -788,7 +790,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                                     dw[u] = pack2(p0 ? a0 : 0.f, p1 ? a1 : 0.f);
                                 }
                                 Bn[c][2 * m + s2] = dw;
-                                if (tvalid) store_nt(dp + (2 * m + s2) * 1024, dw);
+                                if (wr_d) store_nt(dp + (2 * m + s2) * 1024, dw);
                             }
                         }
                     }
@@ -796,7 +798,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                     for (int c = 0; c < 2; ++c)
 #pragma unroll
                         for (int k = 0; k < 2 * MT; ++k) B[c][k] = Bn[c][k];
-                    stage_publish_counted<4 * MT>(tvalid);             // D stores
+                    stage_publish_counted<4 * MT>(wr_d);               // D stores
                     cur ^= 1;
                     si = nsi;
                 }
@@ -869,6 +871,44 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
 // ------------------------------------------------------------------------------------------
 // wgrad, no LDS.  One wave = one (job, split): dW of the whole layer in accumulators.
 // ------------------------------------------------------------------------------------------
+// dW / db of one (job, split) -> its slab, natural [o][i] order
+template <int F, int NTB>
+__device__ __forceinline__ void wgrad_write(const f32x16 (&acc)[F / 32][NTB], const float (&bsum)[F / 32], const NcaWgradJob& job, float* slab, int accumulate, int lane) {
+    constexpr int MT = F / 32;
+    const int lc = lane & 31, lh = lane >> 5;
+    // Hidden blocks hold features in accumulator->operand order: position c = 16s+8a+4b+e of a 32-wide
+    // tile is feature 16s+8b+4a+e (bits 3 and 2 swapped).  The input block is in natural slot order.
+    auto unperm = [](int c) { return (c & 0x13) | ((c & 8) >> 1) | ((c & 4) << 1); };
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int c = 0; c < NTB; ++c) {
+            const int slot = job.is_enc ? 32 * c + lc : 32 * c + unperm(lc);      // H column (layer-0 slot or hidden feature)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int o = 32 * m + unperm(nca_rho(i) + 4 * lh);
+                float* dst = nullptr;
+                if (job.is_enc) {
+                    if (slot < job.ncols_w) dst = slab + job.out_off + (int64_t)o * job.out_ld + (job.fourier_L ? ((slot & 1) ? 3 * job.fourier_L + (slot >> 1) : (slot >> 1)) : slot);
+                    else if (slot >= NCA_BF_LAT_SLOT && slot < NCA_BF_LAT_SLOT + job.T) dst = slab + job.out_off + (int64_t)o * job.out_ld + job.ncols_w + (slot - NCA_BF_LAT_SLOT);
+                    else if (slot >= NCA_BF_HOT_SLOT && slot < NCA_BF_HOT_SLOT + job.P) dst = slab + job.onehot_off + o * job.P + (slot - NCA_BF_HOT_SLOT);
+                } else if (slot < job.ncols_w) {
+                    dst = slab + job.out_off + (int64_t)o * job.out_ld + slot;
+                }
+                if (dst) *dst = accumulate ? *dst + acc[m][c][i] : acc[m][c][i];
+            }
+        }
+        if (job.bias_off >= 0) {
+            // column sums of the transposed D tile = sum over samples; the two lane halves hold disjoint samples
+            const float b = bsum[m] + __shfl_xor(bsum[m], 32);
+            if (lh == 0) {
+                float* dst = slab + job.bias_off + 32 * m + unperm(lc);
+                *dst = accumulate ? *dst + b : b;
+            }
+        }
+    }
+}
+
 template <int F, int NTB>   // NTB = 32-column tiles of the H block (F/32 for hidden inputs, 4 for the 112-wide input block)
 __device__ __forceinline__ void wgrad_job(const NcaWgradArgs& a, const NcaWgradJob& job, int q, int nsplit, int lane) {
     constexpr int MT = F / 32;
@@ -924,38 +964,7 @@ __device__ __forceinline__ void wgrad_job(const NcaWgradArgs& a, const NcaWgradJ
         }
     }
 
-    // Hidden blocks hold features in accumulator->operand order: position c = 16s+8a+4b+e of a 32-wide
-    // tile is feature 16s+8b+4a+e (bits 3 and 2 swapped).  The input block is in natural slot order.
-    auto unperm = [](int c) { return (c & 0x13) | ((c & 8) >> 1) | ((c & 4) << 1); };
-    float* slab = a.slab + (int64_t)q * a.slab_stride;
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-#pragma unroll
-        for (int c = 0; c < NTB; ++c) {
-            const int slot = job.is_enc ? 32 * c + lc : 32 * c + unperm(lc);      // H column (layer-0 slot or hidden feature)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int o = 32 * m + unperm(nca_rho(i) + 4 * lh);
-                float* dst = nullptr;
-                if (job.is_enc) {
-                    if (slot < job.ncols_w) dst = slab + job.out_off + (int64_t)o * job.out_ld + (job.fourier_L ? ((slot & 1) ? 3 * job.fourier_L + (slot >> 1) : (slot >> 1)) : slot);
-                    else if (slot >= NCA_BF_LAT_SLOT && slot < NCA_BF_LAT_SLOT + job.T) dst = slab + job.out_off + (int64_t)o * job.out_ld + job.ncols_w + (slot - NCA_BF_LAT_SLOT);
-                    else if (slot >= NCA_BF_HOT_SLOT && slot < NCA_BF_HOT_SLOT + job.P) dst = slab + job.onehot_off + o * job.P + (slot - NCA_BF_HOT_SLOT);
-                } else if (slot < job.ncols_w) {
-                    dst = slab + job.out_off + (int64_t)o * job.out_ld + slot;
-                }
-                if (dst) *dst = a.accumulate ? *dst + acc[m][c][i] : acc[m][c][i];
-            }
-        }
-        if (job.bias_off >= 0) {
-            // column sums of the transposed D tile = sum over samples; the two lane halves hold disjoint samples
-            const float b = bsum[m] + __shfl_xor(bsum[m], 32);
-            if (lh == 0) {
-                float* dst = slab + job.bias_off + 32 * m + unperm(lc);
-                *dst = a.accumulate ? *dst + b : b;
-            }
-        }
-    }
+    wgrad_write<F, NTB>(acc, bsum, job, a.slab + (int64_t)q * a.slab_stride, a.accumulate, lane);
 }
 
 template <int F>
@@ -963,6 +972,213 @@ __global__ __launch_bounds__(64, 1) void nca_wgrad_bf16(const NcaWgradArgs a) {
     const NcaWgradJob job = a.job[blockIdx.y];
     if (job.is_enc) wgrad_job<F, 4>(a, job, blockIdx.x, gridDim.x, threadIdx.x);
     else wgrad_job<F, F / 32>(a, job, blockIdx.x, gridDim.x, threadIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------
+// paired wgrad (backward from a forward store).  A workgroup = 4 waves (one per SIMD) = 2 splits x the two layers of one
+// pair (2p, 2p+1).  Per 32-sample tile the wave of layer 2p ("lo") loads D_{2p+1}, the wave of layer 2p+1 ("hi") loads the
+// input of layer 2p; both hand their block to the partner through LDS.  lo recomputes D_{2p} = (W_{2p+1}^T D_{2p+1}) (.) ReLU bits,
+// hi recomputes its own input relu(W_{2p} x + b_{2p}) -- the same MFMA sequences on the same operands as the fused kernels
+// ran, so the blocks are bit-identical to what those would have stored -- and each continues as nca_wgrad_bf16 does
+// (identity-MFMA transposes, dW of its whole layer in 256 accumulator registers).  The two weight images live in LDS.
+// ------------------------------------------------------------------------------------------
+template <int F>
+struct PairCfg {
+    static constexpr int MT = F / 32, KS = F / 16, KS0 = NCA_BF_K0SLOTS / 16;
+    static constexpr int NFX = 2 * MT > KS0 + 1 ? 2 * MT : KS0 + 1;                 // fragments of an exchanged block (at most)
+    static constexpr int KSLO = KS > KS0 ? KS : KS0;
+    static constexpr int IMG_LO = (MT * KSLO * 1024 + 2 * MT * 16 * 4 + 1023) & ~1023;   // forward image + bias tail
+    static constexpr int IMG_HI = MT * KS * 1024;                                   // transposed image
+    static constexpr int XB = 2 /*slots*/ * 2 /*buffers*/ * 2 /*roles*/ * NFX * 1024;
+    static constexpr int LDS = IMG_LO + IMG_HI + XB;
+};
+
+// (Tried: these small products as inline-assembly VGPR-form MFMAs -- the compiler selects the AGPR form for every MFMA
+// although the dW accumulators fill the AGPR file, and shuttles a dW tile to VGPRs and back, ~270 v_accvgpr moves per
+// tile.  The assembly form removed them but changed neither the kernel time -- it is bound by the latency of its loads,
+// see DESIGN.md -- nor stayed correct under every schedule (a 1.6 dB training-PSNR drift), so the builtins stay.)
+__device__ __forceinline__ void mfma_v0(f32x16& z, const u32x4& a, const u32x4& b) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(a), frag(b), z, 0, 0, 0);
+}
+__device__ __forceinline__ void mfma_v(f32x16& z, const u32x4& a, const u32x4& b) { z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(a), frag(b), z, 0, 0, 0); }
+
+// one column tile: acc += A(row tile m of the image) * B, A fragments through the same ring as mma_rowtile_ring
+template <int NKS, int MTOT, int NB, int RING>
+__device__ __forceinline__ void mma_rowtile_ring1(const char* imgl, int m, u32x4 (&A)[RING], const u32x4 (&B)[NB], f32x16& acc) {
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        const int g = m * NKS + ks, nx = g + RING - 1;
+        if (nx < MTOT * NKS) A[nx % RING] = *reinterpret_cast<const u32x4*>(imgl + nx * 1024);
+        mfma_v(acc, A[g % RING], B[ks]);
+        __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x10 | 0x400);
+    }
+}
+
+template <int F, int ROLE, bool ENC>
+__device__ __forceinline__ void wgrad_pair_role(const NcaWgradPairArgs& a, const NcaWgradPair& pr, const char* img_lo, const char* img_hi,
+                                                char* xslot, int q, int lane) {
+    constexpr int MT = PairCfg<F>::MT, KS = PairCfg<F>::KS, KS0 = PairCfg<F>::KS0, NFX = PairCfg<F>::NFX;
+    constexpr int NOWN = ROLE == 0 ? 2 * MT : (ENC ? KS0 + 1 : 2 * MT);      // fragments of the block this wave loads from HBM
+    constexpr int NPART = ROLE == 0 ? (ENC ? KS0 + 1 : 2 * MT) : 2 * MT;     // ... of the block it gets from its partner
+    constexpr int NTB = ROLE == 0 ? (ENC ? 4 : MT) : MT;                     // 32-column tiles of my job's H operand
+    constexpr int NKS = ROLE == 1 ? (ENC ? KS0 : KS) : KS;                   // k-steps of my recompute
+    constexpr int RING = 6;
+    const NcaWgradJob& job = ROLE == 0 ? pr.lo : pr.hi;
+    const int lc = lane & 31, lh = lane >> 5;
+    const int64_t per = (a.ntiles + a.nsplit - 1) / a.nsplit;
+    const int64_t t0 = (int64_t)q * per;
+    const bool qvalid = q < a.nsplit;
+
+    f32x16 acc[MT][NTB];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int c = 0; c < NTB; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][c][i] = 0.f;
+    float bsum[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) bsum[m] = 0.f;
+
+    u32x4 OWN[NOWN], NXT[NOWN];
+    u32x4 mv = {0u, 0u, 0u, 0u}, mvn = {0u, 0u, 0u, 0u};
+    auto load_own = [&](int64_t t, u32x4 (&x)[NOWN], u32x4& m4) {
+        const bool ok = qvalid && t < a.ntiles;            // wave-uniform
+        if (!ok) {
+#pragma unroll
+            for (int s = 0; s < NOWN; ++s) x[s] = (u32x4){0u, 0u, 0u, 0u};
+            return;
+        }
+        if (ROLE == 0) {
+            const char* dp = a.dscratch + t * a.d_total + pr.hi.d_row0 + lane * 16;
+#pragma unroll
+            for (int s = 0; s < NOWN; ++s) x[s] = load_nt(dp + s * 1024);
+            const int64_t tg = (t + a.tile0_b) >> 1;
+            m4 = load_nt(a.mstore + ((tg * 2 + pr.net) * a.mstore_layers + pr.mask_layer) * 1024 + lane * 16);
+        } else {
+            const char* bp = a.hstore + (t + a.tile0_b) * a.h_total + pr.lo.b_row0 + lane * 16;
+#pragma unroll
+            for (int s = 0; s < NOWN; ++s) x[s] = load_nt(bp + s * 1024);
+        }
+    };
+    const char* const imgl = (ROLE == 1 ? img_lo : img_hi) + lane * 16;
+    const float* const tail = reinterpret_cast<const float*>(img_lo + MT * NKS * 1024);     // bias of layer 2p (hi only)
+    const u32x4 E0 = ident_frag(8 * lh, lc), E1 = ident_frag(16 + 8 * lh, lc);
+    // one 32-feature tile (fragments x0, x1: lane = sample, k = features) -> rows = samples, lane = feature, packed as two
+    // k-steps of 16 samples (what transpose_block does per tile)
+    auto transpose_tile = [&](const u32x4& x0, const u32x4& x1, u32x4 (&T)[2], float* colsum) __attribute__((always_inline)) {
+        f32x16 z;
+        mfma_v0(z, x0, E0);
+        mfma_v(z, x1, E1);
+        if (colsum) {
+            float cs = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) cs += z[i];
+            *colsum += cs;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            T[0][u] = pack2(z[2 * u], z[2 * u + 1]);
+            T[1][u] = pack2(z[8 + 2 * u], z[8 + 2 * u + 1]);
+        }
+    };
+
+    load_own(t0, OWN, mv);
+    for (int64_t it = 0; it < per; ++it) {
+        const int64_t t = t0 + it;
+        char* const xmine = xslot + (((int)(it & 1) * 2 + ROLE) * NFX) * 1024 + lane * 16;
+        const char* const xpart = xslot + (((int)(it & 1) * 2 + (1 - ROLE)) * NFX) * 1024 + lane * 16;
+#pragma unroll
+        for (int s = 0; s < NOWN; ++s) *reinterpret_cast<u32x4*>(xmine + s * 1024) = OWN[s];
+        if (it + 1 < per) load_own(t + 1, NXT, mvn);
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- my recompute, one 32-row tile at a time, transposed straight away --------------------------------
+        u32x4 TR[MT][2];          // lo: D_{2p} transposed (A operand of dW); hi: the recomputed input transposed (B operand)
+        {
+            const int c = (int)((t + a.tile0_b) & 1);          // which half of the 64-sample wave tile the masks were written for
+            const unsigned w01 = c ? mv[2] : mv[0], w23 = c ? mv[3] : mv[1];
+            u32x4 A[RING];
+            ring_prime<NKS, MT, RING>(imgl, A);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                f32x16 z;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) z[i] = ROLE == 1 ? tail[(lh * MT + m) * 16 + i] : 0.f;
+                mma_rowtile_ring1<NKS, MT, NOWN, RING>(imgl, m, A, OWN, z);
+                u32x4 xs[2];
+                if (ROLE == 1) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) z[i] = relu1(z[i]);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { xs[0][u] = pack2(z[2 * u], z[2 * u + 1]); xs[1][u] = pack2(z[8 + 2 * u], z[8 + 2 * u + 1]); }
+                } else {
+                    const unsigned fld = ((m >> 1) ? w23 : w01) >> (8 * (m & 1));
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const bool p0 = ((fld >> (4 * s2 + u)) & 1u) != 0u;
+                            const bool p1 = ((fld >> (16 + 4 * s2 + u)) & 1u) != 0u;
+                            xs[s2][u] = pack2(p0 ? z[8 * s2 + 2 * u] : 0.f, p1 ? z[8 * s2 + 2 * u + 1] : 0.f);
+                        }
+                }
+                transpose_tile(xs[0], xs[1], TR[m], ROLE == 0 ? &bsum[m] : nullptr);
+            }
+        }
+        lds_barrier();            // the partner's block of this tile is in LDS (and everyone is done with the buffer of tile it-1)
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- the partner's block, one 32-feature tile at a time, into the dW products ----------------------------
+        constexpr int NPT = ROLE == 0 ? NTB : MT;                 // 32-feature tiles of the partner's block
+#pragma unroll
+        for (int tt = 0; tt < NPT; ++tt) {
+            const u32x4 x0 = (2 * tt < NPART) ? *reinterpret_cast<const u32x4*>(xpart + (2 * tt) * 1024) : (u32x4){0u, 0u, 0u, 0u};
+            const u32x4 x1 = (2 * tt + 1 < NPART) ? *reinterpret_cast<const u32x4*>(xpart + (2 * tt + 1) * 1024) : (u32x4){0u, 0u, 0u, 0u};
+            u32x4 TP[2];
+            transpose_tile(x0, x1, TP, ROLE == 1 ? &bsum[tt] : nullptr);
+            // dW[o][i] += sum_n D[o][n] H[i][n]: lo -- the partner's tile is H column tile tt; hi -- it is D row tile tt
+#pragma unroll
+            for (int k = 0; k < (ROLE == 0 ? MT : NTB); ++k)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    if (ROLE == 0) acc[k][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(TR[k][s]), frag(TP[s]), acc[k][tt], 0, 0, 0);
+                    else acc[tt][k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(TP[s]), frag(TR[k][s]), acc[tt][k], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (it + 1 < per) {
+#pragma unroll
+            for (int s = 0; s < NOWN; ++s) OWN[s] = NXT[s];
+            mv = mvn;
+        }
+    }
+    if (qvalid) wgrad_write<F, NTB>(acc, bsum, job, a.slab + (int64_t)q * a.slab_stride, a.accumulate, lane);
+}
+
+template <int F>
+__global__ __launch_bounds__(256, 1) void nca_wgrad_pair_bf16(const NcaWgradPairArgs a) {
+    constexpr int MT = PairCfg<F>::MT, KS = PairCfg<F>::KS, NFX = PairCfg<F>::NFX;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const NcaWgradPair& pr = a.pair[blockIdx.y];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, role = wave & 1, slot = wave >> 1;
+    char* const img_lo = smem;
+    char* const img_hi = smem + PairCfg<F>::IMG_LO;
+    char* const xslot = img_hi + PairCfg<F>::IMG_HI + slot * (2 * 2 * NFX * 1024);
+    const int lo_bytes = MT * pr.ks_lo * 1024 + 2 * MT * 16 * 4;
+    for (int i = tid * 16; i < lo_bytes; i += 256 * 16) *reinterpret_cast<u32x4*>(img_lo + i) = *reinterpret_cast<const u32x4*>(pr.img_lo + i);
+    for (int i = tid * 16; i < MT * KS * 1024; i += 256 * 16) *reinterpret_cast<u32x4*>(img_hi + i) = *reinterpret_cast<const u32x4*>(pr.imgT_hi + i);
+    __syncthreads();
+    const int q = 2 * blockIdx.x + slot;
+    if (pr.lo.is_enc) {
+        if (role == 0) wgrad_pair_role<F, 0, true>(a, pr, img_lo, img_hi, xslot, q, lane);
+        else wgrad_pair_role<F, 1, true>(a, pr, img_lo, img_hi, xslot, q, lane);
+    } else {
+        if (role == 0) wgrad_pair_role<F, 0, false>(a, pr, img_lo, img_hi, xslot, q, lane);
+        else wgrad_pair_role<F, 1, false>(a, pr, img_lo, img_hi, xslot, q, lane);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1015,6 +1231,23 @@ hipError_t nca_launch_wgrad_bf16(int F, const NcaWgradArgs& a, int nsplit, hipSt
         case 32: hipLaunchKernelGGL(nca_wgrad_bf16<32>, dim3(nsplit, a.njobs), dim3(64), 0, st, a); break;
         case 64: hipLaunchKernelGGL(nca_wgrad_bf16<64>, dim3(nsplit, a.njobs), dim3(64), 0, st, a); break;
         case 128: hipLaunchKernelGGL(nca_wgrad_bf16<128>, dim3(nsplit, a.njobs), dim3(64), 0, st, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t nca_launch_wgrad_pair_bf16(int F, const NcaWgradPairArgs& a, hipStream_t st) {
+    const dim3 grid((a.nsplit + 1) / 2, a.npairs), block(256);
+    switch (F) {
+        case 32:
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_wgrad_pair_bf16<32>), hipFuncAttributeMaxDynamicSharedMemorySize, PairCfg<32>::LDS);
+            hipLaunchKernelGGL(nca_wgrad_pair_bf16<32>, grid, block, PairCfg<32>::LDS, st, a); break;
+        case 64:
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_wgrad_pair_bf16<64>), hipFuncAttributeMaxDynamicSharedMemorySize, PairCfg<64>::LDS);
+            hipLaunchKernelGGL(nca_wgrad_pair_bf16<64>, grid, block, PairCfg<64>::LDS, st, a); break;
+        case 128:
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_wgrad_pair_bf16<128>), hipFuncAttributeMaxDynamicSharedMemorySize, PairCfg<128>::LDS);
+            hipLaunchKernelGGL(nca_wgrad_pair_bf16<128>, grid, block, PairCfg<128>::LDS, st, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
