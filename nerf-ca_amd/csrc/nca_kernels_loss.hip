@@ -147,23 +147,37 @@ __global__ __launch_bounds__(LOSS_NT) void nca_loss_rays(const NcaLossArgs a) {
     }
 }
 
-__global__ __launch_bounds__(256) void nca_loss_finish(const NcaLossArgs a, int nblocks) {
-    __shared__ double sh[256];
-    double res[NPART + 2];
+// One block of 1024 threads sums the per-block partials in a fixed order: thread t takes blocks t, t + 1024, ... (all 14
+// columns of a block in one pass, 112 contiguous bytes per block), then the wave and the 16 waves are folded in fixed trees.
+#define LOSS_FIN_NT 1024
+__global__ __launch_bounds__(LOSS_FIN_NT) void nca_loss_finish(const NcaLossArgs a, int nblocks) {
+    __shared__ double sh[LOSS_FIN_NT / 64][NPART + 2];
+    double v[NPART + 2];
+#pragma unroll
+    for (int k = 0; k < NPART + 2; ++k) v[k] = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += LOSS_FIN_NT) {
+        const double* row = a.partials + (int64_t)b * (NPART + 2);
+#pragma unroll
+        for (int k = 0; k < NPART + 2; ++k) v[k] = k < NPART ? v[k] + row[k] : fmax(v[k], row[k]);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
     for (int k = 0; k < NPART + 2; ++k) {
-        double v = 0.0;
-        for (int b = threadIdx.x; b < nblocks; b += 256) {
-            const double x = a.partials[(int64_t)b * (NPART + 2) + k];
-            v = k < NPART ? v + x : fmax(v, x);
+        double x = v[k];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const double y = __shfl_xor(x, d);
+            x = k < NPART ? x + y : fmax(x, y);
         }
-        sh[threadIdx.x] = v;
-        __syncthreads();
-        for (int st = 128; st > 0; st >>= 1) {
-            if (threadIdx.x < st) sh[threadIdx.x] = k < NPART ? sh[threadIdx.x] + sh[threadIdx.x + st] : fmax(sh[threadIdx.x], sh[threadIdx.x + st]);
-            __syncthreads();
-        }
-        res[k] = sh[0];
-        __syncthreads();
+        if (lane == 0) sh[wave][k] = x;
+    }
+    __syncthreads();
+    double res[NPART + 2];
+#pragma unroll
+    for (int k = 0; k < NPART + 2; ++k) {
+        double x = sh[0][k];
+        for (int w = 1; w < LOSS_FIN_NT / 64; ++w) x = k < NPART ? x + sh[w][k] : fmax(x, sh[w][k]);
+        res[k] = x;
     }
     if (threadIdx.x == 0) {
         const double iR = a.inv_R;
@@ -189,7 +203,7 @@ __global__ __launch_bounds__(256) void nca_loss_finish(const NcaLossArgs a, int 
 hipError_t nca_launch_loss(const NcaLossArgs& a, hipStream_t st) {
     const int nblocks = (int)((a.R + LOSS_WAVES - 1) / LOSS_WAVES);
     hipLaunchKernelGGL(nca_loss_rays, dim3(nblocks), dim3(LOSS_NT), 0, st, a);
-    hipLaunchKernelGGL(nca_loss_finish, dim3(1), dim3(256), 0, st, a, nblocks);
+    hipLaunchKernelGGL(nca_loss_finish, dim3(1), dim3(LOSS_FIN_NT), 0, st, a, nblocks);
     return hipGetLastError();
 }
 
