@@ -1119,6 +1119,21 @@ def test_fine_depths_kernel_vs_oracle(dev, R, S, NF):
     assert torch.equal(got1, got)
 
 
+def test_paired_wgrad_jobs_equal_plain_jobs(dev):
+    """NCA_PAIR=1 (opt-in experiment): the storing forward skips every other layer input, the backward from
+    the store every other output gradient, and `nca_wgrad_pair_bf16` recomputes both on chip.  The switch is read once per
+    process, so the stored-vs-recompute equality cases (the recompute backward never pairs) run in a child process with it
+    set: equal gradients there mean the recomputed blocks are the ones the fused kernels would have stored."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NCA_PAIR="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-k", "test_stored_forward_backward_equals_recompute and bf16",
+                        os.path.join(root, "tests", "test_hip_parity.py")], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "passed" in r.stdout
+
+
 @pytest.mark.parametrize("R,S,F,early", [(8, 16, 32, 1), (33, 50, 64, 3), (64, 192, 128, 4), (300, 70, 128, 2)])
 @pytest.mark.parametrize("prec,it_d", [("bf16", 40000), ("bf16", 75000), ("f32", 40000)])
 def test_stored_forward_backward_equals_recompute(dev, prec, it_d, R, S, F, early):
