@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NCA_ABI_VERSION 4
+#define NCA_ABI_VERSION 5
 
 enum {
     NCA_OK = 0,
@@ -136,6 +136,15 @@ int nca_render_bwd(const NcaRays* rays, int32_t prec,
                    const NcaNet* net_d, const void* packed_d, const float* win_d, const float* four_d, const float* params_d,
                    const double* g_pix, const float* g_sig_s, const float* g_sig_d,
                    float* grads_s, float* grads_d, void* work, int64_t work_bytes,
+                   const void* store, int64_t store_bytes, void* stream);
+/* The same, and d loss / d depth of every sample into g_depth f32[R,S] (NULL: as nca_render_bwd).  The reference's fine pass
+ * does not detach its sampled depths: the fine losses reach them through the query point, the positional encoding and the
+ * first layer (train/model_helpers.py:146-148), and through them the coarse nets.  f32 mode, nets of one width, no skip layers. */
+int nca_render_bwd_depth(const NcaRays* rays, int32_t prec,
+                   const NcaNet* net_s, const void* packed_s, const float* win_s, const float* four_s, const float* params_s,
+                   const NcaNet* net_d, const void* packed_d, const float* win_d, const float* four_d, const float* params_d,
+                   const double* g_pix, const float* g_sig_s, const float* g_sig_d,
+                   float* grads_s, float* grads_d, float* g_depth, void* work, int64_t work_bytes,
                    const void* store, int64_t store_bytes, void* stream);
 
 /* ---- point path: replaces CPPN.forward / Temporal.forward_composite on arbitrary points

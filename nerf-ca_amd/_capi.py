@@ -68,6 +68,8 @@ SYMBOLS = {
     "nca_render_bwd_workspace": (_I64, [C.POINTER(NcaRays), C.POINTER(NcaNet), C.POINTER(NcaNet), _I32, _I64]),
     "nca_render_bwd": (C.c_int, [C.POINTER(NcaRays), _I32, C.POINTER(NcaNet), _P, _P, _P, _P, C.POINTER(NcaNet), _P, _P, _P, _P,
                                  _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _P]),
+    "nca_render_bwd_depth": (C.c_int, [C.POINTER(NcaRays), _I32, C.POINTER(NcaNet), _P, _P, _P, _P, C.POINTER(NcaNet), _P, _P, _P, _P,
+                                       _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _P]),
     "nca_mlp_fwd": (C.c_int, [C.POINTER(NcaNet), _I32, _P, _P, _P, _P, _I64, _P, _P, _P, _P]),
     "nca_mlp_bwd_workspace": (_I64, [C.POINTER(NcaNet), _I32, _I64, _I64]),
     "nca_mlp_bwd": (C.c_int, [C.POINTER(NcaNet), _I32, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _I64, _P]),
@@ -99,7 +101,7 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.nca_abi_version() != 4:
+        if handle.nca_abi_version() != 5:
             raise NcaError("libnerfca_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -576,10 +576,18 @@ static void add_jobs_bf16(NcaWgradArgs* w, NcaWgradPairArgs* pairs, int npairs, 
 }
 
 static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t units, int64_t tiles_per_unit, float* const* grads,
-                   void* work, int64_t work_bytes, hipStream_t st, const void* store = nullptr, int64_t store_bytes = 0) {
+                   void* work, int64_t work_bytes, hipStream_t st, const void* store = nullptr, int64_t store_bytes = 0, float* g_depth = nullptr) {
     const bool bf = prec == NCA_PREC_BF16;
     NcaLayout lays[2];
     for (int n = 0; n < a.nnets; ++n) lays[n] = a.net[n].lay;
+    if (g_depth) {
+        if (bf) return fail(NCA_E_UNSUPPORTED, "depth gradients are formed in the f32 mode only");
+        if (a.mode != NCA_MODE_RAYS) return fail(NCA_E_INVALID, "depth gradients need a ray batch");
+        for (int n = 0; n < a.nnets; ++n) {
+            if (binds[n].net->n_late > 0) return fail(NCA_E_UNSUPPORTED, "depth gradients with skip layers are not built");
+            if (lays[n].Kenc > 96) return fail(NCA_E_UNSUPPORTED, "depth gradients: more than 96 encoded features");
+        }
+    }
     // a store left by the forward of the SAME batch: no recompute, the chunk scratch holds the D blocks only
     StorePlan spl;
     const bool stored = store != nullptr;
@@ -713,6 +721,23 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
             if (bf) HIPCHK(nca_launch_fused_bf16(F, a, stored ? NCA_KM_BWD_STORED : NCA_KM_BWD, p.grid, st));
             else HIPCHK(nca_launch_fused_f32(F, a, stored ? NCA_KM_BWD_STORED : NCA_KM_BWD, p.grid, st));
         }
+        if (g_depth) {       // d loss / d depth from the D_0 blocks this chunk's dgrad launch just wrote
+            NcaZgradArgs zg;
+            memset(&zg, 0, sizeof(zg));
+            zg.nnets = a.nnets; zg.S = a.S; zg.nchunk = a.nchunk; zg.ray_is_f64 = a.ray_is_f64;
+            zg.ntiles = a.ntiles; zg.ray0 = u0;
+            zg.origins = a.origins; zg.dirs = a.dirs; zg.z = a.z; zg.zs_r = a.zs_r;
+            zg.dscratch = scratch; zg.d_total = p.tile_stride;
+            zg.g_z = g_depth;
+            for (int n = 0; n < a.nnets; ++n) {
+                NcaZgradNet& zn = zg.net[n];
+                zn.w0 = binds[n].params + lays[n].layer[0].w_off;
+                zn.ldw = lays[n].layer[0].K; zn.F = lays[n].F; zn.enc_mode = lays[n].enc_mode; zn.L = lays[n].L; zn.Kenc = lays[n].Kenc;
+                zn.win = a.net[n].win; zn.four = a.net[n].four;
+                zn.drow0 = a.net[n].drow0;
+            }
+            HIPCHK(nca_launch_zgrad_f32(zg, st));
+        }
         w.rows_total = p.tile_stride;
         w.tile0_b = stored ? u0 * tiles_per_unit * (bf ? 2 : 1) : 0;      // in 32-sample tiles
         w.ntiles = bf ? a.ntiles * 2 : a.ntiles;
@@ -805,6 +830,16 @@ extern "C" int nca_render_bwd(const NcaRays* rays, int32_t prec,
                               const double* g_pix, const float* g_sig_s, const float* g_sig_d,
                               float* grads_s, float* grads_d, void* work, int64_t work_bytes,
                               const void* store, int64_t store_bytes, void* stream) {
+    return nca_render_bwd_depth(rays, prec, net_s, packed_s, win_s, four_s, params_s, net_d, packed_d, win_d, four_d, params_d,
+                                g_pix, g_sig_s, g_sig_d, grads_s, grads_d, nullptr, work, work_bytes, store, store_bytes, stream);
+}
+
+extern "C" int nca_render_bwd_depth(const NcaRays* rays, int32_t prec,
+                              const NcaNet* net_s, const void* packed_s, const float* win_s, const float* four_s, const float* params_s,
+                              const NcaNet* net_d, const void* packed_d, const float* win_d, const float* four_d, const float* params_d,
+                              const double* g_pix, const float* g_sig_s, const float* g_sig_d,
+                              float* grads_s, float* grads_d, float* g_depth, void* work, int64_t work_bytes,
+                              const void* store, int64_t store_bytes, void* stream) {
     int rc = check_rays(rays);
     if (rc) return rc;
     rc = check_prec(prec);
@@ -827,6 +862,7 @@ extern "C" int nca_render_bwd(const NcaRays* rays, int32_t prec,
     hipStream_t st = (hipStream_t)stream;
     if (a.nnets == 2 && a.net[0].lay.F != a.net[1].lay.F) {
         if (store) return fail(NCA_E_UNSUPPORTED, "a forward store needs nets of one width");
+        if (g_depth) return fail(NCA_E_UNSUPPORTED, "depth gradients need nets of one width");
         // different widths: recompute both raw fields, push (g_pix, g_sigma) through the compositing chain rule
         // once, then run each net's backward on its own with the per-sample raw gradient
         const int64_t arr = align_up(rays->R * (int64_t)rays->S * 4, 256);
@@ -871,7 +907,7 @@ extern "C" int nca_render_bwd(const NcaRays* rays, int32_t prec,
     a.g_pix = g_pix;
     a.g_sig_s = g_sig_s;
     a.g_sig_d = g_sig_d;
-    return run_bwd(a, prec, binds, rays->R, a.nchunk, grads, work, work_bytes, st, store, store_bytes);
+    return run_bwd(a, prec, binds, rays->R, a.nchunk, grads, work, work_bytes, st, store, store_bytes, g_depth);
 }
 
 // ---------------------------------------------------------------------------------- point path

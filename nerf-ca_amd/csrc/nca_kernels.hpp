@@ -215,6 +215,26 @@ hipError_t nca_launch_fine_sample(const NcaFineArgs& a, hipStream_t st);
 int64_t nca_fine_partials(int64_t R);
 int64_t nca_loss_partials_bytes(int64_t R);
 
+// d loss / d depth of every sample (the reference differentiates the fine pass through its sampled depths: query point ->
+// positional encoding -> first layer; train/model_helpers.py:147-148): from the first layer's output gradient D_0 that the f32
+// backward leaves in its chunk scratch
+struct NcaZgradNet {
+    const float* w0;      // natural first-layer weight [F][ldw]
+    int32_t ldw, F, enc_mode, L, Kenc, pad;
+    const float* win;     // band weights (or null)
+    const float* four;    // fourier coefficients (or null)
+    int64_t drow0;        // first row of this net's D_0 block inside a tile of the D region
+};
+struct NcaZgradArgs {
+    int32_t nnets, S, nchunk, ray_is_f64;
+    int64_t ntiles, ray0;
+    const void* origins; const void* dirs;
+    const float* z; int64_t zs_r;
+    const float* dscratch; int64_t d_total;      // D region of this launch: [tile][d_total rows][32]
+    float* g_z;                                  // [R][S]
+    NcaZgradNet net[2];
+};
+hipError_t nca_launch_zgrad_f32(const NcaZgradArgs& a, hipStream_t st);
 hipError_t nca_launch_pack_f32(const NcaLayout& y, const float* prm, void* out, hipStream_t st);
 hipError_t nca_launch_fused_f32(int F, const NcaFusedArgs& a, int kmode, int grid, hipStream_t st);
 hipError_t nca_launch_wgrad_f32(const NcaWgradArgs& a, int nsplit, hipStream_t st);

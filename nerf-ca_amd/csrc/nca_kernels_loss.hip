@@ -474,3 +474,117 @@ hipError_t nca_launch_fine(const NcaFineArgs& a, hipStream_t st) {
     hipError_t e = nca_launch_fine_max(a, st);
     return e != hipSuccess ? e : nca_launch_fine_sample(a, st);
 }
+
+// ------------------------------------------------------------------------------------------
+// d loss / d depth per sample (fine pass of the reference, model_helpers.py:131-158: the sampled depths are NOT detached, so
+// the fine losses reach them through  p = o + d z  ->  positional encoding  ->  first layer).  One wave per 32-sample tile of
+// the f32 backward: lane (r, h) reads its 64 values of D_0 exactly as the dgrad kernel's lanes stored them (row
+// 32 m + 8 q + e + 4 h of quad (m, q)), forms its half of G = W0[:, encoded columns]^T D_0 from the weights staged in LDS, the
+// halves are added, and the encoding's derivative is applied in f64:
+//   bands:   dp_c = G[c] + sum_k w_k 2^k ( cos(xb) G[3+6k+c] + cos(fl32(xb + fl32(pi/2))) G[6+6k+c] ),  xb = fl32(p_c 2^k)
+//   fourier: dp_c = sum_{i = c mod 3} 2 pi g_i ( cos(v_i) G[i] - sin(v_i) G[3L+i] ),  v_i = fl32(fl32(2 pi p_c) g_i)
+//   none:    dp_c = G[c];                       dz = sum_c d_c dp_c, summed over the nets of the render.
+// ------------------------------------------------------------------------------------------
+#define ZG_KPAD 96
+__global__ __launch_bounds__(256) void nca_zgrad_f32(const NcaZgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float zw[];        // [F][ZG_KPAD]: encoded columns of W0, zero padded
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 31, lh = lane >> 5;
+    for (int net = 0; net < a.nnets; ++net) {
+        const NcaZgradNet& nn = a.net[net];
+        __syncthreads();
+        for (int i = threadIdx.x; i < nn.F * ZG_KPAD; i += 256) {
+            const int o = i / ZG_KPAD, f = i % ZG_KPAD;
+            zw[i] = f < nn.Kenc ? nn.w0[(int64_t)o * nn.ldw + f] : 0.f;
+        }
+        __syncthreads();
+        const int MT = nn.F / 32;
+        for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < a.ntiles; tile += (int64_t)gridDim.x * 4) {
+            const int64_t ray = a.ray0 + tile / a.nchunk;
+            int smp = (int)(tile % a.nchunk) * 32 + lr;
+            const bool valid = smp < a.S;
+            if (!valid) smp = a.S - 1;
+            const float* dblk = a.dscratch + (tile * a.d_total + nn.drow0) * 32 + lane * 4;
+            float G[ZG_KPAD];
+#pragma unroll
+            for (int f = 0; f < ZG_KPAD; ++f) G[f] = 0.f;
+            for (int mq = 0; mq < MT * 4; ++mq) {
+                const float4 dv = *reinterpret_cast<const float4*>(dblk + mq * 256);
+                const float de[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int o = 32 * (mq >> 2) + 8 * (mq & 3) + e + 4 * lh;
+                    const float4* wr = reinterpret_cast<const float4*>(zw + o * ZG_KPAD);
+#pragma unroll
+                    for (int f4 = 0; f4 < ZG_KPAD / 4; ++f4) {
+                        const float4 w = wr[f4];
+                        G[4 * f4] = fmaf(w.x, de[e], G[4 * f4]);
+                        G[4 * f4 + 1] = fmaf(w.y, de[e], G[4 * f4 + 1]);
+                        G[4 * f4 + 2] = fmaf(w.z, de[e], G[4 * f4 + 2]);
+                        G[4 * f4 + 3] = fmaf(w.w, de[e], G[4 * f4 + 3]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int f = 0; f < ZG_KPAD; ++f) G[f] += __shfl_xor(G[f], 32);
+            // the query point, as the forward forms it (model_helpers.py:117-120)
+            const float zz = a.z[ray * a.zs_r + smp];
+            float p[3];
+            double dd[3];
+            if (a.ray_is_f64) {
+                const double* o = reinterpret_cast<const double*>(a.origins) + ray * 3;
+                const double* d = reinterpret_cast<const double*>(a.dirs) + ray * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { p[c] = (float)__dadd_rn(o[c], __dmul_rn(d[c], (double)zz)); dd[c] = d[c]; }
+            } else {
+                const float* o = reinterpret_cast<const float*>(a.origins) + ray * 3;
+                const float* d = reinterpret_cast<const float*>(a.dirs) + ray * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { p[c] = __fadd_rn(o[c], __fmul_rn(d[c], zz)); dd[c] = (double)d[c]; }
+            }
+            double dp[3] = {0.0, 0.0, 0.0};
+            if (nn.enc_mode == NCA_ENC_FOURIER) {
+                for (int i = 0; i < 3 * nn.L; ++i) {
+                    const int c = i % 3;
+                    const float pc = c == 0 ? p[0] : (c == 1 ? p[1] : p[2]);
+                    const float coef = nn.four[i];
+                    const float v = __fmul_rn(__fmul_rn(6.283185482025146484375f, pc), coef);
+                    const double dv = 6.283185482025146484375 * (double)coef;
+                    const double t = dv * (cos((double)v) * (double)G[i] - sin((double)v) * (double)G[3 * nn.L + i]);
+                    dp[c] += t;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) dp[c] = (double)G[c];
+                if (nn.enc_mode == NCA_ENC_BANDS) {
+                    for (int k = 0; k < nn.L; ++k) {
+                        const double wk = nn.win ? (double)nn.win[k] : 1.0;
+                        const float sc = ldexpf(1.f, k);
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const float xb = __fmul_rn(p[c], sc);
+                            const float u = __fadd_rn(xb, 1.57079637050628662109375f);
+                            dp[c] += wk * (double)sc * (cos((double)xb) * (double)G[3 + 6 * k + c] + cos((double)u) * (double)G[6 + 6 * k + c]);
+                        }
+                    }
+                }
+            }
+            const double gz = dd[0] * dp[0] + dd[1] * dp[1] + dd[2] * dp[2];
+            if (valid && lh == 0) {
+                float* dst = a.g_z + ray * a.S + smp;
+                *dst = net == 0 ? (float)gz : *dst + (float)gz;
+            }
+        }
+    }
+}
+
+hipError_t nca_launch_zgrad_f32(const NcaZgradArgs& a, hipStream_t st) {
+    int F = a.net[0].F;
+    for (int n = 1; n < a.nnets; ++n) if (a.net[n].F > F) F = a.net[n].F;
+    const int lds = F * ZG_KPAD * (int)sizeof(float);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_zgrad_f32), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    int64_t blocks = (a.ntiles + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(nca_zgrad_f32, dim3((unsigned)blocks), dim3(256), lds, st, a);
+    return hipGetLastError();
+}

@@ -240,8 +240,9 @@ def render_forward_raw(batch: _RayBatch, bs: FieldBinding, bd: Optional[FieldBin
     return pix, sig_s, sig_d, (packed_s, packed_d, win_s, four_s, win_d, four_d, store)
 
 
-def render_backward_raw(batch: _RayBatch, bs: FieldBinding, bd: Optional[FieldBinding], keep, g_pix, g_sig_s, g_sig_d):
-    """Fused backward (recompute + dgrad + wgrad + reduce): returns flat f32 gradients per net."""
+def render_backward_raw(batch: _RayBatch, bs: FieldBinding, bd: Optional[FieldBinding], keep, g_pix, g_sig_s, g_sig_d, want_depth_grad: bool = False):
+    """Fused backward (recompute + dgrad + wgrad + reduce): returns flat f32 gradients per net (and, with ``want_depth_grad``,
+    d loss / d depth f32[R,S] as a third value: the f32 path's nca_render_bwd_depth)."""
     lib = _capi.lib()
     packed_s, packed_d, win_s, four_s, win_d, four_d, store = keep
     dev = batch.o.device
@@ -252,6 +253,14 @@ def render_backward_raw(batch: _RayBatch, bs: FieldBinding, bd: Optional[FieldBi
     desc = batch.desc()
     net_d = C.byref(bd.net) if bd is not None else None
     work, wbytes = _alloc_workspace(lambda cap: check(lib.nca_render_bwd_workspace(C.byref(desc), C.byref(bs.net), net_d, bs.prec, cap)), dev)
+    if want_depth_grad:
+        g_depth = torch.zeros((batch.R, batch.S), dtype=torch.float32, device=dev)
+        check(lib.nca_render_bwd_depth(C.byref(desc), bs.prec,
+                                       C.byref(bs.net), ptr(packed_s), ptr(win_s), ptr(four_s), ptr(bs.flat),
+                                       net_d, ptr(packed_d), ptr(win_d), ptr(four_d), ptr(bd.flat) if bd is not None else None,
+                                       ptr(gp), ptr(gs), ptr(gd), ptr(grads_s), ptr(grads_d), ptr(g_depth), ptr(work), wbytes,
+                                       ptr(store), store.numel() if store is not None else 0, _stream()))
+        return grads_s, grads_d, g_depth
     check(lib.nca_render_bwd(C.byref(desc), bs.prec,
                              C.byref(bs.net), ptr(packed_s), ptr(win_s), ptr(four_s), ptr(bs.flat),
                              net_d, ptr(packed_d), ptr(win_d), ptr(four_d), ptr(bd.flat) if bd is not None else None,
@@ -261,14 +270,23 @@ def render_backward_raw(batch: _RayBatch, bs: FieldBinding, bd: Optional[FieldBi
 
 
 class _RenderFn(torch.autograd.Function):
-    """pix, sigma_s, sigma_d = fused(rays; params_s, params_d)."""
+    """pix, sigma_s, sigma_d = fused(rays; depths, dists; params_s, params_d).
+
+    ``z_in`` / ``dists_in`` are the tensors the caller passed (their values already sit in ``batch``): they are inputs only so
+    that autograd can ask for their gradients -- the reference's fine pass differentiates through its sampled depths and
+    through the ray-0 interval lengths (model_helpers.py:146-158)."""
 
     @staticmethod
-    def forward(ctx, batch: _RayBatch, bs: FieldBinding, bd: Optional[FieldBinding], n_s: int, *params):
+    def forward(ctx, batch: _RayBatch, bs: FieldBinding, bd: Optional[FieldBinding], n_s: int, z_in, dists_in, *params):
         # batch.record: autograd is recording this call (see render_rays) -- only then will a backward follow and only
         # then is the forward asked to keep its layer inputs
         pix, sig_s, sig_d, keep = render_forward_raw(batch, bs, bd, for_backward=getattr(batch, "record", False))
         ctx.batch, ctx.bs, ctx.bd, ctx.keep = batch, bs, bd, keep
+        ctx.z_shape = None if z_in is None else tuple(z_in.shape)
+        ctx.z_dtype = None if z_in is None else z_in.dtype
+        ctx.dists_dtype = None if dists_in is None else dists_in.dtype
+        if dists_in is not None and dists_in.requires_grad:
+            ctx.sig = (sig_s, sig_d)
         if not batch.f64:
             pix = pix.to(torch.float32)
         if bd is None:
@@ -277,14 +295,28 @@ class _RenderFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_pix, g_sig_s, g_sig_d=None):
-        bs, bd = ctx.bs, ctx.bd
-        grads_s, grads_d = render_backward_raw(ctx.batch, bs, bd, ctx.keep, g_pix, g_sig_s, g_sig_d)
+        bs, bd, batch = ctx.bs, ctx.bd, ctx.batch
+        want_z, want_dists = ctx.needs_input_grad[4], ctx.needs_input_grad[5]
+        res = render_backward_raw(batch, bs, bd, ctx.keep, g_pix, g_sig_s, g_sig_d, want_depth_grad=want_z)
+        grads_s, grads_d = res[0], res[1]
+        g_z = g_dists = None
+        if want_z:
+            g_z = res[2]
+            if len(ctx.z_shape) == 1:                 # one depth vector shared by all rays
+                g_z = g_z.sum(0)
+            g_z = g_z.to(ctx.z_dtype)
+        if want_dists:
+            # pix = I0 - sum_s (sigma_s + sigma_d) dists  (scaled sigmas; single field: sigma * scale), model_helpers.py:80-82, 92-95
+            sig_s, sig_d = ctx.sig
+            gp = torch.zeros(batch.R, dtype=torch.float64, device=sig_s.device) if g_pix is None else g_pix.to(torch.float64)
+            tot = (sig_s.double() * batch.scale) if bd is None else (sig_s + sig_d).double()
+            g_dists = -(gp[:, None] * tot).sum(0).to(ctx.dists_dtype)
         bs.last_grad = grads_s
         out = bs.split_grads(grads_s)
         if bd is not None:
             bd.last_grad = grads_d
             out = out + bd.split_grads(grads_d)
-        return (None, None, None, None, *out)
+        return (None, None, None, None, g_z, g_dists, *out)
 
 
 def fused_losses(pix, gt, wpix, sig_s, sig_d, dists, run_args, weights, inv_R=None, want_grads=True, weights_dev=None):
@@ -405,8 +437,10 @@ def render_rays(static_model, temp_model, origins, directions, phases, I0, z, di
     batch = _RayBatch(origins, directions, phases, I0, z, dists, act, single or bd is None, scale)
     params = bs.params() + (bd.params() if bd is not None else [])
     # (inside autograd.Function.forward grad mode is always off and needs_input_grad ignores torch.no_grad(): decide here)
-    batch.record = torch.is_grad_enabled() and any(p.requires_grad for p in params)
-    return _RenderFn.apply(batch, bs, bd, len(bs.params()), *params)
+    z_in = z if (torch.is_tensor(z) and z.requires_grad and torch.is_grad_enabled()) else None
+    dists_in = dists if (torch.is_tensor(dists) and dists.requires_grad and torch.is_grad_enabled()) else None
+    batch.record = torch.is_grad_enabled() and (any(p.requires_grad for p in params) or z_in is not None or dists_in is not None)
+    return _RenderFn.apply(batch, bs, bd, len(bs.params()), z_in, dists_in, *params)
 
 
 class _PointsFn(torch.autograd.Function):

@@ -112,17 +112,48 @@ def obtain_train_predictions_static(static_model, batch_origins, batch_direction
     return pix, sigma, dists
 
 
+class _BatchMax(torch.autograd.Function):
+    """torch.max(weights) of model_helpers.py:139 for a ray-sharded batch: the maximum over ALL ranks' rays (``reduce_max``
+    all-reduces the local maximum), and in the backward the summed upstream gradient of all ranks goes to the element that
+    attains it, on the rank that holds it -- what autograd does with the single-process maximum."""
+
+    @staticmethod
+    def forward(ctx, w, reduce_max):
+        local = w.max()
+        glob = local.detach().clone().reshape(1)
+        if reduce_max is not None:
+            reduce_max(glob)
+        ctx.reduce_max = reduce_max
+        ctx.save_for_backward(w, glob)
+        return glob.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        w, glob = ctx.saved_tensors
+        g = g.detach().clone().reshape(1)
+        if ctx.reduce_max is not None and getattr(ctx.reduce_max, "sum", None) is not None:
+            ctx.reduce_max.sum(g)
+        hit = (w == glob)
+        n = hit.sum()
+        gw = torch.where(hit, g / n.clamp(min=1).to(g.dtype), torch.zeros_like(g)).to(w.dtype) if bool(n > 0) else torch.zeros_like(w)
+        return gw, None
+
+
 def obtain_train_predictions_iter(static_model_coarse, temp_model_coarse, static_model_fine, temp_model_fine, batch_origins,
                                   batch_directions, batch_phases, batch_initial_intensities, depth_values, output_activation,
-                                  batch_size, depth_samples_per_ray_fine, device, t_rand=None, u_fine=None, reduce_max=None):
+                                  batch_size, depth_samples_per_ray_fine, device, t_rand=None, u_fine=None, reduce_max=None,
+                                  depth_gradients=None):
     """model_helpers.py:115-160 -> the reference's 8-tuple; the coarse pass is one fused launch.
 
     Fine pass (``depth_samples_per_ray_fine > 0``, off in the reference's configs): all eight outputs equal the reference's
-    (goldens with injected draws).  KNOWN DEVIATION in the backward: the reference never detaches the sampled depths, so its
-    autograd also differentiates the fine losses through ``sample_pdf`` / ``sort`` / the query points / the positional
-    encoding back into the COARSE nets (and through the ray-0 ``dists``).  Here the fine depths are constants of the step, as
-    in NeRF's own hierarchical sampling: coarse nets learn from the coarse terms, fine nets from the fine terms (fine-net
-    gradients equal the reference's; the omitted coarse-net term was measured at ~1e4 times the regular coarse gradient,
+    (goldens with injected draws).  The reference never detaches the sampled depths, so its autograd also differentiates the
+    fine losses through ``sample_pdf`` / ``sort`` / the query points / the positional encoding back into the COARSE nets (and
+    through the ray-0 ``dists``).  ``depth_gradients`` (default: on whenever autograd is recording and the fine nets run in
+    the f32 mode) does the same: the sampling runs as the reference's torch operations on the fused kernels' coarse fields
+    and the fused render returns d loss / d depth (``nca_render_bwd_depth``) and d loss / d dists.  With
+    ``depth_gradients=False`` (and always in bf16 mode) the depths come from the HIP sampling kernel and are constants of the
+    step, as in NeRF's own hierarchical sampling: forward values identical, fine-net gradients identical, the coarse nets
+    then learn from the coarse terms only (the through-depth term is ~1e4 times their regular gradient,
     tests/test_hip_parity.py::test_trainer_with_fine_pass_vs_oracle).  ``u_fine`` injects the uniform draw of ``sample_pdf``;
     ``reduce_max`` (ray-sharded batches) makes the batch-wide weight maximum global, see ``fused.fine_depths``."""
     z = randomize_depth(depth_values, device, t_rand)
@@ -134,8 +165,22 @@ def obtain_train_predictions_iter(static_model_coarse, temp_model_coarse, static
         R, n_coarse = pix_c.shape[0], z.shape[0]
         if u_fine is None:                                         # the draw comes from the CPU generator, as in the reference
             u_fine = torch.rand(R, depth_samples_per_ray_fine)
-        # weights (batch-wide max, :139), sample_pdf and sort(cat[fine, coarse]) in one HIP pass per ray
-        z_all = _fused.fine_depths(sig_s_c, sig_d_c, z, u_fine, reduce_max=reduce_max)
+        if depth_gradients is None:            # the reference's behaviour wherever the backward can follow it: f32 nets, autograd recording
+            depth_gradients = bool(torch.is_grad_enabled() and sig_s_c.requires_grad
+                                   and static_model_fine._binding.prec == _fused._capi.PREC_F32 and temp_model_fine._binding.prec == _fused._capi.PREC_F32)
+        if depth_gradients:
+            # the reference's own operations (model_helpers.py:135-146), under autograd: the sampled depths carry the graph
+            # back to the coarse sigmas; the fused render below returns d loss / d depth (nca_render_bwd_depth)
+            tot = sig_s_c + sig_d_c
+            w = torch.cat([torch.ones_like(tot[:, :1]) * 1e-10, torch.abs(tot[:, 1:] - tot[:, :-1])], dim=-1)
+            w = w / _BatchMax.apply(w, reduce_max)
+            zrep = z[None, :].repeat(R, 1)
+            mid = 0.5 * (zrep[..., 1:] + zrep[..., :-1])
+            z_pdf = sample_pdf(mid, w[..., 1:-1], depth_samples_per_ray_fine, device, u=u_fine.to(device))
+            z_all, _ = torch.sort(torch.cat([z_pdf, zrep.detach()], -1), -1)
+        else:
+            # weights (batch-wide max, :139), sample_pdf and sort(cat[fine, coarse]) in one HIP pass per ray
+            z_all = _fused.fine_depths(sig_s_c, sig_d_c, z, u_fine, reduce_max=reduce_max)
         z0 = z_all[0, :]                                           # dists of ray 0 for every ray (model_helpers.py:150)
         dists_f = _interval_lengths(z0, batch_directions)
         phase_per_ray = batch_phases[:, 0] if batch_phases.dim() > 1 else batch_phases

@@ -25,6 +25,7 @@ class TrainConfig:
     """The hot-path keys of train/composite.txt (defaults = that file)."""
     depth_samples_per_ray_coarse: int = 500
     depth_samples_per_ray_fine: int = 0            # composite.txt:26; > 0 needs the fine model pair (run_composite.py:194-207)
+    fine_depth_gradients: Optional[bool] = None    # as the reference, the fine losses also differentiate through the sampled depths; None = yes in f32 mode
     img_sample_size: int = 1024
     batch_size: int = 32768
     lr: float = 1e-3
@@ -54,6 +55,36 @@ class TrainConfig:
     temp_pos_enc: str = "free_windowed"
     static_pos_enc_window_decay_steps: int = 150000
     temp_pos_enc_window_decay_steps: int = 150000
+
+
+class _MaxReducer:
+    """reduce_max of the fine pass under ray sharding: called on a tensor it takes the maximum over the ranks in place;
+    ``sum`` adds over the ranks (the backward of that maximum, model_helpers._BatchMax)."""
+
+    def __call__(self, t):
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+
+    @staticmethod
+    def sum(t):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+
+class _FromRank0(torch.autograd.Function):
+    """Ray 0 of the GLOBAL batch sits on rank 0: every rank renders its fine pass with that ray's depths (model_helpers.py:150).
+    Forward: broadcast; backward: the ranks' gradients are summed and handed to rank 0's ray."""
+
+    @staticmethod
+    def forward(ctx, z0, rank):
+        ctx.rank = rank
+        out = z0.detach().clone()
+        dist.broadcast(out, src=0)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.detach().clone()
+        dist.all_reduce(g, op=dist.ReduceOp.SUM)
+        return (g if ctx.rank == 0 else torch.zeros_like(g)), None
 
 
 class CompositeTrainer:
@@ -172,12 +203,28 @@ class CompositeTrainer:
             # interval lengths from ray 0 of the GLOBAL batch (:150) -> broadcast from rank 0.  The sampled depths are
             # constants of the step (see the note in model_helpers.obtain_train_predictions_iter).
             sharded = self.world > 1
-            red = (lambda t: dist.all_reduce(t, op=dist.ReduceOp.MAX)) if sharded else None
+            red = _MaxReducer() if sharded else None
             u = self.draw_fine_u(n_iter)[lo:hi].to(self.device)
-            z_all = self.fine_sampler(sig_s.detach(), sig_d.detach(), z, u, reduce_max=red)
-            z0 = z_all[0, :].clone()
-            if sharded:
-                dist.broadcast(z0, src=0)
+            diff = c.fine_depth_gradients
+            if diff is None:
+                diff = all(getattr(getattr(m, "_binding", None), "prec", None) == MH._fused._capi.PREC_F32 for m in (self.s_fine, self.t_fine))
+            if diff:
+                # as the reference: the sampled depths stay in the autograd graph (model_helpers.py:135-146) and the fused
+                # render returns d loss / d depth, so the fine losses also reach the COARSE nets; the batch-wide maximum and
+                # ray 0's depths cross the ranks in both directions
+                tot = sig_s + sig_d
+                wts = torch.cat([torch.ones_like(tot[:, :1]) * 1e-10, torch.abs(tot[:, 1:] - tot[:, :-1])], dim=-1)
+                wts = wts / MH._BatchMax.apply(wts, red)
+                zrep = z[None, :].repeat(hi - lo, 1)
+                mid = 0.5 * (zrep[..., 1:] + zrep[..., :-1])
+                z_pdf = MH.sample_pdf(mid, wts[..., 1:-1], self.n_fine, self.device, u=u)
+                z_all, _ = torch.sort(torch.cat([z_pdf, zrep.detach()], -1), -1)
+                z0 = _FromRank0.apply(z_all[0, :], self.rank) if sharded else z_all[0, :]
+            else:
+                z_all = self.fine_sampler(sig_s.detach(), sig_d.detach(), z, u, reduce_max=red)
+                z0 = z_all[0, :].clone()
+                if sharded:
+                    dist.broadcast(z0, src=0)
             dists_f = MH._interval_lengths(z0, d)
             pix_f, sig_sf, sig_df = self.render(self.s_fine, self.t_fine, o, d, phases, self.I0[: hi - lo], z_all, dists_f,
                                                 act=c.output_activation)

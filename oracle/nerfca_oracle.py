@@ -335,7 +335,8 @@ def predict_iter(ps, spec_s, win_s, pd, spec_d, win_d, origins, directions, phas
     Returns the reference's 8-tuple.
     """
     R, S = origins.shape[0], z_jit.shape[0]
-    pts = query_points(origins, directions, z_jit)
+    dt = next(iter(ps.values())).dtype       # f32 as the reference; f64 parameters give the f64 check run of the tests
+    pts = query_points(origins, directions, z_jit).to(dt)
     ph = phases.flatten().int()
     raw_s = static_forward(ps, spec_s, pts, win_s).reshape(R, S, -1)
     raw_d = dynamic_forward(pd, spec_d, pts, ph, win_d).reshape(R, S, -1)
@@ -358,7 +359,7 @@ def predict_iter(ps, spec_s, win_s, pd, spec_d, win_d, origins, directions, phas
             # NOT the reference's behaviour (its autograd differentiates through sample_pdf, the sort and the query points
             # into the coarse nets): only there to quantify the drop-in's documented deviation in the tests.
             z_all = z_all.detach()
-        pts_f = query_points(origins, directions, z_all)
+        pts_f = query_points(origins, directions, z_all).to(dt)
         z0 = z_all[0, :]  # dists from ray 0 only (model_helpers.py:150)
         ph_f = phases[:, 0, None].repeat(1, tot).flatten()
         raw_sf = static_forward(fine["ps"], fine["spec_s"], pts_f, fine["win_s"]).reshape(R, tot, -1)

@@ -80,9 +80,10 @@ def build(seed=0):
     return cfg, s, t, data, dev, CompositeTrainer
 
 
-def run_steps(rank, world, n_steps=2, n_fine=0):
+def run_steps(rank, world, n_steps=2, n_fine=0, depth_grads=False):
     cfg, s, t, data, dev, CompositeTrainer = build()
     kw = {}
+    cfg.fine_depth_gradients = depth_grads
     if n_fine:
         from nerfca_amd import synthetic
         from nerfca_amd.model.CPPN import CPPN
@@ -101,13 +102,13 @@ def run_steps(rank, world, n_steps=2, n_fine=0):
     return grads, params
 
 
-def _worker(rank, world, port, outdir, n_fine=0):
+def _worker(rank, world, port, outdir, n_fine=0, depth_grads=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        g, p = run_steps(rank, world, n_fine=n_fine)
+        g, p = run_steps(rank, world, n_fine=n_fine, depth_grads=depth_grads)
         torch.save({"g": g, "p": p}, os.path.join(outdir, f"rank{rank}.pt"))
     finally:
         dist.destroy_process_group()
@@ -150,6 +151,28 @@ def test_two_rank_step_with_fine_pass_equals_one_rank_step(tmp_path):
     perr = float((r0["p"] - p1).abs().max() / p1.abs().max())
     assert gerr < 1e-5, gerr
     assert perr < 1e-5, perr
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_step_with_depth_gradients_equals_one_rank_step(tmp_path):
+    """fine_depth_gradients (the reference's undetached fine depths) under sharding: the backward of the batch-wide maximum sums
+    its upstream gradient over the ranks and hands it to the rank holding the maximum; the gradient of ray 0's depths is summed
+    over the ranks and handed to rank 0.  Two ranks = one rank up to f32 reduction order ON THIS PATH, whose terms carry
+    2^k cos(2^k p) factors (1e-4; the detached case above stays at 1e-5) -- and the gradient is not the detached one."""
+    torch.set_num_threads(2)
+    g1, p1 = run_steps(0, 1, n_fine=6, depth_grads=True)
+    g0, _ = run_steps(0, 1, n_fine=6, depth_grads=False)
+    assert float((g1 - g0).abs().max() / g0.abs().max()) > 1e-2          # the through-depth term is there
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), 6, True), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "rank0.pt")
+    r1 = torch.load(tmp_path / "rank1.pt")
+    assert torch.equal(r0["g"], r1["g"]) and torch.equal(r0["p"], r1["p"])
+    gerr = float((r0["g"] - g1).abs().max() / g1.abs().max())
+    perr = float((r0["p"] - p1).abs().max() / p1.abs().max())
+    assert gerr < 1e-4, gerr
+    # parameters after two Adam steps: Adam divides by sqrt(v), so the noise of this path on near-zero gradient components
+    # moves parameters by O(lr); the bound only guards against a wrong step
+    assert perr < 1e-2, perr
 
 
 def test_shards_partition_the_global_batch():

@@ -482,7 +482,7 @@ def test_trainer_with_fine_pass_vs_oracle(dev):
     data = synthetic.make_dataset(16, S, dev, views=synthetic.TRAIN_VIEWS[:2], n_phases=3, F=32)
     cfg = TrainConfig(depth_samples_per_ray_coarse=S, depth_samples_per_ray_fine=NF, img_sample_size=R, favor_s_weight_delay_steps=0,
                       l1_weight_start=1e-3, l1_weight_end=1e-3, occl_weight_start=1e-2, dynamic_entro_weight_start=1e-3,
-                      favor_s_weight_start=1e-3, entro_mask_thre=1e-6)
+                      favor_s_weight_start=1e-3, entro_mask_thre=1e-6, fine_depth_gradients=False)    # (the reference's undetached depths: last part)
 
     def nets():
         torch.manual_seed(21)
@@ -518,10 +518,11 @@ def test_trainer_with_fine_pass_vs_oracle(dev):
     sargs = O.ScheduleArgs(favor_s_weight_start=cfg.favor_s_weight_start, favor_s_weight_delay_steps=0, l1_weight_start=1e-3, l1_weight_end=1e-3,
                            occl_weight_start=1e-2, dynamic_entro_weight_start=1e-3)
 
-    def oracle_grads(detach, z_all=None):
-        P = [{k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.named_parameters()} for m in (s, t, sf, tf)]
-        fine = dict(ps=P[2], spec_s=specs[2], win_s=win, pd=P[3], spec_d=specs[3], win_d=win, n_fine=NF, u=u, detach_depths=detach, z_all=z_all)
-        out = O.predict_iter(P[0], specs[0], win, P[1], specs[1], win, o, d, ph[:, None].repeat(1, S), I0, z, "softplus", fine=fine)
+    def oracle_grads(detach, z_all=None, dt=torch.float32):
+        P = [{k: v.detach().cpu().clone().to(dt).requires_grad_(True) for k, v in m.named_parameters()} for m in (s, t, sf, tf)]
+        win_ = win.to(dt)
+        fine = dict(ps=P[2], spec_s=specs[2], win_s=win_, pd=P[3], spec_d=specs[3], win_d=win_, n_fine=NF, u=u, detach_depths=detach, z_all=z_all)
+        out = O.predict_iter(P[0], specs[0], win_, P[1], specs[1], win_, o, d, ph[:, None].repeat(1, S), I0.to(dt), z, "softplus", fine=fine)
         lc, _, _ = O.composite_total_loss(out[0], out[1], out[2], out[3], gt, w, n_iter, largs, sargs)
         # the fine regularisers use the weighted pixel weights, only its MSE uses ones (run_composite.py:297-300)
         tf_terms = O.compute_losses(out[5], out[6], out[7], w, largs)
@@ -561,6 +562,35 @@ def test_trainer_with_fine_pass_vs_oracle(dev):
     assert l1 == l1 and l0 == l0                              # finite
     with pytest.raises(NotImplementedError):
         tr2.step_graph(n_iter)
+
+    # fine_depth_gradients=True: the sampled depths stay in the graph as in the reference (torch sample_pdf / sort on the HIP
+    # kernels' coarse fields, d loss / d depth from nca_render_bwd_depth): ALL gradients against the oracle's undetached
+    # run.  The omitted term printed above (~1e4 x the regular coarse gradient) is now there; the tolerance is that of the
+    # sampler's conditioning (depths that differ in the last bits enter through 2^k cos(2^k p)), not of the kernels -- those
+    # have their own 1e-5 test (test_depth_gradient_vs_oracle).
+    import dataclasses
+    s3, t3, sf3, tf3 = nets()
+    tr3 = CompositeTrainer(dataclasses.replace(cfg, fine_depth_gradients=True), s3, t3, data, dev, seed=5, static_model_fine=sf3, temp_model_fine=tf3)
+    tr3.update_windows(n_iter)
+    loss3, _, _ = tr3.local_loss(n_iter, ids, t_rand)
+    loss3.backward()
+    assert abs(float(loss3) - full_loss) <= 1e-3 * abs(full_loss)
+    try:
+        _, full64 = oracle_grads(detach=False, dt=torch.float64)
+    except Exception as exc:      # the oracle's f64 path is a convenience here, not a requirement
+        full64 = None
+        print("f64 oracle run failed:", exc)
+    worst = own = 0.0
+    for i, (m, fg, name) in enumerate(zip((s3, t3, sf3, tf3), full, ("static", "dynamic", "static_fine", "dynamic_fine"))):
+        for k, p in m.named_parameters():
+            if float(fg[k].abs().max()) > 0:
+                e = rel_err(p.grad.cpu(), fg[k])
+                worst = max(worst, e)
+                if full64 is not None:
+                    own = max(own, rel_err(fg[k], full64[i][k]))
+    print(f"with fine_depth_gradients: all gradients within {worst:.2e} of the oracle's undetached (reference) gradients; "
+          f"the f32 oracle itself is within {own:.2e} of its f64 run")
+    assert worst < max(5e-2, 3 * own)
 
 
 @pytest.mark.parametrize("R,S", [(8, 16), (64, 192)])
@@ -734,6 +764,86 @@ def test_bf16_other_encodings_vs_emulating_oracle(golden, dev, enc):
         assert rel_err(gs[k], pso[k].grad) < BF_GRAD, ("static", k)
     for k in pdo:
         assert rel_err(gd[k], pdo[k].grad) < BF_GRAD, ("dynamic", k)
+
+
+@pytest.mark.parametrize("enc,F,ray_dt", [("free_windowed", 128, torch.float64), ("free_windowed", 32, torch.float32), ("nerfies_windowed", 64, torch.float64),
+                                          ("none", 64, torch.float64), ("fourier", 64, torch.float64), ("single", 64, torch.float64)])
+def test_depth_gradient_vs_oracle(golden, dev, enc, F, ray_dt):
+    """nca_render_bwd_depth: d loss / d depth of every sample (the path the reference's fine pass differentiates along:
+    depth -> query point -> positional encoding -> first layer, model_helpers.py:146-148) and d loss / d dists (ray-0 interval
+    lengths, :150-158), against autograd through the f64 oracle on the same per-ray depths; parameter gradients of the same
+    call unchanged.  1e-5 of each tensor's max-norm (the mask-flip allowance of the other gradient tests applies)."""
+    from nerfca_amd import render_rays
+    g = golden("mlps")
+    single = enc == "single"
+    penc = "free_windowed" if single else enc
+    gen = torch.Generator().manual_seed(1234 + F)
+    L = 0 if penc == "none" else (6 if penc in ("fourier", "nerfies_windowed") else 12)
+    gauss = g["enc_fourier_gauss"] if penc == "fourier" else None
+    coef = gauss * 3 if penc == "fourier" else None
+    ss = O.NetSpec(num_filters=F, num_early_layers=2, pos_enc=penc, pos_enc_basis=L, fourier_coefficients=coef)
+    sd = O.NetSpec(num_filters=F, num_early_layers=2, pos_enc=penc, pos_enc_basis=L, fourier_coefficients=coef, num_time_dim=8)
+    ps, pd = O.init_params(ss, gen), O.init_params(sd, gen)
+    s = make_static(ps, dev, F=F, early=2, late=0, pos_enc=penc, L=L, gauss=gauss, sigma=3)
+    t = None if single else make_dynamic(pd, dev, F=F, early=2, late=0, pos_enc=penc, L=L, T=8, gauss=gauss, sigma=3)
+    win = None
+    if penc == "free_windowed":
+        for m in (s, t):
+            if m is not None:
+                m.update_freq_mask_alpha(60000, 150000)
+        win = O.freq_mask_alpha(12, 60000, 150000, 1)[0]
+    elif penc == "nerfies_windowed":
+        for m in (s, t):
+            m.update_windowed_alpha(30000, 100000)
+        win = O.nerfies_window(L, O.windowed_alpha(L, 30000, 100000))
+    R, S = 7, 45
+    o = (torch.rand(R, 3, generator=gen) * 0.2 + torch.tensor([3.0, -2.0, 2.5])).to(ray_dt)
+    d = (torch.rand(R, 3, generator=gen) - 0.5).to(ray_dt)
+    ph = torch.randint(0, 10, (R,), generator=gen)
+    z_all = torch.sort(3.4259 + (5.5741 - 3.4259) * torch.rand(R, S, generator=gen), -1)[0]
+    I0 = torch.full((R,), 2.15991)
+    cp, cs, cd = torch.randn(R, generator=gen).double(), torch.randn(R, S, generator=gen), torch.randn(R, S, generator=gen)
+
+    def tail(z0, like):
+        return torch.cat((z0[1:] - z0[:-1], torch.tensor([1e-10], dtype=like.dtype, device=z0.device)), -1)
+
+    def oracle(dt):
+        pso = {k: v.clone().to(dt).requires_grad_(True) for k, v in ps.items()}
+        pdo = {k: v.clone().to(dt).requires_grad_(True) for k, v in pd.items()}
+        zo = z_all.clone().requires_grad_(True)
+        pts = O.query_points(o, d, zo).to(dt)
+        dists = tail(zo[0, :].to(ray_dt), d)
+        f = O.activation("softplus")
+        w_ = None if win is None else win.to(dt)
+        raw_s = O.static_forward(pso, ss, pts, w_).reshape(R, S)
+        if single:
+            sig = f(raw_s)
+            pix = I0.to(dt) - torch.sum(sig * dists * 1e-2, -1)
+            loss = (pix * cp).sum() + (sig * cs).sum() * 50
+        else:
+            raw_d = O.dynamic_forward(pdo, sd, pts, ph[:, None].repeat(1, S).flatten(), w_).reshape(R, S)
+            a_, b_ = f(raw_s) * 1e-2, f(raw_d) * 1e-2
+            pix = I0.to(dt) - torch.sum((a_ + b_) * dists, -1)
+            loss = (pix * cp).sum() + (a_ * cs).sum() * 50 + (b_ * cd).sum() * 50
+        loss.backward()
+        return zo.grad, pso, pdo
+
+    gz64, ps64, pd64 = oracle(torch.float64)
+    gz32, ps32, pd32 = oracle(torch.float32)
+    zt = z_all.to(dev).requires_grad_(True)
+    dists_t = tail(zt[0, :].to(ray_dt), d.to(dev))
+    out = render_rays(s, t, o.to(dev), d.to(dev), None if single else ph.to(dev), I0.to(dev), zt, dists_t, single=single)
+    if single:
+        (out[0] * cp.to(dev)).sum().add((out[1] * cs.to(dev)).sum() * 50).backward()
+    else:
+        ((out[0] * cp.to(dev)).sum() + (out[1] * cs.to(dev)).sum() * 50 + (out[2] * cd.to(dev)).sum() * 50).backward()
+    tol = max(TOL, 3 * rel_err(gz32, gz64))
+    assert rel_err(zt.grad.cpu(), gz64) < tol, (rel_err(zt.grad.cpu(), gz64), tol)
+    for k, p_ in s.named_parameters():
+        assert rel_err(p_.grad.cpu(), ps64[k].grad) < max(TOL, 3 * rel_err(ps32[k].grad, ps64[k].grad)), ("static", k)
+    if not single:
+        for k, p_ in t.named_parameters():
+            assert rel_err(p_.grad.cpu(), pd64[k].grad) < max(TOL, 3 * rel_err(pd32[k].grad, pd64[k].grad)), ("dynamic", k)
 
 
 @pytest.mark.parametrize("prec", ["f32", "bf16"])
