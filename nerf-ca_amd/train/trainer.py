@@ -200,8 +200,9 @@ class CompositeTrainer:
         if self.n_fine > 0:
             # hierarchical pass (model_helpers.py:131-158, run_composite.py:294-301).  The weights are normalised by the
             # maximum over the GLOBAL batch (:139) -> MAX all-reduce inside the sampler; the fine rendering takes its
-            # interval lengths from ray 0 of the GLOBAL batch (:150) -> broadcast from rank 0.  The sampled depths are
-            # constants of the step (see the note in model_helpers.obtain_train_predictions_iter).
+            # interval lengths from ray 0 of the GLOBAL batch (:150) -> broadcast from rank 0.  The sampled depths stay in
+            # the autograd graph as in the reference (f32 mode) or are constants of the step (bf16 mode,
+            # fine_depth_gradients=False); see model_helpers.obtain_train_predictions_iter.
             sharded = self.world > 1
             red = _MaxReducer() if sharded else None
             u = self.draw_fine_u(n_iter)[lo:hi].to(self.device)
