@@ -584,7 +584,6 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
         if (bf) return fail(NCA_E_UNSUPPORTED, "depth gradients are formed in the f32 mode only");
         if (a.mode != NCA_MODE_RAYS) return fail(NCA_E_INVALID, "depth gradients need a ray batch");
         for (int n = 0; n < a.nnets; ++n) {
-            if (binds[n].net->n_late > 0) return fail(NCA_E_UNSUPPORTED, "depth gradients with skip layers are not built");
             if (lays[n].Kenc > 96) return fail(NCA_E_UNSUPPORTED, "depth gradients: more than 96 encoded features");
         }
     }
@@ -731,10 +730,15 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
             zg.g_z = g_depth;
             for (int n = 0; n < a.nnets; ++n) {
                 NcaZgradNet& zn = zg.net[n];
-                zn.w0 = binds[n].params + lays[n].layer[0].w_off;
-                zn.ldw = lays[n].layer[0].K; zn.F = lays[n].F; zn.enc_mode = lays[n].enc_mode; zn.L = lays[n].L; zn.Kenc = lays[n].Kenc;
+                zn.F = lays[n].F; zn.enc_mode = lays[n].enc_mode; zn.L = lays[n].L; zn.Kenc = lays[n].Kenc;
                 zn.win = a.net[n].win; zn.four = a.net[n].four;
-                zn.drow0 = a.net[n].drow0;
+                for (int j = 0; j < lays[n].NL; ++j) {       // every layer that reads the encoded input: layer 0 and a skip layer
+                    if (lays[n].layer[j].kind == NCA_IN_HID || zn.nsrc >= 2) continue;
+                    zn.w[zn.nsrc] = binds[n].params + lays[n].layer[j].w_off;
+                    zn.ldw[zn.nsrc] = lays[n].layer[j].K;
+                    zn.drow[zn.nsrc] = a.net[n].drow0 + (int64_t)j * lays[n].F;
+                    ++zn.nsrc;
+                }
             }
             HIPCHK(nca_launch_zgrad_f32(zg, st));
         }

@@ -219,11 +219,15 @@ int64_t nca_loss_partials_bytes(int64_t R);
 // positional encoding -> first layer; train/model_helpers.py:147-148): from the first layer's output gradient D_0 that the f32
 // backward leaves in its chunk scratch
 struct NcaZgradNet {
-    const float* w0;      // natural first-layer weight [F][ldw]
-    int32_t ldw, F, enc_mode, L, Kenc, pad;
+    // the layers that read the encoded input: the first one and, in a net with late layers, the skip layer (cat[enc, h],
+    // model/CPPN.py:99-103) -- natural weight [F][ldw] whose first Kenc columns meet the encoding, and the first row of the
+    // layer's D block inside a tile of the D region
+    const float* w[2];
+    int32_t ldw[2];
+    int64_t drow[2];
+    int32_t nsrc, F, enc_mode, L, Kenc, pad;
     const float* win;     // band weights (or null)
     const float* four;    // fourier coefficients (or null)
-    int64_t drow0;        // first row of this net's D_0 block inside a tile of the D region
 };
 struct NcaZgradArgs {
     int32_t nnets, S, nchunk, ray_is_f64;

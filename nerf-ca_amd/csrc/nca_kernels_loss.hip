@@ -489,12 +489,15 @@ hipError_t nca_launch_fine(const NcaFineArgs& a, hipStream_t st) {
 __global__ __launch_bounds__(256) void nca_zgrad_f32(const NcaZgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float zw[];        // [F][ZG_KPAD]: encoded columns of W0, zero padded
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 31, lh = lane >> 5;
-    for (int net = 0; net < a.nnets; ++net) {
+    for (int pass = 0; pass < 2 * a.nnets; ++pass) {
+        const int net = pass >> 1, src = pass & 1;
         const NcaZgradNet& nn = a.net[net];
+        if (src >= nn.nsrc) continue;              // (uniform over the block)
+        const bool first = pass == 0;              // the first pass writes g_z, the others add to it
         __syncthreads();
         for (int i = threadIdx.x; i < nn.F * ZG_KPAD; i += 256) {
             const int o = i / ZG_KPAD, f = i % ZG_KPAD;
-            zw[i] = f < nn.Kenc ? nn.w0[(int64_t)o * nn.ldw + f] : 0.f;
+            zw[i] = f < nn.Kenc ? nn.w[src][(int64_t)o * nn.ldw[src] + f] : 0.f;
         }
         __syncthreads();
         const int MT = nn.F / 32;
@@ -503,7 +506,7 @@ __global__ __launch_bounds__(256) void nca_zgrad_f32(const NcaZgradArgs a) {
             int smp = (int)(tile % a.nchunk) * 32 + lr;
             const bool valid = smp < a.S;
             if (!valid) smp = a.S - 1;
-            const float* dblk = a.dscratch + (tile * a.d_total + nn.drow0) * 32 + lane * 4;
+            const float* dblk = a.dscratch + (tile * a.d_total + nn.drow[src]) * 32 + lane * 4;
             float G[ZG_KPAD];
 #pragma unroll
             for (int f = 0; f < ZG_KPAD; ++f) G[f] = 0.f;
@@ -571,7 +574,7 @@ __global__ __launch_bounds__(256) void nca_zgrad_f32(const NcaZgradArgs a) {
             const double gz = dd[0] * dp[0] + dd[1] * dp[1] + dd[2] * dp[2];
             if (valid && lh == 0) {
                 float* dst = a.g_z + ray * a.S + smp;
-                *dst = net == 0 ? (float)gz : *dst + (float)gz;
+                *dst = first ? (float)gz : *dst + (float)gz;
             }
         }
     }

@@ -767,7 +767,8 @@ def test_bf16_other_encodings_vs_emulating_oracle(golden, dev, enc):
 
 
 @pytest.mark.parametrize("enc,F,ray_dt", [("free_windowed", 128, torch.float64), ("free_windowed", 32, torch.float32), ("nerfies_windowed", 64, torch.float64),
-                                          ("none", 64, torch.float64), ("fourier", 64, torch.float64), ("single", 64, torch.float64)])
+                                          ("none", 64, torch.float64), ("fourier", 64, torch.float64), ("single", 64, torch.float64),
+                                          ("single_late", 128, torch.float64)])
 def test_depth_gradient_vs_oracle(golden, dev, enc, F, ray_dt):
     """nca_render_bwd_depth: d loss / d depth of every sample (the path the reference's fine pass differentiates along:
     depth -> query point -> positional encoding -> first layer, model_helpers.py:146-148) and d loss / d dists (ray-0 interval
@@ -775,16 +776,17 @@ def test_depth_gradient_vs_oracle(golden, dev, enc, F, ray_dt):
     call unchanged.  1e-5 of each tensor's max-norm (the mask-flip allowance of the other gradient tests applies)."""
     from nerfca_amd import render_rays
     g = golden("mlps")
-    single = enc == "single"
+    single = enc.startswith("single")
+    late = 2 if enc == "single_late" else 0          # a skip layer reads the encoded input as well (CPPN only)
     penc = "free_windowed" if single else enc
     gen = torch.Generator().manual_seed(1234 + F)
     L = 0 if penc == "none" else (6 if penc in ("fourier", "nerfies_windowed") else 12)
     gauss = g["enc_fourier_gauss"] if penc == "fourier" else None
     coef = gauss * 3 if penc == "fourier" else None
-    ss = O.NetSpec(num_filters=F, num_early_layers=2, pos_enc=penc, pos_enc_basis=L, fourier_coefficients=coef)
+    ss = O.NetSpec(num_filters=F, num_early_layers=2, num_late_layers=late, pos_enc=penc, pos_enc_basis=L, fourier_coefficients=coef)
     sd = O.NetSpec(num_filters=F, num_early_layers=2, pos_enc=penc, pos_enc_basis=L, fourier_coefficients=coef, num_time_dim=8)
     ps, pd = O.init_params(ss, gen), O.init_params(sd, gen)
-    s = make_static(ps, dev, F=F, early=2, late=0, pos_enc=penc, L=L, gauss=gauss, sigma=3)
+    s = make_static(ps, dev, F=F, early=2, late=late, pos_enc=penc, L=L, gauss=gauss, sigma=3)
     t = None if single else make_dynamic(pd, dev, F=F, early=2, late=0, pos_enc=penc, L=L, T=8, gauss=gauss, sigma=3)
     win = None
     if penc == "free_windowed":
