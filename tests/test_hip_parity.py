@@ -848,6 +848,46 @@ def test_depth_gradient_vs_oracle(golden, dev, enc, F, ray_dt):
             assert rel_err(p_.grad.cpu(), pd64[k].grad) < max(TOL, 3 * rel_err(pd32[k].grad, pd64[k].grad)), ("dynamic", k)
 
 
+@pytest.mark.parametrize("limit,ws", [(0, 6 << 30), (96 << 30, 1 << 20), (0, 1 << 20)])
+def test_depth_gradient_store_recompute_and_chunks(dev, limit, ws):
+    """d loss / d depth does not depend on how the backward is run: from the forward's store or with recompute, in one ray
+    chunk or in many (a 1 MiB workspace: one ray per chunk) -- each against the default run (store, one chunk)."""
+    from nerfca_amd import fused, render_rays
+    gen = torch.Generator().manual_seed(99)
+    ss, sd = O.NetSpec(num_filters=64, num_early_layers=2), O.NetSpec(num_filters=64, num_early_layers=2, num_time_dim=8)
+    s = make_static(O.init_params(ss, gen), dev, F=64, early=2, late=0)
+    t = make_dynamic(O.init_params(sd, gen), dev, F=64, early=2, late=0, T=8)
+    for m in (s, t):
+        m.update_freq_mask_alpha(60000, 150000)
+    R, S = 19, 70
+    o = (torch.rand(R, 3, generator=gen) * 0.2 + torch.tensor([3.0, -2.0, 2.5])).double().to(dev)
+    d = (torch.rand(R, 3, generator=gen) - 0.5).double().to(dev)
+    ph = torch.randint(0, 10, (R,), generator=gen).to(dev)
+    z_all = torch.sort(3.4259 + (5.5741 - 3.4259) * torch.rand(R, S, generator=gen), -1)[0].to(dev)
+    I0 = torch.full((R,), 2.15991, device=dev)
+    cp, cs, cd = torch.randn(R, generator=gen).double().to(dev), torch.randn(R, S, generator=gen).to(dev), torch.randn(R, S, generator=gen).to(dev)
+
+    def run():
+        for m in (s, t):
+            m.zero_grad()
+        zt = z_all.clone().requires_grad_(True)
+        z0 = zt[0, :].double()
+        dists = torch.cat((z0[1:] - z0[:-1], torch.tensor([1e-10], dtype=torch.float64, device=dev)), -1)
+        pix, a, b = render_rays(s, t, o, d, ph, I0, zt, dists)
+        ((pix * cp).sum() + (a * cs).sum() * 50 + (b * cd).sum() * 50).backward()
+        return zt.grad.clone(), torch.cat([p.grad.flatten() for p in list(s.parameters()) + list(t.parameters())])
+
+    gz0, gp0 = run()
+    saved = fused.STORE_FORWARD_LIMIT_BYTES, fused.BWD_WORKSPACE_BYTES
+    try:
+        fused.STORE_FORWARD_LIMIT_BYTES, fused.BWD_WORKSPACE_BYTES = limit, ws
+        gz1, gp1 = run()
+    finally:
+        fused.STORE_FORWARD_LIMIT_BYTES, fused.BWD_WORKSPACE_BYTES = saved
+    assert float(gz0.abs().max()) > 0
+    assert rel_err(gz1, gz0) < 2e-6 and rel_err(gp1, gp0) < 2e-6
+
+
 @pytest.mark.parametrize("prec", ["f32", "bf16"])
 def test_nets_of_different_width(dev, prec):
     """static_num_filters != temp_num_filters: per-net fused launches + compositing kernel; outputs and all
