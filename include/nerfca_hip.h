@@ -140,7 +140,7 @@ int nca_render_bwd(const NcaRays* rays, int32_t prec,
 /* The same, and d loss / d depth of every sample into g_depth f32[R,S] (NULL: as nca_render_bwd).  The reference's fine pass
  * does not detach its sampled depths: the fine losses reach them through the query point, the positional encoding and the
  * first layer -- and the skip layer, where a net has one -- (train/model_helpers.py:146-148), and through them the coarse
- * nets.  f32 mode, nets of one width. */
+ * nets.  Nets of one width. */
 int nca_render_bwd_depth(const NcaRays* rays, int32_t prec,
                    const NcaNet* net_s, const void* packed_s, const float* win_s, const float* four_s, const float* params_s,
                    const NcaNet* net_d, const void* packed_d, const float* win_d, const float* four_d, const float* params_d,

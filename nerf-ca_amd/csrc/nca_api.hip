@@ -581,7 +581,6 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     NcaLayout lays[2];
     for (int n = 0; n < a.nnets; ++n) lays[n] = a.net[n].lay;
     if (g_depth) {
-        if (bf) return fail(NCA_E_UNSUPPORTED, "depth gradients are formed in the f32 mode only");
         if (a.mode != NCA_MODE_RAYS) return fail(NCA_E_INVALID, "depth gradients need a ray batch");
         for (int n = 0; n < a.nnets; ++n) {
             if (lays[n].Kenc > 96) return fail(NCA_E_UNSUPPORTED, "depth gradients: more than 96 encoded features");
@@ -648,6 +647,7 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     memset(&wp, 0, sizeof(wp));
     for (int n = 0; n < a.nnets; ++n) {
         const int np = stored ? nca_pairs(lays[n], prec) : 0;
+        if (np > 0 && g_depth) return fail(NCA_E_UNSUPPORTED, "depth gradients need D_0, which the paired weight-gradient jobs (NCA_PAIR=1) do not store");
         if (stored) set_skip_bits(&a.net[n], prec); else { a.net[n].skip_h = 0; a.net[n].skip_d = 0; }
         if (wp.npairs + np > NCA_MAX_PAIRS) return fail(NCA_E_UNSUPPORTED, "too many paired wgrad jobs");
         if (bf) add_jobs_bf16(&w, &wp, np, n, binds[n].packed, lays[n], a.net[n].row0, a.net[n].drow0, slab_off[n], onehot_off[n],
@@ -723,8 +723,11 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
         if (g_depth) {       // d loss / d depth from the D_0 blocks this chunk's dgrad launch just wrote
             NcaZgradArgs zg;
             memset(&zg, 0, sizeof(zg));
-            zg.nnets = a.nnets; zg.S = a.S; zg.nchunk = a.nchunk; zg.ray_is_f64 = a.ray_is_f64;
-            zg.ntiles = a.ntiles; zg.ray0 = u0;
+            zg.nnets = a.nnets; zg.S = a.S; zg.ray_is_f64 = a.ray_is_f64;
+            zg.bf16 = bf ? 1 : 0;
+            zg.nchunk = bf ? 2 * a.nchunk : a.nchunk;          // 32-sample tiles per ray (a bf16 wave tile is two of them)
+            zg.ntiles = bf ? 2 * a.ntiles : a.ntiles;
+            zg.ray0 = u0;
             zg.origins = a.origins; zg.dirs = a.dirs; zg.z = a.z; zg.zs_r = a.zs_r;
             zg.dscratch = scratch; zg.d_total = p.tile_stride;
             zg.g_z = g_depth;
@@ -736,7 +739,7 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
                     if (lays[n].layer[j].kind == NCA_IN_HID || zn.nsrc >= 2) continue;
                     zn.w[zn.nsrc] = binds[n].params + lays[n].layer[j].w_off;
                     zn.ldw[zn.nsrc] = lays[n].layer[j].K;
-                    zn.drow[zn.nsrc] = a.net[n].drow0 + (int64_t)j * lays[n].F;
+                    zn.drow[zn.nsrc] = a.net[n].drow0 + (bf ? (int64_t)j * 32 * lays[n].F * 2 : (int64_t)j * lays[n].F);   // bf16: bytes
                     ++zn.nsrc;
                 }
             }

@@ -234,7 +234,9 @@ struct NcaZgradArgs {
     int64_t ntiles, ray0;
     const void* origins; const void* dirs;
     const float* z; int64_t zs_r;
-    const float* dscratch; int64_t d_total;      // D region of this launch: [tile][d_total rows][32]
+    const float* dscratch; int64_t d_total;      // D region of this launch: f32 [tile][d_total rows][32]; bf16 [tile][d_total BYTES],
+                                                 // blocks of fragments [k-step][lane][8 bf16] (drow = byte offset of the block)
+    int32_t bf16, pad;                           // (ntiles / nchunk count 32-sample tiles in both precisions)
     float* g_z;                                  // [R][S]
     NcaZgradNet net[2];
 };

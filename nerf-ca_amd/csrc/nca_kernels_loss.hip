@@ -507,15 +507,29 @@ __global__ __launch_bounds__(256) void nca_zgrad_f32(const NcaZgradArgs a) {
             const bool valid = smp < a.S;
             if (!valid) smp = a.S - 1;
             const float* dblk = a.dscratch + (tile * a.d_total + nn.drow[src]) * 32 + lane * 4;
+            const char* dblk_b = reinterpret_cast<const char*>(a.dscratch) + tile * a.d_total + nn.drow[src] + lane * 16;
             float G[ZG_KPAD];
 #pragma unroll
             for (int f = 0; f < ZG_KPAD; ++f) G[f] = 0.f;
             for (int mq = 0; mq < MT * 4; ++mq) {
-                const float4 dv = *reinterpret_cast<const float4*>(dblk + mq * 256);
-                const float de[4] = {dv.x, dv.y, dv.z, dv.w};
+                float de[4];
+                int obase;
+                if (a.bf16) {
+                    // quad mq = half (mq & 1) of fragment k-step ks = mq >> 1: elements j = 4 (mq & 1) + e of lane (r, h) are
+                    // features 32 (ks >> 1) + 16 (ks & 1) + 8 (j >> 2) + 4 h + (j & 3)   (nca_bf_kidx_hidden)
+                    const int ks = mq >> 1;
+                    const uint2 w2 = *reinterpret_cast<const uint2*>(dblk_b + ks * 1024 + (mq & 1) * 8);
+                    de[0] = __uint_as_float(w2.x << 16); de[1] = __uint_as_float(w2.x & 0xffff0000u);
+                    de[2] = __uint_as_float(w2.y << 16); de[3] = __uint_as_float(w2.y & 0xffff0000u);
+                    obase = 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (mq & 1);
+                } else {
+                    const float4 dv = *reinterpret_cast<const float4*>(dblk + mq * 256);
+                    de[0] = dv.x; de[1] = dv.y; de[2] = dv.z; de[3] = dv.w;
+                    obase = 32 * (mq >> 2) + 8 * (mq & 3);
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int o = 32 * (mq >> 2) + 8 * (mq & 3) + e + 4 * lh;
+                    const int o = obase + e + 4 * lh;
                     const float4* wr = reinterpret_cast<const float4*>(zw + o * ZG_KPAD);
 #pragma unroll
                     for (int f4 = 0; f4 < ZG_KPAD / 4; ++f4) {

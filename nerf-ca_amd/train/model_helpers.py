@@ -148,10 +148,10 @@ def obtain_train_predictions_iter(static_model_coarse, temp_model_coarse, static
     Fine pass (``depth_samples_per_ray_fine > 0``, off in the reference's configs): all eight outputs equal the reference's
     (goldens with injected draws).  The reference never detaches the sampled depths, so its autograd also differentiates the
     fine losses through ``sample_pdf`` / ``sort`` / the query points / the positional encoding back into the COARSE nets (and
-    through the ray-0 ``dists``).  ``depth_gradients`` (default: on whenever autograd is recording and the fine nets run in
-    the f32 mode) does the same: the sampling runs as the reference's torch operations on the fused kernels' coarse fields
-    and the fused render returns d loss / d depth (``nca_render_bwd_depth``) and d loss / d dists.  With
-    ``depth_gradients=False`` (and always in bf16 mode) the depths come from the HIP sampling kernel and are constants of the
+    through the ray-0 ``dists``).  ``depth_gradients`` (default: on whenever autograd is recording) does the same: the
+    sampling runs as the reference's torch operations on the fused kernels' coarse fields and the fused render returns
+    d loss / d depth (``nca_render_bwd_depth``) and d loss / d dists.  With
+    ``depth_gradients=False`` the depths come from the HIP sampling kernel and are constants of the
     step, as in NeRF's own hierarchical sampling: forward values identical, fine-net gradients identical, the coarse nets
     then learn from the coarse terms only (the through-depth term is ~1e4 times their regular gradient,
     tests/test_hip_parity.py::test_trainer_with_fine_pass_vs_oracle).  ``u_fine`` injects the uniform draw of ``sample_pdf``;
@@ -165,9 +165,8 @@ def obtain_train_predictions_iter(static_model_coarse, temp_model_coarse, static
         R, n_coarse = pix_c.shape[0], z.shape[0]
         if u_fine is None:                                         # the draw comes from the CPU generator, as in the reference
             u_fine = torch.rand(R, depth_samples_per_ray_fine)
-        if depth_gradients is None:            # the reference's behaviour wherever the backward can follow it: f32 nets, autograd recording
-            depth_gradients = bool(torch.is_grad_enabled() and sig_s_c.requires_grad
-                                   and static_model_fine._binding.prec == _fused._capi.PREC_F32 and temp_model_fine._binding.prec == _fused._capi.PREC_F32)
+        if depth_gradients is None:            # the reference's behaviour whenever autograd is recording
+            depth_gradients = bool(torch.is_grad_enabled() and sig_s_c.requires_grad)
         if depth_gradients:
             # the reference's own operations (model_helpers.py:135-146), under autograd: the sampled depths carry the graph
             # back to the coarse sigmas; the fused render below returns d loss / d depth (nca_render_bwd_depth)

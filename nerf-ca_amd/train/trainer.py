@@ -25,7 +25,7 @@ class TrainConfig:
     """The hot-path keys of train/composite.txt (defaults = that file)."""
     depth_samples_per_ray_coarse: int = 500
     depth_samples_per_ray_fine: int = 0            # composite.txt:26; > 0 needs the fine model pair (run_composite.py:194-207)
-    fine_depth_gradients: Optional[bool] = None    # as the reference, the fine losses also differentiate through the sampled depths; None = yes in f32 mode
+    fine_depth_gradients: Optional[bool] = None    # as the reference, the fine losses also differentiate through the sampled depths (None = True)
     img_sample_size: int = 1024
     batch_size: int = 32768
     lr: float = 1e-3
@@ -201,15 +201,12 @@ class CompositeTrainer:
             # hierarchical pass (model_helpers.py:131-158, run_composite.py:294-301).  The weights are normalised by the
             # maximum over the GLOBAL batch (:139) -> MAX all-reduce inside the sampler; the fine rendering takes its
             # interval lengths from ray 0 of the GLOBAL batch (:150) -> broadcast from rank 0.  The sampled depths stay in
-            # the autograd graph as in the reference (f32 mode) or are constants of the step (bf16 mode,
-            # fine_depth_gradients=False); see model_helpers.obtain_train_predictions_iter.
+            # the autograd graph as in the reference, or are constants of the step (fine_depth_gradients=False); see
+            # model_helpers.obtain_train_predictions_iter.
             sharded = self.world > 1
             red = _MaxReducer() if sharded else None
             u = self.draw_fine_u(n_iter)[lo:hi].to(self.device)
-            diff = c.fine_depth_gradients
-            if diff is None:
-                diff = all(getattr(getattr(m, "_binding", None), "prec", None) == MH._fused._capi.PREC_F32 for m in (self.s_fine, self.t_fine))
-            if diff:
+            if c.fine_depth_gradients is None or c.fine_depth_gradients:
                 # as the reference: the sampled depths stay in the autograd graph (model_helpers.py:135-146) and the fused
                 # render returns d loss / d depth, so the fine losses also reach the COARSE nets; the batch-wide maximum and
                 # ray 0's depths cross the ranks in both directions

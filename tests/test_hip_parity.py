@@ -848,6 +848,48 @@ def test_depth_gradient_vs_oracle(golden, dev, enc, F, ray_dt):
             assert rel_err(p_.grad.cpu(), pd64[k].grad) < max(TOL, 3 * rel_err(pd32[k].grad, pd64[k].grad)), ("dynamic", k)
 
 
+@pytest.mark.parametrize("F,R,S,it_s,it_d,tol", [(128, 9, 130, 10000, 10000, 3e-2), (32, 5, 33, 10000, 20000, 3e-2), (128, 9, 130, 60000, 90000, 0.3)])
+def test_depth_gradient_bf16_vs_f32(dev, F, R, S, it_s, it_d, tol):
+    """The bf16 mode forms d loss / d depth from its own (bf16, fragment-major) D_0 blocks -- backward from the forward's
+    store and recompute backward alike: against the f32 mode on the same nets.  With two or three frequency bands open the
+    two agree to bf16 accuracy (3e-2); with eight bands open the quantity itself is ill-conditioned (band k enters with
+    2^k cos(2^k p) and the bands cancel), and bf16's 0.4 % on D_0 shows as ~13 % of the max-norm -- the f32 mode is the one
+    with a parity claim."""
+    from nerfca_amd import fused, render_rays, set_precision
+    gen = torch.Generator().manual_seed(5 + F)
+    ss, sd = O.NetSpec(num_filters=F, num_early_layers=3), O.NetSpec(num_filters=F, num_early_layers=3, num_time_dim=8)
+    s = make_static(O.init_params(ss, gen), dev, F=F, early=3, late=0)
+    t = make_dynamic(O.init_params(sd, gen), dev, F=F, early=3, late=0, T=8)
+    s.update_freq_mask_alpha(it_s, 150000)
+    t.update_freq_mask_alpha(it_d, 150000)
+    o = (torch.rand(R, 3, generator=gen) * 0.2 + torch.tensor([3.0, -2.0, 2.5])).double().to(dev)
+    d = (torch.rand(R, 3, generator=gen) - 0.5).double().to(dev)
+    ph = torch.randint(0, 10, (R,), generator=gen).to(dev)
+    z_all = torch.sort(3.4259 + (5.5741 - 3.4259) * torch.rand(R, S, generator=gen), -1)[0].to(dev)
+    I0 = torch.full((R,), 2.15991, device=dev)
+    cp, cs, cd = torch.randn(R, generator=gen).double().to(dev), torch.randn(R, S, generator=gen).to(dev), torch.randn(R, S, generator=gen).to(dev)
+
+    def run():
+        zt = z_all.clone().requires_grad_(True)
+        z0 = zt[0, :].double()
+        dists = torch.cat((z0[1:] - z0[:-1], torch.tensor([1e-10], dtype=torch.float64, device=dev)), -1)
+        pix, a, b = render_rays(s, t, o, d, ph, I0, zt, dists)
+        ((pix * cp).sum() + (a * cs).sum() * 50 + (b * cd).sum() * 50).backward()
+        return zt.grad.clone()
+
+    g32 = run()
+    set_precision("bf16", s, t)
+    saved = fused.STORE_FORWARD_LIMIT_BYTES
+    try:
+        g16 = run()
+        fused.STORE_FORWARD_LIMIT_BYTES = 0
+        g16r = run()
+    finally:
+        fused.STORE_FORWARD_LIMIT_BYTES = saved
+    assert float(g32.abs().max()) > 0
+    assert rel_err(g16, g32) < tol and rel_err(g16r, g32) < tol, (rel_err(g16, g32), rel_err(g16r, g32))
+
+
 @pytest.mark.parametrize("limit,ws", [(0, 6 << 30), (96 << 30, 1 << 20), (0, 1 << 20)])
 def test_depth_gradient_store_recompute_and_chunks(dev, limit, ws):
     """d loss / d depth does not depend on how the backward is run: from the forward's store or with recompute, in one ray
