@@ -890,6 +890,45 @@ def test_depth_gradient_bf16_vs_f32(dev, F, R, S, it_s, it_d, tol):
     assert rel_err(g16, g32) < tol and rel_err(g16r, g32) < tol, (rel_err(g16, g32), rel_err(g16r, g32))
 
 
+@pytest.mark.parametrize("R,S", [(1, 1), (1, 2), (3, 1), (1, 65), (2, 1000), (129, 33)])
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_depth_gradient_degenerate_shapes(dev, prec, R, S):
+    """Single samples, single rays, ragged tails and long rays: d loss / d depth is finite, zero nowhere it should not be, and
+    the same from the store and with recompute."""
+    from nerfca_amd import fused, render_rays, set_precision
+    gen = torch.Generator().manual_seed(17 + R + S)
+    ss, sd = O.NetSpec(num_filters=32, num_early_layers=2), O.NetSpec(num_filters=32, num_early_layers=2, num_time_dim=8)
+    s = make_static(O.init_params(ss, gen), dev, F=32, early=2, late=0)
+    t = make_dynamic(O.init_params(sd, gen), dev, F=32, early=2, late=0, T=8)
+    set_precision(prec, s, t)
+    for m in (s, t):
+        m.update_freq_mask_alpha(20000, 150000)
+    o = (torch.rand(R, 3, generator=gen) * 0.2 + torch.tensor([3.0, -2.0, 2.5])).double().to(dev)
+    d = (torch.rand(R, 3, generator=gen) - 0.5).double().to(dev)
+    ph = torch.randint(0, 10, (R,), generator=gen).to(dev)
+    z_all = torch.sort(3.4259 + (5.5741 - 3.4259) * torch.rand(R, S, generator=gen), -1)[0].to(dev)
+    I0 = torch.full((R,), 2.15991, device=dev)
+    cs = torch.randn(R, S, generator=gen).to(dev)
+
+    def run():
+        zt = z_all.clone().requires_grad_(True)
+        z0 = zt[0, :].double()
+        dists = torch.cat((z0[1:] - z0[:-1], torch.tensor([1e-10], dtype=torch.float64, device=dev)), -1)
+        pix, a, b = render_rays(s, t, o, d, ph, I0, zt, dists)
+        (pix.sum() + ((a + 2 * b) * cs).sum() * 50).backward()
+        return zt.grad.clone()
+
+    g0 = run()
+    saved = fused.STORE_FORWARD_LIMIT_BYTES
+    try:
+        fused.STORE_FORWARD_LIMIT_BYTES = 0
+        g1 = run()
+    finally:
+        fused.STORE_FORWARD_LIMIT_BYTES = saved
+    assert g0.shape == (R, S) and bool(torch.isfinite(g0).all()) and float(g0.abs().max()) > 0
+    assert rel_err(g1, g0) < 2e-6
+
+
 @pytest.mark.parametrize("limit,ws", [(0, 6 << 30), (96 << 30, 1 << 20), (0, 1 << 20)])
 def test_depth_gradient_store_recompute_and_chunks(dev, limit, ws):
     """d loss / d depth does not depend on how the backward is run: from the forward's store or with recompute, in one ray
