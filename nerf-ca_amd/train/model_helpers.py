@@ -155,7 +155,9 @@ def obtain_train_predictions_iter(static_model_coarse, temp_model_coarse, static
     step, as in NeRF's own hierarchical sampling: forward values identical, fine-net gradients identical, the coarse nets
     then learn from the coarse terms only (the through-depth term is ~1e4 times their regular gradient,
     tests/test_hip_parity.py::test_trainer_with_fine_pass_vs_oracle).  ``u_fine`` injects the uniform draw of ``sample_pdf``;
-    ``reduce_max`` (ray-sharded batches) makes the batch-wide weight maximum global, see ``fused.fine_depths``."""
+    ``reduce_max`` (ray-sharded batches) makes the batch-wide weight maximum global, see ``fused.fine_depths``; with depth
+    gradients it should also carry a ``sum`` attribute (all-reduce SUM, in place) for the backward of that maximum, as
+    ``trainer._MaxReducer`` does."""
     z = randomize_depth(depth_values, device, t_rand)
     dists_c = _interval_lengths(z, batch_directions)
     pix_c, sig_s_c, sig_d_c = _fused.render_rays(static_model_coarse, temp_model_coarse, batch_origins, batch_directions, batch_phases,
