@@ -201,6 +201,16 @@ int nca_loss_fwd_bwd(const NcaLoss* desc, const double* pix, const double* gt, c
 int64_t nca_fine_depths_workspace(int64_t R);
 int nca_fine_depths(int64_t R, int32_t S, int32_t n_fine, const float* sig_s, const float* sig_d, const float* z,
                     const float* u, float* z_all, void* work, int64_t work_bytes, void* stream);
+/* Backward of the three calls above (the reference does not detach the sampled depths, train/model_helpers.py:135-146).
+ * nca_fine_depths_bwd: g_tot f32[R,S] = d loss / d (sigma_s + sigma_d) through sample_pdf and the sort with the maximum held
+ * fixed; gmax_part f32[R] / cnt_part f32[R] = per-ray parts of d loss / d wmax and of the number of jumps that attain wmax.
+ * The caller sums both over rays (and ranks) and passes gmax_each = sum(gmax_part) / count to nca_fine_depths_bwd_max, which
+ * adds it to the jumps that attain the maximum (torch.max distributes its gradient evenly over ties). */
+int nca_fine_depths_bwd(int64_t R, int32_t S, int32_t n_fine, const float* sig_s, const float* sig_d, const float* z,
+                        const float* u, const float* wmax, const float* g_z_all, float* g_tot, float* gmax_part, float* cnt_part,
+                        void* stream);
+int nca_fine_depths_bwd_max(int64_t R, int32_t S, const float* sig_s, const float* sig_d, const float* wmax, const float* gmax_each,
+                            float* g_tot, void* stream);
 /*      The same in two stages for a batch that is sharded over ranks: the weights are normalised by the maximum over
  *      the WHOLE batch (model_helpers.py:139), so a rank computes the maximum of its rays into the device scalar
  *      wmax f32[1], all-reduces it (MAX) and samples with the result. */

@@ -79,6 +79,8 @@ SYMBOLS = {
     "nca_loss_fwd_bwd": (C.c_int, [C.POINTER(NcaLoss), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "nca_fine_depths_workspace": (_I64, [_I64]),
     "nca_fine_depths": (C.c_int, [_I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _I64, _P]),
+    "nca_fine_depths_bwd": (C.c_int, [_I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "nca_fine_depths_bwd_max": (C.c_int, [_I64, _I32, _P, _P, _P, _P, _P, _P]),
     "nca_fine_weight_max": (C.c_int, [_I64, _I32, _P, _P, _P, _P, _I64, _P]),
     "nca_fine_depths_given_max": (C.c_int, [_I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _P]),
     "nca_adam_step": (C.c_int, [C.POINTER(NcaAdam), _I32, C.POINTER(_I64), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P),

@@ -1078,6 +1078,36 @@ extern "C" int nca_fine_depths(int64_t R, int32_t S, int32_t n_fine, const float
     return NCA_OK;
 }
 
+// Backward of nca_fine_depths (the reference keeps the sampled depths in its autograd graph, model_helpers.py:135-146).
+// Stage 1: g_tot f32[R,S] = d loss / d (sigma_s + sigma_d) through the sampling with the maximum held fixed, plus per-ray
+// parts of d loss / d wmax and of the number of jumps that attain wmax.  The caller sums them (over the ranks too), divides,
+// and stage 2 adds the quotient to the jumps that attain the maximum.
+extern "C" int nca_fine_depths_bwd(int64_t R, int32_t S, int32_t n_fine, const float* sig_s, const float* sig_d, const float* z,
+                                   const float* u, const float* wmax, const float* g_z_all, float* g_tot, float* gmax_part, float* cnt_part,
+                                   void* stream) {
+    const int rc = fine_check(R, S, n_fine);
+    if (rc != NCA_OK) return rc;
+    if (!sig_s || !z || !u || !wmax || !g_z_all || !g_tot || !gmax_part || !cnt_part) return fail(NCA_E_INVALID, "a pointer is NULL");
+    if (4 * (int64_t)(2 * (S - 1) + 2 * S + 5 * n_fine) * 4 > 160 * 1024) return fail(NCA_E_UNSUPPORTED, "S + n_fine too large for the LDS-resident sampler backward");
+    NcaFineBwdArgs a{};
+    a.R = R; a.S = S; a.n_fine = n_fine;
+    a.sig_s = sig_s; a.sig_d = sig_d; a.z = z; a.u = u; a.jmax = wmax; a.g_zall = g_z_all;
+    a.g_tot = g_tot; a.gmax_part = gmax_part; a.cnt_part = cnt_part;
+    HIPCHK(nca_launch_fine_bwd(a, (hipStream_t)stream));
+    return NCA_OK;
+}
+extern "C" int nca_fine_depths_bwd_max(int64_t R, int32_t S, const float* sig_s, const float* sig_d, const float* wmax, const float* gmax_each,
+                                       float* g_tot, void* stream) {
+    const int rc = fine_check(R, S, 1);
+    if (rc != NCA_OK) return rc;
+    if (!sig_s || !wmax || !gmax_each || !g_tot) return fail(NCA_E_INVALID, "a pointer is NULL");
+    NcaFineBwdArgs a{};
+    a.R = R; a.S = S; a.n_fine = 1;
+    a.sig_s = sig_s; a.sig_d = sig_d; a.jmax = wmax; a.gmax_each = gmax_each; a.g_tot = g_tot;
+    HIPCHK(nca_launch_fine_bwd_max(a, (hipStream_t)stream));
+    return NCA_OK;
+}
+
 // ---------------------------------------------------------------------------------- optimiser
 extern "C" int nca_adam_step(const NcaAdam* cfg, int32_t n_seg, const int64_t* n, float* const* params, const float* const* grads,
                              float* const* exp_avg, float* const* exp_avg_sq, int64_t* step, void* stream) {

@@ -209,6 +209,20 @@ struct NcaFineArgs {
     float* partial_max;   // [ceil(R / 4)]
     float* jmax;          // [1]
 };
+// backward of the fine-pass depths: d loss / d (sigma_s + sigma_d) of the coarse fields from d loss / d z_all
+struct NcaFineBwdArgs {
+    int64_t R;
+    int32_t S, n_fine;
+    const float* sig_s; const float* sig_d; const float* z; const float* u;
+    const float* jmax;        // [1] the batch-wide maximum the forward sampled with
+    const float* g_zall;      // [R, S + n_fine]
+    float* g_tot;             // [R, S]  (written)
+    float* gmax_part;         // [R] per-ray part of d loss / d jmax
+    float* cnt_part;          // [R] per-ray number of jumps that attain jmax
+    const float* gmax_each;   // [1] second stage: d loss / d jmax divided by the number of elements that attain it (all ranks)
+};
+hipError_t nca_launch_fine_bwd(const NcaFineBwdArgs& a, hipStream_t st);
+hipError_t nca_launch_fine_bwd_max(const NcaFineBwdArgs& a, hipStream_t st);
 hipError_t nca_launch_fine(const NcaFineArgs& a, hipStream_t st);
 hipError_t nca_launch_fine_max(const NcaFineArgs& a, hipStream_t st);
 hipError_t nca_launch_fine_sample(const NcaFineArgs& a, hipStream_t st);

@@ -476,6 +476,173 @@ hipError_t nca_launch_fine(const NcaFineArgs& a, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Backward of the fine-pass depths (the reference leaves them in the autograd graph, model_helpers.py:135-146): from
+// d loss / d z_all back to the coarse densities.  One wave per ray, the forward's own arithmetic redone for the cdf and the
+// searches (same operations in the same order: the same bins are hit), then
+//   g_zp[j]   = g_zall[position of draw j after the stable sort of cat([draws, coarse])]
+//   zp        = b0 + (u - c0) / den (b1 - b0):   d/dc0 = (u - c1) / den^2 (b1 - b0),  d/dc1 = -(u - c0) / den^2 (b1 - b0);
+//               where den < 1e-5 was replaced by 1:  d/dc0 = -(b1 - b0), d/dc1 = 0   (torch.where passes no gradient to it)
+//   cdf[k]    = sum_{i<k} pdf[i]  ->  g_pdf[i] = sum_{k>i} g_cdf[k]   (suffix sums, gathered per cdf entry in a fixed order)
+//   pdf = wp / sum(wp),  wp[i] = |jump_{i+1}| / jmax + 1e-5,  jump_k = tot[k] - tot[k-1]
+// g_tot[s] = sgn(jump_s) g_w[s] - sgn(jump_{s+1}) g_w[s+1].  The maximum jmax is one element of the BATCH: each ray leaves its
+// part of d loss / d jmax and its count of jumps that attain it; the second stage hands (sum / count) to those jumps.
+// LDS per wave: cdf[S-1] | gcdf[S-1] | wp[S] | zc[S] | zp[NF] | clo[NF] | chi[NF] | ibelow[NF] | iabove[NF]
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LOSS_NT) void nca_fine_bwd_k(const NcaFineBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char fsm[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * LOSS_WAVES + wave;
+    if (r >= a.R) return;                                   // waves are independent (no block-wide barrier)
+    const int S = a.S, NF = a.n_fine, NB = S - 1, NW = S - 2;
+    float* cdf = reinterpret_cast<float*>(fsm) + (size_t)wave * (2 * NB + 2 * S + 5 * NF);
+    float* gcdf = cdf + NB;
+    float* wp = gcdf + NB;
+    float* zc = wp + S;
+    float* zp = zc + S;
+    float* clo = zp + NF;
+    float* chi = clo + NF;
+    int* ibel = reinterpret_cast<int*>(chi + NF);
+    int* iabo = ibel + NF;
+    const float jmax = *a.jmax;
+    NcaFineArgs fa{};
+    fa.S = S; fa.sig_s = a.sig_s; fa.sig_d = a.sig_d;
+    for (int k = lane; k < S; k += 64) zc[k] = a.z[k];
+    // forward, as nca_fine_sample_k
+    float sum = 0.f;
+    for (int j = lane; j < NW; j += 64) {
+        const float w = __fadd_rn(__fdiv_rn(fabsf(__fsub_rn(fine_total(fa, r, j + 1), fine_total(fa, r, j))), jmax), 1e-5f);
+        cdf[j + 1] = w;
+        wp[j] = w;
+        sum += w;
+    }
+    sum = (float)wsum((double)sum);
+    __builtin_amdgcn_wave_barrier();
+    float carry = 0.f;
+    for (int base = 0; base < NW; base += 64) {
+        const int j = base + lane;
+        const float p = j < NW ? __fdiv_rn(cdf[j + 1], sum) : 0.f;
+        const float inc = wscan_incl(p, lane) + carry;
+        if (j < NW) cdf[j + 1] = inc;
+        carry = __shfl(inc, 63);
+    }
+    if (lane == 0) cdf[0] = 0.f;
+    __builtin_amdgcn_wave_barrier();
+    for (int j = lane; j < NF; j += 64) {
+        const float u = a.u[r * NF + j];
+        int lo = 0, hi = NB;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdf[mid] <= u) lo = mid + 1; else hi = mid; }
+        const int below = lo - 1 < 0 ? 0 : lo - 1, above = lo > NB - 1 ? NB - 1 : lo;
+        const float c0 = cdf[below], c1 = cdf[above];
+        const float b0 = 0.5f * (zc[below + 1] + zc[below]), b1 = 0.5f * (zc[above + 1] + zc[above]);
+        const float den = c1 - c0, db = b1 - b0;
+        const bool repl = den < 1e-5f;
+        const float dd = repl ? 1.f : den;
+        zp[j] = b0 + (u - c0) / dd * db;
+        ibel[j] = below; iabo[j] = above;
+        clo[j] = repl ? -db : (u - c1) / (den * den) * db;       // d zp / d c0
+        chi[j] = repl ? 0.f : -(u - c0) / (den * den) * db;      // d zp / d c1
+    }
+    __builtin_amdgcn_wave_barrier();
+    // upstream gradient of every draw: its place in the stable sort of cat([draws, coarse])
+    const float* gz = a.g_zall + r * (int64_t)(S + NF);
+    for (int j = lane; j < NF; j += 64) {
+        const float v = zp[j];
+        int pos = 0;
+        for (int k = 0; k < NF; ++k) { const float o = zp[k]; pos += (o < v || (o == v && k < j)) ? 1 : 0; }
+        int lo = 0, hi = S;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (zc[mid] < v) lo = mid + 1; else hi = mid; }
+        const float g = gz[pos + lo];
+        clo[j] *= g;
+        chi[j] *= g;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // g_cdf[k]: gather over the draws in index order (deterministic)
+    for (int k = lane; k < NB; k += 64) {
+        float g = 0.f;
+        for (int j = 0; j < NF; ++j) {
+            if (ibel[j] == k) g += clo[j];
+            if (iabo[j] == k) g += chi[j];
+        }
+        gcdf[k] = g;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // g_pdf[i] = sum_{k = i+1}^{NB-1} g_cdf[k]: suffix sums, chunks of 64 from the end; kept in gcdf[i + 1] (entry of pdf i)
+    float tailsum = 0.f;
+    float dot = 0.f;                                      // sum_i g_pdf[i] wp[i]
+    for (int top = NW; top > 0; top -= 64) {              // pdf indices [top - 64, top)
+        const int i = top - 1 - lane;                     // lane 0 takes the highest index
+        const float v = i >= 0 ? gcdf[i + 1] : 0.f;
+        const float inc = wscan_incl(v, lane) + tailsum;  // sum of g_cdf[i+1 .. NB-1]
+        if (i >= 0) { gcdf[i + 1] = inc; dot += inc * wp[i]; }
+        tailsum = __shfl(inc, 63);
+    }
+    dot = (float)wsum((double)dot);
+    __builtin_amdgcn_wave_barrier();
+    // g_wp -> g_w (jumps 1 .. S-2) -> g_tot; d loss / d jmax
+    float gm = 0.f, cnt = 0.f;
+    float* gt = a.g_tot + r * (int64_t)S;
+    for (int s0 = lane; s0 < S; s0 += 64) {
+        // g_w of jump s0 and of jump s0 + 1 (0 outside 1 .. S-2)
+        float acc = 0.f;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int k = s0 + e;
+            if (k >= 1 && k <= S - 2) {
+                const float gwp = gcdf[k] / sum - dot / (sum * sum);       // pdf index k - 1 lives in gcdf[k]
+                const float gw = gwp / jmax;
+                const float jump = __fsub_rn(fine_total(fa, r, k), fine_total(fa, r, k - 1));
+                const float sg = jump > 0.f ? 1.f : (jump < 0.f ? -1.f : 0.f);
+                acc += e == 0 ? sg * gw : -sg * gw;
+                if (e == 0) gm -= gwp * fabsf(jump) / (jmax * jmax);
+            }
+        }
+        gt[s0] = acc;
+        if (s0 >= 1 && fabsf(__fsub_rn(fine_total(fa, r, s0), fine_total(fa, r, s0 - 1))) == jmax) cnt += 1.f;
+    }
+    gm = (float)wsum((double)gm);
+    cnt = (float)wsum((double)cnt);
+    if (lane == 0) { a.gmax_part[r] = gm; a.cnt_part[r] = cnt; }
+}
+
+// second stage: every jump that attains the batch-wide maximum receives gmax_each
+__global__ __launch_bounds__(LOSS_NT) void nca_fine_bwd_max_k(const NcaFineBwdArgs a) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * LOSS_WAVES + wave;
+    if (r >= a.R) return;
+    const float jmax = *a.jmax, ge = *a.gmax_each;
+    NcaFineArgs fa{};
+    fa.S = a.S; fa.sig_s = a.sig_s; fa.sig_d = a.sig_d;
+    float* gt = a.g_tot + r * (int64_t)a.S;
+    for (int s0 = lane; s0 < a.S; s0 += 64) {
+        float acc = 0.f;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int k = s0 + e;
+            if (k >= 1 && k <= a.S - 1) {
+                const float jump = __fsub_rn(fine_total(fa, r, k), fine_total(fa, r, k - 1));
+                if (fabsf(jump) == jmax) {
+                    const float sg = jump > 0.f ? 1.f : (jump < 0.f ? -1.f : 0.f);
+                    acc += e == 0 ? sg * ge : -sg * ge;
+                }
+            }
+        }
+        if (acc != 0.f) gt[s0] += acc;
+    }
+}
+
+hipError_t nca_launch_fine_bwd(const NcaFineBwdArgs& a, hipStream_t st) {
+    const int nblocks = (int)nca_fine_partials(a.R);
+    const size_t lds = (size_t)LOSS_WAVES * (2 * (a.S - 1) + 2 * a.S + 5 * a.n_fine) * sizeof(float);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_fine_bwd_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(nca_fine_bwd_k, dim3(nblocks), dim3(LOSS_NT), lds, st, a);
+    return hipGetLastError();
+}
+hipError_t nca_launch_fine_bwd_max(const NcaFineBwdArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(nca_fine_bwd_max_k, dim3((int)nca_fine_partials(a.R)), dim3(LOSS_NT), 0, st, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // d loss / d depth per sample (fine pass of the reference, model_helpers.py:131-158: the sampled depths are NOT detached, so
 // the fine losses reach them through  p = o + d z  ->  positional encoding  ->  first layer).  One wave per 32-sample tile of
 // the f32 backward: lane (r, h) reads its 64 values of D_0 exactly as the dgrad kernel's lanes stored them (row

@@ -359,8 +359,8 @@ def fused_losses(pix, gt, wpix, sig_s, sig_d, dists, run_args, weights, inv_R=No
 def fine_depths(sig_s: torch.Tensor, sig_d: Optional[torch.Tensor], z: torch.Tensor, u: torch.Tensor, reduce_max=None) -> torch.Tensor:
     """The sampling half of the hierarchical pass (model_helpers.py:131-148 + sample_pdf): returns the merged, sorted
     depths f32[R, S + n_fine] for coarse fields ``sig_*`` f32[R, S], the shared coarse depths ``z`` f32[S] and the
-    uniform draws ``u`` f32[R, n_fine].  The depths are constants of the step here (no gradient flows through them; see
-    the deviation note in train/model_helpers.obtain_train_predictions_iter).
+    uniform draws ``u`` f32[R, n_fine].  The depths are constants of the step here (``fine_depths_autograd`` is the same with the
+    reference's backward into the coarse fields).
 
     ``reduce_max``: for a batch sharded over ranks.  The weights are normalised by the maximum over the WHOLE batch
     (model_helpers.py:139), so the kernel sequence is split: this rank's maximum lands in a device scalar, ``reduce_max``
@@ -387,6 +387,63 @@ def fine_depths(sig_s: torch.Tensor, sig_d: Optional[torch.Tensor], z: torch.Ten
     reduce_max(wmax)
     check(lib.nca_fine_depths_given_max(R, S, n_fine, ptr(ss), ptr(sd), ptr(zz), ptr(uu), ptr(wmax), ptr(out), _stream()))
     return out
+
+
+class _FineDepthsFn(torch.autograd.Function):
+    """z_all = fine_depths(sigma_s, sigma_d; z, u) with the reference's gradient (it leaves the sampled depths in the autograd
+    graph, model_helpers.py:135-146): forward = the HIP sampler (always through the two-stage form, so that the maximum it
+    sampled with is at hand), backward = nca_fine_depths_bwd / _bwd_max.  ``reduce_max`` as in ``fine_depths``; for the
+    backward it should also have a ``sum`` attribute (all-reduce SUM in place): d loss / d maximum and the number of elements
+    that attain it are sums over the rays of ALL ranks."""
+
+    @staticmethod
+    def forward(ctx, sig_s, sig_d, z, u, reduce_max):
+        dev = sig_s.device
+        R, S = sig_s.shape
+        ss, sd = _f32c(sig_s), (_f32c(sig_d) if sig_d is not None else None)
+        zz = z.detach().to(device=dev, dtype=torch.float32).contiguous()
+        uu = u.detach().to(device=dev, dtype=torch.float32).contiguous()
+        n_fine = uu.shape[1]
+        out = torch.empty((R, S + n_fine), dtype=torch.float32, device=dev)
+        lib = _capi.lib()
+        wbytes = check(lib.nca_fine_depths_workspace(R))
+        work = torch.empty(wbytes, dtype=torch.uint8, device=dev)
+        wmax = torch.zeros(1, dtype=torch.float32, device=dev)
+        check(lib.nca_fine_weight_max(R, S, ptr(ss), ptr(sd), ptr(wmax), ptr(work), wbytes, _stream()))
+        if reduce_max is not None:
+            reduce_max(wmax)
+        check(lib.nca_fine_depths_given_max(R, S, n_fine, ptr(ss), ptr(sd), ptr(zz), ptr(uu), ptr(wmax), ptr(out), _stream()))
+        ctx.keep = (ss, sd, zz, uu, wmax)
+        ctx.reduce_max = reduce_max
+        ctx.has_d = sig_d is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g_zall):
+        ss, sd, zz, uu, wmax = ctx.keep
+        dev = ss.device
+        R, S = ss.shape
+        n_fine = uu.shape[1]
+        lib = _capi.lib()
+        g = g_zall.detach().to(torch.float32).contiguous()
+        g_tot = torch.empty((R, S), dtype=torch.float32, device=dev)
+        part = torch.empty((2, R), dtype=torch.float32, device=dev)
+        check(lib.nca_fine_depths_bwd(R, S, n_fine, ptr(ss), ptr(sd), ptr(zz), ptr(uu), ptr(wmax), ptr(g), ptr(g_tot), ptr(part[0]), ptr(part[1]), _stream()))
+        tot = part.double().sum(1)                         # [d loss / d wmax, number of jumps that attain it] of this rank
+        # the leading 1e-10 of every ray's weight vector ties with the maximum only if no jump exceeds it
+        tot[1] += float(R) * (wmax[0] == 1e-10).double()
+        red = getattr(ctx.reduce_max, "sum", None) if ctx.reduce_max is not None else None
+        if red is not None:
+            red(tot)
+        each = (tot[0] / tot[1].clamp(min=1.0)).to(torch.float32).reshape(1).contiguous()
+        check(lib.nca_fine_depths_bwd_max(R, S, ptr(ss), ptr(sd), ptr(wmax), ptr(each), ptr(g_tot), _stream()))
+        return g_tot, (g_tot if ctx.has_d else None), None, None, None
+
+
+def fine_depths_autograd(sig_s, sig_d, z, u, reduce_max=None):
+    """``fine_depths`` with the reference's backward into the coarse fields (HIP forward and backward)."""
+    _require_cuda(sig_s, "sigma")
+    return _FineDepthsFn.apply(sig_s, sig_d, z, u, reduce_max)
 
 
 class FusedAdam:

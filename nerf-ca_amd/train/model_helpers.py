@@ -148,8 +148,8 @@ def obtain_train_predictions_iter(static_model_coarse, temp_model_coarse, static
     Fine pass (``depth_samples_per_ray_fine > 0``, off in the reference's configs): all eight outputs equal the reference's
     (goldens with injected draws).  The reference never detaches the sampled depths, so its autograd also differentiates the
     fine losses through ``sample_pdf`` / ``sort`` / the query points / the positional encoding back into the COARSE nets (and
-    through the ray-0 ``dists``).  ``depth_gradients`` (default: on whenever autograd is recording) does the same: the
-    sampling runs as the reference's torch operations on the fused kernels' coarse fields and the fused render returns
+    through the ray-0 ``dists``).  ``depth_gradients`` (default: on whenever autograd is recording) does the same: the HIP
+    sampler gets its backward into the coarse densities (``nca_fine_depths_bwd``) and the fused render returns
     d loss / d depth (``nca_render_bwd_depth``) and d loss / d dists.  With
     ``depth_gradients=False`` the depths come from the HIP sampling kernel and are constants of the
     step, as in NeRF's own hierarchical sampling: forward values identical, fine-net gradients identical, the coarse nets
@@ -170,15 +170,9 @@ def obtain_train_predictions_iter(static_model_coarse, temp_model_coarse, static
         if depth_gradients is None:            # the reference's behaviour whenever autograd is recording
             depth_gradients = bool(torch.is_grad_enabled() and sig_s_c.requires_grad)
         if depth_gradients:
-            # the reference's own operations (model_helpers.py:135-146), under autograd: the sampled depths carry the graph
-            # back to the coarse sigmas; the fused render below returns d loss / d depth (nca_render_bwd_depth)
-            tot = sig_s_c + sig_d_c
-            w = torch.cat([torch.ones_like(tot[:, :1]) * 1e-10, torch.abs(tot[:, 1:] - tot[:, :-1])], dim=-1)
-            w = w / _BatchMax.apply(w, reduce_max)
-            zrep = z[None, :].repeat(R, 1)
-            mid = 0.5 * (zrep[..., 1:] + zrep[..., :-1])
-            z_pdf = sample_pdf(mid, w[..., 1:-1], depth_samples_per_ray_fine, device, u=u_fine.to(device))
-            z_all, _ = torch.sort(torch.cat([z_pdf, zrep.detach()], -1), -1)
+            # the sampled depths stay in the autograd graph as in the reference (model_helpers.py:135-146): HIP sampler forward,
+            # HIP backward into the coarse densities (nca_fine_depths_bwd); the fused render below returns d loss / d depth
+            z_all = _fused.fine_depths_autograd(sig_s_c, sig_d_c, z, u_fine, reduce_max=reduce_max)
         else:
             # weights (batch-wide max, :139), sample_pdf and sort(cat[fine, coarse]) in one HIP pass per ray
             z_all = _fused.fine_depths(sig_s_c, sig_d_c, z, u_fine, reduce_max=reduce_max)

@@ -210,13 +210,17 @@ class CompositeTrainer:
                 # as the reference: the sampled depths stay in the autograd graph (model_helpers.py:135-146) and the fused
                 # render returns d loss / d depth, so the fine losses also reach the COARSE nets; the batch-wide maximum and
                 # ray 0's depths cross the ranks in both directions
-                tot = sig_s + sig_d
-                wts = torch.cat([torch.ones_like(tot[:, :1]) * 1e-10, torch.abs(tot[:, 1:] - tot[:, :-1])], dim=-1)
-                wts = wts / MH._BatchMax.apply(wts, red)
-                zrep = z[None, :].repeat(hi - lo, 1)
-                mid = 0.5 * (zrep[..., 1:] + zrep[..., :-1])
-                z_pdf = MH.sample_pdf(mid, wts[..., 1:-1], self.n_fine, self.device, u=u)
-                z_all, _ = torch.sort(torch.cat([z_pdf, zrep.detach()], -1), -1)
+                if self.fine_sampler is MH._fused.fine_depths:      # the product path: HIP sampler, HIP backward
+                    z_all = MH._fused.fine_depths_autograd(sig_s, sig_d, z, u, reduce_max=red)
+                else:
+                    # an injected sampler (the CPU tests run the oracle's): the reference's own operations under autograd
+                    tot = sig_s + sig_d
+                    wts = torch.cat([torch.ones_like(tot[:, :1]) * 1e-10, torch.abs(tot[:, 1:] - tot[:, :-1])], dim=-1)
+                    wts = wts / MH._BatchMax.apply(wts, red)
+                    zrep = z[None, :].repeat(hi - lo, 1)
+                    mid = 0.5 * (zrep[..., 1:] + zrep[..., :-1])
+                    z_pdf = MH.sample_pdf(mid, wts[..., 1:-1], self.n_fine, self.device, u=u)
+                    z_all, _ = torch.sort(torch.cat([z_pdf, zrep.detach()], -1), -1)
                 z0 = _FromRank0.apply(z_all[0, :], self.rank) if sharded else z_all[0, :]
             else:
                 z_all = self.fine_sampler(sig_s.detach(), sig_d.detach(), z, u, reduce_max=red)

@@ -890,6 +890,44 @@ def test_depth_gradient_bf16_vs_f32(dev, F, R, S, it_s, it_d, tol):
     assert rel_err(g16, g32) < tol and rel_err(g16r, g32) < tol, (rel_err(g16, g32), rel_err(g16r, g32))
 
 
+@pytest.mark.parametrize("R,S,NF,single", [(9, 40, 16, False), (3, 130, 64, False), (5, 24, 100, True), (1, 3, 2, False)])
+def test_fine_depths_backward_vs_autograd(dev, R, S, NF, single):
+    """nca_fine_depths_bwd (+ _bwd_max): the gradient of the merged, sorted fine depths w.r.t. the coarse densities -- through
+    the sort, sample_pdf's interpolation, the cumulative sum, the normalisation and the batch-wide maximum -- against autograd
+    through the reference's own torch operations (model_helpers.py:135-146, 162-187) on the same inputs."""
+    from nerfca_amd import fused
+    from nerfca_amd.train import model_helpers as MH
+    gen = torch.Generator().manual_seed(31 + S)
+    sig_s = (torch.rand(R, S, generator=gen) * 0.02).to(dev)
+    sig_d = None if single else (torch.rand(R, S, generator=gen) * 0.02).to(dev)
+    z = O.stratified_depths(O.depth_values(3.4259, 5.5741, S), torch.rand(S, generator=gen)).to(dev)
+    u = torch.rand(R, NF, generator=gen).to(dev)
+    G = torch.randn(R, S + NF, generator=gen).to(dev)
+
+    a1 = sig_s.clone().requires_grad_(True)
+    b1 = None if single else sig_d.clone().requires_grad_(True)
+    tot = a1 if single else a1 + b1
+    w = torch.cat([torch.ones_like(tot[:, :1]) * 1e-10, torch.abs(tot[:, 1:] - tot[:, :-1])], dim=-1)
+    w = w / torch.max(w)
+    zrep = z[None, :].repeat(R, 1)
+    mid = 0.5 * (zrep[..., 1:] + zrep[..., :-1])
+    z_ref, _ = torch.sort(torch.cat([MH.sample_pdf(mid, w[..., 1:-1], NF, dev, u=u), zrep.detach()], -1), -1)
+    (z_ref * G).sum().backward()
+
+    a2 = sig_s.clone().requires_grad_(True)
+    b2 = None if single else sig_d.clone().requires_grad_(True)
+    z_hip = fused.fine_depths_autograd(a2, b2, z, u)
+    assert rel_err(z_hip, z_ref.detach()) < 1e-6
+    (z_hip * G).sum().backward()
+    if S == 3:          # one bin: the pdf is the constant 1, nothing reaches the densities
+        assert float(a1.grad.abs().max()) == 0 and float(a2.grad.abs().max()) == 0
+        return
+    assert float(a1.grad.abs().max()) > 0
+    assert rel_err(a2.grad, a1.grad) < 2e-4, rel_err(a2.grad, a1.grad)
+    if not single:
+        assert rel_err(b2.grad, b1.grad) < 2e-4
+
+
 @pytest.mark.parametrize("R,S", [(1, 1), (1, 2), (3, 1), (1, 65), (2, 1000), (129, 33)])
 @pytest.mark.parametrize("prec", ["f32", "bf16"])
 def test_depth_gradient_degenerate_shapes(dev, prec, R, S):
