@@ -652,9 +652,18 @@ hipError_t nca_launch_fine_bwd_max(const NcaFineBwdArgs& a, hipStream_t st) {
 //   fourier: dp_c = sum_{i = c mod 3} 2 pi g_i ( cos(v_i) G[i] - sin(v_i) G[3L+i] ),  v_i = fl32(fl32(2 pi p_c) g_i)
 //   none:    dp_c = G[c];                       dz = sum_c d_c dp_c, summed over the nets of the render.
 // ------------------------------------------------------------------------------------------
-#define ZG_KPAD 96
+// G = W0[:, encoded columns]^T D_0 runs on the matrix cores (v_mfma_f32_32x32x2_f32, 3 row tiles = 96 encoded rows): D_0 is
+// loaded into registers in the accumulator layout the dgrad kernel held it in -- which IS the B operand of that MFMA, k-step
+// 16 t + i = register i of row tile t (rows rho(i) and rho(i) + 4 from the two lane halves) -- and the A operand comes from an
+// LDS image [k-step][lane][4]: W0[o = 32 (s >> 4) + rho(s & 15) + 4 h][f = 32 m + r].  Lane (r, h) then holds G for the rows
+// 32 m + rho(i) + 4 h of sample r; the encoding's derivative is linear in G, so each half adds its rows and the halves are
+// summed.  sin / cos of all bands: one f64 sincos per coordinate + the double-angle recurrence, as in the forward.
+#define ZG_MT 3
+typedef float zg_f32x16 __attribute__((ext_vector_type(16)));
+template <int F>
 __global__ __launch_bounds__(256) void nca_zgrad_f32(const NcaZgradArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float zw[];        // [F][ZG_KPAD]: encoded columns of W0, zero padded
+    constexpr int MT = F / 32, NS = 16 * MT;
+    extern __shared__ __attribute__((aligned(16))) float zw[];        // [NS][64][4]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 31, lh = lane >> 5;
     for (int pass = 0; pass < 2 * a.nnets; ++pass) {
         const int net = pass >> 1, src = pass & 1;
@@ -662,54 +671,60 @@ __global__ __launch_bounds__(256) void nca_zgrad_f32(const NcaZgradArgs a) {
         if (src >= nn.nsrc) continue;              // (uniform over the block)
         const bool first = pass == 0;              // the first pass writes g_z, the others add to it
         __syncthreads();
-        for (int i = threadIdx.x; i < nn.F * ZG_KPAD; i += 256) {
-            const int o = i / ZG_KPAD, f = i % ZG_KPAD;
-            zw[i] = f < nn.Kenc ? nn.w[src][(int64_t)o * nn.ldw[src] + f] : 0.f;
+        for (int i = threadIdx.x; i < NS * 64 * 4; i += 256) {
+            const int m = i & 3, ln = (i >> 2) & 63, sidx = i >> 8;
+            const int o = 32 * (sidx >> 4) + ((sidx & 15) & 3) + 8 * ((sidx & 15) >> 2) + 4 * (ln >> 5);
+            const int f = 32 * m + (ln & 31);
+            zw[i] = (m < ZG_MT && f < nn.Kenc) ? nn.w[src][(int64_t)o * nn.ldw[src] + f] : 0.f;
         }
         __syncthreads();
-        const int MT = nn.F / 32;
         for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < a.ntiles; tile += (int64_t)gridDim.x * 4) {
             const int64_t ray = a.ray0 + tile / a.nchunk;
             int smp = (int)(tile % a.nchunk) * 32 + lr;
             const bool valid = smp < a.S;
             if (!valid) smp = a.S - 1;
-            const float* dblk = a.dscratch + (tile * a.d_total + nn.drow[src]) * 32 + lane * 4;
-            const char* dblk_b = reinterpret_cast<const char*>(a.dscratch) + tile * a.d_total + nn.drow[src] + lane * 16;
-            float G[ZG_KPAD];
+            // D block of this tile in accumulator order: D[t][i] = row 32 t + rho(i) + 4 h of sample r
+            float D[MT][16];
+            if (a.bf16) {
+                const char* db = reinterpret_cast<const char*>(a.dscratch) + tile * a.d_total + nn.drow[src] + lane * 16;
 #pragma unroll
-            for (int f = 0; f < ZG_KPAD; ++f) G[f] = 0.f;
-            for (int mq = 0; mq < MT * 4; ++mq) {
-                float de[4];
-                int obase;
-                if (a.bf16) {
-                    // quad mq = half (mq & 1) of fragment k-step ks = mq >> 1: elements j = 4 (mq & 1) + e of lane (r, h) are
-                    // features 32 (ks >> 1) + 16 (ks & 1) + 8 (j >> 2) + 4 h + (j & 3)   (nca_bf_kidx_hidden)
-                    const int ks = mq >> 1;
-                    const uint2 w2 = *reinterpret_cast<const uint2*>(dblk_b + ks * 1024 + (mq & 1) * 8);
-                    de[0] = __uint_as_float(w2.x << 16); de[1] = __uint_as_float(w2.x & 0xffff0000u);
-                    de[2] = __uint_as_float(w2.y << 16); de[3] = __uint_as_float(w2.y & 0xffff0000u);
-                    obase = 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (mq & 1);
-                } else {
-                    const float4 dv = *reinterpret_cast<const float4*>(dblk + mq * 256);
-                    de[0] = dv.x; de[1] = dv.y; de[2] = dv.z; de[3] = dv.w;
-                    obase = 32 * (mq >> 2) + 8 * (mq & 3);
-                }
+                for (int ks = 0; ks < 2 * MT; ++ks) {     // fragment k-step ks, element j <-> register 8 (ks & 1) + j of row tile ks >> 1
+                    const uint4 w4 = *reinterpret_cast<const uint4*>(db + ks * 1024);
+                    const unsigned ww[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int o = obase + e + 4 * lh;
-                    const float4* wr = reinterpret_cast<const float4*>(zw + o * ZG_KPAD);
-#pragma unroll
-                    for (int f4 = 0; f4 < ZG_KPAD / 4; ++f4) {
-                        const float4 w = wr[f4];
-                        G[4 * f4] = fmaf(w.x, de[e], G[4 * f4]);
-                        G[4 * f4 + 1] = fmaf(w.y, de[e], G[4 * f4 + 1]);
-                        G[4 * f4 + 2] = fmaf(w.z, de[e], G[4 * f4 + 2]);
-                        G[4 * f4 + 3] = fmaf(w.w, de[e], G[4 * f4 + 3]);
+                    for (int u = 0; u < 4; ++u) {
+                        D[ks >> 1][8 * (ks & 1) + 2 * u] = __uint_as_float(ww[u] << 16);
+                        D[ks >> 1][8 * (ks & 1) + 2 * u + 1] = __uint_as_float(ww[u] & 0xffff0000u);
                     }
                 }
-            }
+            } else {
+                const float* df = a.dscratch + (tile * a.d_total + nn.drow[src]) * 32 + lane * 4;
 #pragma unroll
-            for (int f = 0; f < ZG_KPAD; ++f) G[f] += __shfl_xor(G[f], 32);
+                for (int mq = 0; mq < 4 * MT; ++mq) {
+                    const float4 dv = *reinterpret_cast<const float4*>(df + mq * 256);
+                    D[mq >> 2][4 * (mq & 3)] = dv.x; D[mq >> 2][4 * (mq & 3) + 1] = dv.y;
+                    D[mq >> 2][4 * (mq & 3) + 2] = dv.z; D[mq >> 2][4 * (mq & 3) + 3] = dv.w;
+                }
+            }
+            zg_f32x16 G[ZG_MT];
+#pragma unroll
+            for (int m = 0; m < ZG_MT; ++m)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) G[m][i] = 0.f;
+            const float4* img = reinterpret_cast<const float4*>(zw) + lane;
+#pragma unroll
+            for (int sidx = 0; sidx < NS; ++sidx) {
+                const float4 av = img[sidx * 64];
+                const float b = D[sidx >> 4][sidx & 15];
+                G[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b, G[0], 0, 0, 0);
+                G[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b, G[1], 0, 0, 0);
+                G[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b, G[2], 0, 0, 0);
+            }
+            // G of natural row rr (compile-time) if this lane half holds it, else 0
+            auto pick = [&](int rr) __attribute__((always_inline)) -> double {
+                const int m = rr >> 5, x = rr & 31, hb = (x >> 2) & 1, i = (x & 3) + 4 * (x >> 3);
+                return lh == hb ? (double)G[m][i] : 0.0;
+            };
             // the query point, as the forward forms it (model_helpers.py:117-120)
             const float zz = a.z[ray * a.zs_r + smp];
             float p[3];
@@ -727,31 +742,53 @@ __global__ __launch_bounds__(256) void nca_zgrad_f32(const NcaZgradArgs a) {
             }
             double dp[3] = {0.0, 0.0, 0.0};
             if (nn.enc_mode == NCA_ENC_FOURIER) {
-                for (int i = 0; i < 3 * nn.L; ++i) {
-                    const int c = i % 3;
-                    const float pc = c == 0 ? p[0] : (c == 1 ? p[1] : p[2]);
-                    const float coef = nn.four[i];
-                    const float v = __fmul_rn(__fmul_rn(6.283185482025146484375f, pc), coef);
-                    const double dv = 6.283185482025146484375 * (double)coef;
-                    const double t = dv * (cos((double)v) * (double)G[i] - sin((double)v) * (double)G[3 * nn.L + i]);
-                    dp[c] += t;
+#pragma unroll
+                for (int i = 0; i < 48; ++i) {
+                    if (i < 3 * nn.L) {
+                        const int c = i % 3;
+                        const float coef = nn.four[i];
+                        const float v = __fmul_rn(__fmul_rn(6.283185482025146484375f, p[c]), coef);
+                        const double dv = 6.283185482025146484375 * (double)coef;
+                        double sv, cv;
+                        sincos((double)v, &sv, &cv);
+                        // rows i (sin) and 3 L + i (cos): the second index is not a compile-time constant -> both halves via LDS-free select
+                        double gs = pick(i), gc = 0.0;
+#pragma unroll
+                        for (int LL = 1; LL <= 16; ++LL) if (nn.L == LL && 3 * LL + i < 96) gc = pick(3 * LL + i);
+                        dp[c] += dv * (cv * gs - sv * gc);
+                    }
                 }
             } else {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) dp[c] = (double)G[c];
+                for (int c = 0; c < 3; ++c) dp[c] = pick(c);
                 if (nn.enc_mode == NCA_ENC_BANDS) {
-                    for (int k = 0; k < nn.L; ++k) {
-                        const double wk = nn.win ? (double)nn.win[k] : 1.0;
-                        const float sc = ldexpf(1.f, k);
+                    double sn[3], cs[3];
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            const float xb = __fmul_rn(p[c], sc);
-                            const float u = __fadd_rn(xb, 1.57079637050628662109375f);
-                            dp[c] += wk * (double)sc * (cos((double)xb) * (double)G[3 + 6 * k + c] + cos((double)u) * (double)G[6 + 6 * k + c]);
+                    for (int c = 0; c < 3; ++c) sincos((double)p[c], &sn[c], &cs[c]);
+#pragma unroll
+                    for (int k = 0; k < 15; ++k) {
+                        if (k < nn.L) {
+                            const double wk = nn.win ? (double)nn.win[k] : 1.0;
+                            const float sc = ldexpf(1.f, k);
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) {
+                                // d/dx sin(xb) = cos(xb);  d/dx sin(fl32(xb + fl32(pi/2))) = cos(xb + pi/2 + eps) = -(sin(xb) cos eps + cos(xb) sin eps)
+                                const float xb = __fmul_rn(p[c], sc);
+                                const float u = __fadd_rn(xb, 1.57079637050628662109375f);
+                                const double eps = ((double)u - (double)xb) - 1.57079632679489661923;
+                                const double e2 = eps * eps;
+                                const double se = eps * (1.0 - e2 * (1.0 / 6.0)), ce = 1.0 - e2 * (0.5 - e2 * (1.0 / 24.0));
+                                const double dcos = -(sn[c] * ce + cs[c] * se);
+                                dp[c] += wk * (double)sc * (cs[c] * pick(3 + 6 * k + c) + dcos * pick(6 + 6 * k + c));
+                                const double s2 = 2.0 * sn[c] * cs[c], c2 = 1.0 - 2.0 * sn[c] * sn[c];
+                                sn[c] = s2; cs[c] = c2;
+                            }
                         }
                     }
                 }
             }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) dp[c] += __shfl_xor(dp[c], 32);
             const double gz = dd[0] * dp[0] + dd[1] * dp[1] + dd[2] * dp[2];
             if (valid && lh == 0) {
                 float* dst = a.g_z + ray * a.S + smp;
@@ -761,14 +798,22 @@ __global__ __launch_bounds__(256) void nca_zgrad_f32(const NcaZgradArgs a) {
     }
 }
 
-hipError_t nca_launch_zgrad_f32(const NcaZgradArgs& a, hipStream_t st) {
-    int F = a.net[0].F;
-    for (int n = 1; n < a.nnets; ++n) if (a.net[n].F > F) F = a.net[n].F;
-    const int lds = F * ZG_KPAD * (int)sizeof(float);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_zgrad_f32), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+template <int F>
+static hipError_t launch_zgrad(const NcaZgradArgs& a, hipStream_t st) {
+    const int lds = 16 * (F / 32) * 64 * 4 * (int)sizeof(float);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_zgrad_f32<F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     int64_t blocks = (a.ntiles + 3) / 4;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 512) blocks = 512;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(nca_zgrad_f32, dim3((unsigned)blocks), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(nca_zgrad_f32<F>, dim3((unsigned)blocks), dim3(256), lds, st, a);
     return hipGetLastError();
+}
+hipError_t nca_launch_zgrad_f32(const NcaZgradArgs& a, hipStream_t st) {
+    for (int n = 1; n < a.nnets; ++n) if (a.net[n].F != a.net[0].F) return hipErrorInvalidValue;
+    switch (a.net[0].F) {
+        case 32: return launch_zgrad<32>(a, st);
+        case 64: return launch_zgrad<64>(a, st);
+        case 128: return launch_zgrad<128>(a, st);
+    }
+    return hipErrorInvalidValue;
 }
