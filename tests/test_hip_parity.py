@@ -848,6 +848,47 @@ def test_depth_gradient_vs_oracle(golden, dev, enc, F, ray_dt):
             assert rel_err(p_.grad.cpu(), pd64[k].grad) < max(TOL, 3 * rel_err(pd32[k].grad, pd64[k].grad)), ("dynamic", k)
 
 
+def test_depth_gradient_shared_depth_vector(dev):
+    """One depth vector shared by all rays (the coarse pass's layout) with requires_grad: the per-sample depth gradients are
+    summed over the rays; against autograd through the f64 oracle."""
+    from nerfca_amd import render_rays
+    gen = torch.Generator().manual_seed(4321)
+    ss, sd = O.NetSpec(num_filters=64, num_early_layers=2), O.NetSpec(num_filters=64, num_early_layers=2, num_time_dim=8)
+    ps, pd = O.init_params(ss, gen), O.init_params(sd, gen)
+    s, t = make_static(ps, dev, F=64, early=2, late=0), make_dynamic(pd, dev, F=64, early=2, late=0, T=8)
+    for m in (s, t):
+        m.update_freq_mask_alpha(60000, 150000)
+    win = O.freq_mask_alpha(12, 60000, 150000, 1)[0]
+    R, S = 11, 50
+    o = (torch.rand(R, 3, generator=gen) * 0.2 + torch.tensor([3.0, -2.0, 2.5])).double()
+    d = (torch.rand(R, 3, generator=gen) - 0.5).double()
+    ph = torch.randint(0, 10, (R,), generator=gen)
+    z = O.stratified_depths(O.depth_values(3.4259, 5.5741, S), torch.rand(S, generator=gen))
+    I0 = torch.full((R,), 2.15991)
+    cp, cs, cd = torch.randn(R, generator=gen).double(), torch.randn(R, S, generator=gen), torch.randn(R, S, generator=gen)
+
+    def oracle(dt):
+        pso = {k: v.clone().to(dt) for k, v in ps.items()}
+        pdo = {k: v.clone().to(dt) for k, v in pd.items()}
+        zo = z.clone().requires_grad_(True)
+        pts = O.query_points(o, d, zo).to(dt)
+        dists = torch.cat((zo[1:] - zo[:-1], torch.tensor([1e-10])), -1).double()
+        f = O.activation("softplus")
+        a_ = f(O.static_forward(pso, ss, pts, win.to(dt)).reshape(R, S)) * 1e-2
+        b_ = f(O.dynamic_forward(pdo, sd, pts, ph[:, None].repeat(1, S).flatten(), win.to(dt)).reshape(R, S)) * 1e-2
+        pix = I0.to(dt) - torch.sum((a_ + b_) * dists, -1)
+        ((pix * cp).sum() + (a_ * cs).sum() * 50 + (b_ * cd).sum() * 50).backward()
+        return zo.grad
+
+    g64, g32 = oracle(torch.float64), oracle(torch.float32)
+    zt = z.to(dev).requires_grad_(True)
+    dists_t = torch.cat((zt[1:] - zt[:-1], torch.tensor([1e-10], device=dev)), -1).double()
+    pix, a, b = render_rays(s, t, o.to(dev), d.to(dev), ph.to(dev), I0.to(dev), zt, dists_t)
+    ((pix * cp.to(dev)).sum() + (a * cs.to(dev)).sum() * 50 + (b * cd.to(dev)).sum() * 50).backward()
+    assert zt.grad.shape == (S,)
+    assert rel_err(zt.grad.cpu(), g64) < max(TOL, 3 * rel_err(g32, g64)), rel_err(zt.grad.cpu(), g64)
+
+
 @pytest.mark.parametrize("F,R,S,it_s,it_d,tol", [(128, 9, 130, 10000, 10000, 3e-2), (32, 5, 33, 10000, 20000, 3e-2), (128, 9, 130, 60000, 90000, 0.3)])
 def test_depth_gradient_bf16_vs_f32(dev, F, R, S, it_s, it_d, tol):
     """The bf16 mode forms d loss / d depth from its own (bf16, fragment-major) D_0 blocks -- backward from the forward's
