@@ -647,8 +647,8 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     memset(&wp, 0, sizeof(wp));
     for (int n = 0; n < a.nnets; ++n) {
         const int np = stored ? nca_pairs(lays[n], prec) : 0;
-        if (np > 0 && g_depth) return fail(NCA_E_UNSUPPORTED, "depth gradients need D_0, which the paired weight-gradient jobs (NCA_PAIR=1) do not store");
         if (stored) set_skip_bits(&a.net[n], prec); else { a.net[n].skip_h = 0; a.net[n].skip_d = 0; }
+        if (g_depth) a.net[n].skip_d &= ~1;      // the depth gradient reads D_0: have it written (the pair kernel recomputes its own copy)
         if (wp.npairs + np > NCA_MAX_PAIRS) return fail(NCA_E_UNSUPPORTED, "too many paired wgrad jobs");
         if (bf) add_jobs_bf16(&w, &wp, np, n, binds[n].packed, lays[n], a.net[n].row0, a.net[n].drow0, slab_off[n], onehot_off[n],
                               stored && a.share_enc && n == 0 ? a.net[1].row0 : a.net[n].row0, onchip ? lays[n].NL - 1 : -1);
