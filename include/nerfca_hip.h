@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NCA_ABI_VERSION 5
+#define NCA_ABI_VERSION 6
 
 enum {
     NCA_OK = 0,
@@ -234,6 +234,17 @@ typedef struct NcaAdam {
 /* n, params, grads, exp_avg, exp_avg_sq: HOST arrays of n_seg entries (device pointers, f32). */
 int nca_adam_step(const NcaAdam* cfg, int32_t n_seg, const int64_t* n, float* const* params, const float* const* grads,
                   float* const* exp_avg, float* const* exp_avg_sq, int64_t* step, void* stream);
+
+/* ---- process-wide tunables: A/B switches of the planner, also the hook with which tests force a kernel path at sizes the
+ *      oracle can afford.  nca_set_option returns NCA_OK or NCA_E_INVALID; values persist until changed. ------------------- */
+enum {
+    NCA_OPT_ONCHIP_MIN_TILES = 0, /* bf16 backward from a forward store: keep the last hidden layer's weight gradient on chip (one launch
+                                     per net) when the batch has at least this many 64-sample wave tiles.  0 = always, -1 = never;
+                                     default 8 * 8 waves * CUs (initial value from the environment: NCA_ONCHIP=0 -> never, =force -> always) */
+    NCA_OPT_COUNT
+};
+int64_t nca_get_option(int32_t opt);
+int nca_set_option(int32_t opt, int64_t value);
 
 /* ---- in-library kernel timing (HIP events on the launch stream), used by bench.py -------- */
 enum { NCA_K_PACK = 0, NCA_K_FWD = 1, NCA_K_BWD_DGRAD = 2, NCA_K_BWD_WGRAD = 3, NCA_K_BWD_REDUCE = 4, NCA_K_LOSS = 5, NCA_K_ADAM = 6, NCA_K_COUNT = 7 };

@@ -15,6 +15,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libnerfca_hip.so")
 ENC_NONE, ENC_BANDS, ENC_FOURIER = 0, 1, 2
 ACT_SIGMOID, ACT_SOFTPLUS, ACT_CLAMP = 0, 1, 2
 PREC_F32, PREC_BF16 = 0, 1
+ABI_VERSION = 6
+OPT_ONCHIP_MIN_TILES = 0
 K_PACK, K_FWD, K_BWD_DGRAD, K_BWD_WGRAD, K_BWD_REDUCE, K_LOSS, K_ADAM = 0, 1, 2, 3, 4, 5, 6
 KERNEL_KINDS = {"pack": K_PACK, "fwd": K_FWD, "bwd_dgrad": K_BWD_DGRAD, "bwd_wgrad": K_BWD_WGRAD, "bwd_reduce": K_BWD_REDUCE,
                 "loss": K_LOSS, "adam": K_ADAM}
@@ -85,6 +87,8 @@ SYMBOLS = {
     "nca_fine_depths_given_max": (C.c_int, [_I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _P]),
     "nca_adam_step": (C.c_int, [C.POINTER(NcaAdam), _I32, C.POINTER(_I64), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P),
                                 _P, _P]),
+    "nca_get_option": (_I64, [_I32]),
+    "nca_set_option": (C.c_int, [_I32, _I64]),
     "nca_timing_enable": (C.c_int, [_I32]),
     "nca_timing_read": (C.c_int, [_I32, C.POINTER(C.c_double), C.POINTER(_I64)]),
     "nca_timing_reset": (C.c_int, []),
@@ -103,7 +107,7 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.nca_abi_version() != 5:
+        if handle.nca_abi_version() != ABI_VERSION:
             raise NcaError("libnerfca_hip.so ABI version mismatch")
         _lib = handle
     return _lib
@@ -133,3 +137,11 @@ def timing_read(kind: str):
     ms, n = C.c_double(0.0), C.c_int64(0)
     check(lib().nca_timing_read(KERNEL_KINDS[kind], C.byref(ms), C.byref(n)))
     return ms.value, n.value
+
+
+def get_option(opt: int) -> int:
+    return int(lib().nca_get_option(opt))       # (a value may be negative: -1 = never)
+
+
+def set_option(opt: int, value: int) -> None:
+    check(lib().nca_set_option(opt, int(value)))

@@ -111,6 +111,45 @@ extern "C" int nca_timing_read(int32_t kind, double* total_ms, int64_t* launches
 
 // ---------------------------------------------------------------------------------- basics
 extern "C" int nca_abi_version(void) { return NCA_ABI_VERSION; }
+
+// ---------------------------------------------------------------------------------- tunables
+namespace {
+constexpr int64_t OPT_AUTO = INT64_MIN;
+std::mutex g_omu;
+int64_t g_opt[NCA_OPT_COUNT];
+bool g_opt_init = false;
+void opt_init_locked() {
+    if (g_opt_init) return;
+    for (int i = 0; i < NCA_OPT_COUNT; ++i) g_opt[i] = OPT_AUTO;
+    const char* e = getenv("NCA_ONCHIP");
+    if (e && e[0] == '0') g_opt[NCA_OPT_ONCHIP_MIN_TILES] = -1;
+    else if (e && e[0] == 'f') g_opt[NCA_OPT_ONCHIP_MIN_TILES] = 0;
+    g_opt_init = true;
+}
+int64_t opt_value(int opt) {
+    std::lock_guard<std::mutex> lk(g_omu);
+    opt_init_locked();
+    int64_t v = g_opt[opt];
+    if (v == OPT_AUTO) {
+        // on-chip dW pays only when every workgroup sees enough tiles to amortise the per-net launches and the exchange: at the
+        // reference's default batch of 1024 rays x 500 samples -- 4 tile groups per workgroup -- it costs 3.6 %
+        if (opt == NCA_OPT_ONCHIP_MIN_TILES) v = (int64_t)8 * NCA_WAVES * num_cus();
+    }
+    return v;
+}
+}  // namespace
+extern "C" int64_t nca_get_option(int32_t opt) {
+    if (opt < 0 || opt >= NCA_OPT_COUNT) return fail(NCA_E_INVALID, "option %d out of range", opt);
+    return opt_value(opt);
+}
+extern "C" int nca_set_option(int32_t opt, int64_t value) {
+    if (opt < 0 || opt >= NCA_OPT_COUNT) return fail(NCA_E_INVALID, "option %d out of range", opt);
+    if (opt == NCA_OPT_ONCHIP_MIN_TILES && value < -1) return fail(NCA_E_INVALID, "NCA_OPT_ONCHIP_MIN_TILES takes -1 (never), 0 (always) or a tile count");
+    std::lock_guard<std::mutex> lk(g_omu);
+    opt_init_locked();
+    g_opt[opt] = value;
+    return NCA_OK;
+}
 extern "C" const char* nca_last_error(void) { return g_err; }
 
 static int check_prec(int32_t prec) {
@@ -595,10 +634,8 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
         if (store_bytes < spl.bytes) return fail(NCA_E_WORKSPACE, "forward store %lld < %lld bytes", (long long)store_bytes, (long long)spl.bytes);
     }
     // bf16 backward from a store: the weight gradient of the last hidden layer stays on chip (one launch per net)
-    static const bool onchip_off = getenv("NCA_ONCHIP") != nullptr && getenv("NCA_ONCHIP")[0] == '0';     // NCA_ONCHIP=0: A/B switch
-    // (worth it only when every workgroup sees enough tiles to amortise the per-net launches and the exchange: at the
-    // reference's default batch of 1024 rays x 500 samples -- 4 tile groups per workgroup -- it costs 3.6 %)
-    const bool onchip = !onchip_off && bf && stored && units * tiles_per_unit >= (int64_t)8 * NCA_WAVES * num_cus();
+    const int64_t oc_min = opt_value(NCA_OPT_ONCHIP_MIN_TILES);          // -1: never (see nca_set_option)
+    const bool onchip = oc_min >= 0 && bf && stored && units * tiles_per_unit >= oc_min;
     const bool per_net_launch = onchip;
     BwdPlan p;
     int rc = plan_bwd(lays, a.nnets, prec, units, tiles_per_unit, work_bytes, &p, stored, onchip);

@@ -15,13 +15,14 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 
-def _run(rank, world, mode, prec):
+def _run(rank, world, mode, prec, device_index=0):
     import nerfca_amd
     from nerfca_amd import synthetic
     from nerfca_amd.model.CPPN import CPPN
     from nerfca_amd.model.Temporal import Temporal
     from nerfca_amd.train.trainer import CompositeTrainer, TrainConfig
-    dev = torch.device("cuda", 0)
+    dev = torch.device("cuda", device_index)
+    torch.cuda.set_device(dev)
     S, R = 48, 192
     data = synthetic.make_dataset(16, S, dev, views=synthetic.TRAIN_VIEWS[:2], n_phases=3, F=32)
     torch.manual_seed(3)
@@ -47,12 +48,17 @@ def _run(rank, world, mode, prec):
     return grads.cpu(), params.cpu()
 
 
-def _worker(rank, world, port, outdir, mode, prec):
+def _worker(rank, world, port, outdir, mode, prec, backend="gloo"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend == "nccl":          # RCCL: one device per rank
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        g, p = _run(rank, world, mode, prec)
+        g, p = _run(rank, world, mode, prec, device_index=rank if backend == "nccl" else 0)
         torch.save({"g": g, "p": p}, os.path.join(outdir, f"rank{rank}.pt"))
     finally:
         dist.destroy_process_group()
@@ -80,3 +86,54 @@ def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path, mode, prec, gtol):
     perr = float((r0["p"] - p1).abs().max() / p1.abs().max())
     assert gerr < gtol, gerr
     assert perr < 1e-2, perr
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("mode,prec,gtol", [("fused", "f32", 1e-5), ("fused", "bf16", 1e-3), ("fine", "f32", 1e-3)])
+def test_two_ranks_over_rccl_equal_one_rank(tmp_path, mode, prec, gtol):
+    """The same comparison with backend `nccl` (= RCCL), one GPU per rank: runs where the box has two GPUs (the driver's
+    multi-GPU node); a one-GPU box skips it -- RCCL refuses two ranks on one device."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL takes one device per rank)")
+    g1, p1 = _run(0, 1, mode, prec)
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), mode, prec, "nccl"), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "rank0.pt")
+    r1 = torch.load(tmp_path / "rank1.pt")
+    assert torch.equal(r0["g"], r1["g"]) and torch.equal(r0["p"], r1["p"])
+    assert float((r0["g"] - g1).abs().max() / g1.abs().max()) < gtol
+
+
+def _bench(args, env_extra, timeout=900):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **env_extra)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        if k not in env_extra:
+            env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, cwd=root, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(900)
+def test_bench_over_rccl_with_one_rank():
+    """bench.py's N > 1 code path on the one-GPU box: RCCL process group of one rank (NERFCA_FORCE_PG=1), gradient all-reduce
+    every step, barriers, max-over-ranks time -- in a child process, as the driver runs it."""
+    port = str(_free_port())
+    line = _bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--rays", "8192", "--no-cpu-baseline", "--no-extras"],
+                  {"NERFCA_FORCE_PG": "1", "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": port})
+    assert line["rccl_ranks"] == 1 and line["n_gpus"] == 1 and line["value"] > 0
+
+
+@pytest.mark.timeout(1200)
+def test_bench_self_launch_two_gpus():
+    """`python bench.py --gpus 2` with no launcher around it: the parent starts the two ranks itself (before it touches the
+    GPU), they train over RCCL, rank 0's line comes back.  Needs two GPUs."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    line = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], {})
+    assert line["rccl_ranks"] == 2 and line["n_gpus"] == 2 and line["config"]["parallelism"] == "ray-sharded dp2"

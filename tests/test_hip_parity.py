@@ -1483,9 +1483,10 @@ def test_stored_forward_backward_equals_recompute(dev, prec, it_d, R, S, F, earl
             outs.append([pix.detach().clone(), a.detach().clone(), b.detach().clone()] + [p.grad.clone() for p in list(s.parameters()) + list(t.parameters())])
     finally:
         fused.STORE_FORWARD_LIMIT_BYTES, fused.BWD_WORKSPACE_BYTES = saved
-    # f32: bit for bit.  bf16 from the store: the weight gradient of the LAST hidden layer is accumulated on chip by the dgrad
-    # kernel and the wgrad kernel then spreads its remaining jobs over more sample splits -- the same products in another
-    # (still fixed) summation order: outputs bit for bit, gradients to f32 summation rounding
+    # f32: bit for bit.  bf16: at these sizes the planner runs the plain backward from the store (mode 3; the variant that keeps
+    # the last hidden layer's weight gradient on chip starts at ~1 M samples and has its own tests in test_onchip_bf16.py);
+    # its wgrad grid splits the samples differently from the recompute backward's -- the same products in another (still
+    # fixed) summation order: outputs bit for bit, gradients to f32 summation rounding
     names = ["pix", "sigma_s", "sigma_d"] + ["s." + k for k, _ in s.named_parameters()] + ["t." + k for k, _ in t.named_parameters()]
     for i, (name, x, y) in enumerate(zip(names, outs[0], outs[1])):
         if prec == "bf16" and i >= 3:
