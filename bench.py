@@ -292,6 +292,8 @@ def psnr_record(args, dev):
             tr.step(it)
         tr.update_windows(steps)
         out["hip_" + prec] = psnr_of(tr, steps)
+        if prec == "f32":
+            out["_hip_f32_params"] = torch.cat([p.detach().flatten().cpu() for p in list(tr.t.parameters()) + list(tr.s.parameters())])
     # the oracle on the host cores, fed the SAME ray ids and jitter draws
     tr = fresh("f32")
     ss, sd = O.NetSpec(num_filters=128), O.NetSpec(num_filters=128, num_time_dim=8)
@@ -309,6 +311,9 @@ def psnr_record(args, dev):
         zj = O.stratified_depths(z0, tr.draw_jitter(it))
         ot.step(it, rays[:, 0, :], rays[:, 1, :], ph[:, None].repeat(1, S), I0, zj, rays[:, 2, 0], rays[:, 3, 0])
     cpu_s = time.perf_counter() - t0
+    hip_f32 = out.pop("_hip_f32_params")
+    cpu = torch.cat([v.detach().flatten() for v in list(ot.pd.values()) + list(ot.ps.values())])
+    out["max_param_diff_hip_f32_vs_oracle"] = float((hip_f32 - cpu).abs().max() / cpu.abs().max())
     tr.s.load_state_dict({k: v.detach() for k, v in ot.ps.items()})
     tr.t.load_state_dict({k: v.detach() for k, v in ot.pd.items()})
     tr.update_windows(steps)

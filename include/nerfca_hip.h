@@ -241,6 +241,11 @@ enum {
     NCA_OPT_ONCHIP_MIN_TILES = 0, /* bf16 backward from a forward store: keep the last hidden layer's weight gradient on chip (one launch
                                      per net) when the batch has at least this many 64-sample wave tiles.  0 = always, -1 = never;
                                      default 8 * 8 waves * CUs (initial value from the environment: NCA_ONCHIP=0 -> never, =force -> always) */
+    NCA_OPT_STAGE_FP8 = 1,        /* bf16 mode with a forward store: the layer inputs and output gradients that only the weight-gradient
+                                     kernel reads cross HBM as 8-bit floats (inputs e4m3, gradients e5m2 scaled by a power of two per
+                                     64-sample tile; f32 accumulation; the MLP contractions themselves stay bf16).  1 = on (default),
+                                     0 = bf16 staging.  Read when a forward writes its store and when a backward reads one: do not
+                                     change it between a forward and its backward.  Initial value from NCA_STAGE_FP8 (0 / 1) */
     NCA_OPT_COUNT
 };
 int64_t nca_get_option(int32_t opt);

@@ -124,6 +124,8 @@ void opt_init_locked() {
     const char* e = getenv("NCA_ONCHIP");
     if (e && e[0] == '0') g_opt[NCA_OPT_ONCHIP_MIN_TILES] = -1;
     else if (e && e[0] == 'f') g_opt[NCA_OPT_ONCHIP_MIN_TILES] = 0;
+    e = getenv("NCA_STAGE_FP8");
+    if (e && (e[0] == '0' || e[0] == '1')) g_opt[NCA_OPT_STAGE_FP8] = e[0] - '0';
     g_opt_init = true;
 }
 int64_t opt_value(int opt) {
@@ -134,6 +136,7 @@ int64_t opt_value(int opt) {
         // on-chip dW pays only when every workgroup sees enough tiles to amortise the per-net launches and the exchange: at the
         // reference's default batch of 1024 rays x 500 samples -- 4 tile groups per workgroup -- it costs 3.6 %
         if (opt == NCA_OPT_ONCHIP_MIN_TILES) v = (int64_t)8 * NCA_WAVES * num_cus();
+        if (opt == NCA_OPT_STAGE_FP8) v = 1;
     }
     return v;
 }
@@ -145,6 +148,7 @@ extern "C" int64_t nca_get_option(int32_t opt) {
 extern "C" int nca_set_option(int32_t opt, int64_t value) {
     if (opt < 0 || opt >= NCA_OPT_COUNT) return fail(NCA_E_INVALID, "option %d out of range", opt);
     if (opt == NCA_OPT_ONCHIP_MIN_TILES && value < -1) return fail(NCA_E_INVALID, "NCA_OPT_ONCHIP_MIN_TILES takes -1 (never), 0 (always) or a tile count");
+    if (opt == NCA_OPT_STAGE_FP8 && value != 0 && value != 1) return fail(NCA_E_INVALID, "NCA_OPT_STAGE_FP8 takes 0 or 1");
     std::lock_guard<std::mutex> lk(g_omu);
     opt_init_locked();
     g_opt[opt] = value;
@@ -299,31 +303,14 @@ static bool can_share_enc(const NcaFusedArgs& a, int32_t prec) {
            a.net[0].four == a.net[1].four;
 }
 
-// bf16 backward from a store: weight-gradient jobs of layers (2p, 2p+1), p < nca_pairs(y), run as pairs that recompute the
-// input of layer 2p+1 and D_{2p} (NcaWgradPair), so the fused kernels do not write those blocks.  The last layer never pairs
-// (its input is what the backward restarts from).  EXPERIMENT, off unless NCA_PAIR=1: it takes 13 GB of stores out of the
-// forward (-0.5 ms) and 13 GB out of each net's backward (-0.6 ms each) and halves the weight-gradient reads, but the pair
-// kernel as built is bound by the latency of its loads (8 KB per wave in flight; registers and LDS are full) and runs
-// 11.2 ms against the 7.3 ms of the plain jobs: 25.6 ms per step instead of 24.1.
-static int nca_pairs(const NcaLayout& y, int32_t prec) {
-    static const bool on = getenv("NCA_PAIR") != nullptr && getenv("NCA_PAIR")[0] == '1';
-    if (!on || prec != NCA_PREC_BF16) return 0;
-    return (y.NL - 1) / 2;
-}
-static void set_skip_bits(NcaNetArgs* na, int32_t prec) {
-    const int np = nca_pairs(na->lay, prec);
-    na->skip_h = 0;
-    na->skip_d = 0;
-    for (int p2 = 0; p2 < np; ++p2) { na->skip_h |= 1 << (2 * p2); na->skip_d |= 1 << (2 * p2); }    // hidden block 2p = input of layer 2p+1; D_{2p}
-}
-
 struct StorePlan {
     int64_t h_stride;     // per 32-sample tile of the H region: bytes (bf16) / rows of 32 floats (f32)
     int64_t row0[2], off_m, off_r, bytes;
     int32_t mask_layers;
 };
 // wave_tiles: 64-sample tiles (bf16) / 32-sample tiles (f32)
-static bool store_plan(const NcaLayout* lays, int nnets, int32_t prec, int64_t wave_tiles, StorePlan* sp, bool share_enc = false) {
+// h8: bf16 path, the hidden blocks 0..NL-3 are e4m3 (fp8 staging)
+static bool store_plan(const NcaLayout* lays, int nnets, int32_t prec, int64_t wave_tiles, StorePlan* sp, bool share_enc = false, bool h8 = false) {
     if (nnets == 2 && lays[0].F != lays[1].F) return false;
     const bool bf = prec == NCA_PREC_BF16;
     const int64_t EB = 32 * (int64_t)NCA_BF_ENCROWS * 2;
@@ -331,12 +318,12 @@ static bool store_plan(const NcaLayout* lays, int nnets, int32_t prec, int64_t w
     for (int n = 0; n < nnets; ++n) {
         if (lays[n].NL < 2) return false;                 // no hidden layer: nothing worth storing
         sp->row0[n] = sp->h_stride;
-        if (bf) sp->h_stride += EB + (int64_t)(lays[n].NL - 1) * 32 * lays[n].F * 2;   // inputs of layers 0 .. NL-1
+        if (bf) sp->h_stride += EB + nca_bf_hbytes(lays[n], h8);                      // inputs of layers 0 .. NL-1
         else sp->h_stride += lays[n].K0rows_pad + (int64_t)lays[n].NL * lays[n].F;
         if (lays[n].NL - 1 > sp->mask_layers) sp->mask_layers = lays[n].NL - 1;
     }
     if (share_enc) {      // [dynamic: input block + hidden blocks][static: hidden blocks only]
-        const int64_t dyn = EB + (int64_t)(lays[1].NL - 1) * 32 * lays[1].F * 2;
+        const int64_t dyn = EB + nca_bf_hbytes(lays[1], h8);
         sp->row0[1] = 0;
         sp->row0[0] = dyn - EB;       // so that row0 + EB is where the static net's first hidden block starts
         sp->h_stride -= EB;
@@ -365,6 +352,7 @@ extern "C" int64_t nca_render_store_bytes(const NcaRays* rays, const NcaNet* net
     if (nn == 2) { rc = layout_of(net_d, &lays[1], prec); if (rc) return rc; }
     StorePlan sp;
     const int ts = tile_samples(prec);
+    // (sized for bf16 staging, the larger layout: a store may be allocated before NCA_OPT_STAGE_FP8 is settled)
     if (!store_plan(lays, nn, prec, rays->R * ((rays->S + ts - 1) / ts), &sp)) return 0;
     return sp.bytes;
 }
@@ -438,11 +426,11 @@ extern "C" int nca_render_fwd(const NcaRays* rays, int32_t prec,
         NcaLayout lays[2] = {a.net[0].lay, a.net[1].lay};
         StorePlan spl;
         a.share_enc = can_share_enc(a, prec) ? 1 : 0;
-        if (!store_plan(lays, a.nnets, prec, a.ntiles, &spl, a.share_enc != 0))
+        a.h8 = (prec == NCA_PREC_BF16 && opt_value(NCA_OPT_STAGE_FP8) != 0) ? 1 : 0;
+        if (!store_plan(lays, a.nnets, prec, a.ntiles, &spl, a.share_enc != 0, a.h8 != 0))
             return fail(NCA_E_UNSUPPORTED, "a forward store needs nets of one width with at least one hidden layer");
         if (store_bytes < spl.bytes) return fail(NCA_E_WORKSPACE, "forward store %lld < %lld bytes", (long long)store_bytes, (long long)spl.bytes);
         kmode = NCA_KM_FWD_STORE;
-        for (int n = 0; n < a.nnets; ++n) set_skip_bits(&a.net[n], prec);
         a.scratch = static_cast<float*>(store);
         a.rows_total = spl.h_stride;
         for (int n = 0; n < a.nnets; ++n) a.net[n].row0 = spl.row0[n];
@@ -453,7 +441,7 @@ extern "C" int nca_render_fwd(const NcaRays* rays, int32_t prec,
     }
     {
         Span sp(NCA_K_FWD, st);
-        if (prec == NCA_PREC_BF16) HIPCHK(nca_launch_fused_bf16(a.net[0].lay.F, a, kmode, grid, st));
+        if (prec == NCA_PREC_BF16) HIPCHK(nca_launch_fused_bf16(a.net[0].lay.F, a, kmode, grid, st, a.h8 != 0));
         else HIPCHK(nca_launch_fused_f32(a.net[0].lay.F, a, kmode, grid, st));
     }
     HIPCHK(nca_launch_pix_f32(rays->R, a.nchunk, rays->I0, a.part, pix, st));
@@ -475,19 +463,21 @@ struct BwdPlan {
 
 static int64_t scratch_rows(const NcaLayout& y) { return y.K0rows_pad + (int64_t)(y.NL - 1) * y.F + (int64_t)y.NL * y.F; }
 
+// d8: bf16 backward from a store with fp8 staging (D_0..D_{NL-2} as e5m2 + one inverse-scale record per tile)
 static int plan_bwd(const NcaLayout* lays, int nnets, int32_t prec, int64_t units, int64_t tiles_per_unit, int64_t budget, BwdPlan* p,
-                    bool stored = false, bool onchip = false) {
+                    bool stored = false, bool onchip = false, bool d8 = false) {
     const bool bf = prec == NCA_PREC_BF16;
     p->tile_stride = 0;
     p->slab_stride = 0;
     p->njobs = 0;
     for (int n = 0; n < nnets; ++n) {
-        if (stored) p->tile_stride += bf ? (int64_t)lays[n].NL * 32 * lays[n].F * 2 : (int64_t)lays[n].NL * lays[n].F;   // only the D blocks live in the chunk scratch
+        if (stored) p->tile_stride += bf ? nca_bf_dbytes(lays[n], d8) : (int64_t)lays[n].NL * lays[n].F;   // only the D blocks live in the chunk scratch
         else p->tile_stride += bf ? nca_bf_tile_bytes(lays[n]) : scratch_rows(lays[n]);
         p->slab_stride += lays[n].n_params;
         for (int j = 0; j < lays[n].NL; ++j) p->njobs += lays[n].layer[j].kind == NCA_IN_SKIP ? 2 : 1;
         if (onchip) p->njobs -= 1;                    // the last hidden layer's weight gradient stays in the dgrad kernel
     }
+    if (stored && bf && d8) p->tile_stride += NCA_D8_REC_BYTES;
     for (int n = 0; n < nnets; ++n) p->slab_stride += (int64_t)lays[n].F * lays[n].P;
     p->slab_stride = align_up(p->slab_stride, 64);
     if (p->njobs > NCA_MAX_JOBS) return fail(NCA_E_UNSUPPORTED, "too many wgrad jobs");
@@ -568,12 +558,15 @@ static void add_jobs_f32(NcaWgradArgs* w, const NcaLayout& y, int64_t row0, int6
 }
 
 // net_off: byte offset of the net's input/H blocks in a tile of the H region; d_off: of its D blocks in a tile of the D region
-static void make_job_bf16(NcaWgradJob& g, const NcaLayout& y, int j, int64_t net_off, int64_t d_off, int64_t slab_off, int64_t onehot_off, int64_t enc_off) {
-    const int64_t EB = 32 * (int64_t)NCA_BF_ENCROWS * 2, HB = 32 * (int64_t)y.F * 2;
+// h8 / d8: formats of the store's hidden blocks and of this launch's D blocks (fp8 staging)
+static void make_job_bf16(NcaWgradJob& g, const NcaLayout& y, int j, int64_t net_off, int64_t d_off, int64_t slab_off, int64_t onehot_off, int64_t enc_off,
+                          bool h8, bool d8) {
+    const int64_t EB = 32 * (int64_t)NCA_BF_ENCROWS * 2;
     const NcaLayerL& l = y.layer[j];
     memset(&g, 0, sizeof(g));
     g.F = y.F;
-    g.d_row0 = d_off + (int64_t)j * HB;
+    g.d_row0 = d_off + nca_bf_doff(y, j, d8);
+    g.d8 = d8 ? 1 : 0;
     g.out_off = slab_off + l.w_off;
     g.out_ld = l.K;
     g.out_col0 = 0;
@@ -589,29 +582,24 @@ static void make_job_bf16(NcaWgradJob& g, const NcaLayout& y, int j, int64_t net
         g.fourier_L = y.enc_mode == NCA_ENC_FOURIER ? y.L : 0;
     } else {
         g.is_enc = 0;
-        g.b_row0 = net_off + EB + (int64_t)(j - 1) * HB;
+        g.b_row0 = net_off + EB + nca_bf_hoff(y, j - 1, h8);
+        g.h8 = (h8 && j - 1 < y.NL - 2) ? 1 : 0;
         g.b_row_bytes = y.F * 2;
         g.ncols_w = y.F;
         g.T = 0;
         g.P = 0;
     }
 }
-// jobs of layers below 2 * npairs go to `pairs` (two per entry), the others to `w`; skip_layer: accumulated on chip by the dgrad kernel
-static void add_jobs_bf16(NcaWgradArgs* w, NcaWgradPairArgs* pairs, int npairs, int net_index, const void* packed, const NcaLayout& y, int64_t net_off,
-                          int64_t d_off, int64_t slab_off, int64_t onehot_off, int64_t enc_off, int skip_layer = -1) {
+// skip_layer: accumulated on chip by the dgrad kernel
+static void add_jobs_bf16(NcaWgradArgs* w, int net_index, const NcaLayout& y, int64_t net_off, int64_t d_off, int64_t slab_off, int64_t onehot_off, int64_t enc_off,
+                          int skip_layer, bool h8, bool d8, int64_t dscale_off) {
     for (int j = 0; j < y.NL; ++j) {
         if (j == skip_layer) continue;
-        if (j < 2 * npairs) {
-            NcaWgradPair& pr = pairs->pair[pairs->npairs + j / 2];
-            make_job_bf16((j & 1) ? pr.hi : pr.lo, y, j, net_off, d_off, slab_off, onehot_off, enc_off);
-            const char* pk = static_cast<const char*>(packed);
-            if (j & 1) pr.imgT_hi = pk + y.layer[j].imgT_off;
-            else { pr.img_lo = pk + y.layer[j].img_off; pr.ks_lo = y.layer[j].ksteps; pr.net = net_index; pr.mask_layer = j; }
-        } else {
-            make_job_bf16(w->job[w->njobs++], y, j, net_off, d_off, slab_off, onehot_off, enc_off);
-        }
+        NcaWgradJob& g = w->job[w->njobs++];
+        make_job_bf16(g, y, j, net_off, d_off, slab_off, onehot_off, enc_off, h8, d8);
+        g.net = net_index;
+        g.dscale_off = dscale_off;
     }
-    pairs->npairs += npairs;
 }
 
 static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t units, int64_t tiles_per_unit, float* const* grads,
@@ -628,9 +616,14 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     // a store left by the forward of the SAME batch: no recompute, the chunk scratch holds the D blocks only
     StorePlan spl;
     const bool stored = store != nullptr;
+    // fp8 staging: the store's hidden blocks (as the storing forward left them) and this backward's output gradients -- except
+    // when the depth gradient is wanted, whose kernel reads D_0 as bf16 fragments
+    const bool h8 = bf && stored && opt_value(NCA_OPT_STAGE_FP8) != 0;
+    const bool d8 = h8 && !g_depth;
+    a.h8 = h8 ? 1 : 0;
     if (stored) {
         a.share_enc = can_share_enc(a, prec) ? 1 : 0;        // the same decision the storing forward took (same nets, same vectors)
-        if (!store_plan(lays, a.nnets, prec, units * tiles_per_unit, &spl, a.share_enc != 0)) return fail(NCA_E_UNSUPPORTED, "no forward store exists for this configuration");
+        if (!store_plan(lays, a.nnets, prec, units * tiles_per_unit, &spl, a.share_enc != 0, h8)) return fail(NCA_E_UNSUPPORTED, "no forward store exists for this configuration");
         if (store_bytes < spl.bytes) return fail(NCA_E_WORKSPACE, "forward store %lld < %lld bytes", (long long)store_bytes, (long long)spl.bytes);
     }
     // bf16 backward from a store: the weight gradient of the last hidden layer stays on chip (one launch per net)
@@ -638,7 +631,7 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     const bool onchip = oc_min >= 0 && bf && stored && units * tiles_per_unit >= oc_min;
     const bool per_net_launch = onchip;
     BwdPlan p;
-    int rc = plan_bwd(lays, a.nnets, prec, units, tiles_per_unit, work_bytes, &p, stored, onchip);
+    int rc = plan_bwd(lays, a.nnets, prec, units, tiles_per_unit, work_bytes, &p, stored, onchip, d8);
     if (rc) return rc;
     if (!work || work_bytes < p.bytes_total) return fail(NCA_E_WORKSPACE, "backward workspace %lld < %lld bytes", (long long)work_bytes, (long long)p.bytes_total);
     char* wb = static_cast<char*>(work);
@@ -658,7 +651,7 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
             const char* pk = static_cast<const char*>(binds[n].packed);
             if (bf) {
                 const int64_t EB = 32 * (int64_t)NCA_BF_ENCROWS * 2, HB = 32 * (int64_t)y.F * 2;
-                if (stored) { a.net[n].row0 = spl.row0[n]; a.net[n].drow0 = doff; doff += (int64_t)y.NL * HB; }
+                if (stored) { a.net[n].row0 = spl.row0[n]; a.net[n].drow0 = doff; doff += nca_bf_dbytes(y, d8); }
                 else a.net[n].drow0 = a.net[n].row0 + EB + (int64_t)(y.NL - 1) * HB;
                 a.net[n].wo_src = reinterpret_cast<const float*>(pk + ll.img_off + (int64_t)y.MT * ll.ksteps * 1024) + 2 * y.MT * 16;
             } else {
@@ -679,28 +672,12 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     for (int n = 0; n < a.nnets; ++n) { onehot_off[n] = soff; soff += (int64_t)lays[n].F * lays[n].P; }
 
     static thread_local NcaWgradArgs w;
-    static thread_local NcaWgradPairArgs wp;
     memset(&w, 0, sizeof(w));
-    memset(&wp, 0, sizeof(wp));
     for (int n = 0; n < a.nnets; ++n) {
-        const int np = stored ? nca_pairs(lays[n], prec) : 0;
-        if (stored) set_skip_bits(&a.net[n], prec); else { a.net[n].skip_h = 0; a.net[n].skip_d = 0; }
-        if (g_depth) a.net[n].skip_d &= ~1;      // the depth gradient reads D_0: have it written (the pair kernel recomputes its own copy)
-        if (wp.npairs + np > NCA_MAX_PAIRS) return fail(NCA_E_UNSUPPORTED, "too many paired wgrad jobs");
-        if (bf) add_jobs_bf16(&w, &wp, np, n, binds[n].packed, lays[n], a.net[n].row0, a.net[n].drow0, slab_off[n], onehot_off[n],
-                              stored && a.share_enc && n == 0 ? a.net[1].row0 : a.net[n].row0, onchip ? lays[n].NL - 1 : -1);
+        if (bf) add_jobs_bf16(&w, n, lays[n], a.net[n].row0, a.net[n].drow0, slab_off[n], onehot_off[n],
+                              stored && a.share_enc && n == 0 ? a.net[1].row0 : a.net[n].row0, onchip ? lays[n].NL - 1 : -1, h8, d8,
+                              p.tile_stride - NCA_D8_REC_BYTES);
         else add_jobs_f32(&w, lays[n], a.net[n].row0, a.net[n].drow0, slab_off[n], onehot_off[n]);
-    }
-    if (wp.npairs) {
-        wp.dscratch = reinterpret_cast<const char*>(scratch);
-        wp.d_total = p.tile_stride;
-        wp.hstore = static_cast<const char*>(store);
-        wp.h_total = spl.h_stride;
-        wp.mstore = static_cast<const char*>(store) + spl.off_m;
-        wp.mstore_layers = spl.mask_layers;
-        wp.slab = slab;
-        wp.slab_stride = p.slab_stride;
-        wp.nsplit = p.n_split;
     }
     w.scratch = scratch;
     w.slab = slab;
@@ -711,6 +688,7 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     a.scratch = stored ? const_cast<float*>(static_cast<const float*>(store)) : scratch;
     a.dscratch = reinterpret_cast<char*>(scratch);
     a.d_total = p.tile_stride;
+    a.dscale_off = p.tile_stride - NCA_D8_REC_BYTES;
     if (stored) {
         a.mstore = const_cast<char*>(static_cast<const char*>(store)) + spl.off_m;
         a.rstore = reinterpret_cast<float*>(const_cast<char*>(static_cast<const char*>(store)) + spl.off_r);
@@ -750,11 +728,11 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
                 rc = build_stages(&one, b1, true, 2);
                 if (rc) return rc;
                 Span sp(NCA_K_BWD_DGRAD, st);
-                HIPCHK(nca_launch_fused_bf16(F, one, onchip ? NCA_KM_BWD_ONCHIP : NCA_KM_BWD_STORED, p.grid, st));
+                HIPCHK(nca_launch_fused_bf16(F, one, onchip ? NCA_KM_BWD_ONCHIP : NCA_KM_BWD_STORED, p.grid, st, d8));
             }
         } else {
             Span sp(NCA_K_BWD_DGRAD, st);
-            if (bf) HIPCHK(nca_launch_fused_bf16(F, a, stored ? NCA_KM_BWD_STORED : NCA_KM_BWD, p.grid, st));
+            if (bf) HIPCHK(nca_launch_fused_bf16(F, a, stored ? NCA_KM_BWD_STORED : NCA_KM_BWD, p.grid, st, d8));
             else HIPCHK(nca_launch_fused_f32(F, a, stored ? NCA_KM_BWD_STORED : NCA_KM_BWD, p.grid, st));
         }
         if (g_depth) {       // d loss / d depth from the D_0 blocks this chunk's dgrad launch just wrote
@@ -776,7 +754,7 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
                     if (lays[n].layer[j].kind == NCA_IN_HID || zn.nsrc >= 2) continue;
                     zn.w[zn.nsrc] = binds[n].params + lays[n].layer[j].w_off;
                     zn.ldw[zn.nsrc] = lays[n].layer[j].K;
-                    zn.drow[zn.nsrc] = a.net[n].drow0 + (bf ? (int64_t)j * 32 * lays[n].F * 2 : (int64_t)j * lays[n].F);   // bf16: bytes
+                    zn.drow[zn.nsrc] = a.net[n].drow0 + (bf ? nca_bf_doff(lays[n], j, false) : (int64_t)j * lays[n].F);   // bf16: bytes (never e5m2 here: d8 is off)
                     ++zn.nsrc;
                 }
             }
@@ -789,12 +767,6 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
         {
             Span sp(NCA_K_BWD_WGRAD, st);
             if (bf) {
-                if (wp.npairs) {
-                    wp.ntiles = w.ntiles;
-                    wp.tile0_b = w.tile0_b;
-                    wp.accumulate = w.accumulate;
-                    HIPCHK(nca_launch_wgrad_pair_bf16(F, wp, st));
-                }
                 if (w.njobs) HIPCHK(nca_launch_wgrad_bf16(F, w, p.n_split, st));
             } else HIPCHK(nca_launch_wgrad_f32(w, p.n_split, st));
         }

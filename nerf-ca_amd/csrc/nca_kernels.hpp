@@ -22,9 +22,6 @@ struct NcaNetArgs {
     int64_t row0;        // first scratch row of this net (backward only); bf16: BYTE offset of its input/H blocks in a tile
     int64_t drow0;       // bf16: byte offset of its output-gradient (D) blocks in a tile of the D region
     const float* wo_src; // bf16 stored-forward backward: the [Wo | bo] tail of the packed last-layer image (global)
-    int32_t skip_h;      // bf16 store, paired weight-gradient jobs (NcaWgradPair): bit j = the storing forward does NOT write hidden
-                         // block j (the input of layer j+1) -- the pair kernel recomputes it from the input of layer j
-    int32_t skip_d;      // ... bit l = the backward from the store does NOT write D_l -- the pair kernel recomputes it from D_{l+1}
 };
 
 // kernel modes of nca_fused_bf16
@@ -82,6 +79,9 @@ struct NcaFusedArgs {
     char* mstore;        // stored forward: ReLU masks [wave tile][net][layer][1 KiB]
     float* rstore;       // stored forward: raw outputs [wave tile][net][64]
     int32_t mstore_layers; // layers per net in mstore
+    int32_t h8;          // the forward store holds the hidden blocks 0..NL-3 as e4m3 (nca_bf_hoff): what the storing forward
+                         // writes (S8 instantiation) and where the backward finds the last layer's input
+    int64_t dscale_off;  // S8 backward: byte offset of the inverse-scale record inside a tile of the D region
     float* oslab;        // [grid][2][F+1] output-layer gradient partials
     int32_t accumulate;  // add to oslab instead of overwriting (ray chunks after the first)
     int32_t nstages;
@@ -107,6 +107,10 @@ struct NcaWgradJob {
     int32_t b_row_bytes;  // bf16 path: bytes of one sample row of the H block (d_row0/b_row0 are BYTE offsets in a tile there)
     int32_t is_enc, T;
     int32_t fourier_L;    // bf16 input block of a fourier net: slots are (sin_i, cos_i) interleaved; 0 otherwise
+    int32_t d8, h8;       // bf16 path: the D block is e5m2 scaled by the wave tile's power of two / the H block is e4m3 x 2^NCA_H8_LOG2
+    int32_t net;          // ... which of the tile's two inverse scales applies
+    int32_t pad;
+    int64_t dscale_off;   // ... byte offset of the inverse-scale record inside a tile of the D region
 };
 
 struct NcaWgradArgs {
@@ -119,33 +123,6 @@ struct NcaWgradArgs {
     int64_t slab_stride;
     int32_t accumulate, njobs;
     NcaWgradJob job[NCA_MAX_JOBS];
-};
-
-// bf16 backward from a store: the weight-gradient jobs of layers (2p, 2p+1) run as a PAIR of waves that share one read of
-// the input of layer 2p and of D_{2p+1} (exchanged through LDS): the wave of layer 2p recomputes D_{2p} = W_{2p+1}^T D_{2p+1} (.) mask
-// from the stored ReLU bits, the wave of layer 2p+1 recomputes its input relu(W_{2p} x + b_{2p}).  Neither block is written by the
-// fused kernels, neither is read here: half of the staged bytes of those layers never exist.
-#define NCA_MAX_PAIRS 8
-struct NcaWgradPair {
-    NcaWgradJob lo, hi;       // layer 2p (its D is recomputed) and layer 2p+1 (its input is recomputed)
-    const char* img_lo;       // packed forward image of layer 2p: [row tile][k-step][lane][16 B] + f32 bias tail
-    const char* imgT_hi;      // packed transposed image of layer 2p+1
-    int32_t ks_lo;            // k-steps of img_lo (6 on the encoded layer, F/16 on hidden layers)
-    int32_t net;              // net index inside the mask store
-    int32_t mask_layer;       // = 2p: ReLU bits of layer 2p's output
-    int32_t pad;
-};
-struct NcaWgradPairArgs {
-    const char* dscratch;     // D region of this launch [32-sample tile][d_total bytes]
-    int64_t d_total, ntiles;  // ... its bytes per tile; 32-sample tiles in this launch
-    const char* hstore;       // forward store: input / hidden blocks [32-sample tile][h_total bytes]
-    int64_t h_total, tile0_b; // ... bytes per tile; index of this launch's first 32-sample tile in the store
-    const char* mstore;       // ReLU masks [64-sample tile][net][layer][1 KiB]
-    int32_t mstore_layers, accumulate;
-    float* slab;
-    int64_t slab_stride;
-    int32_t nsplit, npairs;
-    NcaWgradPair pair[NCA_MAX_PAIRS];
 };
 
 struct NcaReduceNet {
@@ -260,7 +237,6 @@ hipError_t nca_launch_fused_f32(int F, const NcaFusedArgs& a, int kmode, int gri
 hipError_t nca_launch_wgrad_f32(const NcaWgradArgs& a, int nsplit, hipStream_t st);
 hipError_t nca_launch_reduce_f32(const NcaReduceArgs& a, hipStream_t st);
 hipError_t nca_launch_pack_bf16(const NcaLayout& y, const float* prm, void* out, hipStream_t st);
-hipError_t nca_launch_fused_bf16(int F, const NcaFusedArgs& a, int kmode, int grid, hipStream_t st);
+hipError_t nca_launch_fused_bf16(int F, const NcaFusedArgs& a, int kmode, int grid, hipStream_t st, bool s8 = false);
 hipError_t nca_launch_wgrad_bf16(int F, const NcaWgradArgs& a, int nsplit, hipStream_t st);
-hipError_t nca_launch_wgrad_pair_bf16(int F, const NcaWgradPairArgs& a, hipStream_t st);
 hipError_t nca_launch_pix_f32(int64_t R, int nchunk, const float* I0, const double* part, double* pix, hipStream_t st);

@@ -22,6 +22,24 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+// fp8 staging (nca_layout.hpp): four f32 -> one dword of e4m3 / e5m2 bytes, value / 2^floor(log2 div) (v_cvt_scalef32_pk_*: the
+// scaling is part of the conversion; round to nearest even; with MODE.FP16_OVFL set -- s8_mode() -- out-of-range values
+// saturate to +-448 / +-57344 instead of becoming NaN / inf: measured, tools/fp8_cvt_probe.hip)
+__device__ __forceinline__ unsigned cvt4_e4m3(float a, float b, float c, float d, float div) {
+    s16x2 v = {0, 0};
+    v = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(v, a, b, div, false);
+    v = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(v, c, d, div, true);
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ unsigned cvt4_e5m2(float a, float b, float c, float d, float div) {
+    s16x2 v = {0, 0};
+    v = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(v, a, b, div, false);
+    v = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(v, c, d, div, true);
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ void s8_mode() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1"); }
 
 __device__ __forceinline__ unsigned pack2(float lo, float hi) {
     bf16x2 v = {(__bf16)lo, (__bf16)hi};
@@ -250,10 +268,57 @@ __device__ __forceinline__ void transpose_block(const u32x4 (&X)[2 * NT], int lc
     }
 }
 
+// The same for an 8-bit block ([row tile][lane][16 B], byte i = accumulator register i: the low / high 8 bytes are the two
+// k-steps of the tile): the transposing products run on the fp8 matrix path against an 8-bit identity (x 1 is exact in any
+// format) and come out as f32, which (MUL) is multiplied by `mul` -- the wave tile's inverse scale for e5m2 output
+// gradients -- before the column sums and the bf16 packing.  E5M2: e5m2 bytes (else e4m3).
+template <bool E5M2>
+__device__ __forceinline__ long ident8(int kbase, int lc) {
+    const int j = lc - kbase;                       // byte j is 1.0 when kbase + j == lc
+    const unsigned long one = E5M2 ? 0x3cul : 0x38ul;
+    return (j >= 0 && j < 8) ? (long)(one << (8 * j)) : 0l;
+}
+template <int NT, int NX, bool E5M2, bool MUL>
+__device__ __forceinline__ void transpose_block8(const u32x4 (&X)[NX], int lc, int lh, float mul, u32x4 (&T)[NT][2], float (*colsum)[NT]) {
+    static_assert(NX >= NT, "one 16-byte fragment per 32-feature tile");
+    const long E0 = ident8<E5M2>(8 * lh, lc), E1 = ident8<E5M2>(16 + 8 * lh, lc);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        f32x16 z;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) z[i] = 0.f;
+        const long lo = (long)(((unsigned long)X[t][1] << 32) | X[t][0]), hi = (long)(((unsigned long)X[t][3] << 32) | X[t][2]);
+        if (E5M2) {
+            z = __builtin_amdgcn_mfma_f32_32x32x16_bf8_bf8(lo, E0, z, 0, 0, 0);
+            z = __builtin_amdgcn_mfma_f32_32x32x16_bf8_bf8(hi, E1, z, 0, 0, 0);
+        } else {
+            z = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(lo, E0, z, 0, 0, 0);
+            z = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(hi, E1, z, 0, 0, 0);
+        }
+        if (MUL) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) z[i] *= mul;
+        }
+        if (colsum) {
+            float cs = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) cs += z[i];
+            (*colsum)[t] += cs;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            T[t][0][u] = pack2(z[2 * u], z[2 * u + 1]);
+            T[t][1][u] = pack2(z[8 + 2 * u], z[8 + 2 * u + 1]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // fused forward / backward-dgrad kernel
 // ------------------------------------------------------------------------------------------
-template <int F, int MODE>
+// S8 (modes 2, 3, 4): fp8 staging -- the storing forward writes the hidden blocks 0..NL-3 as e4m3, the backward from the store
+// writes D_0..D_{NL-2} as e5m2 scaled by a power of two per 64-sample tile (nca_layout.hpp)
+template <int F, int MODE, bool S8>
 __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a) {
     constexpr bool ONCHIP = MODE == NCA_KM_BWD_ONCHIP;                        // mode 3 + on-chip dW of the last hidden layer
     constexpr int RINGK = ONCHIP ? 2 : NCA_BF_RING;                           // A-fragment ring of the layer contractions
@@ -273,6 +338,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
     char* const maskbase = smem + 2 * BUF + NCA_CONST_BYTES + NCA_WAVES * 2 * (F + 1) * 4;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+    if (S8) s8_mode();
 
     for (int net = 0; net < a.nnets; ++net) {
         const NcaNetArgs& na = a.net[net];
@@ -445,6 +511,9 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                 }
             }
 
+            // S8: inverse of the power of two by which this tile's output gradients are scaled on their way to e5m2 (the chain
+            // itself stays unscaled bf16: the scaling is part of the conversion)
+            float inv_s = 1.f;
             // ---------- gradient wrt the raw output, output-layer parameter gradients, D_{NL-1}: expects the last layer's
             // packed output in B and its raw output in raw[net]; leaves D_{NL-1} in B.  `wo` = [Wo | bo] in LDS
             auto last_layer_grads = [&](const float* wo) __attribute__((always_inline)) {
@@ -460,10 +529,21 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                         g = a.g_raw[n];
                     }
                     if (!valid) g = 0.f;
+                    if (S8 && STORED) {
+                        // the dgrad chain is linear in g, so the largest |g| of the tile sizes every D_l of the tile: 2^e <= max < 2^(e+1)
+                        // is scaled to 2^NCA_D8_LOG2 (exponent arithmetic; an all-zero tile gets the smallest inverse scale)
+                        float am = fabsf(g);
+                        am = fmaxf(am, __shfl_xor(am, 32)); am = fmaxf(am, __shfl_xor(am, 16)); am = fmaxf(am, __shfl_xor(am, 8));
+                        am = fmaxf(am, __shfl_xor(am, 4)); am = fmaxf(am, __shfl_xor(am, 2)); am = fmaxf(am, __shfl_xor(am, 1));
+                        int eb = (int)(__float_as_uint(am) >> 23) - NCA_D8_LOG2;
+                        eb = eb < 1 ? 1 : (eb > 254 ? 254 : eb);
+                        inv_s = __uint_as_float((unsigned)eb << 23);
+                        if (lane == 0 && tvalid) reinterpret_cast<float*>(d32 + a.dscale_off)[net + a.net_base] = inv_s;
+                    }
                     // g of tile c for BOTH lane halves: [g.lower|g.lower] and [g.upper|g.upper]
                     const float gc[2] = {__shfl(g, lr), __shfl(g, lr + 32)};
                     float* orow = osum + (wave * 2 + net) * (F + 1);
-                    char* const dblk = db + (y.NL - 1) * HB;
+                    char* const dblk = db + nca_bf_doff(y, y.NL - 1, S8 && STORED);
                     u32x4 Bn[2][2 * MT];
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
@@ -513,7 +593,12 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                                 Bn[c][2 * m][u] = pack2(dv[2 * u], dv[2 * u + 1]);
                                 Bn[c][2 * m + 1][u] = pack2(dv[8 + 2 * u], dv[8 + 2 * u + 1]);
                             }
-                            if (tvalid && !ONCHIP) {
+                            if (S8 && STORED && tvalid && !ONCHIP) {
+                                u32x4 q8;
+#pragma unroll
+                                for (int w = 0; w < 4; ++w) q8[w] = cvt4_e5m2(dv[4 * w], dv[4 * w + 1], dv[4 * w + 2], dv[4 * w + 3], inv_s);
+                                store_nt(dblk + c * a.d_total + lane * 16 + m * 1024, q8);
+                            } else if (tvalid && !ONCHIP) {
                                 char* fp2 = dblk + c * a.d_total + lane * 16;
                                 store_nt(fp2 + (2 * m) * 1024, Bn[c][2 * m]);
                                 store_nt(fp2 + (2 * m + 1) * 1024, Bn[c][2 * m + 1]);
@@ -534,7 +619,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
             if (STORED) {
                 // the backward from the store recomputes ONE layer, the last: its input is in the store anyway (the wgrad
                 // reads it too), which saves the forward from writing that layer's output and the raw outputs
-                const char* hl = nb + EB + (y.NL - 2) * HB + lane * 16;
+                const char* hl = nb + EB + nca_bf_hoff(y, y.NL - 2, a.h8 != 0) + lane * 16;
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -549,9 +634,9 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                 const int nks = l.ksteps;
                 const float* tail = reinterpret_cast<const float*>(img + MT * nks * 1024);
                 const bool last = jj == y.NL - 1;
-                const bool keep_h = last || !((na.skip_h >> jj) & 1);            // a paired wgrad job recomputes a skipped block
-                const bool store_h = STORE && tvalid && !last && keep_h;
-                char* const hblk = STORE ? nb + EB + jj * HB : nullptr;          // input block of layer jj+1
+                const bool store_h = STORE && tvalid && !last;
+                const bool h8 = S8 && FSTORE && jj < y.NL - 2;                    // this layer's output crosses HBM as e4m3
+                char* const hblk = STORE ? nb + EB + nca_bf_hoff(y, jj, S8 && FSTORE) : nullptr;          // input block of layer jj+1
                 u32x4 Bn[2][2 * MT];
                 unsigned mw[2][2] = {{0u, 0u}, {0u, 0u}};     // mask words: [column tile][row-tile pair]
                 const char* imgl = img + lane * 16;
@@ -599,7 +684,18 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                             mw[c][m >> 1] |= fld << (8 * (m & 1));
                         }
                     }
-                    if (store_h) {
+                    if (S8 && FSTORE && store_h && h8) {
+                        // e4m3 from the f32 accumulators (x 2^NCA_H8_LOG2): byte i = register i, [row tile][lane][16 B]
+                        constexpr float DIV = 1.f / (float)(1 << NCA_H8_LOG2);
+                        u32x4 q0, q1;
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            q0[w] = cvt4_e4m3(acc0[4 * w], acc0[4 * w + 1], acc0[4 * w + 2], acc0[4 * w + 3], DIV);
+                            q1[w] = cvt4_e4m3(acc1[4 * w], acc1[4 * w + 1], acc1[4 * w + 2], acc1[4 * w + 3], DIV);
+                        }
+                        store_nt(hblk + lane * 16 + m * 1024, q0);
+                        store_nt(hblk + a.rows_total + lane * 16 + m * 1024, q1);
+                    } else if (store_h) {
                         // the next layer's B-operand fragments exactly as they sit in registers: 1 KiB per
                         // wave instruction, [k-step][lane][16 B] (feature order inside a tile is the
                         // accumulator->operand order; the wgrad un-permutes when it writes dW)
@@ -642,7 +738,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                     // dW_L += D_L * H_{L-1}^T over this workgroup's 8 x 64 samples.  B holds D_L; the layer's input fragments
                     // (consumed by the recompute above) are read once more.  Both are transposed into rows = samples by
                     // identity MFMAs (as the wgrad kernel does) and handed round 16 samples per wave at a time.
-                    const char* hl = nb + EB + (y.NL - 2) * HB + lane * 16;
+                    const char* hl = nb + EB + nca_bf_hoff(y, y.NL - 2, a.h8 != 0) + lane * 16;
                     const int b0 = wave * BPW;                       // my blocks b0 .. b0 + BPW - 1 of the MT x MT grid
                     const int mo = b0 / MT, i0 = b0 % MT;
                     const bool own = b0 < MT * MT;
@@ -734,7 +830,8 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                 // at least 4 MT stores follow the weight DMA of every storing stage: H (plus a mask store in the storing
                 // forward, which it then also waits for), or D_{NL-1} on the last layer of both backward modes; the last
                 // layer of the storing forward stores nothing
-                if ((STORE && !last) || (BWD && last && !ONCHIP)) stage_publish_counted<4 * MT>(tvalid && keep_h);
+                if ((S8 && FSTORE && h8) || (S8 && STORED && last && !ONCHIP)) stage_publish_counted<2 * MT>(tvalid);   // 2 MT 8-bit stores (+ the mask store)
+                else if ((STORE && !last) || (BWD && last && !ONCHIP)) stage_publish_counted<4 * MT>(tvalid);
                 else stage_publish_b();
                 cur ^= 1;
                 si = nsi;
@@ -751,8 +848,8 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                     stage_issue_b(a.stage[nsi], smem + (cur ^ 1) * BUF, wave, lane);
                     const char* img = smem + cur * BUF;
                     const char* const hblk = nb + EB + (jj - 1) * HB;                       // input of layer jj (mask)
-                    char* const dblk = db + (jj - 1) * HB;                                  // D_{jj-1}
-                    const bool wr_d = tvalid && !((na.skip_d >> (jj - 1)) & 1);              // a paired wgrad job recomputes a skipped D
+                    char* const dblk = db + nca_bf_doff(y, jj - 1, S8 && STORED);            // D_{jj-1}
+                    const bool wr_d = tvalid;
                     u32x4 Bn[2][2 * MT];
                     u32x4 mv = {0u, 0u, 0u, 0u};
                     if (lds_mask) mv = *reinterpret_cast<const u32x4*>(mwave + (jj - 1) * 1024);
@@ -774,6 +871,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                         for (int c = 0; c < 2; ++c) {
                             const char* hp = hblk + c * a.rows_total + lane * 16;
                             char* dp = dblk + c * a.d_total + lane * 16;
+                            u32x4 q8 = {0u, 0u, 0u, 0u};           // S8: the 16 masked values of this (row tile, column tile) as e5m2 bytes
 #pragma unroll
                             for (int s2 = 0; s2 < 2; ++s2) {
                                 // word u of fragment 2m+s2 holds accumulator registers 8 s2 + 2u, +1
@@ -781,24 +879,31 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                                 if (!bits) hw = *reinterpret_cast<const u32x4*>(hp + (2 * m + s2) * 1024);
                                 const unsigned fld = mv[2 * c + (m >> 1)] >> (8 * (m & 1));
                                 u32x4 dw;
+                                float mk[8];
 #pragma unroll
                                 for (int u = 0; u < 4; ++u) {
                                     const float a0 = c == 0 ? acc0[8 * s2 + 2 * u] : acc1[8 * s2 + 2 * u];
                                     const float a1 = c == 0 ? acc0[8 * s2 + 2 * u + 1] : acc1[8 * s2 + 2 * u + 1];
                                     const bool p0 = bits ? ((fld >> (4 * s2 + u)) & 1u) != 0u : (short)(hw[u] & 0xffffu) > 0;
                                     const bool p1 = bits ? ((fld >> (16 + 4 * s2 + u)) & 1u) != 0u : (short)(hw[u] >> 16) > 0;
-                                    dw[u] = pack2(p0 ? a0 : 0.f, p1 ? a1 : 0.f);
+                                    mk[2 * u] = p0 ? a0 : 0.f;
+                                    mk[2 * u + 1] = p1 ? a1 : 0.f;
+                                    dw[u] = pack2(mk[2 * u], mk[2 * u + 1]);
                                 }
                                 Bn[c][2 * m + s2] = dw;
-                                if (wr_d) store_nt(dp + (2 * m + s2) * 1024, dw);
+                                if (S8 && STORED) {
+                                    q8[2 * s2] = cvt4_e5m2(mk[0], mk[1], mk[2], mk[3], inv_s);
+                                    q8[2 * s2 + 1] = cvt4_e5m2(mk[4], mk[5], mk[6], mk[7], inv_s);
+                                } else if (wr_d) store_nt(dp + (2 * m + s2) * 1024, dw);
                             }
+                            if (S8 && STORED && wr_d) store_nt(dp + m * 1024, q8);
                         }
                     }
 #pragma unroll
                     for (int c = 0; c < 2; ++c)
 #pragma unroll
                         for (int k = 0; k < 2 * MT; ++k) B[c][k] = Bn[c][k];
-                    stage_publish_counted<4 * MT>(wr_d);               // D stores
+                    stage_publish_counted<(S8 && STORED) ? 2 * MT : 4 * MT>(wr_d);               // D stores
                     cur ^= 1;
                     si = nsi;
                 }
@@ -909,10 +1014,17 @@ __device__ __forceinline__ void wgrad_write(const f32x16 (&acc)[F / 32][NTB], co
     }
 }
 
-template <int F, int NTB>   // NTB = 32-column tiles of the H block (F/32 for hidden inputs, 4 for the 112-wide input block)
+// NTB = 32-column tiles of the H block (F/32 for hidden inputs, 4 for the 112-wide input block).  D8: every D block of the launch
+// is e5m2 scaled per wave tile (fp8 staging, nca_layout.hpp); H8: the job's H block is e4m3 x 2^NCA_H8_LOG2 (the input block and
+// the last layer's input stay bf16).
+template <int F, int NTB, bool D8, bool H8>
 __device__ __forceinline__ void wgrad_job(const NcaWgradArgs& a, const NcaWgradJob& job, int q, int nsplit, int lane) {
     constexpr int MT = F / 32;
+    constexpr int ND_ = D8 ? MT : 2 * MT;                                  // 16-byte fragments per lane of the D block
+    constexpr float HINV = 1.f / (float)(1 << NCA_H8_LOG2);
     const int lc = lane & 31, lh = lane >> 5;
+    constexpr bool h8 = H8;
+    constexpr int NH_ = H8 ? NTB : 2 * NTB;
     const int64_t per = (a.ntiles + nsplit - 1) / nsplit;
     const int64_t t0 = (int64_t)q * per, t1 = (t0 + per < a.ntiles) ? t0 + per : a.ntiles;
     const char* base = reinterpret_cast<const char*>(a.scratch);          // D region of this launch
@@ -929,25 +1041,30 @@ __device__ __forceinline__ void wgrad_job(const NcaWgradArgs& a, const NcaWgradJ
 #pragma unroll
     for (int m = 0; m < MT; ++m) bsum[m] = 0.f;
 
-    // blocks are fragment-major [k-step][lane][16 B]: one coalesced 1 KiB load per fragment.  The next
-    // tile's fragments are requested before this tile's MFMAs so that ~32 KiB per wave stay in flight
-    // (this kernel is HBM-bound: 16 KiB of operands per 48 MFMAs).
-    u32x4 XD[2 * MT], XH[2 * NTB];
-    auto load_tile = [&](int64_t t, u32x4 (&xd)[2 * MT], u32x4 (&xh)[2 * NTB]) {
+    // blocks are fragment-major [k-step][lane][16 B] (8-bit blocks: [row tile][lane][16 B]): one coalesced 1 KiB load per
+    // fragment.  The next tile's fragments are requested before this tile's MFMAs so that 16-32 KiB per wave stay in flight.
+    u32x4 XD[ND_], XH[NH_];
+    float sc = 1.f;
+    auto load_tile = [&](int64_t t, u32x4 (&xd)[ND_], u32x4 (&xh)[NH_], float& scl) {
         const char* dp = base + t * a.rows_total + job.d_row0 + lane * 16;            // rows_total = bytes per 32-sample tile
         const char* bp = base_b + (t + a.tile0_b) * a.rows_total_b + job.b_row0 + lane * 16;
 #pragma unroll
-        for (int s = 0; s < 2 * MT; ++s) xd[s] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(dp + s * 1024));
+        for (int s = 0; s < ND_; ++s) xd[s] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(dp + s * 1024));
 #pragma unroll
-        for (int s = 0; s < 2 * NTB; ++s) xh[s] = (s * 32 + 32 <= brow) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(bp + s * 1024)) : (u32x4){0, 0, 0, 0};
+        for (int s = 0; s < NH_; ++s) xh[s] = (H8 || s * 32 + 32 <= brow) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(bp + s * 1024)) : (u32x4){0, 0, 0, 0};
+        // the wave tile's inverse scale sits in the first of its two 32-sample records
+        if (D8) scl = reinterpret_cast<const float*>(base + (t & ~(int64_t)1) * a.rows_total + job.dscale_off)[job.net];
     };
-    if (t0 < t1) load_tile(t0, XD, XH);
+    if (t0 < t1) load_tile(t0, XD, XH, sc);
     for (int64_t t = t0; t < t1; ++t) {
-        u32x4 ND[2 * MT], NH[2 * NTB];
-        if (t + 1 < t1) load_tile(t + 1, ND, NH);
+        u32x4 ND[ND_], NH[NH_];
+        float nsc = 1.f;
+        if (t + 1 < t1) load_tile(t + 1, ND, NH, nsc);
         u32x4 TD[MT][2], TH[NTB][2];
-        transpose_block<MT>(XD, lc, lh, TD, &bsum);
-        transpose_block<NTB>(XH, lc, lh, TH, nullptr);
+        if constexpr (D8) transpose_block8<MT, ND_, true, true>(XD, lc, lh, h8 ? sc * HINV : sc, TD, &bsum);      // (an e4m3 partner's scale rides along)
+        else transpose_block<MT>(XD, lc, lh, TD, &bsum);
+        if constexpr (H8) transpose_block8<NTB, NH_, false, !D8>(XH, lc, lh, HINV, TH, nullptr);
+        else transpose_block<NTB>(XH, lc, lh, TH, nullptr);
         // dW[o][i] += sum_n D^T-form[o][n] * H-form[n][i]: both operands are accumulator-layout tiles
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -958,233 +1075,33 @@ __device__ __forceinline__ void wgrad_job(const NcaWgradArgs& a, const NcaWgradJ
                     acc[m][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(TD[m][s]), frag(TH[c][s]), acc[m][c], 0, 0, 0);
         if (t + 1 < t1) {
 #pragma unroll
-            for (int s = 0; s < 2 * MT; ++s) XD[s] = ND[s];
+            for (int s = 0; s < ND_; ++s) XD[s] = ND[s];
 #pragma unroll
-            for (int s = 0; s < 2 * NTB; ++s) XH[s] = NH[s];
+            for (int s = 0; s < NH_; ++s) XH[s] = NH[s];
+            sc = nsc;
         }
+    }
+    if (D8 && h8) {          // the H scale rode on the D tiles: the bias sums (column sums of those tiles) carry it too
+#pragma unroll
+        for (int m = 0; m < MT; ++m) bsum[m] *= (float)(1 << NCA_H8_LOG2);
     }
 
     wgrad_write<F, NTB>(acc, bsum, job, a.slab + (int64_t)q * a.slab_stride, a.accumulate, lane);
 }
 
-template <int F>
+template <int F, bool D8>
 __global__ __launch_bounds__(64, 1) void nca_wgrad_bf16(const NcaWgradArgs a) {
     const NcaWgradJob job = a.job[blockIdx.y];
-    if (job.is_enc) wgrad_job<F, 4>(a, job, blockIdx.x, gridDim.x, threadIdx.x);
-    else wgrad_job<F, F / 32>(a, job, blockIdx.x, gridDim.x, threadIdx.x);
-}
-
-// ------------------------------------------------------------------------------------------
-// paired wgrad (backward from a forward store).  A workgroup = 4 waves (one per SIMD) = 2 splits x the two layers of one
-// pair (2p, 2p+1).  Per 32-sample tile the wave of layer 2p ("lo") loads D_{2p+1}, the wave of layer 2p+1 ("hi") loads the
-// input of layer 2p; both hand their block to the partner through LDS.  lo recomputes D_{2p} = (W_{2p+1}^T D_{2p+1}) (.) ReLU bits,
-// hi recomputes its own input relu(W_{2p} x + b_{2p}) -- the same MFMA sequences on the same operands as the fused kernels
-// ran, so the blocks are bit-identical to what those would have stored -- and each continues as nca_wgrad_bf16 does
-// (identity-MFMA transposes, dW of its whole layer in 256 accumulator registers).  The two weight images live in LDS.
-// ------------------------------------------------------------------------------------------
-template <int F>
-struct PairCfg {
-    static constexpr int MT = F / 32, KS = F / 16, KS0 = NCA_BF_K0SLOTS / 16;
-    static constexpr int NFX = 2 * MT > KS0 + 1 ? 2 * MT : KS0 + 1;                 // fragments of an exchanged block (at most)
-    static constexpr int KSLO = KS > KS0 ? KS : KS0;
-    static constexpr int IMG_LO = (MT * KSLO * 1024 + 2 * MT * 16 * 4 + 1023) & ~1023;   // forward image + bias tail
-    static constexpr int IMG_HI = MT * KS * 1024;                                   // transposed image
-    static constexpr int XB = 2 /*slots*/ * 2 /*buffers*/ * 2 /*roles*/ * NFX * 1024;
-    static constexpr int LDS = IMG_LO + IMG_HI + XB;
-};
-
-// (Tried: these small products as inline-assembly VGPR-form MFMAs -- the compiler selects the AGPR form for every MFMA
-// although the dW accumulators fill the AGPR file, and shuttles a dW tile to VGPRs and back, ~270 v_accvgpr moves per
-// tile.  The assembly form removed them but changed neither the kernel time -- it is bound by the latency of its loads,
-// see DESIGN.md -- nor stayed correct under every schedule (a 1.6 dB training-PSNR drift), so the builtins stay.)
-__device__ __forceinline__ void mfma_v0(f32x16& z, const u32x4& a, const u32x4& b) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) z[i] = 0.f;
-    z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(a), frag(b), z, 0, 0, 0);
-}
-__device__ __forceinline__ void mfma_v(f32x16& z, const u32x4& a, const u32x4& b) { z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(a), frag(b), z, 0, 0, 0); }
-
-// one column tile: acc += A(row tile m of the image) * B, A fragments through the same ring as mma_rowtile_ring
-template <int NKS, int MTOT, int NB, int RING>
-__device__ __forceinline__ void mma_rowtile_ring1(const char* imgl, int m, u32x4 (&A)[RING], const u32x4 (&B)[NB], f32x16& acc) {
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-        const int g = m * NKS + ks, nx = g + RING - 1;
-        if (nx < MTOT * NKS) A[nx % RING] = *reinterpret_cast<const u32x4*>(imgl + nx * 1024);
-        mfma_v(acc, A[g % RING], B[ks]);
-        __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x10 | 0x400);
-    }
-}
-
-template <int F, int ROLE, bool ENC>
-__device__ __forceinline__ void wgrad_pair_role(const NcaWgradPairArgs& a, const NcaWgradPair& pr, const char* img_lo, const char* img_hi,
-                                                char* xslot, int q, int lane) {
-    constexpr int MT = PairCfg<F>::MT, KS = PairCfg<F>::KS, KS0 = PairCfg<F>::KS0, NFX = PairCfg<F>::NFX;
-    constexpr int NOWN = ROLE == 0 ? 2 * MT : (ENC ? KS0 + 1 : 2 * MT);      // fragments of the block this wave loads from HBM
-    constexpr int NPART = ROLE == 0 ? (ENC ? KS0 + 1 : 2 * MT) : 2 * MT;     // ... of the block it gets from its partner
-    constexpr int NTB = ROLE == 0 ? (ENC ? 4 : MT) : MT;                     // 32-column tiles of my job's H operand
-    constexpr int NKS = ROLE == 1 ? (ENC ? KS0 : KS) : KS;                   // k-steps of my recompute
-    constexpr int RING = 6;
-    const NcaWgradJob& job = ROLE == 0 ? pr.lo : pr.hi;
-    const int lc = lane & 31, lh = lane >> 5;
-    const int64_t per = (a.ntiles + a.nsplit - 1) / a.nsplit;
-    const int64_t t0 = (int64_t)q * per;
-    const bool qvalid = q < a.nsplit;
-
-    f32x16 acc[MT][NTB];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int c = 0; c < NTB; ++c)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[m][c][i] = 0.f;
-    float bsum[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) bsum[m] = 0.f;
-
-    u32x4 OWN[NOWN], NXT[NOWN];
-    u32x4 mv = {0u, 0u, 0u, 0u}, mvn = {0u, 0u, 0u, 0u};
-    auto load_own = [&](int64_t t, u32x4 (&x)[NOWN], u32x4& m4) {
-        const bool ok = qvalid && t < a.ntiles;            // wave-uniform
-        if (!ok) {
-#pragma unroll
-            for (int s = 0; s < NOWN; ++s) x[s] = (u32x4){0u, 0u, 0u, 0u};
-            return;
-        }
-        if (ROLE == 0) {
-            const char* dp = a.dscratch + t * a.d_total + pr.hi.d_row0 + lane * 16;
-#pragma unroll
-            for (int s = 0; s < NOWN; ++s) x[s] = load_nt(dp + s * 1024);
-            const int64_t tg = (t + a.tile0_b) >> 1;
-            m4 = load_nt(a.mstore + ((tg * 2 + pr.net) * a.mstore_layers + pr.mask_layer) * 1024 + lane * 16);
-        } else {
-            const char* bp = a.hstore + (t + a.tile0_b) * a.h_total + pr.lo.b_row0 + lane * 16;
-#pragma unroll
-            for (int s = 0; s < NOWN; ++s) x[s] = load_nt(bp + s * 1024);
-        }
-    };
-    const char* const imgl = (ROLE == 1 ? img_lo : img_hi) + lane * 16;
-    const float* const tail = reinterpret_cast<const float*>(img_lo + MT * NKS * 1024);     // bias of layer 2p (hi only)
-    const u32x4 E0 = ident_frag(8 * lh, lc), E1 = ident_frag(16 + 8 * lh, lc);
-    // one 32-feature tile (fragments x0, x1: lane = sample, k = features) -> rows = samples, lane = feature, packed as two
-    // k-steps of 16 samples (what transpose_block does per tile)
-    auto transpose_tile = [&](const u32x4& x0, const u32x4& x1, u32x4 (&T)[2], float* colsum) __attribute__((always_inline)) {
-        f32x16 z;
-        mfma_v0(z, x0, E0);
-        mfma_v(z, x1, E1);
-        if (colsum) {
-            float cs = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) cs += z[i];
-            *colsum += cs;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            T[0][u] = pack2(z[2 * u], z[2 * u + 1]);
-            T[1][u] = pack2(z[8 + 2 * u], z[8 + 2 * u + 1]);
-        }
-    };
-
-    load_own(t0, OWN, mv);
-    for (int64_t it = 0; it < per; ++it) {
-        const int64_t t = t0 + it;
-        char* const xmine = xslot + (((int)(it & 1) * 2 + ROLE) * NFX) * 1024 + lane * 16;
-        const char* const xpart = xslot + (((int)(it & 1) * 2 + (1 - ROLE)) * NFX) * 1024 + lane * 16;
-#pragma unroll
-        for (int s = 0; s < NOWN; ++s) *reinterpret_cast<u32x4*>(xmine + s * 1024) = OWN[s];
-        if (it + 1 < per) load_own(t + 1, NXT, mvn);
-        __builtin_amdgcn_sched_barrier(0);
-
-        // ---- my recompute, one 32-row tile at a time, transposed straight away --------------------------------
-        u32x4 TR[MT][2];          // lo: D_{2p} transposed (A operand of dW); hi: the recomputed input transposed (B operand)
-        {
-            const int c = (int)((t + a.tile0_b) & 1);          // which half of the 64-sample wave tile the masks were written for
-            const unsigned w01 = c ? mv[2] : mv[0], w23 = c ? mv[3] : mv[1];
-            u32x4 A[RING];
-            ring_prime<NKS, MT, RING>(imgl, A);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                f32x16 z;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) z[i] = ROLE == 1 ? tail[(lh * MT + m) * 16 + i] : 0.f;
-                mma_rowtile_ring1<NKS, MT, NOWN, RING>(imgl, m, A, OWN, z);
-                u32x4 xs[2];
-                if (ROLE == 1) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) z[i] = relu1(z[i]);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { xs[0][u] = pack2(z[2 * u], z[2 * u + 1]); xs[1][u] = pack2(z[8 + 2 * u], z[8 + 2 * u + 1]); }
-                } else {
-                    const unsigned fld = ((m >> 1) ? w23 : w01) >> (8 * (m & 1));
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const bool p0 = ((fld >> (4 * s2 + u)) & 1u) != 0u;
-                            const bool p1 = ((fld >> (16 + 4 * s2 + u)) & 1u) != 0u;
-                            xs[s2][u] = pack2(p0 ? z[8 * s2 + 2 * u] : 0.f, p1 ? z[8 * s2 + 2 * u + 1] : 0.f);
-                        }
-                }
-                transpose_tile(xs[0], xs[1], TR[m], ROLE == 0 ? &bsum[m] : nullptr);
-            }
-        }
-        lds_barrier();            // the partner's block of this tile is in LDS (and everyone is done with the buffer of tile it-1)
-        __builtin_amdgcn_sched_barrier(0);
-
-        // ---- the partner's block, one 32-feature tile at a time, into the dW products ----------------------------
-        constexpr int NPT = ROLE == 0 ? NTB : MT;                 // 32-feature tiles of the partner's block
-#pragma unroll
-        for (int tt = 0; tt < NPT; ++tt) {
-            const u32x4 x0 = (2 * tt < NPART) ? *reinterpret_cast<const u32x4*>(xpart + (2 * tt) * 1024) : (u32x4){0u, 0u, 0u, 0u};
-            const u32x4 x1 = (2 * tt + 1 < NPART) ? *reinterpret_cast<const u32x4*>(xpart + (2 * tt + 1) * 1024) : (u32x4){0u, 0u, 0u, 0u};
-            u32x4 TP[2];
-            transpose_tile(x0, x1, TP, ROLE == 1 ? &bsum[tt] : nullptr);
-            // dW[o][i] += sum_n D[o][n] H[i][n]: lo -- the partner's tile is H column tile tt; hi -- it is D row tile tt
-#pragma unroll
-            for (int k = 0; k < (ROLE == 0 ? MT : NTB); ++k)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    if (ROLE == 0) acc[k][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(TR[k][s]), frag(TP[s]), acc[k][tt], 0, 0, 0);
-                    else acc[tt][k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(TP[s]), frag(TR[k][s]), acc[tt][k], 0, 0, 0);
-                }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (it + 1 < per) {
-#pragma unroll
-            for (int s = 0; s < NOWN; ++s) OWN[s] = NXT[s];
-            mv = mvn;
-        }
-    }
-    if (qvalid) wgrad_write<F, NTB>(acc, bsum, job, a.slab + (int64_t)q * a.slab_stride, a.accumulate, lane);
-}
-
-template <int F>
-__global__ __launch_bounds__(256, 1) void nca_wgrad_pair_bf16(const NcaWgradPairArgs a) {
-    constexpr int MT = PairCfg<F>::MT, KS = PairCfg<F>::KS, NFX = PairCfg<F>::NFX;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const NcaWgradPair& pr = a.pair[blockIdx.y];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, role = wave & 1, slot = wave >> 1;
-    char* const img_lo = smem;
-    char* const img_hi = smem + PairCfg<F>::IMG_LO;
-    char* const xslot = img_hi + PairCfg<F>::IMG_HI + slot * (2 * 2 * NFX * 1024);
-    const int lo_bytes = MT * pr.ks_lo * 1024 + 2 * MT * 16 * 4;
-    for (int i = tid * 16; i < lo_bytes; i += 256 * 16) *reinterpret_cast<u32x4*>(img_lo + i) = *reinterpret_cast<const u32x4*>(pr.img_lo + i);
-    for (int i = tid * 16; i < MT * KS * 1024; i += 256 * 16) *reinterpret_cast<u32x4*>(img_hi + i) = *reinterpret_cast<const u32x4*>(pr.imgT_hi + i);
-    __syncthreads();
-    const int q = 2 * blockIdx.x + slot;
-    if (pr.lo.is_enc) {
-        if (role == 0) wgrad_pair_role<F, 0, true>(a, pr, img_lo, img_hi, xslot, q, lane);
-        else wgrad_pair_role<F, 1, true>(a, pr, img_lo, img_hi, xslot, q, lane);
-    } else {
-        if (role == 0) wgrad_pair_role<F, 0, false>(a, pr, img_lo, img_hi, xslot, q, lane);
-        else wgrad_pair_role<F, 1, false>(a, pr, img_lo, img_hi, xslot, q, lane);
-    }
+    // (at F = 128 the 112-slot input block and a hidden block have the same shape: one body serves both)
+    if (job.h8) wgrad_job<F, F / 32, D8, true>(a, job, blockIdx.x, gridDim.x, threadIdx.x);
+    else if (F != 128 && job.is_enc) wgrad_job<F, 4, D8, false>(a, job, blockIdx.x, gridDim.x, threadIdx.x);
+    else wgrad_job<F, F == 128 ? 4 : F / 32, D8, false>(a, job, blockIdx.x, gridDim.x, threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-template <int F, int MODE>
+template <int F, int MODE, bool S8>
 static hipError_t launch_fused_bf_mode(const NcaFusedArgs& a, int grid, hipStream_t st) {
     constexpr bool bwd = MODE == NCA_KM_BWD || MODE == NCA_KM_BWD_STORED || MODE == NCA_KM_BWD_ONCHIP;
     size_t lds = 2 * BfCfg<F>::BUF_BYTES + NCA_CONST_BYTES;
@@ -1194,27 +1111,27 @@ static hipError_t launch_fused_bf_mode(const NcaFusedArgs& a, int grid, hipStrea
         constexpr int MT = BfCfg<F>::MT, BPW = (MT * MT + NCA_WAVES - 1) / NCA_WAVES;
         lds += (size_t)NCA_WAVES * (2 * MT * 1024 > BPW * 16 * 256 ? 2 * MT * 1024 : BPW * 16 * 256);
     }
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_fused_bf16<F, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((nca_fused_bf16<F, MODE>), dim3(grid), dim3(NCA_NT), lds, st, a);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_fused_bf16<F, MODE, S8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((nca_fused_bf16<F, MODE, S8>), dim3(grid), dim3(NCA_NT), lds, st, a);
     return hipGetLastError();
 }
 template <int F>
-static hipError_t launch_fused_bf(const NcaFusedArgs& a, int kmode, int grid, hipStream_t st) {
+static hipError_t launch_fused_bf(const NcaFusedArgs& a, int kmode, int grid, hipStream_t st, bool s8) {
     switch (kmode) {
-        case NCA_KM_FWD: return launch_fused_bf_mode<F, NCA_KM_FWD>(a, grid, st);
-        case NCA_KM_BWD: return launch_fused_bf_mode<F, NCA_KM_BWD>(a, grid, st);
-        case NCA_KM_FWD_STORE: return launch_fused_bf_mode<F, NCA_KM_FWD_STORE>(a, grid, st);
-        case NCA_KM_BWD_STORED: return launch_fused_bf_mode<F, NCA_KM_BWD_STORED>(a, grid, st);
-        case NCA_KM_BWD_ONCHIP: return launch_fused_bf_mode<F, NCA_KM_BWD_ONCHIP>(a, grid, st);
+        case NCA_KM_FWD: return launch_fused_bf_mode<F, NCA_KM_FWD, false>(a, grid, st);
+        case NCA_KM_BWD: return launch_fused_bf_mode<F, NCA_KM_BWD, false>(a, grid, st);
+        case NCA_KM_FWD_STORE: return s8 ? launch_fused_bf_mode<F, NCA_KM_FWD_STORE, true>(a, grid, st) : launch_fused_bf_mode<F, NCA_KM_FWD_STORE, false>(a, grid, st);
+        case NCA_KM_BWD_STORED: return s8 ? launch_fused_bf_mode<F, NCA_KM_BWD_STORED, true>(a, grid, st) : launch_fused_bf_mode<F, NCA_KM_BWD_STORED, false>(a, grid, st);
+        case NCA_KM_BWD_ONCHIP: return s8 ? launch_fused_bf_mode<F, NCA_KM_BWD_ONCHIP, true>(a, grid, st) : launch_fused_bf_mode<F, NCA_KM_BWD_ONCHIP, false>(a, grid, st);
     }
     return hipErrorInvalidValue;
 }
 
-hipError_t nca_launch_fused_bf16(int F, const NcaFusedArgs& a, int kmode, int grid, hipStream_t st) {
+hipError_t nca_launch_fused_bf16(int F, const NcaFusedArgs& a, int kmode, int grid, hipStream_t st, bool s8) {
     switch (F) {
-        case 32: return launch_fused_bf<32>(a, kmode, grid, st);
-        case 64: return launch_fused_bf<64>(a, kmode, grid, st);
-        case 128: return launch_fused_bf<128>(a, kmode, grid, st);
+        case 32: return launch_fused_bf<32>(a, kmode, grid, st, s8);
+        case 64: return launch_fused_bf<64>(a, kmode, grid, st, s8);
+        case 128: return launch_fused_bf<128>(a, kmode, grid, st, s8);
     }
     return hipErrorInvalidValue;
 }
@@ -1227,27 +1144,14 @@ hipError_t nca_launch_pack_bf16(const NcaLayout& y, const float* prm, void* out,
 }
 
 hipError_t nca_launch_wgrad_bf16(int F, const NcaWgradArgs& a, int nsplit, hipStream_t st) {
+    const bool d8 = a.njobs > 0 && a.job[0].d8 != 0;          // one format for every D block of a launch
+    for (int j = 0; j < a.njobs; ++j)
+        if ((a.job[j].d8 != 0) != d8) return hipErrorInvalidValue;
+    const dim3 grid(nsplit, a.njobs), block(64);
     switch (F) {
-        case 32: hipLaunchKernelGGL(nca_wgrad_bf16<32>, dim3(nsplit, a.njobs), dim3(64), 0, st, a); break;
-        case 64: hipLaunchKernelGGL(nca_wgrad_bf16<64>, dim3(nsplit, a.njobs), dim3(64), 0, st, a); break;
-        case 128: hipLaunchKernelGGL(nca_wgrad_bf16<128>, dim3(nsplit, a.njobs), dim3(64), 0, st, a); break;
-        default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
-}
-
-hipError_t nca_launch_wgrad_pair_bf16(int F, const NcaWgradPairArgs& a, hipStream_t st) {
-    const dim3 grid((a.nsplit + 1) / 2, a.npairs), block(256);
-    switch (F) {
-        case 32:
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_wgrad_pair_bf16<32>), hipFuncAttributeMaxDynamicSharedMemorySize, PairCfg<32>::LDS);
-            hipLaunchKernelGGL(nca_wgrad_pair_bf16<32>, grid, block, PairCfg<32>::LDS, st, a); break;
-        case 64:
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_wgrad_pair_bf16<64>), hipFuncAttributeMaxDynamicSharedMemorySize, PairCfg<64>::LDS);
-            hipLaunchKernelGGL(nca_wgrad_pair_bf16<64>, grid, block, PairCfg<64>::LDS, st, a); break;
-        case 128:
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_wgrad_pair_bf16<128>), hipFuncAttributeMaxDynamicSharedMemorySize, PairCfg<128>::LDS);
-            hipLaunchKernelGGL(nca_wgrad_pair_bf16<128>, grid, block, PairCfg<128>::LDS, st, a); break;
+        case 32: if (d8) hipLaunchKernelGGL((nca_wgrad_bf16<32, true>), grid, block, 0, st, a); else hipLaunchKernelGGL((nca_wgrad_bf16<32, false>), grid, block, 0, st, a); break;
+        case 64: if (d8) hipLaunchKernelGGL((nca_wgrad_bf16<64, true>), grid, block, 0, st, a); else hipLaunchKernelGGL((nca_wgrad_bf16<64, false>), grid, block, 0, st, a); break;
+        case 128: if (d8) hipLaunchKernelGGL((nca_wgrad_bf16<128, true>), grid, block, 0, st, a); else hipLaunchKernelGGL((nca_wgrad_bf16<128, false>), grid, block, 0, st, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

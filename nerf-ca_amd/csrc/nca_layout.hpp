@@ -242,6 +242,22 @@ inline int nca_build_layout_bf16(const NcaNet& n, NcaLayout* out, const char** w
     return NCA_OK;
 }
 
+// fp8 staging (NCA_OPT_STAGE_FP8): the blocks that only the weight-gradient kernel reads cross HBM as 8-bit floats.
+//   hidden block j = input of layer j+1, j = 0..NL-2, behind the input block of a tile of the forward store:
+//       e4m3 (32 x F bytes, [row tile][lane][16 B]: byte i = accumulator register i, value x 2^NCA_H8_LOG2) for j < NL-2;
+//       the last one stays bf16 (64 x F bytes) -- the backward recomputes the last layer from it
+//   output-gradient block l = 0..NL-1 of a tile of the backward's D region:
+//       e5m2 (32 x F bytes, same byte order, value x the tile's power-of-two scale); with the on-chip layer D_{NL-1} is never
+//       written (its weight gradient is formed from the bf16 registers).  Behind all nets' blocks a 128-byte record holds
+//       the INVERSE scale of the 64-sample wave tile per net (f32[2], in the first of the tile's two 32-sample records)
+#define NCA_H8_LOG2 2
+#define NCA_D8_LOG2 4            // the tile's largest |d loss / d raw| is scaled into [2^4, 2^5)
+#define NCA_D8_REC_BYTES 128
+NCA_HD inline int64_t nca_bf_hoff(const NcaLayout& y, int j, bool h8) { return (int64_t)j * (h8 ? 32 : 64) * y.F; }
+NCA_HD inline int64_t nca_bf_hbytes(const NcaLayout& y, bool h8) { return y.NL < 2 ? 0 : nca_bf_hoff(y, y.NL - 2, h8) + 64 * (int64_t)y.F; }
+NCA_HD inline int64_t nca_bf_doff(const NcaLayout& y, int l, bool d8) { return (int64_t)l * (d8 ? 32 : 64) * y.F; }
+NCA_HD inline int64_t nca_bf_dbytes(const NcaLayout& y, bool d8) { return nca_bf_doff(y, y.NL, d8); }
+
 // bytes of one 32-sample tile of the bf16 backward scratch for this net:
 //   [input block 32 x 112][inputs of layers 1..NL-1: 32 x F each][output gradients D_0..D_{NL-1}: 32 x F each]
 NCA_HD inline int64_t nca_bf_tile_bytes(const NcaLayout& y) {

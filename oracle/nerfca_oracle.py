@@ -53,6 +53,12 @@ class NetSpec:
     num_time_dim: int = 0  # 0 -> static net (CPPN); >0 -> dynamic net (Temporal)
     num_phases: int = 10  # Temporal.py:25 fixed_frame_ids = arange(0, 10)
     emulate_bf16: bool = False  # NOT reference behaviour: round where the bf16 HIP path rounds (see _q)
+    # NOT reference behaviour either: with emulate_bf16, also round what the bf16 HIP path's BACKWARD rounds when it runs from a
+    # forward store with fp8 staging (nca_layout.hpp): value = samples per ray (tiles of 64 consecutive samples of a ray share
+    # a power-of-two scale), 0 = off.  emulate_onchip_last: the last hidden layer's weight gradient is formed on chip from
+    # bf16 operands (the planner's choice from ~1 M samples), else from e5m2 output gradients like the others.
+    emulate_fp8_stage: int = 0
+    emulate_onchip_last: bool = False
 
     @property
     def enc_features(self) -> int:
@@ -188,12 +194,80 @@ def _q(x: Tensor) -> Tensor:
     return x + (x.to(torch.bfloat16).to(x.dtype) - x).detach()
 
 
+def _q8(x: Tensor, fmt: str) -> Tensor:
+    """Round to an 8-bit float (e4m3: OCP e4m3fn, e5m2) with saturation, as v_cvt_scalef32_pk_{fp8,bf8}_f32 does under
+    MODE.FP16_OVFL (round to nearest even; measured on gfx950, tools/fp8_cvt_probe.hip)."""
+    dt, top = (torch.float8_e4m3fn, 448.0) if fmt == "e4m3" else (torch.float8_e5m2, 57344.0)
+    return x.clamp(-top, top).to(dt).to(x.dtype)
+
+
+H8_LOG2, D8_LOG2 = 2, 4          # nca_layout.hpp: NCA_H8_LOG2, NCA_D8_LOG2
+
+
+def _tile_scales(g: Tensor, S: int) -> Tensor:
+    """Per-sample power of two 2^(D8_LOG2 - e), where 2^e <= max |g| < 2^(e+1) over the sample's tile of 64 consecutive samples
+    of its ray (g = d loss / d raw output, [R*S, 1] ray-major); tiles whose gradients are all zero get 1."""
+    R = g.shape[0] // S
+    nt = (S + 63) // 64
+    gp = TF.pad(g.detach().reshape(R, S), (0, nt * 64 - S)).reshape(R, nt, 64)
+    am = gp.abs().amax(dim=-1, keepdim=True)
+    _, ex = torch.frexp(am)                      # am = m 2^ex with m in [0.5, 1): floor(log2 am) = ex - 1
+    sc = torch.ldexp(torch.ones_like(am), D8_LOG2 - (ex - 1))
+    sc = torch.where(am > 0, sc, torch.ones_like(sc))
+    return sc.expand(R, nt, 64).reshape(R, nt * 64)[:, :S].reshape(-1, 1)
+
+
+class _StagedLinear(torch.autograd.Function):
+    """One F-wide layer of the bf16 HIP path, forward AND backward arithmetic, for the fp8-staging emulation:
+    forward  y = bf16(x) bf16(W)^T + b (f32 accumulation);
+    backward dx = bf16(dy) bf16(W) (the deltas are packed to bf16 as the next contraction's operand);
+             dW, db from e5m2(dy s_tile) / s_tile (converted from the f32 deltas) and, where the layer input crossed HBM as
+             e4m3, from e4m3(x 2^H8_LOG2) / 2^H8_LOG2 (converted from the f32 activations) -- else from the bf16 operands.
+             First layer (`first`): its input gradient is only needed for the time latents, which the kernels form in the
+             weight-gradient pass (one-hot phase columns of the input block times the staged D_0, then the f32 weights)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, state, d8: bool, h8: bool, first: bool):
+        xq, Wq = x.to(torch.bfloat16).to(x.dtype), W.to(torch.bfloat16).to(W.dtype)
+        ctx.save_for_backward(x, xq, Wq, W)
+        ctx.state, ctx.d8, ctx.h8, ctx.first = state, d8, h8, first
+        return xq @ Wq.t() + b
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, xq, Wq, W = ctx.saved_tensors
+        dq = dy.to(torch.bfloat16).to(dy.dtype)
+        if ctx.d8:
+            sc = ctx.state["scale"]
+            dd = _q8(dy * sc, "e5m2") / sc
+        else:
+            dd = dq
+        dx = dd @ W if ctx.first else dq @ Wq
+        hh = _q8(x * 2.0 ** H8_LOG2, "e4m3") / 2.0 ** H8_LOG2 if ctx.h8 else xq
+        return dx, dd.t() @ hh, dd.sum(0), None, None, None, None
+
+
 def mlp(params: Dict[str, Tensor], spec: NetSpec, feats: Tensor) -> Tensor:
     """Shared body of CPPN.forward (CPPN.py:98-110) and Temporal.query_time (Temporal.py:125-134).
 
     With ``spec.emulate_bf16`` (used only to test the bf16 HIP kernels) the MFMA operands are rounded
     to bf16 exactly where the kernel rounds them: layer inputs (encoded features, ReLU outputs) and
     weights of the F-wide layers; biases, accumulation and the F->1 output layer stay f32."""
+    if spec.emulate_bf16 and spec.emulate_fp8_stage > 0:
+        if spec.num_late_layers > 0:
+            raise NotImplementedError
+        NL = spec.num_early_layers + 1
+        state: dict = {}
+        h = feats
+        for i in range(NL):
+            last = i == NL - 1
+            d8 = not (last and spec.emulate_onchip_last)       # on chip: bf16 registers, nothing is staged
+            h8 = 1 <= i <= NL - 2                              # inputs of layers 1..NL-2; the input block and the last layer's input stay bf16
+            h = torch.relu(_StagedLinear.apply(h, params[f"early_pts_layers.{2 * i}.weight"], params[f"early_pts_layers.{2 * i}.bias"], state, d8, h8, i == 0))
+        raw = TF.linear(h, params["output_linear.0.weight"], params["output_linear.0.bias"])
+        if raw.requires_grad:      # d loss / d raw arrives before the layers' backward runs: fix the tile scales there
+            raw.register_hook(lambda g: state.__setitem__("scale", _tile_scales(g, spec.emulate_fp8_stage)))
+        return raw
     if spec.emulate_bf16:
         if spec.num_late_layers > 0:
             raise NotImplementedError

@@ -63,3 +63,20 @@ def rel_err(a, b):
     a = torch.as_tensor(a).detach().double()
     b = torch.as_tensor(b).detach().double()
     return float((a - b).abs().max() / max(float(b.abs().max()), 1e-30))
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def nca_option(opt_name, value):
+    """Set a planner option of the library (nca_set_option) for the duration of a block; None leaves it alone."""
+    from nerfca_amd import _capi
+    opt = getattr(_capi, "OPT_" + opt_name)
+    old = _capi.get_option(opt)
+    if value is not None:
+        _capi.set_option(opt, value)
+    try:
+        yield
+    finally:
+        _capi.set_option(opt, old)

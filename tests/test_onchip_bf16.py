@@ -1,10 +1,13 @@
-"""GPU parity of the kernel path the headline bench is timed on: the bf16 backward from the forward's store with the last
+"""GPU parity of the on-chip weight gradient of the bench's backward: the bf16 backward from the forward's store with the last
 hidden layer's weight gradient accumulated on chip -- `nca_fused_bf16<F, NCA_KM_BWD_ONCHIP>` ("mode 4": one launch per net,
 per-workgroup dW slabs) plus the reduced weight-gradient job set.  The planner selects it from 8 * 8 * CUs wave tiles
 (~1.05 M samples); `nca_set_option(NCA_OPT_ONCHIP_MIN_TILES, 0)` forces it at sizes the oracle finishes in seconds, -1
 switches it off (mode 3).  What `loss.backward()` yields in the reference: train/run_composite.py:306.
 
-Every test asserts that mode 4 really ran (two dgrad launches per backward, one per net).
+Every test asserts that mode 4 really ran (two dgrad launches per backward, one per net).  The comparisons with the
+recompute backward and with mode 3 are exact up to summation order, which holds for bf16 staging (NCA_OPT_STAGE_FP8 = 0);
+the default fp8 staging of the same kernels is tested in tests/test_fp8_stage.py, and the PSNR gate at the end of this
+file trains with the library's defaults.
 """
 import contextlib
 import dataclasses
@@ -12,7 +15,7 @@ import dataclasses
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import nca_option, rel_err
 from oracle import nerfca_oracle as O
 from test_hip_parity import BF_GRAD, BF_OUT, make_dynamic, make_static
 
@@ -126,7 +129,7 @@ def test_mode4_forced_vs_emulating_oracle_recompute_and_mode3(dev, R, S, F, earl
         for name, limit, ws, thr in (("recompute", 0, 6 << 30, None), ("mode3", 96 << 30, 6 << 30, -1), ("mode4", 96 << 30, 6 << 30, 0),
                                      ("mode4_chunks", 96 << 30, 24 << 20, 0)):
             fused.STORE_FORWARD_LIMIT_BYTES, fused.BWD_WORKSPACE_BYTES = limit, ws
-            with onchip_min_tiles(thr), count_dgrad_launches(launches):
+            with onchip_min_tiles(thr), nca_option("STAGE_FP8", 0), count_dgrad_launches(launches):
                 res[name] = _hip_grads(s, t, dev, o, d, ph, I0, z, dists, cp, cs, cd)
     finally:
         fused.STORE_FORWARD_LIMIT_BYTES, fused.BWD_WORKSPACE_BYTES = saved
@@ -164,7 +167,7 @@ def test_mode4_forced_with_depth_gradients(dev, F, R, S):
     try:
         for name, limit, thr in (("recompute", 0, None), ("mode3", 96 << 30, -1), ("mode4", 96 << 30, 0)):
             fused.STORE_FORWARD_LIMIT_BYTES = limit
-            with onchip_min_tiles(thr), count_dgrad_launches(launches):
+            with onchip_min_tiles(thr), nca_option("STAGE_FP8", 0), count_dgrad_launches(launches):
                 res[name] = _hip_grads(s, t, dev, o, d, ph, I0, z, dists, cp, cs, cd, want_depth=True)
     finally:
         fused.STORE_FORWARD_LIMIT_BYTES = saved
@@ -198,9 +201,9 @@ def test_mode4_natural_threshold_vs_oracle(dev):
     for m in (s, t):
         m.update_freq_mask_alpha(75000, 150000)
     launches = []
-    with count_dgrad_launches(launches):
+    with nca_option("STAGE_FP8", 0), count_dgrad_launches(launches):
         p4, a4, b4, g4 = _hip_grads(s, t, dev, o, d, ph, I0, z, dists, cp, cs, cd)
-    with onchip_min_tiles(-1), count_dgrad_launches(launches):
+    with nca_option("STAGE_FP8", 0), onchip_min_tiles(-1), count_dgrad_launches(launches):
         p3, a3, b3, g3 = _hip_grads(s, t, dev, o, d, ph, I0, z, dists, cp, cs, cd)
     assert launches == [2, 1], launches
     assert rel_err(a4.cpu(), a) < BF_OUT and rel_err(b4.cpu(), b) < BF_OUT
@@ -230,7 +233,7 @@ def test_mode4_full_size_step_equals_mode3(dev):
         nerfca_amd.set_precision("bf16", s, t)
         cfg = TrainConfig(depth_samples_per_ray_coarse=192, img_sample_size=65536)
         tr = CompositeTrainer(cfg, s, t, data, dev, seed=0)
-        with onchip_min_tiles(thr), count_dgrad_launches(launches):
+        with onchip_min_tiles(thr), nca_option("STAGE_FP8", 0), count_dgrad_launches(launches):
             _, _, terms = tr.step_fused(75000)
         grads = torch.cat([p.grad.flatten() for p in tr.params]).clone()
         res.append((terms.clone(), grads))
@@ -243,7 +246,7 @@ def test_mode4_full_size_step_equals_mode3(dev):
 
 def test_bf16_psnr_gate_at_bench_configuration(dev):
     """The gate of the throughput mode where the bench runs it ("bf16: PSNR on the held-out view within 0.1 dB of
-    fp32 after equal steps"): 200 steps of 65 536 rays x 192 samples on the 256^2 synthetic data set (40 training images, one
+    fp32 after equal steps"): 300 steps of 65 536 rays x 192 samples on the 256^2 synthetic data set (40 training images, one
     held-out view) from the same initial weights, ray batches and depth jitter in f32 (the mode that is within 1e-5 of the
     reference's arithmetic per step) and in bf16 (storing forward + on-chip backward, the kernels the bench times);
     `test_psnr` = -10 log10(test loss) is the reference's own definition (train/run_composite.py:391)."""
@@ -252,7 +255,7 @@ def test_bf16_psnr_gate_at_bench_configuration(dev):
     from nerfca_amd.model.CPPN import CPPN
     from nerfca_amd.model.Temporal import Temporal
     from nerfca_amd.train.trainer import CompositeTrainer, TrainConfig
-    steps = 200
+    steps = 300
     data = synthetic.make_dataset(256, 192, dev, views=synthetic.TRAIN_VIEWS)
     res = {}
     for prec in ("f32", "bf16"):
