@@ -487,7 +487,7 @@ static int plan_bwd(const NcaLayout* lays, int nnets, int32_t prec, int64_t unit
     // f32 wgrad: 256-thread workgroups, two per CU.  bf16 wgrad: one wave per (job, split), four per CU.
     // all (split, job) blocks must be co-resident in ONE round: floor, never ceil (6 stragglers of 1030
     // blocks on 1024 slots double the kernel time)
-    int nsplit = ((bf ? 4 : 2) * cus) / p->njobs;
+    int nsplit = ((bf ? 4 : 2) * cus) / (p->njobs > 0 ? p->njobs : 1);
     if (nsplit < 1) nsplit = 1;
     const int64_t slab_bytes = align_up((int64_t)nsplit * p->slab_stride * 4, 256);
     const int64_t oslab_bytes = align_up((int64_t)cus * 2 * (F + 1) * 4, 256);

@@ -1017,14 +1017,28 @@ __device__ __forceinline__ void wgrad_write(const f32x16 (&acc)[F / 32][NTB], co
 // NTB = 32-column tiles of the H block (F/32 for hidden inputs, 4 for the 112-wide input block).  D8: every D block of the launch
 // is e5m2 scaled per wave tile (fp8 staging, nca_layout.hpp); H8: the job's H block is e4m3 x 2^NCA_H8_LOG2 (the input block and
 // the last layer's input stay bf16).
+//
+// Operand tiles travel HBM -> LDS by LDS-DMA (global_load_lds, no registers) into a ring of NSLOT tile slots per wave, NSLOT - 1
+// tiles ahead of the MFMAs: one wave per SIMD (its 256 dW accumulators fill the AGPR file) keeps 24-32 KiB in flight without
+// holding them in VGPRs -- a CU needs ~50 KiB outstanding to pull its share of 6.5 TB/s at ~2 us of loaded latency, and one
+// 8 KiB 8-bit tile ahead in registers gave 4.5 TB/s.  Fragments are [lane][16 B] in HBM and land in LDS as they are, so the
+// reads back (ds_read_b128, lane * 16) are conflict-free.
 template <int F, int NTB, bool D8, bool H8>
-__device__ __forceinline__ void wgrad_job(const NcaWgradArgs& a, const NcaWgradJob& job, int q, int nsplit, int lane) {
-    constexpr int MT = F / 32;
-    constexpr int ND_ = D8 ? MT : 2 * MT;                                  // 16-byte fragments per lane of the D block
+struct WgradRing {
+    static constexpr int MT = F / 32;
+    static constexpr int ND = D8 ? MT : 2 * MT, NH = H8 ? NTB : 2 * NTB, FR = ND + NH;      // 1 KiB fragments per tile
+    static constexpr int NSLOT = FR <= 8 ? 4 : (FR <= 12 ? 3 : 2);
+    static constexpr int BYTES = NSLOT * FR * 1024;
+};
+constexpr int NCA_WGRAD_LDS = 36 * 1024;
+
+template <int F, int NTB, bool D8, bool H8>
+__device__ __forceinline__ void wgrad_job(const NcaWgradArgs& a, const NcaWgradJob& job, int q, int nsplit, int lane, char* ring) {
+    using R = WgradRing<F, NTB, D8, H8>;
+    constexpr int MT = F / 32, ND_ = R::ND, NH_ = R::NH, FR = R::FR, NSLOT = R::NSLOT;
+    static_assert(R::BYTES <= NCA_WGRAD_LDS, "ring does not fit the wave's LDS share");
     constexpr float HINV = 1.f / (float)(1 << NCA_H8_LOG2);
     const int lc = lane & 31, lh = lane >> 5;
-    constexpr bool h8 = H8;
-    constexpr int NH_ = H8 ? NTB : 2 * NTB;
     const int64_t per = (a.ntiles + nsplit - 1) / nsplit;
     const int64_t t0 = (int64_t)q * per, t1 = (t0 + per < a.ntiles) ? t0 + per : a.ntiles;
     const char* base = reinterpret_cast<const char*>(a.scratch);          // D region of this launch
@@ -1041,27 +1055,45 @@ __device__ __forceinline__ void wgrad_job(const NcaWgradArgs& a, const NcaWgradJ
 #pragma unroll
     for (int m = 0; m < MT; ++m) bsum[m] = 0.f;
 
-    // blocks are fragment-major [k-step][lane][16 B] (8-bit blocks: [row tile][lane][16 B]): one coalesced 1 KiB load per
-    // fragment.  The next tile's fragments are requested before this tile's MFMAs so that 16-32 KiB per wave stay in flight.
-    u32x4 XD[ND_], XH[NH_];
-    float sc = 1.f;
-    auto load_tile = [&](int64_t t, u32x4 (&xd)[ND_], u32x4 (&xh)[NH_], float& scl) {
+    // every tile issues exactly FR DMA instructions (a fragment beyond the input block's 112 slots re-reads fragment 0 and is
+    // zeroed after the read back), so "all but the youngest (NSLOT - 1) FR" is a compile-time vmcnt
+    auto issue = [&](int64_t t, int slot) {
         const char* dp = base + t * a.rows_total + job.d_row0 + lane * 16;            // rows_total = bytes per 32-sample tile
         const char* bp = base_b + (t + a.tile0_b) * a.rows_total_b + job.b_row0 + lane * 16;
+        char* dst = ring + slot * (FR * 1024);
 #pragma unroll
-        for (int s = 0; s < ND_; ++s) xd[s] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(dp + s * 1024));
+        for (int s = 0; s < ND_; ++s)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dp + s * 1024),
+                                             (__attribute__((address_space(3))) void*)(dst + s * 1024), 16, 0, 2);
 #pragma unroll
-        for (int s = 0; s < NH_; ++s) xh[s] = (H8 || s * 32 + 32 <= brow) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(bp + s * 1024)) : (u32x4){0, 0, 0, 0};
-        // the wave tile's inverse scale sits in the first of its two 32-sample records
-        if (D8) scl = reinterpret_cast<const float*>(base + (t & ~(int64_t)1) * a.rows_total + job.dscale_off)[job.net];
+        for (int s = 0; s < NH_; ++s)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bp + ((H8 || s * 32 + 32 <= brow) ? s : 0) * 1024),
+                                             (__attribute__((address_space(3))) void*)(dst + (ND_ + s) * 1024), 16, 0, 2);
     };
-    if (t0 < t1) load_tile(t0, XD, XH, sc);
-    for (int64_t t = t0; t < t1; ++t) {
-        u32x4 ND[ND_], NH[NH_];
-        float nsc = 1.f;
-        if (t + 1 < t1) load_tile(t + 1, ND, NH, nsc);
+    auto scale_of = [&](int64_t t) {      // the wave tile's inverse scale sits in the first of its two 32-sample records
+        return D8 ? reinterpret_cast<const float*>(base + (t & ~(int64_t)1) * a.rows_total + job.dscale_off)[job.net] : 1.f;
+    };
+    const int64_t n = t1 > t0 ? t1 - t0 : 0;
+#pragma unroll
+    for (int p = 0; p < NSLOT - 1; ++p)
+        if (p < n) issue(t0 + p, p);
+    float sc = n > 0 ? scale_of(t0) : 1.f;
+    for (int64_t i = 0; i < n; ++i) {
+        const float nsc = i + 1 < n ? scale_of(t0 + i + 1) : 1.f;
+        if (i + NSLOT - 1 < n) {
+            issue(t0 + i + NSLOT - 1, (int)((i + NSLOT - 1) % NSLOT));       // into the slot tile i - 1 was read from (its reads have been consumed)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSLOT - 1) * FR) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const char* slot = ring + (int)(i % NSLOT) * (FR * 1024) + lane * 16;
+        u32x4 XD[ND_], XH[NH_];
+#pragma unroll
+        for (int s = 0; s < ND_; ++s) XD[s] = *reinterpret_cast<const u32x4*>(slot + s * 1024);
+#pragma unroll
+        for (int s = 0; s < NH_; ++s) XH[s] = (H8 || s * 32 + 32 <= brow) ? *reinterpret_cast<const u32x4*>(slot + (ND_ + s) * 1024) : (u32x4){0, 0, 0, 0};
         u32x4 TD[MT][2], TH[NTB][2];
-        if constexpr (D8) transpose_block8<MT, ND_, true, true>(XD, lc, lh, h8 ? sc * HINV : sc, TD, &bsum);      // (an e4m3 partner's scale rides along)
+        if constexpr (D8) transpose_block8<MT, ND_, true, true>(XD, lc, lh, H8 ? sc * HINV : sc, TD, &bsum);      // (an e4m3 partner's scale rides along)
         else transpose_block<MT>(XD, lc, lh, TD, &bsum);
         if constexpr (H8) transpose_block8<NTB, NH_, false, !D8>(XH, lc, lh, HINV, TH, nullptr);
         else transpose_block<NTB>(XH, lc, lh, TH, nullptr);
@@ -1073,15 +1105,9 @@ __device__ __forceinline__ void wgrad_job(const NcaWgradArgs& a, const NcaWgradJ
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
                     acc[m][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(TD[m][s]), frag(TH[c][s]), acc[m][c], 0, 0, 0);
-        if (t + 1 < t1) {
-#pragma unroll
-            for (int s = 0; s < ND_; ++s) XD[s] = ND[s];
-#pragma unroll
-            for (int s = 0; s < NH_; ++s) XH[s] = NH[s];
-            sc = nsc;
-        }
+        sc = nsc;
     }
-    if (D8 && h8) {          // the H scale rode on the D tiles: the bias sums (column sums of those tiles) carry it too
+    if (D8 && H8) {          // the H scale rode on the D tiles: the bias sums (column sums of those tiles) carry it too
 #pragma unroll
         for (int m = 0; m < MT; ++m) bsum[m] *= (float)(1 << NCA_H8_LOG2);
     }
@@ -1091,11 +1117,12 @@ __device__ __forceinline__ void wgrad_job(const NcaWgradArgs& a, const NcaWgradJ
 
 template <int F, bool D8>
 __global__ __launch_bounds__(64, 1) void nca_wgrad_bf16(const NcaWgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char wring[];
     const NcaWgradJob job = a.job[blockIdx.y];
     // (at F = 128 the 112-slot input block and a hidden block have the same shape: one body serves both)
-    if (job.h8) wgrad_job<F, F / 32, D8, true>(a, job, blockIdx.x, gridDim.x, threadIdx.x);
-    else if (F != 128 && job.is_enc) wgrad_job<F, 4, D8, false>(a, job, blockIdx.x, gridDim.x, threadIdx.x);
-    else wgrad_job<F, F == 128 ? 4 : F / 32, D8, false>(a, job, blockIdx.x, gridDim.x, threadIdx.x);
+    if (job.h8) wgrad_job<F, F / 32, D8, true>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
+    else if (F != 128 && job.is_enc) wgrad_job<F, 4, D8, false>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
+    else wgrad_job<F, F == 128 ? 4 : F / 32, D8, false>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1148,10 +1175,11 @@ hipError_t nca_launch_wgrad_bf16(int F, const NcaWgradArgs& a, int nsplit, hipSt
     for (int j = 0; j < a.njobs; ++j)
         if ((a.job[j].d8 != 0) != d8) return hipErrorInvalidValue;
     const dim3 grid(nsplit, a.njobs), block(64);
+    constexpr int L = NCA_WGRAD_LDS;          // the wave's ring of tile slots: four one-wave workgroups share a CU's 160 KiB
     switch (F) {
-        case 32: if (d8) hipLaunchKernelGGL((nca_wgrad_bf16<32, true>), grid, block, 0, st, a); else hipLaunchKernelGGL((nca_wgrad_bf16<32, false>), grid, block, 0, st, a); break;
-        case 64: if (d8) hipLaunchKernelGGL((nca_wgrad_bf16<64, true>), grid, block, 0, st, a); else hipLaunchKernelGGL((nca_wgrad_bf16<64, false>), grid, block, 0, st, a); break;
-        case 128: if (d8) hipLaunchKernelGGL((nca_wgrad_bf16<128, true>), grid, block, 0, st, a); else hipLaunchKernelGGL((nca_wgrad_bf16<128, false>), grid, block, 0, st, a); break;
+        case 32: if (d8) hipLaunchKernelGGL((nca_wgrad_bf16<32, true>), grid, block, L, st, a); else hipLaunchKernelGGL((nca_wgrad_bf16<32, false>), grid, block, L, st, a); break;
+        case 64: if (d8) hipLaunchKernelGGL((nca_wgrad_bf16<64, true>), grid, block, L, st, a); else hipLaunchKernelGGL((nca_wgrad_bf16<64, false>), grid, block, L, st, a); break;
+        case 128: if (d8) hipLaunchKernelGGL((nca_wgrad_bf16<128, true>), grid, block, L, st, a); else hipLaunchKernelGGL((nca_wgrad_bf16<128, false>), grid, block, L, st, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

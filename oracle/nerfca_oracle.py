@@ -59,6 +59,8 @@ class NetSpec:
     # bf16 operands (the planner's choice from ~1 M samples), else from e5m2 output gradients like the others.
     emulate_fp8_stage: int = 0
     emulate_onchip_last: bool = False
+    emulate_stage_formats: Optional[Tuple[str, str]] = ("e5m2", "e4m3")  # (output gradients, layer inputs); None: bf16 staging with the
+    #                                                                      same emulation of the backward chain (bf16 deltas)
 
     @property
     def enc_features(self) -> int:
@@ -227,7 +229,7 @@ class _StagedLinear(torch.autograd.Function):
              weight-gradient pass (one-hot phase columns of the input block times the staged D_0, then the f32 weights)."""
 
     @staticmethod
-    def forward(ctx, x, W, b, state, d8: bool, h8: bool, first: bool):
+    def forward(ctx, x, W, b, state, d8: Optional[str], h8: Optional[str], first: bool):
         xq, Wq = x.to(torch.bfloat16).to(x.dtype), W.to(torch.bfloat16).to(W.dtype)
         ctx.save_for_backward(x, xq, Wq, W)
         ctx.state, ctx.d8, ctx.h8, ctx.first = state, d8, h8, first
@@ -239,11 +241,11 @@ class _StagedLinear(torch.autograd.Function):
         dq = dy.to(torch.bfloat16).to(dy.dtype)
         if ctx.d8:
             sc = ctx.state["scale"]
-            dd = _q8(dy * sc, "e5m2") / sc
+            dd = _q8(dy * sc, ctx.d8) / sc
         else:
             dd = dq
         dx = dd @ W if ctx.first else dq @ Wq
-        hh = _q8(x * 2.0 ** H8_LOG2, "e4m3") / 2.0 ** H8_LOG2 if ctx.h8 else xq
+        hh = _q8(x * 2.0 ** H8_LOG2, ctx.h8) / 2.0 ** H8_LOG2 if ctx.h8 else xq
         return dx, dd.t() @ hh, dd.sum(0), None, None, None, None
 
 
@@ -258,11 +260,12 @@ def mlp(params: Dict[str, Tensor], spec: NetSpec, feats: Tensor) -> Tensor:
             raise NotImplementedError
         NL = spec.num_early_layers + 1
         state: dict = {}
+        fd, fh = spec.emulate_stage_formats or (None, None)
         h = feats
         for i in range(NL):
             last = i == NL - 1
-            d8 = not (last and spec.emulate_onchip_last)       # on chip: bf16 registers, nothing is staged
-            h8 = 1 <= i <= NL - 2                              # inputs of layers 1..NL-2; the input block and the last layer's input stay bf16
+            d8 = None if (last and spec.emulate_onchip_last) else fd     # on chip: bf16 registers, nothing is staged
+            h8 = fh if 1 <= i <= NL - 2 else None                          # inputs of layers 1..NL-2; the input block and the last layer's input stay bf16
             h = torch.relu(_StagedLinear.apply(h, params[f"early_pts_layers.{2 * i}.weight"], params[f"early_pts_layers.{2 * i}.bias"], state, d8, h8, i == 0))
         raw = TF.linear(h, params["output_linear.0.weight"], params["output_linear.0.bias"])
         if raw.requires_grad:      # d loss / d raw arrives before the layers' backward runs: fix the tile scales there

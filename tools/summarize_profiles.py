@@ -20,7 +20,7 @@ dst = os.path.join(ROOT, "profiles")
 # (no closing bracket: the f32 kernels carry a third template argument, the split-bf16 switch)
 KERNELS = {"fwd": [f"nca_fused_{prec}<128, 2", f"nca_fused_{prec}<128, 0", f"nca_fused_{prec}<128, false"],
            "bwd_dgrad": [f"nca_fused_{prec}<128, 4", f"nca_fused_{prec}<128, 3", f"nca_fused_{prec}<128, 1", f"nca_fused_{prec}<128, true"],
-           "bwd_wgrad": ["nca_wgrad_bf16<128>"] if prec == "bf16" else ["nca_wgrad_f32x3", "nca_wgrad_f32"], "bwd_reduce": ["nca_reduce_f32"],
+           "bwd_wgrad": ["nca_wgrad_bf16<128, true", "nca_wgrad_bf16<128, false", "nca_wgrad_bf16<128>"] if prec == "bf16" else ["nca_wgrad_f32x3", "nca_wgrad_f32"], "bwd_reduce": ["nca_reduce_f32"],
            "loss": ["nca_loss_rays"]}
 
 
