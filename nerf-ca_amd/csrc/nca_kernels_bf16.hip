@@ -39,6 +39,31 @@ __device__ __forceinline__ unsigned cvt4_e5m2(float a, float b, float c, float d
     v = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(v, c, d, div, true);
     return __builtin_bit_cast(unsigned, v);
 }
+// the same from a packed bf16 pair (two values per instruction; the pair has been rounded to bf16 already)
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt4_e4m3_pk(unsigned lo, unsigned hi, float div) {
+    s16x2 v = {0, 0};
+    v = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(v, __builtin_bit_cast(bf16x2v, lo), div, false);
+    v = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(v, __builtin_bit_cast(bf16x2v, hi), div, true);
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ unsigned cvt4_e5m2_pk(unsigned lo, unsigned hi, float div) {
+    s16x2 v = {0, 0};
+    v = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(v, __builtin_bit_cast(bf16x2v, lo), div, false);
+    v = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(v, __builtin_bit_cast(bf16x2v, hi), div, true);
+    return __builtin_bit_cast(unsigned, v);
+}
+// Epilogue arithmetic on PACKED bf16 pairs (the vector ALU, not the matrix pipe, bounds these kernels: ~6 plain vector
+// instructions hide behind one 32x32x16 MFMA, tools/valu_mfma_samewave.hip, and a row tile has 2 values per lane and MFMA):
+// ReLU as one v_pk_max_i16 (rounding to bf16 commutes with ReLU; negative floats and -0 are negative integers), "is positive"
+// as one v_pk_min_u16 against 1 (a ReLU output is >= +0).
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned relu_pk(unsigned w) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, w), (s16x2){0, 0}));
+}
+__device__ __forceinline__ unsigned pos_pk(unsigned w) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(u16x2, w), (u16x2){1, 1}));
+}
 __device__ __forceinline__ void s8_mode() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1"); }
 
 __device__ __forceinline__ unsigned pack2(float lo, float hi) {
@@ -596,7 +621,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                             if (S8 && STORED && tvalid && !ONCHIP) {
                                 u32x4 q8;
 #pragma unroll
-                                for (int w = 0; w < 4; ++w) q8[w] = cvt4_e5m2(dv[4 * w], dv[4 * w + 1], dv[4 * w + 2], dv[4 * w + 3], inv_s);
+                                for (int w = 0; w < 4; ++w) q8[w] = cvt4_e5m2_pk(Bn[c][2 * m + (w >> 1)][2 * (w & 1)], Bn[c][2 * m + (w >> 1)][2 * (w & 1) + 1], inv_s);
                                 store_nt(dblk + c * a.d_total + lane * 16 + m * 1024, q8);
                             } else if (tvalid && !ONCHIP) {
                                 char* fp2 = dblk + c * a.d_total + lane * 16;
@@ -652,9 +677,10 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
 #pragma unroll
                     for (int i = 0; i < 16; ++i) { const float b = tail[(lh * MT + m) * 16 + i]; acc0[i] = b; acc1[i] = b; }
                     mma_rowtile_ring<NKS, MT, KSMAX, RINGK>(imgl, m, A, B, acc0, acc1);
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) { acc0[i] = relu1(acc0[i]); acc1[i] = relu1(acc1[i]); }
                     if (last) {
+                        // the output layer's dot product takes the f32 activations
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) { acc0[i] = relu1(acc0[i]); acc1[i] = relu1(acc1[i]); }
                         const float* wo = tail + 2 * MT * 16;
 #pragma unroll
                         for (int i = 0; i < 16; ++i) {
@@ -662,39 +688,43 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                             part[0] = fmaf(w, acc0[i], part[0]);
                             part[1] = fmaf(w, acc1[i], part[1]);
                         }
-                    }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        Bn[0][2 * m][u] = pack2(acc0[2 * u], acc0[2 * u + 1]);
-                        Bn[0][2 * m + 1][u] = pack2(acc0[8 + 2 * u], acc0[8 + 2 * u + 1]);
-                        Bn[1][2 * m][u] = pack2(acc1[2 * u], acc1[2 * u + 1]);
-                        Bn[1][2 * m + 1][u] = pack2(acc1[8 + 2 * u], acc1[8 + 2 * u + 1]);
+                        for (int u = 0; u < 4; ++u) {
+                            Bn[0][2 * m][u] = pack2(acc0[2 * u], acc0[2 * u + 1]);
+                            Bn[0][2 * m + 1][u] = pack2(acc0[8 + 2 * u], acc0[8 + 2 * u + 1]);
+                            Bn[1][2 * m][u] = pack2(acc1[2 * u], acc1[2 * u + 1]);
+                            Bn[1][2 * m + 1][u] = pack2(acc1[8 + 2 * u], acc1[8 + 2 * u + 1]);
+                        }
+                    } else {
+                        // round to bf16, then ReLU on the packed pair
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            Bn[0][2 * m][u] = relu_pk(pack2(acc0[2 * u], acc0[2 * u + 1]));
+                            Bn[0][2 * m + 1][u] = relu_pk(pack2(acc0[8 + 2 * u], acc0[8 + 2 * u + 1]));
+                            Bn[1][2 * m][u] = relu_pk(pack2(acc1[2 * u], acc1[2 * u + 1]));
+                            Bn[1][2 * m + 1][u] = relu_pk(pack2(acc1[8 + 2 * u], acc1[8 + 2 * u + 1]));
+                        }
                     }
                     if (STORE && !last) {
-                        // bit k / 16+k of a field: low / high bf16 of packed word k (k = 4*(fragment&1) + u) is > 0.
-                        // ReLU output is >= 0, so "nonzero" is (x + 0x7fff) >> 15 per 16-bit half.
+                        // bit k / 16+k of a field: low / high bf16 of packed word k (k = 4*(fragment&1) + u) is > 0
 #pragma unroll
                         for (int c = 0; c < 2; ++c) {
                             unsigned fld = 0u;
 #pragma unroll
-                            for (int k = 0; k < 8; ++k) {
-                                const unsigned w = Bn[c][2 * m + (k >> 2)][k & 3];
-                                fld |= (((w + 0x7fff7fffu) >> 15) & 0x00010001u) << k;
-                            }
+                            for (int k = 0; k < 8; ++k) fld |= pos_pk(Bn[c][2 * m + (k >> 2)][k & 3]) << k;
                             mw[c][m >> 1] |= fld << (8 * (m & 1));
                         }
                     }
                     if (S8 && FSTORE && store_h && h8) {
-                        // e4m3 from the f32 accumulators (x 2^NCA_H8_LOG2): byte i = register i, [row tile][lane][16 B]
+                        // e4m3 of the bf16 activations (x 2^NCA_H8_LOG2): byte i = register i, [row tile][lane][16 B]
                         constexpr float DIV = 1.f / (float)(1 << NCA_H8_LOG2);
-                        u32x4 q0, q1;
 #pragma unroll
-                        for (int w = 0; w < 4; ++w) {
-                            q0[w] = cvt4_e4m3(acc0[4 * w], acc0[4 * w + 1], acc0[4 * w + 2], acc0[4 * w + 3], DIV);
-                            q1[w] = cvt4_e4m3(acc1[4 * w], acc1[4 * w + 1], acc1[4 * w + 2], acc1[4 * w + 3], DIV);
+                        for (int c = 0; c < 2; ++c) {
+                            u32x4 q;
+#pragma unroll
+                            for (int w = 0; w < 4; ++w) q[w] = cvt4_e4m3_pk(Bn[c][2 * m + (w >> 1)][2 * (w & 1)], Bn[c][2 * m + (w >> 1)][2 * (w & 1) + 1], DIV);
+                            store_nt(hblk + c * a.rows_total + lane * 16 + m * 1024, q);
                         }
-                        store_nt(hblk + lane * 16 + m * 1024, q0);
-                        store_nt(hblk + a.rows_total + lane * 16 + m * 1024, q1);
                     } else if (store_h) {
                         // the next layer's B-operand fragments exactly as they sit in registers: 1 KiB per
                         // wave instruction, [k-step][lane][16 B] (feature order inside a tile is the
@@ -874,26 +904,24 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                             u32x4 q8 = {0u, 0u, 0u, 0u};           // S8: the 16 masked values of this (row tile, column tile) as e5m2 bytes
 #pragma unroll
                             for (int s2 = 0; s2 < 2; ++s2) {
-                                // word u of fragment 2m+s2 holds accumulator registers 8 s2 + 2u, +1
+                                // word u of fragment 2m+s2 holds accumulator registers 8 s2 + 2u, +1.  Round to bf16 first, then zero
+                                // the masked halves of the packed pair with ONE and: the pair's two mask bits sit 16 apart, times
+                                // 0xffff they are the pair's and-mask
                                 u32x4 hw = {0u, 0u, 0u, 0u};
                                 if (!bits) hw = *reinterpret_cast<const u32x4*>(hp + (2 * m + s2) * 1024);
                                 const unsigned fld = mv[2 * c + (m >> 1)] >> (8 * (m & 1));
                                 u32x4 dw;
-                                float mk[8];
 #pragma unroll
                                 for (int u = 0; u < 4; ++u) {
                                     const float a0 = c == 0 ? acc0[8 * s2 + 2 * u] : acc1[8 * s2 + 2 * u];
                                     const float a1 = c == 0 ? acc0[8 * s2 + 2 * u + 1] : acc1[8 * s2 + 2 * u + 1];
-                                    const bool p0 = bits ? ((fld >> (4 * s2 + u)) & 1u) != 0u : (short)(hw[u] & 0xffffu) > 0;
-                                    const bool p1 = bits ? ((fld >> (16 + 4 * s2 + u)) & 1u) != 0u : (short)(hw[u] >> 16) > 0;
-                                    mk[2 * u] = p0 ? a0 : 0.f;
-                                    mk[2 * u + 1] = p1 ? a1 : 0.f;
-                                    dw[u] = pack2(mk[2 * u], mk[2 * u + 1]);
+                                    const unsigned two = bits ? (fld >> (4 * s2 + u)) & 0x00010001u : pos_pk(relu_pk(hw[u]));
+                                    dw[u] = pack2(a0, a1) & (two * 0xffffu);
                                 }
                                 Bn[c][2 * m + s2] = dw;
                                 if (S8 && STORED) {
-                                    q8[2 * s2] = cvt4_e5m2(mk[0], mk[1], mk[2], mk[3], inv_s);
-                                    q8[2 * s2 + 1] = cvt4_e5m2(mk[4], mk[5], mk[6], mk[7], inv_s);
+                                    q8[2 * s2] = cvt4_e5m2_pk(dw[0], dw[1], inv_s);
+                                    q8[2 * s2 + 1] = cvt4_e5m2_pk(dw[2], dw[3], inv_s);
                                 } else if (wr_d) store_nt(dp + (2 * m + s2) * 1024, dw);
                             }
                             if (S8 && STORED && wr_d) store_nt(dp + m * 1024, q8);

@@ -223,8 +223,8 @@ class _StagedLinear(torch.autograd.Function):
     """One F-wide layer of the bf16 HIP path, forward AND backward arithmetic, for the fp8-staging emulation:
     forward  y = bf16(x) bf16(W)^T + b (f32 accumulation);
     backward dx = bf16(dy) bf16(W) (the deltas are packed to bf16 as the next contraction's operand);
-             dW, db from e5m2(dy s_tile) / s_tile (converted from the f32 deltas) and, where the layer input crossed HBM as
-             e4m3, from e4m3(x 2^H8_LOG2) / 2^H8_LOG2 (converted from the f32 activations) -- else from the bf16 operands.
+             dW, db from e5m2(bf16(dy) s_tile) / s_tile and, where the layer input crossed HBM as e4m3, from
+             e4m3(bf16(x) 2^H8_LOG2) / 2^H8_LOG2 (both converted from the packed bf16 pairs) -- else from the bf16 operands.
              First layer (`first`): its input gradient is only needed for the time latents, which the kernels form in the
              weight-gradient pass (one-hot phase columns of the input block times the staged D_0, then the f32 weights)."""
 
@@ -241,11 +241,11 @@ class _StagedLinear(torch.autograd.Function):
         dq = dy.to(torch.bfloat16).to(dy.dtype)
         if ctx.d8:
             sc = ctx.state["scale"]
-            dd = _q8(dy * sc, ctx.d8) / sc
+            dd = _q8(dq * sc, ctx.d8) / sc
         else:
             dd = dq
         dx = dd @ W if ctx.first else dq @ Wq
-        hh = _q8(x * 2.0 ** H8_LOG2, ctx.h8) / 2.0 ** H8_LOG2 if ctx.h8 else xq
+        hh = _q8(xq * 2.0 ** H8_LOG2, ctx.h8) / 2.0 ** H8_LOG2 if ctx.h8 else xq
         return dx, dd.t() @ hh, dd.sum(0), None, None, None, None
 
 

@@ -1095,8 +1095,9 @@ def test_degenerate_and_ragged_sizes(dev, prec, R, S):
     from nerfca_amd import render_rays, set_precision
     gen = torch.Generator().manual_seed(100 * R + S)
     emu = prec == "bf16"
-    ss = O.NetSpec(num_filters=32, num_early_layers=1, num_time_dim=0, emulate_bf16=emu)
-    sd = O.NetSpec(num_filters=32, num_early_layers=1, num_time_dim=8, emulate_bf16=emu)
+    # (bf16: the backward runs from the forward's store with fp8 staging, which the oracle emulates as well)
+    ss = O.NetSpec(num_filters=32, num_early_layers=1, num_time_dim=0, emulate_bf16=emu, emulate_fp8_stage=S if emu else 0)
+    sd = O.NetSpec(num_filters=32, num_early_layers=1, num_time_dim=8, emulate_bf16=emu, emulate_fp8_stage=S if emu else 0)
     ps, pd = O.init_params(ss, gen), O.init_params(sd, gen)
     win = O.freq_mask_alpha(12, 75000, 150000, 1)[0]
     o = (torch.rand(R, 3, generator=gen) * 0.2 + torch.tensor([3.0, -2.0, 2.5])).double()
