@@ -182,6 +182,9 @@ typedef struct NcaLoss {
     double inv_R;            /* 1 / GLOBAL ray count: mean-type terms are sums over local rays times this */
     const double* weights_dev; /* NULL, or DEVICE f64[4] = {w_favor, w_dent, w_occl, w_l1} read by the kernels instead of
                                   the four fields above: a captured HIP graph can be replayed with new weights          */
+    int32_t unit_mse;        /* 1: the pixel term uses unit weights while the regularisers keep `wpix` -- the fine pass's
+                                weighted_pixs_ones (train/run_composite.py:296-299)                                      */
+    int32_t reserved;
 } NcaLoss;
 enum { NCA_T_LOSS = 0, NCA_T_PIXEL, NCA_T_BLENDW, NCA_T_SIG_S_MAX, NCA_T_SIG_D_MAX, NCA_T_FAVOR, NCA_T_S_ENTROPY, NCA_T_S_SUM,
        NCA_T_D_ENTROPY, NCA_T_D_SUM, NCA_T_OCCL, NCA_T_L1, NCA_T_L2, NCA_T_COUNT };

@@ -1018,6 +1018,7 @@ extern "C" int nca_loss_fwd_bwd(const NcaLoss* d, const double* pix, const doubl
     a.skew = d->skew; a.mask_thre = d->mask_thre; a.weighted_thresh = d->weighted_thresh;
     a.w_favor = d->w_favor; a.w_dent = d->w_dent; a.w_occl = d->w_occl; a.w_l1 = d->w_l1; a.inv_R = d->inv_R;
     a.weights_dev = d->weights_dev;
+    a.unit_mse = d->unit_mse;
     a.pix = pix; a.gt = gt; a.wpix = wpix; a.sig_s = sig_s; a.sig_d = sig_d; a.dists = dists;
     a.terms = terms; a.g_pix = g_pix; a.g_sig_s = g_sig_s; a.g_sig_d = g_sig_d;
     a.partials = static_cast<double*>(work);

@@ -154,6 +154,7 @@ struct NcaLossArgs {
     double skew, mask_thre, weighted_thresh;
     double w_favor, w_dent, w_occl, w_l1, inv_R;
     const double* weights_dev;
+    int32_t unit_mse, pad_;
     const double* pix; const double* gt; const double* wpix;
     const float* sig_s; const float* sig_d; const double* dists;
     double* terms; double* g_pix; float* g_sig_s; float* g_sig_d;

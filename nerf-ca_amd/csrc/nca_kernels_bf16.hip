@@ -17,12 +17,23 @@
 #include <type_traits>
 #include "nca_kernels.hpp"
 
+// Timing-only elimination builds (tools/elim_build.sh): -DNCA_EXP=<bits> removes a piece of work so that its cost shows as a
+// time difference; results are WRONG by construction.  1: no D stores (backward from the store), 2: no masking / 8-bit
+// conversion in the dgrad sweep, 4: no output-layer reduce-scatter, 8: no per-layer weight DMA and barrier, 16: no H stores
+// (storing forward), 32: no mask bits / 8-bit conversion in the forward, 64: no on-chip dW exchange, 128: no MFMAs in the dgrad sweep.
+#ifndef NCA_EXP
+#define NCA_EXP 0
+#endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+    bf16x2 v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, v);
+}
 
 // fp8 staging (nca_layout.hpp): four f32 -> one dword of e4m3 / e5m2 bytes, value / 2^floor(log2 div) (v_cvt_scalef32_pk_*: the
 // scaling is part of the conversion; round to nearest even; with MODE.FP16_OVFL set -- s8_mode() -- out-of-range values
@@ -57,24 +68,34 @@ __device__ __forceinline__ unsigned cvt4_e5m2_pk(unsigned lo, unsigned hi, float
 // instructions hide behind one 32x32x16 MFMA, tools/valu_mfma_samewave.hip, and a row tile has 2 values per lane and MFMA):
 // ReLU as one v_pk_max_i16 (rounding to bf16 commutes with ReLU; negative floats and -0 are negative integers), "is positive"
 // as one v_pk_min_u16 against 1 (a ReLU output is >= +0).
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+// (Inline assembly on purpose: written with vector types the compiler splits the pair again -- two single conversions and a
+// v_perm_b32 per pack, compare + select per half for the minimum: 5 instructions where 1 is meant.  The operands are VGPRs
+// written by vector-ALU instructions, never straight MFMA results, so no MFMA-to-VALU wait states are involved.)
+__device__ __forceinline__ unsigned pack2_pk(float lo, float hi) {       // pack2 whose result the optimiser must keep as ONE dword
+    unsigned w = pack2(lo, hi);
+    asm("" : "+v"(w));
+    return w;
+}
 __device__ __forceinline__ unsigned relu_pk(unsigned w) {
-    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, w), (s16x2){0, 0}));
+    unsigned r;
+    asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(w));
+    return r;
 }
 __device__ __forceinline__ unsigned pos_pk(unsigned w) {
-    return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(u16x2, w), (u16x2){1, 1}));
+    unsigned r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(w), "s"(0x00010001u));
+    return r;
 }
 __device__ __forceinline__ void s8_mode() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1"); }
 
-__device__ __forceinline__ unsigned pack2(float lo, float hi) {
-    bf16x2 v = {(__bf16)lo, (__bf16)hi};
-    return __builtin_bit_cast(unsigned, v);
-}
 __device__ __forceinline__ float bf_lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
 __device__ __forceinline__ float bf_hi(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
 __device__ __forceinline__ bf16x8 frag(u32x4 x) { return __builtin_bit_cast(bf16x8, x); }
 // scratch blocks are written once and read once by another kernel: stream them past the caches
-__device__ __forceinline__ void store_nt(char* p, u32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p)); }
+__device__ __forceinline__ void store_nt(char* p, u32x4 v) {
+    if (NCA_EXP & 256) *reinterpret_cast<u32x4*>(p) = v;           // (elimination build: plain write-back stores)
+    else __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
+}
 __device__ __forceinline__ u32x4 load_nt(const char* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)); }
 // ReLU as ONE integer max on the bit pattern (negative floats and -0 are negative integers): no canonicalising
 // v_max x,x,x in front as fmaxf would get, and -- unlike an inline-asm v_max_f32 -- visible to the compiler's hazard
@@ -195,6 +216,7 @@ __device__ __forceinline__ void stage_issue_b(const NcaStage& st, char* dst, int
     }
 }
 __device__ __forceinline__ void stage_publish_b() {
+    if (NCA_EXP & 8) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 }
@@ -203,10 +225,15 @@ __device__ __forceinline__ void stage_publish_b() {
 // older) but not for those stores.  The raw barrier avoids the vmcnt(0) a __syncthreads() would add.
 template <int NST>
 __device__ __forceinline__ void stage_publish_counted(bool stores_issued) {
-    if (stores_issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+    if (NCA_EXP & 8) return;
+    if (stores_issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NCA_EXP & 1024) ? NST + 14 : NST) : "memory");       // (1024: wait one stage later -- WRONG results, timing only)
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+#if NCA_EXP & 6144
+    // (elimination builds 2048 / 4096: waves 4-7 -- the SIMD partners of waves 0-3 -- start every stage 4 / 8 x 64 cycles late)
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_sleep((NCA_EXP & 4096) ? 8 : 4);
+#endif
 }
 
 // workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain the wave's global stores / loads
@@ -365,7 +392,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
     if (S8) s8_mode();
 
-    for (int net = 0; net < a.nnets; ++net) {
+    for (int net = 0; RECOMP && net < a.nnets; ++net) {
         const NcaNetArgs& na = a.net[net];
         float* c = cst + net * NCA_CONST_NET_FLOATS;
         if (na.win) for (int i = tid; i < na.lay.L; i += NCA_NT) c[i] = na.win[i];
@@ -455,6 +482,16 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
             char* const mwave = maskbase + (wave * a.mask_layers) * 1024 + lane * 16;
             // stored forward: ReLU masks [wave tile][net][layer][lane][16 B]
             char* const mglob = (FSTORE || STORED) ? a.mstore + ((tg * 2 + net + a.net_base) * a.mstore_layers) * 1024 + lane * 16 : nullptr;
+            // Backward from the store: the ReLU masks of layer L travel HBM -> LDS by LDS-DMA into slot L & 1 of the wave's two
+            // 1 KiB slots (the constant area is idle here: nothing is encoded), one layer ahead of their use and right behind the
+            // weight DMA of a stage, so the stage's counted vmcnt covers them.  (As plain loads into registers they made the
+            // compiler wait for vmcnt(0) at the top of every layer -- loads and stores retire in order, so that waited for all
+            // of the previous layer's D stores: no store ever overlapped the next layer's MFMAs.)
+            char* const mslot = reinterpret_cast<char*>(cst) + wave * 2048;
+            auto mask_dma = [&](int L) __attribute__((always_inline)) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(mglob + L * 1024),
+                                                 (__attribute__((address_space(3))) void*)(mslot + (L & 1) * 1024), 16, 0, 0);
+            };
 
             // ================= encoding, lane = sample ===================================================
             u32x4 B[2][KSMAX];
@@ -587,7 +624,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                         for (int i = 0; i < 16; ++i) v[i] = gc[0] * hv[0][i] + gc[1] * hv[1][i];
                         int cnt = 16;
 #pragma unroll
-                        for (int d = 16; d >= 1; d >>= 1) {
+                        for (int d = (NCA_EXP & 4) ? 0 : 16; d >= 1; d >>= 1) {
                             if (cnt >= 2) {
                                 const int hn = cnt / 2;
                                 const bool up = (lr & d) != 0;
@@ -618,7 +655,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                                 Bn[c][2 * m][u] = pack2(dv[2 * u], dv[2 * u + 1]);
                                 Bn[c][2 * m + 1][u] = pack2(dv[8 + 2 * u], dv[8 + 2 * u + 1]);
                             }
-                            if (S8 && STORED && tvalid && !ONCHIP) {
+                            if (S8 && STORED && tvalid && !ONCHIP && !(NCA_EXP & 1)) {
                                 u32x4 q8;
 #pragma unroll
                                 for (int w = 0; w < 4; ++w) q8[w] = cvt4_e5m2_pk(Bn[c][2 * m + (w >> 1)][2 * (w & 1)], Bn[c][2 * m + (w >> 1)][2 * (w & 1) + 1], inv_s);
@@ -645,6 +682,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                 // the backward from the store recomputes ONE layer, the last: its input is in the store anyway (the wgrad
                 // reads it too), which saves the forward from writing that layer's output and the raw outputs
                 const char* hl = nb + EB + nca_bf_hoff(y, y.NL - 2, a.h8 != 0) + lane * 16;
+                if (y.NL >= 2) mask_dma(y.NL - 2);
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -654,12 +692,12 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
             for (int jj = STORED ? y.NL - 1 : 0; jj < y.NL; ++jj) {
                 const NcaLayerL& l = y.layer[jj];
                 const int nsi = (si + 1 == a.nstages) ? 0 : si + 1;
-                stage_issue_b(a.stage[nsi], smem + (cur ^ 1) * BUF, wave, lane);
+                if (!(NCA_EXP & 8)) stage_issue_b(a.stage[nsi], smem + (cur ^ 1) * BUF, wave, lane);
                 const char* img = smem + cur * BUF;
                 const int nks = l.ksteps;
                 const float* tail = reinterpret_cast<const float*>(img + MT * nks * 1024);
                 const bool last = jj == y.NL - 1;
-                const bool store_h = STORE && tvalid && !last;
+                const bool store_h = STORE && tvalid && !last && !((NCA_EXP & 16) && FSTORE);
                 const bool h8 = S8 && FSTORE && jj < y.NL - 2;                    // this layer's output crosses HBM as e4m3
                 char* const hblk = STORE ? nb + EB + nca_bf_hoff(y, jj, S8 && FSTORE) : nullptr;          // input block of layer jj+1
                 u32x4 Bn[2][2 * MT];
@@ -699,13 +737,13 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                         // round to bf16, then ReLU on the packed pair
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
-                            Bn[0][2 * m][u] = relu_pk(pack2(acc0[2 * u], acc0[2 * u + 1]));
-                            Bn[0][2 * m + 1][u] = relu_pk(pack2(acc0[8 + 2 * u], acc0[8 + 2 * u + 1]));
-                            Bn[1][2 * m][u] = relu_pk(pack2(acc1[2 * u], acc1[2 * u + 1]));
-                            Bn[1][2 * m + 1][u] = relu_pk(pack2(acc1[8 + 2 * u], acc1[8 + 2 * u + 1]));
+                            Bn[0][2 * m][u] = relu_pk(pack2_pk(acc0[2 * u], acc0[2 * u + 1]));
+                            Bn[0][2 * m + 1][u] = relu_pk(pack2_pk(acc0[8 + 2 * u], acc0[8 + 2 * u + 1]));
+                            Bn[1][2 * m][u] = relu_pk(pack2_pk(acc1[2 * u], acc1[2 * u + 1]));
+                            Bn[1][2 * m + 1][u] = relu_pk(pack2_pk(acc1[8 + 2 * u], acc1[8 + 2 * u + 1]));
                         }
                     }
-                    if (STORE && !last) {
+                    if (STORE && !last && !((NCA_EXP & 32) && FSTORE)) {
                         // bit k / 16+k of a field: low / high bf16 of packed word k (k = 4*(fragment&1) + u) is > 0
 #pragma unroll
                         for (int c = 0; c < 2; ++c) {
@@ -722,7 +760,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                         for (int c = 0; c < 2; ++c) {
                             u32x4 q;
 #pragma unroll
-                            for (int w = 0; w < 4; ++w) q[w] = cvt4_e4m3_pk(Bn[c][2 * m + (w >> 1)][2 * (w & 1)], Bn[c][2 * m + (w >> 1)][2 * (w & 1) + 1], DIV);
+                            for (int w = 0; w < 4; ++w) q[w] = (NCA_EXP & 32) ? Bn[c][2 * m + (w >> 1)][2 * (w & 1)] : cvt4_e4m3_pk(Bn[c][2 * m + (w >> 1)][2 * (w & 1)], Bn[c][2 * m + (w >> 1)][2 * (w & 1) + 1], DIV);
                             store_nt(hblk + c * a.rows_total + lane * 16 + m * 1024, q);
                         }
                     } else if (store_h) {
@@ -764,7 +802,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
 
                 if (BWD && last) last_layer_grads(tail + 2 * MT * 16);
 
-                if (ONCHIP && last) {
+                if (ONCHIP && last && !(NCA_EXP & 64)) {
                     // dW_L += D_L * H_{L-1}^T over this workgroup's 8 x 64 samples.  B holds D_L; the layer's input fragments
                     // (consumed by the recompute above) are read once more.  Both are transposed into rows = samples by
                     // identity MFMAs (as the wgrad kernel does) and handed round 16 samples per wave at a time.
@@ -869,13 +907,10 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
 
             // ================= backward sweep (dgrad) =====================================================
             if (BWD) {
-                // masks from the store are requested one layer ahead of their use (a load issued at the top of its own
-                // layer would be needed after one row tile, ~0.25 us later: an exposed HBM latency per layer)
-                u32x4 mnext = {0u, 0u, 0u, 0u};
-                if (STORED && y.NL >= 2) mnext = load_nt(mglob + (y.NL - 2) * 1024);
                 for (int jj = y.NL - 1; jj >= 1; --jj) {
                     const int nsi = (si + 1 == a.nstages) ? 0 : si + 1;
-                    stage_issue_b(a.stage[nsi], smem + (cur ^ 1) * BUF, wave, lane);
+                    if (!(NCA_EXP & 8)) stage_issue_b(a.stage[nsi], smem + (cur ^ 1) * BUF, wave, lane);
+                    if (STORED && jj >= 2) mask_dma(jj - 2);            // for the next iteration; this one's arrived under the previous stage
                     const char* img = smem + cur * BUF;
                     const char* const hblk = nb + EB + (jj - 1) * HB;                       // input of layer jj (mask)
                     char* const dblk = db + nca_bf_doff(y, jj - 1, S8 && STORED);            // D_{jj-1}
@@ -883,10 +918,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                     u32x4 Bn[2][2 * MT];
                     u32x4 mv = {0u, 0u, 0u, 0u};
                     if (lds_mask) mv = *reinterpret_cast<const u32x4*>(mwave + (jj - 1) * 1024);
-                    if (STORED) {
-                        mv = mnext;
-                        if (jj >= 2) mnext = load_nt(mglob + (jj - 2) * 1024);
-                    }
+                    if (STORED) mv = *reinterpret_cast<const u32x4*>(mslot + ((jj - 1) & 1) * 1024 + lane * 16);
                     const bool bits = lds_mask || STORED;         // mask bits at hand (else: re-read the layer input)
                     u32x4 A[RINGK];
                     const char* imgl = img + lane * 16;
@@ -896,11 +928,13 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                         f32x16 acc0, acc1;
 #pragma unroll
                         for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-                        mma_rowtile_ring<KS, MT, KSMAX, RINGK>(imgl, m, A, B, acc0, acc1);
+                        if (!(NCA_EXP & 128)) mma_rowtile_ring<KS, MT, KSMAX, RINGK>(imgl, m, A, B, acc0, acc1);
+                        else { acc0[0] = __builtin_bit_cast(float, B[0][m][0]); acc1[3] = __builtin_bit_cast(float, B[1][m][1]); }
 #pragma unroll
                         for (int c = 0; c < 2; ++c) {
                             const char* hp = hblk + c * a.rows_total + lane * 16;
                             char* dp = dblk + c * a.d_total + lane * 16;
+                            if (NCA_EXP & 8192) dp = a.dscratch + ((blockIdx.x * 8 + wave) * 2 + c) * 4096 + lane * 16;     // (every store of a wave to ONE 8 KiB window)
                             u32x4 q8 = {0u, 0u, 0u, 0u};           // S8: the 16 masked values of this (row tile, column tile) as e5m2 bytes
 #pragma unroll
                             for (int s2 = 0; s2 < 2; ++s2) {
@@ -916,15 +950,16 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                                     const float a0 = c == 0 ? acc0[8 * s2 + 2 * u] : acc1[8 * s2 + 2 * u];
                                     const float a1 = c == 0 ? acc0[8 * s2 + 2 * u + 1] : acc1[8 * s2 + 2 * u + 1];
                                     const unsigned two = bits ? (fld >> (4 * s2 + u)) & 0x00010001u : pos_pk(relu_pk(hw[u]));
-                                    dw[u] = pack2(a0, a1) & (two * 0xffffu);
+                                    dw[u] = (NCA_EXP & 2) ? pack2(a0, a1) : pack2_pk(a0, a1) & (two * 0xffffu);
                                 }
                                 Bn[c][2 * m + s2] = dw;
-                                if (S8 && STORED) {
+                                if ((NCA_EXP & 2) && S8 && STORED) { q8[2 * s2] = dw[0] ^ dw[1]; q8[2 * s2 + 1] = dw[2] ^ dw[3]; }
+                                else if (S8 && STORED) {
                                     q8[2 * s2] = cvt4_e5m2_pk(dw[0], dw[1], inv_s);
                                     q8[2 * s2 + 1] = cvt4_e5m2_pk(dw[2], dw[3], inv_s);
-                                } else if (wr_d) store_nt(dp + (2 * m + s2) * 1024, dw);
+                                } else if (wr_d && !(NCA_EXP & 1)) store_nt(dp + (2 * m + s2) * 1024, dw);
                             }
-                            if (S8 && STORED && wr_d) store_nt(dp + m * 1024, q8);
+                            if (S8 && STORED && wr_d && !(NCA_EXP & 1)) store_nt(dp + m * 1024, q8);
                         }
                     }
 #pragma unroll

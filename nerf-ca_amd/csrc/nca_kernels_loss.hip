@@ -79,7 +79,8 @@ __global__ __launch_bounds__(LOSS_NT) void nca_loss_rays(const NcaLossArgs a) {
         if (a.use_weighting && wr > 1.0 + a.weighted_thresh) mask_d = 1;
         const double diff = a.pix[r] - a.gt[r];
         // ---- gradients ------------------------------------------------------------------------------------
-        if (a.g_pix && lane == 0) a.g_pix[r] = 2.0 * wr * diff * a.inv_R;
+        const double wm = a.unit_mse ? 1.0 : wr;           // (fine pass: unit pixel weights, weighted regularisers)
+        if (a.g_pix && lane == 0) a.g_pix[r] = 2.0 * wm * diff * a.inv_R;
         if (a.g_sig_s) {
             float* gs = a.g_sig_s + r * a.S;
             float* gd = a.g_sig_d + r * a.S;
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(LOSS_NT) void nca_loss_rays(const NcaLossArgs a) {
             }
         }
         if (lane == 0) {
-            part[0] = wr * diff * diff;                 // pixel (sum over rays; scaled by inv_R at the end)
+            part[0] = wm * diff * diff;                 // pixel (sum over rays; scaled by inv_R at the end)
             part[1] = bwsum / (double)a.S;              // mean_s blendw
             part[2] = fav / (double)a.S;                // mean_s entropy
             part[3] = (double)mask_s * -es;

@@ -319,14 +319,15 @@ class _RenderFn(torch.autograd.Function):
         return (None, None, None, None, g_z, g_dists, *out)
 
 
-def fused_losses(pix, gt, wpix, sig_s, sig_d, dists, run_args, weights, inv_R=None, want_grads=True, weights_dev=None):
+def fused_losses(pix, gt, wpix, sig_s, sig_d, dists, run_args, weights, inv_R=None, want_grads=True, weights_dev=None, unit_mse=False):
     """weighted MSE + compute_losses + the loss assembly of run_composite.py:287-292 in one HIP pass.
 
     ``weights`` = (favor_s_weight, dynamic_entro_weight, occl_weight, l1_weight) of this step.
     Returns ``(terms f64[13] on device, g_pix f64[R], g_sigma_s f32[R,S], g_sigma_d f32[R,S])``; see
     ``_capi.TERM_NAMES`` for the order of ``terms``.  ``inv_R`` = 1 / global ray count (default 1/R).
     ``weights_dev`` (device f64[4]) replaces ``weights`` with values the kernels read at run time, which is
-    what a captured HIP graph needs.
+    what a captured HIP graph needs.  ``unit_mse``: the pixel term uses unit weights while the regularisers keep
+    ``wpix`` (the fine pass's ``weighted_pixs_ones``, run_composite.py:296-299).
     """
     lib = _capi.lib()
     _require_cuda(sig_s, "sigma")
@@ -338,7 +339,7 @@ def fused_losses(pix, gt, wpix, sig_s, sig_d, dists, run_args, weights, inv_R=No
     desc = _capi.NcaLoss(R=R, S=S, use_weighting=1 if run_args.entro_use_weighting else 0, skew=float(run_args.skewness_val),
                          mask_thre=float(run_args.entro_mask_thre), weighted_thresh=float(run_args.entro_weighted_thresh),
                          w_favor=float(weights[0]), w_dent=float(weights[1]), w_occl=float(weights[2]), w_l1=float(weights[3]),
-                         inv_R=float(inv_R if inv_R is not None else 1.0 / R), weights_dev=None)
+                         inv_R=float(inv_R if inv_R is not None else 1.0 / R), weights_dev=None, unit_mse=1 if unit_mse else 0, reserved=0)
     if weights_dev is not None:
         if weights_dev.dtype != torch.float64 or weights_dev.numel() != 4 or not weights_dev.is_cuda or not weights_dev.is_contiguous():
             raise _capi.NcaError("weights_dev must be a contiguous device f64[4]")
@@ -389,54 +390,70 @@ def fine_depths(sig_s: torch.Tensor, sig_d: Optional[torch.Tensor], z: torch.Ten
     return out
 
 
+def fine_depths_forward(sig_s, sig_d, z, u, reduce_max=None):
+    """The HIP sampler in its two-stage form (so that the maximum it sampled with is at hand): returns
+    ``(z_all f32[R, S + n_fine], saved)``; ``saved`` is what ``fine_depths_backward`` needs."""
+    dev = sig_s.device
+    R, S = sig_s.shape
+    ss, sd = _f32c(sig_s), (_f32c(sig_d) if sig_d is not None else None)
+    zz = z.detach().to(device=dev, dtype=torch.float32).contiguous()
+    uu = u.detach().to(device=dev, dtype=torch.float32).contiguous()
+    n_fine = uu.shape[1]
+    out = torch.empty((R, S + n_fine), dtype=torch.float32, device=dev)
+    lib = _capi.lib()
+    wbytes = check(lib.nca_fine_depths_workspace(R))
+    work = torch.empty(wbytes, dtype=torch.uint8, device=dev)
+    wmax = torch.zeros(1, dtype=torch.float32, device=dev)
+    check(lib.nca_fine_weight_max(R, S, ptr(ss), ptr(sd), ptr(wmax), ptr(work), wbytes, _stream()))
+    if reduce_max is not None:
+        reduce_max(wmax)
+    check(lib.nca_fine_depths_given_max(R, S, n_fine, ptr(ss), ptr(sd), ptr(zz), ptr(uu), ptr(wmax), ptr(out), _stream()))
+    return out, (ss, sd, zz, uu, wmax)
+
+
+def fine_depths_backward(saved, g_zall, reduce_sum=None):
+    """d loss / d (sigma_s + sigma_d) f32[R, S] of the coarse fields from d loss / d z_all (the reference keeps the sampled
+    depths in its autograd graph, model_helpers.py:135-146): nca_fine_depths_bwd / _bwd_max.  ``reduce_sum`` (in-place
+    all-reduce SUM) under ray sharding: d loss / d maximum and the number of elements that attain it are sums over the rays
+    of ALL ranks."""
+    ss, sd, zz, uu, wmax = saved
+    dev = ss.device
+    R, S = ss.shape
+    n_fine = uu.shape[1]
+    lib = _capi.lib()
+    g = g_zall.detach().to(torch.float32).contiguous()
+    g_tot = torch.empty((R, S), dtype=torch.float32, device=dev)
+    part = torch.empty((2, R), dtype=torch.float32, device=dev)
+    check(lib.nca_fine_depths_bwd(R, S, n_fine, ptr(ss), ptr(sd), ptr(zz), ptr(uu), ptr(wmax), ptr(g), ptr(g_tot), ptr(part[0]), ptr(part[1]), _stream()))
+    tot = part.double().sum(1)                         # [d loss / d wmax, number of jumps that attain it] of this rank
+    # the leading 1e-10 of every ray's weight vector ties with the maximum only if no jump exceeds it
+    tot[1] += float(R) * (wmax[0] == 1e-10).double()
+    if reduce_sum is not None:
+        reduce_sum(tot)
+    each = (tot[0] / tot[1].clamp(min=1.0)).to(torch.float32).reshape(1).contiguous()
+    check(lib.nca_fine_depths_bwd_max(R, S, ptr(ss), ptr(sd), ptr(wmax), ptr(each), ptr(g_tot), _stream()))
+    return g_tot
+
+
 class _FineDepthsFn(torch.autograd.Function):
     """z_all = fine_depths(sigma_s, sigma_d; z, u) with the reference's gradient (it leaves the sampled depths in the autograd
-    graph, model_helpers.py:135-146): forward = the HIP sampler (always through the two-stage form, so that the maximum it
-    sampled with is at hand), backward = nca_fine_depths_bwd / _bwd_max.  ``reduce_max`` as in ``fine_depths``; for the
-    backward it should also have a ``sum`` attribute (all-reduce SUM in place): d loss / d maximum and the number of elements
-    that attain it are sums over the rays of ALL ranks."""
+    graph, model_helpers.py:135-146): ``fine_depths_forward`` / ``fine_depths_backward``.  ``reduce_max`` as in
+    ``fine_depths``; for the backward it must also have a ``sum`` attribute (all-reduce SUM in place)."""
 
     @staticmethod
     def forward(ctx, sig_s, sig_d, z, u, reduce_max):
-        dev = sig_s.device
-        R, S = sig_s.shape
-        ss, sd = _f32c(sig_s), (_f32c(sig_d) if sig_d is not None else None)
-        zz = z.detach().to(device=dev, dtype=torch.float32).contiguous()
-        uu = u.detach().to(device=dev, dtype=torch.float32).contiguous()
-        n_fine = uu.shape[1]
-        out = torch.empty((R, S + n_fine), dtype=torch.float32, device=dev)
-        lib = _capi.lib()
-        wbytes = check(lib.nca_fine_depths_workspace(R))
-        work = torch.empty(wbytes, dtype=torch.uint8, device=dev)
-        wmax = torch.zeros(1, dtype=torch.float32, device=dev)
-        check(lib.nca_fine_weight_max(R, S, ptr(ss), ptr(sd), ptr(wmax), ptr(work), wbytes, _stream()))
-        if reduce_max is not None:
-            reduce_max(wmax)
-        check(lib.nca_fine_depths_given_max(R, S, n_fine, ptr(ss), ptr(sd), ptr(zz), ptr(uu), ptr(wmax), ptr(out), _stream()))
-        ctx.keep = (ss, sd, zz, uu, wmax)
+        if reduce_max is not None and getattr(reduce_max, "sum", None) is None and (sig_s.requires_grad or (sig_d is not None and sig_d.requires_grad)):
+            raise _capi.NcaError("depth gradients under ray sharding need a reducer with a `sum` method (all-reduce SUM): the backward of the "
+                                 "batch-wide maximum adds over the ranks")
+        out, ctx.keep = fine_depths_forward(sig_s, sig_d, z, u, reduce_max)
         ctx.reduce_max = reduce_max
         ctx.has_d = sig_d is not None
         return out
 
     @staticmethod
     def backward(ctx, g_zall):
-        ss, sd, zz, uu, wmax = ctx.keep
-        dev = ss.device
-        R, S = ss.shape
-        n_fine = uu.shape[1]
-        lib = _capi.lib()
-        g = g_zall.detach().to(torch.float32).contiguous()
-        g_tot = torch.empty((R, S), dtype=torch.float32, device=dev)
-        part = torch.empty((2, R), dtype=torch.float32, device=dev)
-        check(lib.nca_fine_depths_bwd(R, S, n_fine, ptr(ss), ptr(sd), ptr(zz), ptr(uu), ptr(wmax), ptr(g), ptr(g_tot), ptr(part[0]), ptr(part[1]), _stream()))
-        tot = part.double().sum(1)                         # [d loss / d wmax, number of jumps that attain it] of this rank
-        # the leading 1e-10 of every ray's weight vector ties with the maximum only if no jump exceeds it
-        tot[1] += float(R) * (wmax[0] == 1e-10).double()
         red = getattr(ctx.reduce_max, "sum", None) if ctx.reduce_max is not None else None
-        if red is not None:
-            red(tot)
-        each = (tot[0] / tot[1].clamp(min=1.0)).to(torch.float32).reshape(1).contiguous()
-        check(lib.nca_fine_depths_bwd_max(R, S, ptr(ss), ptr(sd), ptr(wmax), ptr(each), ptr(g_tot), _stream()))
+        g_tot = fine_depths_backward(ctx.keep, g_zall, red)
         return g_tot, (g_tot if ctx.has_d else None), None, None, None
 
 

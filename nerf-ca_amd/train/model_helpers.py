@@ -130,13 +130,17 @@ class _BatchMax(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         w, glob = ctx.saved_tensors
-        g = g.detach().clone().reshape(1)
-        if ctx.reduce_max is not None and getattr(ctx.reduce_max, "sum", None) is not None:
-            ctx.reduce_max.sum(g)
         hit = (w == glob)
-        n = hit.sum()
-        gw = torch.where(hit, g / n.clamp(min=1).to(g.dtype), torch.zeros_like(g)).to(w.dtype) if bool(n > 0) else torch.zeros_like(w)
-        return gw, None
+        # [upstream gradient, number of elements that attain the maximum]: both are sums over the rays of ALL ranks (torch.max
+        # hands its gradient evenly to ties, wherever they sit)
+        both = torch.stack([g.detach().reshape(()).to(torch.float64), hit.sum().to(torch.float64)])
+        if ctx.reduce_max is not None:
+            red = getattr(ctx.reduce_max, "sum", None)
+            if red is None:
+                raise RuntimeError("the backward of a ray-sharded batch maximum needs a reducer with a `sum` method (all-reduce SUM in place)")
+            red(both)
+        each = (both[0] / both[1].clamp(min=1.0)).to(w.dtype)
+        return torch.where(hit, each, torch.zeros((), dtype=w.dtype, device=w.device)), None
 
 
 def obtain_train_predictions_iter(static_model_coarse, temp_model_coarse, static_model_fine, temp_model_fine, batch_origins,

@@ -101,7 +101,8 @@ class CompositeTrainer:
         on_cuda = device.type == "cuda" if isinstance(device, torch.device) else str(device).startswith("cuda")
         if fused_loss is None:             # default on the GPU: the autograd-free step with the HIP loss kernel (step_fused);
             fused_loss = on_cuda           # fused_loss=False keeps the reference's torch loss functions under autograd
-        self.fused_loss = bool(fused_loss) and render is None and self.n_fine == 0   # the fine pass runs under autograd (step)
+        self.fused_loss = bool(fused_loss) and render is None
+        self.stop_flag = None              # device bool: the reference's early-stop predicate of the last step (see early_stop)
         self.always_allreduce = False      # all-reduce even with one rank (exercises the collective path)
         self._dev_gen = None
         self.render = render or MH._fused.render_rays
@@ -248,14 +249,17 @@ class CompositeTrainer:
             self.allreduce_grads()
         self.opt.step()
         self.sched.step()
+        share = 1.0 / self.world if self.world > 1 else 1.0             # (local means: equal slices)
+        self._note_early_stop(n_iter, d_entropy=terms[6] * share, favor=terms[3] * share)
         return loss.detach(), pixel.detach(), terms
 
     def step_fused(self, n_iter: int):
         """Same step without an autograd graph: fused forward -> fused loss kernel (values + d loss/d(pix,
         sigma)) -> fused backward -> (all-reduce) -> Adam.  Returns (loss, pixel, terms f64[13]) on device;
-        the entries of ``terms`` are this rank's share of the global value (they sum over ranks)."""
+        the entries of ``terms`` are this rank's share of the global value (they sum over ranks).  With a fine model
+        pair (``depth_samples_per_ray_fine > 0``) see ``_step_fused_fine``."""
         if self.n_fine > 0:
-            raise NotImplementedError("step_fused covers the coarse pass only; use step() with depth_samples_per_ray_fine > 0")
+            return self._step_fused_fine(n_iter)
         from ..fused import _RayBatch, fused_losses, render_backward_raw, render_forward_raw
         c = self.cfg
         self.update_windows(n_iter)
@@ -305,7 +309,116 @@ class CompositeTrainer:
             p.grad = g
         self.opt.step()
         self.sched.step()
+        self._note_early_stop(n_iter, terms)
         return terms[0], terms[1], terms
+
+    def _step_fused_fine(self, n_iter: int):
+        """The hierarchical step of run_composite.py:283-308 without an autograd graph: coarse forward -> coarse loss kernel ->
+        HIP sampler (batch-wide maximum all-reduced under sharding) -> fine forward on the merged depths with ray 0's interval
+        lengths -> loss kernel with unit pixel weights and weighted regularisers (:296-299) -> fine backward (+ d loss / d depth)
+        -> sampler backward into the coarse densities (the reference does not detach the sampled depths, model_helpers.py:135-146;
+        ``fine_depth_gradients=False`` skips this) -> coarse backward -> one all-reduce -> Adam over the four nets.
+        Returns (loss, coarse pixel loss, coarse terms + fine terms); ``self.last_fine_terms`` keeps the fine pass's own."""
+        from .. import fused as FU
+        from ..fused import _RayBatch, fused_losses, render_backward_raw, render_forward_raw
+        c, dev = self.cfg, self.device
+        self.update_windows(n_iter)
+        ids = self.draw_ray_ids_device(n_iter)
+        R = ids.shape[0]
+        lo, hi = (R * self.rank) // self.world, (R * (self.rank + 1)) // self.world
+        my = ids[lo:hi]
+        n_loc = hi - lo
+        rays = self.data.rays_train.index_select(0, my)
+        phases = self.data.phases_train.index_select(0, my)
+        o, d, gt, w = rays[:, 0, :], rays[:, 1, :], rays[:, 2, 0], rays[:, 3, 0]
+        z = MH.randomize_depth(self.depth, dev, self.draw_jitter(n_iter))
+        dists = MH._interval_lengths(z, d)
+        bs, bd, bsf, bdf = self.s._binding, self.t._binding, self.s_fine._binding, self.t_fine._binding
+        weights = self.loss_weights(n_iter)
+        fav_w, ent_w, occ_w, l1_w = weights
+        sharded = self.world > 1
+        red = _MaxReducer() if sharded else None
+        depth_grads = c.fine_depth_gradients is None or c.fine_depth_gradients
+        I0 = self.I0[:n_loc]
+        # coarse pass (the whole local batch: the sampler normalises by the batch-wide maximum)
+        batch = _RayBatch(o, d, phases, I0, z, dists, c.output_activation, False, 1e-2)
+        pix, sig_s, sig_d, keep = render_forward_raw(batch, bs, bd, for_backward=True)
+        terms, g_pix, g_s, g_d = fused_losses(pix, gt, w, sig_s, sig_d, dists, c, weights, inv_R=1.0 / R)
+        # fine depths
+        u = self.draw_fine_u(n_iter)[lo:hi].to(dev)
+        z_all, saved = FU.fine_depths_forward(sig_s, sig_d, z, u, red)
+        z0 = z_all[0, :].clone()
+        if sharded:
+            dist.broadcast(z0, src=0)                                     # ray 0 of the GLOBAL batch (model_helpers.py:150)
+        dists_f = MH._interval_lengths(z0, d)
+        batch_f = _RayBatch(o, d, phases, I0, z_all, dists_f, c.output_activation, False, 1e-2)
+        pix_f, sig_sf, sig_df, keep_f = render_forward_raw(batch_f, bsf, bdf, for_backward=True)
+        terms_f, g_pix_f, g_sf, g_df = fused_losses(pix_f, gt, w, sig_sf, sig_df, dists_f, c, weights, inv_R=1.0 / R, unit_mse=True)
+        res = render_backward_raw(batch_f, bsf, bdf, keep_f, g_pix_f, g_sf, g_df, want_depth_grad=depth_grads)
+        grads_sf, grads_df = res[0], res[1]
+        del keep_f
+        if depth_grads:
+            g_zall = res[2]
+            # d loss / d (ray 0's interval lengths): through the ray sums (pix = I0 - sum sigma dists) and through the regularisers
+            # (entropies, occlusion, l1 / l2 all contain sigma * dists; small torch ops on [r, S] tensors, autograd on dists only)
+            g_dists = -(g_pix_f[:, None] * (sig_sf + sig_df).double()).sum(0)
+            dv = dists_f.detach().clone().requires_grad_(True)
+            with torch.enable_grad():
+                tf = LS.all_terms(sig_sf, sig_df, dv, w, c)
+                share = n_loc / R
+                reg = (fav_w * tf[3] + ent_w * tf[6] + occ_w * tf[8]) * share + l1_w * tf[10] + l1_w * tf[9]
+                (g_reg,) = torch.autograd.grad(reg, dv)
+            g_dists = g_dists + g_reg.to(g_dists.dtype)
+            g_z0 = torch.zeros_like(z0, dtype=torch.float64)               # dists = cat(z0[1:] - z0[:-1], [1e-10])
+            g_z0[1:] += g_dists[:-1]
+            g_z0[:-1] -= g_dists[:-1]
+            if sharded:
+                dist.all_reduce(g_z0, op=dist.ReduceOp.SUM)
+            if self.rank == 0:
+                g_zall[0, :] += g_z0.to(g_zall.dtype)
+            g_tot = FU.fine_depths_backward(saved, g_zall, _MaxReducer.sum if sharded else None)
+            g_s = g_s + g_tot
+            g_d = g_d + g_tot
+        grads_s, grads_d = render_backward_raw(batch, bs, bd, keep, g_pix, g_s, g_d)
+        del keep
+        order = [(self.t, bd, grads_d), (self.s, bs, grads_s), (self.t_fine, bdf, grads_df), (self.s_fine, bsf, grads_sf)]   # self.params order
+        if sharded or self.always_allreduce:
+            flat = torch.cat([g for _, _, g in order])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            off = 0
+            for i, (m, b, g) in enumerate(order):
+                order[i] = (m, b, flat[off:off + g.numel()])
+                off += g.numel()
+        for m, b, g in order:
+            for p, gr in zip(m.parameters(), b.split_grads(g)):
+                p.grad = gr
+        self.opt.step()
+        self.sched.step()
+        self.last_fine_terms = terms_f
+        total = terms.clone()
+        total[0] = terms[0] + terms_f[0]                                   # loss += the fine pass's assembled loss (:301)
+        self._note_early_stop(n_iter, terms_f)
+        return total[0], terms[1], total
+
+    # -- early stop (run_composite.py:310-312) ---------------------------------------------------
+    def _note_early_stop(self, n_iter: int, terms=None, d_entropy=None, favor=None) -> None:
+        """The reference breaks its loop when ``dynamic_entropy_loss < 1e-15 or favor_s_loss < 1e-15`` once the frequency windows
+        are fully open (the fine pass's terms when there is one).  Evaluated on the device into ``self.stop_flag`` without a
+        host sync, and only from ``static_pos_enc_window_decay_steps`` on; under ray sharding the two scalars are summed over
+        the ranks first, so that every rank sees the same flag."""
+        if n_iter < self.cfg.static_pos_enc_window_decay_steps:
+            self.stop_flag = None
+            return
+        if terms is not None:
+            d_entropy, favor = terms[8], terms[5]           # (nca_loss_fwd_bwd order: this rank's share of the global means)
+        two = torch.stack([d_entropy.detach().double().reshape(()), favor.detach().double().reshape(())])
+        if self.world > 1:
+            dist.all_reduce(two, op=dist.ReduceOp.SUM)
+        self.stop_flag = (two < 1e-15).any()
+
+    def early_stop(self) -> bool:
+        """Host-side read of the flag (one device sync): call it at the logging cadence, not every step."""
+        return bool(self.stop_flag) if self.stop_flag is not None else False
 
     # -- the same step as a replayed HIP graph ---------------------------------------------------
     def _graph_setup(self) -> None:
@@ -427,6 +540,7 @@ class CompositeTrainer:
                 dist.all_reduce(self._graph_out["flat"], op=dist.ReduceOp.SUM)
             self._graphs[1].replay()
         terms = self._graph_out["terms"]
+        self._note_early_stop(n_iter, terms)
         return terms[0], terms[1], terms
 
     def allreduce_grads(self) -> None:

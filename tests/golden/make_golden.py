@@ -364,6 +364,65 @@ def gen_full_step():
 
 
 
+# ----------------------------------------------------------------------------------- (7-fine)
+def gen_full_step_fine():
+    """Three iterations of run_composite.py's loop body WITH the hierarchical pass (depth_samples_per_ray_fine > 0, :283-308):
+    four nets in one optimiser (:192, :207), fine pixel loss with unit weights, fine regularisers with the pixel weights
+    (:294-301).  The reference does not detach the sampled depths, so the coarse nets' gradients contain the through-depth term."""
+    out = {}
+    R, S, NF = 32, 40, 16
+    s, t, sf, tf = build_models(7300, F=64, Ff=32)
+    out.update(sd(s, "init_sp_")); out.update(sd(t, "init_dp_")); out.update(sd(sf, "init_sfp_")); out.update(sd(tf, "init_dfp_"))
+    plist = list(t.parameters()) + list(s.parameters()) + list(tf.parameters()) + list(sf.parameters())
+    opt = torch.optim.Adam([{"params": plist, "lr": 1e-3}], lr=1e-3)
+    sched = torch.optim.lr_scheduler.LinearLR(opt, start_factor=1, end_factor=0.01, total_iters=150000)
+    o, d, ph = sample_rays(R, np.float64, 73)
+    rng = np.random.default_rng(74)
+    gt = torch.from_numpy(rng.uniform(0.5, 2.0, R))
+    wpix = torch.from_numpy(1 + rng.uniform(0, 1, R))
+    ones = torch.ones_like(wpix)
+    z = DH.create_depth_values(3.4259, 5.5741, S, DEV)
+    I0 = torch.full((R,), float(np.log(8.670397)))
+    phs = ph[:, None].repeat(1, S)
+    out["o"], out["d"], out["ph"], out["gt"], out["wpix"], out["z"], out["I0"] = o, d, ph, gt, wpix, z, I0
+    args = loss_args()
+    base_iter = 50000
+    for k in range(3):
+        n_iter = base_iter + k
+        for m in (s, t, sf, tf):
+            m.update_freq_mask_alpha(n_iter, 150000)
+        fw = MH.linear_param_decay(n_iter, 1e-12, 1e-10, 100000, delay_steps=40000)
+        ew = MH.linear_param_decay(n_iter, 1e-10, 1e-8, 100000)
+        ow = MH.linear_param_decay(n_iter, 1e-8, 1e-4, 100000, delay_steps=40000)
+        lw = MH.linear_param_decay(n_iter, 1e-8, 1e-15, 100000)
+        seed = 7400 + k
+        torch.manual_seed(seed)
+        res = MH.obtain_train_predictions_iter(s, t, sf, tf, o, d, phs, I0, z, "softplus", 32768, NF, DEV)
+        torch.manual_seed(seed)
+        out[f"step{k}_t_rand"] = torch.rand(z.shape)
+        out[f"step{k}_u"] = torch.rand([R, NF])
+        pix, sig_s, sig_d, dists, pix_f, sig_sf, sig_df, dists_f = res
+        pixel = MH.weighted_MSELoss()(pix, gt, wpix).mean()
+        L = MH.compute_losses(sig_s, sig_d, dists, wpix, args)
+        loss = pixel + fw * L[3] + ew * L[6] + ow * L[8] + lw * L[10] + lw * L[9]
+        pixel_f = MH.weighted_MSELoss()(pix_f, gt, ones).mean()
+        Lf = MH.compute_losses(sig_sf, sig_df, dists_f, wpix, args)
+        loss = loss + pixel_f + fw * Lf[3] + ew * Lf[6] + ow * Lf[8] + lw * Lf[10] + lw * Lf[9]
+        opt.zero_grad()
+        loss.backward()
+        out[f"step{k}_loss"], out[f"step{k}_pixel"], out[f"step{k}_pixel_f"] = loss, pixel, pixel_f
+        out[f"step{k}_pix"], out[f"step{k}_pix_f"] = pix, pix_f
+        if k == 0:
+            out.update(grads(s, "step0_sg_")); out.update(grads(t, "step0_dg_"))
+            out.update(grads(sf, "step0_sfg_")); out.update(grads(tf, "step0_dfg_"))
+        opt.step()
+        sched.step()
+    out.update(sd(s, "final_sp_")); out.update(sd(t, "final_dp_")); out.update(sd(sf, "final_sfp_")); out.update(sd(tf, "final_dfp_"))
+    out["base_iter"] = np.array(base_iter)
+    out["n_fine"] = np.array(NF)
+    npz("full_step_fine", **out)
+
+
 # ----------------------------------------------------------------------------------- (7b)
 def gen_static_step():
     """Three iterations of the body of train/run_nerf.py:186-231 (BASELINE configs[0]: static CPPN, 64 samples per
@@ -499,6 +558,6 @@ def gen_checkpoint_keys():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["posenc", "mlps", "depth", "predict_iter", "render", "losses", "full_step", "static_step", "geometry", "schedules", "checkpoint_keys"]
+    which = sys.argv[1:] or ["posenc", "mlps", "depth", "predict_iter", "render", "losses", "full_step", "full_step_fine", "static_step", "geometry", "schedules", "checkpoint_keys"]
     for w in which:
         globals()["gen_" + w]()

@@ -331,3 +331,32 @@ def test_param_names_match_state_dict(golden):
     assert [str(shp[k]) for k in O.param_names(spec_from(128, 4, 2))] == list(g.np("static_late2_shapes"))
     shp = O.param_shapes(spec_from(128, 4, 0, T=8))
     assert [str(shp[k]) for k in O.param_names(spec_from(128, 4, 0, T=8))] == list(g.np("temporal_shapes"))
+
+
+def test_fine_training_step_loss_and_gradients(golden):
+    """Step 0 of the reference's hierarchical loop (tests/golden/full_step_fine.npz: coarse + fine nets, fine pixel loss with
+    unit weights, fine regularisers with the pixel weights, run_composite.py:283-306): the oracle's loss and the gradients
+    of all four nets -- the coarse nets' contain the term through the sampled depths, which the reference does not detach."""
+    g = golden("full_step_fine")
+    nf = int(g["n_fine"])
+    ss, sd = O.NetSpec(num_filters=64), O.NetSpec(num_filters=64, num_time_dim=8)
+    sfs, sfd = O.NetSpec(num_filters=32), O.NetSpec(num_filters=32, num_time_dim=8)
+    P = {k: {n: v.clone().requires_grad_(True) for n, v in g.prefixed(f"init_{k}_").items()} for k in ("sp", "dp", "sfp", "dfp")}
+    n_iter = int(g["base_iter"])
+    win = O.freq_mask_alpha(12, n_iter, 150000, 1)[0]
+    S = g["z"].shape[0]
+    zj = O.stratified_depths(g["z"], g["step0_t_rand"])
+    fine = dict(ps=P["sfp"], spec_s=sfs, win_s=win, pd=P["dfp"], spec_d=sfd, win_d=win, n_fine=nf, u=g["step0_u"])
+    pix, a, b, dists, pix_f, af, bf, dists_f = O.predict_iter(P["sp"], ss, win, P["dp"], sd, win, g["o"], g["d"], g["ph"][:, None].repeat(1, S),
+                                                              g["I0"], zj, fine=fine)
+    la, sa = O.LossArgs(), O.ScheduleArgs()
+    loss_c, pixel, _ = O.composite_total_loss(pix, a, b, dists, g["gt"], g["wpix"], n_iter, la, sa)
+    pixel_f = O.weighted_mse(pix_f, g["gt"], torch.ones_like(g["wpix"])).mean()
+    tf = O.compute_losses(af, bf, dists_f, g["wpix"], la)
+    fw, ew, ow, lw = O.loss_weights(n_iter, sa)
+    loss = loss_c + pixel_f + fw * tf[3] + ew * tf[6] + ow * tf[8] + lw * tf[10] + lw * tf[9]
+    loss.backward()
+    assert rel_err(loss, g["step0_loss"]) < 1e-6 and rel_err(pixel, g["step0_pixel"]) < 1e-6 and rel_err(pixel_f, g["step0_pixel_f"]) < 1e-6
+    for key, pre in (("sp", "step0_sg_"), ("dp", "step0_dg_"), ("sfp", "step0_sfg_"), ("dfp", "step0_dfg_")):
+        for n, ref in g.prefixed(pre).items():
+            assert rel_err(P[key][n].grad, ref) < 2e-4, (key, n, rel_err(P[key][n].grad, ref))

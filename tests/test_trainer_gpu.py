@@ -1,0 +1,150 @@
+"""GPU tests of CompositeTrainer's step functions against the reference's own trajectories and of its device-side ray
+sampler.  The hierarchical loop (run_composite.py:283-312) is checked through BOTH step functions -- the autograd step
+(`fused_loss=False`: torch loss functions on the HIP render) and the graph-free fused step (`step_fused`: HIP loss kernel,
+HIP sampler and its HIP backward, manual chain rule through ray 0's interval lengths) -- on tests/golden/full_step_fine.npz.
+"""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from test_hip_parity import make_dynamic, make_static
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def _golden_data(g, dev):
+    """The golden batch as a ray table (train/data_helpers.py:141-165 layout: origin, direction, pixel x3, weight x3)."""
+    o, d, gt, w = g["o"], g["d"], g["gt"], g["wpix"]
+    table = torch.stack([o, d, gt[:, None].repeat(1, 3), w[:, None].repeat(1, 3)], 1).double()
+    geo = dict(near_thresh=3.4259, far_thresh=5.5741, max_pixel_value=float(g["I0"][0]))
+    return SimpleNamespace(geo=geo, rays_train=table.to(dev), phases_train=g["ph"].to(dev), var_ray_ids=np.zeros(0, dtype=np.int64),
+                           non_var_ray_ids=np.arange(o.shape[0]))
+
+
+@pytest.mark.parametrize("fused_loss", [True, False])
+def test_fine_training_steps_vs_reference(golden, dev, fused_loss):
+    """Three steps of the hierarchical loop on the reference's own inputs, weights and random draws: per-step loss and pixel
+    losses (1e-5), step-0 gradients of all four nets (fine nets 3e-4: the sampled depths carry the f32 rounding of an inverse
+    CDF that divides by increments as small as 1e-5; coarse nets 1e-3: they include the through-depth term, ~1e4 times their
+    regular gradient and ill-conditioned through the sampler, see test_trainer_with_fine_pass_vs_oracle), parameters after
+    three Adam + LinearLR steps."""
+    from nerfca_amd.train.trainer import CompositeTrainer, TrainConfig
+    g = golden("full_step_fine")
+    R, S, NF = g["o"].shape[0], g["z"].shape[0], int(g["n_fine"])
+    s = make_static(g.prefixed("init_sp_"), dev, F=64, early=4, late=0)
+    t = make_dynamic(g.prefixed("init_dp_"), dev, F=64, early=4, late=0, T=8)
+    sf = make_static(g.prefixed("init_sfp_"), dev, F=32, early=4, late=0)
+    tf = make_dynamic(g.prefixed("init_dfp_"), dev, F=32, early=4, late=0, T=8)
+    cfg = TrainConfig(depth_samples_per_ray_coarse=S, depth_samples_per_ray_fine=NF, img_sample_size=R)
+    tr = CompositeTrainer(cfg, s, t, _golden_data(g, dev), dev, seed=0, fused_loss=fused_loss, static_model_fine=sf, temp_model_fine=tf)
+    assert torch.equal(tr.depth.cpu(), g["z"])
+    base = int(g["base_iter"])
+    # the reference's batch and draws instead of the trainer's own
+    tr.draw_ray_ids_device = lambda n_iter: torch.arange(R, device=dev)
+    tr.draw_jitter = lambda n_iter: g[f"step{n_iter - base}_t_rand"]
+    tr.draw_fine_u = lambda n_iter: g[f"step{n_iter - base}_u"]
+    for k in range(3):
+        loss, pixel, terms = tr.step(base + k)
+        assert rel_err(loss.detach().cpu(), g[f"step{k}_loss"]) < 1e-5, k
+        assert rel_err(pixel.detach().cpu(), g[f"step{k}_pixel"]) < 1e-5, k
+        if fused_loss:
+            assert rel_err(tr.last_fine_terms[1].cpu(), g[f"step{k}_pixel_f"]) < 1e-5, k
+        if k == 0:
+            for m, pre, tol in ((s, "step0_sg_", 1e-3), (t, "step0_dg_", 1e-3), (sf, "step0_sfg_", 3e-4), (tf, "step0_dfg_", 3e-4)):
+                got = {n: p.grad.detach().cpu() for n, p in m.named_parameters()}
+                for n, ref in g.prefixed(pre).items():
+                    assert rel_err(got[n], ref) < tol, (pre, n, rel_err(got[n], ref))
+    for m, pre in ((s, "final_sp_"), (t, "final_dp_"), (sf, "final_sfp_"), (tf, "final_dfp_")):
+        for n, ref in g.prefixed(pre).items():
+            assert rel_err(m.state_dict()[n].cpu(), ref) < 2e-3, (pre, n)
+
+
+def test_fused_fine_step_equals_autograd_fine_step(dev):
+    """The two step functions on the trainer's own batches (synthetic data, F = 64 / 32, 3 steps), with and without the
+    through-depth gradient: same losses, same parameters after the optimiser steps."""
+    from nerfca_amd import synthetic
+    from nerfca_amd.model.CPPN import CPPN
+    from nerfca_amd.model.Temporal import Temporal
+    from nerfca_amd.train.trainer import CompositeTrainer, TrainConfig
+    data = synthetic.make_dataset(16, 48, dev, views=synthetic.TRAIN_VIEWS[:2], n_phases=3, F=32)
+    for dg in (True, False):
+        outs = []
+        for fused in (False, True):
+            torch.manual_seed(9)
+            sdef, tdef = synthetic.net_definitions(dev, F=64)
+            fsd, ftd = synthetic.net_definitions(dev, F=32)
+            nets = [CPPN(sdef).to(dev), Temporal(tdef).to(dev), CPPN(fsd).to(dev), Temporal(ftd).to(dev)]
+            cfg = TrainConfig(depth_samples_per_ray_coarse=48, depth_samples_per_ray_fine=16, img_sample_size=256, favor_s_weight_delay_steps=0,
+                              l1_weight_start=1e-3, l1_weight_end=1e-3, occl_weight_start=1e-2, dynamic_entro_weight_start=1e-3,
+                              favor_s_weight_start=1e-3, entro_mask_thre=1e-6, fine_depth_gradients=dg)
+            tr = CompositeTrainer(cfg, nets[0], nets[1], data, dev, seed=5, fused_loss=fused, static_model_fine=nets[2], temp_model_fine=nets[3])
+            losses = [float(tr.step(1000 + it)[0]) for it in range(3)]
+            outs.append((losses, torch.cat([p.detach().flatten() for p in tr.params]).cpu()))
+        for a, b in zip(outs[0][0], outs[1][0]):
+            assert abs(a - b) <= 2e-5 * abs(a), (dg, outs[0][0], outs[1][0])
+        assert rel_err(outs[1][1], outs[0][1]) < 2e-3, dg
+
+
+def test_device_ray_sampler_counts_and_determinism(dev):
+    """draw_ray_ids_device (run_composite.py:250-260 drawn on the GPU): img_sample_size ids, exactly
+    int(var_sample_perc / 100 * img_sample_size) of them from the high-variance table and the rest from its complement (both
+    with replacement), shuffled; the same seed and iteration give the same ids (every rank draws the same global batch),
+    another iteration different ones; var_sample_perc == 0 draws uniformly over all rays."""
+    from nerfca_amd.train.trainer import CompositeTrainer, TrainConfig
+    n_rays = 5000
+    rng = np.random.default_rng(0)
+    var = np.sort(rng.choice(n_rays, 700, replace=False))
+    non = np.setdiff1d(np.arange(n_rays), var)
+    data = SimpleNamespace(geo=dict(near_thresh=3.4, far_thresh=5.6, max_pixel_value=2.0), rays_train=torch.zeros(n_rays, 4, 3, dtype=torch.float64, device=dev),
+                           phases_train=torch.zeros(n_rays, dtype=torch.int64, device=dev), var_ray_ids=var, non_var_ray_ids=non)
+    dummy = SimpleNamespace(parameters=lambda: iter([torch.nn.Parameter(torch.zeros(1, device=dev))]))
+    for perc in (50, 12.5, 0):
+        cfg = TrainConfig(depth_samples_per_ray_coarse=8, img_sample_size=1024, var_sample_perc=perc)
+        tr = CompositeTrainer(cfg, dummy, dummy, data, dev, seed=3, fused_loss=False)
+        ids = tr.draw_ray_ids_device(17)
+        assert ids.shape == (1024,) and ids.dtype == torch.int64
+        assert int(ids.min()) >= 0 and int(ids.max()) < n_rays
+        n_var = int(np.isin(ids.cpu().numpy(), var).sum())
+        if perc > 0:
+            assert n_var == int(perc / 100.0 * 1024), (perc, n_var)
+            # shuffled: the variance rays are not all at the tail
+            assert bool(np.isin(ids[:512].cpu().numpy(), var).any())
+        else:
+            assert 60 < n_var < 240                  # ~14 % of a uniform draw
+        assert torch.equal(ids, tr.draw_ray_ids_device(17))
+        assert not torch.equal(ids, tr.draw_ray_ids_device(18))
+        tr2 = CompositeTrainer(cfg, dummy, dummy, data, dev, rank=1, world=2, seed=3, fused_loss=False)
+        assert torch.equal(ids, tr2.draw_ray_ids_device(17))
+
+
+def test_early_stop_flag(dev):
+    """run_composite.py:310-312: the loop ends when the dynamic entropy or the favor loss falls below 1e-15 once the frequency
+    windows are fully open; the flag is computed on the device and read on demand."""
+    from nerfca_amd import synthetic
+    from nerfca_amd.model.CPPN import CPPN
+    from nerfca_amd.model.Temporal import Temporal
+    from nerfca_amd.train.trainer import CompositeTrainer, TrainConfig
+    data = synthetic.make_dataset(16, 48, dev, views=synthetic.TRAIN_VIEWS[:2], n_phases=3, F=32)
+    torch.manual_seed(2)
+    sdef, tdef = synthetic.net_definitions(dev, F=32)
+    s, t = CPPN(sdef).to(dev), Temporal(tdef).to(dev)
+    cfg = TrainConfig(depth_samples_per_ray_coarse=48, img_sample_size=128, static_pos_enc_window_decay_steps=10, temp_pos_enc_window_decay_steps=10)
+    tr = CompositeTrainer(cfg, s, t, data, dev, seed=1)
+    tr.step(5)
+    assert tr.stop_flag is None and tr.early_stop() is False          # windows still opening: the predicate is not evaluated
+    tr.step(10)
+    assert tr.stop_flag is not None and tr.early_stop() is False      # a live dynamic field: both terms are far above 1e-15
+    with torch.no_grad():                                             # a dead dynamic field: sigma_d == 0 exactly -> blend weight 0, entropy 0
+        t.output_linear[0].weight.zero_()
+        t.output_linear[0].bias.fill_(-1e4)
+    tr.step(11)
+    assert tr.early_stop() is True
