@@ -560,6 +560,63 @@ def eval_points(model, pts: torch.Tensor, phase: Optional[torch.Tensor] = None) 
     return _PointsFn.apply(binding, p, ph, *binding.params())
 
 
+class _PointsLatentsFn(torch.autograd.Function):
+    """raw[n] = net(points[n], table[ids[n]]) with a caller-supplied latent table in place of the module's time_latents."""
+
+    @staticmethod
+    def forward(ctx, binding: FieldBinding, pts, ids, table, *params):
+        lib = _capi.lib()
+        packed = binding.ensure_packed()
+        win, four = binding.module._enc_buffers()
+        N = pts.shape[0]
+        prm = binding.flat.detach().clone()                 # natural parameters with the table where the latents sit
+        prm[: table.numel()] = table.reshape(-1)
+        raw = torch.empty(N, dtype=torch.float32, device=pts.device)
+        check(lib.nca_mlp_fwd(C.byref(binding.net), binding.prec, ptr(packed), ptr(win), ptr(four), ptr(prm), N, ptr(pts), ptr(ids), ptr(raw), _stream()))
+        ctx.binding, ctx.keep, ctx.n_lat = binding, (packed, win, four, pts, ids, prm), table.numel()
+        return raw.view(N, 1)
+
+    @staticmethod
+    def backward(ctx, g_raw):
+        lib = _capi.lib()
+        binding = ctx.binding
+        packed, win, four, pts, ids, prm = ctx.keep
+        N = pts.shape[0]
+        g = _f32c(g_raw).reshape(-1)
+        grads = torch.empty(binding.flat.numel(), dtype=torch.float32, device=pts.device)
+        work, wbytes = _alloc_workspace(lambda cap: check(lib.nca_mlp_bwd_workspace(C.byref(binding.net), binding.prec, N, cap)), pts.device)
+        check(lib.nca_mlp_bwd(C.byref(binding.net), binding.prec, ptr(packed), ptr(win), ptr(four), ptr(prm), N, ptr(pts), ptr(ids), ptr(g), ptr(grads),
+                              ptr(work), wbytes, _stream()))
+        grads[: ctx.n_lat] = 0.0                            # the table is not the module's time_latents
+        return (None, None, None, None, *binding.split_grads(grads))
+
+
+def eval_points_with_latents(model, pts: torch.Tensor, latents: torch.Tensor) -> torch.Tensor:
+    """Temporal.query_time: f32[n,3], latent vectors f32[n,T] -> f32[n,1]."""
+    _require_cuda(pts, "query points")
+    binding: FieldBinding = model._binding
+    T, P = binding.net.T, binding.net.P
+    if latents.requires_grad and torch.is_grad_enabled():
+        raise _capi.NcaError("query_time: gradients with respect to the passed latent vectors are not provided (they are constants of the call)")
+    p = pts.detach().reshape(-1, 3).to(torch.float32).contiguous()
+    lat = latents.detach().reshape(-1, latents.shape[-1]).to(device=p.device, dtype=torch.float32)
+    if lat.shape[0] != p.shape[0] or lat.shape[1] != T:
+        raise _capi.NcaError(f"query_time takes one latent vector of {T} values per point")
+    if p.shape[0] == 0:
+        return torch.empty((0, 1), dtype=torch.float32, device=p.device)
+    uniq, inv = torch.unique(lat, dim=0, return_inverse=True)
+    out = torch.zeros((p.shape[0], 1), dtype=torch.float32, device=p.device)
+    for u0 in range(0, uniq.shape[0], P):                   # one temporary table of P rows per launch
+        sel = ((inv >= u0) & (inv < u0 + P)).nonzero().flatten()
+        table = torch.zeros((P, T), dtype=torch.float32, device=p.device)
+        rows = uniq[u0:u0 + P]
+        table[: rows.shape[0]] = rows
+        ids = (inv.index_select(0, sel) - u0).to(torch.int32).contiguous()
+        vals = _PointsLatentsFn.apply(binding, p.index_select(0, sel).contiguous(), ids, table, *binding.params())
+        out = out.index_put((sel,), vals)
+    return out
+
+
 class _CompositeFn(torch.autograd.Function):
     """render_volume_density[_composite] on raw fields (model_helpers.py:72-97) as one HIP kernel each way."""
 

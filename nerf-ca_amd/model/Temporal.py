@@ -43,10 +43,16 @@ class Temporal(FieldBase):
         return self._points(x, ts)
 
     def query_time(self, xs: torch.Tensor, ts: torch.Tensor) -> torch.Tensor:
-        """The reference's inner call takes already-gathered latent VECTORS (Temporal.py:113-136).
-        The fused kernel gathers by phase id itself, so only ``forward_composite`` is served."""
-        raise _capi.NcaError("query_time(x, latent_vectors) is not served by the fused kernels; "
-                             "call forward_composite(x, phase_ids)")
+        """points f32[n,3], latent VECTORS f32[n, num_time_dim] -> f32[n,1] (model/Temporal.py:113-136: the inner call of
+        forward_composite; on its own it evaluates the field at latents that are not rows of ``time_latents``, e.g. a cardiac
+        phase interpolated between two frames).  The kernels gather latents from a table by id, so the distinct vectors
+        become temporary tables of ``fixed_frame_ids`` rows each (one launch per table).  Gradients reach the network
+        weights; the passed vectors themselves are constants here."""
+        if self.num_late_layers > 0:
+            raise UnboundLocalError("local variable 'outputs' referenced before assignment "
+                                    "(num_late_layers > 0 has no output in the reference, Temporal.py:128-135)")
+        from ..fused import eval_points_with_latents
+        return eval_points_with_latents(self, xs, ts)
 
     def pos_enc(self, values, pos_enc_basis):
         return self._encode(values, pos_enc_basis)

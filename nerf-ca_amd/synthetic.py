@@ -31,6 +31,20 @@ def xcat_geometry(n_det: int) -> dict:
                 near_thresh=NEAR, far_thresh=FAR, max_pixel_value=MAX_PIXEL_VALUE)
 
 
+def magix_geometry(n_det: int, vol_voxels: int = 200) -> dict:
+    """The reference's MAGIX / CCTA cone beam (preprocess/tigre_helpers.py:174-206: DSD 2000 mm, DSO 600 mm, a 200 mm detector,
+    0.9 mm voxels) in the loader's units (x 1e-2, store_general_geo :66-80), detector n x n over the same field of view; near /
+    far as get_near_far (:44-56) gives them for a centred cube of ``vol_voxels`` voxels (the reference takes the volume's size
+    from its data file; 200 is the 200-pixel preset's counterpart)."""
+    dso, half = 6.0, 0.5 * vol_voxels * 0.9e-2
+    reach = math.hypot(half, half)
+    return dict(DSD=20.0, DSO=dso, nDetector=[n_det, n_det], dDetector=[2.0 / n_det, 2.0 / n_det], offDetector=[0.0, 0.0],
+                near_thresh=max(0.0, dso - reach), far_thresh=min(2 * dso, dso + reach), max_pixel_value=MAX_PIXEL_VALUE)
+
+
+GEOMETRIES = {"xcat": xcat_geometry, "magix": magix_geometry}
+
+
 def net_definitions(device, F=128, early=4, L=12, T=8, pos_enc="free_windowed", window_start=1):
     static = dict(num_early_layers=early, num_late_layers=0, num_filters=F, num_input_channels=3, num_output_channels=1,
                   use_bias=True, pos_enc=pos_enc, pos_enc_window_start=window_start, pos_enc_basis=L, fourier_sigma=0,
@@ -55,7 +69,7 @@ class SyntheticData:
 
 def make_dataset(n_det: int, S: int, device, views=None, n_phases: int = 10, teacher_seed: int = 0, F: int = 128,
                  var_sample_thre: float = 3.0, weighted_loss_max: float = 1.0,
-                 render: Optional[Callable] = None, teacher=None, chunk_rays: int = 65536) -> SyntheticData:
+                 render: Optional[Callable] = None, teacher=None, chunk_rays: int = 65536, geometry: str = "xcat") -> SyntheticData:
     """Build the ray table.  ``render(static, temporal, origins, dirs, phase_ids, I0, z, dists) -> pix`` is
     the fused HIP forward by default; ``teacher`` = (static_model, temporal_model) overrides the
     seed-derived teacher pair."""
@@ -63,7 +77,7 @@ def make_dataset(n_det: int, S: int, device, views=None, n_phases: int = 10, tea
     from .model.Temporal import Temporal
     from .train import model_helpers as MH
     views = TRAIN_VIEWS if views is None else views
-    geo = xcat_geometry(n_det)
+    geo = GEOMETRIES[geometry](n_det)
     W = H = n_det
     if teacher is None:
         torch.manual_seed(teacher_seed)

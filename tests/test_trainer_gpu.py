@@ -148,3 +148,68 @@ def test_early_stop_flag(dev):
         t.output_linear[0].bias.fill_(-1e4)
     tr.step(11)
     assert tr.early_stop() is True
+
+
+def test_query_time_with_latent_vectors(golden, dev):
+    """Temporal.query_time(x, latent_vectors) (model/Temporal.py:113-136) with vectors that are NOT rows of time_latents --
+    23 distinct interpolated latents, i.e. three temporary tables -- against the oracle's MLP on cat[posenc(x), latents],
+    outputs and weight gradients at 1e-5; with the module's own rows it equals forward_composite."""
+    from oracle import nerfca_oracle as O
+    g = golden("mlps")
+    tag = "F64_e4_l0"
+    pd = g.prefixed(f"d_{tag}_p_")
+    t = make_dynamic(pd, dev, F=64, early=4, late=0, T=8)
+    t.update_freq_mask_alpha(60000, 150000)
+    x = g["x"]
+    n = x.shape[0]
+    gen = torch.Generator().manual_seed(5)
+    pool = torch.rand(23, 8, generator=gen)
+    pick = torch.randint(0, 23, (n,), generator=gen)
+    lat = pool[pick]
+    sd = O.NetSpec(num_filters=64, num_time_dim=8)
+    win = O.freq_mask_alpha(12, 60000, 150000, 1)[0]
+    po = {k: v.clone().requires_grad_(True) for k, v in pd.items()}
+    yo = O.mlp(po, sd, torch.cat([O.encode(x, sd, win), lat], -1))
+    (yo * g["gout"]).sum().backward()
+    y = t.query_time(x.to(dev), lat.to(dev))
+    assert tuple(y.shape) == (n, 1) and rel_err(y.cpu(), yo) < 1e-5
+    (y * g["gout"].to(dev)).sum().backward()
+    for k, p in t.named_parameters():
+        if k == "time_latents":
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0
+        else:
+            assert rel_err(p.grad.cpu(), po[k].grad) < 1e-5, k
+    ts = g["ts"]
+    with torch.no_grad():
+        assert torch.equal(t.query_time(x.to(dev), t.time_latents[ts.long().to(dev)]), t.forward_composite(x.to(dev), ts.to(dev)))
+
+
+def test_magix_shape_full_size_step(dev):
+    """BASELINE configs[3]'s shape (MAGIX cone beam DSD 2000 / DSO 600, 512^2 detector, 256 samples per ray, f32): one fused
+    step over a full detector runs as ray micro-batches (its forward store would not fit) and is reproducible bit for bit;
+    the ray geometry is the preset's (source at DSO, near / far around it)."""
+    import nerfca_amd
+    from nerfca_amd import fused, synthetic
+    from nerfca_amd.model.CPPN import CPPN
+    from nerfca_amd.model.Temporal import Temporal
+    from nerfca_amd.train.trainer import CompositeTrainer, TrainConfig
+    data = synthetic.make_dataset(512, 256, dev, views=synthetic.TRAIN_VIEWS[:1], n_phases=2, geometry="magix")
+    assert abs(float(data.rays_train[0, 0].norm()) - 6.0) < 1e-6 and abs(data.geo["near_thresh"] - 4.7272) < 1e-3
+    outs, calls = [], []
+    orig = fused.render_forward_raw
+    fused.render_forward_raw = lambda *a, **k: (calls.append(a[0].R), orig(*a, **k))[1]
+    try:
+        for _ in range(2):
+            torch.manual_seed(1)
+            sdef, tdef = synthetic.net_definitions(dev)
+            s, t = CPPN(sdef).to(dev), Temporal(tdef).to(dev)
+            tr = CompositeTrainer(TrainConfig(depth_samples_per_ray_coarse=256, img_sample_size=262144), s, t, data, dev, seed=0)
+            _, _, terms = tr.step_fused(75000)
+            outs.append((terms.clone(), torch.cat([p.grad.flatten() for p in tr.params]).clone()))
+            del tr, s, t
+            torch.cuda.empty_cache()
+    finally:
+        fused.render_forward_raw = orig
+    assert len(calls) >= 4 and sum(calls) == 2 * 262144              # several micro-batches per step
+    assert bool(torch.isfinite(outs[0][1]).all()) and float(outs[0][1].abs().max()) > 0
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
