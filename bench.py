@@ -345,6 +345,7 @@ def main():
         rccl_ranks = dist.get_world_size()
 
     from nerfca_amd import _capi, synthetic
+    from nerfca_amd import fused as fused_mod
     _capi.lib()   # fail loudly if the HIP library is missing
 
     views = synthetic.TRAIN_VIEWS if args.views == 4 else synthetic.TRAIN_VIEWS_8[: args.views]
@@ -393,7 +394,8 @@ def main():
                                       f"{args.rays} rays/step/GPU (one full detector), F=128 x 4 hidden layers x 2 nets, L=12, fwd+losses+bwd+Adam",
                           "rays_per_step_per_gpu": args.rays, "samples_per_ray": args.samples, "parallelism": f"ray-sharded dp{world}", "hip_graph": bool(args.graph),
                           "onchip_last_layer_wgrad": bool(onchip)},
-               "rccl_ranks": rccl_ranks, "roofline": roof, "final_loss": float(loss)}
+               "rccl_ranks": rccl_ranks, "roofline": roof, "final_loss": float(loss),
+               "store_fallbacks": fused_mod.STORE_FALLBACKS}       # > 0: some backward ran on the recompute path (store did not fit)
         del tr
         torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:

@@ -583,8 +583,8 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                     float g;
                     if (a.mode == NCA_MODE_RAYS && !a.g_raw) {
                         const float* gs = net + a.net_base == 0 ? a.g_sig_s : a.g_sig_d;
-                        const double gsig = gs ? (double)gs[n] : 0.0;
-                        const double gp = a.g_pix[ray] * a.dists[smp];
+                        const double gsig = (NCA_EXP & 32768) ? 1e-6 * lane : (gs ? (double)gs[n] : 0.0);                 // (32768: no loads of the upstream gradients)
+                        const double gp = (NCA_EXP & 32768) ? 1e-7 : a.g_pix[ray] * a.dists[smp];
                         const double dsig = a.single ? (gsig - gp * (double)a.scale) : (gsig - gp) * (double)a.scale;
                         g = (float)dsig * act_bwd_b(a.act, raw[net]);
                     } else {
@@ -687,7 +687,8 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
                     for (int k = 0; k < 2 * MT; ++k)      // (on chip: plain loads -- the fragments are read again ~40 us later, let the caches keep them)
-                        B[c][k] = ONCHIP ? *reinterpret_cast<const u32x4*>(hl + c * a.rows_total + k * 1024) : load_nt(hl + c * a.rows_total + k * 1024);
+                        B[c][k] = (NCA_EXP & 16384) ? (u32x4){0x3f803f80u + (unsigned)lane, 0x3f003f80u, 0x3f803f00u, 0x3e803f80u}        // (no loads of the last layer's input)
+                                  : ONCHIP ? *reinterpret_cast<const u32x4*>(hl + c * a.rows_total + k * 1024) : load_nt(hl + c * a.rows_total + k * 1024);
             }
             for (int jj = STORED ? y.NL - 1 : 0; jj < y.NL; ++jj) {
                 const NcaLayerL& l = y.layer[jj];
@@ -1178,14 +1179,160 @@ __device__ __forceinline__ void wgrad_job(const NcaWgradArgs& a, const NcaWgradJ
     wgrad_write<F, NTB>(acc, bsum, job, a.slab + (int64_t)q * a.slab_stride, a.accumulate, lane);
 }
 
+// The 8-bit weight gradient (every D block of the launch is e5m2: fp8 staging).  A 64-sample wave tile is contracted by ONE
+// v_mfma_scale_f32_32x32x64_f8f6f4 per 32 x 32 block of dW: A = D^T (e5m2), B = H^T (e4m3), K = the wave tile's 64 samples, the
+// tile's power-of-two inverse scale (and the 2^-NCA_H8_LOG2 of the layer inputs) as the A operand's e8m0 block scale -- twice
+// the bf16 rate, no scaling or packing on the vector ALU.  The operands need the sample index on K, i.e. the blocks
+// transposed: as before by MFMAs against an 8-bit identity (x 1 is exact), whose f32 results are re-encoded as bytes (exact
+// for D and for e4m3 H blocks; the bf16 input block and a bf16 last-layer input are rounded to e4m3 here).  Lane (feature
+// position, half h) then holds 16 samples of each of the wave tile's two 32-sample halves = its 32 K values; both operands
+// use the same K order, which is all the contraction needs (tools/mx_mfma_probe.hip: lane maps, scales, formats).
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned z4_e5m2(float a, float b, float c, float d) {
+    int v = 0;
+    v = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, v, false);
+    v = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, v, true);
+    return (unsigned)v;
+}
+__device__ __forceinline__ unsigned z4_e4m3(float a, float b, float c, float d) {
+    int v = 0;
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, v, false);
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+    return (unsigned)v;
+}
+
+template <int F, int NTB, bool H8>
+__device__ __forceinline__ void wgrad_job_mx(const NcaWgradArgs& a, const NcaWgradJob& job, int q, int nsplit, int lane, char* ring) {
+    using R = WgradRing<F, NTB, true, H8>;
+    constexpr int MT = F / 32, ND_ = R::ND, NH_ = R::NH, FR = R::FR, NSLOT = R::NSLOT;
+    static_assert(R::BYTES <= NCA_WGRAD_LDS, "ring does not fit the wave's LDS share");
+    const int lc = lane & 31, lh = lane >> 5;
+    // whole wave tiles per split: the two 32-sample halves of a wave tile share one scale and one MFMA
+    const int64_t per = (((a.ntiles + nsplit - 1) / nsplit) + 1) & ~(int64_t)1;
+    const int64_t t0 = (int64_t)q * per, t1 = (t0 + per < a.ntiles) ? t0 + per : a.ntiles;
+    const char* base = reinterpret_cast<const char*>(a.scratch);
+    const char* base_b = reinterpret_cast<const char*>(a.scratch_b);
+    const int brow = job.b_row_bytes;
+    f32x16 acc[MT][NTB];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int c = 0; c < NTB; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][c][i] = 0.f;
+    float bsum[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) bsum[m] = 0.f;
+
+    auto issue = [&](int64_t t, int slot) {
+        const char* dp = base + t * a.rows_total + job.d_row0 + lane * 16;
+        const char* bp = base_b + (t + a.tile0_b) * a.rows_total_b + job.b_row0 + lane * 16;
+        char* dst = ring + slot * (FR * 1024);
+#pragma unroll
+        for (int s = 0; s < ND_; ++s)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dp + s * 1024),
+                                             (__attribute__((address_space(3))) void*)(dst + s * 1024), 16, 0, 2);
+#pragma unroll
+        for (int s = 0; s < NH_; ++s)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bp + ((H8 || s * 32 + 32 <= brow) ? s : 0) * 1024),
+                                             (__attribute__((address_space(3))) void*)(dst + (ND_ + s) * 1024), 16, 0, 2);
+    };
+    const int64_t n = t1 > t0 ? t1 - t0 : 0;
+#pragma unroll
+    for (int p = 0; p < NSLOT - 1; ++p)
+        if (p < n) issue(t0 + p, p);
+    const long ED0 = ident8<true>(8 * lh, lc), ED1 = ident8<true>(16 + 8 * lh, lc);          // e5m2 identity (D blocks)
+    const long EH0 = ident8<false>(8 * lh, lc), EH1 = ident8<false>(16 + 8 * lh, lc);        // e4m3 identity (e4m3 H blocks)
+    const u32x4 EB0 = ident_frag(8 * lh, lc), EB1 = ident_frag(16 + 8 * lh, lc);             // bf16 identity (bf16 H blocks)
+    for (int64_t i = 0; i < n; i += 2) {
+        i32x8 PA[MT], PB[NTB];
+        // the wave tile's inverse scale (first of its two 32-sample records) as an e8m0 exponent, with the layer inputs' 2^-NCA_H8_LOG2
+        const float sc = reinterpret_cast<const float*>(base + (t0 + i) * a.rows_total + job.dscale_off)[job.net];
+        const int sa = (int)(__float_as_uint(sc) >> 23) - NCA_H8_LOG2;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int64_t ii = i + half;
+            if (ii >= n) {                                   // an odd tail: the missing half contributes nothing
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) PA[m][4 * half + w] = 0;
+#pragma unroll
+                for (int c = 0; c < NTB; ++c)
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) PB[c][4 * half + w] = 0;
+                continue;
+            }
+            if (ii + NSLOT - 1 < n) {
+                issue(t0 + ii + NSLOT - 1, (int)((ii + NSLOT - 1) % NSLOT));
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSLOT - 1) * FR) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            const char* slot = ring + (int)(ii % NSLOT) * (FR * 1024) + lane * 16;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {                   // D: e5m2 bytes -> transposed, bias sums, bytes again
+                const u32x4 x = *reinterpret_cast<const u32x4*>(slot + m * 1024);
+                f32x16 z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                z = __builtin_amdgcn_mfma_f32_32x32x16_bf8_bf8((long)(((unsigned long)x[1] << 32) | x[0]), ED0, z, 0, 0, 0);
+                z = __builtin_amdgcn_mfma_f32_32x32x16_bf8_bf8((long)(((unsigned long)x[3] << 32) | x[2]), ED1, z, 0, 0, 0);
+                float cs = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cs += z[r];
+                bsum[m] = fmaf(cs, sc, bsum[m]);
+#pragma unroll
+                for (int w = 0; w < 4; ++w) PA[m][4 * half + w] = (int)z4_e5m2(z[4 * w], z[4 * w + 1], z[4 * w + 2], z[4 * w + 3]);
+            }
+#pragma unroll
+            for (int c = 0; c < NTB; ++c) {                  // H: e4m3 bytes (or bf16 pairs, rounded to e4m3 x 2^NCA_H8_LOG2 here) -> transposed bytes
+                f32x16 z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                if constexpr (H8) {
+                    const u32x4 x = *reinterpret_cast<const u32x4*>(slot + (ND_ + c) * 1024);
+                    z = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8((long)(((unsigned long)x[1] << 32) | x[0]), EH0, z, 0, 0, 0);
+                    z = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8((long)(((unsigned long)x[3] << 32) | x[2]), EH1, z, 0, 0, 0);
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) PB[c][4 * half + w] = (int)z4_e4m3(z[4 * w], z[4 * w + 1], z[4 * w + 2], z[4 * w + 3]);
+                } else {
+                    const bool ok0 = (2 * c) * 32 + 32 <= brow, ok1 = (2 * c + 1) * 32 + 32 <= brow;
+                    u32x4 x0 = *reinterpret_cast<const u32x4*>(slot + (ND_ + 2 * c) * 1024), x1 = *reinterpret_cast<const u32x4*>(slot + (ND_ + 2 * c + 1) * 1024);
+                    if (!ok0) x0 = (u32x4){0u, 0u, 0u, 0u};
+                    if (!ok1) x1 = (u32x4){0u, 0u, 0u, 0u};
+                    z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(x0), frag(EB0), z, 0, 0, 0);
+                    z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(x1), frag(EB1), z, 0, 0, 0);
+                    constexpr float DIV = 1.f / (float)(1 << NCA_H8_LOG2);
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) PB[c][4 * half + w] = (int)cvt4_e4m3(z[4 * w], z[4 * w + 1], z[4 * w + 2], z[4 * w + 3], DIV);
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int c = 0; c < NTB; ++c)
+                acc[m][c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(PA[m], PB[c], acc[m][c], 1 /* A: e5m2 */, 0 /* B: e4m3 */, 0, sa, 0, 127);
+    }
+    wgrad_write<F, NTB>(acc, bsum, job, a.slab + (int64_t)q * a.slab_stride, a.accumulate, lane);
+}
+
 template <int F, bool D8>
 __global__ __launch_bounds__(64, 1) void nca_wgrad_bf16(const NcaWgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char wring[];
     const NcaWgradJob job = a.job[blockIdx.y];
     // (at F = 128 the 112-slot input block and a hidden block have the same shape: one body serves both)
-    if (job.h8) wgrad_job<F, F / 32, D8, true>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
-    else if (F != 128 && job.is_enc) wgrad_job<F, 4, D8, false>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
-    else wgrad_job<F, F == 128 ? 4 : F / 32, D8, false>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
+    if constexpr (D8) {
+        s8_mode();
+        if (job.h8) wgrad_job_mx<F, F / 32, true>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
+        else if (F != 128 && job.is_enc) wgrad_job_mx<F, 4, false>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
+        else wgrad_job_mx<F, F == 128 ? 4 : F / 32, false>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
+    } else {
+        if (job.h8) wgrad_job<F, F / 32, D8, true>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
+        else if (F != 128 && job.is_enc) wgrad_job<F, 4, D8, false>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
+        else wgrad_job<F, F == 128 ? 4 : F / 32, D8, false>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
+    }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -41,8 +41,9 @@ def set_precision(prec: str, *models) -> None:
 
 
 def _alloc_workspace(size_for_cap, dev):
-    """Allocate the backward workspace the library sizes for a byte cap; halve the cap while the allocation fails."""
-    cap = BWD_WORKSPACE_BYTES
+    """Allocate the backward workspace the library sizes for a byte cap (the configured bound, at most 80 % of what the device can
+    still give); halve the cap while the allocation fails."""
+    cap = max(1 << 20, min(BWD_WORKSPACE_BYTES, int(0.8 * _usable_bytes(dev))))
     while True:
         wbytes = size_for_cap(cap)
         try:
@@ -182,10 +183,28 @@ class _RayBatch:
                        single_field=self.single, scale=self.scale, reserved=0)
 
 
-# A bf16 forward that will be followed by a backward leaves every layer input, the ReLU masks and the raw outputs in a
-# store (what the reference's autograd graph keeps); the backward then skips the recompute.  ~3 KB per sample: the
-# store is used when it fits under this limit, otherwise the backward recomputes (set to 0 to always recompute).
+# A forward that will be followed by a backward leaves every layer input, the ReLU masks and the raw outputs in a
+# store (what the reference's autograd graph keeps); the backward then skips the recompute.  1.6 - 2.8 KB per sample in
+# bf16, 5.9 KB in f32: the store is used when it fits under this limit AND under the device's free memory (below),
+# otherwise the backward recomputes (set to 0 to always recompute).
 STORE_FORWARD_LIMIT_BYTES = 96 << 30
+# how often a backward had to fall back to the recompute path because the store did not fit or could not be allocated:
+# a bench line taken with a non-zero count was not timed on the stored path
+STORE_FALLBACKS = 0
+
+
+def _usable_bytes(dev) -> int:
+    """Bytes this process can still take on `dev`: the driver's free memory plus what torch's caching allocator holds unused."""
+    free, _ = torch.cuda.mem_get_info(dev)
+    return int(free + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev))
+
+
+def store_limit_bytes(dev) -> int:
+    """The forward-store limit that applies now: the configured cap, and at most 45 % of what the device can still give (a
+    backward workspace of similar size follows, and the fine pass holds two stores at once)."""
+    if STORE_FORWARD_LIMIT_BYTES <= 0:
+        return 0
+    return min(STORE_FORWARD_LIMIT_BYTES, int(0.45 * _usable_bytes(dev)))
 
 
 def _same_window(bs: FieldBinding, bd: FieldBinding) -> bool:
@@ -224,13 +243,16 @@ def render_forward_raw(batch: _RayBatch, bs: FieldBinding, bd: Optional[FieldBin
     wbytes = check(lib.nca_render_fwd_workspace(C.byref(desc)))
     work = torch.empty(wbytes, dtype=torch.uint8, device=dev)
     store = None
+    global STORE_FALLBACKS
     if for_backward and STORE_FORWARD_LIMIT_BYTES > 0:
         sbytes = check(lib.nca_render_store_bytes(C.byref(desc), C.byref(bs.net), C.byref(bd.net) if bd is not None else None, bs.prec))
-        if 0 < sbytes <= STORE_FORWARD_LIMIT_BYTES:
+        if 0 < sbytes <= store_limit_bytes(dev):
             try:
                 store = torch.empty(sbytes, dtype=torch.uint8, device=dev)
             except torch.cuda.OutOfMemoryError:        # not enough free HBM for the store: the backward recomputes instead
                 store = None
+        if sbytes > 0 and store is None:
+            STORE_FALLBACKS += 1
     check(lib.nca_render_fwd(C.byref(desc), bs.prec,
                              C.byref(bs.net), ptr(packed_s), ptr(win_s), ptr(four_s),
                              C.byref(bd.net) if bd is not None else None, ptr(packed_d), ptr(win_d), ptr(four_d),

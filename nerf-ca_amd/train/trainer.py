@@ -101,7 +101,8 @@ class CompositeTrainer:
         on_cuda = device.type == "cuda" if isinstance(device, torch.device) else str(device).startswith("cuda")
         if fused_loss is None:             # default on the GPU: the autograd-free step with the HIP loss kernel (step_fused);
             fused_loss = on_cuda           # fused_loss=False keeps the reference's torch loss functions under autograd
-        self.fused_loss = bool(fused_loss) and render is None
+        # (an injected renderer or fine sampler -- the CPU tests' oracle -- runs under autograd: the fused steps call the library)
+        self.fused_loss = bool(fused_loss) and render is None and (self.n_fine == 0 or fine_sampler is None)
         self.stop_flag = None              # device bool: the reference's early-stop predicate of the last step (see early_stop)
         self.always_allreduce = False      # all-reduce even with one rank (exercises the collective path)
         self._dev_gen = None
@@ -280,7 +281,7 @@ class CompositeTrainer:
         n_loc = hi - lo
         whole = _RayBatch(o, d, phases, self.I0[:n_loc], z, dists, c.output_activation, False, 1e-2)
         need = FU.forward_store_bytes(whole, bs, bd)
-        limit = FU.STORE_FORWARD_LIMIT_BYTES
+        limit = FU.store_limit_bytes(self.device)
         micro = n_loc if need <= limit or need == 0 or limit <= 0 else max(1, int(n_loc * (limit / need)))
         weights = self.loss_weights(n_iter)
         terms = grads_s = grads_d = None

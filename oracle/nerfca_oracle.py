@@ -265,7 +265,9 @@ def mlp(params: Dict[str, Tensor], spec: NetSpec, feats: Tensor) -> Tensor:
         for i in range(NL):
             last = i == NL - 1
             d8 = None if (last and spec.emulate_onchip_last) else fd     # on chip: bf16 registers, nothing is staged
-            h8 = fh if 1 <= i <= NL - 2 else None                          # inputs of layers 1..NL-2; the input block and the last layer's input stay bf16
+            # every staged layer's input is e4m3 when its weight gradient is formed: the inputs of layers 1..NL-2 cross HBM as
+            # e4m3, the bf16 input block and the bf16 input of the last layer are rounded to e4m3 inside the weight-gradient kernel
+            h8 = fh if d8 is not None else None
             h = torch.relu(_StagedLinear.apply(h, params[f"early_pts_layers.{2 * i}.weight"], params[f"early_pts_layers.{2 * i}.bias"], state, d8, h8, i == 0))
         raw = TF.linear(h, params["output_linear.0.weight"], params["output_linear.0.bias"])
         if raw.requires_grad:      # d loss / d raw arrives before the layers' backward runs: fix the tile scales there
