@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NCA_ABI_VERSION 6
+#define NCA_ABI_VERSION 7
 
 enum {
     NCA_OK = 0,
@@ -249,6 +249,12 @@ enum {
                                      64-sample tile; f32 accumulation; the MLP contractions themselves stay bf16).  1 = on (default),
                                      0 = bf16 staging.  Read when a forward writes its store and when a backward reads one: do not
                                      change it between a forward and its backward.  Initial value from NCA_STAGE_FP8 (0 / 1) */
+    NCA_OPT_RESIDENT_MIN_TILES = 2, /* bf16 mode: run the fused kernels with ONE net per launch and all of that net's weight images
+                                     resident in LDS (no per-layer weight DMA, no workgroup barrier in the tile loop) when the images fit
+                                     (width 128: up to 4 layers of width 128) and the batch has at least this many 64-sample wave
+                                     tiles.  A two-net render then takes two forward launches (the second composites with the first
+                                     one's sigma).  0 = always, -1 = never; default 4 * 8 waves * CUs (NCA_RESIDENT=0 -> never,
+                                     =force -> always).  Results are bit-identical to the streaming kernels */
     NCA_OPT_COUNT
 };
 int64_t nca_get_option(int32_t opt);

@@ -124,6 +124,9 @@ void opt_init_locked() {
     const char* e = getenv("NCA_ONCHIP");
     if (e && e[0] == '0') g_opt[NCA_OPT_ONCHIP_MIN_TILES] = -1;
     else if (e && e[0] == 'f') g_opt[NCA_OPT_ONCHIP_MIN_TILES] = 0;
+    e = getenv("NCA_RESIDENT");
+    if (e && e[0] == '0') g_opt[NCA_OPT_RESIDENT_MIN_TILES] = -1;
+    else if (e && e[0] == 'f') g_opt[NCA_OPT_RESIDENT_MIN_TILES] = 0;
     e = getenv("NCA_STAGE_FP8");
     if (e && (e[0] == '0' || e[0] == '1')) g_opt[NCA_OPT_STAGE_FP8] = e[0] - '0';
     g_opt_init = true;
@@ -137,6 +140,7 @@ int64_t opt_value(int opt) {
         // reference's default batch of 1024 rays x 500 samples -- 4 tile groups per workgroup -- it costs 3.6 %
         if (opt == NCA_OPT_ONCHIP_MIN_TILES) v = (int64_t)8 * NCA_WAVES * num_cus();
         if (opt == NCA_OPT_STAGE_FP8) v = 1;
+        if (opt == NCA_OPT_RESIDENT_MIN_TILES) v = (int64_t)4 * NCA_WAVES * num_cus();
     }
     return v;
 }
@@ -148,6 +152,7 @@ extern "C" int64_t nca_get_option(int32_t opt) {
 extern "C" int nca_set_option(int32_t opt, int64_t value) {
     if (opt < 0 || opt >= NCA_OPT_COUNT) return fail(NCA_E_INVALID, "option %d out of range", opt);
     if (opt == NCA_OPT_ONCHIP_MIN_TILES && value < -1) return fail(NCA_E_INVALID, "NCA_OPT_ONCHIP_MIN_TILES takes -1 (never), 0 (always) or a tile count");
+    if (opt == NCA_OPT_RESIDENT_MIN_TILES && value < -1) return fail(NCA_E_INVALID, "NCA_OPT_RESIDENT_MIN_TILES takes -1 (never), 0 (always) or a tile count");
     if (opt == NCA_OPT_STAGE_FP8 && value != 0 && value != 1) return fail(NCA_E_INVALID, "NCA_OPT_STAGE_FP8 takes 0 or 1");
     std::lock_guard<std::mutex> lk(g_omu);
     opt_init_locked();
@@ -225,7 +230,8 @@ static int add_stage(NcaFusedArgs* a, const void* base, uint32_t off, uint32_t b
     if (a->nstages >= NCA_MAX_STAGES) return fail(NCA_E_UNSUPPORTED, "too many weight stages");
     a->stage[a->nstages].ptr = static_cast<const char*>(base) + off;
     a->stage[a->nstages].bytes = (bytes + 1023u) & ~1023u;   // whole 1 KiB DMA pieces (the pack kernel zero-fills the padding)
-    a->stage[a->nstages].pad = 0;
+    a->stage[a->nstages].lds_off = (uint32_t)a->res_total;       // resident layout: back to back
+    a->res_total += (int32_t)((bytes + 15u) & ~15u);
     a->nstages++;
     return NCA_OK;
 }
@@ -234,6 +240,8 @@ static int add_stage(NcaFusedArgs* a, const void* base, uint32_t off, uint32_t b
 // images only); 2 = backward from a store without the last layer's output (bf16: the last forward image, then dgrad images)
 static int build_stages(NcaFusedArgs* a, const NetBind* binds, bool bwd, int stored = 0) {
     a->nstages = 0;
+    a->res_total = 0;
+    a->res_bytes = 0;
     for (int n = 0; n < a->nnets; ++n) {
         const NcaLayout& y = a->net[n].lay;
         for (int j = stored == 2 ? y.NL - 1 : 0; stored != 1 && j < y.NL; ++j) {
@@ -255,6 +263,29 @@ static int build_stages(NcaFusedArgs* a, const NetBind* binds, bool bwd, int sto
             }
     }
     return NCA_OK;
+}
+
+// bf16: lay every weight image of the launch out in LDS, back to back.  False (and res_bytes = 0: the streaming kernel) when
+// they do not fit next to the launch's other LDS needs or the batch is below NCA_OPT_RESIDENT_MIN_TILES.
+static bool plan_resident(NcaFusedArgs* a, int kmode) {
+    const uint32_t tight = (uint32_t)a->res_total;          // left by build_stages
+    a->res_bytes = 0;
+    const int64_t min_tiles = opt_value(NCA_OPT_RESIDENT_MIN_TILES);
+    if (min_tiles < 0 || a->ntiles < min_tiles || a->nnets != 1) {
+        if (getenv("NCA_DEBUG")) fprintf(stderr, "[nerfca] plan_resident: off (min tiles %lld, tiles %lld, nets %d)\n", (long long)min_tiles, (long long)a->ntiles, a->nnets);
+        return false;
+    }
+    if (a->nstages <= 0) return false;
+    const uint32_t dma_end = a->stage[a->nstages - 1].lds_off + a->stage[a->nstages - 1].bytes;   // the DMA moves whole 1 KiB pieces
+    const size_t other = nca_fused_bf16_lds_other(a->net[0].lay.F, kmode);
+    const size_t need = tight + other > dma_end ? tight + other : dma_end;
+    static const bool dbg = getenv("NCA_DEBUG") != nullptr;
+    const bool fits = need <= (size_t)NCA_LDS_BYTES;
+    if (dbg) fprintf(stderr, "[nerfca] plan_resident: mode %d, %d stages, %u image bytes + %zu other: %s\n", kmode, a->nstages, tight, other,
+                     fits ? "resident" : "streaming");
+    if (!fits) return false;
+    a->res_bytes = (int32_t)tight;
+    return true;
 }
 
 static int check_rays(const NcaRays* r) {
@@ -314,13 +345,17 @@ static bool store_plan(const NcaLayout* lays, int nnets, int32_t prec, int64_t w
     if (nnets == 2 && lays[0].F != lays[1].F) return false;
     const bool bf = prec == NCA_PREC_BF16;
     const int64_t EB = 32 * (int64_t)NCA_BF_ENCROWS * 2;
+    // bf16: slack tile slots up to the next multiple of the 8 waves of a workgroup -- a wave without a tile writes there, so
+    // that the storing forward's hot loops need no store predicate
+    if (bf) wave_tiles = (wave_tiles + NCA_WAVES - 1) / NCA_WAVES * NCA_WAVES;
     memset(sp, 0, sizeof(*sp));
     for (int n = 0; n < nnets; ++n) {
         if (lays[n].NL < 2) return false;                 // no hidden layer: nothing worth storing
         sp->row0[n] = sp->h_stride;
         if (bf) sp->h_stride += EB + nca_bf_hbytes(lays[n], h8);                      // inputs of layers 0 .. NL-1
         else sp->h_stride += lays[n].K0rows_pad + (int64_t)lays[n].NL * lays[n].F;
-        if (lays[n].NL - 1 > sp->mask_layers) sp->mask_layers = lays[n].NL - 1;
+        const int ml = (bf && h8) ? lays[n].NL : lays[n].NL - 1;        // fp8 staging: the masks of every layer (the backward recomputes none)
+        if (ml > sp->mask_layers) sp->mask_layers = ml;
     }
     if (share_enc) {      // [dynamic: input block + hidden blocks][static: hidden blocks only]
         const int64_t dyn = EB + nca_bf_hbytes(lays[1], h8);
@@ -330,8 +365,8 @@ static bool store_plan(const NcaLayout* lays, int nnets, int32_t prec, int64_t w
     }
     if (bf) {
         sp->off_m = align_up(wave_tiles * 2 * sp->h_stride, 1024);
-        sp->off_r = sp->off_m + wave_tiles * 2 * sp->mask_layers * 1024;       // (no raw outputs: the bf16 backward recomputes the last layer)
-        sp->bytes = align_up(sp->off_r, 256);
+        sp->off_r = sp->off_m + wave_tiles * 2 * sp->mask_layers * 1024;       // raw outputs [wave tile][net][64] f32: fp8 staging only
+        sp->bytes = align_up(sp->off_r + (h8 ? wave_tiles * 2 * 64 * 4 : 0), 256);        // (bf16 staging: the backward recomputes the last layer)
     } else {
         sp->off_m = align_up(wave_tiles * sp->h_stride * 32 * 4, 1024);
         sp->off_r = sp->off_m + wave_tiles * 2 * sp->mask_layers * 512;
@@ -352,9 +387,11 @@ extern "C" int64_t nca_render_store_bytes(const NcaRays* rays, const NcaNet* net
     if (nn == 2) { rc = layout_of(net_d, &lays[1], prec); if (rc) return rc; }
     StorePlan sp;
     const int ts = tile_samples(prec);
-    // (sized for bf16 staging, the larger layout: a store may be allocated before NCA_OPT_STAGE_FP8 is settled)
+    // (sized for the larger of the two staging layouts: a store may be allocated before NCA_OPT_STAGE_FP8 is settled)
     if (!store_plan(lays, nn, prec, rays->R * ((rays->S + ts - 1) / ts), &sp)) return 0;
-    return sp.bytes;
+    int64_t bytes = sp.bytes;
+    if (prec == NCA_PREC_BF16 && store_plan(lays, nn, prec, rays->R * ((rays->S + ts - 1) / ts), &sp, false, true) && sp.bytes > bytes) bytes = sp.bytes;
+    return bytes;
 }
 
 extern "C" int64_t nca_render_fwd_workspace(const NcaRays* rays) {
@@ -410,6 +447,7 @@ extern "C" int nca_render_fwd(const NcaRays* rays, int32_t prec,
             NetBind b1[2] = {binds[n], {}};
             rc = build_stages(&one, b1, false);
             if (rc) return rc;
+            if (prec == NCA_PREC_BF16) plan_resident(&one, NCA_KM_FWD);
             Span sp(NCA_K_FWD, st);
             if (prec == NCA_PREC_BF16) HIPCHK(nca_launch_fused_bf16(one.net[0].lay.F, one, false, grid, st));
             else HIPCHK(nca_launch_fused_f32(one.net[0].lay.F, one, false, grid, st));
@@ -439,7 +477,34 @@ extern "C" int nca_render_fwd(const NcaRays* rays, int32_t prec,
         a.rstore = reinterpret_cast<float*>(static_cast<char*>(store) + spl.off_r);
         a.mstore_layers = spl.mask_layers;
     }
-    {
+    bool done = false;
+    if (prec == NCA_PREC_BF16 && a.nnets == 2) {
+        // one launch per net with that net's weight images resident in LDS: the static net writes its sigma, the dynamic net
+        // reads it back and composites
+        static thread_local NcaFusedArgs one[2];
+        bool ok = true;
+        for (int n = 0; n < 2 && ok; ++n) {
+            one[n] = a;
+            one[n].nnets = 1;
+            one[n].net[0] = a.net[n];
+            one[n].net_base = n;
+            one[n].split = n + 1;
+            NetBind b1[2] = {binds[n], {}};
+            rc = build_stages(&one[n], b1, false);
+            if (rc) return rc;
+            ok = plan_resident(&one[n], kmode);
+        }
+        if (ok) {
+            for (int n = 0; n < 2; ++n) {
+                Span sp(NCA_K_FWD, st);
+                HIPCHK(nca_launch_fused_bf16(one[n].net[0].lay.F, one[n], kmode, grid, st, a.h8 != 0));
+            }
+            done = true;
+        }
+    } else if (prec == NCA_PREC_BF16) {
+        plan_resident(&a, kmode);
+    }
+    if (!done) {
         Span sp(NCA_K_FWD, st);
         if (prec == NCA_PREC_BF16) HIPCHK(nca_launch_fused_bf16(a.net[0].lay.F, a, kmode, grid, st, a.h8 != 0));
         else HIPCHK(nca_launch_fused_f32(a.net[0].lay.F, a, kmode, grid, st));
@@ -465,7 +530,7 @@ static int64_t scratch_rows(const NcaLayout& y) { return y.K0rows_pad + (int64_t
 
 // d8: bf16 backward from a store with fp8 staging (D_0..D_{NL-2} as e5m2 + one inverse-scale record per tile)
 static int plan_bwd(const NcaLayout* lays, int nnets, int32_t prec, int64_t units, int64_t tiles_per_unit, int64_t budget, BwdPlan* p,
-                    bool stored = false, bool onchip = false, bool d8 = false) {
+                    bool stored = false, bool onchip = false, bool d8 = false, bool nr = false) {
     const bool bf = prec == NCA_PREC_BF16;
     p->tile_stride = 0;
     p->slab_stride = 0;
@@ -476,8 +541,9 @@ static int plan_bwd(const NcaLayout* lays, int nnets, int32_t prec, int64_t unit
         p->slab_stride += lays[n].n_params;
         for (int j = 0; j < lays[n].NL; ++j) p->njobs += lays[n].layer[j].kind == NCA_IN_SKIP ? 2 : 1;
         if (onchip) p->njobs -= 1;                    // the last hidden layer's weight gradient stays in the dgrad kernel
+        if (nr) p->slab_stride += (int64_t)lays[n].NL * lays[n].F;     // fp8 staging: the output layer's weight gradient, one slot per wgrad job
     }
-    if (stored && bf && d8) p->tile_stride += NCA_D8_REC_BYTES;
+    if (stored && bf && (d8 || nr)) p->tile_stride += NCA_D8_REC_BYTES;
     for (int n = 0; n < nnets; ++n) p->slab_stride += (int64_t)lays[n].F * lays[n].P;
     p->slab_stride = align_up(p->slab_stride, 64);
     if (p->njobs > NCA_MAX_JOBS) return fail(NCA_E_UNSUPPORTED, "too many wgrad jobs");
@@ -493,7 +559,9 @@ static int plan_bwd(const NcaLayout* lays, int nnets, int32_t prec, int64_t unit
     const int64_t oslab_bytes = align_up((int64_t)cus * 2 * (F + 1) * 4, 256);
     p->wslab_stride = (int64_t)F * F + F;                                               // on-chip layer: dW and db per workgroup
     const int64_t wslab_bytes = bf ? align_up((int64_t)cus * 2 * p->wslab_stride * 4, 256) : 0;
-    const int64_t fixed = slab_bytes + oslab_bytes + wslab_bytes;
+    // bf16 backward from a store: slack tile slots behind the D region, for the waves of the last group that have no tile
+    const int64_t dslack = (bf && stored) ? (int64_t)(NCA_WAVES - 1) * 2 * p->tile_stride : 0;
+    const int64_t fixed = slab_bytes + oslab_bytes + wslab_bytes + align_up(dslack, 256);
     // scratch bytes per unit: f32 rows*32 floats per 32-sample tile; bf16 two 32-sample tiles per wave tile
     const int64_t per_unit = bf ? p->tile_stride * 2 * tiles_per_unit : p->tile_stride * tiles_per_unit * 32 * 4;
     int64_t upc = units;
@@ -513,8 +581,8 @@ static int plan_bwd(const NcaLayout* lays, int nnets, int32_t prec, int64_t unit
     p->off_slab = 0;
     p->off_oslab = slab_bytes;
     p->off_wslab = slab_bytes + oslab_bytes;
-    p->off_scratch = fixed;
-    p->bytes_total = p->off_scratch + align_up(per_unit * upc, 256);
+    p->off_scratch = slab_bytes + oslab_bytes + wslab_bytes;
+    p->bytes_total = fixed + align_up(per_unit * upc, 256);
     return NCA_OK;
 }
 
@@ -583,7 +651,7 @@ static void make_job_bf16(NcaWgradJob& g, const NcaLayout& y, int j, int64_t net
     } else {
         g.is_enc = 0;
         g.b_row0 = net_off + EB + nca_bf_hoff(y, j - 1, h8);
-        g.h8 = (h8 && j - 1 < y.NL - 2) ? 1 : 0;
+        g.h8 = h8 ? 1 : 0;
         g.b_row_bytes = y.F * 2;
         g.ncols_w = y.F;
         g.T = 0;
@@ -591,14 +659,23 @@ static void make_job_bf16(NcaWgradJob& g, const NcaLayout& y, int j, int64_t net
     }
 }
 // skip_layer: accumulated on chip by the dgrad kernel
+// wo_parts_off >= 0: fp8 staging -- the net's NL jobs share the output layer's weight gradient (block NL-1 of the store times the g
+// rows of the tile records), one slot of F floats each behind the slab's natural blocks
 static void add_jobs_bf16(NcaWgradArgs* w, int net_index, const NcaLayout& y, int64_t net_off, int64_t d_off, int64_t slab_off, int64_t onehot_off, int64_t enc_off,
-                          int skip_layer, bool h8, bool d8, int64_t dscale_off) {
+                          int skip_layer, bool h8, bool d8, int64_t dscale_off, int64_t wo_parts_off) {
+    const int64_t EB = 32 * (int64_t)NCA_BF_ENCROWS * 2;
     for (int j = 0; j < y.NL; ++j) {
         if (j == skip_layer) continue;
         NcaWgradJob& g = w->job[w->njobs++];
         make_job_bf16(g, y, j, net_off, d_off, slab_off, onehot_off, enc_off, h8, d8);
         g.net = net_index;
         g.dscale_off = dscale_off;
+        if (wo_parts_off >= 0 && !getenv("NCA_T_NO_OUTJOB")) {
+            g.out_nparts = y.NL;
+            g.out_part = j;
+            g.out_w_off = wo_parts_off + (int64_t)j * y.F;
+            g.out_b_row0 = net_off + EB + nca_bf_hoff(y, y.NL - 1, true);
+        }
     }
 }
 
@@ -628,10 +705,29 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     }
     // bf16 backward from a store: the weight gradient of the last hidden layer stays on chip (one launch per net)
     const int64_t oc_min = opt_value(NCA_OPT_ONCHIP_MIN_TILES);          // -1: never (see nca_set_option)
-    const bool onchip = oc_min >= 0 && bf && stored && units * tiles_per_unit >= oc_min;
-    const bool per_net_launch = onchip;
+    // fp8 staging: the store holds every layer's output, masks and raw outputs -- mode 5, nothing recomputed (the on-chip layer
+    // recomputes from a bf16 block: bf16 staging only)
+    const bool nr = h8;
+    const bool onchip = oc_min >= 0 && bf && stored && !nr && units * tiles_per_unit >= oc_min;
+    // ... or, without the on-chip layer, one launch per net with that net's weight images resident in LDS
+    const int64_t res_min = opt_value(NCA_OPT_RESIDENT_MIN_TILES);
+    bool res3 = !onchip && bf && stored && res_min >= 0 && units * tiles_per_unit >= res_min;
+    if (res3) {          // ... only if every net's images do fit (else: one launch for both nets, streaming)
+        for (int n = 0; n < a.nnets && res3; ++n) {
+            static thread_local NcaFusedArgs probe;
+            probe = a;
+            probe.nnets = 1;
+            probe.net[0] = a.net[n];
+            probe.ntiles = units * tiles_per_unit;
+            NetBind b1[2] = {binds[n], {}};
+            int rcp = build_stages(&probe, b1, true, nr ? 1 : 2);
+            if (rcp) return rcp;
+            res3 = plan_resident(&probe, nr ? NCA_KM_BWD_NR : NCA_KM_BWD_STORED);
+        }
+    }
+    const bool per_net_launch = onchip || res3;
     BwdPlan p;
-    int rc = plan_bwd(lays, a.nnets, prec, units, tiles_per_unit, work_bytes, &p, stored, onchip, d8);
+    int rc = plan_bwd(lays, a.nnets, prec, units, tiles_per_unit, work_bytes, &p, stored, onchip, d8, nr);
     if (rc) return rc;
     if (!work || work_bytes < p.bytes_total) return fail(NCA_E_WORKSPACE, "backward workspace %lld < %lld bytes", (long long)work_bytes, (long long)p.bytes_total);
     char* wb = static_cast<char*>(work);
@@ -639,7 +735,7 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     float* oslab = reinterpret_cast<float*>(wb + p.off_oslab);
     float* scratch = reinterpret_cast<float*>(wb + p.off_scratch);
 
-    rc = build_stages(&a, binds, true, stored ? (bf ? 2 : 1) : 0);
+    rc = build_stages(&a, binds, true, stored ? ((bf && !nr) ? 2 : 1) : 0);
     if (rc) return rc;
     int64_t off = 0, soff = 0;
     for (int n = 0; n < a.nnets; ++n) { a.net[n].row0 = off; off += bf ? nca_bf_tile_bytes(lays[n]) : scratch_rows(lays[n]); }
@@ -670,13 +766,15 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     int64_t slab_off[2] = {0, 0}, onehot_off[2] = {0, 0};
     for (int n = 0; n < a.nnets; ++n) { slab_off[n] = soff; soff += lays[n].n_params; }
     for (int n = 0; n < a.nnets; ++n) { onehot_off[n] = soff; soff += (int64_t)lays[n].F * lays[n].P; }
+    int64_t wo_parts_off[2] = {-1, -1};
+    if (nr) for (int n = 0; n < a.nnets; ++n) { wo_parts_off[n] = soff; soff += (int64_t)lays[n].NL * lays[n].F; }
 
     static thread_local NcaWgradArgs w;
     memset(&w, 0, sizeof(w));
     for (int n = 0; n < a.nnets; ++n) {
         if (bf) add_jobs_bf16(&w, n, lays[n], a.net[n].row0, a.net[n].drow0, slab_off[n], onehot_off[n],
                               stored && a.share_enc && n == 0 ? a.net[1].row0 : a.net[n].row0, onchip ? lays[n].NL - 1 : -1, h8, d8,
-                              p.tile_stride - NCA_D8_REC_BYTES);
+                              p.tile_stride - NCA_D8_REC_BYTES, wo_parts_off[n]);
         else add_jobs_f32(&w, lays[n], a.net[n].row0, a.net[n].drow0, slab_off[n], onehot_off[n]);
     }
     w.scratch = scratch;
@@ -725,14 +823,16 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
                 one.wslab = reinterpret_cast<float*>(wb + p.off_wslab) + (int64_t)n * num_cus() * p.wslab_stride;
                 one.wslab_stride = p.wslab_stride;
                 NetBind b1[2] = {binds[n], {}};
-                rc = build_stages(&one, b1, true, 2);
+                const int km = nr ? NCA_KM_BWD_NR : (onchip ? NCA_KM_BWD_ONCHIP : NCA_KM_BWD_STORED);
+                rc = build_stages(&one, b1, true, nr ? 1 : 2);
                 if (rc) return rc;
+                if (res3) plan_resident(&one, km);        // (does not fit: the streaming kernel, still one net per launch)
                 Span sp(NCA_K_BWD_DGRAD, st);
-                HIPCHK(nca_launch_fused_bf16(F, one, onchip ? NCA_KM_BWD_ONCHIP : NCA_KM_BWD_STORED, p.grid, st, d8));
+                HIPCHK(nca_launch_fused_bf16(F, one, km, p.grid, st, d8));
             }
         } else {
             Span sp(NCA_K_BWD_DGRAD, st);
-            if (bf) HIPCHK(nca_launch_fused_bf16(F, a, stored ? NCA_KM_BWD_STORED : NCA_KM_BWD, p.grid, st, d8));
+            if (bf) HIPCHK(nca_launch_fused_bf16(F, a, stored ? (nr ? NCA_KM_BWD_NR : NCA_KM_BWD_STORED) : NCA_KM_BWD, p.grid, st, d8));
             else HIPCHK(nca_launch_fused_f32(F, a, stored ? NCA_KM_BWD_STORED : NCA_KM_BWD, p.grid, st));
         }
         if (g_depth) {       // d loss / d depth from the D_0 blocks this chunk's dgrad launch just wrote
@@ -791,6 +891,8 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
         rn.w0_off = lays[n].layer[0].w_off;
         rn.lat_count = (int64_t)lays[n].P * lays[n].T;
         rn.wo_off = lays[n].wo_off;
+        rn.wo_parts = nr ? lays[n].NL : 0;
+        rn.wo_parts_off = wo_parts_off[n];
         if (onchip) {
             rn.wslab = reinterpret_cast<const float*>(wb + p.off_wslab) + (int64_t)n * num_cus() * p.wslab_stride;
             rn.wslab_stride = p.wslab_stride;
@@ -834,6 +936,13 @@ extern "C" int64_t nca_render_bwd_workspace(const NcaRays* rays, const NcaNet* n
     int64_t need = p.bytes_total;
     if (prec == NCA_PREC_BF16) {       // the on-chip variant of the backward from a store runs fewer jobs over more splits (more slabs)
         rc = plan_bwd(lays, nn, prec, rays->R, (rays->S + ts - 1) / ts, max_bytes, &p, true, true);
+        if (rc) return rc;
+        if (p.bytes_total > need) need = p.bytes_total;
+        // ... and fp8 staging runs one more job per net (the output layer's) and keeps a record per tile
+        rc = plan_bwd(lays, nn, prec, rays->R, (rays->S + ts - 1) / ts, max_bytes, &p, true, false, true, true);
+        if (rc) return rc;
+        if (p.bytes_total > need) need = p.bytes_total;
+        rc = plan_bwd(lays, nn, prec, rays->R, (rays->S + ts - 1) / ts, max_bytes, &p, true, false, false, true);
         if (rc) return rc;
         if (p.bytes_total > need) need = p.bytes_total;
     }
@@ -900,6 +1009,7 @@ extern "C" int nca_render_bwd_depth(const NcaRays* rays, int32_t prec,
             NetBind b1[2] = {binds[n], {}};
             rc = build_stages(&one, b1, false);
             if (rc) return rc;
+            if (prec == NCA_PREC_BF16) plan_resident(&one, NCA_KM_FWD);
             Span sp(NCA_K_FWD, st);
             if (prec == NCA_PREC_BF16) HIPCHK(nca_launch_fused_bf16(one.net[0].lay.F, one, false, grid, st));
             else HIPCHK(nca_launch_fused_f32(one.net[0].lay.F, one, false, grid, st));
@@ -952,6 +1062,7 @@ extern "C" int nca_mlp_fwd(const NcaNet* net, int32_t prec, const void* packed, 
     a.ntiles = (N + ts - 1) / ts;
     const int64_t ngroups = (a.ntiles + NCA_WAVES - 1) / NCA_WAVES;
     const int grid = (int)(ngroups < num_cus() ? ngroups : num_cus());
+    if (prec == NCA_PREC_BF16) plan_resident(&a, NCA_KM_FWD);
     Span sp(NCA_K_FWD, (hipStream_t)stream);
     if (prec == NCA_PREC_BF16) HIPCHK(nca_launch_fused_bf16(a.net[0].lay.F, a, false, grid, (hipStream_t)stream));
     else HIPCHK(nca_launch_fused_f32(a.net[0].lay.F, a, false, grid, (hipStream_t)stream));

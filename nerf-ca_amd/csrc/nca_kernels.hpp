@@ -4,6 +4,7 @@
 #include "nca_layout.hpp"
 
 #define NCA_NT 512      // threads per workgroup of the fused kernel: 8 waves, 2 per SIMD
+#define NCA_LDS_BYTES 163840   // LDS of a gfx950 compute unit (one workgroup of the fused kernels owns it)
 #define NCA_WAVES 8
 
 enum { NCA_MODE_RAYS = 0, NCA_MODE_POINTS = 1 };
@@ -11,7 +12,7 @@ enum { NCA_MODE_RAYS = 0, NCA_MODE_POINTS = 1 };
 struct NcaStage {
     const void* ptr;   // image in the packed buffer
     uint32_t bytes;    // multiple of 16
-    uint32_t pad;
+    uint32_t lds_off;  // bf16 kernels with resident images: where this image sits in LDS (images back to back, 16-byte granularity)
 };
 
 struct NcaNetArgs {
@@ -29,7 +30,9 @@ enum { NCA_KM_FWD = 0,          // forward
        NCA_KM_BWD = 1,          // recompute + output-layer gradients + dgrad; H, D and the input block go to ONE scratch
        NCA_KM_FWD_STORE = 2,    // forward that also writes the input block, every layer input, ReLU masks and raw outputs
        NCA_KM_BWD_STORED = 3,   // output-layer gradients + dgrad from that store (no recompute); D to the chunk scratch
-       NCA_KM_BWD_ONCHIP = 4 }; // mode 3 for one net, with the last hidden layer's weight gradient accumulated on chip
+       NCA_KM_BWD_ONCHIP = 4,   // mode 3 for one net, with the last hidden layer's weight gradient accumulated on chip
+       NCA_KM_BWD_NR = 5 };     // bf16, from a store with fp8 staging: NO recompute -- raw outputs and ReLU masks of all layers come
+                                // from the store, D_{NL-1} = mask (Wo x g); the output layer's weight gradient is the wgrad kernel's
 
 struct NcaFusedArgs {
     int32_t mode, nnets;
@@ -87,6 +90,11 @@ struct NcaFusedArgs {
     int32_t nstages;
     int32_t mask_layers; // backward: ReLU masks of this many layers per wave are kept in LDS (0: re-read H)
     int32_t const_net_floats; // f32 kernels: floats per net of the LDS constant area (window, fourier, latents), set by the launcher
+    int32_t res_bytes;   // bf16: > 0 = every weight image of this launch stays resident in LDS (stage[i].lds_off), this many bytes
+                         // in all
+    int32_t res_total;   // host only: bytes of all images of the launch laid back to back (build_stages)
+    int32_t split;       // bf16 forward, rays mode, one net per launch: 1 = static net (writes sig_s only), 2 = dynamic net (reads
+                         // sig_s, writes sig_d and the per-tile ray sums)
     int32_t raw_only;    // rays mode, forward: write the raw net output to raw_out[n] instead of compositing
                          // (rays mode, backward: a non-null g_raw replaces the compositing chain rule)
     NcaNetArgs net[2];
@@ -109,7 +117,11 @@ struct NcaWgradJob {
     int32_t fourier_L;    // bf16 input block of a fourier net: slots are (sin_i, cos_i) interleaved; 0 otherwise
     int32_t d8, h8;       // bf16 path: the D block is e5m2 scaled by the wave tile's power of two / the H block is e4m3 x 2^NCA_H8_LOG2
     int32_t net;          // ... which of the tile's two inverse scales applies
-    int32_t pad;
+    int32_t out_nparts;   // bf16 path, fp8 staging: > 0 = behind its own work this job's wave forms its share (part out_part of out_nparts
+                          // of the split's tiles) of the OUTPUT layer's weight gradient dWo[f] = sum_n g[n] H_{NL-1}[f][n], g from the tile
+                          // records, into the slab at out_w_off (one slot of F floats per job of the net: the reduce kernel adds them)
+    int32_t out_part;
+    int64_t out_w_off, out_b_row0;   // slab offset of that slot; byte offset of block NL-1 in a tile of the H region
     int64_t dscale_off;   // ... byte offset of the inverse-scale record inside a tile of the D region
 };
 
@@ -135,6 +147,9 @@ struct NcaReduceNet {
     int64_t onehot_off;
     int32_t F, T, P, K0, Kenc, w0_off;
     int64_t lat_count, wo_off;
+    int32_t wo_parts;      // bf16 with fp8 staging: > 0 = the output layer's weight gradient lies in the slabs, wo_parts slots of F floats
+    int32_t pad;           // per split at wo_parts_off (the wgrad kernel's waves); its bias gradient stays with the fused kernel's partials
+    int64_t wo_parts_off;
 };
 
 struct NcaReduceArgs {
@@ -239,5 +254,7 @@ hipError_t nca_launch_wgrad_f32(const NcaWgradArgs& a, int nsplit, hipStream_t s
 hipError_t nca_launch_reduce_f32(const NcaReduceArgs& a, hipStream_t st);
 hipError_t nca_launch_pack_bf16(const NcaLayout& y, const float* prm, void* out, hipStream_t st);
 hipError_t nca_launch_fused_bf16(int F, const NcaFusedArgs& a, int kmode, int grid, hipStream_t st, bool s8 = false);
+// LDS bytes a fused bf16 launch of this mode needs NEXT TO its weight images (constants, output-layer partials)
+size_t nca_fused_bf16_lds_other(int F, int kmode);
 hipError_t nca_launch_wgrad_bf16(int F, const NcaWgradArgs& a, int nsplit, hipStream_t st);
 hipError_t nca_launch_pix_f32(int64_t R, int nchunk, const float* I0, const double* part, double* pix, hipStream_t st);

@@ -203,9 +203,14 @@ struct BfCfg {
 
 #define NCA_CONST_WIN 16
 #define NCA_CONST_FOUR 48
-#define NCA_CONST_LAT 2048
+#define NCA_CONST_LAT 256       // the bf16 path takes at most 16 phases x 16 latent dimensions (nca_build_layout_bf16)
 #define NCA_CONST_NET_FLOATS (NCA_CONST_WIN + NCA_CONST_FOUR + NCA_CONST_LAT)
-#define NCA_CONST_BYTES (2 * NCA_CONST_NET_FLOATS * 4)
+// LDS constant area: encoding constants of both nets (modes that encode) or the waves' ReLU-mask slots (backward from a store)
+__host__ __device__ constexpr int bf_const_bytes(int kmode) {
+    return (kmode == NCA_KM_BWD_STORED || kmode == NCA_KM_BWD_ONCHIP || kmode == NCA_KM_BWD_NR) ? NCA_WAVES * 2048 : 2 * NCA_CONST_NET_FLOATS * 4;
+}
+// mode 5: [Wo | bo] of both nets in accumulator order, f32, behind the output-layer partials
+__host__ __device__ constexpr int bf_wo_floats(int F) { return 2 * (F / 32) * 16 + 16; }
 
 __device__ __forceinline__ void stage_issue_b(const NcaStage& st, char* dst, int wave, int lane) {
     const int npiece = (int)(st.bytes >> 10);
@@ -252,6 +257,12 @@ __device__ __forceinline__ void lds_barrier() {
 #define NCA_BF_PF 3
 #endif
 constexpr int NCA_BF_RING = 4;
+// Software pipelining of the row-tile loops (epilogue of row tile m - 1 behind the MFMAs of row tile m, in one basic block so that
+// the scheduler interleaves them).  Measured at the bench size: forward unchanged (it is bound by its stores: 2.0 ms per net with
+// the MFMAs removed, 2.6 with them), backward sweep 10 % SLOWER (32 more live registers -> spills).  Off.
+#ifndef NCA_BF_PIPE
+#define NCA_BF_PIPE 0
+#endif
 static_assert(NCA_BF_PF >= 1 && NCA_BF_PF < NCA_BF_RING, "prefetch distance must fit the ring");
 // RING registers, prefetch distance RING - 1 (the default ring of 4 for the MFMA-bound modes; the on-chip backward, which is
 // bound by its stores and short of registers, uses a ring of 2)
@@ -370,11 +381,15 @@ __device__ __forceinline__ void transpose_block8(const u32x4 (&X)[NX], int lc, i
 // ------------------------------------------------------------------------------------------
 // S8 (modes 2, 3, 4): fp8 staging -- the storing forward writes the hidden blocks 0..NL-3 as e4m3, the backward from the store
 // writes D_0..D_{NL-2} as e5m2 scaled by a power of two per 64-sample tile (nca_layout.hpp)
-template <int F, int MODE, bool S8>
+// RES (modes 0, 2, 3 with ONE net per launch): every weight image of the launch is RESIDENT in LDS (NcaStage::lds_off, loaded once
+// per workgroup); the tile loop then has no weight DMA, no counted waits and no workgroup barrier -- the eight waves drift apart
+// and fill each other's epilogue and store slots.  The streaming variant double-buffers one image per stage behind a barrier.
+template <int F, int MODE, bool S8, bool RES>
 __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a) {
     constexpr bool ONCHIP = MODE == NCA_KM_BWD_ONCHIP;                        // mode 3 + on-chip dW of the last hidden layer
+    constexpr bool NR = MODE == NCA_KM_BWD_NR;                                // from a store with fp8 staging: nothing is recomputed
     constexpr int RINGK = ONCHIP ? 2 : NCA_BF_RING;                           // A-fragment ring of the layer contractions
-    constexpr bool STORED = MODE == NCA_KM_BWD_STORED || ONCHIP;
+    constexpr bool STORED = MODE == NCA_KM_BWD_STORED || ONCHIP || NR;
     constexpr bool BWD = MODE == NCA_KM_BWD || STORED;                        // output-layer gradients + dgrad sweep
     constexpr bool STORE = MODE == NCA_KM_BWD || MODE == NCA_KM_FWD_STORE;    // writes the input block and the layer inputs
     constexpr bool RECOMP = !STORED;                                          // runs the forward layers
@@ -384,14 +399,27 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
     constexpr int HB = 32 * F * 2;                          // bytes of one hidden scratch block (32 samples x F)
     constexpr int EB = 32 * NCA_BF_ENCROWS * 2;             // bytes of the input block
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* cst = reinterpret_cast<float*>(smem + 2 * BUF);
-    float* osum = reinterpret_cast<float*>(smem + 2 * BUF + NCA_CONST_BYTES);
+    static_assert(!RES || MODE == NCA_KM_FWD || MODE == NCA_KM_FWD_STORE || MODE == NCA_KM_BWD_STORED || NR, "resident images: forward and backward from the store");
+    const int wbytes = RES ? a.res_bytes : 2 * BUF;             // weight images: all of them / the double buffer
+    constexpr int CONSTB = bf_const_bytes(MODE);
+    float* cst = reinterpret_cast<float*>(smem + wbytes);
+    float* osum = reinterpret_cast<float*>(smem + wbytes + CONSTB);
     // ReLU masks of the recomputed layers: [wave][layer][lane][16 B] (2 bits per packed bf16 pair)
-    char* const maskbase = smem + 2 * BUF + NCA_CONST_BYTES + NCA_WAVES * 2 * (F + 1) * 4;
+    char* const maskbase = smem + wbytes + CONSTB + NCA_WAVES * 2 * (F + 1) * 4;
+    float* const wo_lds = reinterpret_cast<float*>(maskbase);          // mode 5 (no other use of that area there)
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
     if (S8) s8_mode();
 
+    if (RES) {
+        // the images sit back to back at 16-byte granularity while the DMA moves whole 1 KiB pieces: the padding behind an image
+        // lands on the start of the next one (behind the last: on the constant area), so they go in one after the other
+        for (int i = 0; i < a.nstages; ++i) {
+            stage_issue_b(a.stage[i], smem + a.stage[i].lds_off, wave, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
     for (int net = 0; RECOMP && net < a.nnets; ++net) {
         const NcaNetArgs& na = a.net[net];
         float* c = cst + net * NCA_CONST_NET_FLOATS;
@@ -400,9 +428,18 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
         if (na.lat) for (int i = tid; i < na.lay.P * na.lay.T; i += NCA_NT) c[NCA_CONST_WIN + NCA_CONST_FOUR + i] = na.lat[i];
     }
     if (BWD) for (int i = tid; i < NCA_WAVES * 2 * (F + 1); i += NCA_NT) osum[i] = 0.f;
+    if (NR)
+        for (int net = 0; net < a.nnets; ++net)
+            for (int i = tid; i < 2 * MT * 16 + 1; i += NCA_NT) wo_lds[net * bf_wo_floats(F) + i] = a.net[net].wo_src[i];
     __syncthreads();
-    stage_issue_b(a.stage[0], smem, wave, lane);
-    stage_publish_b();
+#if NCA_EXP & 65536
+    // (65536: shader clock of this launch = s_memtime ticks per 100 MHz s_memrealtime tick, printed by one wave at the end)
+    const unsigned long long clk_t0 = __builtin_readcyclecounter(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (!RES) {
+        stage_issue_b(a.stage[0], smem, wave, lane);
+        stage_publish_b();
+    }
     int cur = 0, si = 0;
 
     // On-chip weight gradient of the last hidden layer (mode 3, one net per launch): the MT x MT blocks of dW are shared
@@ -419,6 +456,13 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
         for (int q = 0; q < BPW * 16; ++q) park[q * 64] = 0.f;
     }
 
+#if NCA_EXP & 131072
+    // (131072: where a wave's cycles go -- s_memtime stamps between the phases of a tile, summed over the tiles of one wave)
+    unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#define NCA_STAMP(k) { const unsigned long long t_ = __builtin_readcyclecounter(); tph[k] += t_ - tlast; tlast = t_; }
+#else
+#define NCA_STAMP(k)
+#endif
     const int64_t ngroups = (a.ntiles + NCA_WAVES - 1) / NCA_WAVES;
     for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         const int64_t tile = grp * NCA_WAVES + wave;           // 64-sample tile
@@ -457,17 +501,28 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
 #pragma unroll
             for (int c = 0; c < 3; ++c) p[c] = RECOMP ? a.pts[n * 3 + c] : 0.f;
         }
+        // second launch of a split render: the static net's sigma, written by the first launch
+        float ss_other = 0.f;
+        if (!BWD && a.split == 2 && valid) ss_other = a.sig_s[n];
         int ph = 0;
         if (RECOMP && a.phase) ph = a.mode == NCA_MODE_RAYS ? a.phase[ray * a.ps_r + (int64_t)smp * a.ps_s] : a.phase[n];
 
         // Scratch: two 32-sample tiles per wave, fragment-major blocks (see nca_bf_tile_bytes).  The input block and the
         // layer inputs live in the H region (indexed by the tile's position in the whole batch when a stored forward
         // wrote it), the output gradients in the D region of this launch; the recompute backward uses one for both.
-        const int64_t tg = tl + a.tile0;
+        // A wave without a tile (the batch's last group) works on the last tile once more.  Where a region is only WRITTEN -- the
+        // storing forward's store, the D region of a backward from the store -- it writes that copy to its own slot: both
+        // regions end in slack slots up to the next multiple of the 8 waves, so the hot loops store without a predicate.
+        const int64_t tg = (FSTORE ? tile : tl) + a.tile0;
         char* const t32 = (BWD || STORE) ? reinterpret_cast<char*>(a.scratch) + (tg * 2) * a.rows_total : nullptr;   // rows_total = bytes per 32-sample tile
+#ifdef NCA_T_PRED
         char* const d32 = BWD ? a.dscratch + (tl * 2) * a.d_total : nullptr;
+#else
+        char* const d32 = BWD ? a.dscratch + ((STORED ? tile : tl) * 2) * a.d_total : nullptr;
+#endif
 
         float raw[2] = {0.f, 0.f};
+        NCA_STAMP(0)                            // tile prologue: sample positions
 
 #pragma unroll
         for (int net = 0; net < 2; ++net) {
@@ -552,7 +607,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                         B[0][s][w] = r[0];
                         B[1][s][w] = r[1];
                     }
-                if (STORE && tvalid && !(a.share_enc && net == 0)) {
+                if (STORE && (FSTORE || tvalid) && !(a.share_enc && net + a.net_base == 0)) {
                     // input block of both column tiles, fragment-major [k-step][lane][16 B]: the layer-0
                     // operands as they sit in registers, then one k-step of one-hot phase slots
 #pragma unroll
@@ -573,6 +628,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                 }
             }
 
+            NCA_STAMP(1)                        // encoding + input block
             // S8: inverse of the power of two by which this tile's output gradients are scaled on their way to e5m2 (the chain
             // itself stays unscaled bf16: the scaling is part of the conversion)
             float inv_s = 1.f;
@@ -607,8 +663,45 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                     float* orow = osum + (wave * 2 + net) * (F + 1);
                     char* const dblk = db + nca_bf_doff(y, y.NL - 1, S8 && STORED);
                     u32x4 Bn[2][2 * MT];
+                    if (NR) {
+                        // the output layer's weight gradient is the wgrad kernel's: it reads g from the tile records (lane = sample)
+                        *reinterpret_cast<float*>(d32 + lh * a.d_total + a.dscale_off + NCA_D8_REC_G + (net + a.net_base) * 128 + lr * 4) = g;
+                        // D_{NL-1} = relu'(H_{NL-1}) (Wo x g): the layer's mask bits arrived by DMA (requested at the top of the net; the
+                        // loads of raw / g since then have returned, and the queue is in order)
+                        asm volatile("s_waitcnt vmcnt(1)" ::: "memory");          // (1: the store just issued)
+                        const u32x4 mv = *reinterpret_cast<const u32x4*>(mslot + ((y.NL - 1) & 1) * 1024 + lane * 16);
+                        if (y.NL >= 2) mask_dma(y.NL - 2);
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+                            for (int c = 0; c < 2; ++c) {
+                                const unsigned fld = mv[2 * c + (m >> 1)] >> (8 * (m & 1));
+                                u32x4 q8 = {0u, 0u, 0u, 0u};
+#pragma unroll
+                                for (int s2 = 0; s2 < 2; ++s2) {
+                                    u32x4 dw;
+#pragma unroll
+                                    for (int u = 0; u < 4; ++u) {
+                                        const float a0 = wo[(lh * MT + m) * 16 + 8 * s2 + 2 * u] * gc[c];
+                                        const float a1 = wo[(lh * MT + m) * 16 + 8 * s2 + 2 * u + 1] * gc[c];
+                                        const unsigned two = (fld >> (4 * s2 + u)) & 0x00010001u;
+                                        dw[u] = pack2_pk(a0, a1) & (two * 0xffffu);
+                                    }
+                                    Bn[c][2 * m + s2] = dw;
+                                    if (S8) {
+                                        q8[2 * s2] = cvt4_e5m2_pk(dw[0], dw[1], inv_s);
+                                        q8[2 * s2 + 1] = cvt4_e5m2_pk(dw[2], dw[3], inv_s);
+                                    } else {
+                                        store_nt(dblk + c * a.d_total + lane * 16 + (2 * m + s2) * 1024, dw);
+                                    }
+                                }
+                                if (S8) store_nt(dblk + c * a.d_total + lane * 16 + m * 1024, q8);
+                            }
+                        }
+                    }
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
+                        if (NR) break;
                         // H_last of this row tile back to f32 (both column tiles), in accumulator register order
                         float hv[2][16];
 #pragma unroll
@@ -621,10 +714,10 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                         // dWo[f] = sum_n g H[f][n]: reduce-scatter the 16 values over the 32 lanes of each half
                         float v[16];
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) v[i] = gc[0] * hv[0][i] + gc[1] * hv[1][i];
+                        for (int i = 0; i < 16; ++i) v[i] = (NCA_EXP & 262144) ? 0.f : gc[0] * hv[0][i] + gc[1] * hv[1][i];
                         int cnt = 16;
 #pragma unroll
-                        for (int d = (NCA_EXP & 4) ? 0 : 16; d >= 1; d >>= 1) {
+                        for (int d = (NCA_EXP & (4 | 262144)) ? 0 : 16; d >= 1; d >>= 1) {
                             if (cnt >= 2) {
                                 const int hn = cnt / 2;
                                 const bool up = (lr & d) != 0;
@@ -655,12 +748,16 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                                 Bn[c][2 * m][u] = pack2(dv[2 * u], dv[2 * u + 1]);
                                 Bn[c][2 * m + 1][u] = pack2(dv[8 + 2 * u], dv[8 + 2 * u + 1]);
                             }
+#ifdef NCA_T_PRED
                             if (S8 && STORED && tvalid && !ONCHIP && !(NCA_EXP & 1)) {
+#else
+                            if (S8 && STORED && !ONCHIP && !(NCA_EXP & 1)) {
+#endif
                                 u32x4 q8;
 #pragma unroll
                                 for (int w = 0; w < 4; ++w) q8[w] = cvt4_e5m2_pk(Bn[c][2 * m + (w >> 1)][2 * (w & 1)], Bn[c][2 * m + (w >> 1)][2 * (w & 1) + 1], inv_s);
                                 store_nt(dblk + c * a.d_total + lane * 16 + m * 1024, q8);
-                            } else if (tvalid && !ONCHIP) {
+                            } else if ((STORED || tvalid) && !ONCHIP) {
                                 char* fp2 = dblk + c * a.d_total + lane * 16;
                                 store_nt(fp2 + (2 * m) * 1024, Bn[c][2 * m]);
                                 store_nt(fp2 + (2 * m + 1) * 1024, Bn[c][2 * m + 1]);
@@ -678,7 +775,13 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
 
             // ================= layers (forward / recompute) ===============================================
             float part[2] = {0.f, 0.f};       // output-layer partial dot per column tile
-            if (STORED) {
+            if (NR) {
+                // nothing to recompute: the raw output and the masks of every layer are in the store
+                mask_dma(y.NL - 1);
+                raw[net] = a.rstore[((tg * 2 + net + a.net_base) * 64) + lane];
+                last_layer_grads(wo_lds + net * bf_wo_floats(F));
+            }
+            if (STORED && !NR) {
                 // the backward from the store recomputes ONE layer, the last: its input is in the store anyway (the wgrad
                 // reads it too), which saves the forward from writing that layer's output and the raw outputs
                 const char* hl = nb + EB + nca_bf_hoff(y, y.NL - 2, a.h8 != 0) + lane * 16;
@@ -690,33 +793,33 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                         B[c][k] = (NCA_EXP & 16384) ? (u32x4){0x3f803f80u + (unsigned)lane, 0x3f003f80u, 0x3f803f00u, 0x3e803f80u}        // (no loads of the last layer's input)
                                   : ONCHIP ? *reinterpret_cast<const u32x4*>(hl + c * a.rows_total + k * 1024) : load_nt(hl + c * a.rows_total + k * 1024);
             }
-            for (int jj = STORED ? y.NL - 1 : 0; jj < y.NL; ++jj) {
+            for (int jj = NR ? y.NL : (STORED ? y.NL - 1 : 0); jj < y.NL; ++jj) {
                 const NcaLayerL& l = y.layer[jj];
                 const int nsi = (si + 1 == a.nstages) ? 0 : si + 1;
-                if (!(NCA_EXP & 8)) stage_issue_b(a.stage[nsi], smem + (cur ^ 1) * BUF, wave, lane);
-                const char* img = smem + cur * BUF;
+                if (!RES && !(NCA_EXP & 8)) stage_issue_b(a.stage[nsi], smem + (cur ^ 1) * BUF, wave, lane);
+                const char* img = RES ? smem + a.stage[si].lds_off : smem + cur * BUF;
                 const int nks = l.ksteps;
                 const float* tail = reinterpret_cast<const float*>(img + MT * nks * 1024);
                 const bool last = jj == y.NL - 1;
-                const bool store_h = STORE && tvalid && !last && !((NCA_EXP & 16) && FSTORE);
-                const bool h8 = S8 && FSTORE && jj < y.NL - 2;                    // this layer's output crosses HBM as e4m3
+                const bool h8 = S8 && FSTORE;                                     // fp8 staging: EVERY layer's output goes to the store, as e4m3
                 char* const hblk = STORE ? nb + EB + nca_bf_hoff(y, jj, S8 && FSTORE) : nullptr;          // input block of layer jj+1
                 u32x4 Bn[2][2 * MT];
                 unsigned mw[2][2] = {{0u, 0u}, {0u, 0u}};     // mask words: [column tile][row-tile pair]
                 const char* imgl = img + lane * 16;
-                // one instantiation per k-step count (encoded layer / hidden layers): no control-flow join inside the
-                // row-tile loop, so accumulators and ring registers are never copied at a merge point
-                auto rowtiles = [&](auto nks_c) __attribute__((always_inline)) {
+                // One instantiation per (k-step count, last layer?, e4m3 output?): the row-tile loop has no branch in it, so the
+                // scheduler may move the epilogue's vector ALU work (pack, ReLU, mask bits, conversion: ~100 instructions per row
+                // tile) into the shadow of the MFMAs around it (NCA_BF_PIPE: explicitly one row tile behind).
+                // The storing forward writes unconditionally: a wave without a tile recomputes the batch's last tile and writes
+                // it to the slack tile slots behind the store (store_plan rounds the tile count up to the 8 waves).
+                const bool st_ok = FSTORE ? true : tvalid;
+                auto rowtiles = [&](auto nks_c, auto last_c, auto h8_c) __attribute__((always_inline)) {
                 constexpr int NKS = decltype(nks_c)::value;
+                constexpr bool LAST = decltype(last_c)::value, H8 = decltype(h8_c)::value;
+                constexpr bool NOH = (NCA_EXP & 16) && FSTORE, NOM = (NCA_EXP & 32) && FSTORE;
                 u32x4 A[RINGK];
                 ring_prime<NKS, MT, RINGK>(imgl, A);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    f32x16 acc0, acc1;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) { const float b = tail[(lh * MT + m) * 16 + i]; acc0[i] = b; acc1[i] = b; }
-                    mma_rowtile_ring<NKS, MT, KSMAX, RINGK>(imgl, m, A, B, acc0, acc1);
-                    if (last) {
+                auto epilogue = [&](int m, f32x16& acc0, f32x16& acc1) __attribute__((always_inline)) {
+                    if (LAST) {
                         // the output layer's dot product takes the f32 activations
 #pragma unroll
                         for (int i = 0; i < 16; ++i) { acc0[i] = relu1(acc0[i]); acc1[i] = relu1(acc1[i]); }
@@ -744,7 +847,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                             Bn[1][2 * m + 1][u] = relu_pk(pack2_pk(acc1[8 + 2 * u], acc1[8 + 2 * u + 1]));
                         }
                     }
-                    if (STORE && !last && !((NCA_EXP & 32) && FSTORE)) {
+                    if (STORE && (!LAST || H8) && !NOM) {
                         // bit k / 16+k of a field: low / high bf16 of packed word k (k = 4*(fragment&1) + u) is > 0
 #pragma unroll
                         for (int c = 0; c < 2; ++c) {
@@ -754,31 +857,67 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                             mw[c][m >> 1] |= fld << (8 * (m & 1));
                         }
                     }
-                    if (S8 && FSTORE && store_h && h8) {
+                    if (STORE && !NOH && H8) {
                         // e4m3 of the bf16 activations (x 2^NCA_H8_LOG2): byte i = register i, [row tile][lane][16 B]
                         constexpr float DIV = 1.f / (float)(1 << NCA_H8_LOG2);
 #pragma unroll
                         for (int c = 0; c < 2; ++c) {
                             u32x4 q;
 #pragma unroll
-                            for (int w = 0; w < 4; ++w) q[w] = (NCA_EXP & 32) ? Bn[c][2 * m + (w >> 1)][2 * (w & 1)] : cvt4_e4m3_pk(Bn[c][2 * m + (w >> 1)][2 * (w & 1)], Bn[c][2 * m + (w >> 1)][2 * (w & 1) + 1], DIV);
-                            store_nt(hblk + c * a.rows_total + lane * 16 + m * 1024, q);
+                            for (int w = 0; w < 4; ++w) q[w] = NOM ? Bn[c][2 * m + (w >> 1)][2 * (w & 1)] : cvt4_e4m3_pk(Bn[c][2 * m + (w >> 1)][2 * (w & 1)], Bn[c][2 * m + (w >> 1)][2 * (w & 1) + 1], DIV);
+                            if (st_ok) store_nt(hblk + c * a.rows_total + lane * 16 + m * 1024, q);
                         }
-                    } else if (store_h) {
+                    } else if (STORE && !LAST && !NOH) {
                         // the next layer's B-operand fragments exactly as they sit in registers: 1 KiB per
                         // wave instruction, [k-step][lane][16 B] (feature order inside a tile is the
                         // accumulator->operand order; the wgrad un-permutes when it writes dW)
 #pragma unroll
                         for (int c = 0; c < 2; ++c) {
                             char* fp2 = hblk + c * a.rows_total + lane * 16;
-                            store_nt(fp2 + (2 * m) * 1024, Bn[c][2 * m]);
-                            store_nt(fp2 + (2 * m + 1) * 1024, Bn[c][2 * m + 1]);
+                            if (st_ok) {
+                                store_nt(fp2 + (2 * m) * 1024, Bn[c][2 * m]);
+                                store_nt(fp2 + (2 * m + 1) * 1024, Bn[c][2 * m + 1]);
+                            }
                         }
                     }
-                }
                 };
-                if (jj == 0) rowtiles(std::integral_constant<int, KS0>{});
-                else rowtiles(std::integral_constant<int, KS>{});
+                f32x16 pend0, pend1;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    f32x16 acc0, acc1;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { const float b = tail[(lh * MT + m) * 16 + i]; acc0[i] = b; acc1[i] = b; }
+                    if (!(NCA_EXP & 128)) mma_rowtile_ring<NKS, MT, KSMAX, RINGK>(imgl, m, A, B, acc0, acc1);
+                    else { acc0[0] += __builtin_bit_cast(float, B[0][m][0]); acc1[3] += __builtin_bit_cast(float, B[1][m][1]); }       // (128: no MFMAs)
+                    if (NCA_BF_PIPE) {
+                        if (m > 0) epilogue(m - 1, pend0, pend1);
+                        pend0 = acc0; pend1 = acc1;
+                    } else {
+                        epilogue(m, acc0, acc1);
+#ifndef NCA_T_NOFENCE
+                        __builtin_amdgcn_sched_barrier(0);       // one row tile at a time: without the fence the scheduler overlaps row tiles and spills
+#endif
+                    }
+                }
+                if (NCA_BF_PIPE) epilogue(MT - 1, pend0, pend1);
+                };
+                {
+                    const std::integral_constant<int, KS0> ks0c{};
+                    const std::integral_constant<int, KS> ksc{};
+                    const std::true_type yes{};
+                    const std::false_type no{};
+                    if constexpr (STORED) {
+                        if (!(NCA_EXP & 262144)) rowtiles(ksc, yes, no);                  // the recomputed last layer (a store exists only for NL >= 2)
+                        else { for (int c = 0; c < 2; ++c) for (int k = 0; k < 2 * MT; ++k) Bn[c][k] = B[c][k]; }      // (262144: no recompute, no dWo)
+                    } else if constexpr (S8 && FSTORE) {
+                        if (jj == 0) { if (last) rowtiles(ks0c, yes, yes); else rowtiles(ks0c, no, yes); }
+                        else { if (last) rowtiles(ksc, yes, yes); else rowtiles(ksc, no, yes); }
+                    } else {
+                        if (jj == 0) { if (last) rowtiles(ks0c, yes, no); else rowtiles(ks0c, no, no); }
+                        else { if (last) rowtiles(ksc, yes, no); else rowtiles(ksc, no, no); }
+                    }
+                }
+                NCA_STAMP(jj == 0 ? 2 : (last ? 4 : 3))        // layer 0 / hidden layers / last layer: MFMAs + epilogue + stores
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -787,7 +926,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                     u32x4 mv = {mw[0][0], mw[0][1], mw[1][0], mw[1][1]};
                     *reinterpret_cast<u32x4*>(mwave + jj * 1024) = mv;
                 }
-                if (FSTORE && !last && tvalid) {
+                if (FSTORE && (!last || S8)) {
                     u32x4 mv = {mw[0][0], mw[0][1], mw[1][0], mw[1][1]};
                     store_nt(mglob + jj * 1024, mv);
                 }
@@ -799,6 +938,8 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                     const float r0 = part[0] + __shfl_xor(part[0], 32) + bo;
                     const float r1 = part[1] + __shfl_xor(part[1], 32) + bo;
                     raw[net] = lh ? r1 : r0;
+                    // fp8 staging: the raw output goes to the store as well ([wave tile][net][64] f32), the backward recomputes nothing
+                    if (FSTORE && S8) a.rstore[((tg * 2 + net + a.net_base) * 64) + lane] = raw[net];
                 }
 
                 if (BWD && last) last_layer_grads(tail + 2 * MT * 16);
@@ -899,20 +1040,36 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                 // at least 4 MT stores follow the weight DMA of every storing stage: H (plus a mask store in the storing
                 // forward, which it then also waits for), or D_{NL-1} on the last layer of both backward modes; the last
                 // layer of the storing forward stores nothing
-                if ((S8 && FSTORE && h8) || (S8 && STORED && last && !ONCHIP)) stage_publish_counted<2 * MT>(tvalid);   // 2 MT 8-bit stores (+ the mask store)
-                else if ((STORE && !last) || (BWD && last && !ONCHIP)) stage_publish_counted<4 * MT>(tvalid);
+                NCA_STAMP(5)                    // masks, raw output, output-layer gradients, on-chip dW
+                if (RES) {}                                             // nothing to publish, nothing to wait for
+                else if ((S8 && FSTORE && h8) || (S8 && STORED && last && !ONCHIP)) stage_publish_counted<2 * MT>(FSTORE || STORED || tvalid);   // 2 MT 8-bit stores (+ the mask store, + the raw outputs)
+                else if ((STORE && !last) || (BWD && last && !ONCHIP)) stage_publish_counted<4 * MT>(FSTORE || STORED || tvalid);
                 else stage_publish_b();
                 cur ^= 1;
                 si = nsi;
+                NCA_STAMP(6)                    // publish: counted wait + barrier
             }
 
             // ================= backward sweep (dgrad) =====================================================
             if (BWD) {
                 for (int jj = y.NL - 1; jj >= 1; --jj) {
                     const int nsi = (si + 1 == a.nstages) ? 0 : si + 1;
-                    if (!(NCA_EXP & 8)) stage_issue_b(a.stage[nsi], smem + (cur ^ 1) * BUF, wave, lane);
+                    if (NR) {
+                        // this layer's masks were requested before the D stores of the step before (the output layer's step or the
+                        // previous iteration): at most those stores are younger
+                        constexpr int NSTM = S8 ? 2 * MT : 4 * MT;
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTM) : "memory");
+                    }
+                    if (!RES && !(NCA_EXP & 8)) stage_issue_b(a.stage[nsi], smem + (cur ^ 1) * BUF, wave, lane);
                     if (STORED && jj >= 2) mask_dma(jj - 2);            // for the next iteration; this one's arrived under the previous stage
-                    const char* img = smem + cur * BUF;
+                    if (RES && !NR) {
+                        // this layer's masks were requested one layer ago (or before the last layer's input): behind them are at
+                        // most the D stores of that layer and the request just made
+                        constexpr int NST = S8 ? 2 * MT : 4 * MT;
+                        if (jj >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST + 1) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+                    }
+                    const char* img = RES ? smem + a.stage[si].lds_off : smem + cur * BUF;
                     const char* const hblk = nb + EB + (jj - 1) * HB;                       // input of layer jj (mask)
                     char* const dblk = db + nca_bf_doff(y, jj - 1, S8 && STORED);            // D_{jj-1}
                     const bool wr_d = tvalid;
@@ -924,13 +1081,15 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                     u32x4 A[RINGK];
                     const char* imgl = img + lane * 16;
                     ring_prime<KS, MT, RINGK>(imgl, A);
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) {
-                        f32x16 acc0, acc1;
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-                        if (!(NCA_EXP & 128)) mma_rowtile_ring<KS, MT, KSMAX, RINGK>(imgl, m, A, B, acc0, acc1);
-                        else { acc0[0] = __builtin_bit_cast(float, B[0][m][0]); acc1[3] = __builtin_bit_cast(float, B[1][m][1]); }
+                    // software-pipelined like the forward layers: the epilogue of row tile m - 1 (mask, pack, e5m2, stores) shares a
+                    // basic block with the MFMAs of row tile m.  From a store the D blocks are written without a predicate (slack
+                    // tile slots behind the D region take the copies of waves that have no tile)
+#ifdef NCA_T_PRED
+                    const bool st_ok = wr_d;
+#else
+                    const bool st_ok = STORED ? true : wr_d;
+#endif
+                    auto epilogue = [&](int m, const f32x16& acc0, const f32x16& acc1) __attribute__((always_inline)) {
 #pragma unroll
                         for (int c = 0; c < 2; ++c) {
                             const char* hp = hblk + c * a.rows_total + lane * 16;
@@ -958,18 +1117,39 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                                 else if (S8 && STORED) {
                                     q8[2 * s2] = cvt4_e5m2_pk(dw[0], dw[1], inv_s);
                                     q8[2 * s2 + 1] = cvt4_e5m2_pk(dw[2], dw[3], inv_s);
-                                } else if (wr_d && !(NCA_EXP & 1)) store_nt(dp + (2 * m + s2) * 1024, dw);
+                                } else if (st_ok && !(NCA_EXP & 1)) store_nt(dp + (2 * m + s2) * 1024, dw);
                             }
-                            if (S8 && STORED && wr_d && !(NCA_EXP & 1)) store_nt(dp + m * 1024, q8);
+                            if (S8 && STORED && st_ok && !(NCA_EXP & 1)) store_nt(dp + m * 1024, q8);
+                        }
+                    };
+                    f32x16 pend0, pend1;
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        f32x16 acc0, acc1;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+                        if (!(NCA_EXP & 128)) mma_rowtile_ring<KS, MT, KSMAX, RINGK>(imgl, m, A, B, acc0, acc1);
+                        else { acc0[0] = __builtin_bit_cast(float, B[0][m][0]); acc1[3] = __builtin_bit_cast(float, B[1][m][1]); }
+                        if (NCA_BF_PIPE) {
+                            if (m > 0) epilogue(m - 1, pend0, pend1);
+                            pend0 = acc0; pend1 = acc1;
+                        } else {
+                            epilogue(m, acc0, acc1);
+#ifndef NCA_T_NOFENCE
+                            __builtin_amdgcn_sched_barrier(0);
+#endif
                         }
                     }
+                    if (NCA_BF_PIPE) epilogue(MT - 1, pend0, pend1);
 #pragma unroll
                     for (int c = 0; c < 2; ++c)
 #pragma unroll
                         for (int k = 0; k < 2 * MT; ++k) B[c][k] = Bn[c][k];
-                    stage_publish_counted<(S8 && STORED) ? 2 * MT : 4 * MT>(wr_d);               // D stores
+                    NCA_STAMP(3)
+                    if (!RES) stage_publish_counted<(S8 && STORED) ? 2 * MT : 4 * MT>(st_ok);              // D stores
                     cur ^= 1;
                     si = nsi;
+                    NCA_STAMP(6)
                 }
             }
         }  // nets
@@ -978,7 +1158,17 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
         if (!BWD) {
             if (a.mode == NCA_MODE_RAYS && !a.raw_only) {
                 double term;
-                if (a.single) {
+                if (a.split) {
+                    // one net per launch (resident weights): launch 1 = static net, writes its scaled sigma and nothing else;
+                    // launch 2 = dynamic net, composites with the sigma of launch 1
+                    const float sg = __fmul_rn(act_fwd_b(a.act, raw[0]), a.scale);
+                    if (a.split == 1) {
+                        if (valid) a.sig_s[n] = sg;
+                        continue;
+                    }
+                    if (valid) a.sig_d[n] = sg;
+                    term = (double)__fadd_rn(ss_other, sg) * a.dists[smp];
+                } else if (a.single) {
                     const float sa = act_fwd_b(a.act, raw[0]);
                     if (valid) a.sig_s[n] = sa;
                     term = ((double)sa * a.dists[smp]) * (double)a.scale;
@@ -995,7 +1185,17 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                 if (valid) a.raw_out[n] = raw[0];
             }
         }
+        NCA_STAMP(7)                            // tile epilogue
     }  // tile groups
+#if NCA_EXP & 131072
+    if (lane == 0 && (wave == 0 || wave == 5) && (blockIdx.x == 3 || blockIdx.x == 200)) {
+        unsigned long long tot = 0;
+        for (int k = 0; k < 8; ++k) tot += tph[k];
+        printf("mode %d res %d block %d wave %d: cycles %llu = prologue %.1f%% enc %.1f%% layer0 %.1f%% hidden %.1f%% last %.1f%% tail-of-layer %.1f%% publish %.1f%% epilogue %.1f%%\n", MODE, (int)RES,
+               (int)blockIdx.x, wave, tot, 100.0 * tph[0] / tot, 100.0 * tph[1] / tot, 100.0 * tph[2] / tot, 100.0 * tph[3] / tot, 100.0 * tph[4] / tot, 100.0 * tph[5] / tot,
+               100.0 * tph[6] / tot, 100.0 * tph[7] / tot);
+    }
+#endif
 
     if (ONCHIP) {
         // dW blocks and bias sums of the on-chip layer -> this workgroup's slab, natural [o][i] order (both indices of a
@@ -1035,6 +1235,12 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
             *dst = a.accumulate ? *dst + s : s;
         }
     }
+#if NCA_EXP & 65536
+    if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 131)) {
+        const unsigned long long dt = __builtin_readcyclecounter() - clk_t0, dr = __builtin_amdgcn_s_memrealtime() - clk_r0;
+        printf("mode %d block %d: %llu shader cycles in %.1f us = %.3f GHz\n", MODE, (int)blockIdx.x, dt, dr * 0.01, (double)dt / (dr * 10.0));
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1318,6 +1524,78 @@ __device__ __forceinline__ void wgrad_job_mx(const NcaWgradArgs& a, const NcaWgr
     wgrad_write<F, NTB>(acc, bsum, job, a.slab + (int64_t)q * a.slab_stride, a.accumulate, lane);
 }
 
+// The output layer's weight gradient (fp8 staging: the dgrad kernel recomputes nothing, so the layer's input H_{NL-1} exists in
+// the store only): dWo[f] = sum_n g[n] H_{NL-1}[f][n] on the vector ALU -- one output row does not feed a matrix core.  Lane (r, h)
+// reads its 16 MT bytes of a 32-sample tile's e4m3 block (byte i of row tile m = feature 32 m + rho(i) + 4 h of sample r) and
+// g[r] from the tile's record, keeps 16 MT f32 partial sums, and the 32 samples of each half are added once at the end.
+template <int F>
+__device__ __forceinline__ void wgrad_job_out(const NcaWgradArgs& a, const NcaWgradJob& job, int q, int nsplit, int lane) {
+    constexpr int MT = F / 32;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int64_t per = (((a.ntiles + nsplit - 1) / nsplit) + 1) & ~(int64_t)1;          // the split's tiles, as the job's own work divides them
+    const int64_t s0 = (int64_t)q * per, s1 = (s0 + per < a.ntiles) ? s0 + per : a.ntiles;
+    const int64_t sn = s1 > s0 ? s1 - s0 : 0;
+    const int64_t t0 = s0 + sn * job.out_part / job.out_nparts, t1 = s0 + sn * (job.out_part + 1) / job.out_nparts;     // this job's share
+    const char* base = reinterpret_cast<const char*>(a.scratch);
+    const char* base_b = reinterpret_cast<const char*>(a.scratch_b);
+    float acc[MT][16];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
+    // UNR tiles per step, the next step's loads in flight while this one is summed (the job is pure streaming: 4 KiB per tile)
+    constexpr int UNR = 8;
+    u32x4 h[2][UNR][MT];
+    float g[2][UNR];
+    auto fetch = [&](int64_t t, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t tt = t + u < t1 ? t + u : t1 - 1;              // (clamped: a repeated tile is weighted 0 below)
+            const char* bp = base_b + (tt + a.tile0_b) * a.rows_total_b + job.out_b_row0 + lane * 16;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) h[buf][u][m] = load_nt(bp + m * 1024);
+            const float gv = *reinterpret_cast<const float*>(base + tt * a.rows_total + job.dscale_off + NCA_D8_REC_G + job.net * 128 + lr * 4);
+            g[buf][u] = t + u < t1 ? gv : 0.f;
+        }
+    };
+    auto add = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    acc[m][4 * w + 0] = fmaf(__builtin_amdgcn_cvt_f32_fp8((int)h[buf][u][m][w], 0), g[buf][u], acc[m][4 * w + 0]);
+                    acc[m][4 * w + 1] = fmaf(__builtin_amdgcn_cvt_f32_fp8((int)h[buf][u][m][w], 1), g[buf][u], acc[m][4 * w + 1]);
+                    acc[m][4 * w + 2] = fmaf(__builtin_amdgcn_cvt_f32_fp8((int)h[buf][u][m][w], 2), g[buf][u], acc[m][4 * w + 2]);
+                    acc[m][4 * w + 3] = fmaf(__builtin_amdgcn_cvt_f32_fp8((int)h[buf][u][m][w], 3), g[buf][u], acc[m][4 * w + 3]);
+                }
+    };
+    if (t0 < t1) {
+        fetch(t0, 0);
+        for (int64_t t = t0; t < t1; t += 2 * UNR) {
+            if (t + UNR < t1) fetch(t + UNR, 1);
+            add(0);
+            if (t + UNR < t1) {
+                if (t + 2 * UNR < t1) fetch(t + 2 * UNR, 0);
+                add(1);
+            }
+        }
+    }
+    float* slab = a.slab + (int64_t)q * a.slab_stride + job.out_w_off;
+    constexpr float INV = 1.f / (float)(1 << NCA_H8_LOG2);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float v = half_sum_b(acc[m][i]) * INV;           // over the 32 samples of this lane half (fixed xor tree)
+            if (lr == 0) {
+                float* dst = slab + 32 * m + nca_rho(i) + 4 * lh;
+                *dst = a.accumulate ? *dst + v : v;
+            }
+        }
+}
+
 template <int F, bool D8>
 __global__ __launch_bounds__(64, 1) void nca_wgrad_bf16(const NcaWgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char wring[];
@@ -1333,35 +1611,61 @@ __global__ __launch_bounds__(64, 1) void nca_wgrad_bf16(const NcaWgradArgs a) {
         else if (F != 128 && job.is_enc) wgrad_job<F, 4, D8, false>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
         else wgrad_job<F, F == 128 ? 4 : F / 32, D8, false>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
     }
+#ifndef NCA_T_NOOUT
+    if (job.out_nparts > 0) wgrad_job_out<F>(a, job, blockIdx.x, gridDim.x, threadIdx.x);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-template <int F, int MODE, bool S8>
+template <int F, int MODE, bool S8, bool RES = false>
 static hipError_t launch_fused_bf_mode(const NcaFusedArgs& a, int grid, hipStream_t st) {
-    constexpr bool bwd = MODE == NCA_KM_BWD || MODE == NCA_KM_BWD_STORED || MODE == NCA_KM_BWD_ONCHIP;
-    size_t lds = 2 * BfCfg<F>::BUF_BYTES + NCA_CONST_BYTES;
+    constexpr bool bwd = MODE == NCA_KM_BWD || MODE == NCA_KM_BWD_STORED || MODE == NCA_KM_BWD_ONCHIP || MODE == NCA_KM_BWD_NR;
+    size_t lds = (RES ? (size_t)a.res_bytes : 2 * BfCfg<F>::BUF_BYTES) + bf_const_bytes(MODE);
     if (bwd) lds += NCA_WAVES * 2 * (F + 1) * sizeof(float);
+    if (MODE == NCA_KM_BWD_NR) lds += 2 * bf_wo_floats(F) * sizeof(float);
+    if (RES) {
+        if (a.res_bytes <= 0 || a.nstages <= 0) return hipErrorInvalidValue;
+        const size_t dma_end = (size_t)a.stage[a.nstages - 1].lds_off + a.stage[a.nstages - 1].bytes;       // whole 1 KiB pieces
+        if (dma_end > lds) lds = dma_end;
+        if (lds > (size_t)NCA_LDS_BYTES) return hipErrorInvalidValue;
+    }
     if (MODE == NCA_KM_BWD) lds += (size_t)NCA_WAVES * a.mask_layers * 1024;
     if (MODE == NCA_KM_BWD_ONCHIP) {      // exchange / parking area: the larger of 2 MT fragments and the wave's parked accumulators
         constexpr int MT = BfCfg<F>::MT, BPW = (MT * MT + NCA_WAVES - 1) / NCA_WAVES;
         lds += (size_t)NCA_WAVES * (2 * MT * 1024 > BPW * 16 * 256 ? 2 * MT * 1024 : BPW * 16 * 256);
     }
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_fused_bf16<F, MODE, S8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((nca_fused_bf16<F, MODE, S8>), dim3(grid), dim3(NCA_NT), lds, st, a);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_fused_bf16<F, MODE, S8, RES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((nca_fused_bf16<F, MODE, S8, RES>), dim3(grid), dim3(NCA_NT), lds, st, a);
     return hipGetLastError();
 }
 template <int F>
 static hipError_t launch_fused_bf(const NcaFusedArgs& a, int kmode, int grid, hipStream_t st, bool s8) {
+    if (a.res_bytes > 0) {         // resident weight images (one net per launch; the host has checked that they fit)
+        switch (kmode) {
+            case NCA_KM_FWD: return launch_fused_bf_mode<F, NCA_KM_FWD, false, true>(a, grid, st);
+            case NCA_KM_FWD_STORE: return s8 ? launch_fused_bf_mode<F, NCA_KM_FWD_STORE, true, true>(a, grid, st) : launch_fused_bf_mode<F, NCA_KM_FWD_STORE, false, true>(a, grid, st);
+            case NCA_KM_BWD_STORED: return s8 ? hipErrorInvalidValue : launch_fused_bf_mode<F, NCA_KM_BWD_STORED, false, true>(a, grid, st);
+            case NCA_KM_BWD_NR: return s8 ? launch_fused_bf_mode<F, NCA_KM_BWD_NR, true, true>(a, grid, st) : launch_fused_bf_mode<F, NCA_KM_BWD_NR, false, true>(a, grid, st);
+        }
+        return hipErrorInvalidValue;
+    }
     switch (kmode) {
         case NCA_KM_FWD: return launch_fused_bf_mode<F, NCA_KM_FWD, false>(a, grid, st);
         case NCA_KM_BWD: return launch_fused_bf_mode<F, NCA_KM_BWD, false>(a, grid, st);
         case NCA_KM_FWD_STORE: return s8 ? launch_fused_bf_mode<F, NCA_KM_FWD_STORE, true>(a, grid, st) : launch_fused_bf_mode<F, NCA_KM_FWD_STORE, false>(a, grid, st);
-        case NCA_KM_BWD_STORED: return s8 ? launch_fused_bf_mode<F, NCA_KM_BWD_STORED, true>(a, grid, st) : launch_fused_bf_mode<F, NCA_KM_BWD_STORED, false>(a, grid, st);
-        case NCA_KM_BWD_ONCHIP: return s8 ? launch_fused_bf_mode<F, NCA_KM_BWD_ONCHIP, true>(a, grid, st) : launch_fused_bf_mode<F, NCA_KM_BWD_ONCHIP, false>(a, grid, st);
+        // (modes 3 and 4 recompute the last layer from a bf16 block: bf16 staging only; fp8 staging is mode 5)
+        case NCA_KM_BWD_STORED: return s8 ? hipErrorInvalidValue : launch_fused_bf_mode<F, NCA_KM_BWD_STORED, false>(a, grid, st);
+        case NCA_KM_BWD_ONCHIP: return s8 ? hipErrorInvalidValue : launch_fused_bf_mode<F, NCA_KM_BWD_ONCHIP, false>(a, grid, st);
+        case NCA_KM_BWD_NR: return s8 ? launch_fused_bf_mode<F, NCA_KM_BWD_NR, true>(a, grid, st) : launch_fused_bf_mode<F, NCA_KM_BWD_NR, false>(a, grid, st);
     }
     return hipErrorInvalidValue;
+}
+
+size_t nca_fused_bf16_lds_other(int F, int kmode) {
+    const bool bwd = kmode == NCA_KM_BWD || kmode == NCA_KM_BWD_STORED || kmode == NCA_KM_BWD_ONCHIP || kmode == NCA_KM_BWD_NR;
+    return bf_const_bytes(kmode) + (bwd ? NCA_WAVES * 2 * (F + 1) * sizeof(float) : 0) + (kmode == NCA_KM_BWD_NR ? 2 * bf_wo_floats(F) * sizeof(float) : 0);
 }
 
 hipError_t nca_launch_fused_bf16(int F, const NcaFusedArgs& a, int kmode, int grid, hipStream_t st, bool s8) {

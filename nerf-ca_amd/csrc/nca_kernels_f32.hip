@@ -1202,7 +1202,12 @@ __global__ __launch_bounds__(256) void nca_reduce_small_f32(const NcaReduceArgs 
             out = rn.grads + id;
         } else {
             const int k = (int)(id - rn.lat_count);           // 0..F (F = bias)
-            for (int w = lane; w < a.n_wg; w += 64) s += a.oslab[(int64_t)w * a.oslab_stride + net * (rn.F + 1) + k];
+            if (rn.wo_parts > 0 && k < rn.F) {
+                for (int w = lane; w < a.n_split * rn.wo_parts; w += 64)
+                    s += a.slab[(int64_t)(w / rn.wo_parts) * a.slab_stride + rn.wo_parts_off + (int64_t)(w % rn.wo_parts) * rn.F + k];
+            } else {
+                for (int w = lane; w < a.n_wg; w += 64) s += a.oslab[(int64_t)w * a.oslab_stride + net * (rn.F + 1) + k];
+            }
             out = rn.grads + rn.wo_off + k;
         }
         s += __shfl_xor(s, 32); s += __shfl_xor(s, 16); s += __shfl_xor(s, 8); s += __shfl_xor(s, 4); s += __shfl_xor(s, 2); s += __shfl_xor(s, 1);

@@ -56,7 +56,7 @@ class NetSpec:
     # NOT reference behaviour either: with emulate_bf16, also round what the bf16 HIP path's BACKWARD rounds when it runs from a
     # forward store with fp8 staging (nca_layout.hpp): value = samples per ray (tiles of 64 consecutive samples of a ray share
     # a power-of-two scale), 0 = off.  emulate_onchip_last: the last hidden layer's weight gradient is formed on chip from
-    # bf16 operands (the planner's choice from ~1 M samples), else from e5m2 output gradients like the others.
+    # bf16 operands (an option of bf16 staging, emulate_stage_formats = None), else from staged output gradients like the others.
     emulate_fp8_stage: int = 0
     emulate_onchip_last: bool = False
     emulate_stage_formats: Optional[Tuple[str, str]] = ("e5m2", "e4m3")  # (output gradients, layer inputs); None: bf16 staging with the
@@ -249,6 +249,26 @@ class _StagedLinear(torch.autograd.Function):
         return dx, dd.t() @ hh, dd.sum(0), None, None, None, None
 
 
+class _StagedOut(torch.autograd.Function):
+    """The F -> 1 output layer of the bf16 HIP path under the staging emulation: forward in f32 on the f32 activations (as the
+    kernels do); backward: the input gradient g Wo in f32 (the previous layer rounds it to bf16), the weight gradient from the
+    layer input as the weight-gradient kernel reads it -- e4m3(bf16(h) 2^H8_LOG2) / 2^H8_LOG2 under fp8 staging (block NL-1 of the
+    store; g itself stays f32), bf16(h) under bf16 staging."""
+
+    @staticmethod
+    def forward(ctx, h, Wo, bo, h8: Optional[str]):
+        ctx.save_for_backward(h, Wo)
+        ctx.h8 = h8
+        return h @ Wo.t() + bo
+
+    @staticmethod
+    def backward(ctx, g):
+        h, Wo = ctx.saved_tensors
+        hq = h.to(torch.bfloat16).to(h.dtype)
+        hh = _q8(hq * 2.0 ** H8_LOG2, ctx.h8) / 2.0 ** H8_LOG2 if ctx.h8 else hq
+        return g @ Wo, g.t() @ hh, g.sum(0), None
+
+
 def mlp(params: Dict[str, Tensor], spec: NetSpec, feats: Tensor) -> Tensor:
     """Shared body of CPPN.forward (CPPN.py:98-110) and Temporal.query_time (Temporal.py:125-134).
 
@@ -269,7 +289,7 @@ def mlp(params: Dict[str, Tensor], spec: NetSpec, feats: Tensor) -> Tensor:
             # e4m3, the bf16 input block and the bf16 input of the last layer are rounded to e4m3 inside the weight-gradient kernel
             h8 = fh if d8 is not None else None
             h = torch.relu(_StagedLinear.apply(h, params[f"early_pts_layers.{2 * i}.weight"], params[f"early_pts_layers.{2 * i}.bias"], state, d8, h8, i == 0))
-        raw = TF.linear(h, params["output_linear.0.weight"], params["output_linear.0.bias"])
+        raw = _StagedOut.apply(h, params["output_linear.0.weight"], params["output_linear.0.bias"], fh)
         if raw.requires_grad:      # d loss / d raw arrives before the layers' backward runs: fix the tile scales there
             raw.register_hook(lambda g: state.__setitem__("scale", _tile_scales(g, spec.emulate_fp8_stage)))
         return raw

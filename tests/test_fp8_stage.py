@@ -54,17 +54,15 @@ def _oracle_grads(ps, ss, pd, sd, win, win_d, o, d, ph, I0, z, cp, cs, cd, onchi
 
 
 @pytest.mark.parametrize("R,S,F,early", [(8, 16, 32, 1), (33, 50, 64, 3), (64, 192, 128, 4), (7, 500, 128, 4), (300, 70, 128, 2), (40, 130, 64, 0)])
-@pytest.mark.parametrize("onchip", [False, True])
 @pytest.mark.parametrize("it_d", [75000, 30000])
-def test_fp8_stage_vs_emulating_oracle(dev, R, S, F, early, onchip, it_d):
-    """Every parameter gradient of the backward from an fp8-staged store against the oracle that rounds what the kernels
-    round -- plain backward from the store (all output gradients e5m2) and with the last hidden layer's weight gradient on
-    chip (forced; that layer stays bf16), ragged tiles (S not a multiple of 64), nets without a hidden layer to stage
-    (early = 0: only D_0 is staged), one band window for both nets or one each; outputs bit-identical to bf16 staging;
-    several ray chunks equal one."""
+def test_fp8_stage_vs_emulating_oracle(dev, R, S, F, early, it_d):
+    """Every parameter gradient of the backward from an fp8-staged store (mode 5: nothing recomputed -- raw outputs and the masks
+    of all layers come from the store, every output gradient is staged as e5m2, the output layer's weight gradient is a job of
+    the weight-gradient kernel) against the oracle that rounds what the kernels round; ragged tiles (S not a multiple of 64),
+    nets without a hidden layer to stage (early = 0: no store, the recompute backward), one band window for both nets or one
+    each; outputs bit-identical to bf16 staging; several ray chunks equal one; the on-chip option (bf16 staging only) is ignored."""
     from nerfca_amd import fused, set_precision
-    if onchip and early == 0:
-        pytest.skip("a net without hidden layers has no store")
+    onchip = False
     gen = torch.Generator().manual_seed(300 + R + S)
     ss = O.NetSpec(num_filters=F, num_early_layers=early, num_time_dim=0)
     sd = O.NetSpec(num_filters=F, num_early_layers=early, num_time_dim=8)
@@ -79,13 +77,13 @@ def test_fp8_stage_vs_emulating_oracle(dev, R, S, F, early, onchip, it_d):
     set_precision("bf16", s, t)
     s.update_freq_mask_alpha(75000, 150000)
     t.update_freq_mask_alpha(it_d, 150000)
-    thr = 0 if onchip else -1
+    thr = 0 if (R + S) % 2 else -1          # (on-chip threshold: must not matter under fp8 staging)
     saved = fused.BWD_WORKSPACE_BYTES
     launches = []
     try:
         with onchip_min_tiles(thr), count_dgrad_launches(launches):
             p8, a8, b8, g8 = _hip_grads(s, t, dev, o, d, ph, I0, z, dists, cp, cs, cd)
-        with onchip_min_tiles(thr), nca_option("STAGE_FP8", 0):
+        with onchip_min_tiles(-1), nca_option("STAGE_FP8", 0):
             p16, a16, b16, g16 = _hip_grads(s, t, dev, o, d, ph, I0, z, dists, cp, cs, cd)
         fused.BWD_WORKSPACE_BYTES = 24 << 20
         with onchip_min_tiles(thr):
@@ -93,7 +91,9 @@ def test_fp8_stage_vs_emulating_oracle(dev, R, S, F, early, onchip, it_d):
     finally:
         fused.BWD_WORKSPACE_BYTES = saved
     if early > 0:
-        assert launches == [2 if onchip else 1], launches
+        from nerfca_amd import _capi
+        per_net = 0 <= _capi.get_option(_capi.OPT_RESIDENT_MIN_TILES) <= R * ((S + 63) // 64)     # resident weights: one launch per net
+        assert launches == [2 if per_net else 1], launches
     assert torch.equal(p8, p16) and torch.equal(a8, a16) and torch.equal(b8, b16)
     assert torch.equal(pc, p8)
     assert rel_err(a8.cpu(), a) < BF_OUT and rel_err(b8.cpu(), b) < BF_OUT
@@ -106,7 +106,7 @@ def test_fp8_stage_vs_emulating_oracle(dev, R, S, F, early, onchip, it_d):
         # summed in another order -- move a max-norm of ~1e4 random-signed samples by up to ~5e-2 in either staging)
         assert e8 < max(BF_GRAD, e16 + 1e-2), (k, e8, e16)
         assert rel_err(gc[k], g8[k]) < 2e-6, k
-    print(f"fp8 staging {R}x{S} F={F} early={early} onchip={onchip}: worst distance from the oracle that stages in fp8 {worst:.2e} (bf16 staging from its oracle: "
+    print(f"fp8 staging {R}x{S} F={F} early={early}: worst distance from the oracle that stages in fp8 {worst:.2e} (bf16 staging from its oracle: "
           f"{base:.2e}); the staging itself moves the gradient by {shift:.2e}")
 
 
@@ -156,7 +156,9 @@ def test_fp8_stage_with_depth_gradients(dev):
     _, _, _, g8 = _hip_grads(s, t, dev, o, d, ph, I0, z, dists, cp, cs, cd)
     assert torch.equal(gz["depth"], gz16["depth"])
     for k in g8:                                            # ~1 200 random-signed samples: the staging noise is 5 .. 25 % of a max-norm
-        assert bool(torch.isfinite(gz[k]).all()) and rel_err(gz[k], gz16[k]) < 0.3, k           # e4m3 layer inputs vs bf16 ones
+        # (the output layer's weights: 1 170 terms g h that largely cancel, h as e4m3 -- 3 mantissa bits -- instead of bf16)
+        tol = 0.5 if "output_linear" in k else 0.3
+        assert bool(torch.isfinite(gz[k]).all()) and rel_err(gz[k], gz16[k]) < tol, k           # e4m3 layer inputs vs bf16 ones
         assert rel_err(gz[k], g8[k]) < 0.3, k                                                     # bf16 vs e5m2 output gradients
 
 

@@ -11,7 +11,8 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int N, int KIND, bool MFMA>
+// ACCV: the MFMA accumulators in architectural VGPRs ("v") instead of accumulation VGPRs ("a")
+template <int N, int KIND, bool MFMA, bool ACCV = false>
 __global__ void k(int iters, unsigned long long* cyc, float* sink) {
     f32x16 acc0 = (f32x16)(0.f), acc1 = (f32x16)(0.f);
     bf16x8 a, b;
@@ -26,8 +27,13 @@ __global__ void k(int iters, unsigned long long* cyc, float* sink) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             if (MFMA) {
-                if (u & 1) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc1) : "v"(a), "v"(b));
-                else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc0) : "v"(a), "v"(b));
+                if (ACCV) {
+                    if (u & 1) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc1) : "v"(a), "v"(b));
+                    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc0) : "v"(a), "v"(b));
+                } else {
+                    if (u & 1) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc1) : "v"(a), "v"(b));
+                    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc0) : "v"(a), "v"(b));
+                }
             }
 #pragma unroll
             for (int j = 0; j < N; ++j) {
@@ -46,11 +52,11 @@ __global__ void k(int iters, unsigned long long* cyc, float* sink) {
     if (s == 12345.678f) *sink = s;
 }
 
-template <int N, int KIND, bool MFMA>
+template <int N, int KIND, bool MFMA, bool ACCV = false>
 static double run(int threads, int iters, unsigned long long* dcyc, float* sink) {
     const int blocks = 256, waves = blocks * threads / 64;
-    hipLaunchKernelGGL((k<N, KIND, MFMA>), dim3(blocks), dim3(threads), 0, 0, 200, dcyc, sink);       // warm-up
-    hipLaunchKernelGGL((k<N, KIND, MFMA>), dim3(blocks), dim3(threads), 0, 0, iters, dcyc, sink);
+    hipLaunchKernelGGL((k<N, KIND, MFMA, ACCV>), dim3(blocks), dim3(threads), 0, 0, 200, dcyc, sink);       // warm-up
+    hipLaunchKernelGGL((k<N, KIND, MFMA, ACCV>), dim3(blocks), dim3(threads), 0, 0, iters, dcyc, sink);
     std::vector<unsigned long long> h(waves);
     (void)hipMemcpy(h.data(), dcyc, waves * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     std::sort(h.begin(), h.end());
@@ -72,6 +78,14 @@ int main() {
     unsigned long long* dcyc; float* sink;
     (void)hipMalloc(&dcyc, 256 * 8 * sizeof(unsigned long long));
     (void)hipMalloc(&sink, 4);
+    {   // the same with the accumulators in architectural VGPRs (what the compiler picks when it has the registers)
+        const int it = 4000;
+        printf("v_fma_f32, accumulators in a / in v registers: cycles per group of [1 MFMA + N x v_fma_f32]\n   N   a: 1 w/SIMD  2 w/SIMD |  v: 1 w/SIMD  2 w/SIMD\n");
+#define ROWV(N) printf("  %2d   %9.1f  %9.1f  |  %9.1f  %9.1f\n", N, run<N, 0, true, false>(256, it, dcyc, sink), run<N, 0, true, false>(512, it, dcyc, sink), \
+                       run<N, 0, true, true>(256, it, dcyc, sink), run<N, 0, true, true>(512, it, dcyc, sink));
+        ROWV(0) ROWV(2) ROWV(4) ROWV(6) ROWV(8) ROWV(12)
+#undef ROWV
+    }
     sweep<0>("v_fma_f32", dcyc, sink);
     sweep<1>("v_cvt_pk_bf16_f32", dcyc, sink);
     sweep<2>("v_and_b32", dcyc, sink);
