@@ -541,7 +541,6 @@ static int plan_bwd(const NcaLayout* lays, int nnets, int32_t prec, int64_t unit
         p->slab_stride += lays[n].n_params;
         for (int j = 0; j < lays[n].NL; ++j) p->njobs += lays[n].layer[j].kind == NCA_IN_SKIP ? 2 : 1;
         if (onchip) p->njobs -= 1;                    // the last hidden layer's weight gradient stays in the dgrad kernel
-        if (nr) p->slab_stride += (int64_t)lays[n].NL * lays[n].F;     // fp8 staging: the output layer's weight gradient, one slot per wgrad job
     }
     if (stored && bf && (d8 || nr)) p->tile_stride += NCA_D8_REC_BYTES;
     for (int n = 0; n < nnets; ++n) p->slab_stride += (int64_t)lays[n].F * lays[n].P;
@@ -659,23 +658,14 @@ static void make_job_bf16(NcaWgradJob& g, const NcaLayout& y, int j, int64_t net
     }
 }
 // skip_layer: accumulated on chip by the dgrad kernel
-// wo_parts_off >= 0: fp8 staging -- the net's NL jobs share the output layer's weight gradient (block NL-1 of the store times the g
-// rows of the tile records), one slot of F floats each behind the slab's natural blocks
 static void add_jobs_bf16(NcaWgradArgs* w, int net_index, const NcaLayout& y, int64_t net_off, int64_t d_off, int64_t slab_off, int64_t onehot_off, int64_t enc_off,
-                          int skip_layer, bool h8, bool d8, int64_t dscale_off, int64_t wo_parts_off) {
-    const int64_t EB = 32 * (int64_t)NCA_BF_ENCROWS * 2;
+                          int skip_layer, bool h8, bool d8, int64_t dscale_off) {
     for (int j = 0; j < y.NL; ++j) {
         if (j == skip_layer) continue;
         NcaWgradJob& g = w->job[w->njobs++];
         make_job_bf16(g, y, j, net_off, d_off, slab_off, onehot_off, enc_off, h8, d8);
         g.net = net_index;
         g.dscale_off = dscale_off;
-        if (wo_parts_off >= 0 && !getenv("NCA_T_NO_OUTJOB")) {
-            g.out_nparts = y.NL;
-            g.out_part = j;
-            g.out_w_off = wo_parts_off + (int64_t)j * y.F;
-            g.out_b_row0 = net_off + EB + nca_bf_hoff(y, y.NL - 1, true);
-        }
     }
 }
 
@@ -766,15 +756,13 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     int64_t slab_off[2] = {0, 0}, onehot_off[2] = {0, 0};
     for (int n = 0; n < a.nnets; ++n) { slab_off[n] = soff; soff += lays[n].n_params; }
     for (int n = 0; n < a.nnets; ++n) { onehot_off[n] = soff; soff += (int64_t)lays[n].F * lays[n].P; }
-    int64_t wo_parts_off[2] = {-1, -1};
-    if (nr) for (int n = 0; n < a.nnets; ++n) { wo_parts_off[n] = soff; soff += (int64_t)lays[n].NL * lays[n].F; }
 
     static thread_local NcaWgradArgs w;
     memset(&w, 0, sizeof(w));
     for (int n = 0; n < a.nnets; ++n) {
         if (bf) add_jobs_bf16(&w, n, lays[n], a.net[n].row0, a.net[n].drow0, slab_off[n], onehot_off[n],
                               stored && a.share_enc && n == 0 ? a.net[1].row0 : a.net[n].row0, onchip ? lays[n].NL - 1 : -1, h8, d8,
-                              p.tile_stride - NCA_D8_REC_BYTES, wo_parts_off[n]);
+                              p.tile_stride - NCA_D8_REC_BYTES);
         else add_jobs_f32(&w, lays[n], a.net[n].row0, a.net[n].drow0, slab_off[n], onehot_off[n]);
     }
     w.scratch = scratch;
@@ -891,8 +879,9 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
         rn.w0_off = lays[n].layer[0].w_off;
         rn.lat_count = (int64_t)lays[n].P * lays[n].T;
         rn.wo_off = lays[n].wo_off;
-        rn.wo_parts = nr ? lays[n].NL : 0;
-        rn.wo_parts_off = wo_parts_off[n];
+        rn.tail_from_sums = nr ? 1 : 0;
+        rn.tl_w_off = lays[n].layer[lays[n].NL - 1].w_off;
+        rn.tl_b_off = lays[n].layer[lays[n].NL - 1].b_off;
         if (onchip) {
             rn.wslab = reinterpret_cast<const float*>(wb + p.off_wslab) + (int64_t)n * num_cus() * p.wslab_stride;
             rn.wslab_stride = p.wslab_stride;

@@ -117,11 +117,7 @@ struct NcaWgradJob {
     int32_t fourier_L;    // bf16 input block of a fourier net: slots are (sin_i, cos_i) interleaved; 0 otherwise
     int32_t d8, h8;       // bf16 path: the D block is e5m2 scaled by the wave tile's power of two / the H block is e4m3 x 2^NCA_H8_LOG2
     int32_t net;          // ... which of the tile's two inverse scales applies
-    int32_t out_nparts;   // bf16 path, fp8 staging: > 0 = behind its own work this job's wave forms its share (part out_part of out_nparts
-                          // of the split's tiles) of the OUTPUT layer's weight gradient dWo[f] = sum_n g[n] H_{NL-1}[f][n], g from the tile
-                          // records, into the slab at out_w_off (one slot of F floats per job of the net: the reduce kernel adds them)
-    int32_t out_part;
-    int64_t out_w_off, out_b_row0;   // slab offset of that slot; byte offset of block NL-1 in a tile of the H region
+    int32_t pad;
     int64_t dscale_off;   // ... byte offset of the inverse-scale record inside a tile of the D region
 };
 
@@ -147,9 +143,9 @@ struct NcaReduceNet {
     int64_t onehot_off;
     int32_t F, T, P, K0, Kenc, w0_off;
     int64_t lat_count, wo_off;
-    int32_t wo_parts;      // bf16 with fp8 staging: > 0 = the output layer's weight gradient lies in the slabs, wo_parts slots of F floats
-    int32_t pad;           // per split at wo_parts_off (the wgrad kernel's waves); its bias gradient stays with the fused kernel's partials
-    int64_t wo_parts_off;
+    int32_t tail_from_sums; // bf16 with fp8 staging: the slabs hold S = sum relu' g H^T and s = sum relu' g of the LAST F-wide layer
+    int32_t pad;            // (nca_layout.hpp): its gradients are Wo[f] S, Wo[f] s, and dWo[f] = <bf16(W[f]), S[f]> + b[f] s[f]
+    int64_t tl_w_off, tl_b_off;   // natural offsets of that layer's W (F*F) and b (F)
 };
 
 struct NcaReduceArgs {

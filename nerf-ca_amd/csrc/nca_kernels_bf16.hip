@@ -664,13 +664,14 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                     char* const dblk = db + nca_bf_doff(y, y.NL - 1, S8 && STORED);
                     u32x4 Bn[2][2 * MT];
                     if (NR) {
-                        // the output layer's weight gradient is the wgrad kernel's: it reads g from the tile records (lane = sample)
-                        *reinterpret_cast<float*>(d32 + lh * a.d_total + a.dscale_off + NCA_D8_REC_G + (net + a.net_base) * 128 + lr * 4) = g;
-                        // D_{NL-1} = relu'(H_{NL-1}) (Wo x g): the layer's mask bits arrived by DMA (requested at the top of the net; the
-                        // loads of raw / g since then have returned, and the queue is in order)
-                        asm volatile("s_waitcnt vmcnt(1)" ::: "memory");          // (1: the store just issued)
+                        // D_{NL-1} = relu'(H_{NL-1}) (Wo x g) feeds the sweep; the block that goes to the weight-gradient kernel is
+                        // relu'(H_{NL-1}) g WITHOUT Wo (nca_layout.hpp: the reduce kernel puts Wo back and gets dWo from the same sums).
+                        // The layer's mask bits arrived by DMA (requested at the top of the net; the loads of raw / g since then
+                        // have returned, and the queue is in order)
+                        asm volatile("s_waitcnt vmcnt(1)" ::: "memory");          // (1: the scale record of lane 0)
                         const u32x4 mv = *reinterpret_cast<const u32x4*>(mslot + ((y.NL - 1) & 1) * 1024 + lane * 16);
                         if (y.NL >= 2) mask_dma(y.NL - 2);
+                        const unsigned gpk[2] = {pack2_pk(gc[0], gc[0]), pack2_pk(gc[1], gc[1])};        // bf16(g) in both halves
 #pragma unroll
                         for (int m = 0; m < MT; ++m) {
 #pragma unroll
@@ -679,20 +680,21 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                                 u32x4 q8 = {0u, 0u, 0u, 0u};
 #pragma unroll
                                 for (int s2 = 0; s2 < 2; ++s2) {
-                                    u32x4 dw;
+                                    u32x4 dw, ds;
 #pragma unroll
                                     for (int u = 0; u < 4; ++u) {
                                         const float a0 = wo[(lh * MT + m) * 16 + 8 * s2 + 2 * u] * gc[c];
                                         const float a1 = wo[(lh * MT + m) * 16 + 8 * s2 + 2 * u + 1] * gc[c];
-                                        const unsigned two = (fld >> (4 * s2 + u)) & 0x00010001u;
-                                        dw[u] = pack2_pk(a0, a1) & (two * 0xffffu);
+                                        const unsigned msk = ((fld >> (4 * s2 + u)) & 0x00010001u) * 0xffffu;
+                                        dw[u] = pack2_pk(a0, a1) & msk;
+                                        ds[u] = gpk[c] & msk;
                                     }
                                     Bn[c][2 * m + s2] = dw;
                                     if (S8) {
-                                        q8[2 * s2] = cvt4_e5m2_pk(dw[0], dw[1], inv_s);
-                                        q8[2 * s2 + 1] = cvt4_e5m2_pk(dw[2], dw[3], inv_s);
+                                        q8[2 * s2] = cvt4_e5m2_pk(ds[0], ds[1], inv_s);
+                                        q8[2 * s2 + 1] = cvt4_e5m2_pk(ds[2], ds[3], inv_s);
                                     } else {
-                                        store_nt(dblk + c * a.d_total + lane * 16 + (2 * m + s2) * 1024, dw);
+                                        store_nt(dblk + c * a.d_total + lane * 16 + (2 * m + s2) * 1024, ds);
                                     }
                                 }
                                 if (S8) store_nt(dblk + c * a.d_total + lane * 16 + m * 1024, q8);
@@ -801,7 +803,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                 const int nks = l.ksteps;
                 const float* tail = reinterpret_cast<const float*>(img + MT * nks * 1024);
                 const bool last = jj == y.NL - 1;
-                const bool h8 = S8 && FSTORE;                                     // fp8 staging: EVERY layer's output goes to the store, as e4m3
+                const bool h8 = S8 && FSTORE;                                     // fp8 staging: the layer outputs go to the store as e4m3 (the last layer: its mask only)
                 char* const hblk = STORE ? nb + EB + nca_bf_hoff(y, jj, S8 && FSTORE) : nullptr;          // input block of layer jj+1
                 u32x4 Bn[2][2 * MT];
                 unsigned mw[2][2] = {{0u, 0u}, {0u, 0u}};     // mask words: [column tile][row-tile pair]
@@ -857,7 +859,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                             mw[c][m >> 1] |= fld << (8 * (m & 1));
                         }
                     }
-                    if (STORE && !NOH && H8) {
+                    if (STORE && !LAST && !NOH && H8) {
                         // e4m3 of the bf16 activations (x 2^NCA_H8_LOG2): byte i = register i, [row tile][lane][16 B]
                         constexpr float DIV = 1.f / (float)(1 << NCA_H8_LOG2);
 #pragma unroll
@@ -1042,7 +1044,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                 // layer of the storing forward stores nothing
                 NCA_STAMP(5)                    // masks, raw output, output-layer gradients, on-chip dW
                 if (RES) {}                                             // nothing to publish, nothing to wait for
-                else if ((S8 && FSTORE && h8) || (S8 && STORED && last && !ONCHIP)) stage_publish_counted<2 * MT>(FSTORE || STORED || tvalid);   // 2 MT 8-bit stores (+ the mask store, + the raw outputs)
+                else if ((S8 && FSTORE && h8 && !last) || (S8 && STORED && last && !ONCHIP)) stage_publish_counted<2 * MT>(FSTORE || STORED || tvalid);   // 2 MT 8-bit stores (+ the mask store)
                 else if ((STORE && !last) || (BWD && last && !ONCHIP)) stage_publish_counted<4 * MT>(FSTORE || STORED || tvalid);
                 else stage_publish_b();
                 cur ^= 1;
@@ -1524,78 +1526,6 @@ __device__ __forceinline__ void wgrad_job_mx(const NcaWgradArgs& a, const NcaWgr
     wgrad_write<F, NTB>(acc, bsum, job, a.slab + (int64_t)q * a.slab_stride, a.accumulate, lane);
 }
 
-// The output layer's weight gradient (fp8 staging: the dgrad kernel recomputes nothing, so the layer's input H_{NL-1} exists in
-// the store only): dWo[f] = sum_n g[n] H_{NL-1}[f][n] on the vector ALU -- one output row does not feed a matrix core.  Lane (r, h)
-// reads its 16 MT bytes of a 32-sample tile's e4m3 block (byte i of row tile m = feature 32 m + rho(i) + 4 h of sample r) and
-// g[r] from the tile's record, keeps 16 MT f32 partial sums, and the 32 samples of each half are added once at the end.
-template <int F>
-__device__ __forceinline__ void wgrad_job_out(const NcaWgradArgs& a, const NcaWgradJob& job, int q, int nsplit, int lane) {
-    constexpr int MT = F / 32;
-    const int lr = lane & 31, lh = lane >> 5;
-    const int64_t per = (((a.ntiles + nsplit - 1) / nsplit) + 1) & ~(int64_t)1;          // the split's tiles, as the job's own work divides them
-    const int64_t s0 = (int64_t)q * per, s1 = (s0 + per < a.ntiles) ? s0 + per : a.ntiles;
-    const int64_t sn = s1 > s0 ? s1 - s0 : 0;
-    const int64_t t0 = s0 + sn * job.out_part / job.out_nparts, t1 = s0 + sn * (job.out_part + 1) / job.out_nparts;     // this job's share
-    const char* base = reinterpret_cast<const char*>(a.scratch);
-    const char* base_b = reinterpret_cast<const char*>(a.scratch_b);
-    float acc[MT][16];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
-    // UNR tiles per step, the next step's loads in flight while this one is summed (the job is pure streaming: 4 KiB per tile)
-    constexpr int UNR = 8;
-    u32x4 h[2][UNR][MT];
-    float g[2][UNR];
-    auto fetch = [&](int64_t t, int buf) __attribute__((always_inline)) {
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const int64_t tt = t + u < t1 ? t + u : t1 - 1;              // (clamped: a repeated tile is weighted 0 below)
-            const char* bp = base_b + (tt + a.tile0_b) * a.rows_total_b + job.out_b_row0 + lane * 16;
-#pragma unroll
-            for (int m = 0; m < MT; ++m) h[buf][u][m] = load_nt(bp + m * 1024);
-            const float gv = *reinterpret_cast<const float*>(base + tt * a.rows_total + job.dscale_off + NCA_D8_REC_G + job.net * 128 + lr * 4);
-            g[buf][u] = t + u < t1 ? gv : 0.f;
-        }
-    };
-    auto add = [&](int buf) __attribute__((always_inline)) {
-#pragma unroll
-        for (int u = 0; u < UNR; ++u)
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    acc[m][4 * w + 0] = fmaf(__builtin_amdgcn_cvt_f32_fp8((int)h[buf][u][m][w], 0), g[buf][u], acc[m][4 * w + 0]);
-                    acc[m][4 * w + 1] = fmaf(__builtin_amdgcn_cvt_f32_fp8((int)h[buf][u][m][w], 1), g[buf][u], acc[m][4 * w + 1]);
-                    acc[m][4 * w + 2] = fmaf(__builtin_amdgcn_cvt_f32_fp8((int)h[buf][u][m][w], 2), g[buf][u], acc[m][4 * w + 2]);
-                    acc[m][4 * w + 3] = fmaf(__builtin_amdgcn_cvt_f32_fp8((int)h[buf][u][m][w], 3), g[buf][u], acc[m][4 * w + 3]);
-                }
-    };
-    if (t0 < t1) {
-        fetch(t0, 0);
-        for (int64_t t = t0; t < t1; t += 2 * UNR) {
-            if (t + UNR < t1) fetch(t + UNR, 1);
-            add(0);
-            if (t + UNR < t1) {
-                if (t + 2 * UNR < t1) fetch(t + 2 * UNR, 0);
-                add(1);
-            }
-        }
-    }
-    float* slab = a.slab + (int64_t)q * a.slab_stride + job.out_w_off;
-    constexpr float INV = 1.f / (float)(1 << NCA_H8_LOG2);
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float v = half_sum_b(acc[m][i]) * INV;           // over the 32 samples of this lane half (fixed xor tree)
-            if (lr == 0) {
-                float* dst = slab + 32 * m + nca_rho(i) + 4 * lh;
-                *dst = a.accumulate ? *dst + v : v;
-            }
-        }
-}
-
 template <int F, bool D8>
 __global__ __launch_bounds__(64, 1) void nca_wgrad_bf16(const NcaWgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char wring[];
@@ -1611,9 +1541,6 @@ __global__ __launch_bounds__(64, 1) void nca_wgrad_bf16(const NcaWgradArgs a) {
         else if (F != 128 && job.is_enc) wgrad_job<F, 4, D8, false>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
         else wgrad_job<F, F == 128 ? 4 : F / 32, D8, false>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
     }
-#ifndef NCA_T_NOOUT
-    if (job.out_nparts > 0) wgrad_job_out<F>(a, job, blockIdx.x, gridDim.x, threadIdx.x);
-#endif
 }
 
 // ------------------------------------------------------------------------------------------

@@ -1179,7 +1179,14 @@ __global__ void nca_reduce_f32(const NcaReduceArgs a) {
         for (int u = 0; u < 8; ++u) s8[u] += sp[(int64_t)(q + u) * stride];
     }
     for (; q < nsum; ++q) s8[0] += sp[(int64_t)q * stride];
-    *out = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+    float r = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+    if (rn.tail_from_sums) {
+        // the last F-wide layer's sums were formed without the factor Wo[f] of their output row (nca_layout.hpp)
+        const int64_t F2 = (int64_t)rn.F * rn.F;
+        if (le >= rn.tl_w_off && le < rn.tl_w_off + F2) r *= rn.params[rn.wo_off + (le - rn.tl_w_off) / rn.F];
+        else if (le >= rn.tl_b_off && le < rn.tl_b_off + rn.F) r *= rn.params[rn.wo_off + (le - rn.tl_b_off)];
+    }
+    *out = r;
 }
 
 // The few outputs with long sums -- Wo / bo (over the fused kernel's per-workgroup partials) and the time latents (over
@@ -1202,9 +1209,18 @@ __global__ __launch_bounds__(256) void nca_reduce_small_f32(const NcaReduceArgs 
             out = rn.grads + id;
         } else {
             const int k = (int)(id - rn.lat_count);           // 0..F (F = bias)
-            if (rn.wo_parts > 0 && k < rn.F) {
-                for (int w = lane; w < a.n_split * rn.wo_parts; w += 64)
-                    s += a.slab[(int64_t)(w / rn.wo_parts) * a.slab_stride + rn.wo_parts_off + (int64_t)(w % rn.wo_parts) * rn.F + k];
+            if (rn.tail_from_sums && k < rn.F) {
+                // dWo[k] = sum_kk bf16(W[k][kk]) S[k][kk] + b[k] s[k], S and s summed over the splits (nca_layout.hpp); the forward
+                // multiplied with the bf16-rounded weights, so those are the ones the identity holds for
+                const float* wrow = rn.params + rn.tl_w_off + (int64_t)k * rn.F;
+                for (int idx = lane; idx < a.n_split * rn.F; idx += 64) {
+                    const int w = idx / rn.F, kk = idx % rn.F;
+                    const float wq = __uint_as_float(((__float_as_uint(wrow[kk]) + 0x7fffu + ((__float_as_uint(wrow[kk]) >> 16) & 1u)) & 0xffff0000u));
+                    s = fmaf(wq, a.slab[(int64_t)w * a.slab_stride + rn.slab_off + rn.tl_w_off + (int64_t)k * rn.F + kk], s);
+                }
+                float sb = 0.f;
+                for (int w = lane; w < a.n_split; w += 64) sb += a.slab[(int64_t)w * a.slab_stride + rn.slab_off + rn.tl_b_off + k];
+                s = fmaf(rn.params[rn.tl_b_off + k], sb, s);
             } else {
                 for (int w = lane; w < a.n_wg; w += 64) s += a.oslab[(int64_t)w * a.oslab_stride + net * (rn.F + 1) + k];
             }

@@ -244,23 +244,25 @@ inline int nca_build_layout_bf16(const NcaNet& n, NcaLayout* out, const char** w
 
 // fp8 staging (NCA_OPT_STAGE_FP8): the blocks that only the weight-gradient kernel reads cross HBM as 8-bit floats, and the
 // backward recomputes nothing.
-//   hidden block j = output of layer j (input of layer j+1; j = NL-1: input of the output layer), behind the input block of a
-//   tile of the forward store:
-//       bf16 staging: blocks 0..NL-2 as bf16 (64 x F bytes) -- the backward recomputes the last layer from block NL-2;
-//       fp8 staging:  blocks 0..NL-1 as e4m3 (32 x F bytes, [row tile][lane][16 B]: byte i = accumulator register i, value x
-//                     2^NCA_H8_LOG2), the ReLU masks of all NL layers and the raw outputs -- the backward reads masks and raw
-//                     outputs only, the weight-gradient kernel reads every block (block NL-1: the output layer's weights)
+//   hidden block j = output of layer j = input of layer j+1, j = 0..NL-2, behind the input block of a tile of the forward store:
+//       bf16 staging: bf16 (64 x F bytes) -- the backward recomputes the last layer from block NL-2;
+//       fp8 staging:  e4m3 (32 x F bytes, [row tile][lane][16 B]: byte i = accumulator register i, value x 2^NCA_H8_LOG2); the
+//                     store also holds the ReLU masks of ALL NL layers and the raw outputs -- the backward reads masks and raw
+//                     outputs only, the weight-gradient kernel reads the blocks
 //   output-gradient block l = 0..NL-1 of a tile of the backward's D region:
 //       e5m2 (32 x F bytes, same byte order, value x the tile's power-of-two scale), or bf16 fragments when the depth-gradient
-//       kernel is to read D_0.  Behind all nets' blocks of a 32-sample tile a record of NCA_D8_REC_BYTES:
-//         [0, 8)     f32[2]  INVERSE scale of the 64-sample wave tile per net (first of the wave tile's two records only)
-//         [128, 384) f32[2][32]  d loss / d raw of the tile's 32 samples per net (the output layer's weight gradient)
+//       kernel is to read D_0.  Under fp8 staging block NL-1 holds relu'(H_{NL-1}) g WITHOUT the factor Wo[f]: the weight-gradient
+//       kernel then leaves S[f][k] = sum_n relu' g H_{NL-2}[k] and s[f] = sum_n relu' g, from which the reduce kernel forms
+//           dW_{NL-1}[f][k] = Wo[f] S[f][k],  db_{NL-1}[f] = Wo[f] s[f],  dWo[f] = sum_k W_{NL-1}[f][k] S[f][k] + b_{NL-1}[f] s[f]
+//       -- the last identity because sum_n g relu(z) = sum_n g relu'(z) z with z = W_{NL-1} H_{NL-2} + b_{NL-1}: the output layer's
+//       weight gradient needs neither the layer's input in the store nor a pass of its own.
+//       Behind all nets' blocks of a 32-sample tile a 128-byte record; the first record of a 64-sample wave tile holds the
+//       INVERSE scale of the tile per net (f32[2])
 #define NCA_H8_LOG2 2
 #define NCA_D8_LOG2 4            // the tile's largest |d loss / d raw| is scaled into [2^4, 2^5)
-#define NCA_D8_REC_BYTES 384
-#define NCA_D8_REC_G 128         // byte offset of the gradient rows inside a record
+#define NCA_D8_REC_BYTES 128
 NCA_HD inline int64_t nca_bf_hoff(const NcaLayout& y, int j, bool h8) { return (int64_t)j * (h8 ? 32 : 64) * y.F; }
-NCA_HD inline int64_t nca_bf_hbytes(const NcaLayout& y, bool h8) { return y.NL < 2 ? 0 : (h8 ? nca_bf_hoff(y, y.NL, true) : nca_bf_hoff(y, y.NL - 1, false)); }
+NCA_HD inline int64_t nca_bf_hbytes(const NcaLayout& y, bool h8) { return y.NL < 2 ? 0 : nca_bf_hoff(y, y.NL - 1, h8); }
 NCA_HD inline int64_t nca_bf_doff(const NcaLayout& y, int l, bool d8) { return (int64_t)l * (d8 ? 32 : 64) * y.F; }
 NCA_HD inline int64_t nca_bf_dbytes(const NcaLayout& y, bool d8) { return nca_bf_doff(y, y.NL, d8); }
 

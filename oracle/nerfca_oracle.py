@@ -250,23 +250,50 @@ class _StagedLinear(torch.autograd.Function):
 
 
 class _StagedOut(torch.autograd.Function):
-    """The F -> 1 output layer of the bf16 HIP path under the staging emulation: forward in f32 on the f32 activations (as the
-    kernels do); backward: the input gradient g Wo in f32 (the previous layer rounds it to bf16), the weight gradient from the
-    layer input as the weight-gradient kernel reads it -- e4m3(bf16(h) 2^H8_LOG2) / 2^H8_LOG2 under fp8 staging (block NL-1 of the
-    store; g itself stays f32), bf16(h) under bf16 staging."""
+    """The F -> 1 output layer of the bf16 HIP path under the BF16-staging emulation: forward in f32 on the f32 activations (as
+    the kernels do); backward: the input gradient g Wo in f32 (the previous layer rounds it to bf16), the weight gradient from
+    the bf16-rounded layer input (the dgrad kernel forms it from the packed activations of the recomputed last layer)."""
 
     @staticmethod
-    def forward(ctx, h, Wo, bo, h8: Optional[str]):
+    def forward(ctx, h, Wo, bo):
         ctx.save_for_backward(h, Wo)
-        ctx.h8 = h8
         return h @ Wo.t() + bo
 
     @staticmethod
     def backward(ctx, g):
         h, Wo = ctx.saved_tensors
-        hq = h.to(torch.bfloat16).to(h.dtype)
-        hh = _q8(hq * 2.0 ** H8_LOG2, ctx.h8) / 2.0 ** H8_LOG2 if ctx.h8 else hq
-        return g @ Wo, g.t() @ hh, g.sum(0), None
+        return g @ Wo, g.t() @ h.to(torch.bfloat16).to(h.dtype), g.sum(0)
+
+
+class _StagedTail(torch.autograd.Function):
+    """Last F-wide layer + ReLU + the F -> 1 output layer of the bf16 HIP path under FP8 staging (mode 5, nca_layout.hpp): nothing
+    is recomputed, and the block the weight-gradient kernel gets for the last layer is relu'(z) g without the factor Wo:
+        S = e5m2(bf16(g) relu' s_tile)^T / s_tile  x  e4m3(bf16(x) 2^H8_LOG2) / 2^H8_LOG2,      s = column sums of the first factor,
+        dW = Wo[f] S,  db = Wo[f] s,  dWo[f] = <bf16(W)[f], S[f]> + b[f] s[f],  dbo = sum g,
+        dx = (bf16(Wo g) relu') bf16(W)                                  (the chain operand keeps Wo and is rounded to bf16)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, Wo, bo, state, d8: Optional[str], h8: Optional[str]):
+        xq, Wq = x.to(torch.bfloat16).to(x.dtype), W.to(torch.bfloat16).to(W.dtype)
+        z = xq @ Wq.t() + b
+        ctx.save_for_backward(xq, Wq, b, Wo, z)
+        ctx.state, ctx.d8, ctx.h8 = state, d8, h8
+        return torch.relu(z) @ Wo.t() + bo
+
+    @staticmethod
+    def backward(ctx, g):
+        xq, Wq, b, Wo, z = ctx.saved_tensors
+        on = (torch.relu(z).to(torch.bfloat16) > 0).to(g.dtype)          # the stored mask: the packed (bf16) activation is positive
+        chain = (g @ Wo).to(torch.bfloat16).to(g.dtype) * on              # D_{NL-1} as the sweep's operand
+        gq = g.to(torch.bfloat16).to(g.dtype) * on                        # what goes to the weight-gradient kernel
+        if ctx.d8:
+            sc = ctx.state["scale"]
+            gq = _q8(gq * sc, ctx.d8) / sc
+        hh = _q8(xq * 2.0 ** H8_LOG2, ctx.h8) / 2.0 ** H8_LOG2 if ctx.h8 else xq
+        S, s = gq.t() @ hh, gq.sum(0)
+        wo = Wo.reshape(-1)
+        dWo = ((Wq * S).sum(1) + b * s).reshape(Wo.shape)
+        return chain @ Wq, wo[:, None] * S, wo * s, dWo, g.sum(0), None, None, None
 
 
 def mlp(params: Dict[str, Tensor], spec: NetSpec, feats: Tensor) -> Tensor:
@@ -285,11 +312,17 @@ def mlp(params: Dict[str, Tensor], spec: NetSpec, feats: Tensor) -> Tensor:
         for i in range(NL):
             last = i == NL - 1
             d8 = None if (last and spec.emulate_onchip_last) else fd     # on chip: bf16 registers, nothing is staged
-            # every staged layer's input is e4m3 when its weight gradient is formed: the inputs of layers 1..NL-2 cross HBM as
-            # e4m3, the bf16 input block and the bf16 input of the last layer are rounded to e4m3 inside the weight-gradient kernel
+            # every staged layer's input is e4m3 when its weight gradient is formed: the hidden blocks cross HBM as e4m3, the bf16
+            # input block is rounded to e4m3 inside the weight-gradient kernel
             h8 = fh if d8 is not None else None
+            if last and fd is not None and NL >= 2:
+                # fp8 staging (a store needs a hidden layer): last layer and output layer as the mode-5 kernels treat them
+                raw = _StagedTail.apply(h, params[f"early_pts_layers.{2 * i}.weight"], params[f"early_pts_layers.{2 * i}.bias"],
+                                        params["output_linear.0.weight"], params["output_linear.0.bias"], state, d8, h8)
+                break
             h = torch.relu(_StagedLinear.apply(h, params[f"early_pts_layers.{2 * i}.weight"], params[f"early_pts_layers.{2 * i}.bias"], state, d8, h8, i == 0))
-        raw = _StagedOut.apply(h, params["output_linear.0.weight"], params["output_linear.0.bias"], fh)
+        else:
+            raw = _StagedOut.apply(h, params["output_linear.0.weight"], params["output_linear.0.bias"])
         if raw.requires_grad:      # d loss / d raw arrives before the layers' backward runs: fix the tile scales there
             raw.register_hook(lambda g: state.__setitem__("scale", _tile_scales(g, spec.emulate_fp8_stage)))
         return raw
