@@ -344,7 +344,7 @@ struct StorePlan {
 static bool store_plan(const NcaLayout* lays, int nnets, int32_t prec, int64_t wave_tiles, StorePlan* sp, bool share_enc = false, bool h8 = false) {
     if (nnets == 2 && lays[0].F != lays[1].F) return false;
     const bool bf = prec == NCA_PREC_BF16;
-    const int64_t EB = 32 * (int64_t)NCA_BF_ENCROWS * 2;
+    const int64_t EB = nca_bf_ebytes(bf && h8);
     // bf16: slack tile slots up to the next multiple of the 8 waves of a workgroup -- a wave without a tile writes there, so
     // that the storing forward's hot loops need no store predicate
     if (bf) wave_tiles = (wave_tiles + NCA_WAVES - 1) / NCA_WAVES * NCA_WAVES;
@@ -628,7 +628,7 @@ static void add_jobs_f32(NcaWgradArgs* w, const NcaLayout& y, int64_t row0, int6
 // h8 / d8: formats of the store's hidden blocks and of this launch's D blocks (fp8 staging)
 static void make_job_bf16(NcaWgradJob& g, const NcaLayout& y, int j, int64_t net_off, int64_t d_off, int64_t slab_off, int64_t onehot_off, int64_t enc_off,
                           bool h8, bool d8) {
-    const int64_t EB = 32 * (int64_t)NCA_BF_ENCROWS * 2;
+    const int64_t EB = nca_bf_ebytes(h8);
     const NcaLayerL& l = y.layer[j];
     memset(&g, 0, sizeof(g));
     g.F = y.F;
@@ -643,6 +643,7 @@ static void make_job_bf16(NcaWgradJob& g, const NcaLayout& y, int j, int64_t net
         g.is_enc = 1;
         g.b_row0 = enc_off;          // the input block (the other net's when it is shared)
         g.b_row_bytes = NCA_BF_ENCROWS * 2;
+        g.h8 = h8 ? 1 : 0;           // fp8 staging: the input block is stored as e4m3 as well
         g.ncols_w = y.Kenc;
         g.T = y.T;
         g.P = y.P;

@@ -397,7 +397,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
     constexpr int MT = BfCfg<F>::MT, KS = BfCfg<F>::KS, KS0 = BfCfg<F>::KS0, KSMAX = BfCfg<F>::KSMAX;
     constexpr int BUF = BfCfg<F>::BUF_BYTES;
     constexpr int HB = 32 * F * 2;                          // bytes of one hidden scratch block (32 samples x F)
-    constexpr int EB = 32 * NCA_BF_ENCROWS * 2;             // bytes of the input block
+    constexpr int EB = (FSTORE && S8) ? 32 * 128 : 32 * NCA_BF_ENCROWS * 2;      // bytes of the input block (fp8 staging: e4m3, nca_bf_ebytes)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     static_assert(!RES || MODE == NCA_KM_FWD || MODE == NCA_KM_FWD_STORE || MODE == NCA_KM_BWD_STORED || NR, "resident images: forward and backward from the store");
     const int wbytes = RES ? a.res_bytes : 2 * BUF;             // weight images: all of them / the double buffer
@@ -613,8 +613,6 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
 #pragma unroll
                     for (int c = 0; c < 2; ++c) {
                         char* blk = nb + c * a.rows_total + lane * 16;
-#pragma unroll
-                        for (int s = 0; s < KS0; ++s) store_nt(blk + s * 1024, B[c][s]);
                         const int pc = __shfl(phc, 32 * c + lr);          // phase of sample 32c + r
                         u32x4 hot;
 #pragma unroll
@@ -623,7 +621,22 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                             const unsigned hi = (y.P > 0 && pc == 8 * lh + 2 * w + 1) ? 0x3f800000u : 0u;
                             hot[w] = lo | hi;
                         }
-                        store_nt(blk + KS0 * 1024, hot);
+                        if (FSTORE && S8) {
+                            // e4m3 (x 2^NCA_H8_LOG2), two k-steps per 16 bytes: [32-slot tile][lane][16 B] (nca_bf_ebytes)
+                            static_assert(KS0 == 6, "input block: six k-steps of layer-0 slots + one of one-hot slots");
+                            constexpr float DIV = 1.f / (float)(1 << NCA_H8_LOG2);
+                            const u32x4 zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                const u32x4 lo = t < 3 ? B[c][2 * t] : hot, hi = t < 3 ? B[c][2 * t + 1] : zero;
+                                const u32x4 q = {cvt4_e4m3_pk(lo[0], lo[1], DIV), cvt4_e4m3_pk(lo[2], lo[3], DIV), cvt4_e4m3_pk(hi[0], hi[1], DIV), cvt4_e4m3_pk(hi[2], hi[3], DIV)};
+                                store_nt(blk + t * 1024, q);
+                            }
+                        } else {
+#pragma unroll
+                            for (int s = 0; s < KS0; ++s) store_nt(blk + s * 1024, B[c][s]);
+                            store_nt(blk + KS0 * 1024, hot);
+                        }
                     }
                 }
             }
@@ -1533,11 +1546,13 @@ __global__ __launch_bounds__(64, 1) void nca_wgrad_bf16(const NcaWgradArgs a) {
     // (at F = 128 the 112-slot input block and a hidden block have the same shape: one body serves both)
     if constexpr (D8) {
         s8_mode();
-        if (job.h8) wgrad_job_mx<F, F / 32, true>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
+        if (F != 128 && job.is_enc && job.h8) wgrad_job_mx<F, 4, true>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
+        else if (job.h8) wgrad_job_mx<F, F / 32, true>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
         else if (F != 128 && job.is_enc) wgrad_job_mx<F, 4, false>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
         else wgrad_job_mx<F, F == 128 ? 4 : F / 32, false>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
     } else {
-        if (job.h8) wgrad_job<F, F / 32, D8, true>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
+        if (F != 128 && job.is_enc && job.h8) wgrad_job<F, 4, D8, true>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
+        else if (job.h8) wgrad_job<F, F / 32, D8, true>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
         else if (F != 128 && job.is_enc) wgrad_job<F, 4, D8, false>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
         else wgrad_job<F, F == 128 ? 4 : F / 32, D8, false>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
     }

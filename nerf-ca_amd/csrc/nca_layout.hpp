@@ -261,6 +261,10 @@ inline int nca_build_layout_bf16(const NcaNet& n, NcaLayout* out, const char** w
 #define NCA_H8_LOG2 2
 #define NCA_D8_LOG2 4            // the tile's largest |d loss / d raw| is scaled into [2^4, 2^5)
 #define NCA_D8_REC_BYTES 128
+// the input block of a 32-sample tile: bf16 fragments [k-step 0..6][lane][16 B] (6 k-steps of layer-0 slots + the one-hot phase
+// slots), or, under fp8 staging, e4m3 (x 2^NCA_H8_LOG2) [32-slot tile 0..3][lane][16 B] -- byte 8 a + j of lane (r, h) = slot
+// 32 t + 16 a + 8 h + j of sample r: what the weight-gradient kernel rounds the bf16 block to anyway
+NCA_HD inline int64_t nca_bf_ebytes(bool h8) { return h8 ? 32 * 128 : 32 * (int64_t)NCA_BF_ENCROWS * 2; }
 NCA_HD inline int64_t nca_bf_hoff(const NcaLayout& y, int j, bool h8) { return (int64_t)j * (h8 ? 32 : 64) * y.F; }
 NCA_HD inline int64_t nca_bf_hbytes(const NcaLayout& y, bool h8) { return y.NL < 2 ? 0 : nca_bf_hoff(y, y.NL - 1, h8); }
 NCA_HD inline int64_t nca_bf_doff(const NcaLayout& y, int l, bool d8) { return (int64_t)l * (d8 ? 32 : 64) * y.F; }
