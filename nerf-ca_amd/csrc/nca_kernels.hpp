@@ -90,6 +90,8 @@ struct NcaFusedArgs {
     int32_t nstages;
     int32_t mask_layers; // backward: ReLU masks of this many layers per wave are kept in LDS (0: re-read H)
     int32_t const_net_floats; // f32 kernels: floats per net of the LDS constant area (window, fourier, latents), set by the launcher
+    int32_t ctr_off;     // bf16, resident images: byte offset in LDS of the workgroup's tile counter (set by the launcher) -- the waves claim
+                         // tiles as they finish (the second wave of a SIMD runs ~25 % slower than the first)
     int32_t res_bytes;   // bf16: > 0 = every weight image of this launch stays resident in LDS (stage[i].lds_off), this many bytes
                          // in all
     int32_t res_total;   // host only: bytes of all images of the launch laid back to back (build_stages)
@@ -252,5 +254,7 @@ hipError_t nca_launch_pack_bf16(const NcaLayout& y, const float* prm, void* out,
 hipError_t nca_launch_fused_bf16(int F, const NcaFusedArgs& a, int kmode, int grid, hipStream_t st, bool s8 = false);
 // LDS bytes a fused bf16 launch of this mode needs NEXT TO its weight images (constants, output-layer partials)
 size_t nca_fused_bf16_lds_other(int F, int kmode);
+// mode 5: adds the per-tile sums of d loss / d raw in the tile records (in tile order) into workgroup 0's output-bias slot of oslab
+hipError_t nca_launch_sum_tile_records(const char* dregion, int64_t wave_tile_bytes, int64_t dscale_off, int64_t ntiles, int nnets, int F, float* oslab, hipStream_t st);
 hipError_t nca_launch_wgrad_bf16(int F, const NcaWgradArgs& a, int nsplit, hipStream_t st);
 hipError_t nca_launch_pix_f32(int64_t R, int nchunk, const float* I0, const double* part, double* pix, hipStream_t st);

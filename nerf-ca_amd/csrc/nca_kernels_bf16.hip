@@ -428,6 +428,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
         if (na.lat) for (int i = tid; i < na.lay.P * na.lay.T; i += NCA_NT) c[NCA_CONST_WIN + NCA_CONST_FOUR + i] = na.lat[i];
     }
     if (BWD) for (int i = tid; i < NCA_WAVES * 2 * (F + 1); i += NCA_NT) osum[i] = 0.f;
+    if (RES && tid == 0) *reinterpret_cast<int*>(smem + a.ctr_off) = 0;
     if (NR)
         for (int net = 0; net < a.nnets; ++net)
             for (int i = tid; i < 2 * MT * 16 + 1; i += NCA_NT) wo_lds[net * bf_wo_floats(F) + i] = a.net[net].wo_src[i];
@@ -464,8 +465,28 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
 #define NCA_STAMP(k)
 #endif
     const int64_t ngroups = (a.ntiles + NCA_WAVES - 1) / NCA_WAVES;
-    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-        const int64_t tile = grp * NCA_WAVES + wave;           // 64-sample tile
+    // This workgroup's tiles: groups blockIdx.x, blockIdx.x + gridDim.x, ... of 8.  Streaming kernels: wave w takes tile w of every
+    // group (the waves meet at every stage's barrier anyway).  Resident images: no barrier couples the waves, and the second wave
+    // of a SIMD gets the issue slots the first leaves -- it runs ~25 % slower -- so each wave CLAIMS its next tile from a counter
+    // in LDS.  Nothing that is summed across tiles stays in a wave, so the results do not depend on who ran which tile.
+    // (mode 3 keeps per-wave sums of the output layer's gradients across tiles: static there)
+    constexpr bool DYN = RES && MODE != NCA_KM_BWD_STORED;
+    const int64_t my_groups = (int64_t)blockIdx.x < ngroups ? (ngroups - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    for (int64_t it = 0;; ++it) {
+        int64_t grp;
+        int wslot = wave;
+        if (DYN) {
+            int k = 0;
+            if (lane == 0) k = __hip_atomic_fetch_add(static_cast<int*>(__builtin_assume_aligned(smem + a.ctr_off, 16)), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            k = __builtin_amdgcn_readfirstlane(k);
+            if (k >= my_groups * NCA_WAVES) break;
+            grp = blockIdx.x + (int64_t)(k / NCA_WAVES) * gridDim.x;
+            wslot = k % NCA_WAVES;
+        } else {
+            grp = blockIdx.x + it * gridDim.x;
+            if (grp >= ngroups) break;
+        }
+        const int64_t tile = grp * NCA_WAVES + wslot;          // 64-sample tile
         const bool tvalid = tile < a.ntiles;
         const int64_t tl = tvalid ? tile : a.ntiles - 1;
 
@@ -781,7 +802,9 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                     }
                     const float gsum = half_sum_b(g) ;            // sum over the 32 lanes of each half
                     const float gtot = gsum + __shfl_xor(gsum, 32);
-                    if (lane == 0) orow[F] += gtot;
+                    if (NR) {          // the tile's sum goes to its record (the weight-gradient kernel adds the tiles up in tile order)
+                        if (lane == 0 && tvalid) reinterpret_cast<float*>(d32 + a.dscale_off)[2 + net + a.net_base] = gtot;
+                    } else if (lane == 0) orow[F] += gtot;
 #pragma unroll
                     for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -1539,6 +1562,30 @@ __device__ __forceinline__ void wgrad_job_mx(const NcaWgradArgs& a, const NcaWgr
     wgrad_write<F, NTB>(acc, bsum, job, a.slab + (int64_t)q * a.slab_stride, a.accumulate, lane);
 }
 
+// Mode 5: the output layer's bias gradient = sum over the wave tiles of the per-tile sums of d loss / d raw that the dgrad kernel left
+// in the tile records (f32[2] behind the inverse scales) -- added in TILE order by one workgroup (fixed tree), whichever wave ran
+// which tile, into workgroup 0's bias slot of the output-layer partials (the dgrad launch before it left that slot's share at 0).
+__global__ __launch_bounds__(256) void nca_sum_tile_records(const char* dregion, int64_t wave_tile_bytes, int64_t dscale_off, int64_t ntiles, int nnets, int F,
+                                                            float* oslab) {
+    __shared__ float part[256];
+    for (int net = 0; net < nnets; ++net) {
+        float s = 0.f;
+        for (int64_t t = threadIdx.x; t < ntiles; t += 256) s += reinterpret_cast<const float*>(dregion + t * wave_tile_bytes + dscale_off)[2 + net];
+        part[threadIdx.x] = s;
+        __syncthreads();
+        for (int d = 128; d >= 1; d >>= 1) {
+            if ((int)threadIdx.x < d) part[threadIdx.x] += part[threadIdx.x + d];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) oslab[net * (F + 1) + F] += part[0];
+        __syncthreads();
+    }
+}
+hipError_t nca_launch_sum_tile_records(const char* dregion, int64_t wave_tile_bytes, int64_t dscale_off, int64_t ntiles, int nnets, int F, float* oslab, hipStream_t st) {
+    hipLaunchKernelGGL(nca_sum_tile_records, dim3(1), dim3(256), 0, st, dregion, wave_tile_bytes, dscale_off, ntiles, nnets, F, oslab);
+    return hipGetLastError();
+}
+
 template <int F, bool D8>
 __global__ __launch_bounds__(64, 1) void nca_wgrad_bf16(const NcaWgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char wring[];
@@ -1567,8 +1614,14 @@ static hipError_t launch_fused_bf_mode(const NcaFusedArgs& a, int grid, hipStrea
     size_t lds = (RES ? (size_t)a.res_bytes : 2 * BfCfg<F>::BUF_BYTES) + bf_const_bytes(MODE);
     if (bwd) lds += NCA_WAVES * 2 * (F + 1) * sizeof(float);
     if (MODE == NCA_KM_BWD_NR) lds += 2 * bf_wo_floats(F) * sizeof(float);
+    static thread_local NcaFusedArgs b;
+    const NcaFusedArgs* pa = &a;
     if (RES) {
         if (a.res_bytes <= 0 || a.nstages <= 0) return hipErrorInvalidValue;
+        b = a;
+        b.ctr_off = (int32_t)lds;            // the workgroup's tile counter
+        lds += 16;
+        pa = &b;
         const size_t dma_end = (size_t)a.stage[a.nstages - 1].lds_off + a.stage[a.nstages - 1].bytes;       // whole 1 KiB pieces
         if (dma_end > lds) lds = dma_end;
         if (lds > (size_t)NCA_LDS_BYTES) return hipErrorInvalidValue;
@@ -1579,7 +1632,7 @@ static hipError_t launch_fused_bf_mode(const NcaFusedArgs& a, int grid, hipStrea
         lds += (size_t)NCA_WAVES * (2 * MT * 1024 > BPW * 16 * 256 ? 2 * MT * 1024 : BPW * 16 * 256);
     }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_fused_bf16<F, MODE, S8, RES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((nca_fused_bf16<F, MODE, S8, RES>), dim3(grid), dim3(NCA_NT), lds, st, a);
+    hipLaunchKernelGGL((nca_fused_bf16<F, MODE, S8, RES>), dim3(grid), dim3(NCA_NT), lds, st, *pa);
     return hipGetLastError();
 }
 template <int F>
@@ -1607,7 +1660,7 @@ static hipError_t launch_fused_bf(const NcaFusedArgs& a, int kmode, int grid, hi
 
 size_t nca_fused_bf16_lds_other(int F, int kmode) {
     const bool bwd = kmode == NCA_KM_BWD || kmode == NCA_KM_BWD_STORED || kmode == NCA_KM_BWD_ONCHIP || kmode == NCA_KM_BWD_NR;
-    return bf_const_bytes(kmode) + (bwd ? NCA_WAVES * 2 * (F + 1) * sizeof(float) : 0) + (kmode == NCA_KM_BWD_NR ? 2 * bf_wo_floats(F) * sizeof(float) : 0);
+    return bf_const_bytes(kmode) + (bwd ? NCA_WAVES * 2 * (F + 1) * sizeof(float) : 0) + (kmode == NCA_KM_BWD_NR ? 2 * bf_wo_floats(F) * sizeof(float) : 0) + 16;       // (+ the tile counter of a resident launch)
 }
 
 hipError_t nca_launch_fused_bf16(int F, const NcaFusedArgs& a, int kmode, int grid, hipStream_t st, bool s8) {
