@@ -825,7 +825,7 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
             if (bf) HIPCHK(nca_launch_fused_bf16(F, a, stored ? (nr ? NCA_KM_BWD_NR : NCA_KM_BWD_STORED) : NCA_KM_BWD, p.grid, st, d8));
             else HIPCHK(nca_launch_fused_f32(F, a, stored ? NCA_KM_BWD_STORED : NCA_KM_BWD, p.grid, st));
         }
-        if (nr) HIPCHK(nca_launch_sum_tile_records(reinterpret_cast<const char*>(scratch), 2 * p.tile_stride, p.tile_stride - NCA_D8_REC_BYTES, a.ntiles, a.nnets, F, oslab, st));
+        if (nr) HIPCHK(nca_launch_sum_tile_records(reinterpret_cast<const char*>(scratch), 2 * p.tile_stride, p.tile_stride - NCA_D8_REC_BYTES, a.ntiles, a.nnets, F, oslab, p.grid, st));
         if (g_depth) {       // d loss / d depth from the D_0 blocks this chunk's dgrad launch just wrote
             NcaZgradArgs zg;
             memset(&zg, 0, sizeof(zg));

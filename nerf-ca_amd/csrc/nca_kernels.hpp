@@ -254,7 +254,8 @@ hipError_t nca_launch_pack_bf16(const NcaLayout& y, const float* prm, void* out,
 hipError_t nca_launch_fused_bf16(int F, const NcaFusedArgs& a, int kmode, int grid, hipStream_t st, bool s8 = false);
 // LDS bytes a fused bf16 launch of this mode needs NEXT TO its weight images (constants, output-layer partials)
 size_t nca_fused_bf16_lds_other(int F, int kmode);
-// mode 5: adds the per-tile sums of d loss / d raw in the tile records (in tile order) into workgroup 0's output-bias slot of oslab
-hipError_t nca_launch_sum_tile_records(const char* dregion, int64_t wave_tile_bytes, int64_t dscale_off, int64_t ntiles, int nnets, int F, float* oslab, hipStream_t st);
+// mode 5: adds the per-tile sums of d loss / d raw in the tile records (fixed order) into the workgroups' output-bias slots of oslab
+hipError_t nca_launch_sum_tile_records(const char* dregion, int64_t wave_tile_bytes, int64_t dscale_off, int64_t ntiles, int nnets, int F, float* oslab, int n_wg,
+                                       hipStream_t st);
 hipError_t nca_launch_wgrad_bf16(int F, const NcaWgradArgs& a, int nsplit, hipStream_t st);
 hipError_t nca_launch_pix_f32(int64_t R, int nchunk, const float* I0, const double* part, double* pix, hipStream_t st);

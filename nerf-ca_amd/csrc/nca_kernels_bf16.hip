@@ -1563,26 +1563,30 @@ __device__ __forceinline__ void wgrad_job_mx(const NcaWgradArgs& a, const NcaWgr
 }
 
 // Mode 5: the output layer's bias gradient = sum over the wave tiles of the per-tile sums of d loss / d raw that the dgrad kernel left
-// in the tile records (f32[2] behind the inverse scales) -- added in TILE order by one workgroup (fixed tree), whichever wave ran
-// which tile, into workgroup 0's bias slot of the output-layer partials (the dgrad launch before it left that slot's share at 0).
+// in the tile records (f32[2] behind the inverse scales) -- added in TILE order (workgroup b: tiles b, b + grid, ...; fixed tree),
+// whichever wave ran which tile, into workgroup b's bias slot of the output-layer partials (the dgrad launch before it left the
+// slots' shares at 0; the reduce kernel adds the slots up).
 __global__ __launch_bounds__(256) void nca_sum_tile_records(const char* dregion, int64_t wave_tile_bytes, int64_t dscale_off, int64_t ntiles, int nnets, int F,
                                                             float* oslab) {
     __shared__ float part[256];
     for (int net = 0; net < nnets; ++net) {
         float s = 0.f;
-        for (int64_t t = threadIdx.x; t < ntiles; t += 256) s += reinterpret_cast<const float*>(dregion + t * wave_tile_bytes + dscale_off)[2 + net];
+        for (int64_t t = (int64_t)threadIdx.x * gridDim.x + blockIdx.x; t < ntiles; t += 256 * (int64_t)gridDim.x)
+            s += reinterpret_cast<const float*>(dregion + t * wave_tile_bytes + dscale_off)[2 + net];
         part[threadIdx.x] = s;
         __syncthreads();
         for (int d = 128; d >= 1; d >>= 1) {
             if ((int)threadIdx.x < d) part[threadIdx.x] += part[threadIdx.x + d];
             __syncthreads();
         }
-        if (threadIdx.x == 0) oslab[net * (F + 1) + F] += part[0];
+        if (threadIdx.x == 0) oslab[(int64_t)blockIdx.x * 2 * (F + 1) + net * (F + 1) + F] += part[0];
         __syncthreads();
     }
 }
-hipError_t nca_launch_sum_tile_records(const char* dregion, int64_t wave_tile_bytes, int64_t dscale_off, int64_t ntiles, int nnets, int F, float* oslab, hipStream_t st) {
-    hipLaunchKernelGGL(nca_sum_tile_records, dim3(1), dim3(256), 0, st, dregion, wave_tile_bytes, dscale_off, ntiles, nnets, F, oslab);
+// n_wg: the workgroups of the dgrad launch = rows of oslab
+hipError_t nca_launch_sum_tile_records(const char* dregion, int64_t wave_tile_bytes, int64_t dscale_off, int64_t ntiles, int nnets, int F, float* oslab, int n_wg,
+                                       hipStream_t st) {
+    hipLaunchKernelGGL(nca_sum_tile_records, dim3(n_wg), dim3(256), 0, st, dregion, wave_tile_bytes, dscale_off, ntiles, nnets, F, oslab);
     return hipGetLastError();
 }
 
