@@ -200,11 +200,13 @@ def kernel_table(args, prec, timed_steps):
     from nerfca_amd import _capi
     n_samp = args.rays * args.samples * timed_steps
     kern = {}
-    # bf16 with a forward store at this size: the weight gradient of the last hidden layer of both nets (2 x 2 x 128 x 128 FLOP
-    # per sample) is accumulated inside the dgrad kernel (two launches per step, one per net), not by the wgrad kernel
+    # bf16 with BF16 staging at this size (NCA_STAGE_FP8=0): the weight gradient of the last hidden layer of both nets (2 x 2 x 128 x
+    # 128 FLOP per sample) is accumulated inside the dgrad kernel (mode 4), not by the wgrad kernel.  The default, fp8 staging,
+    # runs mode 5 (nothing recomputed; also one dgrad launch per net when the weight images are resident) and all of it in the wgrad
     dg_ms, dg_n = _capi.timing_read("bwd_dgrad")
     wg_ms, wg_n = _capi.timing_read("bwd_wgrad")
-    onchip = prec == "bf16" and wg_n > 0 and dg_n == 2 * wg_n
+    fp8 = prec == "bf16" and _capi.get_option(_capi.OPT_STAGE_FP8) != 0
+    onchip = prec == "bf16" and not fp8 and wg_n > 0 and dg_n == 2 * wg_n
     moved = 2 * 2 * 128 * 128 if onchip else 0
     for name, flop in (("fwd", FLOP_FWD), ("bwd_dgrad", FLOP_DGRAD + moved), ("bwd_wgrad", FLOP_WGRAD - moved), ("bwd_reduce", 0), ("loss", 0), ("pack", 0)):
         ms, n = _capi.timing_read(name)
@@ -393,6 +395,10 @@ def main():
                "config": {"workload": f"run_composite XCAT {args.views}-view x 10 phases, {args.det}^2 detector x {args.samples} samples/ray, "
                                       f"{args.rays} rays/step/GPU (one full detector), F=128 x 4 hidden layers x 2 nets, L=12, fwd+losses+bwd+Adam",
                           "rays_per_step_per_gpu": args.rays, "samples_per_ray": args.samples, "parallelism": f"ray-sharded dp{world}", "hip_graph": bool(args.graph),
+                          "stage_fp8": bool(args.prec == "bf16" and _capi.get_option(_capi.OPT_STAGE_FP8) != 0),
+                          "backward": ("mode 5: from the forward's fp8-staged store, nothing recomputed" if args.prec == "bf16" and _capi.get_option(_capi.OPT_STAGE_FP8) != 0
+                                       else ("mode 4: from the store, last hidden layer's wgrad on chip" if onchip else "from the store / recompute")),
+                          "launches_per_step": {k: (kern[k]["launches"] // max(timed_steps, 1)) for k in ("fwd", "bwd_dgrad", "bwd_wgrad")},
                           "onchip_last_layer_wgrad": bool(onchip)},
                "rccl_ranks": rccl_ranks, "roofline": roof, "final_loss": float(loss),
                "store_fallbacks": fused_mod.STORE_FALLBACKS}       # > 0: some backward ran on the recompute path (store did not fit)

@@ -16,10 +16,11 @@ tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
 src = os.path.join(ROOT, "gpurun_out", f"prof_{prec}")
 dst = os.path.join(ROOT, "profiles")
 # candidate kernel names per role, most specific first (kernel modes: 0 forward, 1 recompute backward, 2 storing forward,
-# 3 backward from the store, 4 the same with the last hidden layer's weight gradient on chip, one launch per net)
+# 3 backward from the store, 4 the same with the last hidden layer's weight gradient on chip, 5 backward from an fp8-staged store
+# without recompute; modes 2 and 5 run one launch per net when the weight images are resident in LDS)
 # (no closing bracket: the f32 kernels carry a third template argument, the split-bf16 switch)
 KERNELS = {"fwd": [f"nca_fused_{prec}<128, 2", f"nca_fused_{prec}<128, 0", f"nca_fused_{prec}<128, false"],
-           "bwd_dgrad": [f"nca_fused_{prec}<128, 4", f"nca_fused_{prec}<128, 3", f"nca_fused_{prec}<128, 1", f"nca_fused_{prec}<128, true"],
+           "bwd_dgrad": [f"nca_fused_{prec}<128, 5", f"nca_fused_{prec}<128, 4", f"nca_fused_{prec}<128, 3", f"nca_fused_{prec}<128, 1", f"nca_fused_{prec}<128, true"],
            "bwd_wgrad": ["nca_wgrad_bf16<128, true", "nca_wgrad_bf16<128, false", "nca_wgrad_bf16<128>"] if prec == "bf16" else ["nca_wgrad_f32x3", "nca_wgrad_f32"], "bwd_reduce": ["nca_reduce_f32"],
            "loss": ["nca_loss_rays"]}
 
@@ -78,7 +79,8 @@ traffic = {"how": "rocprofv3 --pmc FETCH_SIZE (and, in a second run, --pmc WRITE
                   "doubled (gfx950 reports half of a wide coalesced stream, MI355X_MICROARCH.md section HBM); WRITE_SIZE as is",
            "config": {"prec": prec, "rays_per_step": bench["config"]["rays_per_step_per_gpu"], "samples_per_ray": bench["config"]["samples_per_ray"],
                       "ray_chunks_per_step": bench["roofline"]["all_kernels"]["bwd_wgrad"]["launches"] // bench["steps"],
-                      "dgrad_launches_per_step": bench["roofline"]["all_kernels"]["bwd_dgrad"]["launches"] // bench["steps"]},
+                      "dgrad_launches_per_step": bench["roofline"]["all_kernels"]["bwd_dgrad"]["launches"] // bench["steps"],
+                      "fwd_launches_per_step": bench["roofline"]["all_kernels"]["fwd"]["launches"] // bench["steps"]},
            "kernels": {}}
 for key, names in KERNELS.items():
     fk, name = pick(fetch, names)
