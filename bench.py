@@ -57,15 +57,18 @@ def parse(argv=None):
     ap.add_argument("--cpu-steps", type=int, default=5, help="timed CPU steps (plus one warm-up): ~20 s of CPU work at the defaults")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the f32 sub-record, the unfused GPU baseline and the PSNR record")
-    ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph (library Adam+LinearLR); "
+    ap.add_argument("--graph", action="store_true", help="(the default) replay the step from a captured HIP graph (library Adam+LinearLR); "
                     "per-kernel timings then come from a short eager pass after the timed region")
+    ap.add_argument("--eager", action="store_true", help="launch every kernel of the step from the host instead (CompositeTrainer.step, torch Adam)")
     ap.add_argument("--unfused-gpu-rays", type=int, default=16384, help="rays/step of the unfused torch path on cuda:0 (0: skip)")
     ap.add_argument("--unfused-gpu-steps", type=int, default=3)
     ap.add_argument("--f32-steps", type=int, default=4)
     ap.add_argument("--psnr-steps", type=int, default=100, help="steps of the PSNR record (64^2 detector, 256 rays/step; 0: skip)")
     ap.add_argument("--views", type=int, default=4)
     ap.add_argument("--torch-losses", action="store_true", help="losses + autograd in torch ops instead of the fused loss kernel")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    args.graph = not args.eager            # the whole step as one captured HIP graph unless --eager
+    return args
 
 
 def host_cores() -> int:
@@ -376,6 +379,9 @@ def main():
     timed_steps = args.steps
     if args.graph:       # events cannot be recorded inside a replayed graph: time the same kernels eagerly, outside dt
         timed_steps = min(args.steps, 4)
+        tr.step(base_iter)          # (untimed: the eager step's first pass allocates its own store, and first-touch page mapping shows in the kernels)
+        barrier()
+        _capi.timing_reset()
         _capi.timing_enable(True)
         for i in range(timed_steps):
             tr.step(base_iter + i)

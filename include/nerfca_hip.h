@@ -111,11 +111,12 @@ int nca_pack_weights(const NcaNet* net, const float* params, void* packed, int32
  *   pix   f64[R]    = I0 - sum_s (sigma_s + sigma_d) * dists
  *   sig_s f32[R,S], sig_d f32[R,S]  (activation * scale; un-scaled in single_field mode)
  *   work  scratch of nca_render_fwd_workspace() bytes.
- *   store NULL, or a caller-owned buffer of nca_render_store_bytes() bytes: the forward then also leaves every layer
- *         input, the ReLU masks and the raw outputs there (what the reference's autograd graph keeps,
- *         train/run_composite.py:306), and nca_render_bwd given the same buffer does not recompute the layers.
- *         nca_render_store_bytes() returns 0 where this is not available (f32 path, nets of different width, nets
- *         without a hidden layer): pass NULL there. */
+ *   store NULL, or a caller-owned buffer of nca_render_store_bytes() bytes: the forward then also leaves there what the
+ *         reference's autograd graph keeps (train/run_composite.py:306) -- f32: every layer input, the ReLU masks and the
+ *         raw outputs; bf16: the layer inputs as e4m3 (NCA_OPT_STAGE_FP8, default) or bf16, the ReLU masks and (fp8 staging)
+ *         the raw outputs -- and nca_render_bwd given the same buffer does not recompute the layers.
+ *         nca_render_store_bytes() returns 0 where this is not available (nets of different width, nets without a hidden
+ *         layer): pass NULL there. */
 int64_t nca_render_fwd_workspace(const NcaRays* rays);
 int64_t nca_render_store_bytes(const NcaRays* rays, const NcaNet* net_s, const NcaNet* net_d, int32_t prec);
 int nca_render_fwd(const NcaRays* rays, int32_t prec,
@@ -241,17 +242,19 @@ int nca_adam_step(const NcaAdam* cfg, int32_t n_seg, const int64_t* n, float* co
 /* ---- process-wide tunables: A/B switches of the planner, also the hook with which tests force a kernel path at sizes the
  *      oracle can afford.  nca_set_option returns NCA_OK or NCA_E_INVALID; values persist until changed. ------------------- */
 enum {
-    NCA_OPT_ONCHIP_MIN_TILES = 0, /* bf16 backward from a forward store: keep the last hidden layer's weight gradient on chip (one launch
+    NCA_OPT_ONCHIP_MIN_TILES = 0, /* bf16 backward from a forward store with BF16 staging (NCA_OPT_STAGE_FP8 = 0; fp8 staging recomputes
+                                     nothing and has no use for it): keep the last hidden layer's weight gradient on chip (one launch
                                      per net) when the batch has at least this many 64-sample wave tiles.  0 = always, -1 = never;
                                      default 8 * 8 waves * CUs (initial value from the environment: NCA_ONCHIP=0 -> never, =force -> always) */
     NCA_OPT_STAGE_FP8 = 1,        /* bf16 mode with a forward store: the layer inputs and output gradients that only the weight-gradient
                                      kernel reads cross HBM as 8-bit floats (inputs e4m3, gradients e5m2 scaled by a power of two per
-                                     64-sample tile; f32 accumulation; the MLP contractions themselves stay bf16).  1 = on (default),
-                                     0 = bf16 staging.  Read when a forward writes its store and when a backward reads one: do not
+                                     64-sample tile; f32 accumulation; the MLP contractions themselves stay bf16), the store also holds the
+                                     raw outputs and the masks of every layer, and the backward recomputes nothing.  1 = on (default),
+                                     0 = bf16 staging (the backward recomputes the last layer).  Read when a forward writes its store and when a backward reads one: do not
                                      change it between a forward and its backward.  Initial value from NCA_STAGE_FP8 (0 / 1) */
     NCA_OPT_RESIDENT_MIN_TILES = 2, /* bf16 mode: run the fused kernels with ONE net per launch and all of that net's weight images
                                      resident in LDS (no per-layer weight DMA, no workgroup barrier in the tile loop) when the images fit
-                                     (width 128: up to 4 layers of width 128) and the batch has at least this many 64-sample wave
+                                     (width 128: the input layer + 4 hidden layers forward, 4 transposed images backward) and the batch has at least this many 64-sample wave
                                      tiles.  A two-net render then takes two forward launches (the second composites with the first
                                      one's sigma).  0 = always, -1 = never; default 4 * 8 waves * CUs (NCA_RESIDENT=0 -> never,
                                      =force -> always).  Results are bit-identical to the streaming kernels */

@@ -1,7 +1,8 @@
 """Pixel loss and D2NeRF-style separation regularisers (train/model_helpers.py:189-262, 284-288).
 
 All terms are computed from sigma_s, sigma_d [R,S], the interval lengths dists[S] and the per-ray
-weights in one place.  These are torch device ops for now (SURVEY.md 8(f) rank 1 fuses them).
+weights in one place.  These are the reference's autograd-visible helper functions as torch device ops (what its API
+exports); the training steps use the fused HIP loss kernel instead (nca_loss_fwd_bwd, nerfca_amd/fused.py).
 """
 from __future__ import annotations
 

@@ -4,7 +4,7 @@
 for B in "$@"; do
   for OC in 0 1; do
     export NERFCA_LIB=$PWD/nerf-ca_amd/lib/libnerfca_hip_exp$B.so
-    NCA_ONCHIP=$OC timeout -k 10 200 python3 bench.py --no-extras --no-cpu-baseline --steps 4 --warmup 1 > /tmp/clk.out 2>/dev/null
+    NCA_ONCHIP=$OC timeout -k 10 200 python3 bench.py --eager --no-extras --no-cpu-baseline --steps 4 --warmup 1 > /tmp/clk.out 2>/dev/null
     echo "== exp $B onchip $OC"
     grep GHz /tmp/clk.out | awk '{k=$1" "$2; n[k]++; g[k]+=$(NF-1); us[k]+=$9} END {for (k in n) printf "  %s: %.3f GHz  %.0f us (mean of %d)\n", k, g[k]/n[k], us[k]/n[k], n[k]}' | sort
     grep '^{' /tmp/clk.out | python3 -c "

@@ -10,11 +10,11 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 STEPS=8; [ "$PREC" = f32 ] && STEPS=4
 python3 bench.py --prec $PREC --steps $STEPS --warmup 2 --no-extras > $OUT/bench.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --prec $PREC --steps 6 --warmup 2 --no-cpu-baseline --no-extras > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --prec $PREC --steps 6 --warmup 2 --no-cpu-baseline --no-extras --eager > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -- python3 bench.py --prec $PREC --steps 2 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $OUT/pmc_$C.err
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -- python3 bench.py --prec $PREC --steps 2 --warmup 1 --no-cpu-baseline --no-extras --eager > /dev/null 2> $OUT/pmc_$C.err
 done
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE \
-  --kernel-trace --output-format csv -d $OUT/pmc_SQ -- python3 bench.py --prec $PREC --steps 2 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $OUT/pmc_SQ.err
+  --kernel-trace --output-format csv -d $OUT/pmc_SQ -- python3 bench.py --prec $PREC --steps 2 --warmup 1 --no-cpu-baseline --no-extras --eager > /dev/null 2> $OUT/pmc_SQ.err
 find $OUT -name "*.csv" | sort
 tail -c 400 $OUT/bench.json

@@ -5,5 +5,5 @@ export NERFCA_LIB=$PWD/nerf-ca_amd/lib/libnerfca_hip_exp131072.so
 for RS in 0 1; do for OC in 0 1; do
   echo "== resident $RS onchip $OC"
   R=force; [ $RS = 0 ] && R=0
-  NCA_RESIDENT=$R NCA_ONCHIP=$OC timeout -k 10 200 python3 bench.py --no-extras --no-cpu-baseline --steps 1 --warmup 1 2>/dev/null | grep -a "^mode" | sort | uniq | tail -24
+  NCA_RESIDENT=$R NCA_ONCHIP=$OC timeout -k 10 200 python3 bench.py --eager --no-extras --no-cpu-baseline --steps 1 --warmup 1 2>/dev/null | grep -a "^mode" | sort | uniq | tail -24
 done; done

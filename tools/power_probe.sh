@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run ON the GPU box: board power and clocks (rocm-smi, sampled every ~0.3 s) while bench.py loops over training steps.
-python3 bench.py --no-extras --no-cpu-baseline --steps ${1:-600} --warmup 5 ${2:-} > /tmp/pp.json 2>/dev/null &
+python3 bench.py --eager --no-extras --no-cpu-baseline --steps ${1:-600} --warmup 5 ${2:-} > /tmp/pp.json 2>/dev/null &
 BP=$!
 sleep 12
 for i in $(seq 1 12); do
