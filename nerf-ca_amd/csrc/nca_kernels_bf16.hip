@@ -1445,6 +1445,39 @@ __device__ __forceinline__ unsigned z4_e4m3(float a, float b, float c, float d) 
     return (unsigned)v;
 }
 
+// Four 32 x 32 byte tiles transposed by MFMAs against the 8-bit identity, results in ARCHITECTURAL registers: the compiler's own
+// MFMAs put their results into accumulation registers -- all 256 of which hold dW here -- and then moves the tiles (and the dW
+// blocks they displace) back and forth with v_accvgpr_read / _write: 672 such moves per wave tile, more than every other
+// vector instruction of the loop together.  Inline assembly keeps the products in VGPRs (C = the constant 0: no zeroing either).
+// The hardware does not interlock a vector-ALU read behind an MFMA write, and the compiler does not know these are MFMAs: the
+// wait states are spelled out (2nd product of a tile on the 1st: back to back; VALU read after the last 8-pass product: 11,
+// 21 given here once per four tiles).
+template <bool E5M2>
+__device__ __forceinline__ void transpose4_vgpr(const u32x4 (&x)[4], long E0, long E1, f32x16 (&z)[4]) {
+    long lo[4], hi[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        lo[t] = (long)(((unsigned long)x[t][1] << 32) | x[t][0]);
+        hi[t] = (long)(((unsigned long)x[t][3] << 32) | x[t][2]);
+    }
+    if (E5M2)
+        asm volatile("v_mfma_f32_32x32x16_bf8_bf8 %0, %4, %12, 0\n\tv_mfma_f32_32x32x16_bf8_bf8 %1, %5, %12, 0\n\t"
+                     "v_mfma_f32_32x32x16_bf8_bf8 %2, %6, %12, 0\n\tv_mfma_f32_32x32x16_bf8_bf8 %3, %7, %12, 0\n\t"
+                     "v_mfma_f32_32x32x16_bf8_bf8 %0, %8, %13, %0\n\tv_mfma_f32_32x32x16_bf8_bf8 %1, %9, %13, %1\n\t"
+                     "v_mfma_f32_32x32x16_bf8_bf8 %2, %10, %13, %2\n\tv_mfma_f32_32x32x16_bf8_bf8 %3, %11, %13, %3\n\t"
+                     "s_nop 7\n\ts_nop 7\n\ts_nop 4"
+                     : "=&v"(z[0]), "=&v"(z[1]), "=&v"(z[2]), "=&v"(z[3])
+                     : "v"(lo[0]), "v"(lo[1]), "v"(lo[2]), "v"(lo[3]), "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]), "v"(E0), "v"(E1));
+    else
+        asm volatile("v_mfma_f32_32x32x16_fp8_fp8 %0, %4, %12, 0\n\tv_mfma_f32_32x32x16_fp8_fp8 %1, %5, %12, 0\n\t"
+                     "v_mfma_f32_32x32x16_fp8_fp8 %2, %6, %12, 0\n\tv_mfma_f32_32x32x16_fp8_fp8 %3, %7, %12, 0\n\t"
+                     "v_mfma_f32_32x32x16_fp8_fp8 %0, %8, %13, %0\n\tv_mfma_f32_32x32x16_fp8_fp8 %1, %9, %13, %1\n\t"
+                     "v_mfma_f32_32x32x16_fp8_fp8 %2, %10, %13, %2\n\tv_mfma_f32_32x32x16_fp8_fp8 %3, %11, %13, %3\n\t"
+                     "s_nop 7\n\ts_nop 7\n\ts_nop 4"
+                     : "=&v"(z[0]), "=&v"(z[1]), "=&v"(z[2]), "=&v"(z[3])
+                     : "v"(lo[0]), "v"(lo[1]), "v"(lo[2]), "v"(lo[3]), "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]), "v"(E0), "v"(E1));
+}
+
 template <int F, int NTB, bool H8>
 __device__ __forceinline__ void wgrad_job_mx(const NcaWgradArgs& a, const NcaWgradJob& job, int q, int nsplit, int lane, char* ring) {
     using R = WgradRing<F, NTB, true, H8>;
@@ -1514,8 +1547,24 @@ __device__ __forceinline__ void wgrad_job_mx(const NcaWgradArgs& a, const NcaWgr
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             const char* slot = ring + (int)(ii % NSLOT) * (FR * 1024) + lane * 16;
+            if constexpr (MT == 4) {                         // D: e5m2 bytes -> transposed, bias sums, bytes again
+                u32x4 x[4];
+                f32x16 z[4];
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {                   // D: e5m2 bytes -> transposed, bias sums, bytes again
+                for (int m = 0; m < 4; ++m) x[m] = *reinterpret_cast<const u32x4*>(slot + m * 1024);
+                transpose4_vgpr<true>(x, ED0, ED1, z);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    float cs = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) cs += z[m][r];
+                    bsum[m] = fmaf(cs, sc, bsum[m]);
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) PA[m][4 * half + w] = (int)z4_e5m2(z[m][4 * w], z[m][4 * w + 1], z[m][4 * w + 2], z[m][4 * w + 3]);
+                }
+            } else
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
                 const u32x4 x = *reinterpret_cast<const u32x4*>(slot + m * 1024);
                 f32x16 z;
 #pragma unroll
@@ -1529,6 +1578,17 @@ __device__ __forceinline__ void wgrad_job_mx(const NcaWgradArgs& a, const NcaWgr
 #pragma unroll
                 for (int w = 0; w < 4; ++w) PA[m][4 * half + w] = (int)z4_e5m2(z[4 * w], z[4 * w + 1], z[4 * w + 2], z[4 * w + 3]);
             }
+            if constexpr (H8 && NTB == 4) {                  // H: e4m3 bytes -> transposed bytes
+                u32x4 x[4];
+                f32x16 z[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) x[c] = *reinterpret_cast<const u32x4*>(slot + (ND_ + c) * 1024);
+                transpose4_vgpr<false>(x, EH0, EH1, z);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) PB[c][4 * half + w] = (int)z4_e4m3(z[c][4 * w], z[c][4 * w + 1], z[c][4 * w + 2], z[c][4 * w + 3]);
+            } else
 #pragma unroll
             for (int c = 0; c < NTB; ++c) {                  // H: e4m3 bytes (or bf16 pairs, rounded to e4m3 x 2^NCA_H8_LOG2 here) -> transposed bytes
                 f32x16 z;
