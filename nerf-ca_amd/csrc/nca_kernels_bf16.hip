@@ -501,9 +501,11 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
             valid = tvalid && smp < a.S;
             if (smp >= a.S) smp = a.S - 1;
             n = ray * a.S + smp;
-            const float zz = RECOMP ? a.z[ray * a.zs_r + smp] : 0.f;
+            const float zz = RECOMP ? ((NCA_EXP & 524288) ? 4.f + 0.01f * lane : a.z[ray * a.zs_r + smp]) : 0.f;       // (524288: no loads in the tile prologue)
             if (!RECOMP) {
                 p[0] = p[1] = p[2] = 0.f;
+            } else if (NCA_EXP & 524288) {
+                p[0] = 0.01f * zz; p[1] = -0.02f * zz + 0.001f * (float)(tile & 255); p[2] = zz - 4.5f;
             } else if (a.ray_is_f64) {
                 const double* o = reinterpret_cast<const double*>(a.origins) + ray * 3;
                 const double* d = reinterpret_cast<const double*>(a.dirs) + ray * 3;
@@ -524,9 +526,9 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
         }
         // second launch of a split render: the static net's sigma, written by the first launch
         float ss_other = 0.f;
-        if (!BWD && a.split == 2 && valid) ss_other = a.sig_s[n];
+        if (!BWD && a.split == 2 && valid && !(NCA_EXP & 524288)) ss_other = a.sig_s[n];
         int ph = 0;
-        if (RECOMP && a.phase) ph = a.mode == NCA_MODE_RAYS ? a.phase[ray * a.ps_r + (int64_t)smp * a.ps_s] : a.phase[n];
+        if (RECOMP && a.phase && !(NCA_EXP & 524288)) ph = a.mode == NCA_MODE_RAYS ? a.phase[ray * a.ps_r + (int64_t)smp * a.ps_s] : a.phase[n];
 
         // Scratch: two 32-sample tiles per wave, fragment-major blocks (see nca_bf_tile_bytes).  The input block and the
         // layer inputs live in the H region (indexed by the tile's position in the whole batch when a stored forward

@@ -66,7 +66,7 @@ def get_activation_func(output_activation):
 
 def _interval_lengths(depth_values, like):
     """cat(z[1:] - z[:-1], 1e-10) with the tail in the ray directions' dtype (model_helpers.py:73-74)."""
-    tail = torch.tensor([1e-10], dtype=like.dtype, device=like.device).expand(depth_values[..., :1].shape)
+    tail = torch.full((1,), 1e-10, dtype=like.dtype, device=like.device).expand(depth_values[..., :1].shape)     # (a fill, not a host copy: capturable)
     return torch.cat((depth_values[..., 1:] - depth_values[..., :-1], tail), dim=-1)
 
 

@@ -320,23 +320,51 @@ class CompositeTrainer:
         -> sampler backward into the coarse densities (the reference does not detach the sampled depths, model_helpers.py:135-146;
         ``fine_depth_gradients=False`` skips this) -> coarse backward -> one all-reduce -> Adam over the four nets.
         Returns (loss, coarse pixel loss, coarse terms + fine terms); ``self.last_fine_terms`` keeps the fine pass's own."""
-        from .. import fused as FU
-        from ..fused import _RayBatch, fused_losses, render_backward_raw, render_forward_raw
         c, dev = self.cfg, self.device
         self.update_windows(n_iter)
         ids = self.draw_ray_ids_device(n_iter)
         R = ids.shape[0]
         lo, hi = (R * self.rank) // self.world, (R * (self.rank + 1)) // self.world
-        my = ids[lo:hi]
-        n_loc = hi - lo
+        z = MH.randomize_depth(self.depth, dev, self.draw_jitter(n_iter))
+        u = self.draw_fine_u(n_iter)[lo:hi].to(dev)
+        terms, terms_f, order = self._fine_device_work(ids[lo:hi], R, z, u, self.loss_weights(n_iter))
+        sharded = self.world > 1
+        if sharded or self.always_allreduce:
+            flat = torch.cat([g for _, _, g in order])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            off = 0
+            for i, (m, b, g) in enumerate(order):
+                order[i] = (m, b, flat[off:off + g.numel()])
+                off += g.numel()
+        for m, b, g in order:
+            for p, gr in zip(m.parameters(), b.split_grads(g)):
+                p.grad = gr
+        self.opt.step()
+        self.sched.step()
+        self.last_fine_terms = terms_f
+        total = terms.clone()
+        total[0] = terms[0] + terms_f[0]                                   # loss += the fine pass's assembled loss (:301)
+        self._note_early_stop(n_iter, terms_f)
+        return total[0], terms[1], total
+
+    def _fine_device_work(self, my, R, z, u, weights, weights_dev=None):
+        """The device side of the hierarchical step for this rank's ray ids ``my`` (of a global batch of ``R``): everything between
+        the ray gather and the gradient all-reduce.  ``weights`` are the four loss weights as host floats; with ``weights_dev``
+        (f64[4] on the device) nothing of the step depends on host scalars and the whole call can be captured in a HIP graph.
+        Returns (coarse terms, fine terms, [(model, binding, flat gradient)] in ``self.params`` order)."""
+        from .. import fused as FU
+        from ..fused import _RayBatch, fused_losses, render_backward_raw, render_forward_raw
+        c, dev = self.cfg, self.device
+        n_loc = my.shape[0]
         rays = self.data.rays_train.index_select(0, my)
         phases = self.data.phases_train.index_select(0, my)
         o, d, gt, w = rays[:, 0, :], rays[:, 1, :], rays[:, 2, 0], rays[:, 3, 0]
-        z = MH.randomize_depth(self.depth, dev, self.draw_jitter(n_iter))
         dists = MH._interval_lengths(z, d)
         bs, bd, bsf, bdf = self.s._binding, self.t._binding, self.s_fine._binding, self.t_fine._binding
-        weights = self.loss_weights(n_iter)
-        fav_w, ent_w, occ_w, l1_w = weights
+        if weights_dev is not None:
+            fav_w, ent_w, occ_w, l1_w = weights_dev[0], weights_dev[1], weights_dev[2], weights_dev[3]
+        else:
+            fav_w, ent_w, occ_w, l1_w = weights
         sharded = self.world > 1
         red = _MaxReducer() if sharded else None
         depth_grads = c.fine_depth_gradients is None or c.fine_depth_gradients
@@ -344,9 +372,8 @@ class CompositeTrainer:
         # coarse pass (the whole local batch: the sampler normalises by the batch-wide maximum)
         batch = _RayBatch(o, d, phases, I0, z, dists, c.output_activation, False, 1e-2)
         pix, sig_s, sig_d, keep = render_forward_raw(batch, bs, bd, for_backward=True)
-        terms, g_pix, g_s, g_d = fused_losses(pix, gt, w, sig_s, sig_d, dists, c, weights, inv_R=1.0 / R)
+        terms, g_pix, g_s, g_d = fused_losses(pix, gt, w, sig_s, sig_d, dists, c, weights, inv_R=1.0 / R, weights_dev=weights_dev)
         # fine depths
-        u = self.draw_fine_u(n_iter)[lo:hi].to(dev)
         z_all, saved = FU.fine_depths_forward(sig_s, sig_d, z, u, red)
         z0 = z_all[0, :].clone()
         if sharded:
@@ -354,7 +381,7 @@ class CompositeTrainer:
         dists_f = MH._interval_lengths(z0, d)
         batch_f = _RayBatch(o, d, phases, I0, z_all, dists_f, c.output_activation, False, 1e-2)
         pix_f, sig_sf, sig_df, keep_f = render_forward_raw(batch_f, bsf, bdf, for_backward=True)
-        terms_f, g_pix_f, g_sf, g_df = fused_losses(pix_f, gt, w, sig_sf, sig_df, dists_f, c, weights, inv_R=1.0 / R, unit_mse=True)
+        terms_f, g_pix_f, g_sf, g_df = fused_losses(pix_f, gt, w, sig_sf, sig_df, dists_f, c, weights, inv_R=1.0 / R, unit_mse=True, weights_dev=weights_dev)
         res = render_backward_raw(batch_f, bsf, bdf, keep_f, g_pix_f, g_sf, g_df, want_depth_grad=depth_grads)
         grads_sf, grads_df = res[0], res[1]
         del keep_f
@@ -383,23 +410,7 @@ class CompositeTrainer:
         grads_s, grads_d = render_backward_raw(batch, bs, bd, keep, g_pix, g_s, g_d)
         del keep
         order = [(self.t, bd, grads_d), (self.s, bs, grads_s), (self.t_fine, bdf, grads_df), (self.s_fine, bsf, grads_sf)]   # self.params order
-        if sharded or self.always_allreduce:
-            flat = torch.cat([g for _, _, g in order])
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-            off = 0
-            for i, (m, b, g) in enumerate(order):
-                order[i] = (m, b, flat[off:off + g.numel()])
-                off += g.numel()
-        for m, b, g in order:
-            for p, gr in zip(m.parameters(), b.split_grads(g)):
-                p.grad = gr
-        self.opt.step()
-        self.sched.step()
-        self.last_fine_terms = terms_f
-        total = terms.clone()
-        total[0] = terms[0] + terms_f[0]                                   # loss += the fine pass's assembled loss (:301)
-        self._note_early_stop(n_iter, terms_f)
-        return total[0], terms[1], total
+        return terms, terms_f, order
 
     # -- early stop (run_composite.py:310-312) ---------------------------------------------------
     def _note_early_stop(self, n_iter: int, terms=None, d_entropy=None, favor=None) -> None:
@@ -431,9 +442,15 @@ class CompositeTrainer:
         c, dev = self.cfg, self.device
         S = self.depth.shape[0]
         Ls, Ld = self.s.pos_enc_basis, self.t.pos_enc_basis
-        nf = S + Ls + Ld
+        fine = self.n_fine > 0
+        if fine and self.world > 1:
+            raise NotImplementedError("the graph-replayed hierarchical step runs on one rank (the sampler's batch-wide maximum and ray 0's "
+                                      "depths cross the ranks in the middle of the step); use step_fused() under ray sharding")
+        Lsf, Ldf = (self.s_fine.pos_enc_basis, self.t_fine.pos_enc_basis) if fine else (0, 0)
+        nf = S + Ls + Ld + Lsf + Ldf
         off64 = (4 * nf + 7) // 8 * 8
         self._rec_layout = (S, Ls, Ld, off64)
+        self._rec_fine = (Lsf, Ldf)
         self._rec_host = [torch.empty(off64 + 32, dtype=torch.uint8).pin_memory() for _ in range(4)]
         self._rec_done = [None] * 4
         self._rec_dev = torch.zeros(off64 + 32, dtype=torch.uint8, device=dev)
@@ -444,10 +461,21 @@ class CompositeTrainer:
         self._slice = (lo, hi)
         self._ids_buf = torch.zeros(hi - lo, dtype=torch.int64, device=dev)
         tail = torch.tensor([1e-10], dtype=self.data.rays_train.dtype, device=dev)   # model_helpers.py:73
-        self.adam = FusedAdam([self.t, self.s], lr=c.lr, end_factor=c.lr_end_factor, total_iters=c.lr_decay_steps)
+        nets = [self.t, self.s] + ([self.t_fine, self.s_fine] if fine else [])           # self.params order
+        self.adam = FusedAdam(nets, lr=c.lr, end_factor=c.lr_end_factor, total_iters=c.lr_decay_steps)
         bs, bd = self.s._binding, self.t._binding
         split = self.world > 1 or self.always_allreduce
         out = {}
+        if fine:
+            self._u_buf = torch.zeros((hi - lo, self.n_fine), dtype=torch.float32, device=dev)
+
+        def front_fine():
+            z = MH.randomize_depth(self.depth, dev, rec32[:S])
+            terms, terms_f, order = self._fine_device_work(self._ids_buf, R, z, self._u_buf, (0.0, 0.0, 0.0, 0.0), weights_dev=rec64)
+            total = terms.clone()
+            total[0] = terms[0] + terms_f[0]
+            out["terms"], out["terms_f"] = total, terms_f
+            out["flat"] = torch.cat([g for _, _, g in order])
 
         def front():
             rays = self.data.rays_train.index_select(0, self._ids_buf)
@@ -464,17 +492,28 @@ class CompositeTrainer:
             out["flat"] = torch.cat([grads_d, grads_s])
 
         def back():
-            nd = bd.flat.numel()
-            self.adam.step([out["flat"][:nd], out["flat"][nd:]])
+            off, gs = 0, []
+            for b in self.adam.bindings:
+                gs.append(out["flat"][off:off + b.flat.numel()])
+                off += b.flat.numel()
+            self.adam.step(gs)
+
+        if fine:
+            front = front_fine
 
         bs.static_window = rec32[S:S + Ls] if Ls > 0 else None
         bd.static_window = rec32[S + Ls:S + Ls + Ld] if Ld > 0 else None
         if (Ls == Ld and Ls > 0 and c.static_pos_enc == c.temp_pos_enc and c.static_pos_enc_window_decay_steps == c.temp_pos_enc_window_decay_steps
                 and getattr(self.s, "pos_enc_window_start", None) == getattr(self.t, "pos_enc_window_start", None)):
             bd.static_window = bs.static_window     # identical schedules: one vector, the encoded input is stored once
+        if fine:
+            bsf, bdf = self.s_fine._binding, self.t_fine._binding
+            o0 = S + Ls + Ld
+            bsf.static_window = rec32[o0:o0 + Lsf] if Lsf > 0 else None
+            bdf.static_window = rec32[o0 + Lsf:o0 + Lsf + Ldf] if Ldf > 0 else None
         try:
             self._write_record(0)
-            saved = [b.flat.clone() for b in (bd, bs)]
+            saved = [b.flat.clone() for b in self.adam.bindings]
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):          # eager warm-up on the capture stream's allocator pool
@@ -482,7 +521,7 @@ class CompositeTrainer:
                 back()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            for b, keep_flat in zip((bd, bs), saved):      # undo the warm-up's optimiser step
+            for b, keep_flat in zip(self.adam.bindings, saved):      # undo the warm-up's optimiser step
                 b.flat.copy_(keep_flat)
             for t in self.adam.exp_avg + self.adam.exp_avg_sq:
                 t.zero_()
@@ -501,6 +540,8 @@ class CompositeTrainer:
                 self._graphs.append(g2)
         finally:
             bs.static_window = bd.static_window = None
+            if fine:
+                self.s_fine._binding.static_window = self.t_fine._binding.static_window = None
         self._graph_out = out
 
     def _write_record(self, n_iter: int) -> None:
@@ -510,12 +551,17 @@ class CompositeTrainer:
         if self._rec_done[k] is not None:
             self._rec_done[k].synchronize()          # the copy that last used this pinned buffer has run
         host = self._rec_host[k]
-        h32 = host[: 4 * (S + Ls + Ld)].view(torch.float32)
+        h32 = host[: 4 * (S + Ls + Ld + sum(getattr(self, "_rec_fine", (0, 0))))].view(torch.float32)
         h32[:S] = self.draw_jitter(n_iter)
         if Ls > 0:
             h32[S:S + Ls] = self.s._band_window()
         if Ld > 0:
             h32[S + Ls:S + Ls + Ld] = self.t._band_window()
+        Lsf, Ldf = getattr(self, "_rec_fine", (0, 0))
+        if Lsf > 0:
+            h32[S + Ls + Ld:S + Ls + Ld + Lsf] = self.s_fine._band_window()
+        if Ldf > 0:
+            h32[S + Ls + Ld + Lsf:S + Ls + Ld + Lsf + Ldf] = self.t_fine._band_window()
         host[off64:].view(torch.float64).copy_(torch.tensor([float(x) for x in self.loss_weights(n_iter)], dtype=torch.float64))
         self._rec_dev.copy_(host, non_blocking=True)
         ev = torch.cuda.Event()
@@ -527,13 +573,13 @@ class CompositeTrainer:
         (its own moment buffers: do not interleave with ``step``/``step_fused`` in one run).  Per step the host only
         draws the ray ids, fills one pinned record and launches the graph.  Returns (loss, pixel, terms) as
         ``step_fused`` does; the tensors are overwritten by the next call."""
-        if self.n_fine > 0:
-            raise NotImplementedError("the graph-replayed step covers the coarse pass only; use step() with depth_samples_per_ray_fine > 0")
         self.update_windows(n_iter)
         if getattr(self, "_graphs", None) is None:
             self._graph_setup()
         lo, hi = self._slice
         self._ids_buf.copy_(self.draw_ray_ids_device(n_iter)[lo:hi])
+        if self.n_fine > 0:
+            self._u_buf.copy_(self.draw_fine_u(n_iter)[lo:hi], non_blocking=False)       # sample_pdf's uniform draws of this step
         self._write_record(n_iter)
         self._graphs[0].replay()
         if len(self._graphs) > 1:
@@ -541,7 +587,11 @@ class CompositeTrainer:
                 dist.all_reduce(self._graph_out["flat"], op=dist.ReduceOp.SUM)
             self._graphs[1].replay()
         terms = self._graph_out["terms"]
-        self._note_early_stop(n_iter, terms)
+        if self.n_fine > 0:
+            self.last_fine_terms = self._graph_out["terms_f"]
+            self._note_early_stop(n_iter, self.last_fine_terms)
+        else:
+            self._note_early_stop(n_iter, terms)
         return terms[0], terms[1], terms
 
     def allreduce_grads(self) -> None:

@@ -213,3 +213,40 @@ def test_magix_shape_full_size_step(dev):
     assert len(calls) >= 4 and sum(calls) == 2 * 262144              # several micro-batches per step
     assert bool(torch.isfinite(outs[0][1]).all()) and float(outs[0][1].abs().max()) > 0
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_graph_step_with_fine_pass_matches_fused_step(dev, prec):
+    """CompositeTrainer.step_graph with the hierarchical pass on (one rank): the captured graph holds coarse forward -> loss ->
+    sampler -> fine forward -> loss -> fine backward with depth gradients -> sampler backward -> coarse backward -> the library's
+    Adam over all four nets; ray ids, depth jitter, sample_pdf's uniform draws, the four band windows and the loss weights
+    reach it through device memory.  Same loss every step and same parameters as step_fused with torch.optim.Adam."""
+    from nerfca_amd import set_precision, synthetic
+    from nerfca_amd.model.CPPN import CPPN
+    from nerfca_amd.model.Temporal import Temporal
+    from nerfca_amd.train.trainer import CompositeTrainer, TrainConfig
+    data = synthetic.make_dataset(16, 48, dev, views=synthetic.TRAIN_VIEWS[:2], n_phases=3, F=32)
+    outs = []
+    for graph in (False, True):
+        torch.manual_seed(9)
+        sdef, tdef = synthetic.net_definitions(dev, F=64)
+        nets = [CPPN(sdef).to(dev), Temporal(tdef).to(dev), CPPN(sdef).to(dev), Temporal(tdef).to(dev)]
+        set_precision(prec, *nets)
+        cfg = TrainConfig(depth_samples_per_ray_coarse=48, depth_samples_per_ray_fine=16, img_sample_size=256, favor_s_weight_delay_steps=0,
+                          l1_weight_start=1e-3, l1_weight_end=1e-5, occl_weight_start=1e-2, occl_weight_end=1e-4,
+                          dynamic_entro_weight_start=1e-3, favor_s_weight_start=1e-3, entro_mask_thre=1e-6,
+                          hyperparam_decay_steps=40, lr=2e-3, lr_decay_steps=6, lr_end_factor=0.1,
+                          static_pos_enc_window_decay_steps=40, temp_pos_enc_window_decay_steps=40)
+        tr = CompositeTrainer(cfg, nets[0], nets[1], data, dev, seed=5, fused_loss=True, static_model_fine=nets[2], temp_model_fine=nets[3])
+        losses = []
+        for it in range(6):
+            out = tr.step_graph(3 * it) if graph else tr.step_fused(3 * it)
+            losses.append((float(out[0]), float(tr.last_fine_terms[0])))
+        outs.append((losses, torch.cat([p.detach().flatten() for p in tr.params]).cpu()))
+    # (step 0 agrees to rounding; after that the two optimisers' last-bit differences are amplified step by step through the
+    # sampler's ill-conditioned depth gradient -- 2.5e-4 after three steps, 1e-3 after four in f32; a per-step input that did not
+    # advance inside the replay -- ids, jitter, uniform draws, windows, weights -- would show as a difference of order one)
+    for k, (a, b) in enumerate(zip(*[o[0] for o in outs])):
+        tol = (2e-5 if prec == "f32" else 2e-3) if k == 0 else (5e-3 if prec == "f32" else 2e-2)
+        assert abs(a[0] - b[0]) <= tol * abs(a[0]) and abs(a[1] - b[1]) <= tol * abs(a[1]), (k, outs[0][0], outs[1][0])
+    assert rel_err(outs[1][1], outs[0][1]) < (5e-3 if prec == "f32" else 2e-2)
