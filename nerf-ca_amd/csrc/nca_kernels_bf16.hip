@@ -538,11 +538,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
         // regions end in slack slots up to the next multiple of the 8 waves, so the hot loops store without a predicate.
         const int64_t tg = (FSTORE ? tile : tl) + a.tile0;
         char* const t32 = (BWD || STORE) ? reinterpret_cast<char*>(a.scratch) + (tg * 2) * a.rows_total : nullptr;   // rows_total = bytes per 32-sample tile
-#ifdef NCA_T_PRED
-        char* const d32 = BWD ? a.dscratch + (tl * 2) * a.d_total : nullptr;
-#else
         char* const d32 = BWD ? a.dscratch + ((STORED ? tile : tl) * 2) * a.d_total : nullptr;
-#endif
 
         float raw[2] = {0.f, 0.f};
         NCA_STAMP(0)                            // tile prologue: sample positions
@@ -786,11 +782,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                                 Bn[c][2 * m][u] = pack2(dv[2 * u], dv[2 * u + 1]);
                                 Bn[c][2 * m + 1][u] = pack2(dv[8 + 2 * u], dv[8 + 2 * u + 1]);
                             }
-#ifdef NCA_T_PRED
-                            if (S8 && STORED && tvalid && !ONCHIP && !(NCA_EXP & 1)) {
-#else
                             if (S8 && STORED && !ONCHIP && !(NCA_EXP & 1)) {
-#endif
                                 u32x4 q8;
 #pragma unroll
                                 for (int w = 0; w < 4; ++w) q8[w] = cvt4_e5m2_pk(Bn[c][2 * m + (w >> 1)][2 * (w & 1)], Bn[c][2 * m + (w >> 1)][2 * (w & 1) + 1], inv_s);
@@ -934,9 +926,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                         pend0 = acc0; pend1 = acc1;
                     } else {
                         epilogue(m, acc0, acc1);
-#ifndef NCA_T_NOFENCE
                         __builtin_amdgcn_sched_barrier(0);       // one row tile at a time: without the fence the scheduler overlaps row tiles and spills
-#endif
                     }
                 }
                 if (NCA_BF_PIPE) epilogue(MT - 1, pend0, pend1);
@@ -1124,11 +1114,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                     // software-pipelined like the forward layers: the epilogue of row tile m - 1 (mask, pack, e5m2, stores) shares a
                     // basic block with the MFMAs of row tile m.  From a store the D blocks are written without a predicate (slack
                     // tile slots behind the D region take the copies of waves that have no tile)
-#ifdef NCA_T_PRED
-                    const bool st_ok = wr_d;
-#else
                     const bool st_ok = STORED ? true : wr_d;
-#endif
                     auto epilogue = [&](int m, const f32x16& acc0, const f32x16& acc1) __attribute__((always_inline)) {
 #pragma unroll
                         for (int c = 0; c < 2; ++c) {
@@ -1175,9 +1161,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                             pend0 = acc0; pend1 = acc1;
                         } else {
                             epilogue(m, acc0, acc1);
-#ifndef NCA_T_NOFENCE
                             __builtin_amdgcn_sched_barrier(0);
-#endif
                         }
                     }
                     if (NCA_BF_PIPE) epilogue(MT - 1, pend0, pend1);
