@@ -86,6 +86,19 @@ __device__ __forceinline__ unsigned pos_pk(unsigned w) {
     asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(w), "s"(0x00010001u));
     return r;
 }
+// a packed bf16 pair with the halves kept whose flag (0 / 1 per half) is set: ONE multiply (x 1 keeps the bits, x 0 clears them)
+__device__ __forceinline__ unsigned keep_pk(unsigned w, unsigned flags01) {
+    unsigned r;
+    asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(w), "v"(flags01));
+    return r;
+}
+// (a << k) | b in one instruction (the compiler pairs two shifts with a v_or3 instead: 1.5 per term)
+template <int K>
+__device__ __forceinline__ unsigned shl_or(unsigned a, unsigned b) {
+    unsigned r;
+    asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "n"(K), "v"(b));
+    return r;
+}
 __device__ __forceinline__ void s8_mode() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1"); }
 
 __device__ __forceinline__ float bf_lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
@@ -717,9 +730,9 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                                     for (int u = 0; u < 4; ++u) {
                                         const float a0 = wo[(lh * MT + m) * 16 + 8 * s2 + 2 * u] * gc[c];
                                         const float a1 = wo[(lh * MT + m) * 16 + 8 * s2 + 2 * u + 1] * gc[c];
-                                        const unsigned msk = ((fld >> (4 * s2 + u)) & 0x00010001u) * 0xffffu;
-                                        dw[u] = pack2_pk(a0, a1) & msk;
-                                        ds[u] = gpk[c] & msk;
+                                        const unsigned on = (fld >> (4 * s2 + u)) & 0x00010001u;
+                                        dw[u] = keep_pk(pack2_pk(a0, a1), on);
+                                        ds[u] = keep_pk(gpk[c], on);
                                     }
                                     Bn[c][2 * m + s2] = dw;
                                     if (S8) {
@@ -883,9 +896,17 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                         // bit k / 16+k of a field: low / high bf16 of packed word k (k = 4*(fragment&1) + u) is > 0
 #pragma unroll
                         for (int c = 0; c < 2; ++c) {
-                            unsigned fld = 0u;
-#pragma unroll
-                            for (int k = 0; k < 8; ++k) fld |= pos_pk(Bn[c][2 * m + (k >> 2)][k & 3]) << k;
+                            unsigned fld;
+                            {                                    // eight terms, shift amounts as immediates: one v_lshl_or each
+                                fld = pos_pk(Bn[c][2 * m][0]);
+                                fld = shl_or<1>(pos_pk(Bn[c][2 * m][1]), fld);
+                                fld = shl_or<2>(pos_pk(Bn[c][2 * m][2]), fld);
+                                fld = shl_or<3>(pos_pk(Bn[c][2 * m][3]), fld);
+                                fld = shl_or<4>(pos_pk(Bn[c][2 * m + 1][0]), fld);
+                                fld = shl_or<5>(pos_pk(Bn[c][2 * m + 1][1]), fld);
+                                fld = shl_or<6>(pos_pk(Bn[c][2 * m + 1][2]), fld);
+                                fld = shl_or<7>(pos_pk(Bn[c][2 * m + 1][3]), fld);
+                            }
                             mw[c][m >> 1] |= fld << (8 * (m & 1));
                         }
                     }
@@ -1136,7 +1157,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                                     const float a0 = c == 0 ? acc0[8 * s2 + 2 * u] : acc1[8 * s2 + 2 * u];
                                     const float a1 = c == 0 ? acc0[8 * s2 + 2 * u + 1] : acc1[8 * s2 + 2 * u + 1];
                                     const unsigned two = bits ? (fld >> (4 * s2 + u)) & 0x00010001u : pos_pk(relu_pk(hw[u]));
-                                    dw[u] = (NCA_EXP & 2) ? pack2(a0, a1) : pack2_pk(a0, a1) & (two * 0xffffu);
+                                    dw[u] = (NCA_EXP & 2) ? pack2(a0, a1) : keep_pk(pack2_pk(a0, a1), two);
                                 }
                                 Bn[c][2 * m + s2] = dw;
                                 if ((NCA_EXP & 2) && S8 && STORED) { q8[2 * s2] = dw[0] ^ dw[1]; q8[2 * s2 + 1] = dw[2] ^ dw[3]; }
