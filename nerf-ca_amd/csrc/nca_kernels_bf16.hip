@@ -1103,7 +1103,11 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
 
             // ================= backward sweep (dgrad) =====================================================
             if (BWD) {
-                for (int jj = y.NL - 1; jj >= 1; --jj) {
+                // Two layers per trip: each reads one operand array and leaves the next layer's operand in the other -- copying 64
+                // registers back per layer was a sixth of the sweep's vector instructions.
+                static_assert(KSMAX >= 2 * MT, "a layer's output fragments fit the operand array");
+                u32x4 B2[2][KSMAX];
+                auto sweep_layer = [&](int jj, u32x4 (&Bin)[2][KSMAX], u32x4 (&Bout)[2][KSMAX]) __attribute__((always_inline)) {
                     const int nsi = (si + 1 == a.nstages) ? 0 : si + 1;
                     if (NR) {
                         // this layer's masks were requested before the D stores of the step before (the output layer's step or the
@@ -1124,7 +1128,6 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                     const char* const hblk = nb + EB + (jj - 1) * HB;                       // input of layer jj (mask)
                     char* const dblk = db + nca_bf_doff(y, jj - 1, S8 && STORED);            // D_{jj-1}
                     const bool wr_d = tvalid;
-                    u32x4 Bn[2][2 * MT];
                     u32x4 mv = {0u, 0u, 0u, 0u};
                     if (lds_mask) mv = *reinterpret_cast<const u32x4*>(mwave + (jj - 1) * 1024);
                     if (STORED) mv = *reinterpret_cast<const u32x4*>(mslot + ((jj - 1) & 1) * 1024 + lane * 16);
@@ -1159,7 +1162,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                                     const unsigned two = bits ? (fld >> (4 * s2 + u)) & 0x00010001u : pos_pk(relu_pk(hw[u]));
                                     dw[u] = (NCA_EXP & 2) ? pack2(a0, a1) : keep_pk(pack2_pk(a0, a1), two);
                                 }
-                                Bn[c][2 * m + s2] = dw;
+                                Bout[c][2 * m + s2] = dw;
                                 if ((NCA_EXP & 2) && S8 && STORED) { q8[2 * s2] = dw[0] ^ dw[1]; q8[2 * s2 + 1] = dw[2] ^ dw[3]; }
                                 else if (S8 && STORED) {
                                     q8[2 * s2] = cvt4_e5m2_pk(dw[0], dw[1], inv_s);
@@ -1175,8 +1178,8 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                         f32x16 acc0, acc1;
 #pragma unroll
                         for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-                        if (!(NCA_EXP & 128)) mma_rowtile_ring<KS, MT, KSMAX, RINGK>(imgl, m, A, B, acc0, acc1);
-                        else { acc0[0] = __builtin_bit_cast(float, B[0][m][0]); acc1[3] = __builtin_bit_cast(float, B[1][m][1]); }
+                        if (!(NCA_EXP & 128)) mma_rowtile_ring<KS, MT, KSMAX, RINGK>(imgl, m, A, Bin, acc0, acc1);
+                        else { acc0[0] = __builtin_bit_cast(float, Bin[0][m][0]); acc1[3] = __builtin_bit_cast(float, Bin[1][m][1]); }
                         if (NCA_BF_PIPE) {
                             if (m > 0) epilogue(m - 1, pend0, pend1);
                             pend0 = acc0; pend1 = acc1;
@@ -1186,15 +1189,15 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                         }
                     }
                     if (NCA_BF_PIPE) epilogue(MT - 1, pend0, pend1);
-#pragma unroll
-                    for (int c = 0; c < 2; ++c)
-#pragma unroll
-                        for (int k = 0; k < 2 * MT; ++k) B[c][k] = Bn[c][k];
                     NCA_STAMP(3)
                     if (!RES) stage_publish_counted<(S8 && STORED) ? 2 * MT : 4 * MT>(st_ok);              // D stores
                     cur ^= 1;
                     si = nsi;
                     NCA_STAMP(6)
+                };
+                for (int jj = y.NL - 1; jj >= 1; jj -= 2) {
+                    sweep_layer(jj, B, B2);
+                    if (jj - 1 >= 1) sweep_layer(jj - 1, B2, B);
                 }
             }
         }  // nets
