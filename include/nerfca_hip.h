@@ -256,7 +256,7 @@ enum {
                                      resident in LDS (no per-layer weight DMA, no workgroup barrier in the tile loop) when the images fit
                                      (width 128: the input layer + 4 hidden layers forward, 4 transposed images backward) and the batch has at least this many 64-sample wave
                                      tiles.  A two-net render then takes two forward launches (the second composites with the first
-                                     one's sigma).  0 = always, -1 = never; default 4 * 8 waves * CUs (NCA_RESIDENT=0 -> never,
+                                     one's sigma).  0 = always, -1 = never; default 8 * 8 waves * CUs (NCA_RESIDENT=0 -> never,
                                      =force -> always).  Results are bit-identical to the streaming kernels */
     NCA_OPT_COUNT
 };

@@ -140,7 +140,7 @@ int64_t opt_value(int opt) {
         // reference's default batch of 1024 rays x 500 samples -- 4 tile groups per workgroup -- it costs 3.6 %
         if (opt == NCA_OPT_ONCHIP_MIN_TILES) v = (int64_t)8 * NCA_WAVES * num_cus();
         if (opt == NCA_OPT_STAGE_FP8) v = 1;
-        if (opt == NCA_OPT_RESIDENT_MIN_TILES) v = (int64_t)4 * NCA_WAVES * num_cus();
+        if (opt == NCA_OPT_RESIDENT_MIN_TILES) v = (int64_t)8 * NCA_WAVES * num_cus();    // (at 4 tiles per wave -- the reference's 1 024 x 500 batch -- resident and streaming tie)
     }
     return v;
 }

@@ -115,6 +115,6 @@ def test_resident_equals_streaming_point_queries(dev, N, F, early):
 def test_resident_default_threshold_and_option_validation(dev):
     from nerfca_amd import _capi
     cus = torch.cuda.get_device_properties(0).multi_processor_count
-    assert _capi.get_option(_capi.OPT_RESIDENT_MIN_TILES) in (4 * 8 * cus, -1, 0)      # (-1 / 0 when NCA_RESIDENT is set in the environment)
+    assert _capi.get_option(_capi.OPT_RESIDENT_MIN_TILES) in (8 * 8 * cus, -1, 0)      # (-1 / 0 when NCA_RESIDENT is set in the environment)
     with pytest.raises(RuntimeError):
         _capi.set_option(_capi.OPT_RESIDENT_MIN_TILES, -2)
