@@ -428,6 +428,24 @@ class CompositeTrainer:
             dist.all_reduce(two, op=dist.ReduceOp.SUM)
         self.stop_flag = (two < 1e-15).any()
 
+    def global_terms(self, terms: torch.Tensor) -> torch.Tensor:
+        """What a logger wants under ray sharding: ``terms`` as ``step_fused`` / ``step_graph`` return them hold this rank's SHARE of
+        every global value (loss, pixel loss and the regularisers are sums over the ranks) and this rank's own maxima
+        (``sigma_s_max``, ``sigma_d_max``).  Returns the global vector -- one all-reduce(SUM) and one all-reduce(MAX) of 13 doubles;
+        call it at the logging cadence, not every step (``run_composite.py:314-336`` logs every ``log_every`` steps).  With one rank
+        it is the identity."""
+        if self.world <= 1:
+            return terms
+        from .. import _capi
+        i0, i1 = _capi.TERM_NAMES.index("sigma_s_max"), _capi.TERM_NAMES.index("sigma_d_max")
+        tot = terms.detach().clone()
+        mx = tot[[i0, i1]].clone()
+        tot[[i0, i1]] = 0
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        tot[[i0, i1]] = mx
+        return tot
+
     def early_stop(self) -> bool:
         """Host-side read of the flag (one device sync): call it at the logging cadence, not every step."""
         return bool(self.stop_flag) if self.stop_flag is not None else False

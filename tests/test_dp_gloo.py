@@ -99,6 +99,7 @@ def run_steps(rank, world, n_steps=2, n_fine=0, depth_grads=False):
         if it == 0:
             grads = torch.cat([p.grad.flatten() for p in tr.params]).clone()
     params = torch.cat([p.detach().flatten() for p in tr.params]).clone()
+    run_steps.global_terms = tr.global_terms(torch.arange(13, dtype=torch.float64) * (rank + 1) + 0.5 * rank)    # (a made-up local vector)
     return grads, params
 
 
@@ -109,7 +110,7 @@ def _worker(rank, world, port, outdir, n_fine=0, depth_grads=False):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         g, p = run_steps(rank, world, n_fine=n_fine, depth_grads=depth_grads)
-        torch.save({"g": g, "p": p}, os.path.join(outdir, f"rank{rank}.pt"))
+        torch.save({"g": g, "p": p, "terms": run_steps.global_terms}, os.path.join(outdir, f"rank{rank}.pt"))
     finally:
         dist.destroy_process_group()
 
@@ -134,6 +135,11 @@ def test_two_rank_step_equals_one_rank_step(tmp_path):
     perr = float((r0["p"] - p1).abs().max() / p1.abs().max())
     assert gerr < 1e-5, gerr
     assert perr < 1e-5, perr
+    # CompositeTrainer.global_terms: shares summed over the ranks, the two sigma maxima maximised
+    loc = [torch.arange(13, dtype=torch.float64) * (r + 1) + 0.5 * r for r in (0, 1)]
+    want = loc[0] + loc[1]
+    want[3:5] = torch.maximum(loc[0][3:5], loc[1][3:5])
+    assert torch.equal(r0["terms"], want) and torch.equal(r1["terms"], want)
 
 
 @pytest.mark.timeout(300)
