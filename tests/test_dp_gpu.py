@@ -37,12 +37,17 @@ def _run(rank, world, mode, prec, device_index=0):
     cfg = TrainConfig(depth_samples_per_ray_coarse=S, depth_samples_per_ray_fine=n_fine, img_sample_size=R, favor_s_weight_delay_steps=0,
                       l1_weight_start=1e-3, l1_weight_end=1e-3, occl_weight_start=1e-2, dynamic_entro_weight_start=1e-3,
                       favor_s_weight_start=1e-3, entro_mask_thre=1e-6)
-    tr = CompositeTrainer(cfg, s, t, data, dev, rank=rank, world=world, seed=11, fused_loss=(mode == "fused"), **kw)
+    tr = CompositeTrainer(cfg, s, t, data, dev, rank=rank, world=world, seed=11, fused_loss=(mode in ("fused", "graph")), **kw)
     grads = None
     for it in range(2):
-        tr.step(2000 + it)
-        if it == 0:
-            grads = torch.cat([p.grad.flatten() for p in tr.params]).clone()
+        if mode == "graph":        # bench.py's default step: two captured graphs with the gradient all-reduce between them
+            tr.step_graph(2000 + it)
+            if it == 0:
+                grads = tr._graph_out["flat"].clone()            # [dynamic | static] = the order of tr.params
+        else:
+            tr.step(2000 + it)
+            if it == 0:
+                grads = torch.cat([p.grad.flatten() for p in tr.params]).clone()
     params = torch.cat([p.detach().flatten() for p in tr.params]).clone()
     torch.cuda.synchronize()
     return grads.cpu(), params.cpu()
@@ -71,7 +76,8 @@ def _free_port():
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("mode,prec,gtol", [("fused", "f32", 1e-5), ("autograd", "f32", 1e-5), ("fused", "bf16", 1e-3), ("fine", "f32", 1e-3)])
+@pytest.mark.parametrize("mode,prec,gtol", [("fused", "f32", 1e-5), ("autograd", "f32", 1e-5), ("fused", "bf16", 1e-3), ("fine", "f32", 1e-3),
+                                            ("graph", "f32", 1e-5), ("graph", "bf16", 1e-3)])
 def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path, mode, prec, gtol):
     """Gradient of the first step: both ranks hold the same all-reduced buffer, equal to the single-process gradient up to
     f32 summation order (1e-5; bf16 rounds the per-rank partial sums differently, and the fine pass's through-depth term is
