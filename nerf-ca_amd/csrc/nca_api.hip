@@ -319,11 +319,14 @@ static void rays_to_args(const NcaRays* r, NcaFusedArgs* a, int32_t prec) {
 // ---------------------------------------------------------------------------------- forward
 extern "C" int nca_composite_fwd(int64_t, int32_t, int32_t, int32_t, float, const float*, const float*, const float*, const double*, double*, float*, float*, void*);
 extern "C" int nca_composite_bwd(int64_t, int32_t, int32_t, int32_t, float, const float*, const float*, const double*, const double*, const float*, const float*, float*, float*, void*);
-// The store a bf16 forward can leave behind for its backward (so that the backward does not recompute the layers):
-//   H region  [32-sample tile][net][input block | layer outputs]         bf16: the inputs of all NL layers (the backward
-//                                                                          recomputes the last layer); f32: + the last output
-//   masks     [wave tile][2][max(NL) - 1][1 KiB | 512 B]                  ReLU bit masks of the hidden layers
-//   raw       [wave tile][2][32] f32                                      raw net outputs (f32 only)
+// The store a forward can leave behind for its backward (so that the backward does not recompute the layers):
+//   H region  [32-sample tile][net][input block | layer outputs]         the inputs of all NL layers -- bf16 with bf16 staging (the
+//                                                                          backward recomputes the last layer), e4m3 with fp8 staging
+//                                                                          (nca_layout.hpp); f32: + the last output
+//   masks     [wave tile][2][mask layers][1 KiB | 512 B]                  ReLU bit masks: of the hidden layers' inputs (NL - 1), of every
+//                                                                          layer with fp8 staging (NL: the backward recomputes nothing)
+//   raw       [wave tile][2][64 | 32] f32                                 raw net outputs (bf16 with fp8 staging; f32)
+// The tile count is rounded up to the 8 waves of a workgroup (bf16): slack slots for the waves of the last group.
 // bf16, static + dynamic net of one width with the same encoding (mode, bands, the SAME window / coefficient vectors):
 // the dynamic net's input block is a superset of the static one's and is stored once
 static bool can_share_enc(const NcaFusedArgs& a, int32_t prec) {
