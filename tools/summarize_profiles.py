@@ -74,7 +74,15 @@ def mean_last(v, n=20):
 
 fetch = per_kernel("pmc_FETCH_SIZE", os.path.join(dst, f"{tag}_{prec}_pmc_FETCH_SIZE.csv"))
 write = per_kernel("pmc_WRITE_SIZE", os.path.join(dst, f"{tag}_{prec}_pmc_WRITE_SIZE.csv"))
-traffic = {"how": "rocprofv3 --pmc FETCH_SIZE (and, in a second run, --pmc WRITE_SIZE) --kernel-trace --output-format csv -- python3 bench.py "
+def _commit():
+    import subprocess
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, check=True).stdout.strip()
+    except Exception:
+        return None
+
+
+traffic = {"commit": _commit(), "how": "rocprofv3 --pmc FETCH_SIZE (and, in a second run, --pmc WRITE_SIZE) --kernel-trace --output-format csv -- python3 bench.py "
                   "--steps 2 --warmup 1 --no-cpu-baseline; per-kernel mean over the last <=20 dispatches; bytes = counter * 1024; FETCH_SIZE "
                   "doubled (gfx950 reports half of a wide coalesced stream, MI355X_MICROARCH.md section HBM); WRITE_SIZE as is",
            "config": {"prec": prec, "rays_per_step": bench["config"]["rays_per_step_per_gpu"], "samples_per_ray": bench["config"]["samples_per_ray"],
