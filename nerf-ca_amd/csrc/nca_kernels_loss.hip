@@ -64,7 +64,27 @@ __global__ __launch_bounds__(LOSS_NT) void nca_loss_rays(const NcaLossArgs a) {
         // ---- pass 2: ray entropies (compute_sigma_s_ray_loss, model_helpers.py:206-224) ------------------
         const double Mcs = fmax(Ms, 1e-19), Mcd = fmax(Md, 1e-19);
         double es = 0.0, ed = 0.0, qp = 0.0;
-        for (int s = lane; s < a.S; s += 64) {
+        // q = ln(pd + eps) + pd / (pd + eps) of this lane's samples, kept for the gradient pass (an f64 logarithm is the most
+        // expensive thing in this kernel): up to QKEEP * 64 samples per ray, beyond that the gradient pass recomputes
+        constexpr int QKEEP = 8;
+        double qkeep[QKEEP];
+#pragma unroll
+        for (int j = 0; j < QKEEP; ++j) qkeep[j] = 0.0;
+#pragma unroll
+        for (int j = 0; j < QKEEP; ++j) {
+            const int s = lane + 64 * j;
+            if (s < a.S) {
+                const double dl = a.dists[s];
+                const double ps = (double)ss[s] * dl / Mcs, pd = (double)sd[s] * dl / Mcd;
+                es += ps * log(ps + 1e-10);
+                const double lg = log(pd + 1e-10);
+                ed += pd * lg;
+                const double q = lg + pd / (pd + 1e-10);
+                qkeep[j] = q;
+                qp += q * pd;
+            }
+        }
+        for (int s = lane + 64 * QKEEP; s < a.S; s += 64) {
             const double dl = a.dists[s];
             const double ps = (double)ss[s] * dl / Mcs, pd = (double)sd[s] * dl / Mcd;
             es += ps * log(ps + 1e-10);
@@ -87,7 +107,7 @@ __global__ __launch_bounds__(LOSS_NT) void nca_loss_rays(const NcaLossArgs a) {
             const float fscale = (float)(w_favor * a.inv_R / (double)a.S);
             const double escale = w_dent * a.inv_R * (double)mask_d / Mcd;
             const bool unclipped = Md >= 1e-19;      // d clip(M)/dM
-            for (int s = lane; s < a.S; s += 64) {
+            auto grad_of = [&](int s, bool have_q, double qk) __attribute__((always_inline)) {
                 const float vs = ss[s], vd = sd[s];
                 const double dl = a.dists[s];
                 // favor: F = -(b ln b + rb ln rb), b = clip(bw^skew), rb = clip(1 - b)
@@ -108,13 +128,17 @@ __global__ __launch_bounds__(LOSS_NT) void nca_loss_rays(const NcaLossArgs a) {
                 const float g_d_f = gf * ((T - vd) / (T * T));
                 // dynamic ray entropy: E = -sum p ln(p+eps); dE/dm_j = (-q_j + [unclipped] sum_s q_s p_s) / M
                 const double pd = (double)vd * dl / Mcd;
-                const double q = log(pd + 1e-10) + pd / (pd + 1e-10);
+                const double q = have_q ? qk : log(pd + 1e-10) + pd / (pd + 1e-10);
                 const double g_d_e = escale * dl * (-q + (unclipped ? qp : 0.0));
                 const double g_d_o = w_occl * a.inv_R * dl;
                 const double g_s_l = w_l1 * (dl + 2.0 * (double)vs * dl * dl);
                 gs[s] = g_s_f + (float)g_s_l;
                 gd[s] = g_d_f + (float)(g_d_e + g_d_o);
-            }
+            };
+#pragma unroll
+            for (int j = 0; j < QKEEP; ++j)
+                if (lane + 64 * j < a.S) grad_of(lane + 64 * j, true, qkeep[j]);
+            for (int s = lane + 64 * QKEEP; s < a.S; s += 64) grad_of(s, false, 0.0);
         }
         if (lane == 0) {
             part[0] = wm * diff * diff;                 // pixel (sum over rays; scaled by inv_R at the end)
