@@ -377,15 +377,18 @@ def main():
     dt = time.perf_counter() - t0
     loss = float(loss)
     timed_steps = args.steps
+    eager_ms = None
     if args.graph:       # events cannot be recorded inside a replayed graph: time the same kernels eagerly, outside dt
         timed_steps = min(args.steps, 4)
         tr.step(base_iter)          # (untimed: the eager step's first pass allocates its own store, and first-touch page mapping shows in the kernels)
         barrier()
         _capi.timing_reset()
         _capi.timing_enable(True)
+        te = time.perf_counter()
         for i in range(timed_steps):
             tr.step(base_iter + i)
         barrier()
+        eager_ms = (time.perf_counter() - te) / timed_steps * 1e3       # the same step with host-launched kernels and torch's Adam
     _capi.timing_enable(False)
     if use_pg:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -406,7 +409,7 @@ def main():
                                        else ("mode 4: from the store, last hidden layer's wgrad on chip" if onchip else "from the store / recompute")),
                           "launches_per_step": {k: (kern[k]["launches"] // max(timed_steps, 1)) for k in ("fwd", "bwd_dgrad", "bwd_wgrad")},
                           "onchip_last_layer_wgrad": bool(onchip)},
-               "rccl_ranks": rccl_ranks, "roofline": roof, "final_loss": float(loss),
+               "rccl_ranks": rccl_ranks, "roofline": roof, "final_loss": float(loss), "eager_ms_per_step": eager_ms,
                "store_fallbacks": fused_mod.STORE_FALLBACKS}       # > 0: some backward ran on the recompute path (store did not fit)
         del tr
         torch.cuda.empty_cache()
