@@ -87,12 +87,14 @@ __device__ __forceinline__ unsigned pos_pk(unsigned w) {
     return r;
 }
 // a packed bf16 pair with the halves kept whose flag (0 / 1 per half) is set: ONE multiply (x 1 keeps the bits, x 0 clears them)
+// (NOT as inline assembly: the compiler's hazard recognizer does not count an asm statement as a vector-ALU write, and a matrix
+// instruction that reads the result within two wait states gets the register's OLD contents -- seen with exactly this multiply)
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned keep_pk(unsigned w, unsigned flags01) {
-    unsigned r;
-    asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(w), "v"(flags01));
-    return r;
+    return __builtin_bit_cast(unsigned, (u16x2)(__builtin_bit_cast(u16x2, w) * __builtin_bit_cast(u16x2, flags01)));
 }
-// (a << k) | b in one instruction (the compiler pairs two shifts with a v_or3 instead: 1.5 per term)
+// (a << k) | b in one instruction (the compiler pairs two shifts with a v_or3 instead: 1.5 per term).  Inline assembly: only for
+// values that no matrix instruction reads (see keep_pk) -- these are the mask words, which go to memory.
 template <int K>
 __device__ __forceinline__ unsigned shl_or(unsigned a, unsigned b) {
     unsigned r;
@@ -1488,11 +1490,27 @@ __device__ __forceinline__ void transpose4_vgpr(const u32x4 (&x)[4], long E0, lo
                      : "v"(lo[0]), "v"(lo[1]), "v"(lo[2]), "v"(lo[3]), "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]), "v"(E0), "v"(E1));
 }
 
+// Sum of an accumulator's 16 registers on ADJACENT register pairs (v_pk_add_f32 straight on the accumulator: 7 + 1 instructions).
+// Written as a plain loop the compiler pairs the sums of two accumulators instead and gathers every operand pair with two v_mov:
+// 128 moves per wave tile, a fifth of the loop's instructions -- and the loop is issue-bound (one wave per SIMD).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float colsum16(const f32x16& z) {
+    f32x2 p0 = __builtin_shufflevector(z, z, 0, 1) + __builtin_shufflevector(z, z, 2, 3);
+    f32x2 p1 = __builtin_shufflevector(z, z, 4, 5) + __builtin_shufflevector(z, z, 6, 7);
+    f32x2 p2 = __builtin_shufflevector(z, z, 8, 9) + __builtin_shufflevector(z, z, 10, 11);
+    f32x2 p3 = __builtin_shufflevector(z, z, 12, 13) + __builtin_shufflevector(z, z, 14, 15);
+    p0 += p1; p2 += p3; p0 += p2;
+    return p0[0] + p0[1];
+}
+
 template <int F, int NTB, bool H8>
 __device__ __forceinline__ void wgrad_job_mx(const NcaWgradArgs& a, const NcaWgradJob& job, int q, int nsplit, int lane, char* ring) {
     using R = WgradRing<F, NTB, true, H8>;
     constexpr int MT = F / 32, ND_ = R::ND, NH_ = R::NH, FR = R::FR, NSLOT = R::NSLOT;
-    static_assert(R::BYTES <= NCA_WGRAD_LDS, "ring does not fit the wave's LDS share");
+    constexpr int NDMA = FR + 1;              // vector-memory operations per tile: the fragments and the wave tile's scale
+    constexpr int SC0 = NSLOT * FR * 1024;    // the scales' 256 bytes per slot, behind the fragments
+    static_assert(SC0 + NSLOT * 256 <= NCA_WGRAD_LDS, "ring does not fit the wave's LDS share");
+    static_assert((NSLOT - 1) * NDMA <= 63, "counted wait");
     const int lc = lane & 31, lh = lane >> 5;
     // whole wave tiles per split: the two 32-sample halves of a wave tile share one scale and one MFMA
     const int64_t per = (((a.ntiles + nsplit - 1) / nsplit) + 1) & ~(int64_t)1;
@@ -1515,6 +1533,12 @@ __device__ __forceinline__ void wgrad_job_mx(const NcaWgradArgs& a, const NcaWgr
         const char* dp = base + t * a.rows_total + job.d_row0 + lane * 16;
         const char* bp = base_b + (t + a.tile0_b) * a.rows_total_b + job.b_row0 + lane * 16;
         char* dst = ring + slot * (FR * 1024);
+        // The inverse scale of the tile's wave tile (in the record of its first 32-sample tile), one copy per lane, comes through the
+        // ring as well: a register load gets the compiler's s_waitcnt vmcnt(0) in front of its first use, which drains every tile in
+        // flight once per wave tile (-0.55 ms per launch at the bench size without it).  EVERY load of the loop is non-temporal:
+        // loads of different cache policies return out of order with each other, and the counted wait below assumes order.
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (t & ~(int64_t)1) * a.rows_total + job.dscale_off + job.net * 4),
+                                         (__attribute__((address_space(3))) void*)(ring + SC0 + slot * 256), 4, 0, 2);
 #pragma unroll
         for (int s = 0; s < ND_; ++s)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dp + s * 1024),
@@ -1533,9 +1557,7 @@ __device__ __forceinline__ void wgrad_job_mx(const NcaWgradArgs& a, const NcaWgr
     const u32x4 EB0 = ident_frag(8 * lh, lc), EB1 = ident_frag(16 + 8 * lh, lc);             // bf16 identity (bf16 H blocks)
     for (int64_t i = 0; i < n; i += 2) {
         i32x8 PA[MT], PB[NTB];
-        // the wave tile's inverse scale (first of its two 32-sample records) as an e8m0 exponent, with the layer inputs' 2^-NCA_H8_LOG2
-        const float sc = reinterpret_cast<const float*>(base + (t0 + i) * a.rows_total + job.dscale_off)[job.net];
-        const int sa = (int)(__float_as_uint(sc) >> 23) - NCA_H8_LOG2;
+        float sc = 0.f;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int64_t ii = i + half;
@@ -1552,10 +1574,11 @@ __device__ __forceinline__ void wgrad_job_mx(const NcaWgradArgs& a, const NcaWgr
             }
             if (ii + NSLOT - 1 < n) {
                 issue(t0 + ii + NSLOT - 1, (int)((ii + NSLOT - 1) % NSLOT));
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSLOT - 1) * FR) : "memory");
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSLOT - 1) * NDMA) : "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
+            if (half == 0) sc = *reinterpret_cast<const float*>(ring + SC0 + (int)(ii % NSLOT) * 256 + lane * 4);
             const char* slot = ring + (int)(ii % NSLOT) * (FR * 1024) + lane * 16;
             if constexpr (MT == 4) {                         // D: e5m2 bytes -> transposed, bias sums, bytes again
                 u32x4 x[4];
@@ -1565,10 +1588,7 @@ __device__ __forceinline__ void wgrad_job_mx(const NcaWgradArgs& a, const NcaWgr
                 transpose4_vgpr<true>(x, ED0, ED1, z);
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
-                    float cs = 0.f;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) cs += z[m][r];
-                    bsum[m] = fmaf(cs, sc, bsum[m]);
+                    bsum[m] = fmaf(colsum16(z[m]), sc, bsum[m]);
 #pragma unroll
                     for (int w = 0; w < 4; ++w) PA[m][4 * half + w] = (int)z4_e5m2(z[m][4 * w], z[m][4 * w + 1], z[m][4 * w + 2], z[m][4 * w + 3]);
                 }
@@ -1581,10 +1601,7 @@ __device__ __forceinline__ void wgrad_job_mx(const NcaWgradArgs& a, const NcaWgr
                 for (int r = 0; r < 16; ++r) z[r] = 0.f;
                 z = __builtin_amdgcn_mfma_f32_32x32x16_bf8_bf8((long)(((unsigned long)x[1] << 32) | x[0]), ED0, z, 0, 0, 0);
                 z = __builtin_amdgcn_mfma_f32_32x32x16_bf8_bf8((long)(((unsigned long)x[3] << 32) | x[2]), ED1, z, 0, 0, 0);
-                float cs = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) cs += z[r];
-                bsum[m] = fmaf(cs, sc, bsum[m]);
+                bsum[m] = fmaf(colsum16(z), sc, bsum[m]);
 #pragma unroll
                 for (int w = 0; w < 4; ++w) PA[m][4 * half + w] = (int)z4_e5m2(z[4 * w], z[4 * w + 1], z[4 * w + 2], z[4 * w + 3]);
             }
@@ -1623,6 +1640,8 @@ __device__ __forceinline__ void wgrad_job_mx(const NcaWgradArgs& a, const NcaWgr
                 }
             }
         }
+        // the wave tile's inverse scale as an e8m0 exponent, with the layer inputs' 2^-NCA_H8_LOG2
+        const int sa = (int)(__float_as_uint(sc) >> 23) - NCA_H8_LOG2;
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -1668,9 +1687,7 @@ __global__ __launch_bounds__(64, 1) void nca_wgrad_bf16(const NcaWgradArgs a) {
     if constexpr (D8) {
         s8_mode();
         if (F != 128 && job.is_enc && job.h8) wgrad_job_mx<F, 4, true>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
-        else if (job.h8) wgrad_job_mx<F, F / 32, true>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
-        else if (F != 128 && job.is_enc) wgrad_job_mx<F, 4, false>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
-        else wgrad_job_mx<F, F == 128 ? 4 : F / 32, false>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
+        else wgrad_job_mx<F, F / 32, true>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);         // (e5m2 D blocks come with e4m3 H blocks)
     } else {
         if (F != 128 && job.is_enc && job.h8) wgrad_job<F, 4, D8, true>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
         else if (job.h8) wgrad_job<F, F / 32, D8, true>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
@@ -1756,7 +1773,7 @@ hipError_t nca_launch_pack_bf16(const NcaLayout& y, const float* prm, void* out,
 hipError_t nca_launch_wgrad_bf16(int F, const NcaWgradArgs& a, int nsplit, hipStream_t st) {
     const bool d8 = a.njobs > 0 && a.job[0].d8 != 0;          // one format for every D block of a launch
     for (int j = 0; j < a.njobs; ++j)
-        if ((a.job[j].d8 != 0) != d8) return hipErrorInvalidValue;
+        if ((a.job[j].d8 != 0) != d8 || (d8 && !a.job[j].h8)) return hipErrorInvalidValue;
     const dim3 grid(nsplit, a.njobs), block(64);
     constexpr int L = NCA_WGRAD_LDS;          // the wave's ring of tile slots: four one-wave workgroups share a CU's 160 KiB
     switch (F) {
