@@ -14,7 +14,6 @@
 //         accumulator layout (rows = samples), and those tiles feed the weight-gradient MFMAs as A
 //         (X^T form) and B operands; dW of a whole layer stays in 256 accumulator registers.
 #include <hip/hip_runtime.h>
-#include <type_traits>
 #include "nca_kernels.hpp"
 
 // Timing-only elimination builds (tools/elim_build.sh): -DNCA_EXP=<bits> removes a piece of work so that its cost shows as a
@@ -1444,14 +1443,16 @@ __device__ __forceinline__ void wgrad_job(const NcaWgradArgs& a, const NcaWgradJ
 // position, half h) then holds 16 samples of each of the wave tile's two 32-sample halves = its 32 K values; both operands
 // use the same K order, which is all the contraction needs (tools/mx_mfma_probe.hip: lane maps, scales, formats).
 typedef int i32x8 __attribute__((ext_vector_type(8)));
+// (the conversions write one half of a register and keep the other: starting from a value that is live anyway -- both halves get
+// written -- lets the first one work in place instead of on a register zeroed by an extra v_mov)
 __device__ __forceinline__ unsigned z4_e5m2(float a, float b, float c, float d) {
-    int v = 0;
+    int v = __builtin_bit_cast(int, a);
     v = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, v, false);
     v = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, v, true);
     return (unsigned)v;
 }
 __device__ __forceinline__ unsigned z4_e4m3(float a, float b, float c, float d) {
-    int v = 0;
+    int v = __builtin_bit_cast(int, a);
     v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, v, false);
     v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
     return (unsigned)v;
@@ -1503,6 +1504,12 @@ __device__ __forceinline__ float colsum16(const f32x16& z) {
     return p0[0] + p0[1];
 }
 
+// fragment S (1 KiB) of a block: global src + 1024 S -> LDS to + 1024 S (the immediate offset moves both addresses), non-temporal
+template <int S>
+__device__ __forceinline__ void dma_piece(const char* src, char* to) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)to, 16, S * 1024, 2);
+}
+
 template <int F, int NTB, bool H8>
 __device__ __forceinline__ void wgrad_job_mx(const NcaWgradArgs& a, const NcaWgradJob& job, int q, int nsplit, int lane, char* ring) {
     using R = WgradRing<F, NTB, true, H8>;
@@ -1539,14 +1546,17 @@ __device__ __forceinline__ void wgrad_job_mx(const NcaWgradArgs& a, const NcaWgr
         // loads of different cache policies return out of order with each other, and the counted wait below assumes order.
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (t & ~(int64_t)1) * a.rows_total + job.dscale_off + job.net * 4),
                                          (__attribute__((address_space(3))) void*)(ring + SC0 + slot * 256), 4, 0, 2);
-#pragma unroll
-        for (int s = 0; s < ND_; ++s)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dp + s * 1024),
-                                             (__attribute__((address_space(3))) void*)(dst + s * 1024), 16, 0, 2);
-#pragma unroll
-        for (int s = 0; s < NH_; ++s)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bp + ((H8 || s * 32 + 32 <= brow) ? s : 0) * 1024),
-                                             (__attribute__((address_space(3))) void*)(dst + (ND_ + s) * 1024), 16, 0, 2);
+        // (the instruction's immediate offset moves the global AND the LDS address: one address pair per block, no 64-bit add per fragment)
+        static_assert(H8, "fragment s of the H block exists (the bf16 input block has 7 of 8)");
+        dma_piece<0>(dp, dst);
+        if constexpr (ND_ > 1) dma_piece<1>(dp, dst);
+        if constexpr (ND_ > 2) dma_piece<2>(dp, dst);
+        if constexpr (ND_ > 3) dma_piece<3>(dp, dst);
+        static_assert(ND_ <= 4 && NH_ <= 4, "immediate offsets reach 4 KiB");
+        dma_piece<0>(bp, dst + ND_ * 1024);
+        if constexpr (NH_ > 1) dma_piece<1>(bp, dst + ND_ * 1024);
+        if constexpr (NH_ > 2) dma_piece<2>(bp, dst + ND_ * 1024);
+        if constexpr (NH_ > 3) dma_piece<3>(bp, dst + ND_ * 1024);
     };
     const int64_t n = t1 > t0 ? t1 - t0 : 0;
 #pragma unroll
@@ -1560,18 +1570,7 @@ __device__ __forceinline__ void wgrad_job_mx(const NcaWgradArgs& a, const NcaWgr
         float sc = 0.f;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            const int64_t ii = i + half;
-            if (ii >= n) {                                   // an odd tail: the missing half contributes nothing
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) PA[m][4 * half + w] = 0;
-#pragma unroll
-                for (int c = 0; c < NTB; ++c)
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) PB[c][4 * half + w] = 0;
-                continue;
-            }
+            const int64_t ii = i + half;                     // (n is even: the launcher checks that the launch covers whole wave tiles)
             if (ii + NSLOT - 1 < n) {
                 issue(t0 + ii + NSLOT - 1, (int)((ii + NSLOT - 1) % NSLOT));
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSLOT - 1) * NDMA) : "memory");
@@ -1774,6 +1773,7 @@ hipError_t nca_launch_wgrad_bf16(int F, const NcaWgradArgs& a, int nsplit, hipSt
     const bool d8 = a.njobs > 0 && a.job[0].d8 != 0;          // one format for every D block of a launch
     for (int j = 0; j < a.njobs; ++j)
         if ((a.job[j].d8 != 0) != d8 || (d8 && !a.job[j].h8)) return hipErrorInvalidValue;
+    if (d8 && (a.ntiles & 1)) return hipErrorInvalidValue;        // whole wave tiles (two 32-sample tiles share a scale and an MFMA)
     const dim3 grid(nsplit, a.njobs), block(64);
     constexpr int L = NCA_WGRAD_LDS;          // the wave's ring of tile slots: four one-wave workgroups share a CU's 160 KiB
     switch (F) {
