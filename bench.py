@@ -39,6 +39,11 @@ FLOP_FWD, FLOP_DGRAD, FLOP_WGRAD = 303104, 264704, 303104
 # MI355X dense MFMA peaks (MI355X_MICROARCH.md).  The f32 mode's hidden-layer contractions run on the bf16 matrix cores
 # as six bf16 products per f32 product (exact 3-way split), so the pipe it really uses peaks at 2500 / 6
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}
+PEAK_HBM_GBPS = 8000.0
+# The weight-gradient kernel under fp8 staging reads, per sample, one 8-bit 128-wide block pair per layer and net (the layer's
+# output gradient, e5m2, and its input, e4m3): 2 nets x 5 layers x 2 x 128 B.  303 104 FLOP over those bytes =
+# 118 FLOP/B, below the ridge of 2500 TFLOP/s / 8 TB/s = 312 FLOP/B: that kernel's roofline is the HBM one.
+WGRAD_FP8_BYTES_PER_SAMPLE = 2 * 5 * 2 * 128
 PEAK_F32_ON_BF16_PIPE = 2500.0 / 6.0
 PROFILE_TAGS = ("r02", "r01")          # committed PMC summaries, newest first
 
@@ -235,6 +240,20 @@ def roofline_of(args, prec, kern, dt):
             "staging_TBps": (traffic / (kern[dom]["avg_ms"] * 1e-3) / 1e12) if traffic and kern[dom]["avg_ms"] else None,
             "simd_issue_share_pmc": issue,
             "kernel_time_share": kern[dom]["ms_total"] / (dt * 1e3) if dt else None, "all_kernels": kern}
+    from nerfca_amd import _capi
+    wg = kern["bwd_wgrad"]
+    if prec == "bf16" and _capi.get_option(_capi.OPT_STAGE_FP8) != 0 and wg["avg_ms"]:
+        # the weight-gradient kernel's own roofline is the HBM one (see WGRAD_FP8_BYTES_PER_SAMPLE)
+        nbytes = WGRAD_FP8_BYTES_PER_SAMPLE * args.rays * args.samples
+        gbps = nbytes / (wg["avg_ms"] * 1e-3) / 1e9
+        hbm = {"bound": "hbm", "kernel": "bwd_wgrad", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
+               "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": wg["avg_ms"],
+               "traffic": traffic_rec["kernels"]["bwd_wgrad"]["hbm_bytes_per_launch"] if traffic_rec and "bwd_wgrad" in traffic_rec.get("kernels", {}) else None}
+        if dom == "bwd_wgrad":
+            roof.update({k: hbm[k] for k in ("bound", "achieved", "peak", "unit", "frac", "algorithmic_bytes_per_launch")})
+            roof["mfma"] = {"achieved": wg["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": wg["tflops"] / peak}
+        else:
+            roof["bwd_wgrad_roofline"] = hbm
     if prec == "f32":      # the pipe the f32 mode's hidden-layer contractions really run on
         roof["frac_of_bf16_pipe_div_6"] = kern[dom]["tflops"] / PEAK_F32_ON_BF16_PIPE if kern[dom]["tflops"] else None
     return roof
