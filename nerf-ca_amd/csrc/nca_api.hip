@@ -663,14 +663,17 @@ static void make_job_bf16(NcaWgradJob& g, const NcaLayout& y, int j, int64_t net
 }
 // skip_layer: accumulated on chip by the dgrad kernel
 static void add_jobs_bf16(NcaWgradArgs* w, int net_index, const NcaLayout& y, int64_t net_off, int64_t d_off, int64_t slab_off, int64_t onehot_off, int64_t enc_off,
-                          int skip_layer, bool h8, bool d8, int64_t dscale_off) {
+                          int skip_layer, bool h8, bool d8, int64_t dscale_off, int expand_layer = -1, int mask_layers = 0) {
     for (int j = 0; j < y.NL; ++j) {
         if (j == skip_layer) continue;
         NcaWgradJob& g = w->job[w->njobs++];
         make_job_bf16(g, y, j, net_off, d_off, slab_off, onehot_off, enc_off, h8, d8);
         g.net = net_index;
         g.dscale_off = dscale_off;
-
+        if (j == expand_layer) {      // mode 5, e5m2: the block is rebuilt from the forward's mask bits (nca_kernels.hpp)
+            g.expand = 1;
+            g.mask_off = ((int64_t)net_index * mask_layers + j) * 1024;
+        }
     }
 }
 
@@ -767,7 +770,7 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     for (int n = 0; n < a.nnets; ++n) {
         if (bf) add_jobs_bf16(&w, n, lays[n], a.net[n].row0, a.net[n].drow0, slab_off[n], onehot_off[n],
                               stored && a.share_enc && n == 0 ? a.net[1].row0 : a.net[n].row0, onchip ? lays[n].NL - 1 : -1, h8, d8,
-                              p.tile_stride - NCA_D8_REC_BYTES);
+                              p.tile_stride - NCA_D8_REC_BYTES, nr && d8 ? lays[n].NL - 1 : -1, spl.mask_layers);
         else add_jobs_f32(&w, lays[n], a.net[n].row0, a.net[n].drow0, slab_off[n], onehot_off[n]);
     }
     w.scratch = scratch;
@@ -775,6 +778,10 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     w.slab_stride = p.slab_stride;
     w.scratch_b = stored ? static_cast<const float*>(store) : scratch;
     w.rows_total_b = stored ? spl.h_stride : p.tile_stride;
+    if (stored && bf) {
+        w.mask = static_cast<const char*>(store) + spl.off_m;
+        w.mask_stride = 2 * (int64_t)spl.mask_layers * 1024;
+    }
 
     a.scratch = stored ? const_cast<float*>(static_cast<const float*>(store)) : scratch;
     a.dscratch = reinterpret_cast<char*>(scratch);

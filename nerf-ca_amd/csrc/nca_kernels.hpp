@@ -119,8 +119,10 @@ struct NcaWgradJob {
     int32_t fourier_L;    // bf16 input block of a fourier net: slots are (sin_i, cos_i) interleaved; 0 otherwise
     int32_t d8, h8;       // bf16 path: the D block is e5m2 scaled by the wave tile's power of two / the H block is e4m3 x 2^NCA_H8_LOG2
     int32_t net;          // ... which of the tile's two inverse scales applies
-    int32_t pad;
+    int32_t expand;       // mode 5, e5m2: the job's D block is not in the D region -- it is relu'(H_{NL-1}) x one byte per sample, rebuilt
+                          // from the forward's mask bits and the sample's e5m2 byte (the first 128 bytes of the block's place: u32[32])
     int64_t dscale_off;   // ... byte offset of the inverse-scale record inside a tile of the D region
+    int64_t mask_off;     // expand: byte offset of the layer's mask fragment inside a wave tile of the mask store
 };
 
 struct NcaWgradArgs {
@@ -129,6 +131,8 @@ struct NcaWgradArgs {
     const float* scratch_b; // bf16: the region of the H / input blocks (== scratch in recompute mode) ...
     int64_t rows_total_b;   // ... its bytes per 32-sample tile ...
     int64_t tile0_b;        // ... and the 32-sample-tile index of this launch's first tile inside it
+    const char* mask;       // the forward store's mask bits (expand jobs) and their bytes per wave tile
+    int64_t mask_stride;
     float* slab;
     int64_t slab_stride;
     int32_t accumulate, njobs;

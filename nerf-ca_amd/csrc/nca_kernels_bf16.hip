@@ -14,6 +14,7 @@
 //         accumulator layout (rows = samples), and those tiles feed the weight-gradient MFMAs as A
 //         (X^T form) and B operands; dW of a whole layer stays in 256 accumulator registers.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "nca_kernels.hpp"
 
 // Timing-only elimination builds (tools/elim_build.sh): -DNCA_EXP=<bits> removes a piece of work so that its cost shows as a
@@ -723,7 +724,6 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
 #pragma unroll
                             for (int c = 0; c < 2; ++c) {
                                 const unsigned fld = mv[2 * c + (m >> 1)] >> (8 * (m & 1));
-                                u32x4 q8 = {0u, 0u, 0u, 0u};
 #pragma unroll
                                 for (int s2 = 0; s2 < 2; ++s2) {
                                     u32x4 dw, ds;
@@ -733,18 +733,19 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                                         const float a1 = wo[(lh * MT + m) * 16 + 8 * s2 + 2 * u + 1] * gc[c];
                                         const unsigned on = (fld >> (4 * s2 + u)) & 0x00010001u;
                                         dw[u] = keep_pk(pack2_pk(a0, a1), on);
-                                        ds[u] = keep_pk(gpk[c], on);
+                                        if (!S8) ds[u] = keep_pk(gpk[c], on);
                                     }
                                     Bn[c][2 * m + s2] = dw;
-                                    if (S8) {
-                                        q8[2 * s2] = cvt4_e5m2_pk(ds[0], ds[1], inv_s);
-                                        q8[2 * s2 + 1] = cvt4_e5m2_pk(ds[2], ds[3], inv_s);
-                                    } else {
-                                        store_nt(dblk + c * a.d_total + lane * 16 + (2 * m + s2) * 1024, ds);
-                                    }
+                                    if (!S8) store_nt(dblk + c * a.d_total + lane * 16 + (2 * m + s2) * 1024, ds);
                                 }
-                                if (S8) store_nt(dblk + c * a.d_total + lane * 16 + m * 1024, q8);
                             }
+                        }
+                        if (S8) {
+                            // e5m2: the block itself is not written -- the weight-gradient kernel rebuilds it from the forward's mask
+                            // bits and the sample's byte (wgrad_job_mx, EXPAND), left here as byte * 0x00010001 where the block of
+                            // the sample's 32-sample tile would start: u32[32], half lh of the wave writes tile lh
+                            const unsigned gb = lh ? gpk[1] : gpk[0];
+                            *reinterpret_cast<unsigned*>(dblk + lh * a.d_total + lr * 4) = cvt4_e5m2_pk(gb, gb, inv_s) & 0x00ff00ffu;
                         }
                     }
 #pragma unroll
@@ -1113,8 +1114,10 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                     if (NR) {
                         // this layer's masks were requested before the D stores of the step before (the output layer's step or the
                         // previous iteration): at most those stores are younger
+                        // (S8: the output layer's step stores one word per lane and lane 0's record, not a block)
                         constexpr int NSTM = S8 ? 2 * MT : 4 * MT;
-                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTM) : "memory");
+                        if (S8 && jj == y.NL - 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTM) : "memory");
                     }
                     if (!RES && !(NCA_EXP & 8)) stage_issue_b(a.stage[nsi], smem + (cur ^ 1) * BUF, wave, lane);
                     if (STORED && jj >= 2) mask_dma(jj - 2);            // for the next iteration; this one's arrived under the previous stage
@@ -1296,13 +1299,16 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
 // wgrad, no LDS.  One wave = one (job, split): dW of the whole layer in accumulators.
 // ------------------------------------------------------------------------------------------
 // dW / db of one (job, split) -> its slab, natural [o][i] order
-template <int F, int NTB>
+template <int F, int NTB, bool EXPAND = false>
 __device__ __forceinline__ void wgrad_write(const f32x16 (&acc)[F / 32][NTB], const float (&bsum)[F / 32], const NcaWgradJob& job, float* slab, int accumulate, int lane) {
     constexpr int MT = F / 32;
     const int lc = lane & 31, lh = lane >> 5;
     // Hidden blocks hold features in accumulator->operand order: position c = 16s+8a+4b+e of a 32-wide
     // tile is feature 16s+8b+4a+e (bits 3 and 2 swapped).  The input block is in natural slot order.
     auto unperm = [](int c) { return (c & 0x13) | ((c & 8) >> 1) | ((c & 4) << 1); };
+    // A D block rebuilt from mask bits (wgrad_job_mx, EXPAND) has its bytes in mask-bit order: position p = 16e+8h+4s+u is
+    // feature 16s + 8(u>>1) + 4h + 2(u&1) + e.
+    auto drow = [&](int p) { return EXPAND ? ((p & 4) << 2) | ((p & 2) << 2) | ((p & 8) >> 1) | ((p & 1) << 1) | (p >> 4) : unperm(p); };
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
 #pragma unroll
@@ -1310,7 +1316,7 @@ __device__ __forceinline__ void wgrad_write(const f32x16 (&acc)[F / 32][NTB], co
             const int slot = job.is_enc ? 32 * c + lc : 32 * c + unperm(lc);      // H column (layer-0 slot or hidden feature)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int o = 32 * m + unperm(nca_rho(i) + 4 * lh);
+                const int o = 32 * m + drow(nca_rho(i) + 4 * lh);
                 float* dst = nullptr;
                 if (job.is_enc) {
                     if (slot < job.ncols_w) dst = slab + job.out_off + (int64_t)o * job.out_ld + (job.fourier_L ? ((slot & 1) ? 3 * job.fourier_L + (slot >> 1) : (slot >> 1)) : slot);
@@ -1326,7 +1332,7 @@ __device__ __forceinline__ void wgrad_write(const f32x16 (&acc)[F / 32][NTB], co
             // column sums of the transposed D tile = sum over samples; the two lane halves hold disjoint samples
             const float b = bsum[m] + __shfl_xor(bsum[m], 32);
             if (lh == 0) {
-                float* dst = slab + job.bias_off + 32 * m + unperm(lc);
+                float* dst = slab + job.bias_off + 32 * m + drow(lc);
                 *dst = accumulate ? *dst + b : b;
             }
         }
@@ -1443,16 +1449,22 @@ __device__ __forceinline__ void wgrad_job(const NcaWgradArgs& a, const NcaWgradJ
 // position, half h) then holds 16 samples of each of the wave tile's two 32-sample halves = its 32 K values; both operands
 // use the same K order, which is all the contraction needs (tools/mx_mfma_probe.hip: lane maps, scales, formats).
 typedef int i32x8 __attribute__((ext_vector_type(8)));
-// (the conversions write one half of a register and keep the other: starting from a value that is live anyway -- both halves get
-// written -- lets the first one work in place instead of on a register zeroed by an extra v_mov)
+// (the conversions write one half of a register and keep the other.  Both halves get written, so the start value is immaterial: a
+// zero costs a v_mov per word, a live input ties the result to that input's register and costs a v_mov into the MFMA operand
+// tuple afterwards -- an empty asm "defines" a register without an instruction, which the allocator places inside the tuple)
+__device__ __forceinline__ int any_vgpr() {
+    int v;
+    asm volatile("" : "=v"(v));     // (volatile: one definition per use, or the compiler shares one and copies it)
+    return v;
+}
 __device__ __forceinline__ unsigned z4_e5m2(float a, float b, float c, float d) {
-    int v = __builtin_bit_cast(int, a);
+    int v = any_vgpr();
     v = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, v, false);
     v = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, v, true);
     return (unsigned)v;
 }
 __device__ __forceinline__ unsigned z4_e4m3(float a, float b, float c, float d) {
-    int v = __builtin_bit_cast(int, a);
+    int v = any_vgpr();
     v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, v, false);
     v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
     return (unsigned)v;
@@ -1510,13 +1522,21 @@ __device__ __forceinline__ void dma_piece(const char* src, char* to) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)to, 16, S * 1024, 2);
 }
 
-template <int F, int NTB, bool H8>
+// EXPAND (mode 5, the last hidden layer's job): the D block relu'(H_{NL-1}) g is NOT read -- per sample it has one distinct byte,
+// e5m2(g), at the features whose mask bit is set.  A tile brings the lane's two mask words (8 B of the forward's store) and the
+// sample's byte (as byte * 0x00010001; left by the dgrad kernel where the block would start) by three 4-byte LDS-DMAs into the
+// first KiB of its slot, and the fragment bytes are rebuilt on the vector ALU, 4 bytes in 4 instructions: nibble, x 0x204081 &
+// 0x01010101 (one bit per byte), packed 16-bit multiply by the byte.  The nibbles come in mask-bit order, so the rows of dW come
+// out in the order wgrad_write<EXPAND> undoes.  9 B per sample instead of F.
+template <int F, int NTB, bool H8, bool EXPAND = false>
 __device__ __forceinline__ void wgrad_job_mx(const NcaWgradArgs& a, const NcaWgradJob& job, int q, int nsplit, int lane, char* ring) {
     using R = WgradRing<F, NTB, true, H8>;
-    constexpr int MT = F / 32, ND_ = R::ND, NH_ = R::NH, FR = R::FR, NSLOT = R::NSLOT;
-    constexpr int NDMA = FR + 1;              // vector-memory operations per tile: the fragments and the wave tile's scale
+    constexpr int MT = F / 32, ND_ = EXPAND ? 1 : R::ND, NH_ = R::NH, FR = ND_ + NH_;
+    constexpr int NSLOT = EXPAND ? (F == 128 ? 6 : 4) : 4;       // (an expand tile is 5 KiB: more of them in flight)
+    constexpr int NDMA = (EXPAND ? 3 : ND_) + NH_ + 1;              // vector-memory operations per tile: the fragments and the wave tile's scale
     constexpr int SC0 = NSLOT * FR * 1024;    // the scales' 256 bytes per slot, behind the fragments
-    static_assert(SC0 + NSLOT * 256 <= NCA_WGRAD_LDS, "ring does not fit the wave's LDS share");
+    static_assert(SC0 + NSLOT * 256 <= NCA_WGRAD_LDS && NSLOT >= 2, "ring does not fit the wave's LDS share");
+    static_assert(!EXPAND || H8, "expand jobs read an e4m3 H block");
     static_assert((NSLOT - 1) * NDMA <= 63, "counted wait");
     const int lc = lane & 31, lh = lane >> 5;
     // whole wave tiles per split: the two 32-sample halves of a wave tile share one scale and one MFMA
@@ -1536,32 +1556,63 @@ __device__ __forceinline__ void wgrad_job_mx(const NcaWgradArgs& a, const NcaWgr
 #pragma unroll
     for (int m = 0; m < MT; ++m) bsum[m] = 0.f;
 
-    auto issue = [&](int64_t t, int slot) {
-        const char* dp = base + t * a.rows_total + job.d_row0 + lane * 16;
-        const char* bp = base_b + (t + a.tile0_b) * a.rows_total_b + job.b_row0 + lane * 16;
-        char* dst = ring + slot * (FR * 1024);
+    // Tiles are issued in order, so every address stream is a running wave-uniform pointer advanced by its stride (a few scalar adds
+    // per tile; indexed by the tile number the loop spent ~150 scalar instructions per tile on 64-bit multiplies -- with one wave
+    // per SIMD they are issue cycles like any other).  PAR = the tile's parity, known at every call site: the scale record (and
+    // an expand job's mask words) belong to the wave tile, i.e. move on after the odd tile.
+    static_assert(NSLOT == 4 || NSLOT == 6, "the tile issued NSLOT - 1 ahead has the other parity");
+    const int64_t n = t1 > t0 ? t1 - t0 : 0;
+    const char* p_d = base + t0 * a.rows_total + job.d_row0;
+    const char* p_h = base_b + (t0 + a.tile0_b) * a.rows_total_b + job.b_row0;
+    const char* p_sc = base + t0 * a.rows_total + job.dscale_off + job.net * 4;                 // (t0 is even)
+    const char* p_m = EXPAND ? a.mask + ((t0 + a.tile0_b) >> 1) * a.mask_stride + job.mask_off : nullptr;
+    int wslot = 0;
+    auto issue = [&](auto PARC) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(PARC)::value;
+        char* dst = ring + wslot * (FR * 1024);
         // The inverse scale of the tile's wave tile (in the record of its first 32-sample tile), one copy per lane, comes through the
         // ring as well: a register load gets the compiler's s_waitcnt vmcnt(0) in front of its first use, which drains every tile in
         // flight once per wave tile (-0.55 ms per launch at the bench size without it).  EVERY load of the loop is non-temporal:
         // loads of different cache policies return out of order with each other, and the counted wait below assumes order.
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (t & ~(int64_t)1) * a.rows_total + job.dscale_off + job.net * 4),
-                                         (__attribute__((address_space(3))) void*)(ring + SC0 + slot * 256), 4, 0, 2);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p_sc, (__attribute__((address_space(3))) void*)(ring + SC0 + wslot * 256), 4, 0, 2);
         // (the instruction's immediate offset moves the global AND the LDS address: one address pair per block, no 64-bit add per fragment)
         static_assert(H8, "fragment s of the H block exists (the bf16 input block has 7 of 8)");
-        dma_piece<0>(dp, dst);
-        if constexpr (ND_ > 1) dma_piece<1>(dp, dst);
-        if constexpr (ND_ > 2) dma_piece<2>(dp, dst);
-        if constexpr (ND_ > 3) dma_piece<3>(dp, dst);
+        if constexpr (EXPAND) {
+            const char* mp = p_m + lane * 16 + PAR * 8;       // the lane's two mask words of this column tile
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)mp, (__attribute__((address_space(3))) void*)dst, 4, 0, 2);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)mp, (__attribute__((address_space(3))) void*)(dst + 252), 4, 4, 2);   // (LDS dst + 256)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p_d + (lane & 31) * 4), (__attribute__((address_space(3))) void*)(dst + 512), 4, 0, 2);
+        } else {
+            const char* dp = p_d + lane * 16;
+            dma_piece<0>(dp, dst);
+            if constexpr (ND_ > 1) dma_piece<1>(dp, dst);
+            if constexpr (ND_ > 2) dma_piece<2>(dp, dst);
+            if constexpr (ND_ > 3) dma_piece<3>(dp, dst);
+        }
         static_assert(ND_ <= 4 && NH_ <= 4, "immediate offsets reach 4 KiB");
+        const char* bp = p_h + lane * 16;
         dma_piece<0>(bp, dst + ND_ * 1024);
         if constexpr (NH_ > 1) dma_piece<1>(bp, dst + ND_ * 1024);
         if constexpr (NH_ > 2) dma_piece<2>(bp, dst + ND_ * 1024);
         if constexpr (NH_ > 3) dma_piece<3>(bp, dst + ND_ * 1024);
+        p_d += a.rows_total;
+        p_h += a.rows_total_b;
+        if constexpr (PAR) {
+            p_sc += 2 * a.rows_total;
+            if constexpr (EXPAND) p_m += a.mask_stride;
+        }
+        wslot = wslot + 1 == NSLOT ? 0 : wslot + 1;
     };
-    const int64_t n = t1 > t0 ? t1 - t0 : 0;
-#pragma unroll
-    for (int p = 0; p < NSLOT - 1; ++p)
-        if (p < n) issue(t0 + p, p);
+    using Even = std::integral_constant<int, 0>;
+    using Odd = std::integral_constant<int, 1>;
+    if (0 < n) issue(Even{});
+    if (1 < n) issue(Odd{});
+    if (2 < n) issue(Even{});
+    if constexpr (NSLOT == 6) {
+        if (3 < n) issue(Odd{});
+        if (4 < n) issue(Even{});
+    }
+    int rslot = 0;                                            // the slot of the tile being consumed
     const long ED0 = ident8<true>(8 * lh, lc), ED1 = ident8<true>(16 + 8 * lh, lc);          // e5m2 identity (D blocks)
     const long EH0 = ident8<false>(8 * lh, lc), EH1 = ident8<false>(16 + 8 * lh, lc);        // e4m3 identity (e4m3 H blocks)
     const u32x4 EB0 = ident_frag(8 * lh, lc), EB1 = ident_frag(16 + 8 * lh, lc);             // bf16 identity (bf16 H blocks)
@@ -1572,19 +1623,33 @@ __device__ __forceinline__ void wgrad_job_mx(const NcaWgradArgs& a, const NcaWgr
         for (int half = 0; half < 2; ++half) {
             const int64_t ii = i + half;                     // (n is even: the launcher checks that the launch covers whole wave tiles)
             if (ii + NSLOT - 1 < n) {
-                issue(t0 + ii + NSLOT - 1, (int)((ii + NSLOT - 1) % NSLOT));
+                if (half == 0) issue(Odd{}); else issue(Even{});       // tile ii + NSLOT - 1
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSLOT - 1) * NDMA) : "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            if (half == 0) sc = *reinterpret_cast<const float*>(ring + SC0 + (int)(ii % NSLOT) * 256 + lane * 4);
-            const char* slot = ring + (int)(ii % NSLOT) * (FR * 1024) + lane * 16;
-            if constexpr (MT == 4) {                         // D: e5m2 bytes -> transposed, bias sums, bytes again
-                u32x4 x[4];
-                f32x16 z[4];
+            if (half == 0) sc = *reinterpret_cast<const float*>(ring + SC0 + rslot * 256 + lane * 4);
+            const char* slot = ring + rslot * (FR * 1024) + lane * 16;
+            rslot = rslot + 1 == NSLOT ? 0 : rslot + 1;
+            u32x4 xd[MT];
+            if constexpr (EXPAND) {
+                const char* sm = slot - lane * 12;
+                const unsigned mw[2] = {*reinterpret_cast<const unsigned*>(sm), *reinterpret_cast<const unsigned*>(sm + 256)};
+                const unsigned g2 = *reinterpret_cast<const unsigned*>(sm + 512);
 #pragma unroll
-                for (int m = 0; m < 4; ++m) x[m] = *reinterpret_cast<const u32x4*>(slot + m * 1024);
-                transpose4_vgpr<true>(x, ED0, ED1, z);
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const unsigned nib = __builtin_amdgcn_ubfe(mw[m >> 1], 8 * (m & 1) + 4 * (w & 1) + 16 * (w >> 1), 4);
+                        xd[m][w] = keep_pk(__umul24(nib, 0x00204081u) & 0x01010101u, g2);
+                    }
+            } else {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) xd[m] = *reinterpret_cast<const u32x4*>(slot + m * 1024);
+            }
+            if constexpr (MT == 4) {                         // D: e5m2 bytes -> transposed, bias sums, bytes again
+                f32x16 z[4];
+                transpose4_vgpr<true>(xd, ED0, ED1, z);
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     bsum[m] = fmaf(colsum16(z[m]), sc, bsum[m]);
@@ -1594,7 +1659,7 @@ __device__ __forceinline__ void wgrad_job_mx(const NcaWgradArgs& a, const NcaWgr
             } else
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                const u32x4 x = *reinterpret_cast<const u32x4*>(slot + m * 1024);
+                const u32x4 x = xd[m];
                 f32x16 z;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) z[r] = 0.f;
@@ -1647,7 +1712,7 @@ __device__ __forceinline__ void wgrad_job_mx(const NcaWgradArgs& a, const NcaWgr
             for (int c = 0; c < NTB; ++c)
                 acc[m][c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(PA[m], PB[c], acc[m][c], 1 /* A: e5m2 */, 0 /* B: e4m3 */, 0, sa, 0, 127);
     }
-    wgrad_write<F, NTB>(acc, bsum, job, a.slab + (int64_t)q * a.slab_stride, a.accumulate, lane);
+    wgrad_write<F, NTB, EXPAND>(acc, bsum, job, a.slab + (int64_t)q * a.slab_stride, a.accumulate, lane);
 }
 
 // Mode 5: the output layer's bias gradient = sum over the wave tiles of the per-tile sums of d loss / d raw that the dgrad kernel left
@@ -1685,7 +1750,8 @@ __global__ __launch_bounds__(64, 1) void nca_wgrad_bf16(const NcaWgradArgs a) {
     // (at F = 128 the 112-slot input block and a hidden block have the same shape: one body serves both)
     if constexpr (D8) {
         s8_mode();
-        if (F != 128 && job.is_enc && job.h8) wgrad_job_mx<F, 4, true>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
+        if (job.expand) wgrad_job_mx<F, F / 32, true, true>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
+        else if (F != 128 && job.is_enc && job.h8) wgrad_job_mx<F, 4, true>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
         else wgrad_job_mx<F, F / 32, true>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);         // (e5m2 D blocks come with e4m3 H blocks)
     } else {
         if (F != 128 && job.is_enc && job.h8) wgrad_job<F, 4, D8, true>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
