@@ -40,10 +40,11 @@ FLOP_FWD, FLOP_DGRAD, FLOP_WGRAD = 303104, 264704, 303104
 # as six bf16 products per f32 product (exact 3-way split), so the pipe it really uses peaks at 2500 / 6
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}
 PEAK_HBM_GBPS = 8000.0
-# The weight-gradient kernel under fp8 staging reads, per sample, one 8-bit 128-wide block pair per layer and net (the layer's
-# output gradient, e5m2, and its input, e4m3): 2 nets x 5 layers x 2 x 128 B.  303 104 FLOP over those bytes =
-# 118 FLOP/B, below the ridge of 2500 TFLOP/s / 8 TB/s = 312 FLOP/B: that kernel's roofline is the HBM one.
-WGRAD_FP8_BYTES_PER_SAMPLE = 2 * 5 * 2 * 128
+# The weight-gradient kernel under fp8 staging reads, per sample and net, one 8-bit 128-wide block pair per layer (the layer's
+# output gradient, e5m2, and its input, e4m3) -- except the last hidden layer's output gradient, which it rebuilds
+# from 16 B of mask bits and 4 B: 2 nets x (4 x 256 + 128 + 20) B.  303 104 FLOP over those bytes = 129 FLOP/B, below the ridge
+# of 2500 TFLOP/s / 8 TB/s = 312 FLOP/B: that kernel's roofline is the HBM one.
+WGRAD_FP8_BYTES_PER_SAMPLE = 2 * (4 * 256 + 128 + 20)
 PEAK_F32_ON_BF16_PIPE = 2500.0 / 6.0
 PROFILE_TAGS = ("r02", "r01")          # committed PMC summaries, newest first
 

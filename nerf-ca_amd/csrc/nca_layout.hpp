@@ -256,6 +256,9 @@ inline int nca_build_layout_bf16(const NcaNet& n, NcaLayout* out, const char** w
 //           dW_{NL-1}[f][k] = Wo[f] S[f][k],  db_{NL-1}[f] = Wo[f] s[f],  dWo[f] = sum_k W_{NL-1}[f][k] S[f][k] + b_{NL-1}[f] s[f]
 //       -- the last identity because sum_n g relu(z) = sum_n g relu'(z) z with z = W_{NL-1} H_{NL-2} + b_{NL-1}: the output layer's
 //       weight gradient needs neither the layer's input in the store nor a pass of its own.
+//       As e5m2 that block has ONE distinct byte per sample, e5m2(g x scale), at the features whose mask bit is set: it is not
+//       stored.  Its place in the tile keeps, in its first 128 bytes, u32[32] = that byte x 0x00010001 per sample of the 32-sample
+//       tile, and the weight-gradient job rebuilds the fragments from them and the forward's mask bits (wgrad_job_mx, EXPAND).
 //       Behind all nets' blocks of a 32-sample tile a 128-byte record; the first record of a 64-sample wave tile holds, per net,
 //       the INVERSE scale of the tile (f32[2]) and the tile's sum of d loss / d raw (f32[2]: the output layer's bias gradient,
 //       added up over the tiles in tile order by nca_sum_tile_records, whichever wave ran the tile)
