@@ -1532,7 +1532,7 @@ template <int F, int NTB, bool H8, bool EXPAND = false>
 __device__ __forceinline__ void wgrad_job_mx(const NcaWgradArgs& a, const NcaWgradJob& job, int q, int nsplit, int lane, char* ring) {
     using R = WgradRing<F, NTB, true, H8>;
     constexpr int MT = F / 32, ND_ = EXPAND ? 1 : R::ND, NH_ = R::NH, FR = ND_ + NH_;
-    constexpr int NSLOT = EXPAND ? (F == 128 ? 6 : 4) : 4;       // (an expand tile is 5 KiB: more of them in flight)
+    constexpr int NSLOT = (NCA_EXP & 4194304) ? 2 : (EXPAND ? (F == 128 ? 6 : 4) : 4);       // (an expand tile is 5 KiB: more of them in flight; 4194304: one tile ahead, timing only)
     constexpr int NDMA = (EXPAND ? 3 : ND_) + NH_ + 1;              // vector-memory operations per tile: the fragments and the wave tile's scale
     constexpr int SC0 = NSLOT * FR * 1024;    // the scales' 256 bytes per slot, behind the fragments
     static_assert(SC0 + NSLOT * 256 <= NCA_WGRAD_LDS && NSLOT >= 2, "ring does not fit the wave's LDS share");
@@ -1560,7 +1560,7 @@ __device__ __forceinline__ void wgrad_job_mx(const NcaWgradArgs& a, const NcaWgr
     // per tile; indexed by the tile number the loop spent ~150 scalar instructions per tile on 64-bit multiplies -- with one wave
     // per SIMD they are issue cycles like any other).  PAR = the tile's parity, known at every call site: the scale record (and
     // an expand job's mask words) belong to the wave tile, i.e. move on after the odd tile.
-    static_assert(NSLOT == 4 || NSLOT == 6, "the tile issued NSLOT - 1 ahead has the other parity");
+    static_assert(NSLOT == 2 || NSLOT == 4 || NSLOT == 6, "the tile issued NSLOT - 1 ahead has the other parity");
     const int64_t n = t1 > t0 ? t1 - t0 : 0;
     const char* p_d = base + t0 * a.rows_total + job.d_row0;
     const char* p_h = base_b + (t0 + a.tile0_b) * a.rows_total_b + job.b_row0;
@@ -1606,8 +1606,10 @@ __device__ __forceinline__ void wgrad_job_mx(const NcaWgradArgs& a, const NcaWgr
     using Even = std::integral_constant<int, 0>;
     using Odd = std::integral_constant<int, 1>;
     if (0 < n) issue(Even{});
-    if (1 < n) issue(Odd{});
-    if (2 < n) issue(Even{});
+    if constexpr (NSLOT >= 4) {
+        if (1 < n) issue(Odd{});
+        if (2 < n) issue(Even{});
+    }
     if constexpr (NSLOT == 6) {
         if (3 < n) issue(Odd{});
         if (4 < n) issue(Even{});
@@ -1747,6 +1749,9 @@ template <int F, bool D8>
 __global__ __launch_bounds__(64, 1) void nca_wgrad_bf16(const NcaWgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char wring[];
     const NcaWgradJob job = a.job[blockIdx.y];
+#if NCA_EXP & 65536
+    const unsigned long long clk_t0 = __builtin_readcyclecounter(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     // (at F = 128 the 112-slot input block and a hidden block have the same shape: one body serves both)
     if constexpr (D8) {
         s8_mode();
@@ -1759,6 +1764,13 @@ __global__ __launch_bounds__(64, 1) void nca_wgrad_bf16(const NcaWgradArgs a) {
         else if (F != 128 && job.is_enc) wgrad_job<F, 4, D8, false>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
         else wgrad_job<F, F == 128 ? 4 : F / 32, D8, false>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
     }
+#if NCA_EXP & 65536
+    // (65536: cycles and clock of two waves of a standard job and of an expand job -- the grid is one round, the slowest wave is the launch)
+    if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 57) && (blockIdx.y == 1 || blockIdx.y == 4)) {
+        const unsigned long long dt = __builtin_readcyclecounter() - clk_t0, dr = __builtin_amdgcn_s_memrealtime() - clk_r0;
+        printf("wgrad job %d split %d: %llu shader cycles in %.1f us = %.3f GHz\n", (int)blockIdx.y, (int)blockIdx.x, dt, dr * 0.01, (double)dt / (dr * 10.0));
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
