@@ -522,6 +522,7 @@ struct BwdPlan {
     int64_t tile_stride;   // f32: scratch rows per 32-sample tile; bf16: BYTES per 32-sample tile (all nets)
     int64_t slab_stride;   // floats per split slab
     int n_split, njobs, grid;
+    int n_split_x;          // splits of the jobs that rebuild their D block from mask bits (more waves, fewer tiles each); slab rows = the larger
     int64_t units_per_chunk;
     int64_t tiles_per_unit;    // wave tiles (32 samples f32 / 64 samples bf16) per unit
     int64_t bytes_total;
@@ -557,7 +558,20 @@ static int plan_bwd(const NcaLayout* lays, int nnets, int32_t prec, int64_t unit
     // blocks on 1024 slots double the kernel time)
     int nsplit = ((bf ? 4 : 2) * cus) / (p->njobs > 0 ? p->njobs : 1);
     if (nsplit < 1) nsplit = 1;
-    const int64_t slab_bytes = align_up((int64_t)nsplit * p->slab_stride * 4, 256);
+    // The jobs of the last hidden layers under e5m2 staging rebuild their D block on the vector ALU: 1.15 x the cycles per tile of
+    // the others (measured, tools/clock_probe.sh).  The grid is ONE round of one-wave workgroups, so the slowest wave is the launch:
+    // those jobs get 1.15 x the splits.  Their extra slab rows stay zero in every other job's columns (cleared once per backward).
+    int nsplit_x = nsplit;
+    if (bf && stored && d8 && nr && p->njobs > nnets) {
+        const double W = 1.15;
+        int ns = (int)((4.0 * cus) / ((p->njobs - nnets) + nnets * W));
+        if (ns < 1) ns = 1;
+        int nx = (int)(W * ns);
+        while ((p->njobs - nnets) * ns + nnets * nx > 4 * cus && nx > ns) --nx;
+        nsplit = ns;
+        nsplit_x = nx;
+    }
+    const int64_t slab_bytes = align_up((int64_t)nsplit_x * p->slab_stride * 4, 256);
     const int64_t oslab_bytes = align_up((int64_t)cus * 2 * (F + 1) * 4, 256);
     p->wslab_stride = (int64_t)F * F + F;                                               // on-chip layer: dW and db per workgroup
     const int64_t wslab_bytes = bf ? align_up((int64_t)cus * 2 * p->wslab_stride * 4, 256) : 0;
@@ -576,8 +590,12 @@ static int plan_bwd(const NcaLayout* lays, int nnets, int32_t prec, int64_t unit
     p->units_per_chunk = upc;
     const int64_t tiles = upc * tiles_per_unit;
     const int64_t ktiles = bf ? tiles * 2 : tiles;       // 32-sample tiles the wgrad splits over
+    if ((int64_t)nsplit_x > ktiles / 2) { nsplit_x = nsplit < nsplit_x ? nsplit : nsplit_x; }      // small launches: uniform splits
     if ((int64_t)nsplit > ktiles) nsplit = (int)ktiles;
+    if ((int64_t)nsplit_x > ktiles) nsplit_x = (int)ktiles;
+    if (nsplit_x < nsplit) nsplit_x = nsplit;
     p->n_split = nsplit;
+    p->n_split_x = nsplit_x;
     const int64_t ngroups = (tiles + NCA_WAVES - 1) / NCA_WAVES;
     p->grid = (int)(ngroups < cus ? ngroups : cus);
     p->off_slab = 0;
@@ -868,7 +886,13 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
         {
             Span sp(NCA_K_BWD_WGRAD, st);
             if (bf) {
-                if (w.njobs) HIPCHK(nca_launch_wgrad_bf16(F, w, p.n_split, st));
+                if (w.njobs) {
+                    w.nsplit_std = p.n_split;
+                    w.nsplit_x = p.n_split_x;
+                    if (p.n_split_x > p.n_split && chunk == 0)         // the rows that only the expand jobs write: zero for everyone else
+                        HIPCHK(hipMemsetAsync(slab + (int64_t)p.n_split * p.slab_stride, 0, (size_t)(p.n_split_x - p.n_split) * p.slab_stride * 4, st));
+                    HIPCHK(nca_launch_wgrad_bf16(F, w, p.n_split_x, st));
+                }
             } else HIPCHK(nca_launch_wgrad_f32(w, p.n_split, st));
         }
     }
@@ -876,7 +900,7 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     memset(&r, 0, sizeof(r));
     r.slab = slab;
     r.slab_stride = p.slab_stride;
-    r.n_split = p.n_split;
+    r.n_split = bf ? p.n_split_x : p.n_split;
     r.n_wg = p.grid;
     r.oslab = oslab;
     r.oslab_stride = 2 * (F + 1);

@@ -136,6 +136,7 @@ struct NcaWgradArgs {
     float* slab;
     int64_t slab_stride;
     int32_t accumulate, njobs;
+    int32_t nsplit_std, nsplit_x;   // e5m2 staging: splits of the regular jobs / of the `expand` jobs (>=; slab rows)
     NcaWgradJob job[NCA_MAX_JOBS];
 };
 

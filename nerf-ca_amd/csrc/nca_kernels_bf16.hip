@@ -1748,16 +1748,29 @@ hipError_t nca_launch_sum_tile_records(const char* dregion, int64_t wave_tile_by
 template <int F, bool D8>
 __global__ __launch_bounds__(64, 1) void nca_wgrad_bf16(const NcaWgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char wring[];
-    const NcaWgradJob job = a.job[blockIdx.y];
+    // e5m2 staging: a 1-D grid of exactly the working (job, split) pairs, job after job -- expand jobs have nsplit_x splits, the others
+    // nsplit_std.  (A 2-D grid with idle workgroups does not do: the grid must fit ONE round of the chip's 4 x CUs slots, workgroups go
+    // to the XCDs round-robin, and idle ones unbalance that by enough to push a few working ones into a second round: 8.5 instead of 4.6 ms.)
+    int jy = blockIdx.y, qx = blockIdx.x, ns = gridDim.x;
+    if constexpr (D8) {
+        jy = 0;
+        for (;; ++jy) {
+            ns = a.job[jy].expand ? a.nsplit_x : a.nsplit_std;
+            if (qx < ns || jy + 1 >= a.njobs) break;
+            qx -= ns;
+        }
+        if (qx >= ns) return;
+    }
+    const NcaWgradJob job = a.job[jy];
 #if NCA_EXP & 65536
     const unsigned long long clk_t0 = __builtin_readcyclecounter(), clk_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
     // (at F = 128 the 112-slot input block and a hidden block have the same shape: one body serves both)
     if constexpr (D8) {
         s8_mode();
-        if (job.expand) wgrad_job_mx<F, F / 32, true, true>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
-        else if (F != 128 && job.is_enc && job.h8) wgrad_job_mx<F, 4, true>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
-        else wgrad_job_mx<F, F / 32, true>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);         // (e5m2 D blocks come with e4m3 H blocks)
+        if (job.expand) wgrad_job_mx<F, F / 32, true, true>(a, job, qx, ns, threadIdx.x, wring);
+        else if (F != 128 && job.is_enc && job.h8) wgrad_job_mx<F, 4, true>(a, job, qx, ns, threadIdx.x, wring);
+        else wgrad_job_mx<F, F / 32, true>(a, job, qx, ns, threadIdx.x, wring);         // (e5m2 D blocks come with e4m3 H blocks)
     } else {
         if (F != 128 && job.is_enc && job.h8) wgrad_job<F, 4, D8, true>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
         else if (job.h8) wgrad_job<F, F / 32, D8, true>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
@@ -1766,9 +1779,9 @@ __global__ __launch_bounds__(64, 1) void nca_wgrad_bf16(const NcaWgradArgs a) {
     }
 #if NCA_EXP & 65536
     // (65536: cycles and clock of two waves of a standard job and of an expand job -- the grid is one round, the slowest wave is the launch)
-    if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 57) && (blockIdx.y == 1 || blockIdx.y == 4)) {
+    if (threadIdx.x == 0 && (qx == 0 || qx == 57) && (jy == 1 || jy == 4)) {
         const unsigned long long dt = __builtin_readcyclecounter() - clk_t0, dr = __builtin_amdgcn_s_memrealtime() - clk_r0;
-        printf("wgrad job %d split %d: %llu shader cycles in %.1f us = %.3f GHz\n", (int)blockIdx.y, (int)blockIdx.x, dt, dr * 0.01, (double)dt / (dr * 10.0));
+        printf("wgrad job %d split %d: %llu shader cycles in %.1f us = %.3f GHz\n", jy, qx, dt, dr * 0.01, (double)dt / (dr * 10.0));
     }
 #endif
 }
@@ -1852,7 +1865,13 @@ hipError_t nca_launch_wgrad_bf16(int F, const NcaWgradArgs& a, int nsplit, hipSt
     for (int j = 0; j < a.njobs; ++j)
         if ((a.job[j].d8 != 0) != d8 || (d8 && !a.job[j].h8)) return hipErrorInvalidValue;
     if (d8 && (a.ntiles & 1)) return hipErrorInvalidValue;        // whole wave tiles (two 32-sample tiles share a scale and an MFMA)
-    const dim3 grid(nsplit, a.njobs), block(64);
+    dim3 grid(nsplit, a.njobs), block(64);
+    if (d8) {          // one workgroup per working (job, split) pair
+        if (a.nsplit_std <= 0 || a.nsplit_x < a.nsplit_std) return hipErrorInvalidValue;
+        int total = 0;
+        for (int j = 0; j < a.njobs; ++j) total += a.job[j].expand ? a.nsplit_x : a.nsplit_std;
+        grid = dim3(total, 1);
+    }
     constexpr int L = NCA_WGRAD_LDS;          // the wave's ring of tile slots: four one-wave workgroups share a CU's 160 KiB
     switch (F) {
         case 32: if (d8) hipLaunchKernelGGL((nca_wgrad_bf16<32, true>), grid, block, L, st, a); else hipLaunchKernelGGL((nca_wgrad_bf16<32, false>), grid, block, L, st, a); break;
