@@ -13,15 +13,21 @@ One "step" = one pass of the hot path over one batch: ray gather (GPU-resident t
 forward, all losses, fused backward, (all-reduce), Adam + LinearLR.  Inputs are resident in HBM when
 the timed region starts.  Weak scaling: every rank renders --rays rays per step.
 
-Rank 0 prints ONE JSON line.  `roofline` is for the kernel with the largest share of the timed
-region, measured with HIP events on the launch stream inside the library (nca_timing_*);
-`cpu_baseline` is the CPU oracle (reference-equivalent torch CPU ops) on a bounded sample.  At N = 1 the line
-also carries `f32` (the same step in the 1e-5 parity mode, a few steps), `unfused_gpu_baseline` (the
-reference-equivalent torch ops run op by op on the same GPU: the denominator of the north star's >= 10x) and
-`psnr` (held-out PSNR of HIP f32, HIP bf16 and the CPU oracle after equal steps from identical weights and
-batches; train/run_composite.py:391 defines test_psnr).  --no-extras drops those three.
+Rank 0 prints ONE JSON line.  `dtype` names the arithmetic of the timed step as the library's planner ran it:
+"bf16+fp8stage" = bf16 MLP contractions whose layer inputs / output gradients cross HBM as e4m3 / e5m2 on their way to the
+weight-gradient kernel (which contracts them on the MX-fp8 matrix path), "bf16" = the same with bf16 staging, "f32" = the 1e-5
+parity mode.  `roofline` is for the kernel with the largest share of the step, measured with HIP events on the launch stream
+inside the library (nca_timing_*) over an eager pass of the same step (events cannot be recorded inside a replayed graph: the
+table decomposes `eager_ms_per_step`, which it sums to at most); `cpu_baseline` is the CPU oracle (reference-equivalent torch CPU
+ops) on a bounded sample.  At N = 1 the line also carries the other two precisions side by side, each through the same
+graph-replayed step with its own kernel table and roofline -- `bf16_pure` (NCA_OPT_STAGE_FP8 = 0: BASELINE configs[1] as written)
+and `f32` (>= 20 steps after 5 warm-up) --, `sustained` (ms per step over the last 100 of --sustained-steps further graph
+steps: the chip lowers its clock as it heats), `unfused_gpu_baseline` (the reference-equivalent torch ops run op by op on the
+same GPU: the denominator of the north star's >= 10x) and `psnr` (held-out PSNR of HIP f32, HIP bf16 and the CPU oracle after
+equal steps from identical weights and batches; train/run_composite.py:391 defines test_psnr).  --no-extras drops those.
 """
 import argparse
+import hashlib
 import json
 import os
 import subprocess
@@ -46,7 +52,7 @@ PEAK_HBM_GBPS = 8000.0
 # of 2500 TFLOP/s / 8 TB/s = 312 FLOP/B: that kernel's roofline is the HBM one.
 WGRAD_FP8_BYTES_PER_SAMPLE = 2 * (4 * 256 + 128 + 20)
 PEAK_F32_ON_BF16_PIPE = 2500.0 / 6.0
-PROFILE_TAGS = ("r02", "r01")          # committed PMC summaries, newest first
+PROFILE_TAGS = ("r03", "r02", "r01")          # committed PMC summaries, newest first
 
 
 def parse(argv=None):
@@ -68,8 +74,14 @@ def parse(argv=None):
     ap.add_argument("--eager", action="store_true", help="launch every kernel of the step from the host instead (CompositeTrainer.step, torch Adam)")
     ap.add_argument("--unfused-gpu-rays", type=int, default=16384, help="rays/step of the unfused torch path on cuda:0 (0: skip)")
     ap.add_argument("--unfused-gpu-steps", type=int, default=3)
-    ap.add_argument("--f32-steps", type=int, default=4)
+    ap.add_argument("--f32-steps", type=int, default=20, help="timed steps of the f32 sub-record (after --f32-warmup; 0: skip)")
+    ap.add_argument("--f32-warmup", type=int, default=5)
+    ap.add_argument("--pure-steps", type=int, default=8, help="timed steps of the bf16_pure sub-record (bf16 staging; 0: skip)")
+    ap.add_argument("--sustained-steps", type=int, default=500, help="further graph steps after the timed region; the last 100 are timed (0: skip)")
+    ap.add_argument("--kernel-steps", type=int, default=8, help="steps of the eager pass that times the kernels")
     ap.add_argument("--psnr-steps", type=int, default=100, help="steps of the PSNR record (64^2 detector, 256 rays/step; 0: skip)")
+    ap.add_argument("--dry-run", action="store_true", help="rendezvous bookkeeping only: without RANK in the environment print the launch this process would "
+                    "make (and make it, so that every rank reports); as a rank print {rank, world, local_rank, device index} and exit BEFORE anything touches the GPU")
     ap.add_argument("--views", type=int, default=4)
     ap.add_argument("--torch-losses", action="store_true", help="losses + autograd in torch ops instead of the fused loss kernel")
     args = ap.parse_args(argv)
@@ -101,13 +113,28 @@ def self_launch(args) -> int:
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # the host driver only supports dmabuf IPC (RCCL needs it)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    if args.dry_run:
+        print(json.dumps({"launch": cmd, "ranks": args.gpus, "HSA_ENABLE_IPC_MODE_LEGACY": env["HSA_ENABLE_IPC_MODE_LEGACY"]}), flush=True)
     return subprocess.run(cmd, env=env).returncode
 
 
-def committed_pmc(prec, rays, samples):
+def source_sha():
+    """Hash of the kernel sources this library was built from: a committed PMC summary is replayed only for the sources it
+    was taken on."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "nerf-ca_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".hpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(csrc, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def committed_pmc(prec, rays, samples, stage_fp8=None):
     """The committed PMC summaries of this configuration, newest round first: (traffic record, sq record, source) or Nones.
     These are REPLAYED figures (separate rocprofv3 --pmc passes cannot run inside a bench run): the line labels them with
-    the file and commit they come from."""
+    the file and commit they come from, and they are dropped when the kernel sources have changed since (source_sha)."""
+    sha = source_sha()
     for tag in PROFILE_TAGS:
         path = os.path.join(ROOT, "profiles", f"{tag}_{prec}_pmc_traffic.json")
         try:
@@ -117,11 +144,14 @@ def committed_pmc(prec, rays, samples):
         cfg = rec.get("config", {})
         if cfg.get("rays_per_step") != rays or cfg.get("samples_per_ray") != samples or cfg.get("prec") != prec:
             continue
+        if rec.get("source_sha") != sha or (stage_fp8 is not None and cfg.get("stage_fp8", True) != stage_fp8):
+            continue          # taken on other kernel sources / another staging: not this build's traffic
         try:
             sq = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_{prec}_pmc_sq.json")))
         except (OSError, ValueError):
             sq = None
-        return rec, sq, {"file": f"profiles/{tag}_{prec}_pmc_traffic.json", "taken_at_commit": rec.get("commit"), "kind": "replayed from a committed rocprofv3 --pmc pass"}
+        return rec, sq, {"file": f"profiles/{tag}_{prec}_pmc_traffic.json", "taken_at_commit": rec.get("commit"), "source_sha": sha,
+                         "kind": "replayed from a committed rocprofv3 --pmc pass over these kernel sources"}
     return None, None, None
 
 
@@ -204,35 +234,33 @@ def make_trainer(args, prec, data, dev, rank, world, use_pg):
     return tr
 
 
-def kernel_table(args, prec, timed_steps):
-    """Per-kernel HIP-event times of the span the library's timers covered, with algorithmic TFLOP/s."""
+def kernel_table(args, timed_steps, plan):
+    """Per-kernel HIP-event times of the span the library's timers covered, with algorithmic TFLOP/s.  `plan` = the planner's
+    decisions for this backward (nca_last_plan): with the last hidden layer's weight gradient accumulated in the dgrad kernel
+    (bf16 staging at this size) its 2 x 2 x 128 x 128 FLOP per sample count there, not in the weight-gradient kernel."""
     from nerfca_amd import _capi
     n_samp = args.rays * args.samples * timed_steps
     kern = {}
-    # bf16 with BF16 staging at this size (NCA_STAGE_FP8=0): the weight gradient of the last hidden layer of both nets (2 x 2 x 128 x
-    # 128 FLOP per sample) is accumulated inside the dgrad kernel (mode 4), not by the wgrad kernel.  The default, fp8 staging,
-    # runs mode 5 (nothing recomputed; also one dgrad launch per net when the weight images are resident) and all of it in the wgrad
-    dg_ms, dg_n = _capi.timing_read("bwd_dgrad")
-    wg_ms, wg_n = _capi.timing_read("bwd_wgrad")
-    fp8 = prec == "bf16" and _capi.get_option(_capi.OPT_STAGE_FP8) != 0
-    onchip = prec == "bf16" and not fp8 and wg_n > 0 and dg_n == 2 * wg_n
-    moved = 2 * 2 * 128 * 128 if onchip else 0
+    moved = 2 * 2 * 128 * 128 if plan.get("bwd_onchip") else 0
     for name, flop in (("fwd", FLOP_FWD), ("bwd_dgrad", FLOP_DGRAD + moved), ("bwd_wgrad", FLOP_WGRAD - moved), ("bwd_reduce", 0), ("loss", 0), ("pack", 0)):
         ms, n = _capi.timing_read(name)
-        kern[name] = {"ms_total": ms, "launches": n, "avg_ms": ms / n if n else None,
+        kern[name] = {"ms_total": ms, "launches": n, "avg_ms": ms / n if n else None, "ms_per_step": ms / max(timed_steps, 1),
                       "tflops": (flop * n_samp / (ms * 1e-3) / 1e12) if ms > 0 and flop else None}
-    return kern, onchip
+    return kern
 
 
-def roofline_of(args, prec, kern, dt):
+def roofline_of(args, prec, kern, eager_dt, plan):
+    """`eager_dt` = wall seconds of the eager pass the kernel table was taken over (what the table decomposes)."""
     dom = max(("fwd", "bwd_dgrad", "bwd_wgrad"), key=lambda k: kern[k]["ms_total"])
     peak = PEAK_TFLOPS[prec]
-    traffic_rec, sq_rec, source = committed_pmc(prec, args.rays, args.samples)
+    fp8 = bool(plan.get("stage_fp8"))
+    traffic_rec, sq_rec, source = committed_pmc(prec, args.rays, args.samples, fp8 if prec == "bf16" else None)
     traffic = traffic_rec["kernels"][dom]["hbm_bytes_per_launch"] if traffic_rec and dom in traffic_rec.get("kernels", {}) else None
     issue = None
     if sq_rec and dom in sq_rec.get("kernels", {}):
         k = sq_rec["kernels"][dom]
-        issue = {"mfma_busy": k["mfma_busy"], "valu_busy": k.get("valu_busy")}
+        issue = {"mfma_busy": k["mfma_busy"], "valu_busy": k.get("valu_busy"), "valu_mfma_coexec": k.get("valu_mfma_coexec")}
+    ksum = sum(v["ms_total"] for v in kern.values())
     roof = {"bound": "mfma", "kernel": dom, "achieved": kern[dom]["tflops"], "peak": peak, "unit": "TFLOP/s",
             "frac": kern[dom]["tflops"] / peak if kern[dom]["tflops"] else None,
             "traffic": traffic, "traffic_source": source if traffic is not None else None,
@@ -240,10 +268,11 @@ def roofline_of(args, prec, kern, dt):
             # the staged (non-algorithmic) HBM traffic of that kernel per second of its run time: what it is bound by in practice
             "staging_TBps": (traffic / (kern[dom]["avg_ms"] * 1e-3) / 1e12) if traffic and kern[dom]["avg_ms"] else None,
             "simd_issue_share_pmc": issue,
-            "kernel_time_share": kern[dom]["ms_total"] / (dt * 1e3) if dt else None, "all_kernels": kern}
-    from nerfca_amd import _capi
+            # share of the eager pass (the span the table decomposes) spent in the dominant kernel / in all timed kernels
+            "kernel_time_share": kern[dom]["ms_total"] / (eager_dt * 1e3) if eager_dt else None,
+            "all_kernels_time_share": ksum / (eager_dt * 1e3) if eager_dt else None, "all_kernels": kern}
     wg = kern["bwd_wgrad"]
-    if prec == "bf16" and _capi.get_option(_capi.OPT_STAGE_FP8) != 0 and wg["avg_ms"]:
+    if prec == "bf16" and fp8 and wg["avg_ms"]:
         # the weight-gradient kernel's own roofline is the HBM one (see WGRAD_FP8_BYTES_PER_SAMPLE)
         nbytes = WGRAD_FP8_BYTES_PER_SAMPLE * args.rays * args.samples
         gbps = nbytes / (wg["avg_ms"] * 1e-3) / 1e9
@@ -260,25 +289,101 @@ def roofline_of(args, prec, kern, dt):
     return roof
 
 
-def f32_record(args, data, dev):
-    """The same step in the parity mode (1e-5 vs the reference per step): a few steps, own kernel table and roofline."""
+BWD_MODES = {1: "mode 1: recompute backward (no forward store)", 3: "mode 3: from the forward's store, last layer recomputed",
+             4: "mode 4: from the store, last hidden layer's weight gradient on chip", 5: "mode 5: from the forward's fp8-staged store, nothing recomputed"}
+
+
+def measure(args, prec, stage_fp8, data, dev, rank, world, use_pg, steps, warmup, sustained_steps=0):
+    """Warm-up, `steps` timed steps between barriers (max over ranks), then an eager pass that times the kernels with HIP
+    events, then (optionally) the sustained run.  `stage_fp8`: None = the planner's default, 0 / 1 = NCA_OPT_STAGE_FP8 for
+    this record.  Returns the record's fields (value, ms_per_step, dtype label, plan, roofline, ...)."""
     from nerfca_amd import _capi
-    tr = make_trainer(args, "f32", data, dev, 0, 1, False)
-    tr.step(75000)
-    torch.cuda.synchronize()
-    _capi.timing_reset()
-    _capi.timing_enable(True)
-    t0 = time.perf_counter()
-    for i in range(args.f32_steps):
-        tr.step(75001 + i)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    kern, _ = kernel_table(args, "f32", args.f32_steps)
-    _capi.timing_enable(False)
-    _capi.timing_reset()
-    return {"value": args.rays * args.f32_steps / dt, "unit": "rays/s", "steps": args.f32_steps, "warmup": 1, "ms_per_step": dt / args.f32_steps * 1e3,
-            "dtype": "f32", "parity": "1e-5 relative vs the reference's f32 path per step (tests/test_hip_parity.py)",
-            "roofline": roofline_of(args, "f32", kern, dt)}
+    from nerfca_amd import fused as fused_mod
+    old = _capi.get_option(_capi.OPT_STAGE_FP8)
+    if stage_fp8 is not None:
+        _capi.set_option(_capi.OPT_STAGE_FP8, stage_fp8)
+    try:
+        tr = make_trainer(args, prec, data, dev, rank, world, use_pg)
+
+        def barrier():
+            torch.cuda.synchronize()
+            if use_pg:
+                torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+        base_iter = 75000    # steady state: half of the frequency bands open
+        step = tr.step_graph if args.graph else tr.step
+        fallbacks0 = fused_mod.STORE_FALLBACKS
+        for i in range(warmup):
+            step(base_iter + i)
+        barrier()
+        _capi.timing_reset()
+        _capi.timing_enable(not args.graph)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            loss, _, _ = step(base_iter + warmup + i)
+        barrier()
+        dt = time.perf_counter() - t0
+        loss = float(loss)
+        plan = _capi.last_plan()            # of the last backward (graph: of the capture)
+        sustained = None
+        if sustained_steps >= 200 and args.graph:
+            for i in range(sustained_steps - 100):
+                step(base_iter + i)
+            barrier()
+            ts = time.perf_counter()
+            for i in range(100):
+                step(base_iter + i)
+            barrier()
+            sustained = {"ms_per_step": (time.perf_counter() - ts) * 10.0, "over": f"the last 100 of {sustained_steps} further graph-replayed steps (back to back after the timed region)",
+                         "rays_per_s": args.rays * world * 100 / (time.perf_counter() - ts),
+                         "in_kernel_clock": "profiles/r03_clock_probe.txt (tools/clock_probe.sh: the diagnostic build that stamps s_memtime / s_memrealtime; no stamp executes in this build)"}
+        timed_steps, eager_dt = steps, dt
+        eager_ms = None
+        if args.graph:       # events cannot be recorded inside a replayed graph: time the same kernels eagerly, outside dt
+            timed_steps = max(1, min(args.kernel_steps, steps))
+            tr.step(base_iter)          # (untimed: the eager step's first pass allocates its own store, and first-touch page mapping shows in the kernels)
+            tr.step(base_iter + 1)
+            barrier()
+            _capi.timing_reset()
+            _capi.timing_enable(True)
+            te = time.perf_counter()
+            for i in range(timed_steps):
+                tr.step(base_iter + i)
+            barrier()
+            eager_dt = time.perf_counter() - te
+            eager_ms = eager_dt / timed_steps * 1e3       # the same step with host-launched kernels and torch's Adam
+            plan = _capi.last_plan()
+        _capi.timing_enable(False)
+        if use_pg:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+            dt = float(tmax.item())
+        kern = kernel_table(args, timed_steps, plan)
+        _capi.timing_reset()
+        fp8 = bool(plan.get("stage_fp8"))
+        label = "f32" if prec == "f32" else ("bf16+fp8stage" if fp8 else "bf16")
+        rec = {"value": args.rays * world * steps / dt, "unit": "rays/s", "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "dtype": label,
+               "arithmetic": {"f32": "f32 (hidden layers on the bf16 matrix cores from exact 3-way splits): 1e-5 relative vs the reference's f32 path per step (tests/test_hip_parity.py)",
+                              "bf16": "bf16 MFMA operands, f32 accumulation, f32 master weights; layer inputs and output gradients staged as bf16; PSNR-gated (tests/test_psnr_gates.py)",
+                              "bf16+fp8stage": "bf16 MFMA operands for the MLP contractions (forward and dgrad), f32 accumulation, f32 master weights; the layer inputs (e4m3) and output "
+                                               "gradients (e5m2, per-tile power-of-two scale) cross HBM in 8 bits and the weight gradient contracts them on the MX-fp8 matrix path; PSNR-gated "
+                                               "(tests/test_psnr_gates.py)"}[label],
+               "hip_graph": bool(args.graph), "eager_ms_per_step": eager_ms, "kernel_table_steps": timed_steps, "final_loss": loss,
+               "plan": {"stage_fp8": fp8, "backward": BWD_MODES.get(plan.get("bwd_kernel_mode"), str(plan.get("bwd_kernel_mode"))),
+                        "resident_weight_images": {"fwd": bool(plan.get("fwd_resident")), "bwd": bool(plan.get("bwd_resident"))},
+                        "onchip_last_layer_wgrad": bool(plan.get("bwd_onchip")), "ray_chunks": plan.get("chunks"),
+                        "wgrad": {"jobs": plan.get("wgrad_jobs"), "splits": plan.get("wgrad_splits"), "splits_rebuild_jobs": plan.get("wgrad_splits_rebuild")},
+                        "launches_per_step": {k: (kern[k]["launches"] // max(timed_steps, 1)) for k in ("fwd", "bwd_dgrad", "bwd_wgrad")}},
+               "roofline": roofline_of(args, prec, kern, eager_dt, plan),
+               "store_fallbacks": fused_mod.STORE_FALLBACKS - fallbacks0}       # > 0: some backward ran on the recompute path (store did not fit)
+        if sustained:
+            rec["sustained"] = sustained
+        del tr
+        torch.cuda.empty_cache()
+        return rec
+    finally:
+        _capi.set_option(_capi.OPT_STAGE_FP8, old)
 
 
 def psnr_record(args, dev):
@@ -360,6 +465,13 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}: start one rank per GPU (or run `python bench.py --gpus N`, which does)")
+    if not (0 <= rank < world and 0 <= local < world):
+        raise SystemExit(f"RANK={rank} / LOCAL_RANK={local} outside a world of {world}")
+    if args.dry_run:       # nothing below this line has run: no HIP call, no process group
+        print(json.dumps({"rank": rank, "world": world, "local_rank": local, "device": f"cuda:{local}", "backend": "nccl" if world > 1 else None,
+                          "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}", "rays_per_rank": args.rays,
+                          "global_rays_per_step": args.rays * world}), flush=True)
+        return
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_pg = world > 1 or os.environ.get("NERFCA_FORCE_PG") == "1"   # the env switch lets a 1-GPU box exercise RCCL
@@ -368,79 +480,46 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
         rccl_ranks = dist.get_world_size()
+        if rccl_ranks != world or dist.get_rank() != rank:
+            raise SystemExit(f"process group reports rank {dist.get_rank()} of {rccl_ranks}, the environment said {rank} of {world}")
 
     from nerfca_amd import _capi, synthetic
-    from nerfca_amd import fused as fused_mod
     _capi.lib()   # fail loudly if the HIP library is missing
 
     views = synthetic.TRAIN_VIEWS if args.views == 4 else synthetic.TRAIN_VIEWS_8[: args.views]
     data = synthetic.make_dataset(args.det, args.samples, dev, views=views)
-    tr = make_trainer(args, args.prec, data, dev, rank, world, use_pg)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if use_pg:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    base_iter = 75000    # steady state: half of the frequency bands open
-    step = tr.step_graph if args.graph else tr.step
-    for i in range(args.warmup):
-        step(base_iter + i)
-    barrier()
-    _capi.timing_reset()
-    _capi.timing_enable(not args.graph)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss, _, _ = step(base_iter + args.warmup + i)
-    barrier()
-    dt = time.perf_counter() - t0
-    loss = float(loss)
-    timed_steps = args.steps
-    eager_ms = None
-    if args.graph:       # events cannot be recorded inside a replayed graph: time the same kernels eagerly, outside dt
-        timed_steps = min(args.steps, 4)
-        tr.step(base_iter)          # (untimed: the eager step's first pass allocates its own store, and first-touch page mapping shows in the kernels)
-        barrier()
-        _capi.timing_reset()
-        _capi.timing_enable(True)
-        te = time.perf_counter()
-        for i in range(timed_steps):
-            tr.step(base_iter + i)
-        barrier()
-        eager_ms = (time.perf_counter() - te) / timed_steps * 1e3       # the same step with host-launched kernels and torch's Adam
-    _capi.timing_enable(False)
-    if use_pg:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tmax.item())
+    main_rec = measure(args, args.prec, None, data, dev, rank, world, use_pg, args.steps, args.warmup,
+                       sustained_steps=args.sustained_steps if (world == 1 and not args.no_extras) else 0)
 
     if rank == 0:
-        kern, onchip = kernel_table(args, args.prec, timed_steps)
-        roof = roofline_of(args, args.prec, kern, dt)
-        out = {"metric": f"training rays/sec ({args.det}^2 det, {args.samples} samples/ray)", "value": args.rays * world * args.steps / dt, "unit": "rays/s",
-               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.prec, "data": "synthetic",
+        out = {"metric": f"training rays/sec ({args.det}^2 det, {args.samples} samples/ray)", "value": main_rec["value"], "unit": "rays/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_rec["ms_per_step"],
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": main_rec["dtype"], "data": "synthetic",
                "config": {"workload": f"run_composite XCAT {args.views}-view x 10 phases, {args.det}^2 detector x {args.samples} samples/ray, "
                                       f"{args.rays} rays/step/GPU (one full detector), F=128 x 4 hidden layers x 2 nets, L=12, fwd+losses+bwd+Adam",
                           "rays_per_step_per_gpu": args.rays, "samples_per_ray": args.samples, "parallelism": f"ray-sharded dp{world}", "hip_graph": bool(args.graph),
-                          "stage_fp8": bool(args.prec == "bf16" and _capi.get_option(_capi.OPT_STAGE_FP8) != 0),
-                          "backward": ("mode 5: from the forward's fp8-staged store, nothing recomputed" if args.prec == "bf16" and _capi.get_option(_capi.OPT_STAGE_FP8) != 0
-                                       else ("mode 4: from the store, last hidden layer's wgrad on chip" if onchip else "from the store / recompute")),
-                          "launches_per_step": {k: (kern[k]["launches"] // max(timed_steps, 1)) for k in ("fwd", "bwd_dgrad", "bwd_wgrad")},
-                          "onchip_last_layer_wgrad": bool(onchip)},
-               "rccl_ranks": rccl_ranks, "roofline": roof, "final_loss": float(loss), "eager_ms_per_step": eager_ms,
-               "store_fallbacks": fused_mod.STORE_FALLBACKS}       # > 0: some backward ran on the recompute path (store did not fit)
-        del tr
-        torch.cuda.empty_cache()
+                          "arithmetic": main_rec["arithmetic"], "stage_fp8": main_rec["plan"]["stage_fp8"], "backward": main_rec["plan"]["backward"],
+                          "launches_per_step": main_rec["plan"]["launches_per_step"], "onchip_last_layer_wgrad": main_rec["plan"]["onchip_last_layer_wgrad"],
+                          "plan": main_rec["plan"], "library": _capi.build_info()},
+               "rccl_ranks": rccl_ranks, "roofline": main_rec["roofline"], "final_loss": main_rec["final_loss"], "eager_ms_per_step": main_rec["eager_ms_per_step"],
+               "kernel_table_steps": main_rec["kernel_table_steps"], "store_fallbacks": main_rec["store_fallbacks"]}
+        if "sustained" in main_rec:
+            out["sustained"] = main_rec["sustained"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, data)
         if world == 1 and not args.no_extras:
             if args.unfused_gpu_rays > 0:
                 out["unfused_gpu_baseline"] = unfused_gpu_baseline(args, data)
                 out["vs_unfused_gpu"] = out["value"] / out["unfused_gpu_baseline"]["value"]
+            # the other precisions side by side, each through the same (graph-replayed) step
+            if args.prec == "bf16" and args.pure_steps > 0 and main_rec["plan"]["stage_fp8"]:
+                out["bf16_pure"] = measure(args, "bf16", 0, data, dev, 0, 1, False, args.pure_steps, args.warmup)
+                out["bf16_pure"]["note"] = "BASELINE configs[1] as written: bf16 everywhere, nothing staged in 8 bits (NCA_OPT_STAGE_FP8 = 0)"
             if args.prec != "f32" and args.f32_steps > 0:
-                out["f32"] = f32_record(args, data, dev)
+                out["f32"] = measure(args, "f32", None, data, dev, 0, 1, False, args.f32_steps, args.f32_warmup)
+            out["precisions"] = {k: {"rays_per_s": r["value"], "ms_per_step": r["ms_per_step"], "steps": r["steps"], "roofline_frac": r["roofline"]["frac"],
+                                     "roofline_kernel": r["roofline"]["kernel"]}
+                                 for k, r in (("f32", out.get("f32")), ("bf16", out.get("bf16_pure")), (main_rec["dtype"], main_rec)) if r}
             if args.psnr_steps > 0:
                 out["psnr"] = psnr_record(args, dev)
         print(json.dumps(out))

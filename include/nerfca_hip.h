@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NCA_ABI_VERSION 7
+#define NCA_ABI_VERSION 8
 
 enum {
     NCA_OK = 0,
@@ -88,8 +88,21 @@ typedef struct NcaRays {
     int32_t act;            /* NCA_ACT_*                                                     */
     int32_t single_field;   /* 0: composite (sigma scaled);  1: render_volume_density (one net, sigma un-scaled) */
     float scale;            /* scale_value, 1e-2                                             */
-    int32_t reserved;
+    int32_t store_format;   /* backward from a forward store: the value nca_render_fwd returned when it wrote that store
+                               (NCA_STORE_*); ignored by the forward and by a backward without a store */
 } NcaRays;
+
+/* What a storing forward left in its store (the return value of nca_render_fwd; 0 = it wrote no store).  The backward is told
+ * through NcaRays.store_format and lays the store out from THAT, not from the process-wide options, which may have changed in
+ * between; a value that does not fit the nets of the call is NCA_E_INVALID. */
+enum {
+    NCA_STORE_NONE = 0,
+    NCA_STORE_F32 = 1,        /* f32 mode: every layer input, ReLU masks, raw outputs                         */
+    NCA_STORE_BF16 = 2,       /* bf16 mode, bf16 staging: layer inputs as bf16, masks of the hidden layers    */
+    NCA_STORE_FP8 = 3,        /* bf16 mode, fp8 staging: layer inputs as e4m3, masks of all layers, raw outputs */
+    NCA_STORE_KIND_MASK = 15,
+    NCA_STORE_SHARED_ENC = 16 /* flag: both nets share one stored input block (same encoding vectors)          */
+};
 
 int nca_abi_version(void);
 const char* nca_last_error(void);
@@ -116,7 +129,9 @@ int nca_pack_weights(const NcaNet* net, const float* params, void* packed, int32
  *         raw outputs; bf16: the layer inputs as e4m3 (NCA_OPT_STAGE_FP8, default) or bf16, the ReLU masks and (fp8 staging)
  *         the raw outputs -- and nca_render_bwd given the same buffer does not recompute the layers.
  *         nca_render_store_bytes() returns 0 where this is not available (nets of different width, nets without a hidden
- *         layer): pass NULL there. */
+ *         layer): pass NULL there.
+ * Returns a negative error code, or >= 0: the format of the store it wrote (NCA_STORE_*, 0 = none) -- hand it to the backward
+ * in NcaRays.store_format. */
 int64_t nca_render_fwd_workspace(const NcaRays* rays);
 int64_t nca_render_store_bytes(const NcaRays* rays, const NcaNet* net_s, const NcaNet* net_d, int32_t prec);
 int nca_render_fwd(const NcaRays* rays, int32_t prec,
@@ -126,7 +141,8 @@ int nca_render_fwd(const NcaRays* rays, int32_t prec,
                    double* pix, float* sig_s, float* sig_d, void* work, int64_t work_bytes,
                    void* store, int64_t store_bytes, void* stream);
 
-/* Backward: with recompute (store == NULL), or from the store the forward of the SAME rays, weights and windows left.
+/* Backward: with recompute (store == NULL), or from the store the forward of the SAME rays, weights and windows left
+ * (rays->store_format = that forward's return value).
  * Upstream gradients g_pix f64[R], g_sig_s/g_sig_d f32[R,S] (NULL = 0).
  * Writes (overwrites) grads_s / grads_d, flat f32 in the natural parameter order.
  * `params_*` are the natural flat parameters (needed for the latent gradient). */
@@ -240,28 +256,54 @@ int nca_adam_step(const NcaAdam* cfg, int32_t n_seg, const int64_t* n, float* co
                   float* const* exp_avg, float* const* exp_avg_sq, int64_t* step, void* stream);
 
 /* ---- process-wide tunables: A/B switches of the planner, also the hook with which tests force a kernel path at sizes the
- *      oracle can afford.  nca_set_option returns NCA_OK or NCA_E_INVALID; values persist until changed. ------------------- */
+ *      oracle can afford.  Both calls return NCA_OK or NCA_E_INVALID; values persist until changed.  A planner decision that
+ *      shapes a forward store is taken ONCE, by the forward, and travels to the backward in NcaRays.store_format. -------------- */
 enum {
-    NCA_OPT_ONCHIP_MIN_TILES = 0, /* bf16 backward from a forward store with BF16 staging (NCA_OPT_STAGE_FP8 = 0; fp8 staging recomputes
-                                     nothing and has no use for it): keep the last hidden layer's weight gradient on chip (one launch
-                                     per net) when the batch has at least this many 64-sample wave tiles.  0 = always, -1 = never;
-                                     default 8 * 8 waves * CUs (initial value from the environment: NCA_ONCHIP=0 -> never, =force -> always) */
+    NCA_OPT_ONCHIP_MIN_TILES = 0, /* bf16 backward from a forward store with BF16 staging (fp8 staging recomputes nothing and has no use
+                                     for it): keep the last hidden layer's weight gradient on chip (one launch per net) when the batch
+                                     has at least this many 64-sample wave tiles.  0 = always, -1 = never; default 8 * 8 waves * CUs
+                                     (initial value from the environment: NCA_ONCHIP=0 -> never, =force -> always) */
     NCA_OPT_STAGE_FP8 = 1,        /* bf16 mode with a forward store: the layer inputs and output gradients that only the weight-gradient
                                      kernel reads cross HBM as 8-bit floats (inputs e4m3, gradients e5m2 scaled by a power of two per
                                      64-sample tile; f32 accumulation; the MLP contractions themselves stay bf16), the store also holds the
-                                     raw outputs and the masks of every layer, and the backward recomputes nothing.  1 = on (default),
-                                     0 = bf16 staging (the backward recomputes the last layer).  Read when a forward writes its store and when a backward reads one: do not
-                                     change it between a forward and its backward.  Initial value from NCA_STAGE_FP8 (0 / 1) */
+                                     raw outputs and the masks of every layer, and the backward recomputes nothing.
+                                     1 = always, 0 = never (bf16 staging: the backward recomputes the last layer), -1 = auto (default):
+                                     fp8 staging when the batch has at least NCA_OPT_STAGE_FP8_MIN_TILES wave tiles -- the 8-bit
+                                     rounding noise of a step averages over the samples of the batch, and the PSNR gates of tests/
+                                     hold from that size on.  Initial value from NCA_STAGE_FP8 (0 / 1) */
     NCA_OPT_RESIDENT_MIN_TILES = 2, /* bf16 mode: run the fused kernels with ONE net per launch and all of that net's weight images
                                      resident in LDS (no per-layer weight DMA, no workgroup barrier in the tile loop) when the images fit
                                      (width 128: the input layer + 4 hidden layers forward, 4 transposed images backward) and the batch has at least this many 64-sample wave
                                      tiles.  A two-net render then takes two forward launches (the second composites with the first
                                      one's sigma).  0 = always, -1 = never; default 8 * 8 waves * CUs (NCA_RESIDENT=0 -> never,
                                      =force -> always).  Results are bit-identical to the streaming kernels */
+    NCA_OPT_STAGE_FP8_MIN_TILES = 3, /* threshold of NCA_OPT_STAGE_FP8 = auto, in 64-sample wave tiles of the whole batch (>= 0) */
     NCA_OPT_COUNT
 };
-int64_t nca_get_option(int32_t opt);
+int nca_get_option(int32_t opt, int64_t* value);
 int nca_set_option(int32_t opt, int64_t value);
+
+/* What the planner decided in the process's last nca_render_fwd and last nca_render_bwd[_depth] / nca_mlp_bwd (bench.py labels
+ * its line with it; tests assert the path they mean to exercise).  Process-wide, not per thread: a PyTorch backward runs on the
+ * autograd engine's thread. */
+typedef struct NcaPlan {
+    int32_t fwd_store_format;     /* NCA_STORE_* | flags of the last forward (0: no store)                              */
+    int32_t fwd_launches;         /* fused launches of that forward (2: one per net, weight images resident in LDS)     */
+    int32_t fwd_resident;         /* 1: resident weight images                                                          */
+    int32_t bwd_kernel_mode;      /* 1 recompute, 3 from a bf16 / f32 store, 4 = 3 + on-chip last layer, 5 from an fp8 store (nothing recomputed) */
+    int32_t bwd_resident;
+    int32_t bwd_launches_per_chunk; /* fused dgrad launches per ray chunk                                              */
+    int32_t bwd_onchip;           /* last hidden layer's weight gradient accumulated in the dgrad kernel                */
+    int32_t stage_fp8;            /* that backward staged 8-bit blocks                                                  */
+    int32_t wgrad_jobs, wgrad_splits, wgrad_splits_rebuild;
+    int32_t chunks;               /* ray chunks of that backward                                                        */
+    int64_t wave_tiles;           /* wave tiles of the whole batch of the last call                                     */
+    int64_t reserved[4];
+} NcaPlan;
+int nca_last_plan(NcaPlan* out);
+/* Static description of the build: target, ABI, and the timing-experiment mask the kernels were compiled with ("NCA_EXP=0" in
+ * every shipped library; tools/elim_build.sh makes the others, whose results are wrong by construction). */
+const char* nca_build_info(void);
 
 /* ---- in-library kernel timing (HIP events on the launch stream), used by bench.py -------- */
 enum { NCA_K_PACK = 0, NCA_K_FWD = 1, NCA_K_BWD_DGRAD = 2, NCA_K_BWD_WGRAD = 3, NCA_K_BWD_REDUCE = 4, NCA_K_LOSS = 5, NCA_K_ADAM = 6, NCA_K_COUNT = 7 };

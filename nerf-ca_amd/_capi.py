@@ -15,10 +15,12 @@ LIB_PATH = os.environ.get("NERFCA_LIB") or os.path.join(_HERE, "lib", "libnerfca
 ENC_NONE, ENC_BANDS, ENC_FOURIER = 0, 1, 2
 ACT_SIGMOID, ACT_SOFTPLUS, ACT_CLAMP = 0, 1, 2
 PREC_F32, PREC_BF16 = 0, 1
-ABI_VERSION = 7
+ABI_VERSION = 8
 OPT_ONCHIP_MIN_TILES = 0
 OPT_STAGE_FP8 = 1
 OPT_RESIDENT_MIN_TILES = 2
+OPT_STAGE_FP8_MIN_TILES = 3
+STORE_NONE, STORE_F32, STORE_BF16, STORE_FP8, STORE_KIND_MASK, STORE_SHARED_ENC = 0, 1, 2, 3, 15, 16
 K_PACK, K_FWD, K_BWD_DGRAD, K_BWD_WGRAD, K_BWD_REDUCE, K_LOSS, K_ADAM = 0, 1, 2, 3, 4, 5, 6
 KERNEL_KINDS = {"pack": K_PACK, "fwd": K_FWD, "bwd_dgrad": K_BWD_DGRAD, "bwd_wgrad": K_BWD_WGRAD, "bwd_reduce": K_BWD_REDUCE,
                 "loss": K_LOSS, "adam": K_ADAM}
@@ -37,7 +39,7 @@ class NcaRays(C.Structure):
                 ("phase", C.c_void_p), ("phase_stride_r", C.c_int64), ("phase_stride_s", C.c_int64),
                 ("z", C.c_void_p), ("z_stride_r", C.c_int64),
                 ("dists", C.c_void_p), ("I0", C.c_void_p),
-                ("act", C.c_int32), ("single_field", C.c_int32), ("scale", C.c_float), ("reserved", C.c_int32)]
+                ("act", C.c_int32), ("single_field", C.c_int32), ("scale", C.c_float), ("store_format", C.c_int32)]
 
 
 class NcaLoss(C.Structure):
@@ -49,6 +51,12 @@ class NcaLoss(C.Structure):
 class NcaAdam(C.Structure):
     _fields_ = [("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
                 ("lr_end_factor", C.c_double), ("lr_total_iters", C.c_int64)]
+
+
+class NcaPlan(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("fwd_store_format", "fwd_launches", "fwd_resident", "bwd_kernel_mode", "bwd_resident", "bwd_launches_per_chunk",
+                                         "bwd_onchip", "stage_fp8", "wgrad_jobs", "wgrad_splits", "wgrad_splits_rebuild", "chunks")] + \
+               [("wave_tiles", C.c_int64), ("reserved", C.c_int64 * 4)]
 
 
 class NcaError(RuntimeError):
@@ -89,7 +97,9 @@ SYMBOLS = {
     "nca_fine_depths_given_max": (C.c_int, [_I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _P]),
     "nca_adam_step": (C.c_int, [C.POINTER(NcaAdam), _I32, C.POINTER(_I64), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P),
                                 _P, _P]),
-    "nca_get_option": (_I64, [_I32]),
+    "nca_get_option": (C.c_int, [_I32, C.POINTER(_I64)]),
+    "nca_last_plan": (C.c_int, [C.POINTER(NcaPlan)]),
+    "nca_build_info": (C.c_char_p, []),
     "nca_set_option": (C.c_int, [_I32, _I64]),
     "nca_timing_enable": (C.c_int, [_I32]),
     "nca_timing_read": (C.c_int, [_I32, C.POINTER(C.c_double), C.POINTER(_I64)]),
@@ -142,8 +152,21 @@ def timing_read(kind: str):
 
 
 def get_option(opt: int) -> int:
-    return int(lib().nca_get_option(opt))       # (a value may be negative: -1 = never)
+    v = C.c_int64(0)
+    check(lib().nca_get_option(opt, C.byref(v)))
+    return int(v.value)                         # (a value may be negative: -1 = never / auto)
 
 
 def set_option(opt: int, value: int) -> None:
     check(lib().nca_set_option(opt, int(value)))
+
+
+def last_plan() -> dict:
+    """What the planner decided in this thread's last nca_render_fwd / nca_render_bwd (see NcaPlan in include/nerfca_hip.h)."""
+    p = NcaPlan()
+    check(lib().nca_last_plan(C.byref(p)))
+    return {n: int(getattr(p, n)) for n, _ in NcaPlan._fields_ if n != "reserved"}
+
+
+def build_info() -> str:
+    return lib().nca_build_info().decode()

@@ -131,6 +131,8 @@ void opt_init_locked() {
     if (e && (e[0] == '0' || e[0] == '1')) g_opt[NCA_OPT_STAGE_FP8] = e[0] - '0';
     g_opt_init = true;
 }
+// default of NCA_OPT_STAGE_FP8_MIN_TILES: see stage_fp8_for()
+constexpr int64_t STAGE_FP8_DEFAULT_MIN_TILES = 0;
 int64_t opt_value(int opt) {
     std::lock_guard<std::mutex> lk(g_omu);
     opt_init_locked();
@@ -139,27 +141,64 @@ int64_t opt_value(int opt) {
         // on-chip dW pays only when every workgroup sees enough tiles to amortise the per-net launches and the exchange: at the
         // reference's default batch of 1024 rays x 500 samples -- 4 tile groups per workgroup -- it costs 3.6 %
         if (opt == NCA_OPT_ONCHIP_MIN_TILES) v = (int64_t)8 * NCA_WAVES * num_cus();
-        if (opt == NCA_OPT_STAGE_FP8) v = 1;
+        if (opt == NCA_OPT_STAGE_FP8) v = -1;                                            // auto: by batch size
+        if (opt == NCA_OPT_STAGE_FP8_MIN_TILES) v = STAGE_FP8_DEFAULT_MIN_TILES;
         if (opt == NCA_OPT_RESIDENT_MIN_TILES) v = (int64_t)8 * NCA_WAVES * num_cus();    // (at 4 tiles per wave -- the reference's 1 024 x 500 batch -- resident and streaming tie)
     }
     return v;
 }
 }  // namespace
-extern "C" int64_t nca_get_option(int32_t opt) {
+// fp8 staging for a batch of this many wave tiles?  (decided by the storing forward; the backward follows the store's format)
+static bool stage_fp8_for(int64_t wave_tiles) {
+    const int64_t v = opt_value(NCA_OPT_STAGE_FP8);
+    if (v >= 0) return v != 0;
+    return wave_tiles >= opt_value(NCA_OPT_STAGE_FP8_MIN_TILES);
+}
+extern "C" int nca_get_option(int32_t opt, int64_t* value) {
     if (opt < 0 || opt >= NCA_OPT_COUNT) return fail(NCA_E_INVALID, "option %d out of range", opt);
-    return opt_value(opt);
+    if (!value) return fail(NCA_E_INVALID, "value is NULL");
+    *value = opt_value(opt);
+    return NCA_OK;
 }
 extern "C" int nca_set_option(int32_t opt, int64_t value) {
     if (opt < 0 || opt >= NCA_OPT_COUNT) return fail(NCA_E_INVALID, "option %d out of range", opt);
     if (opt == NCA_OPT_ONCHIP_MIN_TILES && value < -1) return fail(NCA_E_INVALID, "NCA_OPT_ONCHIP_MIN_TILES takes -1 (never), 0 (always) or a tile count");
     if (opt == NCA_OPT_RESIDENT_MIN_TILES && value < -1) return fail(NCA_E_INVALID, "NCA_OPT_RESIDENT_MIN_TILES takes -1 (never), 0 (always) or a tile count");
-    if (opt == NCA_OPT_STAGE_FP8 && value != 0 && value != 1) return fail(NCA_E_INVALID, "NCA_OPT_STAGE_FP8 takes 0 or 1");
+    if (opt == NCA_OPT_STAGE_FP8 && value != 0 && value != 1 && value != -1) return fail(NCA_E_INVALID, "NCA_OPT_STAGE_FP8 takes 0 (never), 1 (always) or -1 (auto)");
+    if (opt == NCA_OPT_STAGE_FP8_MIN_TILES && value < 0) return fail(NCA_E_INVALID, "NCA_OPT_STAGE_FP8_MIN_TILES takes a tile count >= 0");
     std::lock_guard<std::mutex> lk(g_omu);
     opt_init_locked();
     g_opt[opt] = value;
     return NCA_OK;
 }
 extern "C" const char* nca_last_error(void) { return g_err; }
+
+// Process-wide (a PyTorch backward runs on the autograd engine's thread, not on the thread that asks): the forward half is
+// replaced by every nca_render_fwd, the backward half by every backward; each call fills a local copy and publishes it whole.
+static NcaPlan g_plan_shared;
+static std::mutex g_pmu;
+static void publish_plan(const NcaPlan& pl, bool fwd) {
+    std::lock_guard<std::mutex> lk(g_pmu);
+    if (fwd) {
+        g_plan_shared.fwd_store_format = pl.fwd_store_format; g_plan_shared.fwd_launches = pl.fwd_launches; g_plan_shared.fwd_resident = pl.fwd_resident;
+    } else {
+        const NcaPlan keep = g_plan_shared;
+        g_plan_shared = pl;
+        g_plan_shared.fwd_store_format = keep.fwd_store_format; g_plan_shared.fwd_launches = keep.fwd_launches; g_plan_shared.fwd_resident = keep.fwd_resident;
+    }
+    g_plan_shared.wave_tiles = pl.wave_tiles;
+}
+extern "C" int nca_last_plan(NcaPlan* out) {
+    if (!out) return fail(NCA_E_INVALID, "out is NULL");
+    std::lock_guard<std::mutex> lk(g_pmu);
+    *out = g_plan_shared;
+    return NCA_OK;
+}
+extern "C" const char* nca_build_info(void) {
+    static char info[128];
+    snprintf(info, sizeof(info), "libnerfca_hip gfx950 abi=%d NCA_EXP=%d", NCA_ABI_VERSION, nca_kernels_exp_mask());
+    return info;
+}
 
 static int check_prec(int32_t prec) {
     if (prec != NCA_PREC_F32 && prec != NCA_PREC_BF16) return fail(NCA_E_UNSUPPORTED, "unknown precision %d", prec);
@@ -420,6 +459,8 @@ extern "C" int nca_render_fwd(const NcaRays* rays, int32_t prec,
 
     static thread_local NcaFusedArgs a;
     memset(&a, 0, sizeof(a));
+    NcaPlan g_plan;
+    memset(&g_plan, 0, sizeof(g_plan));
     rays_to_args(rays, &a, prec);
     a.nnets = rays->single_field ? 1 : 2;
     NetBind binds[2] = {{net_s, packed_s, win_s, four_s, nullptr}, {net_d, packed_d, win_d, four_d, latents_d}};
@@ -432,11 +473,14 @@ extern "C" int nca_render_fwd(const NcaRays* rays, int32_t prec,
         if (a.net[n].lay.T > 0 && !rays->phase) return fail(NCA_E_INVALID, "dynamic net needs phase ids");
     a.ntiles = rays->R * a.nchunk;
     a.ray0 = 0;
+    g_plan.wave_tiles = a.ntiles;
     const int64_t ngroups = (a.ntiles + NCA_WAVES - 1) / NCA_WAVES;
     const int grid = (int)(ngroups < num_cus() ? ngroups : num_cus());
     hipStream_t st = (hipStream_t)stream;
     if (a.nnets == 2 && a.net[0].lay.F != a.net[1].lay.F) {
         if (store) return fail(NCA_E_UNSUPPORTED, "a forward store needs nets of one width");
+        g_plan.fwd_launches = 2;
+        publish_plan(g_plan, true);
         // nets of different width: one fused launch per net writes the raw field into its sigma buffer,
         // then the stand-alone compositing kernel turns both into sigmas + pix in place
         float* outs[2] = {sig_s, sig_d};
@@ -463,11 +507,13 @@ extern "C" int nca_render_fwd(const NcaRays* rays, int32_t prec,
     a.sig_s = sig_s;
     a.sig_d = sig_d;
     int kmode = NCA_KM_FWD;
+    int store_format = NCA_STORE_NONE;
     if (store) {
         NcaLayout lays[2] = {a.net[0].lay, a.net[1].lay};
         StorePlan spl;
         a.share_enc = can_share_enc(a, prec) ? 1 : 0;
-        a.h8 = (prec == NCA_PREC_BF16 && opt_value(NCA_OPT_STAGE_FP8) != 0) ? 1 : 0;
+        a.h8 = (prec == NCA_PREC_BF16 && stage_fp8_for(a.ntiles)) ? 1 : 0;
+        store_format = (prec == NCA_PREC_BF16 ? (a.h8 ? NCA_STORE_FP8 : NCA_STORE_BF16) : NCA_STORE_F32) | (a.share_enc ? NCA_STORE_SHARED_ENC : 0);
         if (!store_plan(lays, a.nnets, prec, a.ntiles, &spl, a.share_enc != 0, a.h8 != 0))
             return fail(NCA_E_UNSUPPORTED, "a forward store needs nets of one width with at least one hidden layer");
         if (store_bytes < spl.bytes) return fail(NCA_E_WORKSPACE, "forward store %lld < %lld bytes", (long long)store_bytes, (long long)spl.bytes);
@@ -503,17 +549,22 @@ extern "C" int nca_render_fwd(const NcaRays* rays, int32_t prec,
                 HIPCHK(nca_launch_fused_bf16(one[n].net[0].lay.F, one[n], kmode, grid, st, a.h8 != 0));
             }
             done = true;
+            g_plan.fwd_launches = 2;
+            g_plan.fwd_resident = 1;
         }
     } else if (prec == NCA_PREC_BF16) {
-        plan_resident(&a, kmode);
+        g_plan.fwd_resident = plan_resident(&a, kmode) ? 1 : 0;
     }
     if (!done) {
         Span sp(NCA_K_FWD, st);
         if (prec == NCA_PREC_BF16) HIPCHK(nca_launch_fused_bf16(a.net[0].lay.F, a, kmode, grid, st, a.h8 != 0));
         else HIPCHK(nca_launch_fused_f32(a.net[0].lay.F, a, kmode, grid, st));
+        g_plan.fwd_launches = 1;
     }
     HIPCHK(nca_launch_pix_f32(rays->R, a.nchunk, rays->I0, a.part, pix, st));
-    return NCA_OK;
+    g_plan.fwd_store_format = store_format;
+    publish_plan(g_plan, true);
+    return store_format;
 }
 
 // ---------------------------------------------------------------------------------- backward
@@ -696,8 +747,12 @@ static void add_jobs_bf16(NcaWgradArgs* w, int net_index, const NcaLayout& y, in
 }
 
 static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t units, int64_t tiles_per_unit, float* const* grads,
-                   void* work, int64_t work_bytes, hipStream_t st, const void* store = nullptr, int64_t store_bytes = 0, float* g_depth = nullptr) {
+                   void* work, int64_t work_bytes, hipStream_t st, const void* store = nullptr, int64_t store_bytes = 0, float* g_depth = nullptr,
+                   int32_t store_format = NCA_STORE_NONE) {
     const bool bf = prec == NCA_PREC_BF16;
+    NcaPlan g_plan;       // (published at the end; what the last forward decided stays on record)
+    memset(&g_plan, 0, sizeof(g_plan));
+    g_plan.wave_tiles = units * tiles_per_unit;
     NcaLayout lays[2];
     for (int n = 0; n < a.nnets; ++n) lays[n] = a.net[n].lay;
     if (g_depth) {
@@ -711,11 +766,22 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     const bool stored = store != nullptr;
     // fp8 staging: the store's hidden blocks (as the storing forward left them) and this backward's output gradients -- except
     // when the depth gradient is wanted, whose kernel reads D_0 as bf16 fragments
-    const bool h8 = bf && stored && opt_value(NCA_OPT_STAGE_FP8) != 0;
+    // The store's format is what the forward that wrote it reported (NcaRays.store_format), never this call's reading of the options
+    if (stored) {
+        const int kind = store_format & NCA_STORE_KIND_MASK;
+        const int want_a = bf ? NCA_STORE_BF16 : NCA_STORE_F32, want_b = bf ? NCA_STORE_FP8 : NCA_STORE_F32;
+        if ((store_format & ~(NCA_STORE_KIND_MASK | NCA_STORE_SHARED_ENC)) || (kind != want_a && kind != want_b))
+            return fail(NCA_E_INVALID, "rays->store_format = %d does not name a store of this precision: pass the value nca_render_fwd returned when it wrote the store", store_format);
+        const bool shared = (store_format & NCA_STORE_SHARED_ENC) != 0;
+        if (shared != can_share_enc(a, prec))
+            return fail(NCA_E_INVALID, "the store was written with %s input block, but the encoding vectors of this call say otherwise: pass the backward the SAME window / coefficient pointers as the forward",
+                        shared ? "one shared" : "one per net");
+    }
+    const bool h8 = bf && stored && (store_format & NCA_STORE_KIND_MASK) == NCA_STORE_FP8;
     const bool d8 = h8 && !g_depth;
     a.h8 = h8 ? 1 : 0;
     if (stored) {
-        a.share_enc = can_share_enc(a, prec) ? 1 : 0;        // the same decision the storing forward took (same nets, same vectors)
+        a.share_enc = (store_format & NCA_STORE_SHARED_ENC) ? 1 : 0;
         if (!store_plan(lays, a.nnets, prec, units * tiles_per_unit, &spl, a.share_enc != 0, h8)) return fail(NCA_E_UNSUPPORTED, "no forward store exists for this configuration");
         if (store_bytes < spl.bytes) return fail(NCA_E_WORKSPACE, "forward store %lld < %lld bytes", (long long)store_bytes, (long long)spl.bytes);
     }
@@ -821,6 +887,13 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     const int F = lays[0].F;
     const int wave_samples = tile_samples(prec);
 
+    g_plan.bwd_kernel_mode = stored ? (nr ? NCA_KM_BWD_NR : (onchip ? NCA_KM_BWD_ONCHIP : NCA_KM_BWD_STORED)) : NCA_KM_BWD;
+    g_plan.bwd_onchip = onchip ? 1 : 0;
+    g_plan.stage_fp8 = h8 ? 1 : 0;
+    g_plan.bwd_launches_per_chunk = (bf && stored && per_net_launch) ? a.nnets : 1;
+    g_plan.wgrad_jobs = w.njobs;
+    g_plan.wgrad_splits = p.n_split;
+    g_plan.wgrad_splits_rebuild = p.n_split_x;
     int chunk = 0;
     for (int64_t u0 = 0; u0 < units; u0 += p.units_per_chunk, ++chunk) {
         const int64_t nu = (u0 + p.units_per_chunk <= units) ? p.units_per_chunk : units - u0;
@@ -844,7 +917,7 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
                 const int km = nr ? NCA_KM_BWD_NR : (onchip ? NCA_KM_BWD_ONCHIP : NCA_KM_BWD_STORED);
                 rc = build_stages(&one, b1, true, nr ? 1 : 2);
                 if (rc) return rc;
-                if (res3) plan_resident(&one, km);        // (does not fit: the streaming kernel, still one net per launch)
+                if (res3) g_plan.bwd_resident = plan_resident(&one, km) ? 1 : 0;        // (does not fit: the streaming kernel, still one net per launch)
                 Span sp(NCA_K_BWD_DGRAD, st);
                 HIPCHK(nca_launch_fused_bf16(F, one, km, p.grid, st, d8));
             }
@@ -889,8 +962,10 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
                 if (w.njobs) {
                     w.nsplit_std = p.n_split;
                     w.nsplit_x = p.n_split_x;
-                    if (p.n_split_x > p.n_split && chunk == 0)         // the rows that only the expand jobs write: zero for everyone else
-                        HIPCHK(hipMemsetAsync(slab + (int64_t)p.n_split * p.slab_stride, 0, (size_t)(p.n_split_x - p.n_split) * p.slab_stride * 4, st));
+                    // (slab rows n_split .. n_split_x - 1 are written by the rebuilding jobs only, in their own columns; the reduce
+                    // kernels sum every column over the rows its job wrote -- NcaReduceArgs::n_split_std -- so nothing has to be
+                    // cleared.  A hipMemsetAsync of those rows used to stand here: captured into a HIP graph it left them unwritten
+                    // and the replayed step added whatever the memory held to the gradient, tools/determinism_probe.py)
                     HIPCHK(nca_launch_wgrad_bf16(F, w, p.n_split_x, st));
                 }
             } else HIPCHK(nca_launch_wgrad_f32(w, p.n_split, st));
@@ -901,6 +976,7 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     r.slab = slab;
     r.slab_stride = p.slab_stride;
     r.n_split = bf ? p.n_split_x : p.n_split;
+    r.n_split_std = p.n_split;
     r.n_wg = p.grid;
     r.oslab = oslab;
     r.oslab_stride = 2 * (F + 1);
@@ -930,6 +1006,8 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
         Span sp(NCA_K_BWD_REDUCE, st);
         HIPCHK(nca_launch_reduce_f32(r, st));
     }
+    g_plan.chunks = chunk;
+    publish_plan(g_plan, false);
     return NCA_OK;
 }
 
@@ -1059,7 +1137,7 @@ extern "C" int nca_render_bwd_depth(const NcaRays* rays, int32_t prec,
     a.g_pix = g_pix;
     a.g_sig_s = g_sig_s;
     a.g_sig_d = g_sig_d;
-    return run_bwd(a, prec, binds, rays->R, a.nchunk, grads, work, work_bytes, st, store, store_bytes, g_depth);
+    return run_bwd(a, prec, binds, rays->R, a.nchunk, grads, work, work_bytes, st, store, store_bytes, g_depth, rays->store_format);
 }
 
 // ---------------------------------------------------------------------------------- point path

@@ -160,7 +160,9 @@ struct NcaReduceArgs {
     int64_t n_params[2];
     const float* slab;
     int64_t slab_stride;
-    int32_t n_split, n_wg;
+    int32_t n_split, n_wg;   // n_split: slab rows of the columns the rebuilding (`expand`) jobs write -- the last F-wide layer under tail_from_sums
+    int32_t n_split_std;     // slab rows of every other column (<= n_split; the rows beyond hold nothing for them and are never read)
+    int32_t pad_;
     const float* oslab;
     int64_t oslab_stride;
     NcaReduceNet net[2];
@@ -263,4 +265,6 @@ size_t nca_fused_bf16_lds_other(int F, int kmode);
 hipError_t nca_launch_sum_tile_records(const char* dregion, int64_t wave_tile_bytes, int64_t dscale_off, int64_t ntiles, int nnets, int F, float* oslab, int n_wg,
                                        hipStream_t st);
 hipError_t nca_launch_wgrad_bf16(int F, const NcaWgradArgs& a, int nsplit, hipStream_t st);
+// the timing-experiment mask the bf16 kernels were compiled with (0 in every shipped library; tools/elim_build.sh)
+int nca_kernels_exp_mask();
 hipError_t nca_launch_pix_f32(int64_t R, int nchunk, const float* I0, const double* part, double* pix, hipStream_t st);

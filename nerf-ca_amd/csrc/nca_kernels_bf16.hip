@@ -24,6 +24,7 @@
 #ifndef NCA_EXP
 #define NCA_EXP 0
 #endif
+int nca_kernels_exp_mask() { return NCA_EXP; }
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -50,16 +51,24 @@ __device__ __forceinline__ unsigned cvt4_e5m2(float a, float b, float c, float d
     v = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(v, c, d, div, true);
     return __builtin_bit_cast(unsigned, v);
 }
-// the same from a packed bf16 pair (two values per instruction; the pair has been rounded to bf16 already)
+// the same from a packed bf16 pair (two values per instruction; the pair has been rounded to bf16 already).
+// (the conversions write one half of a register and keep the other.  Both halves get written, so the start value is immaterial: a
+// zero costs a v_mov per word -- 8 per row tile of an epilogue that is bound by vector-instruction issue -- while an empty asm
+// "defines" a register without an instruction)
 typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 undef_pair() {
+    int v;
+    asm volatile("" : "=v"(v));     // (volatile: one definition per use, or the compiler shares one and copies it)
+    return __builtin_bit_cast(s16x2, v);
+}
 __device__ __forceinline__ unsigned cvt4_e4m3_pk(unsigned lo, unsigned hi, float div) {
-    s16x2 v = {0, 0};
+    s16x2 v = undef_pair();
     v = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(v, __builtin_bit_cast(bf16x2v, lo), div, false);
     v = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(v, __builtin_bit_cast(bf16x2v, hi), div, true);
     return __builtin_bit_cast(unsigned, v);
 }
 __device__ __forceinline__ unsigned cvt4_e5m2_pk(unsigned lo, unsigned hi, float div) {
-    s16x2 v = {0, 0};
+    s16x2 v = undef_pair();
     v = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(v, __builtin_bit_cast(bf16x2v, lo), div, false);
     v = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(v, __builtin_bit_cast(bf16x2v, hi), div, true);
     return __builtin_bit_cast(unsigned, v);
@@ -100,6 +109,46 @@ __device__ __forceinline__ unsigned shl_or(unsigned a, unsigned b) {
     unsigned r;
     asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "n"(K), "v"(b));
     return r;
+}
+// ReLU of eight packed bf16 pairs (one 32-feature row tile of one column tile: fragment words 0..7) and their "is positive" bits as
+// one field -- bit k / 16+k = low / high half of word k -- in ONE asm block of 8 v_pk_max_i16 + 8 v_pk_min_u16 + 7 v_lshl_or_b32.
+// As 23 separate asm statements the compiler's hazard recognizer put an s_nop between every producer and the asm that reads it (it
+// must assume an asm writes or reads a register half, the dst_sel forwarding hazard): 26 s_nop per row tile, a quarter of the
+// epilogue's issue slots, for full-dword instructions that need none.  The inputs come from compiler-visible conversions (the
+// MFMA-to-VALU wait states are the compiler's), the outputs are first read by the NEXT layer's matrix instructions, a whole
+// row-tile epilogue later at the least (see keep_pk for why that distance matters).
+__device__ __forceinline__ unsigned relu_mask8(unsigned (&w)[8]) {
+    unsigned f, t1, t2, t3;
+    asm("v_pk_max_i16 %0, %0, 0\n\tv_pk_max_i16 %1, %1, 0\n\tv_pk_max_i16 %2, %2, 0\n\tv_pk_max_i16 %3, %3, 0\n\t"
+        "v_pk_max_i16 %4, %4, 0\n\tv_pk_max_i16 %5, %5, 0\n\tv_pk_max_i16 %6, %6, 0\n\tv_pk_max_i16 %7, %7, 0\n\t"
+        "v_pk_min_u16 %8, %0, %12\n\tv_pk_min_u16 %9, %1, %12\n\tv_pk_min_u16 %10, %2, %12\n\tv_pk_min_u16 %11, %3, %12\n\t"
+        "v_lshl_or_b32 %8, %9, 1, %8\n\tv_pk_min_u16 %9, %4, %12\n\t"
+        "v_lshl_or_b32 %8, %10, 2, %8\n\tv_pk_min_u16 %10, %5, %12\n\t"
+        "v_lshl_or_b32 %8, %11, 3, %8\n\tv_pk_min_u16 %11, %6, %12\n\t"
+        "v_lshl_or_b32 %8, %9, 4, %8\n\tv_pk_min_u16 %9, %7, %12\n\t"
+        "v_lshl_or_b32 %8, %10, 5, %8\n\tv_lshl_or_b32 %8, %11, 6, %8\n\tv_lshl_or_b32 %8, %9, 7, %8"
+        : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]), "=&v"(f), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "s"(0x00010001u));
+    return f;
+}
+// the ReLU alone (layers whose mask nobody stores)
+__device__ __forceinline__ void relu8(unsigned (&w)[8]) {
+    asm("v_pk_max_i16 %0, %0, 0\n\tv_pk_max_i16 %1, %1, 0\n\tv_pk_max_i16 %2, %2, 0\n\tv_pk_max_i16 %3, %3, 0\n\t"
+        "v_pk_max_i16 %4, %4, 0\n\tv_pk_max_i16 %5, %5, 0\n\tv_pk_max_i16 %6, %6, 0\n\tv_pk_max_i16 %7, %7, 0"
+        : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]));
+}
+// the field alone, of words that are ReLU outputs already (the last layer packs its f32 ReLU)
+__device__ __forceinline__ unsigned mask8(const unsigned (&w)[8]) {
+    unsigned f, t1, t2, t3;
+    asm("v_pk_min_u16 %0, %4, %12\n\tv_pk_min_u16 %1, %5, %12\n\tv_pk_min_u16 %2, %6, %12\n\tv_pk_min_u16 %3, %7, %12\n\t"
+        "v_lshl_or_b32 %0, %1, 1, %0\n\tv_pk_min_u16 %1, %8, %12\n\t"
+        "v_lshl_or_b32 %0, %2, 2, %0\n\tv_pk_min_u16 %2, %9, %12\n\t"
+        "v_lshl_or_b32 %0, %3, 3, %0\n\tv_pk_min_u16 %3, %10, %12\n\t"
+        "v_lshl_or_b32 %0, %1, 4, %0\n\tv_pk_min_u16 %1, %11, %12\n\t"
+        "v_lshl_or_b32 %0, %2, 5, %0\n\tv_lshl_or_b32 %0, %3, 6, %0\n\tv_lshl_or_b32 %0, %1, 7, %0"
+        : "=&v"(f), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "s"(0x00010001u));
+    return f;
 }
 __device__ __forceinline__ void s8_mode() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1"); }
 
@@ -278,6 +327,13 @@ constexpr int NCA_BF_RING = 4;
 #ifndef NCA_BF_PIPE
 #define NCA_BF_PIPE 0
 #endif
+// Two waves share a SIMD.  While one runs the MFMAs of a row tile the other is usually in an epilogue (dense vector-ALU work) or
+// issuing stores; the SIMD arbitrates by priority, then age, so an older wave's vector instructions keep the younger wave's MFMAs
+// waiting although a 32-cycle MFMA needs the issue port for 8 cycles only.  NCA_BF_PRIO: the MFMA block of a row tile runs at
+// priority 1 -- its MFMAs issue on time and the partner's vector work fills the 24 cycles between them.
+#ifndef NCA_BF_PRIO
+#define NCA_BF_PRIO 0
+#endif
 static_assert(NCA_BF_PF >= 1 && NCA_BF_PF < NCA_BF_RING, "prefetch distance must fit the ring");
 // RING registers, prefetch distance RING - 1 (the default ring of 4 for the MFMA-bound modes; the on-chip backward, which is
 // bound by its stores and short of registers, uses a ring of 2)
@@ -290,6 +346,7 @@ __device__ __forceinline__ void ring_prime(const char* imgl, u32x4 (&A)[RING]) {
 template <int NKS, int MTOT, int NB, int RING>
 __device__ __forceinline__ void mma_rowtile_ring(const char* imgl, int m, u32x4 (&A)[RING], const u32x4 (&B)[2][NB],
                                                  f32x16& acc0, f32x16& acc1) {
+    if (NCA_BF_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
         const int g = m * NKS + ks, nx = g + RING - 1;
@@ -300,6 +357,7 @@ __device__ __forceinline__ void mma_rowtile_ring(const char* imgl, int m, u32x4 
         // use and the prefetch distance is lost); vector/scalar ALU and global memory instructions may still move
         __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x10 | 0x400);
     }
+    if (NCA_BF_PRIO) __builtin_amdgcn_s_setprio(0);
 }
 
 // identity fragment of k-step s for the transposing product Z = X^T * E: element j of lane (c,h) is
@@ -884,32 +942,28 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                             Bn[1][2 * m][u] = pack2(acc1[2 * u], acc1[2 * u + 1]);
                             Bn[1][2 * m + 1][u] = pack2(acc1[8 + 2 * u], acc1[8 + 2 * u + 1]);
                         }
-                    } else {
-                        // round to bf16, then ReLU on the packed pair
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            Bn[0][2 * m][u] = relu_pk(pack2_pk(acc0[2 * u], acc0[2 * u + 1]));
-                            Bn[0][2 * m + 1][u] = relu_pk(pack2_pk(acc0[8 + 2 * u], acc0[8 + 2 * u + 1]));
-                            Bn[1][2 * m][u] = relu_pk(pack2_pk(acc1[2 * u], acc1[2 * u + 1]));
-                            Bn[1][2 * m + 1][u] = relu_pk(pack2_pk(acc1[8 + 2 * u], acc1[8 + 2 * u + 1]));
-                        }
                     }
-                    if (STORE && (!LAST || H8) && !NOM) {
-                        // bit k / 16+k of a field: low / high bf16 of packed word k (k = 4*(fragment&1) + u) is > 0
+                    // words 0..7 of a (row tile, column tile): fragment 2m holds accumulator registers 0..7, fragment 2m + 1 registers 8..15
+                    const bool want_mask = STORE && (!LAST || H8) && !NOM;
 #pragma unroll
-                        for (int c = 0; c < 2; ++c) {
-                            unsigned fld;
-                            {                                    // eight terms, shift amounts as immediates: one v_lshl_or each
-                                fld = pos_pk(Bn[c][2 * m][0]);
-                                fld = shl_or<1>(pos_pk(Bn[c][2 * m][1]), fld);
-                                fld = shl_or<2>(pos_pk(Bn[c][2 * m][2]), fld);
-                                fld = shl_or<3>(pos_pk(Bn[c][2 * m][3]), fld);
-                                fld = shl_or<4>(pos_pk(Bn[c][2 * m + 1][0]), fld);
-                                fld = shl_or<5>(pos_pk(Bn[c][2 * m + 1][1]), fld);
-                                fld = shl_or<6>(pos_pk(Bn[c][2 * m + 1][2]), fld);
-                                fld = shl_or<7>(pos_pk(Bn[c][2 * m + 1][3]), fld);
-                            }
-                            mw[c][m >> 1] |= fld << (8 * (m & 1));
+                    for (int c = 0; c < 2; ++c) {
+                        unsigned w[8];
+                        if (LAST) {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) { w[u] = Bn[c][2 * m][u]; w[4 + u] = Bn[c][2 * m + 1][u]; }
+                        } else {
+                            // round to bf16 (compiler-visible conversions: the wait states behind the MFMAs are the compiler's), then
+                            // ReLU -- and the mask bits -- on the packed pairs
+                            const f32x16& acc = c == 0 ? acc0 : acc1;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) { w[u] = pack2(acc[2 * u], acc[2 * u + 1]); w[4 + u] = pack2(acc[8 + 2 * u], acc[8 + 2 * u + 1]); }
+                        }
+                        // bit k / 16+k of a field: low / high bf16 of packed word k (k = 4*(fragment&1) + u) is > 0
+                        if (want_mask) mw[c][m >> 1] |= (LAST ? mask8(w) : relu_mask8(w)) << (8 * (m & 1));
+                        else if (!LAST) relu8(w);
+                        if (!LAST) {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) { Bn[c][2 * m][u] = w[u]; Bn[c][2 * m + 1][u] = w[4 + u]; }
                         }
                     }
                     if (STORE && !LAST && !NOH && H8) {

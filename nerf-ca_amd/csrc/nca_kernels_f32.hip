@@ -1166,7 +1166,9 @@ __global__ void nca_reduce_f32(const NcaReduceArgs a) {
     float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const float* sp = a.slab + rn.slab_off + le;
     int64_t stride = a.slab_stride;
-    int nsum = a.n_split;
+    // rows of this column: the rebuilding jobs of the last F-wide layer may run over more splits than the others
+    const bool tail_col = rn.tail_from_sums && le >= rn.tl_w_off && le < rn.tl_b_off + rn.F;
+    int nsum = tail_col ? a.n_split : a.n_split_std;
     if (rn.wslab) {
         // the layer whose weight gradient the dgrad kernel accumulated on chip: one partial per workgroup
         const int64_t F2 = (int64_t)rn.F * rn.F;
@@ -1242,11 +1244,11 @@ __global__ void nca_onehot_sum_f32(const NcaReduceArgs a) {
         float* p0 = const_cast<float*>(a.slab) + rn.onehot_off + e;
         float s4[4] = {0.f, 0.f, 0.f, 0.f};
         int q = 0;
-        for (; q + 4 <= a.n_split; q += 4) {
+        for (; q + 4 <= a.n_split_std; q += 4) {         // (the one-hot block belongs to the layer-0 jobs)
 #pragma unroll
             for (int u = 0; u < 4; ++u) s4[u] += p0[(int64_t)(q + u) * a.slab_stride];
         }
-        for (; q < a.n_split; ++q) s4[0] += p0[(int64_t)q * a.slab_stride];
+        for (; q < a.n_split_std; ++q) s4[0] += p0[(int64_t)q * a.slab_stride];
         *p0 = (s4[0] + s4[1]) + (s4[2] + s4[3]);
     }
 }

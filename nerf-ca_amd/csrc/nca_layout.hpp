@@ -12,10 +12,10 @@
 #include <stdint.h>
 #include "../../include/nerfca_hip.h"
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define NCA_HD __host__ __device__
 #else
-#define NCA_HD
+#define NCA_HD          // (the host-only unit tests of the layout include this header with a plain C++ compiler)
 #endif
 
 #define NCA_MAX_LAYERS 12

@@ -40,6 +40,20 @@ def set_precision(prec: str, *models) -> None:
             b.packed = None
 
 
+# Debug switch (tests/test_soak_bench_path.py, NERFCA_POISON=1): every scratch buffer handed to the library -- forward workspace and
+# store, backward workspace, loss workspace -- is filled with a NaN pattern first (f32 NaN, bf16 NaN pairs, large e4m3 / e5m2
+# bytes), eagerly or as part of a captured graph.  The library never reads a byte it has not written, so results must not change.
+import os as _os
+POISON_BUFFERS = _os.environ.get("NERFCA_POISON") == "1"
+
+
+def _scratch(nbytes: int, dev) -> torch.Tensor:
+    t = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    if POISON_BUFFERS and nbytes >= 4:
+        t[: nbytes // 4 * 4].view(torch.int32).fill_(0x7FC12345)
+    return t
+
+
 def _alloc_workspace(size_for_cap, dev):
     """Allocate the backward workspace the library sizes for a byte cap (the configured bound, at most 80 % of what the device can
     still give); halve the cap while the allocation fails."""
@@ -47,7 +61,7 @@ def _alloc_workspace(size_for_cap, dev):
     while True:
         wbytes = size_for_cap(cap)
         try:
-            return torch.empty(wbytes, dtype=torch.uint8, device=dev), wbytes
+            return _scratch(wbytes, dev), wbytes
         except torch.cuda.OutOfMemoryError:
             if cap <= (1 << 30):
                 raise
@@ -176,11 +190,11 @@ class _RayBatch:
             self.ph = ph
         self.act, self.single, self.scale = act_code(act), 1 if single else 0, float(scale)
 
-    def desc(self) -> NcaRays:
+    def desc(self, store_format: int = 0) -> NcaRays:
         return NcaRays(R=self.R, S=self.S, ray_is_f64=1 if self.f64 else 0, origins=ptr(self.o), dirs=ptr(self.d),
                        phase=ptr(self.ph), phase_stride_r=self.ps_r, phase_stride_s=self.ps_s, z=ptr(self.z),
                        z_stride_r=self.z_stride_r, dists=ptr(self.dists), I0=ptr(self.I0), act=self.act,
-                       single_field=self.single, scale=self.scale, reserved=0)
+                       single_field=self.single, scale=self.scale, store_format=store_format)
 
 
 # A forward that will be followed by a backward leaves every layer input, the ReLU masks and the raw outputs in a
@@ -241,38 +255,40 @@ def render_forward_raw(batch: _RayBatch, bs: FieldBinding, bd: Optional[FieldBin
     sig_d = torch.empty((R, S), dtype=torch.float32, device=dev) if bd is not None else None
     desc = batch.desc()
     wbytes = check(lib.nca_render_fwd_workspace(C.byref(desc)))
-    work = torch.empty(wbytes, dtype=torch.uint8, device=dev)
+    work = _scratch(wbytes, dev)
     store = None
     global STORE_FALLBACKS
     if for_backward and STORE_FORWARD_LIMIT_BYTES > 0:
         sbytes = check(lib.nca_render_store_bytes(C.byref(desc), C.byref(bs.net), C.byref(bd.net) if bd is not None else None, bs.prec))
         if 0 < sbytes <= store_limit_bytes(dev):
             try:
-                store = torch.empty(sbytes, dtype=torch.uint8, device=dev)
+                store = _scratch(sbytes, dev)
             except torch.cuda.OutOfMemoryError:        # not enough free HBM for the store: the backward recomputes instead
                 store = None
         if sbytes > 0 and store is None:
             STORE_FALLBACKS += 1
-    check(lib.nca_render_fwd(C.byref(desc), bs.prec,
-                             C.byref(bs.net), ptr(packed_s), ptr(win_s), ptr(four_s),
-                             C.byref(bd.net) if bd is not None else None, ptr(packed_d), ptr(win_d), ptr(four_d),
-                             ptr(bd.flat) if bd is not None else None,
-                             ptr(pix), ptr(sig_s), ptr(sig_d), ptr(work), wbytes,
-                             ptr(store), store.numel() if store is not None else 0, _stream()))
-    return pix, sig_s, sig_d, (packed_s, packed_d, win_s, four_s, win_d, four_d, store)
+    # (the return value names what the forward left in the store -- the planner's choice of staging for this batch; the backward
+    # is told through NcaRays.store_format, so a change of the process-wide options in between cannot reinterpret the bytes)
+    fmt = check(lib.nca_render_fwd(C.byref(desc), bs.prec,
+                                   C.byref(bs.net), ptr(packed_s), ptr(win_s), ptr(four_s),
+                                   C.byref(bd.net) if bd is not None else None, ptr(packed_d), ptr(win_d), ptr(four_d),
+                                   ptr(bd.flat) if bd is not None else None,
+                                   ptr(pix), ptr(sig_s), ptr(sig_d), ptr(work), wbytes,
+                                   ptr(store), store.numel() if store is not None else 0, _stream()))
+    return pix, sig_s, sig_d, (packed_s, packed_d, win_s, four_s, win_d, four_d, store, fmt)
 
 
 def render_backward_raw(batch: _RayBatch, bs: FieldBinding, bd: Optional[FieldBinding], keep, g_pix, g_sig_s, g_sig_d, want_depth_grad: bool = False):
     """Fused backward (recompute + dgrad + wgrad + reduce): returns flat f32 gradients per net (and, with ``want_depth_grad``,
     d loss / d depth f32[R,S] as a third value: the f32 path's nca_render_bwd_depth)."""
     lib = _capi.lib()
-    packed_s, packed_d, win_s, four_s, win_d, four_d, store = keep
+    packed_s, packed_d, win_s, four_s, win_d, four_d, store, fmt = keep
     dev = batch.o.device
     gp = torch.zeros(batch.R, dtype=torch.float64, device=dev) if g_pix is None else g_pix.detach().to(torch.float64).contiguous()
     gs, gd = _f32c(g_sig_s), _f32c(g_sig_d)
     grads_s = torch.empty(bs.flat.numel(), dtype=torch.float32, device=dev)
     grads_d = torch.empty(bd.flat.numel(), dtype=torch.float32, device=dev) if bd is not None else None
-    desc = batch.desc()
+    desc = batch.desc(store_format=fmt if store is not None else 0)
     net_d = C.byref(bd.net) if bd is not None else None
     work, wbytes = _alloc_workspace(lambda cap: check(lib.nca_render_bwd_workspace(C.byref(desc), C.byref(bs.net), net_d, bs.prec, cap)), dev)
     if want_depth_grad:
@@ -373,7 +389,7 @@ def fused_losses(pix, gt, wpix, sig_s, sig_d, dists, run_args, weights, inv_R=No
         g_s = torch.empty((R, S), dtype=torch.float32, device=dev)
         g_d = torch.empty((R, S), dtype=torch.float32, device=dev)
     wbytes = check(lib.nca_loss_workspace(R))
-    work = torch.empty(wbytes, dtype=torch.uint8, device=dev)
+    work = _scratch(wbytes, dev)
     check(lib.nca_loss_fwd_bwd(C.byref(desc), ptr(pix), ptr(gt), ptr(wpix), ptr(ss), ptr(sd), ptr(dists), ptr(terms),
                                ptr(g_pix), ptr(g_s), ptr(g_d), ptr(work), wbytes, _stream()))
     return terms, g_pix, g_s, g_d

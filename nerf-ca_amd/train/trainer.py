@@ -235,6 +235,7 @@ class CompositeTrainer:
             pixel_f = MH.weighted_MSELoss()(pix_f, gt, torch.ones_like(w)).mean() * share       # weighted_pixs_ones (:297)
             tf = LS.all_terms(sig_sf, sig_df, dists_f, w, c)
             loss = loss + pixel_f + fav_w * tf[3] * share + ent_w * tf[6] * share + occ_w * tf[8] * share + l1_w * tf[10] + l1_w * tf[9]
+            self.last_fine_terms_autograd = tf      # (the early stop reads the fine pass's entropy / favor terms, run_composite.py:298-310)
         return loss, pixel, terms
 
     def step(self, n_iter: int):
@@ -246,21 +247,21 @@ class CompositeTrainer:
         loss, pixel, terms = self.local_loss(n_iter, ids, self.draw_jitter(n_iter))
         self.opt.zero_grad(set_to_none=True)
         loss.backward()
+        # the reference overwrites dynamic_entropy_loss / favor_s_loss with the fine pass's values before its check (run_composite.py:298-310)
+        tt = self.last_fine_terms_autograd if self.n_fine > 0 else terms
+        share = 1.0 / self.world if self.world > 1 else 1.0             # (local means: equal slices)
+        pair = self._stop_pair(n_iter, d_entropy=tt[6] * share, favor=tt[3] * share)
         if self.world > 1 or self.always_allreduce:
-            self.allreduce_grads()
+            pair = self.allreduce_grads(pair)
         self.opt.step()
         self.sched.step()
-        share = 1.0 / self.world if self.world > 1 else 1.0             # (local means: equal slices)
-        self._note_early_stop(n_iter, d_entropy=terms[6] * share, favor=terms[3] * share)
+        self._note_early_stop(n_iter, pair)
         return loss.detach(), pixel.detach(), terms
 
-    def step_fused(self, n_iter: int):
-        """Same step without an autograd graph: fused forward -> fused loss kernel (values + d loss/d(pix,
-        sigma)) -> fused backward -> (all-reduce) -> Adam.  Returns (loss, pixel, terms f64[13]) on device;
-        the entries of ``terms`` are this rank's share of the global value (they sum over ranks).  With a fine model
-        pair (``depth_samples_per_ray_fine > 0``) see ``_step_fused_fine``."""
-        if self.n_fine > 0:
-            return self._step_fused_fine(n_iter)
+    def fused_gradients(self, n_iter: int):
+        """What ``loss.backward()`` yields in the reference (run_composite.py:283-306) for this rank's slice of step ``n_iter``'s
+        batch, without an autograd graph and without touching the optimiser: fused forward -> fused loss kernel (values + d loss /
+        d(pix, sigma)) -> fused backward.  Returns ``(terms f64[13], flat gradient of the static net, of the dynamic net)``."""
         from ..fused import _RayBatch, fused_losses, render_backward_raw, render_forward_raw
         c = self.cfg
         self.update_windows(n_iter)
@@ -300,17 +301,33 @@ class CompositeTrainer:
                 terms[3:5] = mx
                 grads_s += gs_m
                 grads_d += gd_m
+        return terms, grads_s, grads_d
+
+    def step_fused(self, n_iter: int):
+        """Same step without an autograd graph: fused forward -> fused loss kernel (values + d loss/d(pix,
+        sigma)) -> fused backward -> (all-reduce) -> Adam.  Returns (loss, pixel, terms f64[13]) on device;
+        the entries of ``terms`` are this rank's share of the global value (they sum over ranks).  With a fine model
+        pair (``depth_samples_per_ray_fine > 0``) see ``_step_fused_fine``."""
+        if self.n_fine > 0:
+            return self._step_fused_fine(n_iter)
+        bs, bd = self.s._binding, self.t._binding
+        terms, grads_s, grads_d = self.fused_gradients(n_iter)
+        pair = self._stop_pair(n_iter, terms)
         if self.world > 1 or self.always_allreduce:
-            flat = torch.cat([grads_d, grads_s])
+            # ONE collective per step: the early-stop predicate's two scalars ride behind the gradients
+            nd, ns = grads_d.numel(), grads_s.numel()
+            flat = torch.cat([grads_d, grads_s] + ([pair] if pair is not None else []))
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-            grads_d, grads_s = flat[: grads_d.numel()], flat[grads_d.numel():]
+            grads_d, grads_s = flat[:nd], flat[nd:nd + ns]
+            if pair is not None:
+                pair = flat[nd + ns:]
         for p, g in zip(self.t.parameters(), bd.split_grads(grads_d)):
             p.grad = g
         for p, g in zip(self.s.parameters(), bs.split_grads(grads_s)):
             p.grad = g
         self.opt.step()
         self.sched.step()
-        self._note_early_stop(n_iter, terms)
+        self._note_early_stop(n_iter, pair)
         return terms[0], terms[1], terms
 
     def _step_fused_fine(self, n_iter: int):
@@ -329,13 +346,16 @@ class CompositeTrainer:
         u = self.draw_fine_u(n_iter)[lo:hi].to(dev)
         terms, terms_f, order = self._fine_device_work(ids[lo:hi], R, z, u, self.loss_weights(n_iter))
         sharded = self.world > 1
+        pair = self._stop_pair(n_iter, terms_f)
         if sharded or self.always_allreduce:
-            flat = torch.cat([g for _, _, g in order])
+            flat = torch.cat([g for _, _, g in order] + ([pair] if pair is not None else []))
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
             off = 0
             for i, (m, b, g) in enumerate(order):
                 order[i] = (m, b, flat[off:off + g.numel()])
                 off += g.numel()
+            if pair is not None:
+                pair = flat[off:]
         for m, b, g in order:
             for p, gr in zip(m.parameters(), b.split_grads(g)):
                 p.grad = gr
@@ -344,7 +364,7 @@ class CompositeTrainer:
         self.last_fine_terms = terms_f
         total = terms.clone()
         total[0] = terms[0] + terms_f[0]                                   # loss += the fine pass's assembled loss (:301)
-        self._note_early_stop(n_iter, terms_f)
+        self._note_early_stop(n_iter, pair)
         return total[0], terms[1], total
 
     def _fine_device_work(self, my, R, z, u, weights, weights_dev=None):
@@ -413,20 +433,21 @@ class CompositeTrainer:
         return terms, terms_f, order
 
     # -- early stop (run_composite.py:310-312) ---------------------------------------------------
-    def _note_early_stop(self, n_iter: int, terms=None, d_entropy=None, favor=None) -> None:
-        """The reference breaks its loop when ``dynamic_entropy_loss < 1e-15 or favor_s_loss < 1e-15`` once the frequency windows
-        are fully open (the fine pass's terms when there is one).  Evaluated on the device into ``self.stop_flag`` without a
-        host sync, and only from ``static_pos_enc_window_decay_steps`` on; under ray sharding the two scalars are summed over
-        the ranks first, so that every rank sees the same flag."""
+    def _stop_pair(self, n_iter: int, terms=None, d_entropy=None, favor=None):
+        """This rank's share of [dynamic entropy, favor] (f32[2] on the device) for the early-stop predicate, or None while the
+        frequency windows are still opening (the predicate is not evaluated then).  Under ray sharding the pair is appended to
+        the flat gradient buffer and summed by the step's ONE all-reduce."""
         if n_iter < self.cfg.static_pos_enc_window_decay_steps:
-            self.stop_flag = None
-            return
+            return None
         if terms is not None:
             d_entropy, favor = terms[8], terms[5]           # (nca_loss_fwd_bwd order: this rank's share of the global means)
-        two = torch.stack([d_entropy.detach().double().reshape(()), favor.detach().double().reshape(())])
-        if self.world > 1:
-            dist.all_reduce(two, op=dist.ReduceOp.SUM)
-        self.stop_flag = (two < 1e-15).any()
+        return torch.stack([d_entropy.detach().reshape(()), favor.detach().reshape(())]).to(torch.float32)
+
+    def _note_early_stop(self, n_iter: int, pair) -> None:
+        """The reference breaks its loop when ``dynamic_entropy_loss < 1e-15 or favor_s_loss < 1e-15`` once the frequency windows
+        are fully open (the fine pass's terms when there is one, run_composite.py:298-312).  ``pair`` = the two values summed
+        over the ranks (``_stop_pair``); evaluated on the device into ``self.stop_flag`` without a host sync."""
+        self.stop_flag = None if pair is None else (pair < 1e-15).any()
 
     def global_terms(self, terms: torch.Tensor) -> torch.Tensor:
         """What a logger wants under ray sharding: ``terms`` as ``step_fused`` / ``step_graph`` return them hold this rank's SHARE of
@@ -493,7 +514,7 @@ class CompositeTrainer:
             total = terms.clone()
             total[0] = terms[0] + terms_f[0]
             out["terms"], out["terms_f"] = total, terms_f
-            out["flat"] = torch.cat([g for _, _, g in order])
+            out["flat"] = torch.cat([g for _, _, g in order] + [torch.stack([terms_f[8], terms_f[5]]).to(torch.float32)])       # (+ the early-stop pair)
 
         def front():
             rays = self.data.rays_train.index_select(0, self._ids_buf)
@@ -507,7 +528,7 @@ class CompositeTrainer:
                                                   weights_dev=rec64)
             grads_s, grads_d = render_backward_raw(batch, bs, bd, keep, g_pix, g_s, g_d)
             out["terms"] = terms
-            out["flat"] = torch.cat([grads_d, grads_s])
+            out["flat"] = torch.cat([grads_d, grads_s, torch.stack([terms[8], terms[5]]).to(torch.float32)])                    # (+ the early-stop pair)
 
         def back():
             off, gs = 0, []
@@ -607,18 +628,21 @@ class CompositeTrainer:
         terms = self._graph_out["terms"]
         if self.n_fine > 0:
             self.last_fine_terms = self._graph_out["terms_f"]
-            self._note_early_stop(n_iter, self.last_fine_terms)
-        else:
-            self._note_early_stop(n_iter, terms)
+        # the last two floats of the flat buffer: [dynamic entropy, favor], summed over the ranks by the gradient all-reduce
+        self._note_early_stop(n_iter, self._graph_out["flat"][-2:] if n_iter >= self.cfg.static_pos_enc_window_decay_steps else None)
         return terms[0], terms[1], terms
 
-    def allreduce_grads(self) -> None:
-        """ONE all-reduce(SUM) over a flat f32 buffer of every gradient (152 914 floats by default)."""
+    def allreduce_grads(self, extra=None):
+        """ONE all-reduce(SUM) over a flat f32 buffer of every gradient (152 914 floats by default); ``extra`` (a small f32
+        tensor, e.g. the early-stop pair) rides behind the gradients and comes back summed."""
         grads = [p.grad for p in self.params]
-        flat = torch._utils._flatten_dense_tensors(grads)
+        both = grads + ([extra.to(grads[0].dtype)] if extra is not None else [])
+        flat = torch._utils._flatten_dense_tensors(both)
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        for g, r in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
+        outs = torch._utils._unflatten_dense_tensors(flat, both)
+        for g, r in zip(grads, outs):
             g.copy_(r)
+        return outs[-1] if extra is not None else None
 
     # -- held-out view (run_composite.py:346-413) ------------------------------------------------
     @torch.no_grad()
@@ -642,14 +666,22 @@ class CompositeTrainer:
         pix, sig_s, sig_d = torch.cat(pix), torch.cat(sig_s), torch.cat(sig_d)
         gt = d.test_image.to(pix.dtype)
         ones = torch.ones_like(gt)
-        pixel = MH.weighted_MSELoss()(pix, gt, ones).mean()
-        terms = LS.all_terms(sig_s, sig_d, dists, ones, c)
-        fav_w, ent_w, occ_w, l1_w = self.loss_weights(n_iter)
-        test_loss = pixel + fav_w * terms[3] + ent_w * terms[6] + occ_w * terms[8] + l1_w * terms[10] + l1_w * terms[9]
+        if self.fused_loss and pix.is_cuda:
+            # the HIP loss kernel, values only: all terms and the assembled test loss in one pass (unit pixel weights)
+            from ..fused import fused_losses
+            tk, _, _, _ = fused_losses(pix, gt, ones, sig_s, sig_d, dists, c, self.loss_weights(n_iter), inv_R=1.0 / pix.shape[0], want_grads=False)
+            test_loss, pixel = tk[0], tk[1]
+            favor, blendw, s_ent, d_ent = tk[5], tk[2], tk[6], tk[8]
+        else:
+            pixel = MH.weighted_MSELoss()(pix, gt, ones).mean()
+            terms = LS.all_terms(sig_s, sig_d, dists, ones, c)
+            fav_w, ent_w, occ_w, l1_w = self.loss_weights(n_iter)
+            test_loss = pixel + fav_w * terms[3] + ent_w * terms[6] + occ_w * terms[8] + l1_w * terms[10] + l1_w * terms[9]
+            favor, blendw, s_ent, d_ent = terms[3], terms[0], terms[4], terms[6]
         I0 = d.geo["max_pixel_value"]
         mse = ((pix.float() - d.test_image) ** 2).mean()
         return {"test_loss": test_loss, "test_psnr": -10.0 * torch.log10(test_loss), "test_pixel_loss_coarse": pixel,
-                "test_favor_s_loss": terms[3], "test_blendw": terms[0], "test_s_entropy_loss": terms[4], "test_d_entropy_loss": terms[6],
+                "test_favor_s_loss": favor, "test_blendw": blendw, "test_s_entropy_loss": s_ent, "test_d_entropy_loss": d_ent,
                 "test_mse": mse, "test_psnr_mse": -10.0 * torch.log10(mse), "pred": pix.float(),
                 "pred_static": (I0 - (sig_s.double() * dists).sum(-1)).float(), "pred_dynamic": (I0 - (sig_d.double() * dists).sum(-1)).float()}
 

@@ -191,3 +191,71 @@ def test_shards_partition_the_global_batch():
     # same seed -> same ids on every rank
     ids2 = CompositeTrainer(cfg, s, t, data, dev, rank=1, world=2, seed=3, render=oracle_render, fused_adam=False).draw_ray_ids(5)
     assert np.array_equal(ids, ids2)
+
+
+def _fine_trainer(window_steps=10):
+    from nerfca_amd import synthetic
+    from nerfca_amd.model.CPPN import CPPN
+    from nerfca_amd.model.Temporal import Temporal
+    cfg, s, t, data, dev, CompositeTrainer = build()
+    cfg.depth_samples_per_ray_fine = 6
+    cfg.fine_depth_gradients = False
+    cfg.static_pos_enc_window_decay_steps = cfg.temp_pos_enc_window_decay_steps = window_steps
+    sdef, tdef = synthetic.net_definitions(dev, F=32, early=1, L=4, T=4)
+    torch.manual_seed(11)
+    sf, tf = CPPN(sdef), Temporal(tdef)
+    tr = CompositeTrainer(cfg, s, t, data, dev, seed=7, render=oracle_render, fused_adam=False, static_model_fine=sf, temp_model_fine=tf,
+                          fine_sampler=oracle_fine_sampler)
+    return tr, tf
+
+
+def test_early_stop_of_the_autograd_step_reads_the_fine_pass():
+    """run_composite.py:298-310: with a fine model pair the reference overwrites dynamic_entropy_loss / favor_s_loss with the
+    FINE pass's values before its early-stop check.  A dead fine dynamic field (sigma_d == 0 exactly: blend weight 0, entropy 0)
+    beside a live coarse one must raise the flag; the other way round (dead coarse, live fine) must not."""
+    tr, tf = _fine_trainer()
+    tr.step(5)
+    assert tr.stop_flag is None and tr.early_stop() is False              # windows still opening
+    tr.step(10)
+    assert tr.stop_flag is not None and tr.early_stop() is False          # both passes alive
+    with torch.no_grad():
+        tf.output_linear[0].weight.zero_()
+        tf.output_linear[0].bias.fill_(-1e4)
+    tr.step(11)
+    assert tr.early_stop() is True
+    tr2, _ = _fine_trainer()
+    with torch.no_grad():                                                 # dead COARSE dynamic field, live fine one
+        tr2.t.output_linear[0].weight.zero_()
+        tr2.t.output_linear[0].bias.fill_(-1e4)
+    tr2.step(12)
+    assert tr2.stop_flag is not None and tr2.early_stop() is False
+
+
+def _stop_worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        calls = []
+        orig = dist.all_reduce
+        dist.all_reduce = lambda t, *a, **k: (calls.append(t.numel()), orig(t, *a, **k))[1]
+        cfg, s, t, data, dev, CompositeTrainer = build()
+        cfg.static_pos_enc_window_decay_steps = cfg.temp_pos_enc_window_decay_steps = 10
+        tr = CompositeTrainer(cfg, s, t, data, dev, rank=rank, world=world, seed=7, render=oracle_render, fused_adam=False)
+        tr.step(10)
+        n_params = sum(p.numel() for p in tr.params)
+        torch.save({"flag": bool(tr.stop_flag), "calls": calls, "n_params": n_params}, os.path.join(outdir, f"stop{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_early_stop_scalars_ride_on_the_gradient_all_reduce(tmp_path):
+    """Under ray sharding a steady-state step issues ONE collective: the early-stop predicate's two scalars are appended to the
+    flat gradient buffer instead of being all-reduced on their own (one all-reduce per step)."""
+    mp.spawn(_stop_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in (0, 1):
+        rec = torch.load(tmp_path / f"stop{r}.pt")
+        assert rec["flag"] is False
+        assert rec["calls"] == [rec["n_params"] + 2], rec["calls"]

@@ -1,13 +1,20 @@
 #!/usr/bin/env python3
-"""PSNR at matched steps on the BENCH configuration (BASELINE.json: "rays/sec ...; PSNR vs ref").
+"""PSNR at matched steps (BASELINE.json: "rays/sec ...; PSNR vs ref").
 
-Trains the composite model on the synthetic 256^2 x 192-sample data set of bench.py (40 training images, one held-out
-view) from the same initial weights, ray batches and depth jitter in f32 (the mode that is within 1e-5 of the
-reference's arithmetic per step, tests/test_hip_parity.py) and in bf16 (the throughput mode), and evaluates the
-held-out view every `--every` steps with CompositeTrainer.evaluate (MSE PSNR and the reference's own test_psnr,
-run_composite.py:391).  One JSON line; run on the GPU box:
+Trains the composite model on the synthetic data set of bench.py (40 training images of det^2, one held-out view) from the
+same initial weights, ray batches and depth jitter in every arithmetic the library offers --
 
-    python tools/psnr_run.py --steps 300 --every 100 > gpurun_out/psnr.json
+    f32             the parity mode (within 1e-5 of the reference's arithmetic per step, tests/test_hip_parity.py)
+    bf16_bf16stage  bf16 MFMA operands, layer inputs / output gradients cross HBM as bf16 (NCA_OPT_STAGE_FP8 = 0)
+    bf16_fp8stage   bf16 MFMA operands, staged as e4m3 / e5m2 (NCA_OPT_STAGE_FP8 = 1)
+    bf16            bf16 with the planner's own choice of staging for this batch size (the library default)
+
+-- and evaluates the held-out view every `--every` steps with CompositeTrainer.evaluate (MSE PSNR and the reference's own
+test_psnr, run_composite.py:391).  One JSON line; run on the GPU box:
+
+    python tools/psnr_run.py --steps 300 --every 100 > gpurun_out/psnr.json                                  # bench batch
+    python tools/psnr_run.py --rays 1024 --samples 500 --steps 5000 --every 500 --variants f32,bf16_bf16stage,bf16_fp8stage
+                                                                             # the reference's default batch (composite.txt:25,40)
 """
 import argparse
 import json
@@ -20,54 +27,119 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
+VARIANTS = {"f32": ("f32", None), "bf16": ("bf16", None), "bf16_bf16stage": ("bf16", 0), "bf16_fp8stage": ("bf16", 1),
+            # f32 again from initial weights moved by 1e-6 (relative): the run-to-run spread of the parity mode itself, i.e. the
+            # resolution of a PSNR comparison at this batch size
+            "f32_perturbed": ("f32", None)}
 
-def run(prec, args, dev, data):
+
+def run(variant, args, dev, data, log=None, seed=0):
     import nerfca_amd
-    from nerfca_amd import synthetic
+    from nerfca_amd import _capi, synthetic
     from nerfca_amd.model.CPPN import CPPN
     from nerfca_amd.model.Temporal import Temporal
     from nerfca_amd.train.trainer import CompositeTrainer, TrainConfig
-    torch.manual_seed(1)
-    sdef, tdef = synthetic.net_definitions(dev)
-    s, t = CPPN(sdef).to(dev), Temporal(tdef).to(dev)
-    nerfca_amd.set_precision(prec, s, t)
-    # schedules compressed to the length of the run (the reference anneals over 150 k steps of 1 024 rays)
-    cfg = TrainConfig(depth_samples_per_ray_coarse=args.samples, img_sample_size=args.rays, static_pos_enc_window_decay_steps=args.steps,
-                      temp_pos_enc_window_decay_steps=args.steps, lr_decay_steps=args.steps)
-    tr = CompositeTrainer(cfg, s, t, data, dev, seed=0)
-    tr.update_windows(0)
-    curve = []
+    prec, stage = VARIANTS[variant]
+    old = _capi.get_option(_capi.OPT_STAGE_FP8)
+    if stage is not None:
+        _capi.set_option(_capi.OPT_STAGE_FP8, stage)
+    try:
+        torch.manual_seed(1 + 1000 * seed)
+        sdef, tdef = synthetic.net_definitions(dev)
+        s, t = CPPN(sdef).to(dev), Temporal(tdef).to(dev)
+        if variant == "f32_perturbed":
+            with torch.no_grad():
+                g = torch.Generator(device=dev).manual_seed(12345 + seed)
+                for m in (s, t):
+                    for prm in m.parameters():
+                        prm.mul_(1.0 + 1e-6 * torch.randn(prm.shape, generator=g, device=dev))
+        nerfca_amd.set_precision(prec, s, t)
+        # schedules compressed to the length of the run (the reference anneals over 150 k steps of 1 024 rays)
+        cfg = TrainConfig(depth_samples_per_ray_coarse=args.samples, img_sample_size=args.rays, static_pos_enc_window_decay_steps=args.steps,
+                          temp_pos_enc_window_decay_steps=args.steps, lr_decay_steps=args.steps)
+        tr = CompositeTrainer(cfg, s, t, data, dev, seed=seed)
+        tr.update_windows(0)
+        curve = []
 
-    def point(it):
-        e = tr.evaluate(it)
-        curve.append({"step": it, "psnr_mse_db": float(e["test_psnr_mse"]), "test_psnr_reference_def_db": float(e["test_psnr"]), "test_loss": float(e["test_loss"])})
+        def point(it):
+            tr.update_windows(it)
+            e = tr.evaluate(it)
+            curve.append({"step": it, "psnr_mse_db": float(e["test_psnr_mse"]), "test_psnr_reference_def_db": float(e["test_psnr"]), "test_loss": float(e["test_loss"])})
+            if log:
+                print(f"[psnr_run] {variant} step {it}: {curve[-1]['psnr_mse_db']:.3f} dB", file=log, flush=True)
 
-    point(0)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for it in range(args.steps):
-        loss, _, _ = tr.step(it)
-        if (it + 1) % args.every == 0:
-            point(it + 1)
-    torch.cuda.synchronize()
-    return {"curve": curve, "final_train_loss": float(loss), "wall_s_incl_eval": time.perf_counter() - t0}
+        point(0)
+        step = tr.step_graph if args.graph else tr.step
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fp8_seen = [None]
+        for it in range(args.steps):
+            loss, _, _ = step(it)
+            if it == 0:
+                fp8_seen[0] = bool(_capi.last_plan().get("stage_fp8"))       # what the planner staged this batch size in
+            if (it + 1) % args.every == 0:
+                point(it + 1)
+        torch.cuda.synchronize()
+        return {"curve": curve, "final_train_loss": float(loss), "wall_s_incl_eval": time.perf_counter() - t0, "seed": seed,
+                "stage_fp8_in_effect": None if prec == "f32" else fp8_seen[0]}
+    finally:
+        _capi.set_option(_capi.OPT_STAGE_FP8, old)
+
+
+def gap_statistics(runs, names, tail=1):
+    """Per variant: mean and standard deviation over the seeds of (variant - f32) in dB, at the final evaluation and averaged over
+    the last `tail` evaluations, for both PSNR definitions; `f32_perturbed` (when run) is the resolution of the comparison."""
+    import statistics as st
+    out = {}
+    for key in ("psnr_mse_db", "test_psnr_reference_def_db"):
+        for v in names:
+            if v == "f32" or "f32" not in runs:
+                continue
+            fin = [r["curve"][-1][key] - f["curve"][-1][key] for r, f in zip(runs[v], runs["f32"])]
+            avg = [sum(c[key] for c in r["curve"][-tail:]) / tail - sum(c[key] for c in f["curve"][-tail:]) / tail for r, f in zip(runs[v], runs["f32"])]
+            out.setdefault(v, {})[key] = {"final_gap_per_seed": fin, "final_gap_mean": st.mean(fin), "final_gap_sd": st.stdev(fin) if len(fin) > 1 else None,
+                                          f"last{tail}_gap_per_seed": avg, f"last{tail}_gap_mean": st.mean(avg), f"last{tail}_gap_sd": st.stdev(avg) if len(avg) > 1 else None}
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--tail", type=int, default=3, help="evaluations averaged for the smoothed gap (multi-seed records)")
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--every", type=int, default=100)
     ap.add_argument("--rays", type=int, default=65536)
     ap.add_argument("--det", type=int, default=256)
     ap.add_argument("--samples", type=int, default=192)
+    ap.add_argument("--variants", default="f32,bf16")
+    ap.add_argument("--seeds", default="0", help="comma-separated trainer seeds (ray batches, depth jitter, initial weights); > 1: the record keeps every "
+                    "run and the mean / standard deviation of the final gaps over the seeds")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a HIP graph (library Adam) instead of the eager fused step")
     args = ap.parse_args()
     from nerfca_amd import _capi, synthetic
     _capi.lib()
     dev = torch.device("cuda", 0)
     data = synthetic.make_dataset(args.det, args.samples, dev, views=synthetic.TRAIN_VIEWS)
-    out = {"config": f"{args.det}^2 detector x {args.samples} samples/ray, {args.rays} rays/step, {args.steps} steps, 4 views x 10 phases + 1 held-out view, synthetic phantom",
-           "f32": run("f32", args, dev, data), "bf16": run("bf16", args, dev, data)}
-    out["final_psnr_gap_db"] = out["f32"]["curve"][-1]["psnr_mse_db"] - out["bf16"]["curve"][-1]["psnr_mse_db"]
+    out = {"config": f"{args.det}^2 detector x {args.samples} samples/ray, {args.rays} rays/step, {args.steps} steps, 4 views x 10 phases + 1 held-out view, "
+                     f"synthetic phantom, {'HIP-graph step' if args.graph else 'eager fused step'}"}
+    names = [v for v in args.variants.split(",") if v]
+    seeds = [int(x) for x in args.seeds.split(",") if x != ""]
+    if len(seeds) > 1:
+        runs = {v: [run(v, args, dev, data, log=sys.stderr, seed=sd) for sd in seeds] for v in names}
+        out["seeds"] = seeds
+        out["runs"] = runs
+        tail = max(1, min(args.tail, len(runs[names[0]][0]["curve"])))
+        out["gaps"] = gap_statistics(runs, names, tail)
+        print(json.dumps(out))
+        return
+    for v in names:
+        out[v] = run(v, args, dev, data, log=sys.stderr, seed=seeds[0])
+    if "f32" in out:
+        ref = out["f32"]["curve"][-1]
+        out["final_gap_vs_f32_db"] = {v: {"psnr_mse": out[v]["curve"][-1]["psnr_mse_db"] - ref["psnr_mse_db"],
+                                          "test_psnr_reference_def": out[v]["curve"][-1]["test_psnr_reference_def_db"] - ref["test_psnr_reference_def_db"]}
+                                      for v in names if v != "f32"}
+        if "bf16" in out:      # (key of the round-1 / round-2 records)
+            out["final_psnr_gap_db"] = ref["psnr_mse_db"] - out["bf16"]["curve"][-1]["psnr_mse_db"]
     print(json.dumps(out))
 
 

@@ -2,7 +2,8 @@
 """Turn gpurun_out/prof_<prec>/ (written by tools/collect_profiles.sh on the GPU box) into the committed summaries:
     profiles/<tag>_<prec>_bench.json, _bench_under_rocprof.json, _bench_kernel_stats.csv,
     _pmc_FETCH_SIZE.csv / _pmc_WRITE_SIZE.csv (rows of this library's kernels), _pmc_traffic.json, _pmc_sq.json
-usage: python tools/summarize_profiles.py bf16 [tag=r01]"""
+usage: python tools/summarize_profiles.py bf16 [tag=r01] [suffix]      (suffix: the collect_profiles.sh suffix, e.g. _pure; the files
+are then named <tag>_<prec><suffix>_*)"""
 import collections
 import csv
 import glob
@@ -13,7 +14,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prec = sys.argv[1]
 tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
-src = os.path.join(ROOT, "gpurun_out", f"prof_{prec}")
+suffix = sys.argv[3] if len(sys.argv) > 3 else ""
+src = os.path.join(ROOT, "gpurun_out", f"prof_{prec}{suffix}")
+sys.path.insert(0, ROOT)
+from bench import source_sha          # (hash of the kernel sources: bench.py replays a PMC summary only on the sources it was taken on)
 dst = os.path.join(ROOT, "profiles")
 # candidate kernel names per role, most specific first (kernel modes: 0 forward, 1 recompute backward, 2 storing forward,
 # 3 backward from the store, 4 the same with the last hidden layer's weight gradient on chip, 5 backward from an fp8-staged store
@@ -47,9 +51,9 @@ def find(pattern):
 
 
 bench = last_json_line(os.path.join(src, "bench.json"))
-json.dump(bench, open(os.path.join(dst, f"{tag}_{prec}_bench.json"), "w"))
-json.dump(last_json_line(os.path.join(src, "bench_under_rocprof.json")), open(os.path.join(dst, f"{tag}_{prec}_bench_under_rocprof.json"), "w"))
-with open(find("stats/**/*kernel_stats.csv")) as f, open(os.path.join(dst, f"{tag}_{prec}_bench_kernel_stats.csv"), "w") as g:
+json.dump(bench, open(os.path.join(dst, f"{tag}_{prec}{suffix}_bench.json"), "w"))
+json.dump(last_json_line(os.path.join(src, "bench_under_rocprof.json")), open(os.path.join(dst, f"{tag}_{prec}{suffix}_bench_under_rocprof.json"), "w"))
+with open(find("stats/**/*kernel_stats.csv")) as f, open(os.path.join(dst, f"{tag}_{prec}{suffix}_bench_kernel_stats.csv"), "w") as g:
     g.write(f.read())
 
 
@@ -72,8 +76,8 @@ def mean_last(v, n=20):
     return sum(v) / len(v)
 
 
-fetch = per_kernel("pmc_FETCH_SIZE", os.path.join(dst, f"{tag}_{prec}_pmc_FETCH_SIZE.csv"))
-write = per_kernel("pmc_WRITE_SIZE", os.path.join(dst, f"{tag}_{prec}_pmc_WRITE_SIZE.csv"))
+fetch = per_kernel("pmc_FETCH_SIZE", os.path.join(dst, f"{tag}_{prec}{suffix}_pmc_FETCH_SIZE.csv"))
+write = per_kernel("pmc_WRITE_SIZE", os.path.join(dst, f"{tag}_{prec}{suffix}_pmc_WRITE_SIZE.csv"))
 def _commit():
     import subprocess
     try:
@@ -82,10 +86,10 @@ def _commit():
         return None
 
 
-traffic = {"commit": _commit(), "how": "rocprofv3 --pmc FETCH_SIZE (and, in a second run, --pmc WRITE_SIZE) --kernel-trace --output-format csv -- python3 bench.py "
+traffic = {"commit": _commit(), "source_sha": source_sha(), "how": "rocprofv3 --pmc FETCH_SIZE (and, in a second run, --pmc WRITE_SIZE) --kernel-trace --output-format csv -- python3 bench.py "
                   "--steps 2 --warmup 1 --no-cpu-baseline; per-kernel mean over the last <=20 dispatches; bytes = counter * 1024; FETCH_SIZE "
                   "doubled (gfx950 reports half of a wide coalesced stream, MI355X_MICROARCH.md section HBM); WRITE_SIZE as is",
-           "config": {"prec": prec, "rays_per_step": bench["config"]["rays_per_step_per_gpu"], "samples_per_ray": bench["config"]["samples_per_ray"],
+           "config": {"prec": prec, "stage_fp8": bool(bench["config"].get("stage_fp8")), "rays_per_step": bench["config"]["rays_per_step_per_gpu"], "samples_per_ray": bench["config"]["samples_per_ray"],
                       "ray_chunks_per_step": bench["roofline"]["all_kernels"]["bwd_wgrad"]["launches"] // bench["steps"],
                       "dgrad_launches_per_step": bench["roofline"]["all_kernels"]["bwd_dgrad"]["launches"] // bench["steps"],
                       "fwd_launches_per_step": bench["roofline"]["all_kernels"]["fwd"]["launches"] // bench["steps"]},
@@ -98,7 +102,7 @@ for key, names in KERNELS.items():
     rd = mean_last(fetch[fk]["FETCH_SIZE"]) * 1024 * 2
     wr = mean_last(write[wk]["WRITE_SIZE"]) * 1024
     traffic["kernels"][key] = {"kernel": name, "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr}
-json.dump(traffic, open(os.path.join(dst, f"{tag}_{prec}_pmc_traffic.json"), "w"), indent=1)
+json.dump(traffic, open(os.path.join(dst, f"{tag}_{prec}{suffix}_pmc_traffic.json"), "w"), indent=1)
 # bench.py reads roofline.traffic from the traffic file that was committed when it ran; the bench line kept here gets the
 # figure of THIS collection (same box, same build) instead
 dom = bench["roofline"]["kernel"]
@@ -106,7 +110,7 @@ if dom in traffic["kernels"]:
     t = traffic["kernels"][dom]["hbm_bytes_per_launch"]
     bench["roofline"]["traffic"] = t
     bench["roofline"]["staging_TBps"] = t / (bench["roofline"]["avg_launch_ms"] * 1e-3) / 1e12
-    json.dump(bench, open(os.path.join(dst, f"{tag}_{prec}_bench.json"), "w"))
+    json.dump(bench, open(os.path.join(dst, f"{tag}_{prec}{suffix}_bench.json"), "w"))
 
 sq = per_kernel("pmc_SQ")
 out = {"how": "one rocprofv3 --pmc pass (8 SQ counters + GRBM_GUI_ACTIVE) --kernel-trace over bench.py --steps 2 --warmup 1; means per dispatch. "
@@ -124,9 +128,12 @@ for key, names in KERNELS.items():
                            "mfma_busy": d["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / cyc,
                            "valu_busy": d["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / cyc if "SQ_ACTIVE_INST_VALU" in d else None,
                            "wait_any": d["SQ_WAIT_ANY"] / d["SQ_WAVE_CYCLES"], "wait_inst_any": d["SQ_WAIT_INST_ANY"] / d["SQ_WAVE_CYCLES"],
-                           "active_inst_any": d["SQ_ACTIVE_INST_ANY"] / d["SQ_WAVE_CYCLES"], "wait_inst_lds": d["SQ_WAIT_INST_LDS"] / d["SQ_WAVE_CYCLES"],
+                           "active_inst_any": d["SQ_ACTIVE_INST_ANY"] / d["SQ_WAVE_CYCLES"],
+                           # cycles in which vector-ALU and matrix instructions execute together, as a share of the SIMD cycles (same normalisation as mfma_busy)
+                           "valu_mfma_coexec": d["SQ_VALU_MFMA_COEXEC_CYCLES"] / 1024 / cyc if "SQ_VALU_MFMA_COEXEC_CYCLES" in d else None,
+                           "wait_inst_lds": d["SQ_WAIT_INST_LDS"] / d["SQ_WAVE_CYCLES"] if "SQ_WAIT_INST_LDS" in d else None,
                            "lds_bank_conflict_cycles": d["SQ_LDS_BANK_CONFLICT"]}
-json.dump(out, open(os.path.join(dst, f"{tag}_{prec}_pmc_sq.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(dst, f"{tag}_{prec}{suffix}_pmc_sq.json"), "w"), indent=1)
 print(json.dumps({k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items() if kk != "kernel"} for k, v in out["kernels"].items()}, indent=1))
 print({k: round(v["hbm_bytes_per_launch"] / 1e9, 3) for k, v in traffic["kernels"].items()})
 print(bench["value"], bench["ms_per_step"], bench["roofline"]["frac"], bench.get("cpu_baseline", {}).get("value"))

@@ -1,0 +1,14 @@
+#!/bin/bash
+# A/B builds of the bf16 kernels with other values of their tuning macros (NCA_BF_PRIO, NCA_BF_PIPE, NCA_BF_PF ...):
+#   tools/variant_build.sh prio1 "-DNCA_BF_PRIO=1"  [name2 "flags2" ...]   ->  nerf-ca_amd/lib/libnerfca_hip_<name>.so
+# Run a bench or the tests against one with NERFCA_LIB=<path>.  These are CORRECT libraries (unlike tools/elim_build.sh's): a variant
+# that wins becomes the default in the source.  The other objects come from the regular build.
+set -e
+cd "$(dirname "$0")/.."
+make -j4 > /dev/null
+while [ $# -ge 2 ]; do
+  N=$1; F=$2; shift 2
+  ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function $F -c nerf-ca_amd/csrc/nca_kernels_bf16.hip -o /tmp/nca_bf16_$N.o &&
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC nerf-ca_amd/csrc/nca_api.o nerf-ca_amd/csrc/nca_kernels_f32.o nerf-ca_amd/csrc/nca_kernels_loss.o /tmp/nca_bf16_$N.o -o nerf-ca_amd/lib/libnerfca_hip_$N.so && echo built $N ) &
+done
+wait
