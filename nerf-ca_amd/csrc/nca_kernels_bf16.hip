@@ -327,13 +327,11 @@ constexpr int NCA_BF_RING = 4;
 #ifndef NCA_BF_PIPE
 #define NCA_BF_PIPE 0
 #endif
-// Two waves share a SIMD.  While one runs the MFMAs of a row tile the other is usually in an epilogue (dense vector-ALU work) or
-// issuing stores; the SIMD arbitrates by priority, then age, so an older wave's vector instructions keep the younger wave's MFMAs
-// waiting although a 32-cycle MFMA needs the issue port for 8 cycles only.  NCA_BF_PRIO: the MFMA block of a row tile runs at
-// priority 1 -- its MFMAs issue on time and the partner's vector work fills the 24 cycles between them.
-#ifndef NCA_BF_PRIO
-#define NCA_BF_PRIO 0
-#endif
+// Two A/B experiments on how the two waves of a SIMD share it, both measured at the bench size and removed again (round 3):
+// s_setprio 1 around the 16 MFMAs of a row tile (so that they win the issue port against the partner's epilogue): forward 4.75 ->
+// 4.60 / 4.75 ms in two runs, backward 3.68 -> 3.64 / 3.67 -- inside the run-to-run spread; an advisory LDS lock per SIMD that lets
+// only one of the two waves be in its MFMA block at a time (forced anti-phase): forward 4.76 -> 8.16 ms, backward 3.68 -> 5.26 --
+// the blocks of the two waves overlap to the kernels' advantage as they are.
 static_assert(NCA_BF_PF >= 1 && NCA_BF_PF < NCA_BF_RING, "prefetch distance must fit the ring");
 // RING registers, prefetch distance RING - 1 (the default ring of 4 for the MFMA-bound modes; the on-chip backward, which is
 // bound by its stores and short of registers, uses a ring of 2)
@@ -346,7 +344,6 @@ __device__ __forceinline__ void ring_prime(const char* imgl, u32x4 (&A)[RING]) {
 template <int NKS, int MTOT, int NB, int RING>
 __device__ __forceinline__ void mma_rowtile_ring(const char* imgl, int m, u32x4 (&A)[RING], const u32x4 (&B)[2][NB],
                                                  f32x16& acc0, f32x16& acc1) {
-    if (NCA_BF_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
         const int g = m * NKS + ks, nx = g + RING - 1;
@@ -357,7 +354,6 @@ __device__ __forceinline__ void mma_rowtile_ring(const char* imgl, int m, u32x4 
         // use and the prefetch distance is lost); vector/scalar ALU and global memory instructions may still move
         __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x10 | 0x400);
     }
-    if (NCA_BF_PRIO) __builtin_amdgcn_s_setprio(0);
 }
 
 // identity fragment of k-step s for the transposing product Z = X^T * E: element j of lane (c,h) is

@@ -499,7 +499,10 @@ class CompositeTrainer:
         lo, hi = (R * self.rank) // self.world, (R * (self.rank + 1)) // self.world
         self._slice = (lo, hi)
         self._ids_buf = torch.zeros(hi - lo, dtype=torch.int64, device=dev)
-        tail = torch.tensor([1e-10], dtype=self.data.rays_train.dtype, device=dev)   # model_helpers.py:73
+        # model_helpers.py:73.  An attribute, not a local: the captured kernels read this address at every replay, and a tensor that
+        # dies with this function hands its memory back to the allocator (the last interval length then was whatever the next
+        # owner wrote there: seen as a garbage loss at 8 192 rays per step, tests/test_configs.py)
+        tail = self._graph_tail = torch.tensor([1e-10], dtype=self.data.rays_train.dtype, device=dev)
         nets = [self.t, self.s] + ([self.t_fine, self.s_fine] if fine else [])           # self.params order
         self.adam = FusedAdam(nets, lr=c.lr, end_factor=c.lr_end_factor, total_iters=c.lr_decay_steps)
         bs, bd = self.s._binding, self.t._binding

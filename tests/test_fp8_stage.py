@@ -9,7 +9,7 @@ measured distances per gradient: the kernels with fp8 staging from the oracle th
 staging from the oracle that does not; the first must be within the bound of the other bf16 tests (5e-2 of the max-norm) or
 within 1e-2 of the second -- although the staging itself moves a gradient of a few thousand random-signed samples by
 5 .. 25 % of its max-norm.  Outputs must be BIT-identical to bf16 staging (the forward's arithmetic does not change).  The training-quality gate (held-out PSNR within 0.1 dB of f32 at
-the bench configuration) is tests/test_onchip_bf16.py::test_bf16_psnr_gate_at_bench_configuration, which runs the defaults.
+the bench configuration) is tests/test_psnr_gates.py, which runs the defaults (and both stagings at the reference's default batch).
 """
 import dataclasses
 

@@ -6,8 +6,8 @@ switches it off (mode 3).  What `loss.backward()` yields in the reference: train
 
 Every test asserts that mode 4 really ran (two dgrad launches per backward, one per net).  The comparisons with the
 recompute backward and with mode 3 are exact up to summation order, which holds for bf16 staging (NCA_OPT_STAGE_FP8 = 0);
-the default fp8 staging of the same kernels is tested in tests/test_fp8_stage.py, and the PSNR gate at the end of this
-file trains with the library's defaults.
+the default fp8 staging of the same kernels is tested in tests/test_fp8_stage.py; the PSNR gates (tests/test_psnr_gates.py) train
+with the library's defaults.
 """
 import contextlib
 import dataclasses
@@ -242,41 +242,3 @@ def test_mode4_full_size_step_equals_mode3(dev):
     e = rel_err(res[0][1], res[1][1])
     print(f"flat gradient, mode 4 vs mode 3 at 65 536 x 192: {e:.2e}")
     assert e < 5e-6
-
-
-def test_bf16_psnr_gate_at_bench_configuration(dev):
-    """The gate of the throughput mode where the bench runs it ("bf16: PSNR on the held-out view within 0.1 dB of
-    fp32 after equal steps"): 300 steps of 65 536 rays x 192 samples on the 256^2 synthetic data set (40 training images, one
-    held-out view) from the same initial weights, ray batches and depth jitter in f32 (the mode that is within 1e-5 of the
-    reference's arithmetic per step) and in bf16 (storing forward + on-chip backward, the kernels the bench times);
-    `test_psnr` = -10 log10(test loss) is the reference's own definition (train/run_composite.py:391)."""
-    import nerfca_amd
-    from nerfca_amd import synthetic
-    from nerfca_amd.model.CPPN import CPPN
-    from nerfca_amd.model.Temporal import Temporal
-    from nerfca_amd.train.trainer import CompositeTrainer, TrainConfig
-    steps = 300
-    data = synthetic.make_dataset(256, 192, dev, views=synthetic.TRAIN_VIEWS)
-    res = {}
-    for prec in ("f32", "bf16"):
-        torch.manual_seed(1)
-        sdef, tdef = synthetic.net_definitions(dev)
-        s, t = CPPN(sdef).to(dev), Temporal(tdef).to(dev)
-        nerfca_amd.set_precision(prec, s, t)
-        cfg = TrainConfig(depth_samples_per_ray_coarse=192, img_sample_size=65536, static_pos_enc_window_decay_steps=steps,
-                          temp_pos_enc_window_decay_steps=steps, lr_decay_steps=steps)
-        tr = CompositeTrainer(cfg, s, t, data, dev, seed=0)
-        tr.update_windows(0)
-        p0 = float(tr.evaluate(0)["test_psnr_mse"])
-        for it in range(steps):
-            tr.step(it)
-        tr.update_windows(steps)
-        e = tr.evaluate(steps)
-        res[prec] = (p0, float(e["test_psnr_mse"]), float(e["test_psnr"]))
-        del tr, s, t
-        torch.cuda.empty_cache()
-    print(f"held-out PSNR after {steps} steps at 65 536 x 192: untrained {res['f32'][0]:.2f} dB, f32 {res['f32'][1]:.2f} dB, bf16 {res['bf16'][1]:.2f} dB "
-          f"(reference's test_psnr: {res['f32'][2]:.2f} / {res['bf16'][2]:.2f})")
-    assert res["f32"][1] - res["f32"][0] > 25.0 and res["bf16"][1] - res["bf16"][0] > 25.0
-    assert abs(res["f32"][1] - res["bf16"][1]) < 0.1
-    assert abs(res["f32"][2] - res["bf16"][2]) < 0.1

@@ -114,6 +114,35 @@ def test_steps_do_not_read_unwritten_memory(dev, prec, rays, samples, det):
         assert torch.equal(res[graph, False][1], res[graph, True][1]), graph
 
 
+@pytest.mark.parametrize("rays,samples,det", [(8192, 192, 256), (1024, 500, 64), (700, 70, 64)])
+def test_graph_step_survives_allocator_churn(dev, rays, samples, det):
+    """Everything a captured graph reads at replay time must stay allocated for the graph's lifetime.  After the capture (and
+    again between replays) the caching allocator is churned with thousands of small NaN-filled tensors that take over every block
+    freed since; each replayed step's loss terms must equal those of the eager fused path evaluated at the graph trainer's current
+    weights.  (Found this way: the 1e-10 tail of the interval lengths was a local of the capture function -- its memory went
+    back to the allocator and the last interval length of every later replay was whatever the next owner had written there.)"""
+    from nerfca_amd import synthetic
+    data = synthetic.make_dataset(det, samples, dev, views=synthetic.TRAIN_VIEWS[:2], n_phases=3)
+    tr = _trainer(dev, "bf16", rays, samples, data)
+    ref = _trainer(dev, "bf16", rays, samples, data)
+
+    def churn():
+        junk = [torch.full((n,), float("nan"), dtype=torch.float64, device=dev) for n in (1, 2, 3, 8, 24, 96, 192, 500, 1000, 4096) * 300]
+        torch.cuda.synchronize()
+        del junk
+
+    for it in range(4):
+        # the eager path at the graph trainer's weights (its own optimiser is never stepped)
+        with torch.no_grad():
+            for pr, pg in zip(ref.params, tr.params):
+                pr.copy_(pg)
+        want = ref.fused_gradients(75000 + it)[0].clone()
+        got = tr.step_graph(75000 + it)[2].clone()
+        assert bool(torch.isfinite(got).all()), (it, got)
+        assert rel_err(got, want) < 1e-6, (it, got, want)          # (the two paths build the interval lengths with different torch ops)
+        churn()
+
+
 @pytest.mark.timeout(600)
 def test_graph_step_is_deterministic_across_processes(dev):
     """The graph-replayed bench step in two fresh processes, the second after the free device memory was filled with a NaN pattern
