@@ -121,12 +121,16 @@ def self_launch(args) -> int:
 def source_sha():
     """Hash of the kernel sources this library was built from: a committed PMC summary is replayed only for the sources it
     was taken on."""
+    import re
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "nerf-ca_amd", "csrc")
     for name in sorted(os.listdir(csrc)):
         if name.endswith((".hip", ".hpp")):
+            text = open(os.path.join(csrc, name), encoding="utf-8", errors="replace").read()
+            text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)            # comments and layout do not change a kernel
+            text = re.sub(r"//[^\n]*", " ", text)
             h.update(name.encode())
-            h.update(open(os.path.join(csrc, name), "rb").read())
+            h.update(" ".join(text.split()).encode())
     return h.hexdigest()[:16]
 
 
@@ -135,8 +139,9 @@ def committed_pmc(prec, rays, samples, stage_fp8=None):
     These are REPLAYED figures (separate rocprofv3 --pmc passes cannot run inside a bench run): the line labels them with
     the file and commit they come from, and they are dropped when the kernel sources have changed since (source_sha)."""
     sha = source_sha()
+    stem = f"{prec}_pure" if (prec == "bf16" and stage_fp8 is False) else prec        # (the bf16-staging passes are kept under <tag>_bf16_pure_*)
     for tag in PROFILE_TAGS:
-        path = os.path.join(ROOT, "profiles", f"{tag}_{prec}_pmc_traffic.json")
+        path = os.path.join(ROOT, "profiles", f"{tag}_{stem}_pmc_traffic.json")
         try:
             rec = json.load(open(path))
         except (OSError, ValueError):
@@ -147,10 +152,10 @@ def committed_pmc(prec, rays, samples, stage_fp8=None):
         if rec.get("source_sha") != sha or (stage_fp8 is not None and cfg.get("stage_fp8", True) != stage_fp8):
             continue          # taken on other kernel sources / another staging: not this build's traffic
         try:
-            sq = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_{prec}_pmc_sq.json")))
+            sq = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_{stem}_pmc_sq.json")))
         except (OSError, ValueError):
             sq = None
-        return rec, sq, {"file": f"profiles/{tag}_{prec}_pmc_traffic.json", "taken_at_commit": rec.get("commit"), "source_sha": sha,
+        return rec, sq, {"file": f"profiles/{tag}_{stem}_pmc_traffic.json", "taken_at_commit": rec.get("commit"), "source_sha": sha,
                          "kind": "replayed from a committed rocprofv3 --pmc pass over these kernel sources"}
     return None, None, None
 

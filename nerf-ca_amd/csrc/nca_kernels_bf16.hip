@@ -332,6 +332,14 @@ constexpr int NCA_BF_RING = 4;
 // 4.60 / 4.75 ms in two runs, backward 3.68 -> 3.64 / 3.67 -- inside the run-to-run spread; an advisory LDS lock per SIMD that lets
 // only one of the two waves be in its MFMA block at a time (forced anti-phase): forward 4.76 -> 8.16 ms, backward 3.68 -> 5.26 --
 // the blocks of the two waves overlap to the kernels' advantage as they are.
+// A third: the epilogue of one 32-sample column tile cut into eight pieces of five vector instructions, each placed behind one of the
+// eight MFMAs of the OTHER column tile (the two accumulators alternate between being produced and consumed: no extra registers, every
+// A fragment read from LDS twice; the ISA showed  M d v5 w M d v5 ...  as meant): forward 4.63 -> 4.64 ms, and 3.97 -> 3.97 ms with
+// the H stores compiled out.  Two instruction orders that differ this much and cost the same, and elimination builds whose savings ADD
+// (MFMAs 0.76 + stores 0.65 + mask / 8-bit conversion 0.35 + the rest 0.69 = the kernel's 2.45 ms, profiles/r02_elimination_builds.txt),
+// are what a power cap looks like: time = energy / cap, whatever overlaps.  What is left is fewer instructions and fewer bytes.
+// (profiles/r03_valu_mfma_samewave.txt has the issue costs of the epilogue's own instructions: the packed 16-bit ones and v_lshl_or
+// 4.4 cycles of SIMD time each also with two waves per SIMD, v_cvt_scalef32_pk_{fp8,bf8}_bf16 8.3)
 static_assert(NCA_BF_PF >= 1 && NCA_BF_PF < NCA_BF_RING, "prefetch distance must fit the ring");
 // RING registers, prefetch distance RING - 1 (the default ring of 4 for the MFMA-bound modes; the on-chip backward, which is
 // bound by its stores and short of registers, uses a ring of 2)

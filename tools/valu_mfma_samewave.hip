@@ -41,6 +41,12 @@ __global__ void k(int iters, unsigned long long* cyc, float* sink) {
                 if (KIND == 0) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(r) : "v"(c1), "v"(c2));
                 else if (KIND == 1) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(r) : "v"(c1));
                 else if (KIND == 2) asm volatile("v_and_b32 %0, %0, %1" : "+v"(r) : "v"(m));
+                else if (KIND == 4) asm volatile("v_pk_max_i16 %0, %0, 0" : "+v"(r));
+                else if (KIND == 5) asm volatile("v_pk_min_u16 %0, %0, %1" : "+v"(r) : "s"(0x00010001u));
+                else if (KIND == 6) asm volatile("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(r) : "v"(c1));
+                else if (KIND == 7) asm volatile("v_cvt_scalef32_pk_fp8_bf16 %0, %1, %2" : "+v"(r) : "v"(c1), "s"(0.25f));
+                else if (KIND == 8) asm volatile("v_pk_mul_lo_u16 %0, %0, %1" : "+v"(r) : "v"(c1));
+                else if (KIND == 9) asm volatile("v_cvt_scalef32_pk_bf8_bf16 %0, %1, %2" : "+v"(r) : "v"(c1), "v"(c2));
                 else asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r) : "v"(c1));
             }
         }
@@ -90,5 +96,11 @@ int main() {
     sweep<1>("v_cvt_pk_bf16_f32", dcyc, sink);
     sweep<2>("v_and_b32", dcyc, sink);
     sweep<3>("v_cndmask_b32", dcyc, sink);
+    sweep<4>("v_pk_max_i16", dcyc, sink);
+    sweep<5>("v_pk_min_u16", dcyc, sink);
+    sweep<6>("v_lshl_or_b32", dcyc, sink);
+    sweep<7>("v_cvt_scalef32_pk_fp8_bf16", dcyc, sink);
+    sweep<8>("v_pk_mul_lo_u16", dcyc, sink);
+    sweep<9>("v_cvt_scalef32_pk_bf8_bf16", dcyc, sink);
     return 0;
 }
