@@ -66,6 +66,41 @@ def assemble_ray_table(geom, pix, wgt, heart_phases):
     return table.reshape(-1, 4, 3), phases
 
 
+class TrainingData(SimpleNamespace):
+    """What ``CompositeTrainer`` / ``StaticTrainer`` take as ``data`` (the tensors run_composite.py:84-125 builds before its loop)."""
+
+
+def load_training_data(general_file: str, train_file: str, test_file: str, run_args, device) -> TrainingData:
+    """The loop glue of train/run_composite.py:65-125 from the reference's on-disk schema: ``general.json`` (TIGRE geometry, detector
+    size, near / far thresholds, ``max_pixel_value``), ``train-*.json`` / ``test-*.json`` (``frames``: angles, ``file_path`` and
+    ``weighted_file_path`` of the ``.npy`` images, ``img_min_max``, ``heart_phase``, ``image_id_str``) -> the ray table and phase
+    vector, the high-variance ray ids of the importance sampler (:97-99) and the tensors of the ONE held-out view the loop
+    evaluates (:68-70, :110-125).  ``run_args`` supplies ``depth_samples_per_ray_coarse``, ``weighted_loss_max``, ``var_sample_thre``."""
+    import json
+    with open(general_file) as fh:
+        info = json.load(fh)
+    with open(train_file) as fh:
+        train = json.load(fh)["frames"]
+    with open(test_file) as fh:
+        test = json.load(fh)["frames"][:1]                 # "always only use one test image" (:72-74)
+    W, H = info["nDetector"]
+    rays, phases = prepare_data_for_loader_tigre(train, info, W, H, run_args.depth_samples_per_ray_coarse, run_args.weighted_loss_max, device)
+    var_ids = np.argwhere(rays[:, -1, 0] > 1.0 + run_args.var_sample_thre / 100.0).flatten()
+    non_var = np.setxor1d(var_ids, np.arange(rays.shape[0]))
+    out = TrainingData(geo=info, rays_train=torch.from_numpy(rays).to(device), phases_train=torch.from_numpy(phases).to(device), n_images=len(train),
+                       var_ray_ids=var_ids, non_var_ray_ids=non_var, train_img_indices=[f.get("image_id_str") for f in train],
+                       test_img_indices=[f.get("image_id_str") for f in test])
+    if test:
+        f = test[0]
+        to, td = get_ray_values_tigre(f["theta"], f["phi"], f["larm"], info, device)
+        img = denormalize_image(np.load(f["file_path"]), W, H, f["img_min_max"])
+        out.test_origins = torch.as_tensor(np.asarray(to), dtype=torch.float32).reshape(-1, 3).to(device)       # torch.Tensor(...) of the reference: f32
+        out.test_directions = torch.as_tensor(np.asarray(td), dtype=torch.float32).reshape(-1, 3).to(device)
+        out.test_image = torch.as_tensor(np.asarray(img), dtype=torch.float32).reshape(-1).to(device)
+        out.test_phase = int(f["heart_phase"])
+    return out
+
+
 def create_depth_values(near_thresh, far_thresh, depth_samples_per_ray_coarse, device):
     """data_helpers.py:167-171."""
     t = torch.linspace(0.0, 1.0, depth_samples_per_ray_coarse)

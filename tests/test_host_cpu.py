@@ -308,3 +308,71 @@ def test_three_way_bf16_split_is_exact_and_accurate():
     err6 = np.abs(six - exact).max() / np.abs(exact).max()
     err32 = np.abs((a.T @ b).astype(np.float64) - exact).max() / np.abs(exact).max()
     assert err6 < 2e-7 and err6 <= err32
+
+
+def test_on_disk_schema_loader_and_log_records(tmp_path):
+    """The loop glue of train/run_composite.py:65-125 from the reference's on-disk schema (general.json, train-*.json, test-*.json,
+    .npy images): ray table / phases as prepare_data_for_loader_tigre builds them, the variance-ray split of the importance sampler
+    (:97-99), one held-out view; and the reference's log keys (:314-344, :393-404) as JSON lines."""
+    import json
+    from types import SimpleNamespace
+    from nerfca_amd import synthetic
+    from nerfca_amd.train import data_helpers as DH
+    from nerfca_amd.train import run_log as RL
+    W = H = 6
+    geo = synthetic.xcat_geometry(W)
+    geo = {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in geo.items()}
+    geo["nDetector"] = [W, H]
+    rng = np.random.default_rng(0)
+    frames = []
+    for i, (theta, phi, ph) in enumerate([(0.1, 0.2, 0), (0.1, 0.2, 4), (1.3, -0.4, 7)]):
+        img = rng.random((W * H,))
+        wgt = 1.0 + rng.random((W * H,)) * (i > 0)             # the first image has no high-variance rays
+        np.save(tmp_path / f"img{i}.npy", img)
+        np.save(tmp_path / f"w{i}.npy", wgt)
+        frames.append({"theta": theta, "phi": phi, "larm": 0, "file_path": str(tmp_path / f"img{i}.npy"), "weighted_file_path": str(tmp_path / f"w{i}.npy"),
+                       "img_min_max": [0.0, 2.0], "heart_phase": ph, "image_id_str": f"im{i}"})
+    (tmp_path / "general.json").write_text(json.dumps(geo))
+    (tmp_path / "train.json").write_text(json.dumps({"frames": frames[:2]}))
+    (tmp_path / "test.json").write_text(json.dumps({"frames": frames[2:] + frames[:1]}))
+    args = SimpleNamespace(depth_samples_per_ray_coarse=8, weighted_loss_max=1.0, var_sample_thre=3.0)
+    d = DH.load_training_data(str(tmp_path / "general.json"), str(tmp_path / "train.json"), str(tmp_path / "test.json"), args, "cpu")
+    rays, phases = DH.prepare_data_for_loader_tigre(frames[:2], geo, W, H, 8, 1.0, "cpu")
+    assert d.rays_train.dtype == torch.float64 and tuple(d.rays_train.shape) == (2 * W * H, 4, 3)
+    assert np.array_equal(d.rays_train.numpy(), rays) and np.array_equal(d.phases_train.numpy(), phases)
+    assert np.array_equal(d.var_ray_ids, np.argwhere(rays[:, -1, 0] > 1.03).flatten()) and d.var_ray_ids.min() >= W * H
+    assert len(d.var_ray_ids) + len(d.non_var_ray_ids) == 2 * W * H and np.intersect1d(d.var_ray_ids, d.non_var_ray_ids).size == 0
+    assert d.test_img_indices == ["im2"] and d.test_phase == 7 and tuple(d.test_origins.shape) == (W * H, 3) and d.test_origins.dtype == torch.float32
+    want = DH.denormalize_image(np.load(frames[2]["file_path"]), W, H, [0.0, 2.0]).reshape(-1)
+    assert np.allclose(d.test_image.numpy(), want.astype(np.float32))
+    # log records under the reference's keys
+    from nerfca_amd import _capi
+    from nerfca_amd.train.trainer import TrainConfig
+    tr = SimpleNamespace(cfg=TrainConfig(), s=SimpleNamespace(windowed_alpha=6.0), t=SimpleNamespace(windowed_alpha=5.5))
+    tr.loss_weights = lambda n: (1e-12, 1e-10, 1e-8, 1e-8)
+    terms = torch.arange(1, 14, dtype=torch.float64) * 1e-3
+    rec = RL.train_record(tr, 100, terms, start_time=0.0)
+    ref_keys = {"train_loss", "train_psnr", "train_pixel_loss_coarse", "train_pixel_loss_fine", "train_blendw", "train_sigma_s_max", "train_sigma_d_max",
+                "train_favor_s_loss", "train_s_entropy_loss", "train_d_entropy_loss", "train_s_entropy_sum", "train_d_entropy_sum", "train_d_occl_loss",
+                "train_s_l1", "train_s_l2", "favor_s_weight", "dynamic_entro_weight", "occl_weight", "l1_weight", "train_time", "train_static_windowed",
+                "train_temp_windowed"}
+    assert set(rec) == ref_keys
+    assert rec["train_loss"] == 1e-3 and abs(rec["train_psnr"] - 30.0) < 1e-9 and rec["train_d_entropy_loss"] == terms[_capi.TERM_NAMES.index("d_entropy")]
+    log = RL.JsonlLogger(str(tmp_path / "log.jsonl"))
+    log.log(rec, step=100)
+    log.log(RL.test_record({k: torch.tensor(0.5) for k in ("test_loss", "test_psnr", "test_pixel_loss_coarse", "test_favor_s_loss", "test_blendw",
+                                                          "test_s_entropy_loss", "test_d_entropy_loss", "pred")}), step=100)
+    lines = [json.loads(l) for l in (tmp_path / "log.jsonl").read_text().splitlines()]
+    assert len(lines) == 2 and lines[0]["step"] == 100 and set(lines[1]) == {"test_loss", "test_psnr", "test_pixel_loss_coarse", "test_favor_s_loss",
+                                                                              "test_blendw", "test_s_entropy_loss", "test_d_entropy_loss", "step"}
+
+
+def test_shipped_library_is_not_a_timing_build():
+    """tools/elim_build.sh makes libraries whose kernels leave work out (NCA_EXP != 0: results wrong by construction, timing only).
+    The library the package loads must be the product build."""
+    from nerfca_amd import _capi
+    info = _capi.build_info()
+    assert "NCA_EXP=0" in info and f"abi={_capi.ABI_VERSION}" in info and "gfx950" in info, info
+    assert _capi.get_option(_capi.OPT_STAGE_FP8) in (-1, 0, 1) and _capi.get_option(_capi.OPT_STAGE_FP8_MIN_TILES) >= 0
+    with pytest.raises(_capi.NcaError):
+        _capi.get_option(99)
