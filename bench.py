@@ -58,8 +58,8 @@ PROFILE_TAGS = ("r03", "r02", "r01")          # committed PMC summaries, newest 
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50, help="timed steps (SURVEY.md 8d: >= 50 steady-state steps after 10 warm-up)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--rays", type=int, default=65536, help="rays per step per GPU (one full 256^2 detector)")
     ap.add_argument("--det", type=int, default=256)
     ap.add_argument("--samples", type=int, default=192)
@@ -76,7 +76,7 @@ def parse(argv=None):
     ap.add_argument("--unfused-gpu-steps", type=int, default=3)
     ap.add_argument("--f32-steps", type=int, default=20, help="timed steps of the f32 sub-record (after --f32-warmup; 0: skip)")
     ap.add_argument("--f32-warmup", type=int, default=5)
-    ap.add_argument("--pure-steps", type=int, default=8, help="timed steps of the bf16_pure sub-record (bf16 staging; 0: skip)")
+    ap.add_argument("--pure-steps", type=int, default=20, help="timed steps of the bf16_pure sub-record (bf16 staging; 0: skip)")
     ap.add_argument("--sustained-steps", type=int, default=500, help="further graph steps after the timed region; the last 100 are timed (0: skip)")
     ap.add_argument("--kernel-steps", type=int, default=8, help="steps of the eager pass that times the kernels")
     ap.add_argument("--psnr-steps", type=int, default=100, help="steps of the PSNR record (64^2 detector, 256 rays/step; 0: skip)")
@@ -289,6 +289,15 @@ def roofline_of(args, prec, kern, eager_dt, plan):
             roof["mfma"] = {"achieved": wg["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": wg["tflops"] / peak}
         else:
             roof["bwd_wgrad_roofline"] = hbm
+    # every large kernel against its own bound, whichever is the largest this run (forward and weight gradient trade places from
+    # box to box): the fused kernels against the dense MFMA peak, the fp8-staged weight gradient against HBM
+    roof["per_kernel"] = {k: {"bound": "mfma", "achieved": kern[k]["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": kern[k]["tflops"] / peak if kern[k]["tflops"] else None,
+                              "avg_launch_ms": kern[k]["avg_ms"], "ms_per_step": kern[k]["ms_per_step"],
+                              "traffic": traffic_rec["kernels"][k]["hbm_bytes_per_launch"] if traffic_rec and k in traffic_rec.get("kernels", {}) else None}
+                          for k in ("fwd", "bwd_dgrad", "bwd_wgrad")}
+    if prec == "bf16" and fp8 and wg["avg_ms"]:
+        roof["per_kernel"]["bwd_wgrad"].update({"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
+                                                "mfma_frac": wg["tflops"] / peak})
     if prec == "f32":      # the pipe the f32 mode's hidden-layer contractions really run on
         roof["frac_of_bf16_pipe_div_6"] = kern[dom]["tflops"] / PEAK_F32_ON_BF16_PIPE if kern[dom]["tflops"] else None
     return roof

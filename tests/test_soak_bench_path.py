@@ -257,10 +257,21 @@ def test_fp8_stage_at_natural_resident_threshold_vs_oracle(dev):
         p1, a1, b1, g1 = _hip_grads(s, t, dev, o, d, ph, I0, z, dists, cp, cs, cd)
     assert torch.equal(pr, p1) and torch.equal(ar, a1) and torch.equal(br, b1)
     assert rel_err(ar.cpu(), a) < BF_OUT and rel_err(br.cpu(), b) < BF_OUT
-    worst = 0.0
+    worst = worst_l2 = worst_scale = 0.0
     for k in go:
         assert torch.equal(gr[k], g1[k]), k
         e = rel_err(gr[k].cpu(), go[k])
         worst = max(worst, e)
         assert e < BF_GRAD, (k, e)
-    print(f"fp8 staging, resident plan at {R} x {S}: worst gradient distance from the emulating oracle {worst:.2e}")
+        # Beyond the max-norm: over a million samples the roundings the oracle does not share (summation order, a few ReLU mask
+        # flips) average out, so a SYSTEMATIC error -- a layer's gradient scaled by 1 - 2 %, a dropped block -- shows in the
+        # projection of the kernel's gradient on the oracle's and in the relative L2 distance even where the max-norm hides it
+        x, y = gr[k].detach().cpu().double().flatten(), go[k].detach().double().flatten()
+        if y.numel() >= 64:
+            scale = float((x * y).sum() / (y * y).sum())
+            l2 = float((x - y).norm() / y.norm())
+            worst_l2, worst_scale = max(worst_l2, l2), max(worst_scale, abs(scale - 1.0))
+            assert abs(scale - 1.0) < 5e-3, (k, scale)
+            assert l2 < 2e-2, (k, l2)
+    print(f"fp8 staging, resident plan at {R} x {S}: worst gradient distance from the emulating oracle {worst:.2e} (max-norm), {worst_l2:.2e} (relative L2), "
+          f"projection coefficient within {worst_scale:.2e} of 1")

@@ -8,8 +8,8 @@ PREC=${1:-bf16}
 OUT=gpurun_out/prof_$PREC${2:-}
 mkdir -p $OUT
 export TMPDIR=/tmp
-STEPS=8; [ "$PREC" = f32 ] && STEPS=4
-python3 bench.py --prec $PREC --steps $STEPS --warmup 2 --no-extras --pure-steps 0 > $OUT/bench.json 2> $OUT/bench.err
+STEPS=20; [ "$PREC" = f32 ] && STEPS=8
+python3 bench.py --prec $PREC --steps $STEPS --warmup 3 --no-extras --pure-steps 0 > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --prec $PREC --steps 6 --warmup 2 --no-cpu-baseline --no-extras --eager > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -- python3 bench.py --prec $PREC --steps 2 --warmup 1 --no-cpu-baseline --no-extras --eager > /dev/null 2> $OUT/pmc_$C.err
