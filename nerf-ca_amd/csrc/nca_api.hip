@@ -83,6 +83,10 @@ int num_cus() {
         hipDeviceProp_t p;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
         if (n <= 0) n = 256;
+        // (experiments only: NCA_CUS=<k> sizes every persistent grid for k compute units -- how the kernels scale with the part of the
+        // chip they occupy tells a per-CU bound from a chip-wide one)
+        const char* e = getenv("NCA_CUS");
+        if (e && atoi(e) > 0 && atoi(e) < n) n = atoi(e);
     }
     return n;
 }

@@ -150,6 +150,7 @@ __device__ __forceinline__ unsigned mask8(const unsigned (&w)[8]) {
         : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "s"(0x00010001u));
     return f;
 }
+
 __device__ __forceinline__ void s8_mode() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1"); }
 
 __device__ __forceinline__ float bf_lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
@@ -327,6 +328,7 @@ constexpr int NCA_BF_RING = 4;
 #ifndef NCA_BF_PIPE
 #define NCA_BF_PIPE 0
 #endif
+
 // Two A/B experiments on how the two waves of a SIMD share it, both measured at the bench size and removed again (round 3):
 // s_setprio 1 around the 16 MFMAs of a row tile (so that they win the issue port against the partner's epilogue): forward 4.75 ->
 // 4.60 / 4.75 ms in two runs, backward 3.68 -> 3.64 / 3.67 -- inside the run-to-run spread; an advisory LDS lock per SIMD that lets
@@ -338,6 +340,10 @@ constexpr int NCA_BF_RING = 4;
 // the H stores compiled out.  Two instruction orders that differ this much and cost the same, and elimination builds whose savings ADD
 // (MFMAs 0.76 + stores 0.65 + mask / 8-bit conversion 0.35 + the rest 0.69 = the kernel's 2.45 ms, profiles/r02_elimination_builds.txt),
 // are what a power cap looks like: time = energy / cap, whatever overlaps.  What is left is fewer instructions and fewer bytes.
+// The per-wave timeline (NCA_EXP 8388608: s_memtime around the MFMA block and the epilogue of every row tile, profiles/r03_timeline.txt)
+// shows where a wave's cycles go: an undisturbed MFMA block of a hidden layer takes 650 - 750 cycles (16 MFMAs = 512), an undisturbed
+// epilogue 530 - 620 (80 vector instructions: 64 x 4.4 + 16 x 8.3 cycles of SIMD time), and on average each takes 1.5 - 2 x that because
+// the SIMD's other wave is executing one or the other -- two waves share a SIMD serially.
 // (profiles/r03_valu_mfma_samewave.txt has the issue costs of the epilogue's own instructions: the packed 16-bit ones and v_lshl_or
 // 4.4 cycles of SIMD time each also with two waves per SIMD, v_cvt_scalef32_pk_{fp8,bf8}_bf16 8.3)
 static_assert(NCA_BF_PF >= 1 && NCA_BF_PF < NCA_BF_RING, "prefetch distance must fit the ring");
@@ -541,6 +547,17 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
 #else
 #define NCA_STAMP(k)
 #endif
+#if NCA_EXP & 8388608
+    // (8388608: timeline of one tile -- s_memtime before / after the MFMA block and after the epilogue of every row tile of the hidden
+    // layers, for each wave of workgroup 0, in the LDS left over behind the resident images; printed at the end with the SIMD each wave
+    // ran on: how the two waves of a SIMD really interleave)
+    unsigned long long* const tl_buf = reinterpret_cast<unsigned long long*>(smem + a.ctr_off + 16) + wave * 36;
+    int tl_n = 0;
+    bool tl_on = false;
+#define NCA_TL() { if (tl_on && tl_n < 36 && lane == 0) tl_buf[tl_n] = __builtin_readcyclecounter(); if (tl_on) ++tl_n; }
+#else
+#define NCA_TL()
+#endif
     const int64_t ngroups = (a.ntiles + NCA_WAVES - 1) / NCA_WAVES;
     // This workgroup's tiles: groups blockIdx.x, blockIdx.x + gridDim.x, ... of 8.  Streaming kernels: wave w takes tile w of every
     // group (the waves meet at every stage's barrier anyway).  Resident images: no barrier couples the waves, and the second wave
@@ -563,6 +580,10 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
             grp = blockIdx.x + it * gridDim.x;
             if (grp >= ngroups) break;
         }
+#if NCA_EXP & 8388608
+        tl_on = RES && blockIdx.x == 0 && it == 3;
+        tl_n = 0;
+#endif
         const int64_t tile = grp * NCA_WAVES + wslot;          // 64-sample tile
         const bool tvalid = tile < a.ntiles;
         const int64_t tl = tvalid ? tile : a.ntiles - 1;
@@ -903,11 +924,15 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                                   : ONCHIP ? *reinterpret_cast<const u32x4*>(hl + c * a.rows_total + k * 1024) : load_nt(hl + c * a.rows_total + k * 1024);
             }
             for (int jj = NR ? y.NL : (STORED ? y.NL - 1 : 0); jj < y.NL; ++jj) {
-                const NcaLayerL& l = y.layer[jj];
                 const int nsi = (si + 1 == a.nstages) ? 0 : si + 1;
                 if (!RES && !(NCA_EXP & 8)) stage_issue_b(a.stage[nsi], smem + (cur ^ 1) * BUF, wave, lane);
-                const char* img = RES ? smem + a.stage[si].lds_off : smem + cur * BUF;
-                const int nks = l.ksteps;
+                // Resident images: the layer's image offset and k-step count follow from the width alone (build_stages lays the forward
+                // images of the launch's one net back to back: layer 0, then the hidden-width layers; nca_build_layout_bf16).  Read from
+                // the argument block instead -- y.layer[jj], a.stage[si] with run-time indices -- they were two dependent scalar loads
+                // from memory at every layer boundary of every tile, ~1 500 cycles per boundary in the timeline (NCA_EXP 8388608)
+                constexpr int IMG0 = MT * KS0 * 1024 + 2 * MT * 16 * 4, IMGH = MT * KS * 1024 + 2 * MT * 16 * 4;
+                const char* img = (RES && !STORED) ? smem + (jj == 0 ? 0 : IMG0 + (jj - 1) * IMGH) : (RES ? smem + a.stage[si].lds_off : smem + cur * BUF);      // (mode 3 resident: the one recomputed layer's image comes first)
+                const int nks = jj == 0 ? KS0 : KS;
                 const float* tail = reinterpret_cast<const float*>(img + MT * nks * 1024);
                 const bool last = jj == y.NL - 1;
                 const bool h8 = S8 && FSTORE;                                     // fp8 staging: the layer outputs go to the store as e4m3 (the last layer: its mask only)
@@ -1000,8 +1025,10 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                     f32x16 acc0, acc1;
 #pragma unroll
                     for (int i = 0; i < 16; ++i) { const float b = tail[(lh * MT + m) * 16 + i]; acc0[i] = b; acc1[i] = b; }
+                    NCA_TL()
                     if (!(NCA_EXP & 128)) mma_rowtile_ring<NKS, MT, KSMAX, RINGK>(imgl, m, A, B, acc0, acc1);
                     else { acc0[0] += __builtin_bit_cast(float, B[0][m][0]); acc1[3] += __builtin_bit_cast(float, B[1][m][1]); }       // (128: no MFMAs)
+                    NCA_TL()
                     if (NCA_BF_PIPE) {
                         if (m > 0) epilogue(m - 1, pend0, pend1);
                         pend0 = acc0; pend1 = acc1;
@@ -1009,6 +1036,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                         epilogue(m, acc0, acc1);
                         __builtin_amdgcn_sched_barrier(0);       // one row tile at a time: without the fence the scheduler overlaps row tiles and spills
                     }
+                    NCA_TL()
                 }
                 if (NCA_BF_PIPE) epilogue(MT - 1, pend0, pend1);
                 };
@@ -1186,7 +1214,8 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                         if (jj >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST + 1) : "memory");
                         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
                     }
-                    const char* img = RES ? smem + a.stage[si].lds_off : smem + cur * BUF;
+                    // (resident: the transposed images of layers NL-1 .. 1 back to back, one per sweep step -- see the forward)
+                    const char* img = (RES && NR) ? smem + si * (MT * KS * 1024) : (RES ? smem + a.stage[si].lds_off : smem + cur * BUF);
                     const char* const hblk = nb + EB + (jj - 1) * HB;                       // input of layer jj (mask)
                     char* const dblk = db + nca_bf_doff(y, jj - 1, S8 && STORED);            // D_{jj-1}
                     const bool wr_d = tvalid;
@@ -1345,6 +1374,12 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
             *dst = a.accumulate ? *dst + s : s;
         }
     }
+#if NCA_EXP & 8388608
+    if (RES && blockIdx.x == 0 && lane == 0 && (MODE == NCA_KM_FWD_STORE)) {
+        const unsigned simd = __builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11)) & 3;
+        for (int i = 0; i < 36; ++i) printf("TL %d %d %u %d %llu\n", (int)a.net_base, wave, simd, i, tl_buf[i]);
+    }
+#endif
 #if NCA_EXP & 65536
     if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 131)) {
         const unsigned long long dt = __builtin_readcyclecounter() - clk_t0, dr = __builtin_amdgcn_s_memrealtime() - clk_r0;
@@ -1860,6 +1895,7 @@ static hipError_t launch_fused_bf_mode(const NcaFusedArgs& a, int grid, hipStrea
         b = a;
         b.ctr_off = (int32_t)lds;            // the workgroup's tile counter
         lds += 16;
+        if ((NCA_EXP & 8388608) && MODE == NCA_KM_FWD_STORE && lds + NCA_WAVES * 36 * 8 <= (size_t)NCA_LDS_BYTES) lds += NCA_WAVES * 36 * 8;
         pa = &b;
         const size_t dma_end = (size_t)a.stage[a.nstages - 1].lds_off + a.stage[a.nstages - 1].bytes;       // whole 1 KiB pieces
         if (dma_end > lds) lds = dma_end;
