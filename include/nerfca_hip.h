@@ -202,6 +202,11 @@ typedef struct NcaLoss {
     int32_t unit_mse;        /* 1: the pixel term uses unit weights while the regularisers keep `wpix` -- the fine pass's
                                 weighted_pixs_ones (train/run_composite.py:296-299)                                      */
     int32_t reserved;
+    double* g_dists;         /* NULL, or DEVICE f64[S]: d loss / d dists -- through the ray sums pix = I0 - sum sigma dists (given the
+                                pixel term of THIS call) and through every regulariser that contains sigma * dists.  The reference's
+                                fine pass differentiates through the interval lengths of ray 0 (train/model_helpers.py:150); needs the
+                                three gradient outputs and `dists_work`                                                    */
+    double* dists_work;      /* DEVICE f64[R * S] scratch for g_dists (per-ray contributions, summed over rays in a fixed order) */
 } NcaLoss;
 enum { NCA_T_LOSS = 0, NCA_T_PIXEL, NCA_T_BLENDW, NCA_T_SIG_S_MAX, NCA_T_SIG_D_MAX, NCA_T_FAVOR, NCA_T_S_ENTROPY, NCA_T_S_SUM,
        NCA_T_D_ENTROPY, NCA_T_D_SUM, NCA_T_OCCL, NCA_T_L1, NCA_T_L2, NCA_T_COUNT };

@@ -45,7 +45,8 @@ class NcaRays(C.Structure):
 class NcaLoss(C.Structure):
     _fields_ = [("R", C.c_int64), ("S", C.c_int32), ("use_weighting", C.c_int32), ("skew", C.c_double), ("mask_thre", C.c_double),
                 ("weighted_thresh", C.c_double), ("w_favor", C.c_double), ("w_dent", C.c_double), ("w_occl", C.c_double),
-                ("w_l1", C.c_double), ("inv_R", C.c_double), ("weights_dev", C.c_void_p), ("unit_mse", C.c_int32), ("reserved", C.c_int32)]
+                ("w_l1", C.c_double), ("inv_R", C.c_double), ("weights_dev", C.c_void_p), ("unit_mse", C.c_int32), ("reserved", C.c_int32),
+                ("g_dists", C.c_void_p), ("dists_work", C.c_void_p)]
 
 
 class NcaAdam(C.Structure):

@@ -1241,6 +1241,9 @@ extern "C" int nca_loss_fwd_bwd(const NcaLoss* d, const double* pix, const doubl
     a.pix = pix; a.gt = gt; a.wpix = wpix; a.sig_s = sig_s; a.sig_d = sig_d; a.dists = dists;
     a.terms = terms; a.g_pix = g_pix; a.g_sig_s = g_sig_s; a.g_sig_d = g_sig_d;
     a.partials = static_cast<double*>(work);
+    if (d->g_dists && !(any && d->dists_work)) return fail(NCA_E_INVALID, "g_dists needs the three gradient outputs and dists_work (f64[R * S])");
+    a.g_dists = d->g_dists;
+    a.dists_work = d->g_dists ? d->dists_work : nullptr;
     Span sp(NCA_K_LOSS, (hipStream_t)stream);
     HIPCHK(nca_launch_loss(a, (hipStream_t)stream));
     return NCA_OK;

@@ -179,6 +179,8 @@ struct NcaLossArgs {
     const float* sig_s; const float* sig_d; const double* dists;
     double* terms; double* g_pix; float* g_sig_s; float* g_sig_d;
     double* partials;
+    double* g_dists;      // [S] or null
+    double* dists_work;   // [R * S] per-ray d loss / d dists
 };
 struct NcaCompositeArgs {
     int64_t R;

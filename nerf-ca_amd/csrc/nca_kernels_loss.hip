@@ -134,6 +134,12 @@ __global__ __launch_bounds__(LOSS_NT) void nca_loss_rays(const NcaLossArgs a) {
                 const double g_s_l = w_l1 * (dl + 2.0 * (double)vs * dl * dl);
                 gs[s] = g_s_f + (float)g_s_l;
                 gd[s] = g_d_f + (float)(g_d_e + g_d_o);
+                // d loss / d dists[s] of this ray: every term above reaches dists through m = sigma * dists (swap the factor), the
+                // pixel term through pix = I0 - sum (sigma_s + sigma_d) dists
+                if (a.dists_work)
+                    a.dists_work[r * a.S + s] = -(2.0 * wm * diff * a.inv_R) * ((double)vs + (double)vd)
+                                                + escale * (double)vd * (-q + (unclipped ? qp : 0.0)) + w_occl * a.inv_R * (double)vd
+                                                + w_l1 * ((double)vs + 2.0 * (double)vs * (double)vs * dl);
             };
 #pragma unroll
             for (int j = 0; j < QKEEP; ++j)
@@ -225,10 +231,27 @@ __global__ __launch_bounds__(LOSS_FIN_NT) void nca_loss_finish(const NcaLossArgs
     }
 }
 
+// g_dists[s] = sum over rays of the per-ray contributions, one block per sample index, fixed order (thread t takes rays t, t + 256, ...;
+// then a fixed tree)
+__global__ __launch_bounds__(256) void nca_loss_dists_sum(const NcaLossArgs a) {
+    __shared__ double sh[256];
+    const int s = blockIdx.x;
+    double v = 0.0;
+    for (int64_t r = threadIdx.x; r < a.R; r += 256) v += a.dists_work[r * a.S + s];
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.g_dists[s] = sh[0];
+}
+
 hipError_t nca_launch_loss(const NcaLossArgs& a, hipStream_t st) {
     const int nblocks = (int)((a.R + LOSS_WAVES - 1) / LOSS_WAVES);
     hipLaunchKernelGGL(nca_loss_rays, dim3(nblocks), dim3(LOSS_NT), 0, st, a);
     hipLaunchKernelGGL(nca_loss_finish, dim3(1), dim3(LOSS_FIN_NT), 0, st, a, nblocks);
+    if (a.g_dists) hipLaunchKernelGGL(nca_loss_dists_sum, dim3(a.S), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

@@ -357,7 +357,8 @@ class _RenderFn(torch.autograd.Function):
         return (None, None, None, None, g_z, g_dists, *out)
 
 
-def fused_losses(pix, gt, wpix, sig_s, sig_d, dists, run_args, weights, inv_R=None, want_grads=True, weights_dev=None, unit_mse=False):
+def fused_losses(pix, gt, wpix, sig_s, sig_d, dists, run_args, weights, inv_R=None, want_grads=True, weights_dev=None, unit_mse=False,
+                 want_dists_grad=False):
     """weighted MSE + compute_losses + the loss assembly of run_composite.py:287-292 in one HIP pass.
 
     ``weights`` = (favor_s_weight, dynamic_entro_weight, occl_weight, l1_weight) of this step.
@@ -365,7 +366,8 @@ def fused_losses(pix, gt, wpix, sig_s, sig_d, dists, run_args, weights, inv_R=No
     ``_capi.TERM_NAMES`` for the order of ``terms``.  ``inv_R`` = 1 / global ray count (default 1/R).
     ``weights_dev`` (device f64[4]) replaces ``weights`` with values the kernels read at run time, which is
     what a captured HIP graph needs.  ``unit_mse``: the pixel term uses unit weights while the regularisers keep
-    ``wpix`` (the fine pass's ``weighted_pixs_ones``, run_composite.py:296-299).
+    ``wpix`` (the fine pass's ``weighted_pixs_ones``, run_composite.py:296-299).  ``want_dists_grad``: a fifth return value,
+    d loss / d dists f64[S] (the fine pass differentiates through ray 0's interval lengths, model_helpers.py:150).
     """
     lib = _capi.lib()
     _require_cuda(sig_s, "sigma")
@@ -377,7 +379,8 @@ def fused_losses(pix, gt, wpix, sig_s, sig_d, dists, run_args, weights, inv_R=No
     desc = _capi.NcaLoss(R=R, S=S, use_weighting=1 if run_args.entro_use_weighting else 0, skew=float(run_args.skewness_val),
                          mask_thre=float(run_args.entro_mask_thre), weighted_thresh=float(run_args.entro_weighted_thresh),
                          w_favor=float(weights[0]), w_dent=float(weights[1]), w_occl=float(weights[2]), w_l1=float(weights[3]),
-                         inv_R=float(inv_R if inv_R is not None else 1.0 / R), weights_dev=None, unit_mse=1 if unit_mse else 0, reserved=0)
+                         inv_R=float(inv_R if inv_R is not None else 1.0 / R), weights_dev=None, unit_mse=1 if unit_mse else 0, reserved=0,
+                         g_dists=None, dists_work=None)
     if weights_dev is not None:
         if weights_dev.dtype != torch.float64 or weights_dev.numel() != 4 or not weights_dev.is_cuda or not weights_dev.is_contiguous():
             raise _capi.NcaError("weights_dev must be a contiguous device f64[4]")
@@ -390,8 +393,17 @@ def fused_losses(pix, gt, wpix, sig_s, sig_d, dists, run_args, weights, inv_R=No
         g_d = torch.empty((R, S), dtype=torch.float32, device=dev)
     wbytes = check(lib.nca_loss_workspace(R))
     work = _scratch(wbytes, dev)
+    g_dists = dwork = None
+    if want_dists_grad:
+        if not want_grads:
+            raise _capi.NcaError("want_dists_grad needs want_grads")
+        g_dists = torch.empty(S, dtype=torch.float64, device=dev)
+        dwork = _scratch(R * S * 8, dev)
+        desc.g_dists, desc.dists_work = ptr(g_dists), ptr(dwork)
     check(lib.nca_loss_fwd_bwd(C.byref(desc), ptr(pix), ptr(gt), ptr(wpix), ptr(ss), ptr(sd), ptr(dists), ptr(terms),
                                ptr(g_pix), ptr(g_s), ptr(g_d), ptr(work), wbytes, _stream()))
+    if want_dists_grad:
+        return terms, g_pix, g_s, g_d, g_dists
     return terms, g_pix, g_s, g_d
 
 

@@ -381,13 +381,8 @@ class CompositeTrainer:
         o, d, gt, w = rays[:, 0, :], rays[:, 1, :], rays[:, 2, 0], rays[:, 3, 0]
         dists = MH._interval_lengths(z, d)
         bs, bd, bsf, bdf = self.s._binding, self.t._binding, self.s_fine._binding, self.t_fine._binding
-        if weights_dev is not None:
-            fav_w, ent_w, occ_w, l1_w = weights_dev[0], weights_dev[1], weights_dev[2], weights_dev[3]
-        else:
-            fav_w, ent_w, occ_w, l1_w = weights
         sharded = self.world > 1
         red = _MaxReducer() if sharded else None
-        depth_grads = c.fine_depth_gradients is None or c.fine_depth_gradients
         I0 = self.I0[:n_loc]
         # coarse pass (the whole local batch: the sampler normalises by the batch-wide maximum)
         batch = _RayBatch(o, d, phases, I0, z, dists, c.output_activation, False, 1e-2)
@@ -401,22 +396,18 @@ class CompositeTrainer:
         dists_f = MH._interval_lengths(z0, d)
         batch_f = _RayBatch(o, d, phases, I0, z_all, dists_f, c.output_activation, False, 1e-2)
         pix_f, sig_sf, sig_df, keep_f = render_forward_raw(batch_f, bsf, bdf, for_backward=True)
-        terms_f, g_pix_f, g_sf, g_df = fused_losses(pix_f, gt, w, sig_sf, sig_df, dists_f, c, weights, inv_R=1.0 / R, unit_mse=True, weights_dev=weights_dev)
+        depth_grads = c.fine_depth_gradients is None or c.fine_depth_gradients
+        # (with depth gradients the loss kernel also returns d loss / d (ray 0's interval lengths): through the ray sums
+        # pix = I0 - sum sigma dists and through the regularisers, all of which contain sigma * dists)
+        lf = fused_losses(pix_f, gt, w, sig_sf, sig_df, dists_f, c, weights, inv_R=1.0 / R, unit_mse=True, weights_dev=weights_dev,
+                          want_dists_grad=depth_grads)
+        terms_f, g_pix_f, g_sf, g_df = lf[:4]
         res = render_backward_raw(batch_f, bsf, bdf, keep_f, g_pix_f, g_sf, g_df, want_depth_grad=depth_grads)
         grads_sf, grads_df = res[0], res[1]
         del keep_f
         if depth_grads:
             g_zall = res[2]
-            # d loss / d (ray 0's interval lengths): through the ray sums (pix = I0 - sum sigma dists) and through the regularisers
-            # (entropies, occlusion, l1 / l2 all contain sigma * dists; small torch ops on [r, S] tensors, autograd on dists only)
-            g_dists = -(g_pix_f[:, None] * (sig_sf + sig_df).double()).sum(0)
-            dv = dists_f.detach().clone().requires_grad_(True)
-            with torch.enable_grad():
-                tf = LS.all_terms(sig_sf, sig_df, dv, w, c)
-                share = n_loc / R
-                reg = (fav_w * tf[3] + ent_w * tf[6] + occ_w * tf[8]) * share + l1_w * tf[10] + l1_w * tf[9]
-                (g_reg,) = torch.autograd.grad(reg, dv)
-            g_dists = g_dists + g_reg.to(g_dists.dtype)
+            g_dists = lf[4]
             g_z0 = torch.zeros_like(z0, dtype=torch.float64)               # dists = cat(z0[1:] - z0[:-1], [1e-10])
             g_z0[1:] += g_dists[:-1]
             g_z0[:-1] -= g_dists[:-1]

@@ -446,6 +446,36 @@ def test_fused_loss_kernel_vs_reference(golden, dev, dtn):
     assert rel_err(g_s.cpu(), ao.grad) < TOL and rel_err(g_d.cpu(), bo.grad) < TOL
 
 
+@pytest.mark.parametrize("dtn", ["f64", "f32"])
+@pytest.mark.parametrize("unit_mse", [False, True])
+def test_fused_loss_kernel_dists_gradient(golden, dev, dtn, unit_mse):
+    """d loss / d dists of nca_loss_fwd_bwd (the reference's fine pass differentiates through ray 0's interval lengths,
+    train/model_helpers.py:150): through pix = I0 - sum (sigma_s + sigma_d) dists and through every regulariser, against autograd
+    through the oracle's loss functions on the golden inputs."""
+    from types import SimpleNamespace
+    from nerfca_amd.fused import fused_losses
+    g = golden("losses")
+    args = SimpleNamespace(favor_s_opt=None, skewness_val=1.0, entro_mask_thre=1e-4, entro_use_weighting=True,
+                           entro_weighted_thresh=0.03, occl_reg_perc=0.2)
+    a, b = g[f"{dtn}_sig_s"], g[f"{dtn}_sig_d"]
+    dists, wpix = g[f"{dtn}_dists"], g[f"{dtn}_wpix"]
+    R = a.shape[0]
+    gen = torch.Generator().manual_seed(1)
+    gt = torch.randn(R, generator=gen).double()
+    I0 = torch.full((R,), 2.16, dtype=torch.float64)
+    weights = (0.7, 0.9, 0.5, 0.25)
+    do = dists.clone().double().requires_grad_(True)
+    pix = I0 - ((a + b).double() * do).sum(-1)
+    t = O.compute_losses(a, b, do, wpix, O.LossArgs())
+    wm = torch.ones_like(wpix).double() if unit_mse else wpix.double()
+    loss = O.weighted_mse(pix, gt, wm).mean() + weights[0] * t[3] + weights[1] * t[6] + weights[2] * t[8] + weights[3] * t[10] + weights[3] * t[9]
+    (gd_ref,) = torch.autograd.grad(loss, do)
+    out = fused_losses(pix.detach().to(dev), gt.to(dev), wpix.to(dev), a.to(dev), b.to(dev), dists.to(dev), args, weights, unit_mse=unit_mse,
+                       want_dists_grad=True)
+    assert abs(float(out[0][0]) - float(loss)) <= 2e-6 * abs(float(loss))
+    assert rel_err(out[4].cpu(), gd_ref) < TOL, rel_err(out[4].cpu(), gd_ref)
+
+
 def test_fused_step_equals_autograd_step(dev):
     """CompositeTrainer.step_fused (no autograd graph) and the autograd step produce the same update."""
     from nerfca_amd import synthetic
