@@ -244,6 +244,17 @@ int nca_fine_weight_max(int64_t R, int32_t S, const float* sig_s, const float* s
 int nca_fine_depths_given_max(int64_t R, int32_t S, int32_t n_fine, const float* sig_s, const float* sig_d, const float* z,
                               const float* u, const float* wmax, float* z_all, void* stream);
 
+/* ---- per-step batch preparation: the ray gather of train/run_composite.py:262-273 (rays_train[ids] split into origins, directions,
+ *      pixel values and loss weights; the rays' heart phases) and randomize_depth + the interval lengths of
+ *      train/model_helpers.py:3-12, 73-74, in one launch instead of ~20 small torch kernels.  Bit-exact with the torch ops:
+ *      z' = lo + (hi - lo) * t with mid = 0.5 * (z[1:] + z[:-1]) in f32; dists[i] = z'[i+1] - z'[i] (f32 subtraction, widened) and the
+ *      1e-10 tail in the ray table's dtype.
+ *      table f64[N,4,3] (rows: origin, direction, pixel x3, weight x3); phases i64[N]; ids i64[R] (0 <= id < N, not checked).
+ *      Outputs: o, d f64[R,3]; gt, w f64[R]; ph i32[R]; z f32[S]; dists f64[S].  depth / t_rand f32[S].  ------------------------------ */
+int nca_prepare_batch(int64_t R, int32_t S, const int64_t* ids, const double* table, const int64_t* phases,
+                      const float* depth, const float* t_rand,
+                      double* o, double* d, double* gt, double* w, int32_t* ph, float* z, double* dists, void* stream);
+
 /* ---- optimiser: torch.optim.Adam(lr) + LinearLR(start_factor=1, end_factor, total_iters) of
  *      train/run_composite.py:209-215, 307-308, as one launch over up to NCA_ADAM_MAX_SEG flat buffers.
  *      `step` is a DEVICE counter = optimiser steps taken so far: the kernel uses t = *step + 1 for the

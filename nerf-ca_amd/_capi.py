@@ -96,6 +96,7 @@ SYMBOLS = {
     "nca_fine_depths_bwd_max": (C.c_int, [_I64, _I32, _P, _P, _P, _P, _P, _P]),
     "nca_fine_weight_max": (C.c_int, [_I64, _I32, _P, _P, _P, _P, _I64, _P]),
     "nca_fine_depths_given_max": (C.c_int, [_I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _P]),
+    "nca_prepare_batch": (C.c_int, [_I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "nca_adam_step": (C.c_int, [C.POINTER(NcaAdam), _I32, C.POINTER(_I64), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P),
                                 _P, _P]),
     "nca_get_option": (C.c_int, [_I32, C.POINTER(_I64)]),

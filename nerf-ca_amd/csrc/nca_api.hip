@@ -1340,6 +1340,16 @@ extern "C" int nca_fine_depths_bwd_max(int64_t R, int32_t S, const float* sig_s,
     return NCA_OK;
 }
 
+// ---------------------------------------------------------------------------------- batch preparation
+extern "C" int nca_prepare_batch(int64_t R, int32_t S, const int64_t* ids, const double* table, const int64_t* phases,
+                                 const float* depth, const float* t_rand,
+                                 double* o, double* d, double* gt, double* w, int32_t* ph, float* z, double* dists, void* stream) {
+    if (R <= 0 || S <= 0) return fail(NCA_E_INVALID, "empty ray batch (R=%lld, S=%d)", (long long)R, S);
+    if (!ids || !table || !phases || !depth || !t_rand || !o || !d || !gt || !w || !ph || !z || !dists) return fail(NCA_E_INVALID, "a pointer is NULL");
+    HIPCHK(nca_launch_prepare_batch(R, S, ids, table, phases, depth, t_rand, o, d, gt, w, ph, z, dists, (hipStream_t)stream));
+    return NCA_OK;
+}
+
 // ---------------------------------------------------------------------------------- optimiser
 extern "C" int nca_adam_step(const NcaAdam* cfg, int32_t n_seg, const int64_t* n, float* const* params, const float* const* grads,
                              float* const* exp_avg, float* const* exp_avg_sq, int64_t* step, void* stream) {

@@ -201,6 +201,8 @@ struct NcaAdamArgs {
     int64_t* step;
 };
 hipError_t nca_launch_adam(const NcaAdamArgs& a, hipStream_t st);
+hipError_t nca_launch_prepare_batch(int64_t R, int S, const int64_t* ids, const double* table, const int64_t* phases, const float* depth, const float* t_rand,
+                                    double* o, double* d, double* gt, double* w, int32_t* ph, float* z, double* dists, hipStream_t st);
 struct NcaFineArgs {
     int64_t R;
     int32_t S, n_fine;

@@ -1182,6 +1182,10 @@ __global__ void nca_reduce_f32(const NcaReduceArgs a) {
     }
     for (; q < nsum; ++q) s8[0] += sp[(int64_t)q * stride];
     float r = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+    // the last F-wide layer under tail_from_sums: leave the sum over the splits in slab row 0 (this thread is the only reader of its
+    // column) -- nca_reduce_small_f32, launched next, forms dWo from S and s summed over the splits and reads 129 values per output
+    // instead of 129 x n_split (it was 83 us of one wave per output walking the slabs: as long at 1 024 rays per step as at 65 536)
+    if (tail_col && !rn.wslab) const_cast<float*>(a.slab)[rn.slab_off + le] = r;
     if (rn.tail_from_sums) {
         // the last F-wide layer's sums were formed without the factor Wo[f] of their output row (nca_layout.hpp)
         const int64_t F2 = (int64_t)rn.F * rn.F;
@@ -1214,15 +1218,13 @@ __global__ __launch_bounds__(256) void nca_reduce_small_f32(const NcaReduceArgs 
             if (rn.tail_from_sums && k < rn.F) {
                 // dWo[k] = sum_kk bf16(W[k][kk]) S[k][kk] + b[k] s[k], S and s summed over the splits (nca_layout.hpp); the forward
                 // multiplied with the bf16-rounded weights, so those are the ones the identity holds for
+                // (S[k][.] and s[k] summed over the splits sit in slab row 0: nca_reduce_f32 left them there)
                 const float* wrow = rn.params + rn.tl_w_off + (int64_t)k * rn.F;
-                for (int idx = lane; idx < a.n_split * rn.F; idx += 64) {
-                    const int w = idx / rn.F, kk = idx % rn.F;
+                for (int kk = lane; kk < rn.F; kk += 64) {
                     const float wq = __uint_as_float(((__float_as_uint(wrow[kk]) + 0x7fffu + ((__float_as_uint(wrow[kk]) >> 16) & 1u)) & 0xffff0000u));
-                    s = fmaf(wq, a.slab[(int64_t)w * a.slab_stride + rn.slab_off + rn.tl_w_off + (int64_t)k * rn.F + kk], s);
+                    s = fmaf(wq, a.slab[rn.slab_off + rn.tl_w_off + (int64_t)k * rn.F + kk], s);
                 }
-                float sb = 0.f;
-                for (int w = lane; w < a.n_split; w += 64) sb += a.slab[(int64_t)w * a.slab_stride + rn.slab_off + rn.tl_b_off + k];
-                s = fmaf(rn.params[rn.tl_b_off + k], sb, s);
+                if (lane == 0) s = fmaf(rn.params[rn.tl_b_off + k], a.slab[rn.slab_off + rn.tl_b_off + k], s);
             } else {
                 for (int w = lane; w < a.n_wg; w += 64) s += a.oslab[(int64_t)w * a.oslab_stride + net * (rn.F + 1) + k];
             }

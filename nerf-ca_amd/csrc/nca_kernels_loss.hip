@@ -369,6 +369,45 @@ hipError_t nca_launch_adam(const NcaAdamArgs& a, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Per-step batch preparation: gather of the sampled rays out of the resident table (run_composite.py:262-273) and the stratified
+// depth jitter with its interval lengths (model_helpers.py:3-12, 73-74).  Thread r copies ray ids[r]; the first S threads also
+// jitter one depth each.  Arithmetic in the reference's order and precision (the library is compiled with -ffp-contract=off).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nca_prepare_batch_k(int64_t R, int S, const int64_t* __restrict__ ids, const double* __restrict__ table,
+                                                           const int64_t* __restrict__ phases, const float* __restrict__ depth, const float* __restrict__ t_rand,
+                                                           double* __restrict__ o, double* __restrict__ d, double* __restrict__ gt, double* __restrict__ w,
+                                                           int32_t* __restrict__ ph, float* __restrict__ z, double* __restrict__ dists) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    auto jitter = [&](int k) {
+        // mid = 0.5 * (z[1:] + z[:-1]); hi = cat(mid, z[-1:]); lo = cat(z[:1], mid); z' = lo + (hi - lo) * t
+        const float hi = k + 1 < S ? __fmul_rn(0.5f, __fadd_rn(depth[k + 1], depth[k])) : depth[S - 1];
+        const float lo = k > 0 ? __fmul_rn(0.5f, __fadd_rn(depth[k], depth[k - 1])) : depth[0];
+        return __fadd_rn(lo, __fmul_rn(__fsub_rn(hi, lo), t_rand[k]));
+    };
+    if (i < S) {
+        const int k = (int)i;
+        const float zk = jitter(k);
+        z[k] = zk;
+        dists[k] = k + 1 < S ? (double)__fsub_rn(jitter(k + 1), zk) : 1e-10;
+    }
+    if (i < R) {
+        const int64_t id = ids[i];
+        const double* row = table + id * 12;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { o[i * 3 + c] = row[c]; d[i * 3 + c] = row[3 + c]; }
+        gt[i] = row[6];
+        w[i] = row[9];
+        ph[i] = (int32_t)phases[id];
+    }
+}
+hipError_t nca_launch_prepare_batch(int64_t R, int S, const int64_t* ids, const double* table, const int64_t* phases, const float* depth, const float* t_rand,
+                                    double* o, double* d, double* gt, double* w, int32_t* ph, float* z, double* dists, hipStream_t st) {
+    const int64_t n = R > S ? R : S;
+    hipLaunchKernelGGL(nca_prepare_batch_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, R, S, ids, table, phases, depth, t_rand, o, d, gt, w, ph, z, dists);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // Fine-pass depths (train/model_helpers.py:131-148 + sample_pdf 162-187): per ray, the jump of the total density
 // between neighbouring coarse samples -- normalised by the BATCH-wide maximum (:139) -- is the weight of the bin
 // between their mid-points; n_fine depths are drawn by inverse-transform sampling of that piecewise-constant pdf and

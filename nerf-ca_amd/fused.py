@@ -513,6 +513,31 @@ def fine_depths_autograd(sig_s, sig_d, z, u, reduce_max=None):
     return _FineDepthsFn.apply(sig_s, sig_d, z, u, reduce_max)
 
 
+def prepare_batch(ids: torch.Tensor, table: torch.Tensor, phases: torch.Tensor, depth: torch.Tensor, t_rand: torch.Tensor):
+    """The per-step ray gather (run_composite.py:262-273) and randomize_depth + interval lengths (model_helpers.py:3-12, 73-74) as ONE
+    launch: ``ids`` i64[R] into the resident f64 ray table [N,4,3] and its i64 phase vector -> ``(o, d f64[R,3], gt, w f64[R], ph
+    i32[R], z f32[S], dists f64[S])``.  Bit-identical to the torch ops it replaces."""
+    _require_cuda(table, "the ray table")
+    dev = table.device
+    if table.dtype != torch.float64 or table.dim() != 3 or tuple(table.shape[1:]) != (4, 3) or not table.is_contiguous():
+        raise _capi.NcaError("prepare_batch takes the f64 ray table [N, 4, 3]")
+    if phases.dtype != torch.int64 or ids.dtype != torch.int64 or not ids.is_contiguous() or not phases.is_contiguous():
+        raise _capi.NcaError("prepare_batch takes i64 ray ids and i64 phases")
+    R, S = ids.shape[0], depth.shape[0]
+    dep = depth.detach().to(device=dev, dtype=torch.float32).contiguous()
+    tr = t_rand.detach().to(device=dev, dtype=torch.float32).contiguous()
+    o = torch.empty((R, 3), dtype=torch.float64, device=dev)
+    d = torch.empty((R, 3), dtype=torch.float64, device=dev)
+    gt = torch.empty(R, dtype=torch.float64, device=dev)
+    w = torch.empty(R, dtype=torch.float64, device=dev)
+    ph = torch.empty(R, dtype=torch.int32, device=dev)
+    z = torch.empty(S, dtype=torch.float32, device=dev)
+    dists = torch.empty(S, dtype=torch.float64, device=dev)
+    check(_capi.lib().nca_prepare_batch(R, S, ptr(ids), ptr(table), ptr(phases), ptr(dep), ptr(tr), ptr(o), ptr(d), ptr(gt), ptr(w), ptr(ph), ptr(z),
+                                        ptr(dists), _stream()))
+    return o, d, gt, w, ph, z, dists
+
+
 class FusedAdam:
     """torch.optim.Adam(lr) + LinearLR(1 -> end_factor over total_iters) of run_composite.py:209-215 as ONE library
     launch over the flat parameter buffers of the given models (order as given).  The step counter lives on the

@@ -258,6 +258,20 @@ class CompositeTrainer:
         self._note_early_stop(n_iter, pair)
         return loss.detach(), pixel.detach(), terms
 
+    def _prepare(self, my: torch.Tensor, t_rand: torch.Tensor):
+        """This rank's rays of the step and the jittered depths: ``(o, d, gt, w, phases, z, dists)`` as run_composite.py:262-273 and
+        model_helpers.py:3-12, 73-74 build them -- one library launch on the GPU (fused.prepare_batch, bit-identical to the torch
+        operations below, tests/test_hip_parity.py), the torch operations elsewhere."""
+        rt, pt = self.data.rays_train, self.data.phases_train
+        if rt.is_cuda and rt.dtype == torch.float64 and pt.dtype == torch.int64 and rt.is_contiguous() and pt.dim() == 1 and my.dtype == torch.int64:
+            from ..fused import prepare_batch
+            return prepare_batch(my.contiguous(), rt, pt, self.depth, t_rand)
+        rays = rt.index_select(0, my)
+        phases = pt.index_select(0, my)
+        o, d, gt, w = rays[:, 0, :], rays[:, 1, :], rays[:, 2, 0], rays[:, 3, 0]
+        z = MH.randomize_depth(self.depth, self.device, t_rand)
+        return o, d, gt, w, phases, z, MH._interval_lengths(z, d)
+
     def fused_gradients(self, n_iter: int):
         """What ``loss.backward()`` yields in the reference (run_composite.py:283-306) for this rank's slice of step ``n_iter``'s
         batch, without an autograd graph and without touching the optimiser: fused forward -> fused loss kernel (values + d loss /
@@ -269,11 +283,7 @@ class CompositeTrainer:
         R = ids.shape[0]
         lo, hi = (R * self.rank) // self.world, (R * (self.rank + 1)) // self.world
         my = ids[lo:hi]
-        rays = self.data.rays_train.index_select(0, my)
-        phases = self.data.phases_train.index_select(0, my)
-        o, d, gt, w = rays[:, 0, :], rays[:, 1, :], rays[:, 2, 0], rays[:, 3, 0]
-        z = MH.randomize_depth(self.depth, self.device, self.draw_jitter(n_iter))
-        dists = MH._interval_lengths(z, d)
+        o, d, gt, w, phases, z, dists = self._prepare(my, self.draw_jitter(n_iter))
         bs, bd = self.s._binding, self.t._binding
         # Rays are independent given the weights and every loss term is a sum over rays (times the GLOBAL 1/R), so the
         # step may run over ray micro-batches and add up: that keeps the forward store (the tensors autograd would keep)
@@ -490,10 +500,8 @@ class CompositeTrainer:
         lo, hi = (R * self.rank) // self.world, (R * (self.rank + 1)) // self.world
         self._slice = (lo, hi)
         self._ids_buf = torch.zeros(hi - lo, dtype=torch.int64, device=dev)
-        # model_helpers.py:73.  An attribute, not a local: the captured kernels read this address at every replay, and a tensor that
-        # dies with this function hands its memory back to the allocator (the last interval length then was whatever the next
-        # owner wrote there: seen as a garbage loss at 8 192 rays per step, tests/test_configs.py)
-        tail = self._graph_tail = torch.tensor([1e-10], dtype=self.data.rays_train.dtype, device=dev)
+        # (every tensor the captured kernels read must outlive the graph: a local that dies with this function hands its memory
+        # back to the allocator and the replays read whatever the next owner wrote there -- tests/test_configs.py)
         nets = [self.t, self.s] + ([self.t_fine, self.s_fine] if fine else [])           # self.params order
         self.adam = FusedAdam(nets, lr=c.lr, end_factor=c.lr_end_factor, total_iters=c.lr_decay_steps)
         bs, bd = self.s._binding, self.t._binding
@@ -511,11 +519,7 @@ class CompositeTrainer:
             out["flat"] = torch.cat([g for _, _, g in order] + [torch.stack([terms_f[8], terms_f[5]]).to(torch.float32)])       # (+ the early-stop pair)
 
         def front():
-            rays = self.data.rays_train.index_select(0, self._ids_buf)
-            phases = self.data.phases_train.index_select(0, self._ids_buf)
-            o, d, gt, w = rays[:, 0, :], rays[:, 1, :], rays[:, 2, 0], rays[:, 3, 0]
-            z = MH.randomize_depth(self.depth, dev, rec32[:S])
-            dists = torch.cat((z[1:] - z[:-1], tail))
+            o, d, gt, w, phases, z, dists = self._prepare(self._ids_buf, rec32[:S])
             batch = _RayBatch(o, d, phases, self.I0[: hi - lo], z, dists, c.output_activation, False, 1e-2)
             pix, sig_s, sig_d, keep = render_forward_raw(batch, bs, bd, for_backward=True)
             terms, g_pix, g_s, g_d = fused_losses(pix, gt, w, sig_s, sig_d, dists, c, (0.0, 0.0, 0.0, 0.0), inv_R=1.0 / R,

@@ -1627,3 +1627,29 @@ def test_f32_store_with_skip_layers(dev, late):
     for name, got, pe in (("static", grads_of(s), pso), ("dynamic", grads_of(t), pdo)):
         for k in pe:
             assert rel_err(got[k], pe[k].grad) < TOL, (name, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,S", [(1, 2), (37, 5), (1024, 500), (65536, 192), (100, 1000)])
+def test_prepare_batch_is_bit_identical_to_the_torch_operations(R, S):
+    """fused.prepare_batch (one launch) against the reference's own sequence: rays_train[ids] split into origins / directions /
+    pixel / weight (run_composite.py:262-273), randomize_depth and the interval lengths (model_helpers.py:3-12, 73-74)."""
+    from nerfca_amd import fused
+    from nerfca_amd.train import model_helpers as MH
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(R * 31 + S)
+    N = 4 * R + 3
+    table = torch.randn((N, 4, 3), generator=g, dtype=torch.float64).to(dev)
+    phases = torch.randint(0, 10, (N,), generator=g).to(dev)
+    ids = torch.randint(0, N, (R,), generator=g).to(dev)
+    depth = torch.linspace(2.0, 6.0, S).to(dev)
+    t = torch.rand(S, generator=g)
+    o, d, gt, w, ph, z, dists = fused.prepare_batch(ids, table, phases, depth, t)
+    rays = table.index_select(0, ids)
+    z_ref = MH.randomize_depth(depth, dev, t)
+    dists_ref = MH._interval_lengths(z_ref, rays[:, 1, :])
+    assert torch.equal(o, rays[:, 0, :]) and torch.equal(d, rays[:, 1, :])
+    assert torch.equal(gt, rays[:, 2, 0]) and torch.equal(w, rays[:, 3, 0])
+    assert torch.equal(ph.to(torch.int64), phases.index_select(0, ids))
+    assert z.dtype == torch.float32 and torch.equal(z, z_ref)
+    assert dists.dtype == torch.float64 and torch.equal(dists, dists_ref)
