@@ -3,9 +3,11 @@
 #include <hip/hip_runtime.h>
 #include "nca_layout.hpp"
 
-#define NCA_NT 512      // threads per workgroup of the fused kernel: 8 waves, 2 per SIMD
+#ifndef NCA_WAVES
+#define NCA_WAVES 8     // waves per workgroup of the fused kernels: 2 per SIMD (tools/variant_build_all.sh w4 "-DNCA_WAVES=4": one per SIMD, for timing)
+#endif
+#define NCA_NT (64 * NCA_WAVES)
 #define NCA_LDS_BYTES 163840   // LDS of a gfx950 compute unit (one workgroup of the fused kernels owns it)
-#define NCA_WAVES 8
 
 enum { NCA_MODE_RAYS = 0, NCA_MODE_POINTS = 1 };
 

@@ -662,30 +662,43 @@ class _PointsLatentsFn(torch.autograd.Function):
         work, wbytes = _alloc_workspace(lambda cap: check(lib.nca_mlp_bwd_workspace(C.byref(binding.net), binding.prec, N, cap)), pts.device)
         check(lib.nca_mlp_bwd(C.byref(binding.net), binding.prec, ptr(packed), ptr(win), ptr(four), ptr(prm), N, ptr(pts), ptr(ids), ptr(g), ptr(grads),
                               ptr(work), wbytes, _stream()))
+        g_table = grads[: ctx.n_lat].clone().view(-1, binding.net.T) if ctx.needs_input_grad[3] else None
         grads[: ctx.n_lat] = 0.0                            # the table is not the module's time_latents
-        return (None, None, None, None, *binding.split_grads(grads))
+        return (None, None, None, g_table, *binding.split_grads(grads))
 
 
 def eval_points_with_latents(model, pts: torch.Tensor, latents: torch.Tensor) -> torch.Tensor:
-    """Temporal.query_time: f32[n,3], latent vectors f32[n,T] -> f32[n,1]."""
+    """Temporal.query_time: f32[n,3], latent vectors f32[n,T] -> f32[n,1].
+
+    The distinct latent vectors of the call become rows of temporary latent tables (P rows per launch) and the kernels' own
+    latent-table gradient (the sum over the points that use a row) is handed to the FIRST point that carries that vector.  That is
+    the reference's autograd gradient (Temporal.py:113-136) whenever equal rows are one autograd value -- an expanded / repeated /
+    indexed smaller table, which is how forward_composite itself builds them (Temporal.py:147-149) -- or all rows differ; a leaf tensor
+    with repeated rows would get the sum on one of them and is refused."""
     _require_cuda(pts, "query points")
     binding: FieldBinding = model._binding
     T, P = binding.net.T, binding.net.P
-    if latents.requires_grad and torch.is_grad_enabled():
-        raise _capi.NcaError("query_time: gradients with respect to the passed latent vectors are not provided (they are constants of the call)")
+    want_lat = latents.requires_grad and torch.is_grad_enabled()
     p = pts.detach().reshape(-1, 3).to(torch.float32).contiguous()
-    lat = latents.detach().reshape(-1, latents.shape[-1]).to(device=p.device, dtype=torch.float32)
+    lat_g = latents.reshape(-1, latents.shape[-1]).to(device=p.device, dtype=torch.float32)
+    lat = lat_g.detach()
     if lat.shape[0] != p.shape[0] or lat.shape[1] != T:
         raise _capi.NcaError(f"query_time takes one latent vector of {T} values per point")
     if p.shape[0] == 0:
         return torch.empty((0, 1), dtype=torch.float32, device=p.device)
     uniq, inv = torch.unique(lat, dim=0, return_inverse=True)
+    if want_lat:
+        if latents.is_leaf and uniq.shape[0] != lat.shape[0]:
+            raise _capi.NcaError("query_time: a leaf tensor of latent vectors with repeated rows: the per-row gradients of equal rows are not provided "
+                                 "(pass the distinct vectors and index / expand them, as forward_composite does)")
+        # first point of every distinct vector
+        first = torch.full((uniq.shape[0],), lat.shape[0], dtype=torch.int64, device=p.device).scatter_reduce(
+            0, inv, torch.arange(lat.shape[0], device=p.device), reduce="amin")
     out = torch.zeros((p.shape[0], 1), dtype=torch.float32, device=p.device)
     for u0 in range(0, uniq.shape[0], P):                   # one temporary table of P rows per launch
         sel = ((inv >= u0) & (inv < u0 + P)).nonzero().flatten()
-        table = torch.zeros((P, T), dtype=torch.float32, device=p.device)
-        rows = uniq[u0:u0 + P]
-        table[: rows.shape[0]] = rows
+        rows = lat_g.index_select(0, first[u0:u0 + P]) if want_lat else uniq[u0:u0 + P]
+        table = torch.cat([rows, torch.zeros((P - rows.shape[0], T), dtype=torch.float32, device=p.device)]) if rows.shape[0] < P else rows
         ids = (inv.index_select(0, sel) - u0).to(torch.int32).contiguous()
         vals = _PointsLatentsFn.apply(binding, p.index_select(0, sel).contiguous(), ids, table, *binding.params())
         out = out.index_put((sel,), vals)

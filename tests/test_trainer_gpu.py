@@ -184,6 +184,44 @@ def test_query_time_with_latent_vectors(golden, dev):
         assert torch.equal(t.query_time(x.to(dev), t.time_latents[ts.long().to(dev)]), t.forward_composite(x.to(dev), ts.to(dev)))
 
 
+def test_query_time_latent_vector_gradients(golden, dev):
+    """Gradients with respect to the latent vectors passed to query_time (plain autograd in the reference, Temporal.py:113-136):
+    a pool of 23 vectors indexed per point, as forward_composite builds its own (:147-149), against autograd through the oracle;
+    a leaf with repeated rows is refused."""
+    from oracle import nerfca_oracle as O
+    from nerfca_amd import _capi
+    g = golden("mlps")
+    pd = g.prefixed("d_F64_e4_l0_p_")
+    t = make_dynamic(pd, dev, F=64, early=4, late=0, T=8)
+    t.update_freq_mask_alpha(60000, 150000)
+    x = g["x"]
+    n = x.shape[0]
+    gen = torch.Generator().manual_seed(6)
+    pool = torch.rand(23, 8, generator=gen)
+    pick = torch.randint(0, 23, (n,), generator=gen)
+    sd = O.NetSpec(num_filters=64, num_time_dim=8)
+    win = O.freq_mask_alpha(12, 60000, 150000, 1)[0]
+    pool_o = pool.clone().requires_grad_(True)
+    yo = O.mlp({k: v.clone() for k, v in pd.items()}, sd, torch.cat([O.encode(x, sd, win), pool_o[pick]], -1))
+    (yo * g["gout"]).sum().backward()
+    pool_d = pool.to(dev).requires_grad_(True)
+    y = t.query_time(x.to(dev), pool_d[pick.to(dev)])
+    assert rel_err(y.detach().cpu(), yo.detach()) < 1e-5
+    (y * g["gout"].to(dev)).sum().backward()
+    assert rel_err(pool_d.grad.cpu(), pool_o.grad) < 1e-5
+    leaf = pool[pick].to(dev).requires_grad_(True)
+    with pytest.raises(_capi.NcaError, match="repeated rows"):
+        t.query_time(x.to(dev), leaf)
+    # all rows distinct: every point owns its gradient
+    m = min(n, 16)
+    lat_o = torch.rand(m, 8, generator=gen).requires_grad_(True)
+    yo2 = O.mlp({k: v.clone() for k, v in pd.items()}, sd, torch.cat([O.encode(x[:m], sd, win), lat_o], -1))
+    (yo2 * g["gout"][:m]).sum().backward()
+    lat_d = lat_o.detach().to(dev).requires_grad_(True)
+    (t.query_time(x[:m].to(dev), lat_d) * g["gout"][:m].to(dev)).sum().backward()
+    assert rel_err(lat_d.grad.cpu(), lat_o.grad) < 1e-5
+
+
 def test_magix_shape_full_size_step(dev):
     """BASELINE configs[3]'s shape (MAGIX cone beam DSD 2000 / DSO 600, 512^2 detector, 256 samples per ray, f32): one fused
     step over a full detector runs as ray micro-batches (its forward store would not fit) and is reproducible bit for bit;
