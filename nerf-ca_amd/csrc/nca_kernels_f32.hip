@@ -402,8 +402,11 @@ __device__ __forceinline__ void stage_publish_counted(bool stores_issued) {
 
 // Kernel modes as in the bf16 kernel (nca_kernels.hpp): 0 forward, 1 recompute backward (one scratch for H and D),
 // 2 forward that also stores the input block / layer inputs / ReLU masks / raw outputs, 3 backward from that store.
+#ifndef NCA_F32_MINBLOCKS
+#define NCA_F32_MINBLOCKS 2     // (1 with NCA_WAVES=4: one 512-register wave per SIMD -- tools/variant_build_all.sh, timing experiment)
+#endif
 template <int F, int MODE, bool X3>
-__global__ __launch_bounds__(NCA_NT, 2) void nca_fused_f32(const NcaFusedArgs a) {
+__global__ __launch_bounds__(NCA_NT, NCA_F32_MINBLOCKS) void nca_fused_f32(const NcaFusedArgs a) {
     constexpr bool BWD = MODE == NCA_KM_BWD || MODE == NCA_KM_BWD_STORED;
     constexpr bool STORE = MODE == NCA_KM_BWD || MODE == NCA_KM_FWD_STORE;
     constexpr bool RECOMP = MODE != NCA_KM_BWD_STORED;
