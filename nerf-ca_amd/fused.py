@@ -93,6 +93,7 @@ class FieldBinding:
         self.packed: Optional[torch.Tensor] = None
         self.static_window: Optional[torch.Tensor] = None   # device f32[L] that overrides the module's band window
         self._offsets: List[int] = []
+        self.gaps: List[tuple] = []                         # (offset, count) of bias slots of a module built with use_bias=False
         self.reflatten()
 
     # -- parameters ---------------------------------------------------------------------------
@@ -104,23 +105,40 @@ class FieldBinding:
 
     def reflatten(self) -> None:
         """(Re)create the flat buffer on the parameters' current device and re-point every
-        ``nn.Parameter`` at its slice.  Called at construction and after ``module.to(...)``."""
+        ``nn.Parameter`` at its slice.  Called at construction and after ``module.to(...)``.
+
+        The buffer is in the library's natural order (``[time_latents,] weight, bias, weight, bias, ...``).  A module built with
+        ``use_bias=False`` (CPPN.py:15-19) owns no bias parameters: their slots stay in the buffer as zeros (``self.gaps``) -- a
+        layer without a bias is a layer whose bias is zero and never updated -- and the kernels' gradients for them are dropped."""
         ps = self.params()
         if not ps:
             return
         dev = ps[0].device
-        flat = torch.empty(sum(p.numel() for p in ps), dtype=torch.float32, device=dev)
-        self._offsets = []
+        biasless = not getattr(self.module, "use_bias", True)
+        slots = []                                     # (parameter or None, numel)
+        for name, p in self.module.named_parameters():
+            slots.append((p, p.numel()))
+            if biasless and name.endswith(".weight"):
+                slots.append((None, p.shape[0]))
+        flat = torch.zeros(sum(n for _, n in slots), dtype=torch.float32, device=dev)
+        self._offsets, self.gaps = [], []
         off = 0
         with torch.no_grad():
-            for p in ps:
-                n = p.numel()
-                flat[off:off + n].copy_(p.detach().reshape(-1).to(torch.float32))
-                p.data = flat[off:off + n].view(p.shape)
-                self._offsets.append(off)
+            for p, n in slots:
+                if p is None:
+                    self.gaps.append((off, n))
+                else:
+                    flat[off:off + n].copy_(p.detach().reshape(-1).to(torch.float32))
+                    p.data = flat[off:off + n].view(p.shape)
+                    self._offsets.append(off)
                 off += n
         self.flat = flat
         self.packed = None
+
+    def zero_gaps(self, t: torch.Tensor) -> None:
+        """Zero the slots of ``t`` (a flat tensor in the buffer's layout) that belong to no parameter."""
+        for off, n in self.gaps:
+            t[off:off + n].zero_()
 
     def _is_flat(self) -> bool:
         if self.flat is None:
@@ -567,6 +585,8 @@ class FusedAdam:
         n = (C.c_int64 * k)(*[b.flat.numel() for b in self.bindings])
         check(_capi.lib().nca_adam_step(C.byref(self.cfg), k, n, arr([b.flat for b in self.bindings]), arr(grads), arr(self.exp_avg),
                                         arr(self.exp_avg_sq), ptr(self.step_count), _stream()))
+        for b in self.bindings:          # (bias slots of a net without biases stay zero)
+            b.zero_gaps(b.flat)
 
 
 def render_rays(static_model, temp_model, origins, directions, phases, I0, z, dists, act="softplus", single=False, scale=1e-2):

@@ -44,8 +44,6 @@ class FieldBase(nn.Module):
         self.act_func = nn.ReLU()
         self.store_activations = False
         self.activation_dictionary = {}
-        if not self.use_bias:
-            raise _capi.NcaError("use_bias=False is not supported by the fused kernels (the reference always passes True)")
         if self.num_input_channels != 3 or self.num_output_channels != 1:
             raise _capi.NcaError("the fused kernels take 3 input channels and produce 1 output channel")
         self.pos_enc_basis = 0

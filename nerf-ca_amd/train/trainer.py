@@ -484,8 +484,7 @@ class CompositeTrainer:
         Ls, Ld = self.s.pos_enc_basis, self.t.pos_enc_basis
         fine = self.n_fine > 0
         if fine and self.world > 1:
-            raise NotImplementedError("the graph-replayed hierarchical step runs on one rank (the sampler's batch-wide maximum and ray 0's "
-                                      "depths cross the ranks in the middle of the step); use step_fused() under ray sharding")
+            raise RuntimeError("the graph-replayed hierarchical step runs on one rank (step_graph routes the sharded case to the host-launched step)")
         Lsf, Ldf = (self.s_fine.pos_enc_basis, self.t_fine.pos_enc_basis) if fine else (0, 0)
         nf = S + Ls + Ld + Lsf + Ldf
         off64 = (4 * nf + 7) // 8 * 8
@@ -610,6 +609,11 @@ class CompositeTrainer:
         (its own moment buffers: do not interleave with ``step``/``step_fused`` in one run).  Per step the host only
         draws the ray ids, fills one pinned record and launches the graph.  Returns (loss, pixel, terms) as
         ``step_fused`` does; the tensors are overwritten by the next call."""
+        if self.n_fine > 0 and self.world > 1:
+            # The hierarchical step under ray sharding has four collectives between its kernels (the sampler's batch-wide maximum,
+            # ray 0's depths, and both again on the way back): nothing long enough to replay is left between them.  Same step,
+            # launched from the host, torch Adam.
+            return self._step_fused_fine(n_iter)
         self.update_windows(n_iter)
         if getattr(self, "_graphs", None) is None:
             self._graph_setup()

@@ -29,7 +29,7 @@ def _run(rank, world, mode, prec, device_index=0):
     sdef, tdef = synthetic.net_definitions(dev, F=64)
     s, t = CPPN(sdef).to(dev), Temporal(tdef).to(dev)
     kw = {}
-    n_fine = 8 if mode == "fine" else 0
+    n_fine = 8 if mode in ("fine", "graphfine") else 0
     if n_fine:
         fs, ft = synthetic.net_definitions(dev, F=32)
         kw = dict(static_model_fine=CPPN(fs).to(dev), temp_model_fine=Temporal(ft).to(dev))
@@ -37,10 +37,14 @@ def _run(rank, world, mode, prec, device_index=0):
     cfg = TrainConfig(depth_samples_per_ray_coarse=S, depth_samples_per_ray_fine=n_fine, img_sample_size=R, favor_s_weight_delay_steps=0,
                       l1_weight_start=1e-3, l1_weight_end=1e-3, occl_weight_start=1e-2, dynamic_entro_weight_start=1e-3,
                       favor_s_weight_start=1e-3, entro_mask_thre=1e-6)
-    tr = CompositeTrainer(cfg, s, t, data, dev, rank=rank, world=world, seed=11, fused_loss=(mode in ("fused", "graph")), **kw)
+    tr = CompositeTrainer(cfg, s, t, data, dev, rank=rank, world=world, seed=11, fused_loss=(mode in ("fused", "graph", "graphfine")), **kw)
     grads = None
     for it in range(2):
-        if mode == "graph":        # bench.py's default step: two captured graphs with the gradient all-reduce between them
+        if mode == "graphfine":    # step_graph with a fine pass: one rank replays a graph, sharded ranks run the host-launched step
+            tr.step_graph(2000 + it)
+            if it == 0:
+                grads = (tr._graph_out["flat"][:-2] if getattr(tr, "_graphs", None) else torch.cat([p.grad.flatten() for p in tr.params])).clone()
+        elif mode == "graph":      # bench.py's default step: two captured graphs with the gradient all-reduce between them
             tr.step_graph(2000 + it)
             if it == 0:
                 grads = tr._graph_out["flat"].clone()            # [dynamic | static] = the order of tr.params
@@ -77,7 +81,7 @@ def _free_port():
 
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("mode,prec,gtol", [("fused", "f32", 1e-5), ("autograd", "f32", 1e-5), ("fused", "bf16", 1e-3), ("fine", "f32", 1e-3),
-                                            ("graph", "f32", 1e-5), ("graph", "bf16", 1e-3)])
+                                            ("graph", "f32", 1e-5), ("graph", "bf16", 1e-3), ("graphfine", "f32", 1e-3)])
 def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path, mode, prec, gtol):
     """Gradient of the first step: both ranks hold the same all-reduced buffer, equal to the single-process gradient up to
     f32 summation order (1e-5; bf16 rounds the per-rank partial sums differently, and the fine pass's through-depth term is

@@ -1653,3 +1653,75 @@ def test_prepare_batch_is_bit_identical_to_the_torch_operations(R, S):
     assert torch.equal(ph.to(torch.int64), phases.index_select(0, ids))
     assert z.dtype == torch.float32 and torch.equal(z, z_ref)
     assert dists.dtype == torch.float64 and torch.equal(dists, dists_ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_nets_without_biases(dev, prec):
+    """use_bias=False (the reference's CPPN / Temporal accept it, model/CPPN.py:15-19; its scripts always pass True): the modules own
+    no bias parameters, the library sees zero biases and never moves them.  Render outputs and weight gradients against the oracle
+    evaluated with zero biases; after graph-replayed steps (library Adam over the flat buffers) the bias slots are still zero."""
+    import nerfca_amd
+    from nerfca_amd import render_rays
+    from nerfca_amd.model.CPPN import CPPN
+    from nerfca_amd.model.Temporal import Temporal
+    R, S, F = 33, 50, 64
+    gen = torch.Generator().manual_seed(77)
+    ss = O.NetSpec(num_filters=F, num_early_layers=3, num_time_dim=0)
+    sd = O.NetSpec(num_filters=F, num_early_layers=3, num_time_dim=8)
+    ps, pd = O.init_params(ss, gen), O.init_params(sd, gen)
+    for prm in (ps, pd):
+        for k in prm:
+            if k.endswith(".bias"):
+                prm[k] = torch.zeros_like(prm[k])
+    win = O.freq_mask_alpha(12, 75000, 150000, 1)[0]
+    o = (torch.rand(R, 3, generator=gen) * 0.2 + torch.tensor([3.0, -2.0, 2.5])).to(torch.float64)
+    d = (torch.rand(R, 3, generator=gen) - 0.5).to(torch.float64)
+    d = d / d.norm(dim=-1, keepdim=True) * 1.001
+    ph = torch.randint(0, 10, (R,), generator=gen)
+    z = O.stratified_depths(O.depth_values(3.4259, 5.5741, S), torch.rand(S, generator=gen))
+    I0 = torch.full((R,), 2.15991)
+    cp, cs, cd = torch.randn(R, generator=gen).to(torch.float64), torch.randn(R, S, generator=gen), torch.randn(R, S, generator=gen)
+    pix, a, b, dists, ps64, pd64 = _oracle_render_grads(ps, ss, pd, sd, win, o, d, ph, I0, z, cp, cs, cd, torch.float64)
+
+    ds, dd = model_def(F=F, early=3, late=0, device=dev), model_def(F=F, early=3, late=0, T=8, device=dev)
+    ds["use_bias"] = dd["use_bias"] = False
+    s, t = CPPN(ds), Temporal(dd)
+    assert not any(k.endswith(".bias") for k, _ in list(s.named_parameters()) + list(t.named_parameters()))
+    s.load_state_dict({k: v for k, v in ps.items() if not k.endswith(".bias")})
+    t.load_state_dict({k: v for k, v in pd.items() if not k.endswith(".bias")})
+    s, t = s.to(dev), t.to(dev)
+    nerfca_amd.set_precision(prec, s, t)
+    s.update_freq_mask_alpha(75000, 150000)
+    t.update_freq_mask_alpha(75000, 150000)
+    pix2, a2, b2 = render_rays(s, t, o.to(dev), d.to(dev), ph.to(dev), I0.to(dev), z.to(dev), dists.to(dev))
+    ((pix2 * cp.to(dev)).sum() + (a2 * cs.to(dev)).sum() * 50 + (b2 * cd.to(dev)).sum() * 50).backward()
+    if prec == "f32":
+        assert rel_err(pix2.cpu(), pix) < TOL and rel_err(a2.cpu(), a) < TOL and rel_err(b2.cpu(), b) < TOL
+        for got, ref in ((grads_of(s), ps64), (grads_of(t), pd64)):
+            for k, gk in got.items():
+                assert rel_err(gk, ref[k].grad) < 1e-4, (prec, k)
+    # ... and bit for bit what the same nets WITH bias parameters that are zero give (same kernels, same flat buffer)
+    s1 = make_static(ps, dev, F=F, early=3, late=0)
+    t1 = make_dynamic(pd, dev, F=F, early=3, late=0, T=8)
+    nerfca_amd.set_precision(prec, s1, t1)
+    s1.update_freq_mask_alpha(75000, 150000)
+    t1.update_freq_mask_alpha(75000, 150000)
+    pix1, a1, b1 = render_rays(s1, t1, o.to(dev), d.to(dev), ph.to(dev), I0.to(dev), z.to(dev), dists.to(dev))
+    assert torch.equal(pix1, pix2) and torch.equal(a1, a2) and torch.equal(b1, b2)
+    ((pix1 * cp.to(dev)).sum() + (a1 * cs.to(dev)).sum() * 50 + (b1 * cd.to(dev)).sum() * 50).backward()
+    for m0, m1 in ((s, s1), (t, t1)):
+        g1 = grads_of(m1)
+        for k, gk in grads_of(m0).items():
+            assert torch.equal(gk, g1[k]), (prec, k)
+    for m in (s, t):
+        bnd = m._binding
+        assert bnd.gaps and bnd.flat.numel() == sum(p.numel() for p in m.parameters()) + sum(n for _, n in bnd.gaps)
+    # the library's Adam over the flat buffers leaves the bias slots alone
+    from nerfca_amd.fused import FusedAdam
+    adam = FusedAdam([t, s], lr=1e-2)
+    adam.step([torch.ones_like(t._binding.flat), torch.ones_like(s._binding.flat)])
+    for m in (s, t):
+        for off, n in m._binding.gaps:
+            assert float(m._binding.flat[off:off + n].abs().max()) == 0.0
+        assert m._binding._is_flat()
