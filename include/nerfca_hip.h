@@ -294,6 +294,12 @@ enum {
                                      one's sigma).  0 = always, -1 = never; default 8 * 8 waves * CUs (NCA_RESIDENT=0 -> never,
                                      =force -> always).  Results are bit-identical to the streaming kernels */
     NCA_OPT_STAGE_FP8_MIN_TILES = 3, /* threshold of NCA_OPT_STAGE_FP8 = auto, in 64-sample wave tiles of the whole batch (>= 0) */
+    NCA_OPT_WGRAD_REBUILD_WEIGHT_PCT = 4, /* fp8 staging: the weight-gradient launch is ONE round of one-wave jobs, so its slowest wave is
+                                     the launch; the jobs that rebuild their output-gradient block from mask bits take more cycles per
+                                     tile than the others and get this many percent of the others' sample splits (100 .. 200; default
+                                     115 = the cycle ratio measured on MI355X, tools/clock_probe.sh; initial value from NCA_WGRAD_W).
+                                     A constant rather than a calibration at first use: the splits fix the summation order, and with it
+                                     the bits of the gradient -- tools/calibrate_wgrad.py times the candidates on a given box */
     NCA_OPT_COUNT
 };
 int nca_get_option(int32_t opt, int64_t* value);

@@ -20,6 +20,7 @@ OPT_ONCHIP_MIN_TILES = 0
 OPT_STAGE_FP8 = 1
 OPT_RESIDENT_MIN_TILES = 2
 OPT_STAGE_FP8_MIN_TILES = 3
+OPT_WGRAD_REBUILD_WEIGHT_PCT = 4
 STORE_NONE, STORE_F32, STORE_BF16, STORE_FP8, STORE_KIND_MASK, STORE_SHARED_ENC = 0, 1, 2, 3, 15, 16
 K_PACK, K_FWD, K_BWD_DGRAD, K_BWD_WGRAD, K_BWD_REDUCE, K_LOSS, K_ADAM = 0, 1, 2, 3, 4, 5, 6
 KERNEL_KINDS = {"pack": K_PACK, "fwd": K_FWD, "bwd_dgrad": K_BWD_DGRAD, "bwd_wgrad": K_BWD_WGRAD, "bwd_reduce": K_BWD_REDUCE,

@@ -133,6 +133,8 @@ void opt_init_locked() {
     else if (e && e[0] == 'f') g_opt[NCA_OPT_RESIDENT_MIN_TILES] = 0;
     e = getenv("NCA_STAGE_FP8");
     if (e && (e[0] == '0' || e[0] == '1')) g_opt[NCA_OPT_STAGE_FP8] = e[0] - '0';
+    e = getenv("NCA_WGRAD_W");
+    if (e && atoi(e) >= 100 && atoi(e) <= 200) g_opt[NCA_OPT_WGRAD_REBUILD_WEIGHT_PCT] = atoi(e);
     g_opt_init = true;
 }
 // default of NCA_OPT_STAGE_FP8_MIN_TILES: see stage_fp8_for()
@@ -147,6 +149,7 @@ int64_t opt_value(int opt) {
         if (opt == NCA_OPT_ONCHIP_MIN_TILES) v = (int64_t)8 * NCA_WAVES * num_cus();
         if (opt == NCA_OPT_STAGE_FP8) v = -1;                                            // auto: by batch size
         if (opt == NCA_OPT_STAGE_FP8_MIN_TILES) v = STAGE_FP8_DEFAULT_MIN_TILES;
+        if (opt == NCA_OPT_WGRAD_REBUILD_WEIGHT_PCT) v = 115;
         if (opt == NCA_OPT_RESIDENT_MIN_TILES) v = (int64_t)8 * NCA_WAVES * num_cus();    // (at 4 tiles per wave -- the reference's 1 024 x 500 batch -- resident and streaming tie)
     }
     return v;
@@ -170,6 +173,7 @@ extern "C" int nca_set_option(int32_t opt, int64_t value) {
     if (opt == NCA_OPT_RESIDENT_MIN_TILES && value < -1) return fail(NCA_E_INVALID, "NCA_OPT_RESIDENT_MIN_TILES takes -1 (never), 0 (always) or a tile count");
     if (opt == NCA_OPT_STAGE_FP8 && value != 0 && value != 1 && value != -1) return fail(NCA_E_INVALID, "NCA_OPT_STAGE_FP8 takes 0 (never), 1 (always) or -1 (auto)");
     if (opt == NCA_OPT_STAGE_FP8_MIN_TILES && value < 0) return fail(NCA_E_INVALID, "NCA_OPT_STAGE_FP8_MIN_TILES takes a tile count >= 0");
+    if (opt == NCA_OPT_WGRAD_REBUILD_WEIGHT_PCT && (value < 100 || value > 200)) return fail(NCA_E_INVALID, "NCA_OPT_WGRAD_REBUILD_WEIGHT_PCT takes 100 .. 200");
     std::lock_guard<std::mutex> lk(g_omu);
     opt_init_locked();
     g_opt[opt] = value;
@@ -615,10 +619,10 @@ static int plan_bwd(const NcaLayout* lays, int nnets, int32_t prec, int64_t unit
     if (nsplit < 1) nsplit = 1;
     // The jobs of the last hidden layers under e5m2 staging rebuild their D block on the vector ALU: 1.15 x the cycles per tile of
     // the others (measured, tools/clock_probe.sh).  The grid is ONE round of one-wave workgroups, so the slowest wave is the launch:
-    // those jobs get 1.15 x the splits.  Their extra slab rows stay zero in every other job's columns (cleared once per backward).
+    // those jobs get W x the splits (NCA_OPT_WGRAD_REBUILD_WEIGHT_PCT, default 1.15).  Their extra slab rows stay zero in every other job's columns (cleared once per backward).
     int nsplit_x = nsplit;
     if (bf && stored && d8 && nr && p->njobs > nnets) {
-        const double W = 1.15;
+        const double W = 0.01 * (double)opt_value(NCA_OPT_WGRAD_REBUILD_WEIGHT_PCT);
         int ns = (int)((4.0 * cus) / ((p->njobs - nnets) + nnets * W));
         if (ns < 1) ns = 1;
         int nx = (int)(W * ns);

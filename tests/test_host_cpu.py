@@ -374,5 +374,8 @@ def test_shipped_library_is_not_a_timing_build():
     info = _capi.build_info()
     assert "NCA_EXP=0" in info and f"abi={_capi.ABI_VERSION}" in info and "gfx950" in info, info
     assert _capi.get_option(_capi.OPT_STAGE_FP8) in (-1, 0, 1) and _capi.get_option(_capi.OPT_STAGE_FP8_MIN_TILES) >= 0
+    assert _capi.get_option(_capi.OPT_WGRAD_REBUILD_WEIGHT_PCT) == int(os.environ.get("NCA_WGRAD_W", 115))
+    with pytest.raises(_capi.NcaError):
+        _capi.set_option(_capi.OPT_WGRAD_REBUILD_WEIGHT_PCT, 99)
     with pytest.raises(_capi.NcaError):
         _capi.get_option(99)
