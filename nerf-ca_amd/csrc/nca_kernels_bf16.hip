@@ -328,6 +328,19 @@ constexpr int NCA_BF_RING = 4;
 #ifndef NCA_BF_PIPE
 #define NCA_BF_PIPE 0
 #endif
+// Deferred epilogue (storing forward with e4m3 staging, every layer but the last hidden one): behind the MFMAs of row tile m only
+// the 16 conversions to bf16 run (into the next layer's operand slots, which they are headed for anyway: no extra registers); ReLU,
+// mask bits, the e4m3 conversion and the store of row tile m follow in six pieces behind the MFMA pairs of row tile m + 1, where
+// the same wave's matrix instructions are in flight (tools/valu_mfma_samewave.hip, tools/mfma_shape_power.hip: ~10 packed vector
+// instructions per MFMA pair hide almost completely when they are interleaved IN THE WAVE THAT ISSUES THE MFMAs).  The backward from an
+// e5m2-staged store does the same with its mask / conversion / store.  Measured at the bench size (tools/variant_build.sh p2
+// "-DNCA_BF_PIPE2=1", bit-identical results, 246 / 234 VGPRs and no vector spill): forward 4.63 -> 4.45 ms, backward 3.63 -> 3.57 ms
+// per step in the per-kernel table -- and the graph-replayed STEP 13.03 -> 12.99 ms: what the two kernels gain the weight gradient
+// behind them loses (4.46 -> 4.87 ms in one run).  Same instructions, same bytes, same energy: under the power cap the step does
+// not care how they overlap.  Off.
+#ifndef NCA_BF_PIPE2
+#define NCA_BF_PIPE2 0
+#endif
 
 // Two A/B experiments on how the two waves of a SIMD share it, both measured at the bench size and removed again (round 3):
 // s_setprio 1 around the 16 MFMAs of a row tile (so that they win the issue port against the partner's epilogue): forward 4.75 ->
@@ -354,6 +367,21 @@ __device__ __forceinline__ void ring_prime(const char* imgl, u32x4 (&A)[RING]) {
 #pragma unroll
     for (int g = 0; g < RING - 1; ++g)
         if (g < MTOT * NKS) A[g % RING] = *reinterpret_cast<const u32x4*>(imgl + g * 1024);
+}
+// The same with a piece of vector-ALU work placed behind the two MFMAs of every k-step (NCA_BF_PIPE2: the deferred epilogue of the
+// previous row tile; `piece(ks)` must not touch acc0 / acc1).  Everything of a step stays in its step.
+template <int NKS, int MTOT, int NB, int RING, typename PIECE>
+__device__ __forceinline__ void mma_rowtile_ring_il(const char* imgl, int m, u32x4 (&A)[RING], const u32x4 (&B)[2][NB],
+                                                    f32x16& acc0, f32x16& acc1, PIECE&& piece) {
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        const int g = m * NKS + ks, nx = g + RING - 1;
+        if (nx < MTOT * NKS) A[nx % RING] = *reinterpret_cast<const u32x4*>(imgl + nx * 1024);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(A[g % RING]), frag(B[0][ks]), acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(A[g % RING]), frag(B[1][ks]), acc1, 0, 0, 0);
+        piece(ks);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 template <int NKS, int MTOT, int NB, int RING>
 __device__ __forceinline__ void mma_rowtile_ring(const char* imgl, int m, u32x4 (&A)[RING], const u32x4 (&B)[2][NB],
@@ -1020,6 +1048,58 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                     }
                 };
                 f32x16 pend0, pend1;
+                // NCA_BF_PIPE2: the deferred part of row tile mp's epilogue, piece 0..5 = (column tile, {ReLU, mask bits, e4m3 + store}),
+                // on the packed words where pack_only left them
+                constexpr bool P2 = NCA_BF_PIPE2 && FSTORE && H8 && !LAST && STORE && !NOH && !NOM;
+                auto pack_only = [&](int m, const f32x16& acc0, const f32x16& acc1) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const f32x16& acc = c == 0 ? acc0 : acc1;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { Bn[c][2 * m][u] = pack2(acc[2 * u], acc[2 * u + 1]); Bn[c][2 * m + 1][u] = pack2(acc[8 + 2 * u], acc[8 + 2 * u + 1]); }
+                    }
+                };
+                auto deferred = [&](int mp, int piece) __attribute__((always_inline)) {
+                    if (piece >= 6) return;
+                    const int c = piece / 3, part = piece % 3;
+                    if (part < 2) {
+                        unsigned w[8];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { w[u] = Bn[c][2 * mp][u]; w[4 + u] = Bn[c][2 * mp + 1][u]; }
+                        if (part == 0) {
+                            relu8(w);
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) { Bn[c][2 * mp][u] = w[u]; Bn[c][2 * mp + 1][u] = w[4 + u]; }
+                        } else {
+                            mw[c][mp >> 1] |= mask8(w) << (8 * (mp & 1));
+                        }
+                    } else {
+                        constexpr float DIV = 1.f / (float)(1 << NCA_H8_LOG2);
+                        u32x4 q;
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) q[w] = cvt4_e4m3_pk(Bn[c][2 * mp + (w >> 1)][2 * (w & 1)], Bn[c][2 * mp + (w >> 1)][2 * (w & 1) + 1], DIV);
+                        if (st_ok) store_nt(hblk + c * a.rows_total + lane * 16 + mp * 1024, q);
+                    }
+                };
+                if constexpr (P2) {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        f32x16 acc0, acc1;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) { const float b = tail[(lh * MT + m) * 16 + i]; acc0[i] = b; acc1[i] = b; }
+                        if (m == 0) mma_rowtile_ring<NKS, MT, KSMAX, RINGK>(imgl, m, A, B, acc0, acc1);
+                        else mma_rowtile_ring_il<NKS, MT, KSMAX, RINGK>(imgl, m, A, B, acc0, acc1, [&](int ks) __attribute__((always_inline)) { deferred(m - 1, ks); });
+                        if (m > 0 && NKS < 6) {
+#pragma unroll
+                            for (int pc = NKS; pc < 6; ++pc) deferred(m - 1, pc);
+                        }
+                        pack_only(m, acc0, acc1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int pc = 0; pc < 6; ++pc) deferred(MT - 1, pc);
+                    return;
+                }
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
                     f32x16 acc0, acc1;
@@ -1264,6 +1344,53 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                         }
                     };
                     f32x16 pend0, pend1;
+                    // NCA_BF_PIPE2 (as in the storing forward): behind the MFMAs of row tile m only the conversions to bf16 run, into
+                    // the next layer's operand slots; mask, e5m2 conversion and the store of row tile m follow in six pieces behind the
+                    // MFMA pairs of row tile m + 1 (from a store with e5m2 staging and the mask bits at hand: the bench path)
+                    constexpr bool P2 = NCA_BF_PIPE2 && S8 && STORED && !(NCA_EXP & (1 | 2 | 128 | 8192));
+                    if constexpr (P2) {
+                        auto pack_only = [&](int m, const f32x16& acc0, const f32x16& acc1) __attribute__((always_inline)) {
+#pragma unroll
+                            for (int c = 0; c < 2; ++c) {
+                                const f32x16& acc = c == 0 ? acc0 : acc1;
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) { Bout[c][2 * m][u] = pack2_pk(acc[2 * u], acc[2 * u + 1]); Bout[c][2 * m + 1][u] = pack2_pk(acc[8 + 2 * u], acc[8 + 2 * u + 1]); }
+                            }
+                        };
+                        auto deferred = [&](int mp, int piece) __attribute__((always_inline)) {
+                            if (piece >= 6) return;
+                            const int c = piece / 3, part = piece % 3;
+                            if (part < 2) {             // fragment 2 mp + part: the masked halves of its four words cleared
+                                const unsigned fld = mv[2 * c + (mp >> 1)] >> (8 * (mp & 1));
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) Bout[c][2 * mp + part][u] = keep_pk(Bout[c][2 * mp + part][u], (fld >> (4 * part + u)) & 0x00010001u);
+                            } else {
+                                u32x4 q8;
+#pragma unroll
+                                for (int s2 = 0; s2 < 2; ++s2) {
+                                    q8[2 * s2] = cvt4_e5m2_pk(Bout[c][2 * mp + s2][0], Bout[c][2 * mp + s2][1], inv_s);
+                                    q8[2 * s2 + 1] = cvt4_e5m2_pk(Bout[c][2 * mp + s2][2], Bout[c][2 * mp + s2][3], inv_s);
+                                }
+                                store_nt(dblk + c * a.d_total + lane * 16 + mp * 1024, q8);
+                            }
+                        };
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) {
+                            f32x16 acc0, acc1;
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+                            if (m == 0) mma_rowtile_ring<KS, MT, KSMAX, RINGK>(imgl, m, A, Bin, acc0, acc1);
+                            else mma_rowtile_ring_il<KS, MT, KSMAX, RINGK>(imgl, m, A, Bin, acc0, acc1, [&](int ks) __attribute__((always_inline)) { deferred(m - 1, ks); });
+                            if (m > 0 && KS < 6) {
+#pragma unroll
+                                for (int pc = KS; pc < 6; ++pc) deferred(m - 1, pc);
+                            }
+                            pack_only(m, acc0, acc1);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+#pragma unroll
+                        for (int pc = 0; pc < 6; ++pc) deferred(MT - 1, pc);
+                    } else {
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
                         f32x16 acc0, acc1;
@@ -1280,6 +1407,7 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                         }
                     }
                     if (NCA_BF_PIPE) epilogue(MT - 1, pend0, pend1);
+                    }
                     NCA_STAMP(3)
                     if (!RES) stage_publish_counted<(S8 && STORED) ? 2 * MT : 4 * MT>(st_ok);              // D stores
                     cur ^= 1;
