@@ -1749,6 +1749,23 @@ __device__ __forceinline__ void dma_piece(const char* src, char* to) {
 // first KiB of its slot, and the fragment bytes are rebuilt on the vector ALU, 4 bytes in 4 instructions: nibble, x 0x204081 &
 // 0x01010101 (one bit per byte), packed 16-bit multiply by the byte.  The nibbles come in mask-bit order, so the rows of dW come
 // out in the order wgrad_write<EXPAND> undoes.  9 B per sample instead of F.
+// NCA_WGRAD_TR: the transposes by the LDS read instead of by MFMAs.  A fragment sits in its ring slot as [lane][16 B] = 16 features of
+// one sample per lane; ds_read_b64_tr_b8 hands lane i of a 16-lane group byte column i of 8 rows whose addresses the group's lanes
+// supply (lane 2q + p: row q, bytes 8p .. 8p+7; tools/ds_tr8_probe.hip), so with rows = 8 consecutive samples and the two byte halves
+// taken from the two lane halves of the fragment, a lane receives 8 consecutive samples of ONE feature -- at the same feature
+// position the identity MFMAs put it (wgrad_write does not change).  Two reads per block and 32-sample tile fill the 16 K bytes
+// a lane takes from that tile (lane half h: samples 16h .. 16h+15; both operands alike, which is all the contraction needs):
+// 32 ds_read_b64_tr_b8 per wave tile replace 16 ds_read_b128, 32 transposing MFMAs and 128 conversions back to bytes.  The bias
+// gradient (column sums of the transposed D tile before) becomes one more MX product per row block: A = a row selector (1.0 in row
+// m), B = the D operand itself, so row m of one extra accumulator collects block m's sums over the 64 samples, scaled like dW.
+// Measured at the bench size (tools/variant_build.sh tr "-DNCA_WGRAD_TR=1"; the fp8-staging oracle tests pass, the loss differs in
+// the 7th digit: another summation order): weight gradient 4.72 - 4.88 -> 4.93 ms, step 13.43 -> 13.70 - 13.88 ms on the same box.
+// The launch is bound by its HBM reads, and what the vector ALU and the small MFMAs no longer do the LDS transpose network and
+// four more MX products do.  Off.
+#ifndef NCA_WGRAD_TR
+#define NCA_WGRAD_TR 0
+#endif
+typedef int i32x2 __attribute__((ext_vector_type(2)));
 template <int F, int NTB, bool H8, bool EXPAND = false>
 __device__ __forceinline__ void wgrad_job_mx(const NcaWgradArgs& a, const NcaWgradJob& job, int q, int nsplit, int lane, char* ring) {
     using R = WgradRing<F, NTB, true, H8>;
@@ -1839,6 +1856,12 @@ __device__ __forceinline__ void wgrad_job_mx(const NcaWgradArgs& a, const NcaWgr
     const long ED0 = ident8<true>(8 * lh, lc), ED1 = ident8<true>(16 + 8 * lh, lc);          // e5m2 identity (D blocks)
     const long EH0 = ident8<false>(8 * lh, lc), EH1 = ident8<false>(16 + 8 * lh, lc);        // e4m3 identity (e4m3 H blocks)
     const u32x4 EB0 = ident_frag(8 * lh, lc), EB1 = ident_frag(16 + 8 * lh, lc);             // bf16 identity (bf16 H blocks)
+    constexpr bool TR = NCA_WGRAD_TR && !EXPAND && MT == 4 && NTB == 4 && H8;       // (an expand job rebuilds its D fragments in registers: it keeps the MFMA transposes, for both operands -- they must agree on the K order)
+    // transposed reads: this lane's row / byte-half inside a fragment (see above); + 1024 per fragment, + 128 for the second 8 samples
+    const int troff = (32 * (lc & 1) + 16 * lh + ((lc & 15) >> 1)) * 16 + 8 * ((lc >> 4) & 1);
+    f32x16 accb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[r] = 0.f;
     for (int64_t i = 0; i < n; i += 2) {
         i32x8 PA[MT], PB[NTB];
         float sc = 0.f;
@@ -1853,8 +1876,20 @@ __device__ __forceinline__ void wgrad_job_mx(const NcaWgradArgs& a, const NcaWgr
             }
             if (half == 0) sc = *reinterpret_cast<const float*>(ring + SC0 + rslot * 256 + lane * 4);
             const char* slot = ring + rslot * (FR * 1024) + lane * 16;
+            const char* trp = ring + rslot * (FR * 1024) + troff;
             rslot = rslot + 1 == NSLOT ? 0 : rslot + 1;
+            auto tr_block = [&](int frag, i32x8& P) __attribute__((always_inline)) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const i32x2 v = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) i32x2*)(trp + frag * 1024 + t * 128));
+                    P[4 * half + 2 * t] = v[0]; P[4 * half + 2 * t + 1] = v[1];
+                }
+            };
             u32x4 xd[MT];
+            if constexpr (TR) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) tr_block(m, PA[m]);
+            } else {
             if constexpr (EXPAND) {
                 const char* sm = slot - lane * 12;
                 const unsigned mw[2] = {*reinterpret_cast<const unsigned*>(sm), *reinterpret_cast<const unsigned*>(sm + 256)};
@@ -1892,7 +1927,11 @@ __device__ __forceinline__ void wgrad_job_mx(const NcaWgradArgs& a, const NcaWgr
 #pragma unroll
                 for (int w = 0; w < 4; ++w) PA[m][4 * half + w] = (int)z4_e5m2(z[4 * w], z[4 * w + 1], z[4 * w + 2], z[4 * w + 3]);
             }
-            if constexpr (H8 && NTB == 4) {                  // H: e4m3 bytes -> transposed bytes
+            }
+            if constexpr (TR) {
+#pragma unroll
+                for (int c = 0; c < NTB; ++c) tr_block(ND_ + c, PB[c]);
+            } else if constexpr (H8 && NTB == 4) {                  // H: e4m3 bytes -> transposed bytes
                 u32x4 x[4];
                 f32x16 z[4];
 #pragma unroll
@@ -1934,6 +1973,20 @@ __device__ __forceinline__ void wgrad_job_mx(const NcaWgradArgs& a, const NcaWgr
 #pragma unroll
             for (int c = 0; c < NTB; ++c)
                 acc[m][c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(PA[m], PB[c], acc[m][c], 1 /* A: e5m2 */, 0 /* B: e4m3 */, 0, sa, 0, 127);
+        if constexpr (TR) {
+            // bias sums: row m of accb += sum over the 64 samples of block m (A = 1.0 in row m, B = the D operand, its scale without
+            // the layer inputs' 2^-NCA_H8_LOG2)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int one = lc == m ? 0x38383838 : 0;
+                const i32x8 sel = {one, one, one, one, one, one, one, one};
+                accb = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(sel, PA[m], accb, 0 /* A: e4m3 */, 1 /* B: e5m2 */, 0, 127, 0, sa + NCA_H8_LOG2);
+            }
+        }
+    }
+    if constexpr (TR) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) bsum[m] = lh == 0 ? accb[m] : 0.f;          // (rows 0 .. 3 sit in registers 0 .. 3 of lane half 0)
     }
     wgrad_write<F, NTB, EXPAND>(acc, bsum, job, a.slab + (int64_t)q * a.slab_stride, a.accumulate, lane);
 }
