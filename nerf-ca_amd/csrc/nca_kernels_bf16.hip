@@ -336,8 +336,7 @@ constexpr int NCA_BF_RING = 4;
 // e5m2-staged store does the same with its mask / conversion / store.  Measured at the bench size (tools/variant_build.sh p2
 // "-DNCA_BF_PIPE2=1", bit-identical results, 246 / 234 VGPRs and no vector spill): forward 4.63 -> 4.45 ms, backward 3.63 -> 3.57 ms
 // per step in the per-kernel table -- and the graph-replayed STEP 13.03 -> 12.99 ms: what the two kernels gain the weight gradient
-// behind them loses (4.46 -> 4.87 ms in one run).  Same instructions, same bytes, same energy: under the power cap the step does
-// not care how they overlap.  Off.
+// behind them loses (4.46 -> 4.87 ms in one run).  Same instructions, same bytes: the step did not care how they overlap.  Off.
 #ifndef NCA_BF_PIPE2
 #define NCA_BF_PIPE2 0
 #endif
