@@ -93,6 +93,7 @@ class FieldBinding:
         self.packed: Optional[torch.Tensor] = None
         self.static_window: Optional[torch.Tensor] = None   # device f32[L] that overrides the module's band window
         self._offsets: List[int] = []
+        self._pads: List[tuple] = []                        # (padded shape, logical shape) per parameter
         self.gaps: List[tuple] = []                         # (offset, count) of bias slots of a module built with use_bias=False
         self.reflatten()
 
@@ -115,22 +116,38 @@ class FieldBinding:
             return
         dev = ps[0].device
         biasless = not getattr(self.module, "use_bias", True)
-        slots = []                                     # (parameter or None, numel)
+        F = int(getattr(self.module, "num_filters", self.net.F))
+        Fp = int(self.net.F)                          # the kernels' width: F rounded up to 32 / 64 / 128 (model/_field.py)
+        # (parameter, logical shape, padded shape) per slot of the library's natural order.  A net narrower than the kernels' width
+        # runs as the wider net whose extra units have zero weights and biases: they stay at relu(0) = 0, feed nothing and receive
+        # zero gradients, so no optimiser ever moves them; every parameter is the leading [rows, columns] block of its padded matrix.
+        slots = []
         for name, p in self.module.named_parameters():
-            slots.append((p, p.numel()))
-            if biasless and name.endswith(".weight"):
-                slots.append((None, p.shape[0]))
-        flat = torch.zeros(sum(n for _, n in slots), dtype=torch.float32, device=dev)
-        self._offsets, self.gaps = [], []
+            if name.endswith(".weight"):
+                out, inn = p.shape
+                first, last = name.startswith("early_pts_layers.0."), name.startswith("output_linear.")
+                slots.append((p, (out, inn), (out if last else Fp, inn if first else inn + (Fp - F))))
+                if biasless:
+                    slots.append((None, None, (1 if last else Fp,)))
+            elif name.endswith(".bias"):
+                slots.append((p, tuple(p.shape), (1 if name.startswith("output_linear.") else Fp,)))
+            else:
+                slots.append((p, tuple(p.shape), tuple(p.shape)))
+        numel = lambda shp: int(torch.Size(shp).numel())
+        flat = torch.zeros(sum(numel(pad) for _, _, pad in slots), dtype=torch.float32, device=dev)
+        self._offsets, self._pads, self.gaps = [], [], []
         off = 0
         with torch.no_grad():
-            for p, n in slots:
+            for p, shp, pad in slots:
+                n = numel(pad)
                 if p is None:
                     self.gaps.append((off, n))
                 else:
-                    flat[off:off + n].copy_(p.detach().reshape(-1).to(torch.float32))
-                    p.data = flat[off:off + n].view(p.shape)
+                    view = flat[off:off + n].view(pad)[tuple(slice(0, d) for d in shp)]
+                    view.copy_(p.detach().to(torch.float32))
+                    p.data = view
                     self._offsets.append(off)
+                    self._pads.append((pad, shp))
                 off += n
         self.flat = flat
         self.packed = None
@@ -144,8 +161,10 @@ class FieldBinding:
         if self.flat is None:
             return False
         base = self.flat.data_ptr()
-        for p, off in zip(self.params(), self._offsets):
-            if p.data_ptr() != base + 4 * off or p.dtype != torch.float32:
+        for p, off, (pad, shp) in zip(self.params(), self._offsets, self._pads):
+            if p.data_ptr() != base + 4 * off or p.dtype != torch.float32 or tuple(p.shape) != tuple(shp):
+                return False
+            if tuple(p.stride()) != tuple(torch.empty(pad, device="meta").stride()):
                 return False
         return True
 
@@ -168,8 +187,9 @@ class FieldBinding:
 
     def split_grads(self, gflat: torch.Tensor) -> List[torch.Tensor]:
         out = []
-        for p, off in zip(self.params(), self._offsets):
-            out.append(gflat[off:off + p.numel()].view(p.shape))
+        for off, (pad, shp) in zip(self._offsets, self._pads):
+            n = int(torch.Size(pad).numel())
+            out.append(gflat[off:off + n].view(pad)[tuple(slice(0, d) for d in shp)])
         return out
 
 

@@ -78,7 +78,11 @@ class FieldBase(nn.Module):
         mode = _capi.ENC_NONE
         if self.use_pos_enc != "none" and self.pos_enc_basis > 0:
             mode = _capi.ENC_FOURIER if self.use_pos_enc == "fourier" else _capi.ENC_BANDS
-        net = _capi.NcaNet(F=self.num_filters, n_hidden=self.num_early_layers, n_late=self.num_late_layers, enc_mode=mode,
+        if self.num_filters < 1 or self.num_filters > 128:
+            raise _capi.NcaError(f"num_filters = {self.num_filters}: the fused kernels run nets of up to 128 units per layer")
+        # the kernels exist for 32, 64 and 128 units: a net of another width runs as the next one up with zero-weight units (FieldBinding)
+        width = 32 if self.num_filters <= 32 else (64 if self.num_filters <= 64 else 128)
+        net = _capi.NcaNet(F=width, n_hidden=self.num_early_layers, n_late=self.num_late_layers, enc_mode=mode,
                            L=self.pos_enc_basis if mode != _capi.ENC_NONE else 0, T=time_dim, P=phases, reserved=0)
         object.__setattr__(self, "_binding", FieldBinding(self, net))
 

@@ -113,7 +113,7 @@ class CompositeTrainer:
         kw = {}
         if fused_adam is None:
             fused_adam = device.type == "cuda" if isinstance(device, torch.device) else str(device).startswith("cuda")
-        if fused_adam:
+        if fused_adam and all(p.is_contiguous() for p in self.params):      # (nets padded to a kernel width own strided views: torch's fused Adam wants one layout)
             kw["fused"] = True
         self.opt = torch.optim.Adam([{"params": self.params, "lr": cfg.lr}], lr=cfg.lr, **kw)
         self.sched = torch.optim.lr_scheduler.LinearLR(self.opt, start_factor=1, end_factor=cfg.lr_end_factor, total_iters=cfg.lr_decay_steps)
@@ -706,7 +706,7 @@ class StaticTrainer:
         kw = {}
         if fused_adam is None:
             fused_adam = torch.device(device).type == "cuda"
-        if fused_adam:
+        if fused_adam and all(p.is_contiguous() for p in self.params):      # (nets padded to a kernel width own strided views: torch's fused Adam wants one layout)
             kw["fused"] = True
         self.opt = torch.optim.Adam([{"params": self.params, "lr": cfg.lr}], lr=cfg.lr, **kw)
         self.sched = torch.optim.lr_scheduler.LinearLR(self.opt, start_factor=1, end_factor=cfg.lr_end_factor, total_iters=cfg.lr_decay_steps)

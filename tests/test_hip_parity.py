@@ -1725,3 +1725,63 @@ def test_nets_without_biases(dev, prec):
         for off, n in m._binding.gaps:
             assert float(m._binding.flat[off:off + n].abs().max()) == 0.0
         assert m._binding._is_flat()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Fs,Fd,late", [(48, 20, 0), (100, 100, 0), (96, 33, 2), (7, 128, 0)])
+def test_nets_of_any_width_up_to_128(dev, Fs, Fd, late):
+    """num_filters other than 32 / 64 / 128 (the reference's CPPN / Temporal accept any, model/CPPN.py:15-19): the net runs at the
+    next kernel width with zero-weight units; parameters keep the reference's shapes (state_dict, optimiser), are views into the
+    padded flat buffer and the padding stays exactly zero through optimiser steps.  f32 outputs and gradients against the oracle."""
+    from nerfca_amd import render_rays
+    from nerfca_amd.fused import FusedAdam
+    R, S = 19, 40
+    gen = torch.Generator().manual_seed(100 + Fs + Fd)
+    ss = O.NetSpec(num_filters=Fs, num_early_layers=2, num_late_layers=late, num_time_dim=0)
+    sd = O.NetSpec(num_filters=Fd, num_early_layers=3, num_time_dim=8)
+    ps, pd = O.init_params(ss, gen), O.init_params(sd, gen)
+    win = O.freq_mask_alpha(12, 75000, 150000, 1)[0]
+    o = (torch.rand(R, 3, generator=gen) * 0.2 + torch.tensor([3.0, -2.0, 2.5])).to(torch.float64)
+    d = (torch.rand(R, 3, generator=gen) - 0.5).to(torch.float64)
+    d = d / d.norm(dim=-1, keepdim=True) * 1.001
+    ph = torch.randint(0, 10, (R,), generator=gen)
+    z = O.stratified_depths(O.depth_values(3.4259, 5.5741, S), torch.rand(S, generator=gen))
+    I0 = torch.full((R,), 2.15991)
+    cp, cs, cd = torch.randn(R, generator=gen).to(torch.float64), torch.randn(R, S, generator=gen), torch.randn(R, S, generator=gen)
+    pix, a, b, dists, ps64, pd64 = _oracle_render_grads(ps, ss, pd, sd, win, o, d, ph, I0, z, cp, cs, cd, torch.float64)
+    _, _, _, _, ps32, pd32 = _oracle_render_grads(ps, ss, pd, sd, win, o, d, ph, I0, z, cp, cs, cd, torch.float32)
+    s = make_static(ps, dev, F=Fs, early=2, late=late)
+    t = make_dynamic(pd, dev, F=Fd, early=3, late=0, T=8)
+    s.update_freq_mask_alpha(75000, 150000)
+    t.update_freq_mask_alpha(75000, 150000)
+    for m, prm in ((s, ps), (t, pd)):
+        assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v.shape) for k, v in prm.items()}
+        assert m._binding._is_flat()
+    pix2, a2, b2 = render_rays(s, t, o.to(dev), d.to(dev), ph.to(dev), I0.to(dev), z.to(dev), dists.to(dev))
+    assert rel_err(pix2.cpu(), pix) < TOL and rel_err(a2.cpu(), a) < TOL and rel_err(b2.cpu(), b) < TOL
+    ((pix2 * cp.to(dev)).sum() + (a2 * cs.to(dev)).sum() * 50 + (b2 * cd.to(dev)).sum() * 50).backward()
+    for name, got, p32, p64 in (("static", grads_of(s), ps32, ps64), ("dynamic", grads_of(t), pd32, pd64)):
+        for k in p32:
+            floor = rel_err(p32[k].grad, p64[k].grad)
+            assert rel_err(got[k], p64[k].grad) < max(TOL, 3 * floor), (name, k, floor)
+    # the padding of the flat buffers is zero and stays zero: torch's Adam on the views, the library's Adam on the whole buffers
+    def padding_is_zero(m):
+        bnd = m._binding
+        mask = torch.ones_like(bnd.flat, dtype=torch.bool)
+        for g in bnd.split_grads(mask):
+            g.fill_(False)
+        return float(bnd.flat[mask].abs().max()) == 0.0 if bool(mask.any()) else True
+    opt = torch.optim.Adam(list(t.parameters()) + list(s.parameters()), lr=1e-2)
+    opt.step()
+    assert padding_is_zero(s) and padding_is_zero(t) and s._binding._is_flat() and t._binding._is_flat()
+    pix3, _, _ = render_rays(s, t, o.to(dev), d.to(dev), ph.to(dev), I0.to(dev), z.to(dev), dists.to(dev))
+    assert torch.isfinite(pix3).all() and not torch.equal(pix3, pix2)
+    if late == 0:
+        import nerfca_amd
+        nerfca_amd.set_precision("bf16", s, t)
+        pix4, a4, b4 = render_rays(s, t, o.to(dev), d.to(dev), ph.to(dev), I0.to(dev), z.to(dev), dists.to(dev))
+        assert rel_err(pix4, pix3) < 5e-3
+        (pix4.sum() + a4.sum() + b4.sum()).backward()
+        adam = FusedAdam([t, s], lr=1e-2)
+        adam.step([torch.cat([torch.zeros_like(t._binding.flat)]), torch.zeros_like(s._binding.flat)])
+        assert padding_is_zero(s) and padding_is_zero(t)

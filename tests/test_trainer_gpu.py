@@ -288,3 +288,42 @@ def test_graph_step_with_fine_pass_matches_fused_step(dev, prec):
         tol = (2e-5 if prec == "f32" else 2e-3) if k == 0 else (5e-3 if prec == "f32" else 2e-2)
         assert abs(a[0] - b[0]) <= tol * abs(a[0]) and abs(a[1] - b[1]) <= tol * abs(a[1]), (k, outs[0][0], outs[1][0])
     assert rel_err(outs[1][1], outs[0][1]) < (5e-3 if prec == "f32" else 2e-2)
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_trainer_with_odd_widths(dev, prec):
+    """CompositeTrainer over nets of 48 units (kernel width 64): the autograd step with torch's fused Adam, the fused step and the
+    graph-replayed step all train (parameters are strided views into the padded flat buffers), agree on the first step's loss and
+    leave the padding at zero."""
+    import nerfca_amd
+    from nerfca_amd import synthetic
+    from nerfca_amd.model.CPPN import CPPN
+    from nerfca_amd.model.Temporal import Temporal
+    from nerfca_amd.train.trainer import CompositeTrainer, TrainConfig
+    data = synthetic.make_dataset(16, 48, dev, views=synthetic.TRAIN_VIEWS[:2], n_phases=3, F=32)
+    losses = {}
+    for mode in ("autograd", "fused", "graph"):
+        torch.manual_seed(5)
+        sdef, tdef = synthetic.net_definitions(dev, F=48)
+        s, t = CPPN(sdef).to(dev), Temporal(tdef).to(dev)
+        nerfca_amd.set_precision(prec, s, t)
+        cfg = TrainConfig(depth_samples_per_ray_coarse=48, img_sample_size=160)
+        tr = CompositeTrainer(cfg, s, t, data, dev, seed=3, fused_loss=(mode != "autograd"))
+        step = tr.step_graph if mode == "graph" else tr.step
+        first = None
+        for it in range(3):
+            loss, _, _ = step(1000 + it)
+            first = float(loss) if first is None else first
+        assert torch.isfinite(loss)
+        losses[mode] = first
+        for m in (s, t):
+            bnd = m._binding
+            assert bnd.net.F == 64 and m.num_filters == 48 and bnd._is_flat()
+            mask = torch.ones_like(bnd.flat, dtype=torch.bool)
+            for g in bnd.split_grads(mask):
+                g.fill_(False)
+            assert bool(mask.any()) and float(bnd.flat[mask].abs().max()) == 0.0
+            assert tuple(m.state_dict()["early_pts_layers.2.weight"].shape) == (48, 48)
+    tol = 1e-5 if prec == "f32" else 2e-2
+    assert abs(losses["fused"] - losses["autograd"]) <= tol * abs(losses["autograd"]), losses
+    assert abs(losses["graph"] - losses["fused"]) <= 1e-6 * abs(losses["fused"]), losses
