@@ -94,6 +94,7 @@ class FieldBinding:
         self.static_window: Optional[torch.Tensor] = None   # device f32[L] that overrides the module's band window
         self._offsets: List[int] = []
         self._pads: List[tuple] = []                        # (padded shape, logical shape) per parameter
+        self._strides: List[tuple] = []                     # the parameter views' strides
         self.gaps: List[tuple] = []                         # (offset, count) of bias slots of a module built with use_bias=False
         self.reflatten()
 
@@ -135,7 +136,7 @@ class FieldBinding:
                 slots.append((p, tuple(p.shape), tuple(p.shape)))
         numel = lambda shp: int(torch.Size(shp).numel())
         flat = torch.zeros(sum(numel(pad) for _, _, pad in slots), dtype=torch.float32, device=dev)
-        self._offsets, self._pads, self.gaps = [], [], []
+        self._offsets, self._pads, self._strides, self.gaps = [], [], [], []
         off = 0
         with torch.no_grad():
             for p, shp, pad in slots:
@@ -148,6 +149,7 @@ class FieldBinding:
                     p.data = view
                     self._offsets.append(off)
                     self._pads.append((pad, shp))
+                    self._strides.append(tuple(view.stride()))
                 off += n
         self.flat = flat
         self.packed = None
@@ -161,10 +163,8 @@ class FieldBinding:
         if self.flat is None:
             return False
         base = self.flat.data_ptr()
-        for p, off, (pad, shp) in zip(self.params(), self._offsets, self._pads):
-            if p.data_ptr() != base + 4 * off or p.dtype != torch.float32 or tuple(p.shape) != tuple(shp):
-                return False
-            if tuple(p.stride()) != tuple(torch.empty(pad, device="meta").stride()):
+        for p, off, st in zip(self.params(), self._offsets, self._strides):
+            if p.data_ptr() != base + 4 * off or p.dtype != torch.float32 or p.stride() != st:
                 return False
         return True
 
