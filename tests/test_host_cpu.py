@@ -379,3 +379,42 @@ def test_shipped_library_is_not_a_timing_build():
         _capi.set_option(_capi.OPT_WGRAD_REBUILD_WEIGHT_PCT, 99)
     with pytest.raises(_capi.NcaError):
         _capi.get_option(99)
+
+
+def test_flat_buffer_of_padded_and_biasless_nets():
+    """Host logic of FieldBinding (no GPU): a net of 48 units is laid out at the kernels' width 64 -- every parameter the leading block
+    of its padded matrix, as a view into ONE flat buffer in the library's natural order whose size is what the descriptor expects,
+    padding zero; without biases the bias slots stay in the buffer as zero gaps; state_dict keeps the reference's shapes and
+    load_state_dict writes through the views; split_grads cuts the same blocks out of a gradient in the buffer's layout."""
+    from nerfca_amd import _capi
+    from nerfca_amd.model.CPPN import CPPN
+    from nerfca_amd.model.Temporal import Temporal
+    from nerfca_amd import synthetic
+    sdef, tdef = synthetic.net_definitions("cpu", F=48, early=2)
+    torch.manual_seed(0)
+    for cls, d, bias in ((CPPN, sdef, True), (Temporal, tdef, True), (CPPN, sdef, False), (Temporal, tdef, False)):
+        d = dict(d, use_bias=bias)
+        m = cls(d)
+        b = m._binding
+        assert b.net.F == 64 and m.num_filters == 48
+        assert b.flat.numel() == _capi.check(_capi.lib().nca_param_count(C.byref(b.net)))
+        assert b._is_flat()
+        shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        assert shapes["early_pts_layers.2.weight"] == (48, 48) and shapes["output_linear.0.weight"] == (1, 48)
+        assert ("early_pts_layers.0.bias" in shapes) == bias
+        assert bool(b.gaps) == (not bias)
+        # everything outside the parameter views is zero, and the views cover exactly the parameters
+        mask = torch.ones_like(b.flat, dtype=torch.bool)
+        for g in b.split_grads(mask):
+            g.fill_(False)
+        assert int((~mask).sum()) == sum(p.numel() for p in m.parameters()) and float(b.flat[mask].abs().max()) == 0.0
+        # writes through load_state_dict land in the flat buffer
+        sd = {k: torch.full_like(v, 0.5) for k, v in m.state_dict().items()}
+        m.load_state_dict(sd)
+        assert b._is_flat() and float(b.flat[~mask].min()) == 0.5 and float(b.flat[mask].abs().max()) == 0.0
+        with torch.no_grad():
+            for p in m.parameters():
+                p.add_(1.0)
+        assert float(b.flat[~mask].min()) == 1.5 and float(b.flat[mask].abs().max()) == 0.0
+    with pytest.raises(_capi.NcaError, match="128"):
+        CPPN(dict(sdef, num_filters=256))
