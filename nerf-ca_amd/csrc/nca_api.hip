@@ -799,9 +799,12 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     // recomputes from a bf16 block: bf16 staging only)
     const bool nr = h8;
     const bool onchip = oc_min >= 0 && bf && stored && !nr && units * tiles_per_unit >= oc_min;
+    // EXPERIMENT (NCA_ONCHIP_NR, nca_kernels.hpp): fp8 staging with layer NL - 2's weight gradient on chip -- streamed weights, one launch per net
+    bool oc_nr = NCA_ONCHIP_NR && NCA_WAVES == 4 && nr && d8 && bf && stored && lays[0].F == 128 && !getenv("NCA_ONCHIP_NR_OFF");
+    for (int n = 0; n < a.nnets; ++n) oc_nr = oc_nr && lays[n].NL >= 3 && lays[n].F == 128;
     // ... or, without the on-chip layer, one launch per net with that net's weight images resident in LDS
     const int64_t res_min = opt_value(NCA_OPT_RESIDENT_MIN_TILES);
-    bool res3 = !onchip && bf && stored && res_min >= 0 && units * tiles_per_unit >= res_min;
+    bool res3 = !onchip && !oc_nr && bf && stored && res_min >= 0 && units * tiles_per_unit >= res_min;
     if (res3) {          // ... only if every net's images do fit (else: one launch for both nets, streaming)
         for (int n = 0; n < a.nnets && res3; ++n) {
             static thread_local NcaFusedArgs probe;
@@ -815,9 +818,9 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
             res3 = plan_resident(&probe, nr ? NCA_KM_BWD_NR : NCA_KM_BWD_STORED);
         }
     }
-    const bool per_net_launch = onchip || res3;
+    const bool per_net_launch = onchip || res3 || oc_nr;
     BwdPlan p;
-    int rc = plan_bwd(lays, a.nnets, prec, units, tiles_per_unit, work_bytes, &p, stored, onchip, d8, nr);
+    int rc = plan_bwd(lays, a.nnets, prec, units, tiles_per_unit, work_bytes, &p, stored, onchip || oc_nr, d8, nr);
     if (rc) return rc;
     if (!work || work_bytes < p.bytes_total) return fail(NCA_E_WORKSPACE, "backward workspace %lld < %lld bytes", (long long)work_bytes, (long long)p.bytes_total);
     char* wb = static_cast<char*>(work);
@@ -861,7 +864,7 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     memset(&w, 0, sizeof(w));
     for (int n = 0; n < a.nnets; ++n) {
         if (bf) add_jobs_bf16(&w, n, lays[n], a.net[n].row0, a.net[n].drow0, slab_off[n], onehot_off[n],
-                              stored && a.share_enc && n == 0 ? a.net[1].row0 : a.net[n].row0, onchip ? lays[n].NL - 1 : -1, h8, d8,
+                              stored && a.share_enc && n == 0 ? a.net[1].row0 : a.net[n].row0, oc_nr ? lays[n].NL - 2 : (onchip ? lays[n].NL - 1 : -1), h8, d8,
                               p.tile_stride - NCA_D8_REC_BYTES, nr && d8 ? lays[n].NL - 1 : -1, spl.mask_layers);
         else add_jobs_f32(&w, lays[n], a.net[n].row0, a.net[n].drow0, slab_off[n], onehot_off[n]);
     }
@@ -918,7 +921,7 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
                 one.nnets = 1;
                 one.net[0] = a.net[n];
                 one.net_base = n;
-                one.onchip = onchip ? 1 : 0;
+                one.onchip = oc_nr ? (getenv("NCA_ONCHIP_NR_DRY") ? 3 : 2) : (onchip ? 1 : 0);          // (3: the launch structure without the on-chip work -- timing only, that layer's gradient is then missing)
                 one.wslab = reinterpret_cast<float*>(wb + p.off_wslab) + (int64_t)n * num_cus() * p.wslab_stride;
                 one.wslab_stride = p.wslab_stride;
                 NetBind b1[2] = {binds[n], {}};
@@ -1003,11 +1006,12 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
         rn.tail_from_sums = nr ? 1 : 0;
         rn.tl_w_off = lays[n].layer[lays[n].NL - 1].w_off;
         rn.tl_b_off = lays[n].layer[lays[n].NL - 1].b_off;
-        if (onchip) {
+        if (onchip || oc_nr) {
+            const int ocl = oc_nr ? lays[n].NL - 2 : lays[n].NL - 1;
             rn.wslab = reinterpret_cast<const float*>(wb + p.off_wslab) + (int64_t)n * num_cus() * p.wslab_stride;
             rn.wslab_stride = p.wslab_stride;
-            rn.oc_w_off = lays[n].layer[lays[n].NL - 1].w_off;
-            rn.oc_b_off = lays[n].layer[lays[n].NL - 1].b_off;
+            rn.oc_w_off = lays[n].layer[ocl].w_off;
+            rn.oc_b_off = lays[n].layer[ocl].b_off;
         }
     }
     {
@@ -1057,6 +1061,11 @@ extern "C" int64_t nca_render_bwd_workspace(const NcaRays* rays, const NcaNet* n
         rc = plan_bwd(lays, nn, prec, rays->R, (rays->S + ts - 1) / ts, max_bytes, &p, true, false, false, true);
         if (rc) return rc;
         if (p.bytes_total > need) need = p.bytes_total;
+        if (NCA_ONCHIP_NR) {       // (experiment: fp8 staging with one layer on chip)
+            rc = plan_bwd(lays, nn, prec, rays->R, (rays->S + ts - 1) / ts, max_bytes, &p, true, true, true, true);
+            if (rc) return rc;
+            if (p.bytes_total > need) need = p.bytes_total;
+        }
     }
     return need;
 }

@@ -7,6 +7,14 @@
 #define NCA_WAVES 8     // waves per workgroup of the fused kernels: 2 per SIMD (tools/variant_build_all.sh w4 "-DNCA_WAVES=4": one per SIMD, for timing)
 #endif
 #define NCA_NT (64 * NCA_WAVES)
+// EXPERIMENT (off; tools/variant_build_all.sh oc "-DNCA_WAVES=4 -DNCA_ONCHIP_NR=1"): the backward from an fp8-staged store keeps the
+// weight gradient of ONE hidden layer (NL - 2) on chip -- four 512-register waves per workgroup, streamed weights: the layer's e5m2
+// output-gradient fragments go to an LDS tile instead of HBM, its e4m3 input fragments come HBM -> LDS, and after the layer's barrier
+// wave w contracts rows 32w .. 32w+31 of dW over the workgroup's four wave tiles (transposed 8-bit reads, MX MFMAs) into 64 + 16
+// accumulators that are written to the per-workgroup slab (NcaFusedArgs::wslab) at the end.  Prices one layer of DESIGN.md 7-1.
+#ifndef NCA_ONCHIP_NR
+#define NCA_ONCHIP_NR 0
+#endif
 #define NCA_LDS_BYTES 163840   // LDS of a gfx950 compute unit (one workgroup of the fused kernels owns it)
 
 enum { NCA_MODE_RAYS = 0, NCA_MODE_POINTS = 1 };

@@ -31,6 +31,8 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack2(float lo, float hi) {
     bf16x2 v = {(__bf16)lo, (__bf16)hi};
     return __builtin_bit_cast(unsigned, v);
@@ -494,8 +496,11 @@ __device__ __forceinline__ void transpose_block8(const u32x4 (&X)[NX], int lc, i
 // RES (modes 0, 2, 3 with ONE net per launch): every weight image of the launch is RESIDENT in LDS (NcaStage::lds_off, loaded once
 // per workgroup); the tile loop then has no weight DMA, no counted waits and no workgroup barrier -- the eight waves drift apart
 // and fill each other's epilogue and store slots.  The streaming variant double-buffers one image per stage behind a barrier.
+#ifndef NCA_BF_MINBLOCKS
+#define NCA_BF_MINBLOCKS 2     // (1 with NCA_WAVES=4: up to 512 registers per wave -- the NCA_ONCHIP_NR experiment)
+#endif
 template <int F, int MODE, bool S8, bool RES>
-__global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a) {
+__global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const NcaFusedArgs a) {
     constexpr bool ONCHIP = MODE == NCA_KM_BWD_ONCHIP;                        // mode 3 + on-chip dW of the last hidden layer
     constexpr bool NR = MODE == NCA_KM_BWD_NR;                                // from a store with fp8 staging: nothing is recomputed
     constexpr int RINGK = ONCHIP ? 2 : NCA_BF_RING;                           // A-fragment ring of the layer contractions
@@ -517,6 +522,14 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
     // ReLU masks of the recomputed layers: [wave][layer][lane][16 B] (2 bits per packed bf16 pair)
     char* const maskbase = smem + wbytes + CONSTB + NCA_WAVES * 2 * (F + 1) * 4;
     float* const wo_lds = reinterpret_cast<float*>(maskbase);          // mode 5 (no other use of that area there)
+    // NCA_ONCHIP_NR (nca_kernels.hpp): D tiles [wave][column tile][row tile][1 KiB] | H tiles (same) | the four wave tiles' scales
+    constexpr bool OC = NCA_ONCHIP_NR && NR && !RES && S8 && F == 128 && NCA_WAVES == 4;
+    char* const octile = smem + ((2 * BUF + CONSTB + NCA_WAVES * 2 * (F + 1) * 4 + 2 * bf_wo_floats(F) * 4 + 1023) & ~1023);
+    f32x16 ocW[4], ocB;
+    if (OC) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ocW[0][r] = 0.f; ocW[1][r] = 0.f; ocW[2][r] = 0.f; ocW[3][r] = 0.f; ocB[r] = 0.f; }
+    }
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
     if (S8) s8_mode();
@@ -1276,6 +1289,17 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                 u32x4 B2[2][KSMAX];
                 auto sweep_layer = [&](int jj, u32x4 (&Bin)[2][KSMAX], u32x4 (&Bout)[2][KSMAX]) __attribute__((always_inline)) {
                     const int nsi = (si + 1 == a.nstages) ? 0 : si + 1;
+                    const bool oc = OC && a.onchip == 2 && jj == y.NL - 1;          // this step produces D_{NL-2}: the on-chip layer's
+                    if (OC && oc) {
+                        // the on-chip layer's e4m3 input fragments of this wave's tile: store -> H tile (input of layer jj - 1)
+                        const char* hsrc = nb + 32 * 128 + (int64_t)(jj - 2) * 32 * F + lane * 16;
+#pragma unroll
+                        for (int c = 0; c < 2; ++c)
+#pragma unroll
+                            for (int m = 0; m < MT; ++m)
+                                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(hsrc + c * a.rows_total + m * 1024),
+                                                                 (__attribute__((address_space(3))) void*)(octile + 32768 + ((wave * 2 + c) * MT + m) * 1024), 16, 0, 0);
+                    }
                     if (NR) {
                         // this layer's masks were requested before the D stores of the step before (the output layer's step or the
                         // previous iteration): at most those stores are younger
@@ -1339,6 +1363,10 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                                     q8[2 * s2 + 1] = cvt4_e5m2_pk(dw[2], dw[3], inv_s);
                                 } else if (st_ok && !(NCA_EXP & 1)) store_nt(dp + (2 * m + s2) * 1024, dw);
                             }
+                            if (OC && oc) {
+                                const u32x4 zero = {0u, 0u, 0u, 0u};
+                                *reinterpret_cast<u32x4*>(octile + ((wave * 2 + c) * MT + m) * 1024 + lane * 16) = tvalid ? q8 : zero;      // (a wave without a tile repeats the last one: no contribution)
+                            } else
                             if (S8 && STORED && st_ok && !(NCA_EXP & 1)) store_nt(dp + m * 1024, q8);
                         }
                     };
@@ -1408,7 +1436,42 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
                     if (NCA_BF_PIPE) epilogue(MT - 1, pend0, pend1);
                     }
                     NCA_STAMP(3)
-                    if (!RES) stage_publish_counted<(S8 && STORED) ? 2 * MT : 4 * MT>(st_ok);              // D stores
+                    if (OC && oc && lane == 0) reinterpret_cast<float*>(octile + 65536)[wave] = inv_s;
+                    if (!RES) stage_publish_counted<(S8 && STORED) ? 2 * MT : 4 * MT>((OC && oc) ? false : st_ok);              // D stores  (on-chip layer: nothing stored, drain the H tile's DMA)
+                    if constexpr (OC) {
+                        if (oc) {
+                            // dW rows 32 wave .. + 31 of the on-chip layer over the workgroup's four wave tiles (wgrad_job_mx, NCA_WGRAD_TR: same operands)
+                            const int troff = (32 * (lr & 1) + 16 * lh + ((lr & 15) >> 1)) * 16 + 8 * ((lr >> 4) & 1);
+                            const int one = lr == 0 ? 0x38383838 : 0;
+                            const i32x8 sel = {one, one, one, one, one, one, one, one};
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                i32x8 PA, PB[4];
+#pragma unroll
+                                for (int half = 0; half < 2; ++half) {
+                                    const char* dp = octile + (t * 2 + half) * (MT * 1024) + troff;
+#pragma unroll
+                                    for (int tt = 0; tt < 2; ++tt) {
+                                        const i32x2 v = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) i32x2*)(dp + wave * 1024 + tt * 128));
+                                        PA[4 * half + 2 * tt] = v[0]; PA[4 * half + 2 * tt + 1] = v[1];
+                                    }
+#pragma unroll
+                                    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                                        for (int tt = 0; tt < 2; ++tt) {
+                                            const i32x2 v = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) i32x2*)(dp + 32768 + cb * 1024 + tt * 128));
+                                            PB[cb][4 * half + 2 * tt] = v[0]; PB[cb][4 * half + 2 * tt + 1] = v[1];
+                                        }
+                                }
+                                const float sct = reinterpret_cast<const float*>(octile + 65536)[t];
+                                const int sa = (int)(__float_as_uint(sct) >> 23) - NCA_H8_LOG2;
+#pragma unroll
+                                for (int cb = 0; cb < 4; ++cb)
+                                    ocW[cb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(PA, PB[cb], ocW[cb], 1 /* A: e5m2 */, 0 /* B: e4m3 */, 0, sa, 0, 127);
+                                ocB = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(sel, PA, ocB, 0, 1, 0, 127, 0, sa + NCA_H8_LOG2);
+                            }
+                        }
+                    }
                     cur ^= 1;
                     si = nsi;
                     NCA_STAMP(6)
@@ -1463,6 +1526,27 @@ __global__ __launch_bounds__(NCA_NT, 2) void nca_fused_bf16(const NcaFusedArgs a
     }
 #endif
 
+    if constexpr (OC) {
+        if (a.onchip == 2) {
+            // rows 32 wave .. + 31 of the on-chip layer's dW and its bias sums -> this workgroup's slab, natural [o][i] order (wgrad_write)
+            auto unperm = [](int c) { return (c & 0x13) | ((c & 8) >> 1) | ((c & 4) << 1); };
+            float* ws = a.wslab + (int64_t)blockIdx.x * a.wslab_stride;
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                const int col = 32 * cb + unperm(lr);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int o = 32 * wave + unperm(nca_rho(i) + 4 * lh);
+                    float* dst = ws + (int64_t)o * F + col;
+                    *dst = a.accumulate ? *dst + ocW[cb][i] : ocW[cb][i];
+                }
+            }
+            if (lh == 0) {
+                float* dst = ws + (int64_t)F * F + 32 * wave + unperm(lr);
+                *dst = a.accumulate ? *dst + ocB[0] : ocB[0];
+            }
+        }
+    }
     if (ONCHIP) {
         // dW blocks and bias sums of the on-chip layer -> this workgroup's slab, natural [o][i] order (both indices of a
         // hidden block are in accumulator->operand order: un-permute them as the wgrad kernel does)
@@ -1668,7 +1752,6 @@ __device__ __forceinline__ void wgrad_job(const NcaWgradArgs& a, const NcaWgradJ
 // for D and for e4m3 H blocks; the bf16 input block and a bf16 last-layer input are rounded to e4m3 here).  Lane (feature
 // position, half h) then holds 16 samples of each of the wave tile's two 32-sample halves = its 32 K values; both operands
 // use the same K order, which is all the contraction needs (tools/mx_mfma_probe.hip: lane maps, scales, formats).
-typedef int i32x8 __attribute__((ext_vector_type(8)));
 // (the conversions write one half of a register and keep the other.  Both halves get written, so the start value is immaterial: a
 // zero costs a v_mov per word, a live input ties the result to that input's register and costs a v_mov into the MFMA operand
 // tuple afterwards -- an empty asm "defines" a register without an instruction, which the allocator places inside the tuple)
@@ -1764,7 +1847,6 @@ __device__ __forceinline__ void dma_piece(const char* src, char* to) {
 #ifndef NCA_WGRAD_TR
 #define NCA_WGRAD_TR 0
 #endif
-typedef int i32x2 __attribute__((ext_vector_type(2)));
 template <int F, int NTB, bool H8, bool EXPAND = false>
 __device__ __forceinline__ void wgrad_job_mx(const NcaWgradArgs& a, const NcaWgradJob& job, int q, int nsplit, int lane, char* ring) {
     using R = WgradRing<F, NTB, true, H8>;
@@ -2068,6 +2150,7 @@ static hipError_t launch_fused_bf_mode(const NcaFusedArgs& a, int grid, hipStrea
     size_t lds = (RES ? (size_t)a.res_bytes : 2 * BfCfg<F>::BUF_BYTES) + bf_const_bytes(MODE);
     if (bwd) lds += NCA_WAVES * 2 * (F + 1) * sizeof(float);
     if (MODE == NCA_KM_BWD_NR) lds += 2 * bf_wo_floats(F) * sizeof(float);
+    if (NCA_ONCHIP_NR && MODE == NCA_KM_BWD_NR && !RES && a.onchip == 2) lds = ((lds + 1023) & ~(size_t)1023) + 65536 + 64;          // D tiles, H tiles, scales
     static thread_local NcaFusedArgs b;
     const NcaFusedArgs* pa = &a;
     if (RES) {

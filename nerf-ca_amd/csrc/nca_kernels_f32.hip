@@ -1188,7 +1188,7 @@ __global__ void nca_reduce_f32(const NcaReduceArgs a) {
     // the last F-wide layer under tail_from_sums: leave the sum over the splits in slab row 0 (this thread is the only reader of its
     // column) -- nca_reduce_small_f32, launched next, forms dWo from S and s summed over the splits and reads 129 values per output
     // instead of 129 x n_split (it was 83 us of one wave per output walking the slabs: as long at 1 024 rays per step as at 65 536)
-    if (tail_col && !rn.wslab) const_cast<float*>(a.slab)[rn.slab_off + le] = r;
+    if (tail_col) const_cast<float*>(a.slab)[rn.slab_off + le] = r;          // (tail_from_sums and an on-chip tail layer exclude each other: a tail column is a slab column)
     if (rn.tail_from_sums) {
         // the last F-wide layer's sums were formed without the factor Wo[f] of their output row (nca_layout.hpp)
         const int64_t F2 = (int64_t)rn.F * rn.F;
