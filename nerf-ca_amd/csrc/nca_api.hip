@@ -204,7 +204,7 @@ extern "C" int nca_last_plan(NcaPlan* out) {
 }
 extern "C" const char* nca_build_info(void) {
     static char info[128];
-    snprintf(info, sizeof(info), "libnerfca_hip gfx950 abi=%d NCA_EXP=%d", NCA_ABI_VERSION, nca_kernels_exp_mask());
+    snprintf(info, sizeof(info), "libnerfca_hip gfx950 abi=%d NCA_EXP=%d variant=0x%x", NCA_ABI_VERSION, nca_kernels_exp_mask(), nca_kernels_variant_mask());
     return info;
 }
 

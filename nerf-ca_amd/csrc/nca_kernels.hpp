@@ -281,4 +281,5 @@ hipError_t nca_launch_sum_tile_records(const char* dregion, int64_t wave_tile_by
 hipError_t nca_launch_wgrad_bf16(int F, const NcaWgradArgs& a, int nsplit, hipStream_t st);
 // the timing-experiment mask the bf16 kernels were compiled with (0 in every shipped library; tools/elim_build.sh)
 int nca_kernels_exp_mask();
+int nca_kernels_variant_mask();
 hipError_t nca_launch_pix_f32(int64_t R, int nchunk, const float* I0, const double* part, double* pix, hipStream_t st);

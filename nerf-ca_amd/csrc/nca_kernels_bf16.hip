@@ -25,6 +25,7 @@
 #define NCA_EXP 0
 #endif
 int nca_kernels_exp_mask() { return NCA_EXP; }
+int nca_kernels_variant_mask();       // (defined at the end of this file: the A/B macros are declared where they are used)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -2238,3 +2239,6 @@ hipError_t nca_launch_wgrad_bf16(int F, const NcaWgradArgs& a, int nsplit, hipSt
     }
     return hipGetLastError();
 }
+
+// bit 0 NCA_BF_PIPE2, bit 1 NCA_WGRAD_TR, bit 2 NCA_ONCHIP_NR, bit 3 NCA_BF_PIPE, bits 8.. NCA_WAVES: 0x800 is the product build
+int nca_kernels_variant_mask() { return (NCA_BF_PIPE2 ? 1 : 0) | (NCA_WGRAD_TR ? 2 : 0) | (NCA_ONCHIP_NR ? 4 : 0) | (NCA_BF_PIPE ? 8 : 0) | (NCA_WAVES << 8); }
