@@ -8,6 +8,10 @@ several arithmetic models of the MLP and reports the held-out PSNR of each:
   f32       plain f32 (the reference's arithmetic)
   bf16      what the bf16 HIP path does today: MFMA operands (layer inputs, weights, back-propagated deltas) rounded to
             bf16, f32 accumulation, f32 master weights
+  fp8c+X/Y  (round 3: would fp8 CONTRACTIONS survive?)  like bf16+X/Y, but the FORWARD contractions of every layer take e4m3
+            operands: the layer inputs x 2^h_log2 (the bytes the store already holds) and the weights scaled per layer by a power
+            of two that brings max |W| into [128, 256); f32 accumulation; the backward as in bf16+X/Y
+  fp8cd+X/Y the same with the dgrad contraction on 8-bit operands as well: deltas as e5m2 (scaled per tile), transposed weights e4m3
   bf16+X/Y  the same, but the weight gradient of every layer whose operands are staged through HBM is formed from
             D rounded to format X and H rounded to format Y (e4m3 / e5m2).  D is pre-scaled per 64-sample tile of a
             ray by a power of two taken from max |d loss / d raw| of the tile (the dgrad chain is linear in it, so the
@@ -47,6 +51,8 @@ class Arith:
     def __init__(self, name):
         self.name = name
         self.bf16 = name != "f32"
+        self.chain8 = name.startswith("fp8c")            # forward contractions on e4m3 operands
+        self.dgrad8 = name.startswith("fp8cd")           # dgrad contraction on e5m2 x e4m3 operands
         self.d_fmt = self.h_fmt = None
         self.d_log2, self.h_log2 = 4, 3
         if "+" in name:
@@ -62,7 +68,11 @@ class _Linear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, W, b, ar: Arith, staged: bool, is_out: bool):
-        if ar.bf16 and not is_out:
+        if ar.chain8 and not is_out:
+            sw = torch.exp2(7.0 - torch.floor(torch.log2(W.detach().abs().max().clamp(min=1e-30))))       # max |W| sw in [128, 256)
+            hs = 2.0 ** ar.h_log2
+            x, Wq = q8(bf(x) * hs, "e4m3") / hs, q8(W * sw, "e4m3") / sw
+        elif ar.bf16 and not is_out:
             x, Wq = bf(x), bf(W)
         else:
             Wq = W
@@ -90,7 +100,11 @@ class _Linear(torch.autograd.Function):
                 ar.tile_scale = sc.expand(-1, -1, 64).reshape(g.shape[0], nt * 64)[:, :S].reshape(-1, 1)
             return dy @ Wq, dy.t() @ x, dy.sum(0), None, None, None
         dq = bf(dy)                                  # the deltas are packed to bf16 as the next dgrad's B operand
-        dx = dq @ Wq
+        if ar.dgrad8 and ar.tile_scale is not None:
+            s = ar.tile_scale
+            dx = (q8(dy * s, "e5m2") / s) @ Wq       # (Wq is the e4m3 image of the forward)
+        else:
+            dx = dq @ Wq
         if ctx.staged and ar.d_fmt:
             s = ar.tile_scale
             d8 = q8(dy * s, ar.d_fmt) / s            # converted from the f32 accumulators, scaled by the tile's power of two
