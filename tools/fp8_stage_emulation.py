@@ -116,11 +116,11 @@ class _Linear(torch.autograd.Function):
 def encode(p, L, window):
     if L <= 0:
         return p
-    scales = 2.0 ** torch.arange(0, L)
+    scales = 2.0 ** torch.arange(0, L, device=p.device)
     xb = p[..., None, :] * scales[:, None]
     feat = torch.sin(torch.stack([xb, xb + 0.5 * torch.pi], dim=-2))
     if window is not None:
-        feat = window.float()[..., None, None] * feat
+        feat = window.float().to(p.device)[..., None, None] * feat
     return torch.cat([p, feat.reshape(p.shape[0], -1)], dim=-1)
 
 
@@ -162,12 +162,13 @@ def main():
     ap.add_argument("--filters", type=int, default=128)
     ap.add_argument("--runs", default="f32,bf16,bf16+e4m3/e4m3,bf16+e5m2/e4m3,bf16+e5m2/e5m2")
     ap.add_argument("--seeds", type=int, default=2)
+    ap.add_argument("--device", default="cpu", help="cpu, or cuda: the same torch operations on the GPU (no library kernel is involved either way)")
     args = ap.parse_args()
     from nerfca_amd import synthetic
     from nerfca_amd.model.CPPN import CPPN
     from nerfca_amd.model.Temporal import Temporal
     from nerfca_amd.train.trainer import CompositeTrainer, TrainConfig
-    dev = torch.device("cpu")
+    dev = torch.device(args.device)
     f32r = make_render(Arith("f32"), False)
     data = synthetic.make_dataset(args.det, args.samples, dev, views=synthetic.TRAIN_VIEWS, n_phases=4, F=64,
                                   render=lambda *a: f32r(*a)[0])
@@ -181,7 +182,8 @@ def main():
             s, t = CPPN(sdef), Temporal(tdef)
             cfg = TrainConfig(depth_samples_per_ray_coarse=args.samples, img_sample_size=args.rays, static_pos_enc_window_decay_steps=args.steps,
                               temp_pos_enc_window_decay_steps=args.steps, lr_decay_steps=args.steps)
-            tr = CompositeTrainer(cfg, s, t, data, dev, seed=seed, render=make_render(ar, False), fused_adam=False)
+            s, t = s.to(dev), t.to(dev)
+            tr = CompositeTrainer(cfg, s, t, data, dev, seed=seed, render=make_render(ar, False), fused_adam=False, fused_loss=False)
             tr.update_windows(0)
             t0 = time.perf_counter()
             for it in range(args.steps):
