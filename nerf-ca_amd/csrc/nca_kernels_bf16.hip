@@ -388,6 +388,29 @@ __device__ __forceinline__ void mma_rowtile_ring_il(const char* imgl, int m, u32
 template <int NKS, int MTOT, int NB, int RING>
 __device__ __forceinline__ void mma_rowtile_ring(const char* imgl, int m, u32x4 (&A)[RING], const u32x4 (&B)[2][NB],
                                                  f32x16& acc0, f32x16& acc1) {
+    if constexpr ((NCA_EXP & 16777216) != 0) {
+        // (16777216: TIMING ONLY, results wrong -- the matrix work and LDS traffic an fp8 chain would have: per row tile (NKS + 3) / 4 MX
+        // k-steps of 64 features, each two 16-byte fragment reads and one v_mfma_scale_f32_32x32x64_f8f6f4 per column tile, on whatever the
+        // bf16 operand registers hold)
+        constexpr int NK8 = (NKS + 3) / 4;
+        i32x8 a8[2];
+        auto rd8 = [&](int k8) __attribute__((always_inline)) {
+            const u32x4 lo = *reinterpret_cast<const u32x4*>(imgl + ((m * NK8 + k8) * 2) * 1024), hi = *reinterpret_cast<const u32x4*>(imgl + ((m * NK8 + k8) * 2 + 1) * 1024);
+            return (i32x8){(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+        };
+        a8[0] = rd8(0);
+#pragma unroll
+        for (int k8 = 0; k8 < NK8; ++k8) {
+            if (k8 + 1 < NK8) a8[(k8 + 1) & 1] = rd8(k8 + 1);
+            const u32x4 b0l = B[0][2 * k8], b0h = B[0][2 * k8 + 1], b1l = B[1][2 * k8], b1h = B[1][2 * k8 + 1];
+            const i32x8 b0 = {(int)b0l[0], (int)b0l[1], (int)b0l[2], (int)b0l[3], (int)b0h[0], (int)b0h[1], (int)b0h[2], (int)b0h[3]};
+            const i32x8 b1 = {(int)b1l[0], (int)b1l[1], (int)b1l[2], (int)b1l[3], (int)b1h[0], (int)b1h[1], (int)b1h[2], (int)b1h[3]};
+            acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[k8 & 1], b0, acc0, 0, 0, 0, 127, 0, 127);
+            acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[k8 & 1], b1, acc1, 0, 0, 0, 127, 0, 127);
+            __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x10 | 0x400);
+        }
+        return;
+    }
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
         const int g = m * NKS + ks, nx = g + RING - 1;
