@@ -285,14 +285,15 @@ static int add_stage(NcaFusedArgs* a, const void* base, uint32_t off, uint32_t b
 
 // stored: 0 = all forward images (+ dgrad images when bwd); 1 = backward from a store that holds everything (f32: dgrad
 // images only); 2 = backward from a store without the last layer's output (bf16: the last forward image, then dgrad images)
-static int build_stages(NcaFusedArgs* a, const NetBind* binds, bool bwd, int stored = 0) {
+static int build_stages(NcaFusedArgs* a, const NetBind* binds, bool bwd, int stored = 0, bool c8 = false) {
     a->nstages = 0;
     a->res_total = 0;
     a->res_bytes = 0;
     for (int n = 0; n < a->nnets; ++n) {
         const NcaLayout& y = a->net[n].lay;
         for (int j = stored == 2 ? y.NL - 1 : 0; stored != 1 && j < y.NL; ++j) {
-            int rc = add_stage(a, binds[n].packed, y.layer[j].img_off, y.layer[j].img_bytes);
+            const bool i8 = NCA_CHAIN8 && c8 && y.layer[j].img8_bytes;          // (experiment: the e4m3 image of a hidden-width layer)
+            int rc = add_stage(a, binds[n].packed, i8 ? y.layer[j].img8_off : y.layer[j].img_off, i8 ? y.layer[j].img8_bytes : y.layer[j].img_bytes);
             if (rc) return rc;
             if (y.layer[j].img2_bytes) {            // second stage of a skip layer
                 rc = add_stage(a, binds[n].packed, y.layer[j].img2_off, y.layer[j].img2_bytes);
@@ -547,9 +548,13 @@ extern "C" int nca_render_fwd(const NcaRays* rays, int32_t prec,
             one[n].net_base = n;
             one[n].split = n + 1;
             NetBind b1[2] = {binds[n], {}};
-            rc = build_stages(&one[n], b1, false);
+            rc = build_stages(&one[n], b1, false, 0, NCA_CHAIN8 && kmode == NCA_KM_FWD_STORE && a.h8 && one[n].net[0].lay.F == 128);
             if (rc) return rc;
             ok = plan_resident(&one[n], kmode);
+            if (NCA_CHAIN8 && !ok && kmode == NCA_KM_FWD_STORE && a.h8 && one[n].net[0].lay.F == 128) {       // (the e4m3 images exist for the resident launch only)
+                rc = build_stages(&one[n], b1, false);
+                if (rc) return rc;
+            }
         }
         if (ok) {
             for (int n = 0; n < 2; ++n) {

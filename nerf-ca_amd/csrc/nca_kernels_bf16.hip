@@ -214,6 +214,42 @@ __global__ void nca_pack_bf16(NcaLayout y, const float* __restrict__ prm, unsign
                     v = __builtin_bit_cast(unsigned, f);
                 }
             }
+            if (NCA_CHAIN8 && l.img8_bytes && byte >= l.img8_off && byte < l.img8_off + l.img8_bytes) {
+                // e4m3 image: fragment (m, k8, half16) at ((m * 2 + k8) * 2 + half16) * 1 KiB, lane (r, h) 16 bytes: byte b = 16 half16 + e is
+                // W[32 m + r][feature of (row tile 2 k8 + half16, register e, lane half h)] x 2^NCA_W8_LOG2  (tools/fp8_chain_probe.hip)
+                const uint32_t wbytes = (uint32_t)y.MT * 4u * 1024u;
+                const uint32_t off = byte - l.img8_off;
+                if (off < wbytes) {
+                    float four[4];
+                    for (int e4 = 0; e4 < 4; ++e4) {
+                        const uint32_t bidx = off + e4;
+                        const int e = bidx % 16, lane = (bidx / 16) % 64, half16 = (bidx / 1024) % 2, k8 = (bidx / 2048) % 2, m = bidx / 4096;
+                        const int r = lane & 31, h = lane >> 5;
+                        // hidden layers: the previous layer's accumulator bytes; layer 0: the input block's bytes (fragment t = 2 k8 + half16
+                        // holds slots 32 t + 16 (e >> 3) + 8 h + (e & 7); padding and one-hot slots carry no weight)
+                        const int f = j == 0 ? nca_bf_slot_to_nat(y, 32 * (2 * k8 + half16) + 16 * (e >> 3) + 8 * h + (e & 7)) : 32 * (2 * k8 + half16) + 8 * (e >> 2) + 4 * h + (e & 3);
+                        four[e4] = (f >= 0 && (j != 0 || 32 * (2 * k8 + half16) + 16 * (e >> 3) + 8 * h + (e & 7) < NCA_BF_K0SLOTS)) ? prm[l.w_off + (32 * m + r) * l.K + f] : 0.f;
+                    }
+                    v = cvt4_e4m3(four[0], four[1], four[2], four[3], 1.f / (float)(1 << NCA_W8_LOG2));
+                } else {
+                    uint32_t q = (off - wbytes) / 4u;
+                    const uint32_t tail = 2u * (uint32_t)y.MT * 16u;
+                    float f = 0.f;
+                    if (q < tail) {
+                        const int i = q % 16, m = (q / 16) % y.MT, h = q / (16 * y.MT);
+                        f = prm[l.b_off + 32 * m + nca_rho(i) + 4 * h];
+                    } else if (j == y.NL - 1) {
+                        q -= tail;
+                        if (q < tail) {
+                            const int i = q % 16, m = (q / 16) % y.MT, h = q / (16 * y.MT);
+                            f = prm[y.wo_off + 32 * m + nca_rho(i) + 4 * h];
+                        } else if (q == tail) {
+                            f = prm[y.bo_off];
+                        }
+                    }
+                    v = __builtin_bit_cast(unsigned, f);
+                }
+            }
             if (l.imgT_bytes && byte >= l.imgT_off && byte < l.imgT_off + l.imgT_bytes) {
                 const uint32_t off = byte - l.imgT_off;
                 const int KS = y.F / 16;
@@ -369,6 +405,22 @@ __device__ __forceinline__ void ring_prime(const char* imgl, u32x4 (&A)[RING]) {
 #pragma unroll
     for (int g = 0; g < RING - 1; ++g)
         if (g < MTOT * NKS) A[g % RING] = *reinterpret_cast<const u32x4*>(imgl + g * 1024);
+}
+// NCA_CHAIN8: one row tile of a width-128 hidden layer on e4m3 operands -- two MX k-steps of 64 features; the A fragment is two 16-byte
+// reads of the e4m3 image ([row tile][k-step][16-byte half][lane][16 B]), the B fragment {bytes of row tile 2k, bytes of row tile 2k+1}
+// of the previous layer (tools/fp8_chain_probe.hip); weights x 2^NCA_W8_LOG2 and inputs x 2^NCA_H8_LOG2 go back through the e8m0 scales.
+__device__ __forceinline__ void mma_rowtile_c8(const char* imgl, int m, const u32x4 (&Q)[2][4], f32x16& acc0, f32x16& acc1) {
+    u32x4 a[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const u32x4*>(imgl + (m * 4 + i) * 1024);
+#pragma unroll
+    for (int k8 = 0; k8 < 2; ++k8) {
+        const i32x8 A8 = {(int)a[2 * k8][0], (int)a[2 * k8][1], (int)a[2 * k8][2], (int)a[2 * k8][3], (int)a[2 * k8 + 1][0], (int)a[2 * k8 + 1][1], (int)a[2 * k8 + 1][2], (int)a[2 * k8 + 1][3]};
+        const i32x8 B0 = {(int)Q[0][2 * k8][0], (int)Q[0][2 * k8][1], (int)Q[0][2 * k8][2], (int)Q[0][2 * k8][3], (int)Q[0][2 * k8 + 1][0], (int)Q[0][2 * k8 + 1][1], (int)Q[0][2 * k8 + 1][2], (int)Q[0][2 * k8 + 1][3]};
+        const i32x8 B1 = {(int)Q[1][2 * k8][0], (int)Q[1][2 * k8][1], (int)Q[1][2 * k8][2], (int)Q[1][2 * k8][3], (int)Q[1][2 * k8 + 1][0], (int)Q[1][2 * k8 + 1][1], (int)Q[1][2 * k8 + 1][2], (int)Q[1][2 * k8 + 1][3]};
+        acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A8, B0, acc0, 0, 0, 0, 127 - NCA_W8_LOG2, 0, 127 - NCA_H8_LOG2);
+        acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A8, B1, acc1, 0, 0, 0, 127 - NCA_W8_LOG2, 0, 127 - NCA_H8_LOG2);
+    }
 }
 // The same with a piece of vector-ALU work placed behind the two MFMAs of every k-step (NCA_BF_PIPE2: the deferred epilogue of the
 // previous row tile; `piece(ks)` must not touch acc0 / acc1).  Everything of a step stays in its step.
@@ -731,6 +783,7 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
 
             // ================= encoding, lane = sample ===================================================
             u32x4 B[2][KSMAX];
+            u32x4 Q8[2][4], Q8n[2][4];            // NCA_CHAIN8: the previous / this layer's e4m3 bytes per (column tile, row tile)
             if (RECOMP) {
                 float fe[NCA_BF_K0SLOTS];
 #pragma unroll
@@ -788,7 +841,9 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
                         B[0][s][w] = r[0];
                         B[1][s][w] = r[1];
                     }
-                if (STORE && (FSTORE || tvalid) && !(a.share_enc && net + a.net_base == 0)) {
+                constexpr bool C8E = NCA_CHAIN8 && FSTORE && S8 && RES && F == 128;
+                const bool store_in = STORE && (FSTORE || tvalid) && !(a.share_enc && net + a.net_base == 0);
+                if (store_in || C8E) {
                     // input block of both column tiles, fragment-major [k-step][lane][16 B]: the layer-0
                     // operands as they sit in registers, then one k-step of one-hot phase slots
 #pragma unroll
@@ -811,7 +866,8 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
                             for (int t = 0; t < 4; ++t) {
                                 const u32x4 lo = t < 3 ? B[c][2 * t] : hot, hi = t < 3 ? B[c][2 * t + 1] : zero;
                                 const u32x4 q = {cvt4_e4m3_pk(lo[0], lo[1], DIV), cvt4_e4m3_pk(lo[2], lo[3], DIV), cvt4_e4m3_pk(hi[0], hi[1], DIV), cvt4_e4m3_pk(hi[2], hi[3], DIV)};
-                                store_nt(blk + t * 1024, q);
+                                if constexpr (C8E) Q8[c][t] = q;          // (fp8 chain: the input block's bytes are layer 0's operand)
+                                if (store_in) store_nt(blk + t * 1024, q);
                             }
                         } else {
 #pragma unroll
@@ -994,9 +1050,11 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
                 // images of the launch's one net back to back: layer 0, then the hidden-width layers; nca_build_layout_bf16).  Read from
                 // the argument block instead -- y.layer[jj], a.stage[si] with run-time indices -- they were two dependent scalar loads
                 // from memory at every layer boundary of every tile, ~1 500 cycles per boundary in the timeline (NCA_EXP 8388608)
-                constexpr int IMG0 = MT * KS0 * 1024 + 2 * MT * 16 * 4, IMGH = MT * KS * 1024 + 2 * MT * 16 * 4;
+                // NCA_CHAIN8 (nca_layout.hpp): hidden-width layers of the resident storing forward contract e4m3 operands
+                constexpr bool C8 = NCA_CHAIN8 && FSTORE && S8 && RES && F == 128;
+                constexpr int IMG0 = (C8 ? MT * 4 * 1024 : MT * KS0 * 1024) + 2 * MT * 16 * 4, IMGH = (C8 ? MT * 4 * 1024 : MT * KS * 1024) + 2 * MT * 16 * 4;
                 const char* img = (RES && !STORED) ? smem + (jj == 0 ? 0 : IMG0 + (jj - 1) * IMGH) : (RES ? smem + a.stage[si].lds_off : smem + cur * BUF);      // (mode 3 resident: the one recomputed layer's image comes first)
-                const int nks = jj == 0 ? KS0 : KS;
+                const int nks = C8 ? 4 : (jj == 0 ? KS0 : KS);
                 const float* tail = reinterpret_cast<const float*>(img + MT * nks * 1024);
                 const bool last = jj == y.NL - 1;
                 const bool h8 = S8 && FSTORE;                                     // fp8 staging: the layer outputs go to the store as e4m3 (the last layer: its mask only)
@@ -1067,6 +1125,7 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
                             u32x4 q;
 #pragma unroll
                             for (int w = 0; w < 4; ++w) q[w] = NOM ? Bn[c][2 * m + (w >> 1)][2 * (w & 1)] : cvt4_e4m3_pk(Bn[c][2 * m + (w >> 1)][2 * (w & 1)], Bn[c][2 * m + (w >> 1)][2 * (w & 1) + 1], DIV);
+                            if constexpr (C8) Q8n[c][m < 4 ? m : 0] = q;
                             if (st_ok) store_nt(hblk + c * a.rows_total + lane * 16 + m * 1024, q);
                         }
                     } else if (STORE && !LAST && !NOH) {
@@ -1142,6 +1201,8 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
 #pragma unroll
                     for (int i = 0; i < 16; ++i) { const float b = tail[(lh * MT + m) * 16 + i]; acc0[i] = b; acc1[i] = b; }
                     NCA_TL()
+                    if constexpr (C8) mma_rowtile_c8(imgl, m, Q8, acc0, acc1);
+                    else
                     if (!(NCA_EXP & 128)) mma_rowtile_ring<NKS, MT, KSMAX, RINGK>(imgl, m, A, B, acc0, acc1);
                     else { acc0[0] += __builtin_bit_cast(float, B[0][m][0]); acc1[3] += __builtin_bit_cast(float, B[1][m][1]); }       // (128: no MFMAs)
                     NCA_TL()
@@ -1173,10 +1234,18 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
                     }
                 }
                 NCA_STAMP(jj == 0 ? 2 : (last ? 4 : 3))        // layer 0 / hidden layers / last layer: MFMAs + epilogue + stores
+                if constexpr (!C8) {          // (fp8 chain: the bf16 words of a layer's output serve its own epilogue only)
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
                     for (int k = 0; k < 2 * MT; ++k) B[c][k] = Bn[c][k];
+                }
+                if constexpr (C8) {
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) Q8[c][m] = Q8n[c][m];
+                }
                 if (lds_mask && !last) {
                     u32x4 mv = {mw[0][0], mw[0][1], mw[1][0], mw[1][1]};
                     *reinterpret_cast<u32x4*>(mwave + jj * 1024) = mv;
