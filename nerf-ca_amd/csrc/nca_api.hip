@@ -7,6 +7,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include <mutex>
+#include <string>
 #include <vector>
 #include "nca_kernels.hpp"
 
@@ -203,9 +204,16 @@ extern "C" int nca_last_plan(NcaPlan* out) {
     return NCA_OK;
 }
 extern "C" const char* nca_build_info(void) {
-    static char info[128];
-    snprintf(info, sizeof(info), "libnerfca_hip gfx950 abi=%d NCA_EXP=%d variant=0x%x", NCA_ABI_VERSION, nca_kernels_exp_mask(), nca_kernels_variant_mask());
-    return info;
+    // formatted once (thread-safe static initialisation); the compile-time experiment / variant / ablation masks are all 0 in a shipped
+    // library (tests/test_host_cpu.py::test_shipped_library_is_not_a_timing_build).  The effective CU count is NOT part of the string
+    // (reading it would initialise the device): nca_last_plan() and the NCA_CUS note in tools/cu_scaling.sh cover it.
+    static const std::string info = [] {
+        char b[160];
+        snprintf(b, sizeof(b), "libnerfca_hip gfx950 abi=%d NCA_EXP=%d variant=0x%x ablation=0x%x", NCA_ABI_VERSION, nca_kernels_exp_mask(), nca_kernels_variant_mask(),
+                 nca_kernels_ablation_mask());
+        return std::string(b);
+    }();
+    return info.c_str();
 }
 
 static int check_prec(int32_t prec) {

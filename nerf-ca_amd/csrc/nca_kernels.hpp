@@ -282,4 +282,6 @@ hipError_t nca_launch_wgrad_bf16(int F, const NcaWgradArgs& a, int nsplit, hipSt
 // the timing-experiment mask the bf16 kernels were compiled with (0 in every shipped library; tools/elim_build.sh)
 int nca_kernels_exp_mask();
 int nca_kernels_variant_mask();
+// rounding-ablation mask of the f32 kernels (NCA_ABL; 0 in every shipped library)
+int nca_kernels_ablation_mask();
 hipError_t nca_launch_pix_f32(int64_t R, int nchunk, const float* I0, const double* part, double* pix, hipStream_t st);

@@ -26,6 +26,19 @@ typedef float f32x4e __attribute__((ext_vector_type(4)));
 #define NCA_HALF_PI_D 1.57079632679489661923
 #define NCA_TWO_PI_F 6.283185482025146484375f      // fl32(2 * pi)
 
+// Rounding ablations (tools/ablation_build.sh; 0 in every shipped library -- nca_build_info() reports the mask): the
+// parity kernels with ONE of the bf16 mode's roundings switched on, to find which of them costs held-out PSNR.  1: encoded input
+// features, 2: hidden-layer weights, 4: hidden activations (after ReLU), 8: output gradients of the dgrad chain, 16: layer-0 weights.
+#ifndef NCA_ABL
+#define NCA_ABL 0
+#endif
+template <int BIT>
+__device__ __forceinline__ float abl(float x) {
+    if constexpr ((NCA_ABL & BIT) != 0) return (float)(__bf16)x;
+    else return x;
+}
+int nca_kernels_ablation_mask() { return NCA_ABL; }
+
 // x3 split (see the x3 section below): exact three-way bf16 split of f32 values
 typedef float x3_f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 x3_bf16x2 __attribute__((ext_vector_type(2)));
@@ -52,7 +65,20 @@ __device__ __forceinline__ unsigned x3_piece(float w, int p) {
 // ------------------------------------------------------------------------------------------
 // pack
 // ------------------------------------------------------------------------------------------
-__global__ void nca_pack_f32(NcaLayout y, const float* __restrict__ prm, float* __restrict__ out) {
+__global__ void nca_pack_f32(NcaLayout y, const float* __restrict__ prm_, float* __restrict__ out) {
+#if NCA_ABL & (2 | 16)
+    // (ablation: weights of the F-wide layers as the bf16 mode sees them; biases, Wo and bo stay f32 there too)
+    struct Rounded {
+        const float* p; NcaLayout y;
+        __device__ float operator[](int i) const {
+            for (int j = 0; j < y.NL; ++j)
+                if (i >= y.layer[j].w_off && i < y.layer[j].b_off) return (j == 0) ? abl<16>(p[i]) : abl<2>(p[i]);
+            return p[i];
+        }
+    } prm{prm_, y};
+#else
+    const float* __restrict__ prm = prm_;
+#endif
     const uint32_t total = y.packed_bytes / 4u;
     for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
         float v = 0.f;
@@ -585,7 +611,7 @@ __global__ __launch_bounds__(NCA_NT, NCA_F32_MINBLOCKS) void nca_fused_f32(const
 #pragma unroll
                         for (int m = 0; m < MT; ++m) {
 #pragma unroll
-                            for (int i = 0; i < 16; ++i) hprev[m][i] = hprev[m][i] > 0.f ? wo[(lh * MT + m) * 16 + i] * g : 0.f;
+                            for (int i = 0; i < 16; ++i) hprev[m][i] = hprev[m][i] > 0.f ? abl<8>(wo[(lh * MT + m) * 16 + i] * g) : 0.f;
                         }
             };
 
@@ -613,7 +639,7 @@ __global__ __launch_bounds__(NCA_NT, NCA_F32_MINBLOCKS) void nca_fused_f32(const
                 if (l.kind != NCA_IN_HID) {
                     float* const henc = hc;   // rows [0, K0rows_pad)
                     enc_steps(y, p, cwin, cfour, lat, [&](int s, float fa, float fb) {
-                        const float bop = lh ? fb : fa;
+                        const float bop = abl<1>(lh ? fb : fa);
                         float av[MT];
                         load_a<MT>(imgl + s * 64 * MT, av);
 #pragma unroll
@@ -665,7 +691,7 @@ __global__ __launch_bounds__(NCA_NT, NCA_F32_MINBLOCKS) void nca_fused_f32(const
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) hprev[m][i] = fmaxf(acc[m][i], 0.f);
+                    for (int i = 0; i < 16; ++i) hprev[m][i] = abl<4>(fmaxf(acc[m][i], 0.f));
 
                 if (((MODE == NCA_KM_BWD && a.mask_layers > 0) || FSTORE) && jj + 1 < y.NL) {
                     // ReLU mask of this layer's output for the dgrad sweep: bit 16 (m & 1) + i of word m >> 1 <-> acc[m][i]
@@ -779,7 +805,7 @@ __global__ __launch_bounds__(NCA_NT, NCA_F32_MINBLOCKS) void nca_fused_f32(const
                                                 bits ? ((fld >> (4 * q + 2)) & 1u) != 0u : hv.z > 0.f,
                                                 bits ? ((fld >> (4 * q + 3)) & 1u) != 0u : hv.w > 0.f};
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) hprev[m][4 * q + k] = on[k] ? acc[m][4 * q + k] : 0.f;
+                            for (int k = 0; k < 4; ++k) hprev[m][4 * q + k] = on[k] ? abl<8>(acc[m][4 * q + k]) : 0.f;
                         }
                     }
                     if (X3 && MT >= 2) stage_publish();           // (the second sub-stage's DMA was issued after the D_jj stores)

@@ -374,7 +374,7 @@ def test_shipped_library_is_not_a_timing_build():
     info = _capi.build_info()
     assert "NCA_EXP=0" in info and f"abi={_capi.ABI_VERSION}" in info and "gfx950" in info, info
     if "NERFCA_LIB" not in os.environ:          # (an A/B variant under test says what it is)
-        assert info.endswith("variant=0x800"), info          # 8 waves per workgroup, NCA_BF_PIPE2 / NCA_WGRAD_TR / NCA_ONCHIP_NR / NCA_BF_PIPE = 0
+        assert info.endswith("variant=0x800 ablation=0x0"), info          # no rounding ablation (tools/ablation_build.sh); 8 waves per workgroup, NCA_BF_PIPE2 / NCA_WGRAD_TR / NCA_ONCHIP_NR / NCA_BF_PIPE = 0
     assert _capi.get_option(_capi.OPT_STAGE_FP8) in (-1, 0, 1) and _capi.get_option(_capi.OPT_STAGE_FP8_MIN_TILES) >= 0
     assert _capi.get_option(_capi.OPT_WGRAD_REBUILD_WEIGHT_PCT) == int(os.environ.get("NCA_WGRAD_W", 115))
     with pytest.raises(_capi.NcaError):

@@ -31,6 +31,7 @@ VARIANTS = {"f32": ("f32", None), "bf16": ("bf16", None), "bf16_bf16stage": ("bf
             # f32 again from initial weights moved by 1e-6 (relative): the run-to-run spread of the parity mode itself, i.e. the
             # resolution of a PSNR comparison at this batch size
             "f32_perturbed": ("f32", None)}
+# --perturb R: the relative size of that move (default 1e-6; 2e-3 is the size of a bf16 rounding of every weight)
 
 
 def run(variant, args, dev, data, log=None, seed=0):
@@ -52,8 +53,15 @@ def run(variant, args, dev, data, log=None, seed=0):
                 g = torch.Generator(device=dev).manual_seed(12345 + seed)
                 for m in (s, t):
                     for prm in m.parameters():
-                        prm.mul_(1.0 + 1e-6 * torch.randn(prm.shape, generator=g, device=dev))
+                        prm.mul_(1.0 + args.perturb * torch.randn(prm.shape, generator=g, device=dev))
         nerfca_amd.set_precision(prec, s, t)
+        # --cross-eval: a second pair of models in the OTHER arithmetic that takes over the trained weights at every evaluation -- separates
+        # what an arithmetic costs the training from what it costs the rendering of the held-out view
+        shadow = None
+        if args.cross_eval:
+            s2, t2 = CPPN(sdef).to(dev), Temporal(tdef).to(dev)
+            nerfca_amd.set_precision("f32" if prec == "bf16" else "bf16", s2, t2)
+            shadow = (s2, t2)
         # schedules compressed to the length of the run (the reference anneals over 150 k steps of 1 024 rays)
         cfg = TrainConfig(depth_samples_per_ray_coarse=args.samples, img_sample_size=args.rays, static_pos_enc_window_decay_steps=args.steps,
                           temp_pos_enc_window_decay_steps=args.steps, lr_decay_steps=args.steps)
@@ -65,6 +73,20 @@ def run(variant, args, dev, data, log=None, seed=0):
             tr.update_windows(it)
             e = tr.evaluate(it)
             curve.append({"step": it, "psnr_mse_db": float(e["test_psnr_mse"]), "test_psnr_reference_def_db": float(e["test_psnr"]), "test_loss": float(e["test_loss"])})
+            if shadow is not None:
+                with torch.no_grad():
+                    for dst, src in zip(shadow, (tr.s, tr.t)):
+                        for pd, ps in zip(dst.parameters(), src.parameters()):
+                            pd.copy_(ps)
+                own = (tr.s, tr.t)
+                tr.s, tr.t = shadow
+                try:
+                    tr.update_windows(it)
+                    e2 = tr.evaluate(it)
+                finally:
+                    tr.s, tr.t = own
+                curve[-1]["other_arithmetic_psnr_mse_db"] = float(e2["test_psnr_mse"])
+                curve[-1]["other_arithmetic_test_psnr_reference_def_db"] = float(e2["test_psnr"])
             if log:
                 print(f"[psnr_run] {variant} step {it}: {curve[-1]['psnr_mse_db']:.3f} dB", file=log, flush=True)
 
@@ -80,6 +102,10 @@ def run(variant, args, dev, data, log=None, seed=0):
             if (it + 1) % args.every == 0:
                 point(it + 1)
         torch.cuda.synchronize()
+        if args.jsonl:          # every finished run is on disk at once: a run that is cut off keeps what it has
+            with open(args.jsonl, "a") as f:
+                f.write(json.dumps({"variant": variant, "seed": seed, "label": args.label, "library": _capi.build_info(), "rays": args.rays, "samples": args.samples,
+                                    "steps": args.steps, "perturb": args.perturb if variant == "f32_perturbed" else None, "curve": curve}) + "\n")
         return {"curve": curve, "final_train_loss": float(loss), "wall_s_incl_eval": time.perf_counter() - t0, "seed": seed,
                 "stage_fp8_in_effect": None if prec == "f32" else fp8_seen[0]}
     finally:
@@ -113,6 +139,10 @@ def main():
     ap.add_argument("--variants", default="f32,bf16")
     ap.add_argument("--seeds", default="0", help="comma-separated trainer seeds (ray batches, depth jitter, initial weights); > 1: the record keeps every "
                     "run and the mean / standard deviation of the final gaps over the seeds")
+    ap.add_argument("--perturb", type=float, default=1e-6, help="relative size of f32_perturbed's move of the initial weights")
+    ap.add_argument("--cross-eval", action="store_true", help="also evaluate the trained weights in the other arithmetic (f32 <-> bf16) at every evaluation")
+    ap.add_argument("--jsonl", default="", help="append one line per finished run to this file")
+    ap.add_argument("--label", default="", help="free text kept in the record (e.g. which ablation library NERFCA_LIB points at)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a HIP graph (library Adam) instead of the eager fused step")
     args = ap.parse_args()
     from nerfca_amd import _capi, synthetic
@@ -120,7 +150,8 @@ def main():
     dev = torch.device("cuda", 0)
     data = synthetic.make_dataset(args.det, args.samples, dev, views=synthetic.TRAIN_VIEWS)
     out = {"config": f"{args.det}^2 detector x {args.samples} samples/ray, {args.rays} rays/step, {args.steps} steps, 4 views x 10 phases + 1 held-out view, "
-                     f"synthetic phantom, {'HIP-graph step' if args.graph else 'eager fused step'}"}
+                     f"synthetic phantom, {'HIP-graph step' if args.graph else 'eager fused step'}",
+           "library": _capi.build_info(), "label": args.label, "perturb": args.perturb}
     names = [v for v in args.variants.split(",") if v]
     seeds = [int(x) for x in args.seeds.split(",") if x != ""]
     if len(seeds) > 1:
