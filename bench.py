@@ -52,7 +52,10 @@ PEAK_HBM_GBPS = 8000.0
 # of 2500 TFLOP/s / 8 TB/s = 312 FLOP/B: that kernel's roofline is the HBM one.
 WGRAD_FP8_BYTES_PER_SAMPLE = 2 * (4 * 256 + 128 + 20)
 PEAK_F32_ON_BF16_PIPE = 2500.0 / 6.0
-PROFILE_TAGS = ("r03", "r02", "r01")          # committed PMC summaries, newest first
+PROFILE_TAGS = ("r04", "r03", "r02", "r01")          # committed PMC summaries, newest first
+FLOP_STEP = FLOP_FWD + FLOP_DGRAD + FLOP_WGRAD            # 870 912 FLOP per sample of a training step
+# the pipe a precision's contractions run on: the f32 mode's hidden layers are six bf16 products per f32 product
+PIPE_PEAK_TFLOPS = {"f32": PEAK_F32_ON_BF16_PIPE, "bf16": 2500.0}
 
 
 def parse(argv=None):
@@ -84,9 +87,18 @@ def parse(argv=None):
                     "make (and make it, so that every rank reports); as a rank print {rank, world, local_rank, device index} and exit BEFORE anything touches the GPU")
     ap.add_argument("--views", type=int, default=4)
     ap.add_argument("--torch-losses", action="store_true", help="losses + autograd in torch ops instead of the fused loss kernel")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): every rank renders --rays rays per step; strong: ONE global batch of --rays rays is split N ways "
+                         "(SURVEY.md 8e's partitioning: rank g takes ids [g R/N, (g+1) R/N) of the same id vector)")
     args = ap.parse_args(argv)
     args.graph = not args.eager            # the whole step as one captured HIP graph unless --eager
+    if args.scaling == "strong" and args.rays % max(args.gpus, 1):
+        ap.error(f"--scaling strong: --rays {args.rays} does not divide by --gpus {args.gpus}")
     return args
+
+
+def rays_per_rank(args, world: int) -> int:
+    return args.rays // world if args.scaling == "strong" else args.rays
 
 
 def host_cores() -> int:
@@ -233,18 +245,18 @@ def make_trainer(args, prec, data, dev, rank, world, use_pg):
     sdef, tdef = synthetic.net_definitions(dev)
     s, t = CPPN(sdef).to(dev), Temporal(tdef).to(dev)
     nerfca_amd.set_precision(prec, s, t)
-    cfg = TrainConfig(depth_samples_per_ray_coarse=args.samples, img_sample_size=args.rays * world)
+    cfg = TrainConfig(depth_samples_per_ray_coarse=args.samples, img_sample_size=rays_per_rank(args, world) * world)
     tr = CompositeTrainer(cfg, s, t, data, dev, rank=rank, world=world, seed=0, fused_loss=not args.torch_losses)
     tr.always_allreduce = use_pg
     return tr
 
 
-def kernel_table(args, timed_steps, plan):
+def kernel_table(args, timed_steps, plan, world=1):
     """Per-kernel HIP-event times of the span the library's timers covered, with algorithmic TFLOP/s.  `plan` = the planner's
     decisions for this backward (nca_last_plan): with the last hidden layer's weight gradient accumulated in the dgrad kernel
     (bf16 staging at this size) its 2 x 2 x 128 x 128 FLOP per sample count there, not in the weight-gradient kernel."""
     from nerfca_amd import _capi
-    n_samp = args.rays * args.samples * timed_steps
+    n_samp = rays_per_rank(args, world) * args.samples * timed_steps
     kern = {}
     moved = 2 * 2 * 128 * 128 if plan.get("bwd_onchip") else 0
     for name, flop in (("fwd", FLOP_FWD), ("bwd_dgrad", FLOP_DGRAD + moved), ("bwd_wgrad", FLOP_WGRAD - moved), ("bwd_reduce", 0), ("loss", 0), ("pack", 0)):
@@ -254,12 +266,20 @@ def kernel_table(args, timed_steps, plan):
     return kern
 
 
-def roofline_of(args, prec, kern, eager_dt, plan):
-    """`eager_dt` = wall seconds of the eager pass the kernel table was taken over (what the table decomposes)."""
-    dom = max(("fwd", "bwd_dgrad", "bwd_wgrad"), key=lambda k: kern[k]["ms_total"])
-    peak = PEAK_TFLOPS[prec]
+def roofline_of(args, prec, kern, eager_dt, plan, ms_per_step, world=1):
+    """`eager_dt` = wall seconds of the eager pass the kernel table was taken over (what the table decomposes); `ms_per_step` = the
+    timed region's.  The kernel the record is about is the one with the largest time per step, with a FIXED tie-break: the forward
+    unless another kernel takes more than 10 % longer (forward and weight gradient are within a few percent of each other and
+    trade places from box to box; a reader should not see the record change its subject with them).  `frac` divides by the peak of
+    the pipe the contractions run on -- 2 500 TFLOP/s bf16; for f32 2 500 / 6, since its hidden layers are six bf16 products per
+    f32 product (the 157.3 TFLOP/s f32-MFMA peak it does NOT use is kept as `frac_of_f32_mfma_peak`).  `step` is the whole step:
+    870 912 FLOP per sample over the timed region's ms_per_step -- the one number that does not depend on which kernel leads."""
+    big = max(("fwd", "bwd_dgrad", "bwd_wgrad"), key=lambda k: kern[k]["ms_per_step"])
+    dom = big if kern[big]["ms_per_step"] > 1.10 * kern["fwd"]["ms_per_step"] else "fwd"
+    peak = PIPE_PEAK_TFLOPS[prec]
+    n_step = rays_per_rank(args, world) * args.samples
     fp8 = bool(plan.get("stage_fp8"))
-    traffic_rec, sq_rec, source = committed_pmc(prec, args.rays, args.samples, fp8 if prec == "bf16" else None)
+    traffic_rec, sq_rec, source = committed_pmc(prec, rays_per_rank(args, world), args.samples, fp8 if prec == "bf16" else None)
     traffic = traffic_rec["kernels"][dom]["hbm_bytes_per_launch"] if traffic_rec and dom in traffic_rec.get("kernels", {}) else None
     issue = None
     if sq_rec and dom in sq_rec.get("kernels", {}):
@@ -276,10 +296,18 @@ def roofline_of(args, prec, kern, eager_dt, plan):
             # share of the eager pass (the span the table decomposes) spent in the dominant kernel / in all timed kernels
             "kernel_time_share": kern[dom]["ms_total"] / (eager_dt * 1e3) if eager_dt else None,
             "all_kernels_time_share": ksum / (eager_dt * 1e3) if eager_dt else None, "all_kernels": kern}
+    step_tflops = FLOP_STEP * n_step / (ms_per_step * 1e-3) / 1e12
+    roof["step"] = {"bound": "mfma", "achieved": step_tflops, "peak": peak, "unit": "TFLOP/s", "frac": step_tflops / peak,
+                    "flop_per_sample": FLOP_STEP, "samples_per_step_per_gpu": n_step, "ms_per_step": ms_per_step,
+                    "note": "whole step (forward + losses + backward + Adam) against the peak of the pipe its contractions run on; per GPU"}
+    roof["kernel_choice"] = "largest time per step; the forward unless another kernel is > 10 % slower"
+    if prec == "f32":
+        roof["frac_of_f32_mfma_peak"] = kern[dom]["tflops"] / PEAK_TFLOPS["f32"] if kern[dom]["tflops"] else None
+        roof["peak_note"] = "2 500 / 6 TFLOP/s: the hidden layers run as six bf16 products per f32 product on the bf16 matrix cores (exact 3-way split)"
     wg = kern["bwd_wgrad"]
     if prec == "bf16" and fp8 and wg["avg_ms"]:
         # the weight-gradient kernel's own roofline is the HBM one (see WGRAD_FP8_BYTES_PER_SAMPLE)
-        nbytes = WGRAD_FP8_BYTES_PER_SAMPLE * args.rays * args.samples
+        nbytes = WGRAD_FP8_BYTES_PER_SAMPLE * n_step
         gbps = nbytes / (wg["avg_ms"] * 1e-3) / 1e9
         hbm = {"bound": "hbm", "kernel": "bwd_wgrad", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
                "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": wg["avg_ms"],
@@ -298,8 +326,6 @@ def roofline_of(args, prec, kern, eager_dt, plan):
     if prec == "bf16" and fp8 and wg["avg_ms"]:
         roof["per_kernel"]["bwd_wgrad"].update({"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
                                                 "mfma_frac": wg["tflops"] / peak})
-    if prec == "f32":      # the pipe the f32 mode's hidden-layer contractions really run on
-        roof["frac_of_bf16_pipe_div_6"] = kern[dom]["tflops"] / PEAK_F32_ON_BF16_PIPE if kern[dom]["tflops"] else None
     return roof
 
 
@@ -350,7 +376,7 @@ def measure(args, prec, stage_fp8, data, dev, rank, world, use_pg, steps, warmup
                 step(base_iter + i)
             barrier()
             sustained = {"ms_per_step": (time.perf_counter() - ts) * 10.0, "over": f"the last 100 of {sustained_steps} further graph-replayed steps (back to back after the timed region)",
-                         "rays_per_s": args.rays * world * 100 / (time.perf_counter() - ts),
+                         "rays_per_s": rays_per_rank(args, world) * world * 100 / (time.perf_counter() - ts),
                          "in_kernel_clock": "profiles/r03_clock_probe.txt (tools/clock_probe.sh: the diagnostic build that stamps s_memtime / s_memrealtime; no stamp executes in this build)"}
         timed_steps, eager_dt = steps, dt
         eager_ms = None
@@ -373,11 +399,11 @@ def measure(args, prec, stage_fp8, data, dev, rank, world, use_pg, steps, warmup
             tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
             torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
             dt = float(tmax.item())
-        kern = kernel_table(args, timed_steps, plan)
+        kern = kernel_table(args, timed_steps, plan, world)
         _capi.timing_reset()
         fp8 = bool(plan.get("stage_fp8"))
         label = "f32" if prec == "f32" else ("bf16+fp8stage" if fp8 else "bf16")
-        rec = {"value": args.rays * world * steps / dt, "unit": "rays/s", "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "dtype": label,
+        rec = {"value": rays_per_rank(args, world) * world * steps / dt, "unit": "rays/s", "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "dtype": label,
                "arithmetic": {"f32": "f32 (hidden layers on the bf16 matrix cores from exact 3-way splits): 1e-5 relative vs the reference's f32 path per step (tests/test_hip_parity.py)",
                               "bf16": "bf16 MFMA operands, f32 accumulation, f32 master weights; layer inputs and output gradients staged as bf16; PSNR-gated (tests/test_psnr_gates.py)",
                               "bf16+fp8stage": "bf16 MFMA operands for the MLP contractions (forward and dgrad), f32 accumulation, f32 master weights; the layer inputs (e4m3) and output "
@@ -389,7 +415,7 @@ def measure(args, prec, stage_fp8, data, dev, rank, world, use_pg, steps, warmup
                         "onchip_last_layer_wgrad": bool(plan.get("bwd_onchip")), "ray_chunks": plan.get("chunks"),
                         "wgrad": {"jobs": plan.get("wgrad_jobs"), "splits": plan.get("wgrad_splits"), "splits_rebuild_jobs": plan.get("wgrad_splits_rebuild")},
                         "launches_per_step": {k: (kern[k]["launches"] // max(timed_steps, 1)) for k in ("fwd", "bwd_dgrad", "bwd_wgrad")}},
-               "roofline": roofline_of(args, prec, kern, eager_dt, plan),
+               "roofline": roofline_of(args, prec, kern, eager_dt, plan, dt / steps * 1e3, world),
                "store_fallbacks": fused_mod.STORE_FALLBACKS - fallbacks0}       # > 0: some backward ran on the recompute path (store did not fit)
         if sustained:
             rec["sustained"] = sustained
@@ -483,8 +509,8 @@ def main():
         raise SystemExit(f"RANK={rank} / LOCAL_RANK={local} outside a world of {world}")
     if args.dry_run:       # nothing below this line has run: no HIP call, no process group
         print(json.dumps({"rank": rank, "world": world, "local_rank": local, "device": f"cuda:{local}", "backend": "nccl" if world > 1 else None,
-                          "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}", "rays_per_rank": args.rays,
-                          "global_rays_per_step": args.rays * world}), flush=True)
+                          "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}", "scaling": args.scaling,
+                          "rays_per_rank": rays_per_rank(args, world), "global_rays_per_step": rays_per_rank(args, world) * world}), flush=True)
         return
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -508,10 +534,11 @@ def main():
     if rank == 0:
         out = {"metric": f"training rays/sec ({args.det}^2 det, {args.samples} samples/ray)", "value": main_rec["value"], "unit": "rays/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_rec["ms_per_step"],
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": main_rec["dtype"], "data": "synthetic",
+               "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": main_rec["dtype"], "data": "synthetic",
                "config": {"workload": f"run_composite XCAT {args.views}-view x 10 phases, {args.det}^2 detector x {args.samples} samples/ray, "
-                                      f"{args.rays} rays/step/GPU (one full detector), F=128 x 4 hidden layers x 2 nets, L=12, fwd+losses+bwd+Adam",
-                          "rays_per_step_per_gpu": args.rays, "samples_per_ray": args.samples, "parallelism": f"ray-sharded dp{world}", "hip_graph": bool(args.graph),
+                                      f"{rays_per_rank(args, world)} rays/step/GPU ({'one full detector' if args.scaling == 'weak' else f'a global batch of {args.rays} rays split {world} ways'}), "
+                                      f"F=128 x 4 hidden layers x 2 nets, L=12, fwd+losses+bwd+Adam",
+                          "rays_per_step_per_gpu": rays_per_rank(args, world), "global_rays_per_step": rays_per_rank(args, world) * world, "samples_per_ray": args.samples, "parallelism": f"ray-sharded dp{world}", "hip_graph": bool(args.graph),
                           "arithmetic": main_rec["arithmetic"], "stage_fp8": main_rec["plan"]["stage_fp8"], "backward": main_rec["plan"]["backward"],
                           "launches_per_step": main_rec["plan"]["launches_per_step"], "onchip_last_layer_wgrad": main_rec["plan"]["onchip_last_layer_wgrad"],
                           "plan": main_rec["plan"], "library": _capi.build_info()},
@@ -532,7 +559,7 @@ def main():
             if args.prec != "f32" and args.f32_steps > 0:
                 out["f32"] = measure(args, "f32", None, data, dev, 0, 1, False, args.f32_steps, args.f32_warmup)
             out["precisions"] = {k: {"rays_per_s": r["value"], "ms_per_step": r["ms_per_step"], "steps": r["steps"], "roofline_frac": r["roofline"]["frac"],
-                                     "roofline_kernel": r["roofline"]["kernel"]}
+                                     "roofline_kernel": r["roofline"]["kernel"], "roofline_step_frac": r["roofline"]["step"]["frac"]}
                                  for k, r in (("f32", out.get("f32")), ("bf16", out.get("bf16_pure")), (main_rec["dtype"], main_rec)) if r}
             if args.psnr_steps > 0:
                 out["psnr"] = psnr_record(args, dev)

@@ -283,17 +283,19 @@ enum {
                                      kernel reads cross HBM as 8-bit floats (inputs e4m3, gradients e5m2 scaled by a power of two per
                                      64-sample tile; f32 accumulation; the MLP contractions themselves stay bf16), the store also holds the
                                      raw outputs and the masks of every layer, and the backward recomputes nothing.
-                                     1 = always, 0 = never (bf16 staging: the backward recomputes the last layer), -1 = auto (default):
-                                     fp8 staging when the batch has at least NCA_OPT_STAGE_FP8_MIN_TILES wave tiles -- the 8-bit
-                                     rounding noise of a step averages over the samples of the batch, and the PSNR gates of tests/
-                                     hold from that size on.  Initial value from NCA_STAGE_FP8 (0 / 1) */
+                                     1 = always, 0 = never (bf16 staging: the backward recomputes the last layer), -1 = by batch size:
+                                     fp8 staging when the batch has at least NCA_OPT_STAGE_FP8_MIN_TILES wave tiles.  The default is
+                                     -1 with a threshold of 0, i.e. fp8 staging is UNCONDITIONAL unless the caller sets one of the two:
+                                     at no batch size did bf16 staging measure better in held-out PSNR, so no
+                                     threshold is claimed.  nca_last_plan().stage_fp8 says what ran.  Initial value from
+                                     NCA_STAGE_FP8 (0 / 1) */
     NCA_OPT_RESIDENT_MIN_TILES = 2, /* bf16 mode: run the fused kernels with ONE net per launch and all of that net's weight images
                                      resident in LDS (no per-layer weight DMA, no workgroup barrier in the tile loop) when the images fit
                                      (width 128: the input layer + 4 hidden layers forward, 4 transposed images backward) and the batch has at least this many 64-sample wave
                                      tiles.  A two-net render then takes two forward launches (the second composites with the first
                                      one's sigma).  0 = always, -1 = never; default 8 * 8 waves * CUs (NCA_RESIDENT=0 -> never,
                                      =force -> always).  Results are bit-identical to the streaming kernels */
-    NCA_OPT_STAGE_FP8_MIN_TILES = 3, /* threshold of NCA_OPT_STAGE_FP8 = auto, in 64-sample wave tiles of the whole batch (>= 0) */
+    NCA_OPT_STAGE_FP8_MIN_TILES = 3, /* threshold of NCA_OPT_STAGE_FP8 = -1, in 64-sample wave tiles of the whole batch (>= 0; default 0 = always) */
     NCA_OPT_WGRAD_REBUILD_WEIGHT_PCT = 4, /* fp8 staging: the weight-gradient launch is ONE round of one-wave jobs, so its slowest wave is
                                      the launch; the jobs that rebuild their output-gradient block from mask bits take more cycles per
                                      tile than the others and get this many percent of the others' sample splits (100 .. 200; default

@@ -84,10 +84,13 @@ int num_cus() {
         hipDeviceProp_t p;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
         if (n <= 0) n = 256;
-        // (experiments only: NCA_CUS=<k> sizes every persistent grid for k compute units -- how the kernels scale with the part of the
-        // chip they occupy tells a per-CU bound from a chip-wide one)
+#ifdef NCA_CU_OVERRIDE
+        // (the CU-scaling experiment's build only -- tools/cu_scaling.sh builds it with tools/variant_build_all.sh cus "-DNCA_CU_OVERRIDE=1";
+        // the shipped library reads no such variable: NCA_CUS=<k> sizes every persistent grid for k compute units -- how the kernels
+        // scale with the part of the chip they occupy tells a per-CU bound from a chip-wide one)
         const char* e = getenv("NCA_CUS");
         if (e && atoi(e) > 0 && atoi(e) < n) n = atoi(e);
+#endif
     }
     return n;
 }
@@ -206,11 +209,18 @@ extern "C" int nca_last_plan(NcaPlan* out) {
 extern "C" const char* nca_build_info(void) {
     // formatted once (thread-safe static initialisation); the compile-time experiment / variant / ablation masks are all 0 in a shipped
     // library (tests/test_host_cpu.py::test_shipped_library_is_not_a_timing_build).  The effective CU count is NOT part of the string
-    // (reading it would initialise the device): nca_last_plan() and the NCA_CUS note in tools/cu_scaling.sh cover it.
+    // (reading it would initialise the device); the shipped library always sizes its grids for the whole chip (NCA_CU_OVERRIDE builds only
+    // -- tools/cu_scaling.sh -- read NCA_CUS, and say so here).
     static const std::string info = [] {
         char b[160];
-        snprintf(b, sizeof(b), "libnerfca_hip gfx950 abi=%d NCA_EXP=%d variant=0x%x ablation=0x%x", NCA_ABI_VERSION, nca_kernels_exp_mask(), nca_kernels_variant_mask(),
-                 nca_kernels_ablation_mask());
+        snprintf(b, sizeof(b), "libnerfca_hip gfx950 abi=%d NCA_EXP=%d variant=0x%x ablation=0x%x%s", NCA_ABI_VERSION, nca_kernels_exp_mask(), nca_kernels_variant_mask(),
+                 nca_kernels_ablation_mask(),
+#ifdef NCA_CU_OVERRIDE
+                 " cu-override"
+#else
+                 ""
+#endif
+        );
         return std::string(b);
     }();
     return info.c_str();
@@ -632,7 +642,7 @@ static int plan_bwd(const NcaLayout* lays, int nnets, int32_t prec, int64_t unit
     if (nsplit < 1) nsplit = 1;
     // The jobs of the last hidden layers under e5m2 staging rebuild their D block on the vector ALU: 1.15 x the cycles per tile of
     // the others (measured, tools/clock_probe.sh).  The grid is ONE round of one-wave workgroups, so the slowest wave is the launch:
-    // those jobs get W x the splits (NCA_OPT_WGRAD_REBUILD_WEIGHT_PCT, default 1.15).  Their extra slab rows stay zero in every other job's columns (cleared once per backward).
+    // those jobs get W x the splits (NCA_OPT_WGRAD_REBUILD_WEIGHT_PCT, default 1.15).  Their extra slab rows hold NOTHING in every other job's columns and are never read there (NcaReduceArgs::n_split_std).
     int nsplit_x = nsplit;
     if (bf && stored && d8 && nr && p->njobs > nnets) {
         const double W = 0.01 * (double)opt_value(NCA_OPT_WGRAD_REBUILD_WEIGHT_PCT);

@@ -168,7 +168,8 @@ struct NcaReduceNet {
 struct NcaReduceArgs {
     int64_t n_total;
     int64_t n_params[2];
-    const float* slab;
+    float* slab;             // (not const: nca_reduce_f32 / nca_onehot_sum_f32 leave sums over the splits in slab row 0 for nca_reduce_small_f32,
+                             //  which must be launched after them on the same stream)
     int64_t slab_stride;
     int32_t n_split, n_wg;   // n_split: slab rows of the columns the rebuilding (`expand`) jobs write -- the last F-wide layer under tail_from_sums
     int32_t n_split_std;     // slab rows of every other column (<= n_split; the rows beyond hold nothing for them and are never read)

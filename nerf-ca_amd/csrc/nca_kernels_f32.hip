@@ -28,16 +28,25 @@ typedef float f32x4e __attribute__((ext_vector_type(4)));
 
 // Rounding ablations (tools/ablation_build.sh; 0 in every shipped library -- nca_build_info() reports the mask): the
 // parity kernels with ONE of the bf16 mode's roundings switched on, to find which of them costs held-out PSNR.  1: encoded input
-// features, 2: hidden-layer weights, 4: hidden activations (after ReLU), 8: output gradients of the dgrad chain, 16: layer-0 weights.
+// features, 2: hidden-layer weights, 4: hidden activations (after ReLU), 8: output gradients of the dgrad chain, 16: layer-0 weights
+// -- each rounded to NCA_ABL_MANT significant bits (8 = bf16, 11 = f16's precision without its range) --, 32: the layer inputs as the
+// weight-gradient kernel reads them (what is STORED; the chain keeps f32) to 4 significant bits (e4m3's), 64: the stored output
+// gradients to 3 (e5m2's).
 #ifndef NCA_ABL
 #define NCA_ABL 0
 #endif
+#ifndef NCA_ABL_MANT
+#define NCA_ABL_MANT 8
+#endif
 template <int BIT>
 __device__ __forceinline__ float abl(float x) {
-    if constexpr ((NCA_ABL & BIT) != 0) return (float)(__bf16)x;
-    else return x;
+    if constexpr ((NCA_ABL & BIT) != 0) {
+        constexpr int MANT = BIT == 32 ? 4 : (BIT == 64 ? 3 : NCA_ABL_MANT), DROP = 24 - MANT;
+        const unsigned u = __float_as_uint(x);
+        return __uint_as_float((u + ((1u << (DROP - 1)) - 1u) + ((u >> DROP) & 1u)) & ~((1u << DROP) - 1u));     // round to nearest even
+    } else return x;
 }
-int nca_kernels_ablation_mask() { return NCA_ABL; }
+int nca_kernels_ablation_mask() { return NCA_ABL | (NCA_ABL ? NCA_ABL_MANT << 8 : 0); }
 
 // x3 split (see the x3 section below): exact three-way bf16 split of f32 values
 typedef float x3_f32x2 __attribute__((ext_vector_type(2)));
@@ -297,12 +306,12 @@ __device__ __forceinline__ void x3_sub(const char* __restrict__ sub, const f32x1
         __builtin_amdgcn_sched_barrier(0);
     }
 }
-template <int MT>
+template <int MT, int ABL_BIT>
 __device__ __forceinline__ void x3_store_block(float* st, const f32x16 (&h)[MT]) {
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) store_quad(st + (m * 4 + g) * 256, h[m][4 * g], h[m][4 * g + 1], h[m][4 * g + 2], h[m][4 * g + 3]);
+        for (int g = 0; g < 4; ++g) store_quad(st + (m * 4 + g) * 256, abl<ABL_BIT>(h[m][4 * g]), abl<ABL_BIT>(h[m][4 * g + 1]), abl<ABL_BIT>(h[m][4 * g + 2]), abl<ABL_BIT>(h[m][4 * g + 3]));
 }
 
 // Backward: the B operands are also what the weight-gradient kernel needs (a layer input H or an output gradient D), and
@@ -648,7 +657,7 @@ __global__ __launch_bounds__(NCA_NT, NCA_F32_MINBLOCKS) void nca_fused_f32(const
                             int ia, ib;
                             nca_enc_pair(y, s, &ia, &ib);
                             const int row = lh ? ib : ia;
-                            if (row >= 0) __builtin_nontemporal_store(bop, henc + row * 32);
+                            if (row >= 0) __builtin_nontemporal_store(abl<32>(bop), henc + row * 32);
                         }
                     });
                     if (STORE && jj == 0 && y.P > 0 && tvalid) {
@@ -669,7 +678,7 @@ __global__ __launch_bounds__(NCA_NT, NCA_F32_MINBLOCKS) void nca_fused_f32(const
                     nsi_final = nsi2;
                 } else if (x3h) {
                     constexpr int KH = MT >= 2 ? MT : 2 * MT;          // k-steps per sub-stage
-                    if (STORE && tvalid) x3_store_block<MT>(hf + (y.K0rows_pad + (jj - 1) * F) * 32, hprev);                  // H_{jj-1}
+                    if (STORE && tvalid) x3_store_block<MT, 32>(hf + (y.K0rows_pad + (jj - 1) * F) * 32, hprev);                  // H_{jj-1}
                     x3_sub<MT, KH, 0>(reinterpret_cast<const char*>(img) + lane * 16, hprev, acc);
                     if (MT >= 2) {
                         // second sub-stage (the other half of the k-steps): publish its image, prefetch the one after it.  The
@@ -721,7 +730,7 @@ __global__ __launch_bounds__(NCA_NT, NCA_F32_MINBLOCKS) void nca_fused_f32(const
 #pragma unroll
                         for (int m = 0; m < MT; ++m)
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) store_quad(hl + (m * 4 + q) * 256, hprev[m][4 * q], hprev[m][4 * q + 1], hprev[m][4 * q + 2], hprev[m][4 * q + 3]);
+                            for (int q = 0; q < 4; ++q) store_quad(hl + (m * 4 + q) * 256, abl<32>(hprev[m][4 * q]), abl<32>(hprev[m][4 * q + 1]), abl<32>(hprev[m][4 * q + 2]), abl<32>(hprev[m][4 * q + 3]));
                         if (lh == 0) __builtin_nontemporal_store(raw[net], rglob);
                     }
 
@@ -769,7 +778,7 @@ __global__ __launch_bounds__(NCA_NT, NCA_F32_MINBLOCKS) void nca_fused_f32(const
                     int nsi_d = nsi;
                     if (X3) {
                         constexpr int KH = MT >= 2 ? MT : 2 * MT;
-                        if (tvalid) x3_store_block<MT>(df + jj * F * 32, hprev);                                                // D_jj
+                        if (tvalid) x3_store_block<MT, 64>(df + jj * F * 32, hprev);                                                // D_jj
                         x3_sub<MT, KH, 0>(smem + cur * BUF + lane * 16, hprev, acc);
                         if (MT >= 2) {
                             stage_publish_counted<4 * MT>(tvalid);      // the D_jj stores are younger than this sub-stage's DMA
@@ -820,7 +829,7 @@ __global__ __launch_bounds__(NCA_NT, NCA_F32_MINBLOCKS) void nca_fused_f32(const
                     for (int m = 0; m < MT; ++m)
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            store_quad(dd + (m * 4 + q) * 256, hprev[m][4 * q], hprev[m][4 * q + 1], hprev[m][4 * q + 2], hprev[m][4 * q + 3]);
+                            store_quad(dd + (m * 4 + q) * 256, abl<64>(hprev[m][4 * q]), abl<64>(hprev[m][4 * q + 1]), abl<64>(hprev[m][4 * q + 2]), abl<64>(hprev[m][4 * q + 3]));
                 }
             }
         }  // nets
@@ -1196,7 +1205,11 @@ __global__ void nca_reduce_f32(const NcaReduceArgs a) {
     const float* sp = a.slab + rn.slab_off + le;
     int64_t stride = a.slab_stride;
     // rows of this column: the rebuilding jobs of the last F-wide layer may run over more splits than the others
-    const bool tail_col = rn.tail_from_sums && le >= rn.tl_w_off && le < rn.tl_b_off + rn.F;
+    // (two explicit ranges, W then b, as the scaling below: nothing here assumes the bias follows the weight in the flat buffer)
+    const int64_t F2t = (int64_t)rn.F * rn.F;
+    const bool tail_w = rn.tail_from_sums && le >= rn.tl_w_off && le < rn.tl_w_off + F2t;
+    const bool tail_b = rn.tail_from_sums && le >= rn.tl_b_off && le < rn.tl_b_off + rn.F;
+    const bool tail_col = tail_w || tail_b;
     int nsum = tail_col ? a.n_split : a.n_split_std;
     if (rn.wslab) {
         // the layer whose weight gradient the dgrad kernel accumulated on chip: one partial per workgroup
@@ -1214,13 +1227,10 @@ __global__ void nca_reduce_f32(const NcaReduceArgs a) {
     // the last F-wide layer under tail_from_sums: leave the sum over the splits in slab row 0 (this thread is the only reader of its
     // column) -- nca_reduce_small_f32, launched next, forms dWo from S and s summed over the splits and reads 129 values per output
     // instead of 129 x n_split (it was 83 us of one wave per output walking the slabs: as long at 1 024 rays per step as at 65 536)
-    if (tail_col) const_cast<float*>(a.slab)[rn.slab_off + le] = r;          // (tail_from_sums and an on-chip tail layer exclude each other: a tail column is a slab column)
-    if (rn.tail_from_sums) {
-        // the last F-wide layer's sums were formed without the factor Wo[f] of their output row (nca_layout.hpp)
-        const int64_t F2 = (int64_t)rn.F * rn.F;
-        if (le >= rn.tl_w_off && le < rn.tl_w_off + F2) r *= rn.params[rn.wo_off + (le - rn.tl_w_off) / rn.F];
-        else if (le >= rn.tl_b_off && le < rn.tl_b_off + rn.F) r *= rn.params[rn.wo_off + (le - rn.tl_b_off)];
-    }
+    if (tail_col) a.slab[rn.slab_off + le] = r;          // (tail_from_sums and an on-chip tail layer exclude each other: a tail column is a slab column)
+    // the last F-wide layer's sums were formed without the factor Wo[f] of their output row (nca_layout.hpp)
+    if (tail_w) r *= rn.params[rn.wo_off + (le - rn.tl_w_off) / rn.F];
+    else if (tail_b) r *= rn.params[rn.wo_off + (le - rn.tl_b_off)];
     *out = r;
 }
 
@@ -1272,7 +1282,7 @@ __global__ void nca_onehot_sum_f32(const NcaReduceArgs a) {
         const NcaReduceNet& rn = a.net[net];
         const int64_t cnt = (int64_t)rn.F * rn.P;
         if (e >= cnt || !rn.grads) continue;
-        float* p0 = const_cast<float*>(a.slab) + rn.onehot_off + e;
+        float* p0 = a.slab + rn.onehot_off + e;
         float s4[4] = {0.f, 0.f, 0.f, 0.f};
         int q = 0;
         for (; q + 4 <= a.n_split_std; q += 4) {         // (the one-hot block belongs to the layer-0 jobs)

@@ -113,6 +113,58 @@ def test_two_ranks_over_rccl_equal_one_rank(tmp_path, mode, prec, gtol):
     assert float((r0["g"] - g1).abs().max() / g1.abs().max()) < gtol
 
 
+def _graph_steps(n_steps, prec, allreduce):
+    """`n_steps` graph-replayed steps (bench.py's default step) of one rank; with `allreduce` the gradient all-reduce runs between
+    the two captured graphs as it does under ray sharding.  Returns the bits of every step's loss and the final parameters."""
+    import nerfca_amd
+    from nerfca_amd import synthetic
+    from nerfca_amd.model.CPPN import CPPN
+    from nerfca_amd.model.Temporal import Temporal
+    from nerfca_amd.train.trainer import CompositeTrainer, TrainConfig
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    S, R = 64, 2048
+    data = synthetic.make_dataset(32, S, dev, views=synthetic.TRAIN_VIEWS[:2], n_phases=3, F=32)
+    torch.manual_seed(5)
+    sdef, tdef = synthetic.net_definitions(dev)
+    s, t = CPPN(sdef).to(dev), Temporal(tdef).to(dev)
+    nerfca_amd.set_precision(prec, s, t)
+    tr = CompositeTrainer(TrainConfig(depth_samples_per_ray_coarse=S, img_sample_size=R), s, t, data, dev, rank=0, world=1, seed=4)
+    tr.always_allreduce = allreduce
+    losses = []
+    for it in range(n_steps):
+        loss, _, _ = tr.step_graph(75000 + it)
+        losses.append(loss.detach().clone().view(1).view(torch.int64 if loss.dtype == torch.float64 else torch.int32).cpu())
+    torch.cuda.synchronize()
+    return torch.cat(losses), torch.cat([p.detach().flatten() for p in tr.params]).cpu()
+
+
+def _rccl_one_rank_worker(rank, port, outdir, n_steps, prec):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        l, p = _graph_steps(n_steps, prec, True)
+        torch.save({"l": l, "p": p}, os.path.join(outdir, "rccl1.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("prec", ["bf16", "f32"])
+def test_one_rank_rccl_graph_step_is_bit_identical_to_no_process_group(tmp_path, prec):
+    """The graph-replayed step with an RCCL process group of ONE rank (what `NERFCA_FORCE_PG=1 bench.py` runs, and the N = 1 end of the
+    driver's scaling run): the all-reduce between the two captured graphs must be a no-op on values -- ten steps, every loss and the
+    final parameters bit-identical to the step without a process group."""
+    l0, p0 = _graph_steps(10, prec, False)
+    mp.spawn(_rccl_one_rank_worker, args=(_free_port(), str(tmp_path), 10, prec), nprocs=1, join=True)
+    r = torch.load(tmp_path / "rccl1.pt")
+    assert torch.equal(r["l"], l0), (r["l"], l0)
+    assert torch.equal(r["p"].view(torch.int32), p0.view(torch.int32))
+
+
 def _bench(args, env_extra, timeout=900):
     import json
     import subprocess
