@@ -20,8 +20,8 @@ parity mode.  `roofline` is for the kernel with the largest share of the step, m
 inside the library (nca_timing_*) over an eager pass of the same step (events cannot be recorded inside a replayed graph: the
 table decomposes `eager_ms_per_step`, which it sums to at most); `cpu_baseline` is the CPU oracle (reference-equivalent torch CPU
 ops) on a bounded sample.  At N = 1 the line also carries the other two precisions side by side, each through the same
-graph-replayed step with its own kernel table and roofline -- `bf16_pure` (NCA_OPT_STAGE_FP8 = 0: BASELINE configs[1] as written)
-and `f32` (>= 20 steps after 5 warm-up) --, `sustained` (ms per step over the last 100 of --sustained-steps further graph
+graph-replayed step with its own kernel table and roofline -- `bf16_pure` (stage_fp8 = 0: BASELINE configs[1] as written -- bf16
+operands everywhere, no 8-bit staged store, the backward recomputes the layers) and `f32` (>= 20 steps after 5 warm-up) --, `sustained` (ms per step over the last 100 of --sustained-steps further graph
 steps: the chip lowers its clock as it heats), `unfused_gpu_baseline` (the reference-equivalent torch ops run op by op on the
 same GPU: the denominator of the north star's >= 10x) and `psnr` (held-out PSNR of HIP f32, HIP bf16 and the CPU oracle after
 equal steps from identical weights and batches; train/run_composite.py:391 defines test_psnr).  --no-extras drops those.
@@ -235,7 +235,7 @@ def unfused_gpu_baseline(args, data):
             "sample": f"{steps} full training steps of {R} rays x {args.samples} samples with unfused PyTorch-ROCm ops, {dt:.2f} s"}
 
 
-def make_trainer(args, prec, data, dev, rank, world, use_pg):
+def make_trainer(args, prec, data, dev, rank, world, use_pg, plan_opts=None):
     import nerfca_amd
     from nerfca_amd import synthetic
     from nerfca_amd.model.CPPN import CPPN
@@ -246,20 +246,18 @@ def make_trainer(args, prec, data, dev, rank, world, use_pg):
     s, t = CPPN(sdef).to(dev), Temporal(tdef).to(dev)
     nerfca_amd.set_precision(prec, s, t)
     cfg = TrainConfig(depth_samples_per_ray_coarse=args.samples, img_sample_size=rays_per_rank(args, world) * world)
-    tr = CompositeTrainer(cfg, s, t, data, dev, rank=rank, world=world, seed=0, fused_loss=not args.torch_losses)
+    tr = CompositeTrainer(cfg, s, t, data, dev, rank=rank, world=world, seed=0, fused_loss=not args.torch_losses, plan_opts=plan_opts)
     tr.always_allreduce = use_pg
     return tr
 
 
 def kernel_table(args, timed_steps, plan, world=1):
-    """Per-kernel HIP-event times of the span the library's timers covered, with algorithmic TFLOP/s.  `plan` = the planner's
-    decisions for this backward (nca_last_plan): with the last hidden layer's weight gradient accumulated in the dgrad kernel
-    (bf16 staging at this size) its 2 x 2 x 128 x 128 FLOP per sample count there, not in the weight-gradient kernel."""
+    """Per-kernel HIP-event times of the span the library's timers covered, with algorithmic TFLOP/s (the recompute backward's
+    repeated forward is NOT counted as work: its dgrad kernel is charged the dgrad FLOPs only)."""
     from nerfca_amd import _capi
     n_samp = rays_per_rank(args, world) * args.samples * timed_steps
     kern = {}
-    moved = 2 * 2 * 128 * 128 if plan.get("bwd_onchip") else 0
-    for name, flop in (("fwd", FLOP_FWD), ("bwd_dgrad", FLOP_DGRAD + moved), ("bwd_wgrad", FLOP_WGRAD - moved), ("bwd_reduce", 0), ("loss", 0), ("pack", 0)):
+    for name, flop in (("fwd", FLOP_FWD), ("bwd_dgrad", FLOP_DGRAD), ("bwd_wgrad", FLOP_WGRAD), ("bwd_reduce", 0), ("loss", 0), ("pack", 0)):
         ms, n = _capi.timing_read(name)
         kern[name] = {"ms_total": ms, "launches": n, "avg_ms": ms / n if n else None, "ms_per_step": ms / max(timed_steps, 1),
                       "tflops": (flop * n_samp / (ms * 1e-3) / 1e12) if ms > 0 and flop else None}
@@ -329,21 +327,21 @@ def roofline_of(args, prec, kern, eager_dt, plan, ms_per_step, world=1):
     return roof
 
 
-BWD_MODES = {1: "mode 1: recompute backward (no forward store)", 3: "mode 3: from the forward's store, last layer recomputed",
-             4: "mode 4: from the store, last hidden layer's weight gradient on chip", 5: "mode 5: from the forward's fp8-staged store, nothing recomputed"}
+BWD_MODES = {1: "mode 1: recompute backward (no forward store)", 3: "mode 3: from the forward's f32 store",
+             5: "mode 5: from the forward's 8-bit staged store, nothing recomputed"}
 
 
 def measure(args, prec, stage_fp8, data, dev, rank, world, use_pg, steps, warmup, sustained_steps=0):
     """Warm-up, `steps` timed steps between barriers (max over ranks), then an eager pass that times the kernels with HIP
-    events, then (optionally) the sustained run.  `stage_fp8`: None = the planner's default, 0 / 1 = NCA_OPT_STAGE_FP8 for
-    this record.  Returns the record's fields (value, ms_per_step, dtype label, plan, roofline, ...)."""
+    events, then (optionally) the sustained run.  `stage_fp8`: None = the planner's default, 0 / 1 = this record's
+    trainer runs with that value of NCA_OPT_STAGE_FP8 as ITS planner option (per trainer: nothing process-wide is touched).  Returns
+    the record's fields (value, ms_per_step, dtype label, plan, roofline, ...).  A forward store that cannot be allocated is an
+    error here (fused.STRICT_STORE): the bench never silently times the recompute path."""
     from nerfca_amd import _capi
     from nerfca_amd import fused as fused_mod
-    old = _capi.get_option(_capi.OPT_STAGE_FP8)
-    if stage_fp8 is not None:
-        _capi.set_option(_capi.OPT_STAGE_FP8, stage_fp8)
-    try:
-        tr = make_trainer(args, prec, data, dev, rank, world, use_pg)
+    fused_mod.STRICT_STORE = True
+    if True:
+        tr = make_trainer(args, prec, data, dev, rank, world, use_pg, plan_opts=None if stage_fp8 is None else {"stage_fp8": stage_fp8})
 
         def barrier():
             torch.cuda.synchronize()
@@ -365,7 +363,7 @@ def measure(args, prec, stage_fp8, data, dev, rank, world, use_pg, steps, warmup
         barrier()
         dt = time.perf_counter() - t0
         loss = float(loss)
-        plan = _capi.last_plan()            # of the last backward (graph: of the capture)
+        plan = tr.plan()            # of this trainer's last backward (graph: of the capture)
         sustained = None
         if sustained_steps >= 200 and args.graph:
             for i in range(sustained_steps - 100):
@@ -393,7 +391,7 @@ def measure(args, prec, stage_fp8, data, dev, rank, world, use_pg, steps, warmup
             barrier()
             eager_dt = time.perf_counter() - te
             eager_ms = eager_dt / timed_steps * 1e3       # the same step with host-launched kernels and torch's Adam
-            plan = _capi.last_plan()
+            plan = tr.plan()
         _capi.timing_enable(False)
         if use_pg:
             tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -405,14 +403,14 @@ def measure(args, prec, stage_fp8, data, dev, rank, world, use_pg, steps, warmup
         label = "f32" if prec == "f32" else ("bf16+fp8stage" if fp8 else "bf16")
         rec = {"value": rays_per_rank(args, world) * world * steps / dt, "unit": "rays/s", "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "dtype": label,
                "arithmetic": {"f32": "f32 (hidden layers on the bf16 matrix cores from exact 3-way splits): 1e-5 relative vs the reference's f32 path per step (tests/test_hip_parity.py)",
-                              "bf16": "bf16 MFMA operands, f32 accumulation, f32 master weights; layer inputs and output gradients staged as bf16; PSNR-gated (tests/test_psnr_gates.py)",
+                              "bf16": "bf16 MFMA operands everywhere, f32 accumulation, f32 master weights; no forward store: the backward recomputes the layers, nothing is staged in 8 bits",
                               "bf16+fp8stage": "bf16 MFMA operands for the MLP contractions (forward and dgrad), f32 accumulation, f32 master weights; the layer inputs (e4m3) and output "
                                                "gradients (e5m2, per-tile power-of-two scale) cross HBM in 8 bits and the weight gradient contracts them on the MX-fp8 matrix path; PSNR-gated "
                                                "(tests/test_psnr_gates.py)"}[label],
                "hip_graph": bool(args.graph), "eager_ms_per_step": eager_ms, "kernel_table_steps": timed_steps, "final_loss": loss,
                "plan": {"stage_fp8": fp8, "backward": BWD_MODES.get(plan.get("bwd_kernel_mode"), str(plan.get("bwd_kernel_mode"))),
                         "resident_weight_images": {"fwd": bool(plan.get("fwd_resident")), "bwd": bool(plan.get("bwd_resident"))},
-                        "onchip_last_layer_wgrad": bool(plan.get("bwd_onchip")), "ray_chunks": plan.get("chunks"),
+                        "ray_chunks": plan.get("chunks"),
                         "wgrad": {"jobs": plan.get("wgrad_jobs"), "splits": plan.get("wgrad_splits"), "splits_rebuild_jobs": plan.get("wgrad_splits_rebuild")},
                         "launches_per_step": {k: (kern[k]["launches"] // max(timed_steps, 1)) for k in ("fwd", "bwd_dgrad", "bwd_wgrad")}},
                "roofline": roofline_of(args, prec, kern, eager_dt, plan, dt / steps * 1e3, world),
@@ -422,8 +420,6 @@ def measure(args, prec, stage_fp8, data, dev, rank, world, use_pg, steps, warmup
         del tr
         torch.cuda.empty_cache()
         return rec
-    finally:
-        _capi.set_option(_capi.OPT_STAGE_FP8, old)
 
 
 def psnr_record(args, dev):
@@ -540,7 +536,7 @@ def main():
                                       f"F=128 x 4 hidden layers x 2 nets, L=12, fwd+losses+bwd+Adam",
                           "rays_per_step_per_gpu": rays_per_rank(args, world), "global_rays_per_step": rays_per_rank(args, world) * world, "samples_per_ray": args.samples, "parallelism": f"ray-sharded dp{world}", "hip_graph": bool(args.graph),
                           "arithmetic": main_rec["arithmetic"], "stage_fp8": main_rec["plan"]["stage_fp8"], "backward": main_rec["plan"]["backward"],
-                          "launches_per_step": main_rec["plan"]["launches_per_step"], "onchip_last_layer_wgrad": main_rec["plan"]["onchip_last_layer_wgrad"],
+                          "launches_per_step": main_rec["plan"]["launches_per_step"],
                           "plan": main_rec["plan"], "library": _capi.build_info()},
                "rccl_ranks": rccl_ranks, "roofline": main_rec["roofline"], "final_loss": main_rec["final_loss"], "eager_ms_per_step": main_rec["eager_ms_per_step"],
                "kernel_table_steps": main_rec["kernel_table_steps"], "store_fallbacks": main_rec["store_fallbacks"]}
@@ -555,7 +551,8 @@ def main():
             # the other precisions side by side, each through the same (graph-replayed) step
             if args.prec == "bf16" and args.pure_steps > 0 and main_rec["plan"]["stage_fp8"]:
                 out["bf16_pure"] = measure(args, "bf16", 0, data, dev, 0, 1, False, args.pure_steps, args.warmup)
-                out["bf16_pure"]["note"] = "BASELINE configs[1] as written: bf16 everywhere, nothing staged in 8 bits (NCA_OPT_STAGE_FP8 = 0)"
+                out["bf16_pure"]["note"] = ("BASELINE configs[1] as written: bf16 everywhere, nothing staged in 8 bits (stage_fp8 = 0: no forward store, recompute backward; "
+                                            "the bf16-STAGED store of rounds 1-3 was retired in round 4, DESIGN.md 4.5)")
             if args.prec != "f32" and args.f32_steps > 0:
                 out["f32"] = measure(args, "f32", None, data, dev, 0, 1, False, args.f32_steps, args.f32_warmup)
             out["precisions"] = {k: {"rays_per_s": r["value"], "ms_per_step": r["ms_per_step"], "steps": r["steps"], "roofline_frac": r["roofline"]["frac"],

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NCA_ABI_VERSION 8
+#define NCA_ABI_VERSION 9
 
 enum {
     NCA_OK = 0,
@@ -70,6 +70,18 @@ typedef struct NcaNet {
     int32_t reserved;
 } NcaNet;
 
+/* Per-call planner options (NcaRays.plan_opts): a field that is not NCA_OPT_UNSET replaces the process-wide tunable of the same name
+ * (nca_set_option) for THIS call only -- two trainers, or two threads, of one process then do not see each other's settings.  A
+ * backward should be given the options of its forward (the store's format travels in NcaRays.store_format either way). */
+#define NCA_OPT_UNSET INT64_MIN
+typedef struct NcaPlanOpts {
+    int64_t stage_fp8;                /* NCA_OPT_STAGE_FP8                */
+    int64_t stage_fp8_min_tiles;      /* NCA_OPT_STAGE_FP8_MIN_TILES      */
+    int64_t resident_min_tiles;       /* NCA_OPT_RESIDENT_MIN_TILES       */
+    int64_t wgrad_rebuild_weight_pct; /* NCA_OPT_WGRAD_REBUILD_WEIGHT_PCT */
+} NcaPlanOpts;
+struct NcaPlan;
+
 /* A batch of rays and the per-step sampling state: the arguments of
  * obtain_train_predictions_iter / _static (train/model_helpers.py:99-160). */
 typedef struct NcaRays {
@@ -90,6 +102,10 @@ typedef struct NcaRays {
     float scale;            /* scale_value, 1e-2                                             */
     int32_t store_format;   /* backward from a forward store: the value nca_render_fwd returned when it wrote that store
                                (NCA_STORE_*); ignored by the forward and by a backward without a store */
+    const NcaPlanOpts* plan_opts; /* HOST pointer or NULL: per-call planner options (above)                                   */
+    struct NcaPlan* plan_out;     /* HOST pointer or NULL: filled with what the planner decided in THIS call (the forward fills
+                                     the fwd_* fields and wave_tiles, a backward the rest; the other fields are left as they are) --
+                                     the per-caller counterpart of the process-wide nca_last_plan() */
 } NcaRays;
 
 /* What a storing forward left in its store (the return value of nca_render_fwd; 0 = it wrote no store).  The backward is told
@@ -98,8 +114,8 @@ typedef struct NcaRays {
 enum {
     NCA_STORE_NONE = 0,
     NCA_STORE_F32 = 1,        /* f32 mode: every layer input, ReLU masks, raw outputs                         */
-    NCA_STORE_BF16 = 2,       /* bf16 mode, bf16 staging: layer inputs as bf16, masks of the hidden layers    */
-    NCA_STORE_FP8 = 3,        /* bf16 mode, fp8 staging: layer inputs as e4m3, masks of all layers, raw outputs */
+    NCA_STORE_RESERVED2 = 2,  /* (ABI <= 8: bf16 mode with bf16 staging -- retired; never returned, refused by the backward)          */
+    NCA_STORE_FP8 = 3,        /* bf16 mode: layer inputs as e4m3, masks of all layers, raw outputs               */
     NCA_STORE_KIND_MASK = 15,
     NCA_STORE_SHARED_ENC = 16 /* flag: both nets share one stored input block (same encoding vectors)          */
 };
@@ -126,8 +142,8 @@ int nca_pack_weights(const NcaNet* net, const float* params, void* packed, int32
  *   work  scratch of nca_render_fwd_workspace() bytes.
  *   store NULL, or a caller-owned buffer of nca_render_store_bytes() bytes: the forward then also leaves there what the
  *         reference's autograd graph keeps (train/run_composite.py:306) -- f32: every layer input, the ReLU masks and the
- *         raw outputs; bf16: the layer inputs as e4m3 (NCA_OPT_STAGE_FP8, default) or bf16, the ReLU masks and (fp8 staging)
- *         the raw outputs -- and nca_render_bwd given the same buffer does not recompute the layers.
+ *         raw outputs; bf16: the layer inputs as e4m3, the ReLU masks of every layer and the raw outputs (NCA_OPT_STAGE_FP8 = 0:
+ *         no store at all) -- and nca_render_bwd given the same buffer does not recompute the layers.
  *         nca_render_store_bytes() returns 0 where this is not available (nets of different width, nets without a hidden
  *         layer): pass NULL there.
  * Returns a negative error code, or >= 0: the format of the store it wrote (NCA_STORE_*, 0 = none) -- hand it to the backward
@@ -249,9 +265,12 @@ int nca_fine_depths_given_max(int64_t R, int32_t S, int32_t n_fine, const float*
  *      train/model_helpers.py:3-12, 73-74, in one launch instead of ~20 small torch kernels.  Bit-exact with the torch ops:
  *      z' = lo + (hi - lo) * t with mid = 0.5 * (z[1:] + z[:-1]) in f32; dists[i] = z'[i+1] - z'[i] (f32 subtraction, widened) and the
  *      1e-10 tail in the ray table's dtype.
- *      table f64[N,4,3] (rows: origin, direction, pixel x3, weight x3); phases i64[N]; ids i64[R] (0 <= id < N, not checked).
+ *      table f64[N,4,3] (rows: origin, direction, pixel x3, weight x3); phases i64[N]; ids i64[R].
+ *      n_rows = N: an id outside [0, N) does not reach memory -- it is clamped into the table and, if `bad_ids` (device i32[1],
+ *      caller-zeroed, may be NULL) is given, counted there; the caller reads the counter when it can afford a synchronisation
+ *      (CompositeTrainer.early_stop() / evaluate() do, and raise).  n_rows <= 0 = unknown: ids are trusted as in ABI <= 8.
  *      Outputs: o, d f64[R,3]; gt, w f64[R]; ph i32[R]; z f32[S]; dists f64[S].  depth / t_rand f32[S].  ------------------------------ */
-int nca_prepare_batch(int64_t R, int32_t S, const int64_t* ids, const double* table, const int64_t* phases,
+int nca_prepare_batch(int64_t R, int32_t S, const int64_t* ids, const double* table, const int64_t* phases, int64_t n_rows, int32_t* bad_ids,
                       const float* depth, const float* t_rand,
                       double* o, double* d, double* gt, double* w, int32_t* ph, float* z, double* dists, void* stream);
 
@@ -275,20 +294,18 @@ int nca_adam_step(const NcaAdam* cfg, int32_t n_seg, const int64_t* n, float* co
  *      oracle can afford.  Both calls return NCA_OK or NCA_E_INVALID; values persist until changed.  A planner decision that
  *      shapes a forward store is taken ONCE, by the forward, and travels to the backward in NcaRays.store_format. -------------- */
 enum {
-    NCA_OPT_ONCHIP_MIN_TILES = 0, /* bf16 backward from a forward store with BF16 staging (fp8 staging recomputes nothing and has no use
-                                     for it): keep the last hidden layer's weight gradient on chip (one launch per net) when the batch
-                                     has at least this many 64-sample wave tiles.  0 = always, -1 = never; default 8 * 8 waves * CUs
-                                     (initial value from the environment: NCA_ONCHIP=0 -> never, =force -> always) */
-    NCA_OPT_STAGE_FP8 = 1,        /* bf16 mode with a forward store: the layer inputs and output gradients that only the weight-gradient
-                                     kernel reads cross HBM as 8-bit floats (inputs e4m3, gradients e5m2 scaled by a power of two per
-                                     64-sample tile; f32 accumulation; the MLP contractions themselves stay bf16), the store also holds the
-                                     raw outputs and the masks of every layer, and the backward recomputes nothing.
-                                     1 = always, 0 = never (bf16 staging: the backward recomputes the last layer), -1 = by batch size:
-                                     fp8 staging when the batch has at least NCA_OPT_STAGE_FP8_MIN_TILES wave tiles.  The default is
-                                     -1 with a threshold of 0, i.e. fp8 staging is UNCONDITIONAL unless the caller sets one of the two:
-                                     at no batch size did bf16 staging measure better in held-out PSNR, so no
-                                     threshold is claimed.  nca_last_plan().stage_fp8 says what ran.  Initial value from
-                                     NCA_STAGE_FP8 (0 / 1) */
+    NCA_OPT_RESERVED0 = 0,        /* (ABI <= 8: NCA_OPT_ONCHIP_MIN_TILES of the retired bf16-staged backward; get / set return NCA_E_INVALID) */
+    NCA_OPT_STAGE_FP8 = 1,        /* bf16 mode: whether the forward may leave a STORE for its backward.  The store is 8-bit staged: the layer
+                                     inputs and output gradients that only the weight-gradient kernel reads cross HBM as 8-bit floats (inputs
+                                     e4m3, gradients e5m2 scaled by a power of two per 64-sample tile; f32 accumulation; the MLP contractions
+                                     themselves stay bf16), the store also holds the raw outputs and the masks of every layer, and the backward
+                                     recomputes nothing.  1 = always; 0 = never: nca_render_store_bytes returns 0, a forward that is handed a
+                                     store leaves it untouched and returns NCA_STORE_NONE, and the backward recomputes the layers -- bf16
+                                     operands everywhere, nothing in 8 bits (BASELINE configs[1] "as written"; the bf16-STAGED store of
+                                     ABI <= 8 was retired in round 4: never better in held-out PSNR, 1.75 x slower);
+                                     -1 = by batch size: a store when the batch has at least NCA_OPT_STAGE_FP8_MIN_TILES wave tiles.  The
+                                     default is -1 with a threshold of 0, i.e. the store is UNCONDITIONAL unless the caller sets one of the
+                                     two.  nca_last_plan().stage_fp8 says what ran.  Initial value from NCA_STAGE_FP8 (0 / 1) */
     NCA_OPT_RESIDENT_MIN_TILES = 2, /* bf16 mode: run the fused kernels with ONE net per launch and all of that net's weight images
                                      resident in LDS (no per-layer weight DMA, no workgroup barrier in the tile loop) when the images fit
                                      (width 128: the input layer + 4 hidden layers forward, 4 transposed images backward) and the batch has at least this many 64-sample wave
@@ -314,10 +331,10 @@ typedef struct NcaPlan {
     int32_t fwd_store_format;     /* NCA_STORE_* | flags of the last forward (0: no store)                              */
     int32_t fwd_launches;         /* fused launches of that forward (2: one per net, weight images resident in LDS)     */
     int32_t fwd_resident;         /* 1: resident weight images                                                          */
-    int32_t bwd_kernel_mode;      /* 1 recompute, 3 from a bf16 / f32 store, 4 = 3 + on-chip last layer, 5 from an fp8 store (nothing recomputed) */
+    int32_t bwd_kernel_mode;      /* 1 recompute, 3 from the f32 store, 5 from the bf16 mode's 8-bit staged store (nothing recomputed) */
     int32_t bwd_resident;
     int32_t bwd_launches_per_chunk; /* fused dgrad launches per ray chunk                                              */
-    int32_t bwd_onchip;           /* last hidden layer's weight gradient accumulated in the dgrad kernel                */
+    int32_t bwd_onchip;           /* always 0 (ABI <= 8: the retired bf16-staged backward's on-chip layer)              */
     int32_t stage_fp8;            /* that backward staged 8-bit blocks                                                  */
     int32_t wgrad_jobs, wgrad_splits, wgrad_splits_rebuild;
     int32_t chunks;               /* ray chunks of that backward                                                        */

@@ -15,13 +15,13 @@ LIB_PATH = os.environ.get("NERFCA_LIB") or os.path.join(_HERE, "lib", "libnerfca
 ENC_NONE, ENC_BANDS, ENC_FOURIER = 0, 1, 2
 ACT_SIGMOID, ACT_SOFTPLUS, ACT_CLAMP = 0, 1, 2
 PREC_F32, PREC_BF16 = 0, 1
-ABI_VERSION = 8
-OPT_ONCHIP_MIN_TILES = 0
-OPT_STAGE_FP8 = 1
+ABI_VERSION = 9
+OPT_STAGE_FP8 = 1          # (0 is reserved: the retired bf16-staged backward's on-chip threshold)
 OPT_RESIDENT_MIN_TILES = 2
 OPT_STAGE_FP8_MIN_TILES = 3
 OPT_WGRAD_REBUILD_WEIGHT_PCT = 4
-STORE_NONE, STORE_F32, STORE_BF16, STORE_FP8, STORE_KIND_MASK, STORE_SHARED_ENC = 0, 1, 2, 3, 15, 16
+STORE_NONE, STORE_F32, STORE_FP8, STORE_KIND_MASK, STORE_SHARED_ENC = 0, 1, 3, 15, 16       # (2 was the retired bf16-staged store)
+OPT_UNSET = -(1 << 63)     # NCA_OPT_UNSET: "use the process-wide value" in an NcaPlanOpts field
 K_PACK, K_FWD, K_BWD_DGRAD, K_BWD_WGRAD, K_BWD_REDUCE, K_LOSS, K_ADAM = 0, 1, 2, 3, 4, 5, 6
 KERNEL_KINDS = {"pack": K_PACK, "fwd": K_FWD, "bwd_dgrad": K_BWD_DGRAD, "bwd_wgrad": K_BWD_WGRAD, "bwd_reduce": K_BWD_REDUCE,
                 "loss": K_LOSS, "adam": K_ADAM}
@@ -34,13 +34,28 @@ class NcaNet(C.Structure):
                 ("L", C.c_int32), ("T", C.c_int32), ("P", C.c_int32), ("reserved", C.c_int32)]
 
 
+class NcaPlanOpts(C.Structure):
+    """Per-call planner options (NcaRays.plan_opts): a field other than OPT_UNSET replaces the process-wide tunable for that call."""
+    _fields_ = [("stage_fp8", C.c_int64), ("stage_fp8_min_tiles", C.c_int64), ("resident_min_tiles", C.c_int64), ("wgrad_rebuild_weight_pct", C.c_int64)]
+
+    def __init__(self, **kw):
+        super().__init__()
+        for n, _ in self._fields_:
+            setattr(self, n, OPT_UNSET)
+        for k, v in kw.items():
+            if k not in dict(self._fields_):
+                raise NcaError(f"unknown planner option {k!r}")
+            setattr(self, k, OPT_UNSET if v is None else int(v))
+
+
 class NcaRays(C.Structure):
     _fields_ = [("R", C.c_int64), ("S", C.c_int32), ("ray_is_f64", C.c_int32),
                 ("origins", C.c_void_p), ("dirs", C.c_void_p),
                 ("phase", C.c_void_p), ("phase_stride_r", C.c_int64), ("phase_stride_s", C.c_int64),
                 ("z", C.c_void_p), ("z_stride_r", C.c_int64),
                 ("dists", C.c_void_p), ("I0", C.c_void_p),
-                ("act", C.c_int32), ("single_field", C.c_int32), ("scale", C.c_float), ("store_format", C.c_int32)]
+                ("act", C.c_int32), ("single_field", C.c_int32), ("scale", C.c_float), ("store_format", C.c_int32),
+                ("plan_opts", C.c_void_p), ("plan_out", C.c_void_p)]          # host pointers: NcaPlanOpts* / NcaPlan* (or NULL)
 
 
 class NcaLoss(C.Structure):
@@ -97,7 +112,7 @@ SYMBOLS = {
     "nca_fine_depths_bwd_max": (C.c_int, [_I64, _I32, _P, _P, _P, _P, _P, _P]),
     "nca_fine_weight_max": (C.c_int, [_I64, _I32, _P, _P, _P, _P, _I64, _P]),
     "nca_fine_depths_given_max": (C.c_int, [_I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _P]),
-    "nca_prepare_batch": (C.c_int, [_I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "nca_prepare_batch": (C.c_int, [_I64, _I32, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "nca_adam_step": (C.c_int, [C.POINTER(NcaAdam), _I32, C.POINTER(_I64), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P),
                                 _P, _P]),
     "nca_get_option": (C.c_int, [_I32, C.POINTER(_I64)]),
@@ -164,11 +179,16 @@ def set_option(opt: int, value: int) -> None:
     check(lib().nca_set_option(opt, int(value)))
 
 
+def plan_dict(p: "NcaPlan") -> dict:
+    return {n: int(getattr(p, n)) for n, _ in NcaPlan._fields_ if n != "reserved"}
+
+
 def last_plan() -> dict:
-    """What the planner decided in this thread's last nca_render_fwd / nca_render_bwd (see NcaPlan in include/nerfca_hip.h)."""
+    """What the planner decided in the PROCESS's last nca_render_fwd / nca_render_bwd (see NcaPlan in include/nerfca_hip.h).  A caller
+    that shares the process with others reads its own record instead: NcaRays.plan_out (fused.PlanScope / CompositeTrainer.plan)."""
     p = NcaPlan()
     check(lib().nca_last_plan(C.byref(p)))
-    return {n: int(getattr(p, n)) for n, _ in NcaPlan._fields_ if n != "reserved"}
+    return plan_dict(p)
 
 
 def build_info() -> str:

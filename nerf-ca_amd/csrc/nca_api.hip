@@ -129,10 +129,7 @@ bool g_opt_init = false;
 void opt_init_locked() {
     if (g_opt_init) return;
     for (int i = 0; i < NCA_OPT_COUNT; ++i) g_opt[i] = OPT_AUTO;
-    const char* e = getenv("NCA_ONCHIP");
-    if (e && e[0] == '0') g_opt[NCA_OPT_ONCHIP_MIN_TILES] = -1;
-    else if (e && e[0] == 'f') g_opt[NCA_OPT_ONCHIP_MIN_TILES] = 0;
-    e = getenv("NCA_RESIDENT");
+    const char* e = getenv("NCA_RESIDENT");
     if (e && e[0] == '0') g_opt[NCA_OPT_RESIDENT_MIN_TILES] = -1;
     else if (e && e[0] == 'f') g_opt[NCA_OPT_RESIDENT_MIN_TILES] = 0;
     e = getenv("NCA_STAGE_FP8");
@@ -143,41 +140,66 @@ void opt_init_locked() {
 }
 // default of NCA_OPT_STAGE_FP8_MIN_TILES: see stage_fp8_for()
 constexpr int64_t STAGE_FP8_DEFAULT_MIN_TILES = 0;
+// per-call options of the entry point this thread is in (NcaRays.plan_opts; CallOpts below sets and clears it)
+thread_local const NcaPlanOpts* t_call_opts = nullptr;
 int64_t opt_value(int opt) {
+    if (t_call_opts) {
+        const int64_t c = opt == NCA_OPT_STAGE_FP8 ? t_call_opts->stage_fp8 : opt == NCA_OPT_STAGE_FP8_MIN_TILES ? t_call_opts->stage_fp8_min_tiles
+                        : opt == NCA_OPT_RESIDENT_MIN_TILES ? t_call_opts->resident_min_tiles : opt == NCA_OPT_WGRAD_REBUILD_WEIGHT_PCT ? t_call_opts->wgrad_rebuild_weight_pct : NCA_OPT_UNSET;
+        if (c != NCA_OPT_UNSET) return c;
+    }
     std::lock_guard<std::mutex> lk(g_omu);
     opt_init_locked();
     int64_t v = g_opt[opt];
     if (v == OPT_AUTO) {
-        // on-chip dW pays only when every workgroup sees enough tiles to amortise the per-net launches and the exchange: at the
-        // reference's default batch of 1024 rays x 500 samples -- 4 tile groups per workgroup -- it costs 3.6 %
-        if (opt == NCA_OPT_ONCHIP_MIN_TILES) v = (int64_t)8 * NCA_WAVES * num_cus();
-        if (opt == NCA_OPT_STAGE_FP8) v = -1;                                            // auto: by batch size
+        if (opt == NCA_OPT_STAGE_FP8) v = -1;                                            // by batch size (threshold 0: always)
         if (opt == NCA_OPT_STAGE_FP8_MIN_TILES) v = STAGE_FP8_DEFAULT_MIN_TILES;
         if (opt == NCA_OPT_WGRAD_REBUILD_WEIGHT_PCT) v = 115;
         if (opt == NCA_OPT_RESIDENT_MIN_TILES) v = (int64_t)8 * NCA_WAVES * num_cus();    // (at 4 tiles per wave -- the reference's 1 024 x 500 batch -- resident and streaming tie)
     }
     return v;
 }
+struct CallOpts {          // RAII: the per-call options apply while an entry point that takes NcaRays runs on this thread
+    explicit CallOpts(const NcaRays* r) { t_call_opts = r ? r->plan_opts : nullptr; }
+    ~CallOpts() { t_call_opts = nullptr; }
+};
+int check_plan_opts(const NcaPlanOpts* o);
 }  // namespace
-// fp8 staging for a batch of this many wave tiles?  (decided by the storing forward; the backward follows the store's format)
+// A forward store (8-bit staging) for a bf16 batch of this many wave tiles?  Otherwise the bf16 forward writes no store and the backward
+// recomputes the layers -- bf16 operands everywhere, nothing in 8 bits.  (Decided by nca_render_store_bytes / the storing forward; the
+// backward follows what the forward reported.)
 static bool stage_fp8_for(int64_t wave_tiles) {
     const int64_t v = opt_value(NCA_OPT_STAGE_FP8);
     if (v >= 0) return v != 0;
     return wave_tiles >= opt_value(NCA_OPT_STAGE_FP8_MIN_TILES);
 }
 extern "C" int nca_get_option(int32_t opt, int64_t* value) {
-    if (opt < 0 || opt >= NCA_OPT_COUNT) return fail(NCA_E_INVALID, "option %d out of range", opt);
+    if (opt < 0 || opt >= NCA_OPT_COUNT || opt == NCA_OPT_RESERVED0) return fail(NCA_E_INVALID, "option %d out of range", opt);
     if (!value) return fail(NCA_E_INVALID, "value is NULL");
     *value = opt_value(opt);
     return NCA_OK;
 }
-extern "C" int nca_set_option(int32_t opt, int64_t value) {
-    if (opt < 0 || opt >= NCA_OPT_COUNT) return fail(NCA_E_INVALID, "option %d out of range", opt);
-    if (opt == NCA_OPT_ONCHIP_MIN_TILES && value < -1) return fail(NCA_E_INVALID, "NCA_OPT_ONCHIP_MIN_TILES takes -1 (never), 0 (always) or a tile count");
+static int check_option_value(int32_t opt, int64_t value) {
+    if (opt < 0 || opt >= NCA_OPT_COUNT || opt == NCA_OPT_RESERVED0) return fail(NCA_E_INVALID, "option %d out of range", opt);
     if (opt == NCA_OPT_RESIDENT_MIN_TILES && value < -1) return fail(NCA_E_INVALID, "NCA_OPT_RESIDENT_MIN_TILES takes -1 (never), 0 (always) or a tile count");
-    if (opt == NCA_OPT_STAGE_FP8 && value != 0 && value != 1 && value != -1) return fail(NCA_E_INVALID, "NCA_OPT_STAGE_FP8 takes 0 (never), 1 (always) or -1 (auto)");
+    if (opt == NCA_OPT_STAGE_FP8 && value != 0 && value != 1 && value != -1) return fail(NCA_E_INVALID, "NCA_OPT_STAGE_FP8 takes 0 (no forward store), 1 (always) or -1 (by batch size)");
     if (opt == NCA_OPT_STAGE_FP8_MIN_TILES && value < 0) return fail(NCA_E_INVALID, "NCA_OPT_STAGE_FP8_MIN_TILES takes a tile count >= 0");
     if (opt == NCA_OPT_WGRAD_REBUILD_WEIGHT_PCT && (value < 100 || value > 200)) return fail(NCA_E_INVALID, "NCA_OPT_WGRAD_REBUILD_WEIGHT_PCT takes 100 .. 200");
+    return NCA_OK;
+}
+namespace {
+int check_plan_opts(const NcaPlanOpts* o) {
+    if (!o) return NCA_OK;
+    const int64_t v[4] = {o->stage_fp8, o->stage_fp8_min_tiles, o->resident_min_tiles, o->wgrad_rebuild_weight_pct};
+    const int32_t k[4] = {NCA_OPT_STAGE_FP8, NCA_OPT_STAGE_FP8_MIN_TILES, NCA_OPT_RESIDENT_MIN_TILES, NCA_OPT_WGRAD_REBUILD_WEIGHT_PCT};
+    for (int i = 0; i < 4; ++i)
+        if (v[i] != NCA_OPT_UNSET) { int rc = check_option_value(k[i], v[i]); if (rc) return rc; }
+    return NCA_OK;
+}
+}  // namespace
+extern "C" int nca_set_option(int32_t opt, int64_t value) {
+    int rc = check_option_value(opt, value);
+    if (rc) return rc;
     std::lock_guard<std::mutex> lk(g_omu);
     opt_init_locked();
     g_opt[opt] = value;
@@ -189,16 +211,21 @@ extern "C" const char* nca_last_error(void) { return g_err; }
 // replaced by every nca_render_fwd, the backward half by every backward; each call fills a local copy and publishes it whole.
 static NcaPlan g_plan_shared;
 static std::mutex g_pmu;
-static void publish_plan(const NcaPlan& pl, bool fwd) {
-    std::lock_guard<std::mutex> lk(g_pmu);
+static void merge_plan(NcaPlan& dst, const NcaPlan& pl, bool fwd) {
     if (fwd) {
-        g_plan_shared.fwd_store_format = pl.fwd_store_format; g_plan_shared.fwd_launches = pl.fwd_launches; g_plan_shared.fwd_resident = pl.fwd_resident;
+        dst.fwd_store_format = pl.fwd_store_format; dst.fwd_launches = pl.fwd_launches; dst.fwd_resident = pl.fwd_resident;
     } else {
-        const NcaPlan keep = g_plan_shared;
-        g_plan_shared = pl;
-        g_plan_shared.fwd_store_format = keep.fwd_store_format; g_plan_shared.fwd_launches = keep.fwd_launches; g_plan_shared.fwd_resident = keep.fwd_resident;
+        const NcaPlan keep = dst;
+        dst = pl;
+        dst.fwd_store_format = keep.fwd_store_format; dst.fwd_launches = keep.fwd_launches; dst.fwd_resident = keep.fwd_resident;
     }
-    g_plan_shared.wave_tiles = pl.wave_tiles;
+    dst.wave_tiles = pl.wave_tiles;
+}
+// `mine`: the caller's own record (NcaRays.plan_out) or null
+static void publish_plan(const NcaPlan& pl, bool fwd, NcaPlan* mine = nullptr) {
+    if (mine) merge_plan(*mine, pl, fwd);
+    std::lock_guard<std::mutex> lk(g_pmu);
+    merge_plan(g_plan_shared, pl, fwd);
 }
 extern "C" int nca_last_plan(NcaPlan* out) {
     if (!out) return fail(NCA_E_INVALID, "out is NULL");
@@ -301,17 +328,16 @@ static int add_stage(NcaFusedArgs* a, const void* base, uint32_t off, uint32_t b
     return NCA_OK;
 }
 
-// stored: 0 = all forward images (+ dgrad images when bwd); 1 = backward from a store that holds everything (f32: dgrad
-// images only); 2 = backward from a store without the last layer's output (bf16: the last forward image, then dgrad images)
-static int build_stages(NcaFusedArgs* a, const NetBind* binds, bool bwd, int stored = 0, bool c8 = false) {
+// stored: 0 = all forward images (+ dgrad images when bwd); 1 = backward from a store (it holds everything the backward needs:
+// dgrad images only)
+static int build_stages(NcaFusedArgs* a, const NetBind* binds, bool bwd, int stored = 0) {
     a->nstages = 0;
     a->res_total = 0;
     a->res_bytes = 0;
     for (int n = 0; n < a->nnets; ++n) {
         const NcaLayout& y = a->net[n].lay;
-        for (int j = stored == 2 ? y.NL - 1 : 0; stored != 1 && j < y.NL; ++j) {
-            const bool i8 = NCA_CHAIN8 && c8 && y.layer[j].img8_bytes;          // (experiment: the e4m3 image of a hidden-width layer)
-            int rc = add_stage(a, binds[n].packed, i8 ? y.layer[j].img8_off : y.layer[j].img_off, i8 ? y.layer[j].img8_bytes : y.layer[j].img_bytes);
+        for (int j = 0; stored != 1 && j < y.NL; ++j) {
+            int rc = add_stage(a, binds[n].packed, y.layer[j].img_off, y.layer[j].img_bytes);
             if (rc) return rc;
             if (y.layer[j].img2_bytes) {            // second stage of a skip layer
                 rc = add_stage(a, binds[n].packed, y.layer[j].img2_off, y.layer[j].img2_bytes);
@@ -359,7 +385,7 @@ static int check_rays(const NcaRays* r) {
     if (r->R <= 0 || r->S <= 0) return fail(NCA_E_INVALID, "empty ray batch (R=%lld, S=%d)", (long long)r->R, r->S);
     if (!r->origins || !r->dirs || !r->z || !r->dists || !r->I0) return fail(NCA_E_INVALID, "a ray input pointer is NULL");
     if (r->act < 0 || r->act > 2) return fail(NCA_E_INVALID, "unknown activation %d", r->act);
-    return NCA_OK;
+    return check_plan_opts(r->plan_opts);
 }
 
 static inline int tile_samples(int32_t prec) { return prec == NCA_PREC_BF16 ? 64 : 32; }
@@ -386,12 +412,11 @@ static void rays_to_args(const NcaRays* r, NcaFusedArgs* a, int32_t prec) {
 extern "C" int nca_composite_fwd(int64_t, int32_t, int32_t, int32_t, float, const float*, const float*, const float*, const double*, double*, float*, float*, void*);
 extern "C" int nca_composite_bwd(int64_t, int32_t, int32_t, int32_t, float, const float*, const float*, const double*, const double*, const float*, const float*, float*, float*, void*);
 // The store a forward can leave behind for its backward (so that the backward does not recompute the layers):
-//   H region  [32-sample tile][net][input block | layer outputs]         the inputs of all NL layers -- bf16 with bf16 staging (the
-//                                                                          backward recomputes the last layer), e4m3 with fp8 staging
-//                                                                          (nca_layout.hpp); f32: + the last output
-//   masks     [wave tile][2][mask layers][1 KiB | 512 B]                  ReLU bit masks: of the hidden layers' inputs (NL - 1), of every
-//                                                                          layer with fp8 staging (NL: the backward recomputes nothing)
-//   raw       [wave tile][2][64 | 32] f32                                 raw net outputs (bf16 with fp8 staging; f32)
+//   H region  [32-sample tile][net][input block | layer outputs]         bf16 mode: the input block and the outputs of layers 0 .. NL-2 as
+//                                                                          e4m3 (nca_layout.hpp); f32: the inputs of all NL layers + the last output
+//   masks     [wave tile][2][mask layers][1 KiB | 512 B]                  ReLU bit masks: bf16 mode of every layer (NL: the backward recomputes
+//                                                                          nothing), f32 of the hidden layers' inputs (NL - 1)
+//   raw       [wave tile][2][64 | 32] f32                                 raw net outputs
 // The tile count is rounded up to the 8 waves of a workgroup (bf16): slack slots for the waves of the last group.
 // bf16, static + dynamic net of one width with the same encoding (mode, bands, the SAME window / coefficient vectors):
 // the dynamic net's input block is a superset of the static one's and is stored once
@@ -409,10 +434,10 @@ struct StorePlan {
     int32_t mask_layers;
 };
 // wave_tiles: 64-sample tiles (bf16) / 32-sample tiles (f32)
-// h8: bf16 path, the hidden blocks 0..NL-3 are e4m3 (fp8 staging)
-static bool store_plan(const NcaLayout* lays, int nnets, int32_t prec, int64_t wave_tiles, StorePlan* sp, bool share_enc = false, bool h8 = false) {
+static bool store_plan(const NcaLayout* lays, int nnets, int32_t prec, int64_t wave_tiles, StorePlan* sp, bool share_enc = false) {
     if (nnets == 2 && lays[0].F != lays[1].F) return false;
     const bool bf = prec == NCA_PREC_BF16;
+    const bool h8 = bf;          // the bf16 mode's store is the 8-bit one
     const int64_t EB = nca_bf_ebytes(bf && h8);
     // bf16: slack tile slots up to the next multiple of the 8 waves of a workgroup -- a wave without a tile writes there, so
     // that the storing forward's hot loops need no store predicate
@@ -445,6 +470,7 @@ static bool store_plan(const NcaLayout* lays, int nnets, int32_t prec, int64_t w
 }
 
 extern "C" int64_t nca_render_store_bytes(const NcaRays* rays, const NcaNet* net_s, const NcaNet* net_d, int32_t prec) {
+    CallOpts co(rays);
     int rc = check_rays(rays);
     if (rc) return rc;
     rc = check_prec(prec);
@@ -456,11 +482,10 @@ extern "C" int64_t nca_render_store_bytes(const NcaRays* rays, const NcaNet* net
     if (nn == 2) { rc = layout_of(net_d, &lays[1], prec); if (rc) return rc; }
     StorePlan sp;
     const int ts = tile_samples(prec);
-    // (sized for the larger of the two staging layouts: a store may be allocated before NCA_OPT_STAGE_FP8 is settled)
-    if (!store_plan(lays, nn, prec, rays->R * ((rays->S + ts - 1) / ts), &sp)) return 0;
-    int64_t bytes = sp.bytes;
-    if (prec == NCA_PREC_BF16 && store_plan(lays, nn, prec, rays->R * ((rays->S + ts - 1) / ts), &sp, false, true) && sp.bytes > bytes) bytes = sp.bytes;
-    return bytes;
+    const int64_t wave_tiles = rays->R * ((rays->S + ts - 1) / ts);
+    if (prec == NCA_PREC_BF16 && !stage_fp8_for(wave_tiles)) return 0;          // NCA_OPT_STAGE_FP8 says: no store, the backward recomputes
+    if (!store_plan(lays, nn, prec, wave_tiles, &sp)) return 0;
+    return sp.bytes;          // (the layout with one input block per net: a shared one needs less)
 }
 
 extern "C" int64_t nca_render_fwd_workspace(const NcaRays* rays) {
@@ -475,6 +500,7 @@ extern "C" int nca_render_fwd(const NcaRays* rays, int32_t prec,
                               const float* latents_d,
                               double* pix, float* sig_s, float* sig_d, void* work, int64_t work_bytes,
                               void* store, int64_t store_bytes, void* stream) {
+    CallOpts co(rays);
     int rc = check_rays(rays);
     if (rc) return rc;
     rc = check_prec(prec);
@@ -507,7 +533,7 @@ extern "C" int nca_render_fwd(const NcaRays* rays, int32_t prec,
     if (a.nnets == 2 && a.net[0].lay.F != a.net[1].lay.F) {
         if (store) return fail(NCA_E_UNSUPPORTED, "a forward store needs nets of one width");
         g_plan.fwd_launches = 2;
-        publish_plan(g_plan, true);
+        publish_plan(g_plan, true, rays->plan_out);
         // nets of different width: one fused launch per net writes the raw field into its sigma buffer,
         // then the stand-alone compositing kernel turns both into sigmas + pix in place
         float* outs[2] = {sig_s, sig_d};
@@ -535,13 +561,15 @@ extern "C" int nca_render_fwd(const NcaRays* rays, int32_t prec,
     a.sig_d = sig_d;
     int kmode = NCA_KM_FWD;
     int store_format = NCA_STORE_NONE;
+    // bf16 with NCA_OPT_STAGE_FP8 saying "no store" for this batch: the buffer is left untouched and the return value says so (0)
+    if (store && prec == NCA_PREC_BF16 && !stage_fp8_for(a.ntiles)) store = nullptr;
     if (store) {
         NcaLayout lays[2] = {a.net[0].lay, a.net[1].lay};
         StorePlan spl;
         a.share_enc = can_share_enc(a, prec) ? 1 : 0;
-        a.h8 = (prec == NCA_PREC_BF16 && stage_fp8_for(a.ntiles)) ? 1 : 0;
-        store_format = (prec == NCA_PREC_BF16 ? (a.h8 ? NCA_STORE_FP8 : NCA_STORE_BF16) : NCA_STORE_F32) | (a.share_enc ? NCA_STORE_SHARED_ENC : 0);
-        if (!store_plan(lays, a.nnets, prec, a.ntiles, &spl, a.share_enc != 0, a.h8 != 0))
+        a.h8 = prec == NCA_PREC_BF16 ? 1 : 0;
+        store_format = (prec == NCA_PREC_BF16 ? NCA_STORE_FP8 : NCA_STORE_F32) | (a.share_enc ? NCA_STORE_SHARED_ENC : 0);
+        if (!store_plan(lays, a.nnets, prec, a.ntiles, &spl, a.share_enc != 0))
             return fail(NCA_E_UNSUPPORTED, "a forward store needs nets of one width with at least one hidden layer");
         if (store_bytes < spl.bytes) return fail(NCA_E_WORKSPACE, "forward store %lld < %lld bytes", (long long)store_bytes, (long long)spl.bytes);
         kmode = NCA_KM_FWD_STORE;
@@ -566,13 +594,9 @@ extern "C" int nca_render_fwd(const NcaRays* rays, int32_t prec,
             one[n].net_base = n;
             one[n].split = n + 1;
             NetBind b1[2] = {binds[n], {}};
-            rc = build_stages(&one[n], b1, false, 0, NCA_CHAIN8 && kmode == NCA_KM_FWD_STORE && a.h8 && one[n].net[0].lay.F == 128);
+            rc = build_stages(&one[n], b1, false);
             if (rc) return rc;
             ok = plan_resident(&one[n], kmode);
-            if (NCA_CHAIN8 && !ok && kmode == NCA_KM_FWD_STORE && a.h8 && one[n].net[0].lay.F == 128) {       // (the e4m3 images exist for the resident launch only)
-                rc = build_stages(&one[n], b1, false);
-                if (rc) return rc;
-            }
         }
         if (ok) {
             for (int n = 0; n < 2; ++n) {
@@ -594,7 +618,7 @@ extern "C" int nca_render_fwd(const NcaRays* rays, int32_t prec,
     }
     HIPCHK(nca_launch_pix_f32(rays->R, a.nchunk, rays->I0, a.part, pix, st));
     g_plan.fwd_store_format = store_format;
-    publish_plan(g_plan, true);
+    publish_plan(g_plan, true, rays->plan_out);
     return store_format;
 }
 
@@ -608,15 +632,14 @@ struct BwdPlan {
     int64_t units_per_chunk;
     int64_t tiles_per_unit;    // wave tiles (32 samples f32 / 64 samples bf16) per unit
     int64_t bytes_total;
-    int64_t off_slab, off_oslab, off_wslab, off_scratch;
-    int64_t wslab_stride;
+    int64_t off_slab, off_oslab, off_scratch;
 };
 
 static int64_t scratch_rows(const NcaLayout& y) { return y.K0rows_pad + (int64_t)(y.NL - 1) * y.F + (int64_t)y.NL * y.F; }
 
 // d8: bf16 backward from a store with fp8 staging (D_0..D_{NL-2} as e5m2 + one inverse-scale record per tile)
 static int plan_bwd(const NcaLayout* lays, int nnets, int32_t prec, int64_t units, int64_t tiles_per_unit, int64_t budget, BwdPlan* p,
-                    bool stored = false, bool onchip = false, bool d8 = false, bool nr = false) {
+                    bool stored = false, bool d8 = false, bool nr = false) {
     const bool bf = prec == NCA_PREC_BF16;
     p->tile_stride = 0;
     p->slab_stride = 0;
@@ -626,7 +649,6 @@ static int plan_bwd(const NcaLayout* lays, int nnets, int32_t prec, int64_t unit
         else p->tile_stride += bf ? nca_bf_tile_bytes(lays[n]) : scratch_rows(lays[n]);
         p->slab_stride += lays[n].n_params;
         for (int j = 0; j < lays[n].NL; ++j) p->njobs += lays[n].layer[j].kind == NCA_IN_SKIP ? 2 : 1;
-        if (onchip) p->njobs -= 1;                    // the last hidden layer's weight gradient stays in the dgrad kernel
     }
     if (stored && bf && (d8 || nr)) p->tile_stride += NCA_D8_REC_BYTES;
     for (int n = 0; n < nnets; ++n) p->slab_stride += (int64_t)lays[n].F * lays[n].P;
@@ -655,11 +677,9 @@ static int plan_bwd(const NcaLayout* lays, int nnets, int32_t prec, int64_t unit
     }
     const int64_t slab_bytes = align_up((int64_t)nsplit_x * p->slab_stride * 4, 256);
     const int64_t oslab_bytes = align_up((int64_t)cus * 2 * (F + 1) * 4, 256);
-    p->wslab_stride = (int64_t)F * F + F;                                               // on-chip layer: dW and db per workgroup
-    const int64_t wslab_bytes = bf ? align_up((int64_t)cus * 2 * p->wslab_stride * 4, 256) : 0;
     // bf16 backward from a store: slack tile slots behind the D region, for the waves of the last group that have no tile
     const int64_t dslack = (bf && stored) ? (int64_t)(NCA_WAVES - 1) * 2 * p->tile_stride : 0;
-    const int64_t fixed = slab_bytes + oslab_bytes + wslab_bytes + align_up(dslack, 256);
+    const int64_t fixed = slab_bytes + oslab_bytes + align_up(dslack, 256);
     // scratch bytes per unit: f32 rows*32 floats per 32-sample tile; bf16 two 32-sample tiles per wave tile
     const int64_t per_unit = bf ? p->tile_stride * 2 * tiles_per_unit : p->tile_stride * tiles_per_unit * 32 * 4;
     int64_t upc = units;
@@ -682,8 +702,7 @@ static int plan_bwd(const NcaLayout* lays, int nnets, int32_t prec, int64_t unit
     p->grid = (int)(ngroups < cus ? ngroups : cus);
     p->off_slab = 0;
     p->off_oslab = slab_bytes;
-    p->off_wslab = slab_bytes + oslab_bytes;
-    p->off_scratch = slab_bytes + oslab_bytes + wslab_bytes;
+    p->off_scratch = slab_bytes + oslab_bytes;
     p->bytes_total = fixed + align_up(per_unit * upc, 256);
     return NCA_OK;
 }
@@ -761,11 +780,9 @@ static void make_job_bf16(NcaWgradJob& g, const NcaLayout& y, int j, int64_t net
         g.P = 0;
     }
 }
-// skip_layer: accumulated on chip by the dgrad kernel
 static void add_jobs_bf16(NcaWgradArgs* w, int net_index, const NcaLayout& y, int64_t net_off, int64_t d_off, int64_t slab_off, int64_t onehot_off, int64_t enc_off,
-                          int skip_layer, bool h8, bool d8, int64_t dscale_off, int expand_layer = -1, int mask_layers = 0) {
+                          bool h8, bool d8, int64_t dscale_off, int expand_layer = -1, int mask_layers = 0) {
     for (int j = 0; j < y.NL; ++j) {
-        if (j == skip_layer) continue;
         NcaWgradJob& g = w->job[w->njobs++];
         make_job_bf16(g, y, j, net_off, d_off, slab_off, onehot_off, enc_off, h8, d8);
         g.net = net_index;
@@ -779,7 +796,7 @@ static void add_jobs_bf16(NcaWgradArgs* w, int net_index, const NcaLayout& y, in
 
 static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t units, int64_t tiles_per_unit, float* const* grads,
                    void* work, int64_t work_bytes, hipStream_t st, const void* store = nullptr, int64_t store_bytes = 0, float* g_depth = nullptr,
-                   int32_t store_format = NCA_STORE_NONE) {
+                   int32_t store_format = NCA_STORE_NONE, NcaPlan* plan_out = nullptr) {
     const bool bf = prec == NCA_PREC_BF16;
     NcaPlan g_plan;       // (published at the end; what the last forward decided stays on record)
     memset(&g_plan, 0, sizeof(g_plan));
@@ -800,34 +817,28 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     // The store's format is what the forward that wrote it reported (NcaRays.store_format), never this call's reading of the options
     if (stored) {
         const int kind = store_format & NCA_STORE_KIND_MASK;
-        const int want_a = bf ? NCA_STORE_BF16 : NCA_STORE_F32, want_b = bf ? NCA_STORE_FP8 : NCA_STORE_F32;
-        if ((store_format & ~(NCA_STORE_KIND_MASK | NCA_STORE_SHARED_ENC)) || (kind != want_a && kind != want_b))
-            return fail(NCA_E_INVALID, "rays->store_format = %d does not name a store of this precision: pass the value nca_render_fwd returned when it wrote the store", store_format);
+        const int want = bf ? NCA_STORE_FP8 : NCA_STORE_F32;
+        if ((store_format & ~(NCA_STORE_KIND_MASK | NCA_STORE_SHARED_ENC)) || kind != want)
+            return fail(NCA_E_INVALID, "rays->store_format = %d does not name a store of this precision: pass the value nca_render_fwd returned when it wrote the store "
+                                       "(0 = it wrote none: pass store = NULL)", store_format);
         const bool shared = (store_format & NCA_STORE_SHARED_ENC) != 0;
         if (shared != can_share_enc(a, prec))
             return fail(NCA_E_INVALID, "the store was written with %s input block, but the encoding vectors of this call say otherwise: pass the backward the SAME window / coefficient pointers as the forward",
                         shared ? "one shared" : "one per net");
     }
-    const bool h8 = bf && stored && (store_format & NCA_STORE_KIND_MASK) == NCA_STORE_FP8;
+    const bool h8 = bf && stored;          // the bf16 mode's store: layer inputs as e4m3, masks of every layer, raw outputs
     const bool d8 = h8 && !g_depth;
     a.h8 = h8 ? 1 : 0;
     if (stored) {
         a.share_enc = (store_format & NCA_STORE_SHARED_ENC) ? 1 : 0;
-        if (!store_plan(lays, a.nnets, prec, units * tiles_per_unit, &spl, a.share_enc != 0, h8)) return fail(NCA_E_UNSUPPORTED, "no forward store exists for this configuration");
+        if (!store_plan(lays, a.nnets, prec, units * tiles_per_unit, &spl, a.share_enc != 0)) return fail(NCA_E_UNSUPPORTED, "no forward store exists for this configuration");
         if (store_bytes < spl.bytes) return fail(NCA_E_WORKSPACE, "forward store %lld < %lld bytes", (long long)store_bytes, (long long)spl.bytes);
     }
-    // bf16 backward from a store: the weight gradient of the last hidden layer stays on chip (one launch per net)
-    const int64_t oc_min = opt_value(NCA_OPT_ONCHIP_MIN_TILES);          // -1: never (see nca_set_option)
-    // fp8 staging: the store holds every layer's output, masks and raw outputs -- mode 5, nothing recomputed (the on-chip layer
-    // recomputes from a bf16 block: bf16 staging only)
+    // the store holds every layer's output, masks and raw outputs -- mode 5, nothing recomputed
     const bool nr = h8;
-    const bool onchip = oc_min >= 0 && bf && stored && !nr && units * tiles_per_unit >= oc_min;
-    // EXPERIMENT (NCA_ONCHIP_NR, nca_kernels.hpp): fp8 staging with layer NL - 2's weight gradient on chip -- streamed weights, one launch per net
-    bool oc_nr = NCA_ONCHIP_NR && NCA_WAVES == 4 && nr && d8 && bf && stored && lays[0].F == 128 && !getenv("NCA_ONCHIP_NR_OFF");
-    for (int n = 0; n < a.nnets; ++n) oc_nr = oc_nr && lays[n].NL >= 3 && lays[n].F == 128;
-    // ... or, without the on-chip layer, one launch per net with that net's weight images resident in LDS
+    // one launch per net with that net's weight images resident in LDS
     const int64_t res_min = opt_value(NCA_OPT_RESIDENT_MIN_TILES);
-    bool res3 = !onchip && !oc_nr && bf && stored && res_min >= 0 && units * tiles_per_unit >= res_min;
+    bool res3 = bf && stored && res_min >= 0 && units * tiles_per_unit >= res_min;
     if (res3) {          // ... only if every net's images do fit (else: one launch for both nets, streaming)
         for (int n = 0; n < a.nnets && res3; ++n) {
             static thread_local NcaFusedArgs probe;
@@ -836,14 +847,14 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
             probe.net[0] = a.net[n];
             probe.ntiles = units * tiles_per_unit;
             NetBind b1[2] = {binds[n], {}};
-            int rcp = build_stages(&probe, b1, true, nr ? 1 : 2);
+            int rcp = build_stages(&probe, b1, true, 1);
             if (rcp) return rcp;
-            res3 = plan_resident(&probe, nr ? NCA_KM_BWD_NR : NCA_KM_BWD_STORED);
+            res3 = plan_resident(&probe, NCA_KM_BWD_NR);
         }
     }
-    const bool per_net_launch = onchip || res3 || oc_nr;
+    const bool per_net_launch = res3;
     BwdPlan p;
-    int rc = plan_bwd(lays, a.nnets, prec, units, tiles_per_unit, work_bytes, &p, stored, onchip || oc_nr, d8, nr);
+    int rc = plan_bwd(lays, a.nnets, prec, units, tiles_per_unit, work_bytes, &p, stored, d8, nr);
     if (rc) return rc;
     if (!work || work_bytes < p.bytes_total) return fail(NCA_E_WORKSPACE, "backward workspace %lld < %lld bytes", (long long)work_bytes, (long long)p.bytes_total);
     char* wb = static_cast<char*>(work);
@@ -851,7 +862,7 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     float* oslab = reinterpret_cast<float*>(wb + p.off_oslab);
     float* scratch = reinterpret_cast<float*>(wb + p.off_scratch);
 
-    rc = build_stages(&a, binds, true, stored ? ((bf && !nr) ? 2 : 1) : 0);
+    rc = build_stages(&a, binds, true, stored ? 1 : 0);
     if (rc) return rc;
     int64_t off = 0, soff = 0;
     for (int n = 0; n < a.nnets; ++n) { a.net[n].row0 = off; off += bf ? nca_bf_tile_bytes(lays[n]) : scratch_rows(lays[n]); }
@@ -887,7 +898,7 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     memset(&w, 0, sizeof(w));
     for (int n = 0; n < a.nnets; ++n) {
         if (bf) add_jobs_bf16(&w, n, lays[n], a.net[n].row0, a.net[n].drow0, slab_off[n], onehot_off[n],
-                              stored && a.share_enc && n == 0 ? a.net[1].row0 : a.net[n].row0, oc_nr ? lays[n].NL - 2 : (onchip ? lays[n].NL - 1 : -1), h8, d8,
+                              stored && a.share_enc && n == 0 ? a.net[1].row0 : a.net[n].row0, h8, d8,
                               p.tile_stride - NCA_D8_REC_BYTES, nr && d8 ? lays[n].NL - 1 : -1, spl.mask_layers);
         else add_jobs_f32(&w, lays[n], a.net[n].row0, a.net[n].drow0, slab_off[n], onehot_off[n]);
     }
@@ -921,8 +932,8 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     const int F = lays[0].F;
     const int wave_samples = tile_samples(prec);
 
-    g_plan.bwd_kernel_mode = stored ? (nr ? NCA_KM_BWD_NR : (onchip ? NCA_KM_BWD_ONCHIP : NCA_KM_BWD_STORED)) : NCA_KM_BWD;
-    g_plan.bwd_onchip = onchip ? 1 : 0;
+    g_plan.bwd_kernel_mode = stored ? (nr ? NCA_KM_BWD_NR : NCA_KM_BWD_STORED) : NCA_KM_BWD;
+    g_plan.bwd_onchip = 0;
     g_plan.stage_fp8 = h8 ? 1 : 0;
     g_plan.bwd_launches_per_chunk = (bf && stored && per_net_launch) ? a.nnets : 1;
     g_plan.wgrad_jobs = w.njobs;
@@ -944,12 +955,9 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
                 one.nnets = 1;
                 one.net[0] = a.net[n];
                 one.net_base = n;
-                one.onchip = oc_nr ? (getenv("NCA_ONCHIP_NR_DRY") ? 3 : 2) : (onchip ? 1 : 0);          // (3: the launch structure without the on-chip work -- timing only, that layer's gradient is then missing)
-                one.wslab = reinterpret_cast<float*>(wb + p.off_wslab) + (int64_t)n * num_cus() * p.wslab_stride;
-                one.wslab_stride = p.wslab_stride;
                 NetBind b1[2] = {binds[n], {}};
-                const int km = nr ? NCA_KM_BWD_NR : (onchip ? NCA_KM_BWD_ONCHIP : NCA_KM_BWD_STORED);
-                rc = build_stages(&one, b1, true, nr ? 1 : 2);
+                const int km = NCA_KM_BWD_NR;
+                rc = build_stages(&one, b1, true, 1);
                 if (rc) return rc;
                 if (res3) g_plan.bwd_resident = plan_resident(&one, km) ? 1 : 0;        // (does not fit: the streaming kernel, still one net per launch)
                 Span sp(NCA_K_BWD_DGRAD, st);
@@ -1029,24 +1037,18 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
         rn.tail_from_sums = nr ? 1 : 0;
         rn.tl_w_off = lays[n].layer[lays[n].NL - 1].w_off;
         rn.tl_b_off = lays[n].layer[lays[n].NL - 1].b_off;
-        if (onchip || oc_nr) {
-            const int ocl = oc_nr ? lays[n].NL - 2 : lays[n].NL - 1;
-            rn.wslab = reinterpret_cast<const float*>(wb + p.off_wslab) + (int64_t)n * num_cus() * p.wslab_stride;
-            rn.wslab_stride = p.wslab_stride;
-            rn.oc_w_off = lays[n].layer[ocl].w_off;
-            rn.oc_b_off = lays[n].layer[ocl].b_off;
-        }
     }
     {
         Span sp(NCA_K_BWD_REDUCE, st);
         HIPCHK(nca_launch_reduce_f32(r, st));
     }
     g_plan.chunks = chunk;
-    publish_plan(g_plan, false);
+    publish_plan(g_plan, false, plan_out);
     return NCA_OK;
 }
 
 extern "C" int64_t nca_render_bwd_workspace(const NcaRays* rays, const NcaNet* net_s, const NcaNet* net_d, int32_t prec, int64_t max_bytes) {
+    CallOpts co(rays);
     int rc = check_rays(rays);
     if (rc) return rc;
     rc = check_prec(prec);
@@ -1073,22 +1075,13 @@ extern "C" int64_t nca_render_bwd_workspace(const NcaRays* rays, const NcaNet* n
     rc = plan_bwd(lays, nn, prec, rays->R, (rays->S + ts - 1) / ts, max_bytes, &p);
     if (rc) return rc;
     int64_t need = p.bytes_total;
-    if (prec == NCA_PREC_BF16) {       // the on-chip variant of the backward from a store runs fewer jobs over more splits (more slabs)
-        rc = plan_bwd(lays, nn, prec, rays->R, (rays->S + ts - 1) / ts, max_bytes, &p, true, true);
+    if (prec == NCA_PREC_BF16) {       // from a store: a record per tile, e5m2 or (depth gradients) bf16 output-gradient blocks
+        rc = plan_bwd(lays, nn, prec, rays->R, (rays->S + ts - 1) / ts, max_bytes, &p, true, true, true);
         if (rc) return rc;
         if (p.bytes_total > need) need = p.bytes_total;
-        // ... and fp8 staging runs one more job per net (the output layer's) and keeps a record per tile
-        rc = plan_bwd(lays, nn, prec, rays->R, (rays->S + ts - 1) / ts, max_bytes, &p, true, false, true, true);
+        rc = plan_bwd(lays, nn, prec, rays->R, (rays->S + ts - 1) / ts, max_bytes, &p, true, false, true);
         if (rc) return rc;
         if (p.bytes_total > need) need = p.bytes_total;
-        rc = plan_bwd(lays, nn, prec, rays->R, (rays->S + ts - 1) / ts, max_bytes, &p, true, false, false, true);
-        if (rc) return rc;
-        if (p.bytes_total > need) need = p.bytes_total;
-        if (NCA_ONCHIP_NR) {       // (experiment: fp8 staging with one layer on chip)
-            rc = plan_bwd(lays, nn, prec, rays->R, (rays->S + ts - 1) / ts, max_bytes, &p, true, true, true, true);
-            if (rc) return rc;
-            if (p.bytes_total > need) need = p.bytes_total;
-        }
     }
     return need;
 }
@@ -1109,6 +1102,7 @@ extern "C" int nca_render_bwd_depth(const NcaRays* rays, int32_t prec,
                               const double* g_pix, const float* g_sig_s, const float* g_sig_d,
                               float* grads_s, float* grads_d, float* g_depth, void* work, int64_t work_bytes,
                               const void* store, int64_t store_bytes, void* stream) {
+    CallOpts co(rays);
     int rc = check_rays(rays);
     if (rc) return rc;
     rc = check_prec(prec);
@@ -1177,7 +1171,7 @@ extern "C" int nca_render_bwd_depth(const NcaRays* rays, int32_t prec,
     a.g_pix = g_pix;
     a.g_sig_s = g_sig_s;
     a.g_sig_d = g_sig_d;
-    return run_bwd(a, prec, binds, rays->R, a.nchunk, grads, work, work_bytes, st, store, store_bytes, g_depth, rays->store_format);
+    return run_bwd(a, prec, binds, rays->R, a.nchunk, grads, work, work_bytes, st, store, store_bytes, g_depth, rays->store_format, rays->plan_out);
 }
 
 // ---------------------------------------------------------------------------------- point path
@@ -1377,12 +1371,12 @@ extern "C" int nca_fine_depths_bwd_max(int64_t R, int32_t S, const float* sig_s,
 }
 
 // ---------------------------------------------------------------------------------- batch preparation
-extern "C" int nca_prepare_batch(int64_t R, int32_t S, const int64_t* ids, const double* table, const int64_t* phases,
+extern "C" int nca_prepare_batch(int64_t R, int32_t S, const int64_t* ids, const double* table, const int64_t* phases, int64_t n_rows, int32_t* bad_ids,
                                  const float* depth, const float* t_rand,
                                  double* o, double* d, double* gt, double* w, int32_t* ph, float* z, double* dists, void* stream) {
     if (R <= 0 || S <= 0) return fail(NCA_E_INVALID, "empty ray batch (R=%lld, S=%d)", (long long)R, S);
     if (!ids || !table || !phases || !depth || !t_rand || !o || !d || !gt || !w || !ph || !z || !dists) return fail(NCA_E_INVALID, "a pointer is NULL");
-    HIPCHK(nca_launch_prepare_batch(R, S, ids, table, phases, depth, t_rand, o, d, gt, w, ph, z, dists, (hipStream_t)stream));
+    HIPCHK(nca_launch_prepare_batch(R, S, ids, table, phases, n_rows, bad_ids, depth, t_rand, o, d, gt, w, ph, z, dists, (hipStream_t)stream));
     return NCA_OK;
 }
 

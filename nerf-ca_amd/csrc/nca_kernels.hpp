@@ -7,14 +7,6 @@
 #define NCA_WAVES 8     // waves per workgroup of the fused kernels: 2 per SIMD (tools/variant_build_all.sh w4 "-DNCA_WAVES=4": one per SIMD, for timing)
 #endif
 #define NCA_NT (64 * NCA_WAVES)
-// EXPERIMENT (off; tools/variant_build_all.sh oc "-DNCA_WAVES=4 -DNCA_ONCHIP_NR=1"): the backward from an fp8-staged store keeps the
-// weight gradient of ONE hidden layer (NL - 2) on chip -- four 512-register waves per workgroup, streamed weights: the layer's e5m2
-// output-gradient fragments go to an LDS tile instead of HBM, its e4m3 input fragments come HBM -> LDS, and after the layer's barrier
-// wave w contracts rows 32w .. 32w+31 of dW over the workgroup's four wave tiles (transposed 8-bit reads, MX MFMAs) into 64 + 16
-// accumulators that are written to the per-workgroup slab (NcaFusedArgs::wslab) at the end.  Prices one layer of DESIGN.md 7-1.
-#ifndef NCA_ONCHIP_NR
-#define NCA_ONCHIP_NR 0
-#endif
 #define NCA_LDS_BYTES 163840   // LDS of a gfx950 compute unit (one workgroup of the fused kernels owns it)
 
 enum { NCA_MODE_RAYS = 0, NCA_MODE_POINTS = 1 };
@@ -35,13 +27,13 @@ struct NcaNetArgs {
     const float* wo_src; // bf16 stored-forward backward: the [Wo | bo] tail of the packed last-layer image (global)
 };
 
-// kernel modes of nca_fused_bf16
+// kernel modes of the fused kernels
 enum { NCA_KM_FWD = 0,          // forward
        NCA_KM_BWD = 1,          // recompute + output-layer gradients + dgrad; H, D and the input block go to ONE scratch
        NCA_KM_FWD_STORE = 2,    // forward that also writes the input block, every layer input, ReLU masks and raw outputs
-       NCA_KM_BWD_STORED = 3,   // output-layer gradients + dgrad from that store (no recompute); D to the chunk scratch
-       NCA_KM_BWD_ONCHIP = 4,   // mode 3 for one net, with the last hidden layer's weight gradient accumulated on chip
-       NCA_KM_BWD_NR = 5 };     // bf16, from a store with fp8 staging: NO recompute -- raw outputs and ReLU masks of all layers come
+       NCA_KM_BWD_STORED = 3,   // f32: output-layer gradients + dgrad from that store (no recompute); D to the chunk scratch
+                                // (4 was the bf16-staged backward with one layer's weight gradient on chip: retired in round 4 with bf16 staging)
+       NCA_KM_BWD_NR = 5 };     // bf16, from its (8-bit staged) store: NO recompute -- raw outputs and ReLU masks of all layers come
                                 // from the store, D_{NL-1} = mask (Wo x g); the output layer's weight gradient is the wgrad kernel's
 
 struct NcaFusedArgs {
@@ -75,11 +67,6 @@ struct NcaFusedArgs {
     float* scratch;      // [tile][rows_total x 32 floats]: layer inputs H and output gradients D of each 32-sample tile
                          // (f32: input block row-major [row][32], hidden blocks [row tile][quad][lane][4]; bf16: see nca_bf_tile_bytes)
     int64_t rows_total;  // f32: scratch rows per 32-sample tile over all nets;  bf16: BYTES per 32-sample tile
-    int32_t onchip;      // bf16 backward from the store, one net per launch: the weight gradient of the last hidden layer is
-                         // accumulated in registers (8 waves share the F x F blocks, operand tiles exchanged through LDS)
-                         // and written to wslab at the end; its D block is not stored and the wgrad kernel skips that layer
-    float* wslab;        // [workgroup][F*F + F] f32: dW and db of that layer per workgroup (summed by the reduce kernel)
-    int64_t wslab_stride;
     int32_t net_base;    // a launch that carries ONE net of a two-net render (nnets == 1): its index (0 static, 1 dynamic) for
                          // the per-net upstream gradient, mask region and output-layer partial slot
     int32_t share_enc;   // bf16, two nets with the same encoding (mode, bands, the SAME window / coefficient vectors): net 0 (static)
@@ -153,9 +140,6 @@ struct NcaWgradArgs {
 struct NcaReduceNet {
     float* grads;
     const float* params;
-    const float* wslab;   // on-chip layer: per-workgroup [F*F + F] partials (or null)
-    int64_t wslab_stride;
-    int64_t oc_w_off, oc_b_off;   // natural offsets of that layer's W (F*F) and b (F)
     int64_t slab_off;     // where this net's natural block starts inside a slab
     int64_t onehot_off;
     int32_t F, T, P, K0, Kenc, w0_off;
@@ -212,7 +196,8 @@ struct NcaAdamArgs {
     int64_t* step;
 };
 hipError_t nca_launch_adam(const NcaAdamArgs& a, hipStream_t st);
-hipError_t nca_launch_prepare_batch(int64_t R, int S, const int64_t* ids, const double* table, const int64_t* phases, const float* depth, const float* t_rand,
+hipError_t nca_launch_prepare_batch(int64_t R, int S, const int64_t* ids, const double* table, const int64_t* phases, int64_t n_rows, int32_t* bad_ids,
+                                    const float* depth, const float* t_rand,
                                     double* o, double* d, double* gt, double* w, int32_t* ph, float* z, double* dists, hipStream_t st);
 struct NcaFineArgs {
     int64_t R;

@@ -17,15 +17,12 @@
 #include <type_traits>
 #include "nca_kernels.hpp"
 
-// Timing-only elimination builds (tools/elim_build.sh): -DNCA_EXP=<bits> removes a piece of work so that its cost shows as a
-// time difference; results are WRONG by construction.  1: no D stores (backward from the store), 2: no masking / 8-bit
-// conversion in the dgrad sweep, 4: no output-layer reduce-scatter, 8: no per-layer weight DMA and barrier, 16: no H stores
-// (storing forward), 32: no mask bits / 8-bit conversion in the forward, 64: no on-chip dW exchange, 128: no MFMAs in the dgrad sweep.
-#ifndef NCA_EXP
-#define NCA_EXP 0
-#endif
-int nca_kernels_exp_mask() { return NCA_EXP; }
-int nca_kernels_variant_mask();       // (defined at the end of this file: the A/B macros are declared where they are used)
+// This file holds ONLY the code that runs in the shipped library.  The timing-only elimination builds (NCA_EXP) and the measured-and-
+// switched-off variants of rounds 2 and 3 (NCA_BF_PIPE / NCA_BF_PIPE2, NCA_WGRAD_TR, NCA_ONCHIP_NR, NCA_CHAIN8, the s_setprio / lock /
+// split-pipeline experiments) live in the repository's history: tools/r03_experiments.sh checks the round-3 kernel sources out (git tag
+// r03-kernels) and builds any of them there; DESIGN.md 4.4 / 7 has their numbers.
+int nca_kernels_exp_mask() { return 0; }
+int nca_kernels_variant_mask() { return NCA_WAVES << 8; }       // (bits 0..3 named the round-3 A/B macros: all gone, all 0)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -161,8 +158,7 @@ __device__ __forceinline__ float bf_hi(unsigned w) { return __builtin_bit_cast(f
 __device__ __forceinline__ bf16x8 frag(u32x4 x) { return __builtin_bit_cast(bf16x8, x); }
 // scratch blocks are written once and read once by another kernel: stream them past the caches
 __device__ __forceinline__ void store_nt(char* p, u32x4 v) {
-    if (NCA_EXP & 256) *reinterpret_cast<u32x4*>(p) = v;           // (elimination build: plain write-back stores)
-    else __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
 }
 __device__ __forceinline__ u32x4 load_nt(const char* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)); }
 // ReLU as ONE integer max on the bit pattern (negative floats and -0 are negative integers): no canonicalising
@@ -198,42 +194,6 @@ __global__ void nca_pack_bf16(NcaLayout y, const float* __restrict__ prm, unsign
                     v = pack2(two[0], two[1]);
                 } else {
                     uint32_t q = (off - wbytes) / 4u;
-                    float f = 0.f;
-                    if (q < tail) {
-                        const int i = q % 16, m = (q / 16) % y.MT, h = q / (16 * y.MT);
-                        f = prm[l.b_off + 32 * m + nca_rho(i) + 4 * h];
-                    } else if (j == y.NL - 1) {
-                        q -= tail;
-                        if (q < tail) {
-                            const int i = q % 16, m = (q / 16) % y.MT, h = q / (16 * y.MT);
-                            f = prm[y.wo_off + 32 * m + nca_rho(i) + 4 * h];
-                        } else if (q == tail) {
-                            f = prm[y.bo_off];
-                        }
-                    }
-                    v = __builtin_bit_cast(unsigned, f);
-                }
-            }
-            if (NCA_CHAIN8 && l.img8_bytes && byte >= l.img8_off && byte < l.img8_off + l.img8_bytes) {
-                // e4m3 image: fragment (m, k8, half16) at ((m * 2 + k8) * 2 + half16) * 1 KiB, lane (r, h) 16 bytes: byte b = 16 half16 + e is
-                // W[32 m + r][feature of (row tile 2 k8 + half16, register e, lane half h)] x 2^NCA_W8_LOG2  (tools/fp8_chain_probe.hip)
-                const uint32_t wbytes = (uint32_t)y.MT * 4u * 1024u;
-                const uint32_t off = byte - l.img8_off;
-                if (off < wbytes) {
-                    float four[4];
-                    for (int e4 = 0; e4 < 4; ++e4) {
-                        const uint32_t bidx = off + e4;
-                        const int e = bidx % 16, lane = (bidx / 16) % 64, half16 = (bidx / 1024) % 2, k8 = (bidx / 2048) % 2, m = bidx / 4096;
-                        const int r = lane & 31, h = lane >> 5;
-                        // hidden layers: the previous layer's accumulator bytes; layer 0: the input block's bytes (fragment t = 2 k8 + half16
-                        // holds slots 32 t + 16 (e >> 3) + 8 h + (e & 7); padding and one-hot slots carry no weight)
-                        const int f = j == 0 ? nca_bf_slot_to_nat(y, 32 * (2 * k8 + half16) + 16 * (e >> 3) + 8 * h + (e & 7)) : 32 * (2 * k8 + half16) + 8 * (e >> 2) + 4 * h + (e & 3);
-                        four[e4] = (f >= 0 && (j != 0 || 32 * (2 * k8 + half16) + 16 * (e >> 3) + 8 * h + (e & 7) < NCA_BF_K0SLOTS)) ? prm[l.w_off + (32 * m + r) * l.K + f] : 0.f;
-                    }
-                    v = cvt4_e4m3(four[0], four[1], four[2], four[3], 1.f / (float)(1 << NCA_W8_LOG2));
-                } else {
-                    uint32_t q = (off - wbytes) / 4u;
-                    const uint32_t tail = 2u * (uint32_t)y.MT * 16u;
                     float f = 0.f;
                     if (q < tail) {
                         const int i = q % 16, m = (q / 16) % y.MT, h = q / (16 * y.MT);
@@ -311,7 +271,7 @@ struct BfCfg {
 #define NCA_CONST_NET_FLOATS (NCA_CONST_WIN + NCA_CONST_FOUR + NCA_CONST_LAT)
 // LDS constant area: encoding constants of both nets (modes that encode) or the waves' ReLU-mask slots (backward from a store)
 __host__ __device__ constexpr int bf_const_bytes(int kmode) {
-    return (kmode == NCA_KM_BWD_STORED || kmode == NCA_KM_BWD_ONCHIP || kmode == NCA_KM_BWD_NR) ? NCA_WAVES * 2048 : 2 * NCA_CONST_NET_FLOATS * 4;
+    return kmode == NCA_KM_BWD_NR ? NCA_WAVES * 2048 : 2 * NCA_CONST_NET_FLOATS * 4;
 }
 // mode 5: [Wo | bo] of both nets in accumulator order, f32, behind the output-layer partials
 __host__ __device__ constexpr int bf_wo_floats(int F) { return 2 * (F / 32) * 16 + 16; }
@@ -325,7 +285,6 @@ __device__ __forceinline__ void stage_issue_b(const NcaStage& st, char* dst, int
     }
 }
 __device__ __forceinline__ void stage_publish_b() {
-    if (NCA_EXP & 8) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 }
@@ -334,15 +293,10 @@ __device__ __forceinline__ void stage_publish_b() {
 // older) but not for those stores.  The raw barrier avoids the vmcnt(0) a __syncthreads() would add.
 template <int NST>
 __device__ __forceinline__ void stage_publish_counted(bool stores_issued) {
-    if (NCA_EXP & 8) return;
-    if (stores_issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NCA_EXP & 1024) ? NST + 14 : NST) : "memory");       // (1024: wait one stage later -- WRONG results, timing only)
+    if (stores_issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-#if NCA_EXP & 6144
-    // (elimination builds 2048 / 4096: waves 4-7 -- the SIMD partners of waves 0-3 -- start every stage 4 / 8 x 64 cycles late)
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_sleep((NCA_EXP & 4096) ? 8 : 4);
-#endif
 }
 
 // workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain the wave's global stores / loads
@@ -361,42 +315,11 @@ __device__ __forceinline__ void lds_barrier() {
 #define NCA_BF_PF 3
 #endif
 constexpr int NCA_BF_RING = 4;
-// Software pipelining of the row-tile loops (epilogue of row tile m - 1 behind the MFMAs of row tile m, in one basic block so that
-// the scheduler interleaves them).  Measured at the bench size: forward unchanged (it is bound by its stores: 2.0 ms per net with
-// the MFMAs removed, 2.6 with them), backward sweep 10 % SLOWER (32 more live registers -> spills).  Off.
-#ifndef NCA_BF_PIPE
-#define NCA_BF_PIPE 0
-#endif
-// Deferred epilogue (storing forward with e4m3 staging, every layer but the last hidden one): behind the MFMAs of row tile m only
-// the 16 conversions to bf16 run (into the next layer's operand slots, which they are headed for anyway: no extra registers); ReLU,
-// mask bits, the e4m3 conversion and the store of row tile m follow in six pieces behind the MFMA pairs of row tile m + 1, where
-// the same wave's matrix instructions are in flight (tools/valu_mfma_samewave.hip, tools/mfma_shape_power.hip: ~10 packed vector
-// instructions per MFMA pair hide almost completely when they are interleaved IN THE WAVE THAT ISSUES THE MFMAs).  The backward from an
-// e5m2-staged store does the same with its mask / conversion / store.  Measured at the bench size (tools/variant_build.sh p2
-// "-DNCA_BF_PIPE2=1", bit-identical results, 246 / 234 VGPRs and no vector spill): forward 4.63 -> 4.45 ms, backward 3.63 -> 3.57 ms
-// per step in the per-kernel table -- and the graph-replayed STEP 13.03 -> 12.99 ms: what the two kernels gain the weight gradient
-// behind them loses (4.46 -> 4.87 ms in one run).  Same instructions, same bytes: the step did not care how they overlap.  Off.
-#ifndef NCA_BF_PIPE2
-#define NCA_BF_PIPE2 0
-#endif
-
-// Two A/B experiments on how the two waves of a SIMD share it, both measured at the bench size and removed again (round 3):
-// s_setprio 1 around the 16 MFMAs of a row tile (so that they win the issue port against the partner's epilogue): forward 4.75 ->
-// 4.60 / 4.75 ms in two runs, backward 3.68 -> 3.64 / 3.67 -- inside the run-to-run spread; an advisory LDS lock per SIMD that lets
-// only one of the two waves be in its MFMA block at a time (forced anti-phase): forward 4.76 -> 8.16 ms, backward 3.68 -> 5.26 --
-// the blocks of the two waves overlap to the kernels' advantage as they are.
-// A third: the epilogue of one 32-sample column tile cut into eight pieces of five vector instructions, each placed behind one of the
-// eight MFMAs of the OTHER column tile (the two accumulators alternate between being produced and consumed: no extra registers, every
-// A fragment read from LDS twice; the ISA showed  M d v5 w M d v5 ...  as meant): forward 4.63 -> 4.64 ms, and 3.97 -> 3.97 ms with
-// the H stores compiled out.  Two instruction orders that differ this much and cost the same, and elimination builds whose savings ADD
-// (MFMAs 0.76 + stores 0.65 + mask / 8-bit conversion 0.35 + the rest 0.69 = the kernel's 2.45 ms, profiles/r02_elimination_builds.txt),
-// are what a power cap looks like: time = energy / cap, whatever overlaps.  What is left is fewer instructions and fewer bytes.
-// The per-wave timeline (NCA_EXP 8388608: s_memtime around the MFMA block and the epilogue of every row tile, profiles/r03_timeline.txt)
-// shows where a wave's cycles go: an undisturbed MFMA block of a hidden layer takes 650 - 750 cycles (16 MFMAs = 512), an undisturbed
-// epilogue 530 - 620 (80 vector instructions: 64 x 4.4 + 16 x 8.3 cycles of SIMD time), and on average each takes 1.5 - 2 x that because
-// the SIMD's other wave is executing one or the other -- two waves share a SIMD serially.
-// (profiles/r03_valu_mfma_samewave.txt has the issue costs of the epilogue's own instructions: the packed 16-bit ones and v_lshl_or
-// 4.4 cycles of SIMD time each also with two waves per SIMD, v_cvt_scalef32_pk_{fp8,bf8}_bf16 8.3)
+// How the two waves of a SIMD share it, and why the row-tile loops below are plain (MFMA block, then epilogue, one row tile at a
+// time): every re-ordering measured in rounds 2 and 3 -- software pipelining of the row tiles, the deferred epilogue in six pieces
+// behind the next row tile's MFMA pairs, s_setprio around the MFMAs, a forced anti-phase of the two waves, the epilogue of one column
+// tile behind the MFMAs of the other -- left the STEP where it was (the chip runs these kernels at its power cap; the
+// same instructions and bytes cost the same time in any order).  What is left is fewer instructions and fewer bytes.
 static_assert(NCA_BF_PF >= 1 && NCA_BF_PF < NCA_BF_RING, "prefetch distance must fit the ring");
 // RING registers, prefetch distance RING - 1 (the default ring of 4 for the MFMA-bound modes; the on-chip backward, which is
 // bound by its stores and short of registers, uses a ring of 2)
@@ -406,63 +329,9 @@ __device__ __forceinline__ void ring_prime(const char* imgl, u32x4 (&A)[RING]) {
     for (int g = 0; g < RING - 1; ++g)
         if (g < MTOT * NKS) A[g % RING] = *reinterpret_cast<const u32x4*>(imgl + g * 1024);
 }
-// NCA_CHAIN8: one row tile of a width-128 hidden layer on e4m3 operands -- two MX k-steps of 64 features; the A fragment is two 16-byte
-// reads of the e4m3 image ([row tile][k-step][16-byte half][lane][16 B]), the B fragment {bytes of row tile 2k, bytes of row tile 2k+1}
-// of the previous layer (tools/fp8_chain_probe.hip); weights x 2^NCA_W8_LOG2 and inputs x 2^NCA_H8_LOG2 go back through the e8m0 scales.
-__device__ __forceinline__ void mma_rowtile_c8(const char* imgl, int m, const u32x4 (&Q)[2][4], f32x16& acc0, f32x16& acc1) {
-    u32x4 a[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const u32x4*>(imgl + (m * 4 + i) * 1024);
-#pragma unroll
-    for (int k8 = 0; k8 < 2; ++k8) {
-        const i32x8 A8 = {(int)a[2 * k8][0], (int)a[2 * k8][1], (int)a[2 * k8][2], (int)a[2 * k8][3], (int)a[2 * k8 + 1][0], (int)a[2 * k8 + 1][1], (int)a[2 * k8 + 1][2], (int)a[2 * k8 + 1][3]};
-        const i32x8 B0 = {(int)Q[0][2 * k8][0], (int)Q[0][2 * k8][1], (int)Q[0][2 * k8][2], (int)Q[0][2 * k8][3], (int)Q[0][2 * k8 + 1][0], (int)Q[0][2 * k8 + 1][1], (int)Q[0][2 * k8 + 1][2], (int)Q[0][2 * k8 + 1][3]};
-        const i32x8 B1 = {(int)Q[1][2 * k8][0], (int)Q[1][2 * k8][1], (int)Q[1][2 * k8][2], (int)Q[1][2 * k8][3], (int)Q[1][2 * k8 + 1][0], (int)Q[1][2 * k8 + 1][1], (int)Q[1][2 * k8 + 1][2], (int)Q[1][2 * k8 + 1][3]};
-        acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A8, B0, acc0, 0, 0, 0, 127 - NCA_W8_LOG2, 0, 127 - NCA_H8_LOG2);
-        acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A8, B1, acc1, 0, 0, 0, 127 - NCA_W8_LOG2, 0, 127 - NCA_H8_LOG2);
-    }
-}
-// The same with a piece of vector-ALU work placed behind the two MFMAs of every k-step (NCA_BF_PIPE2: the deferred epilogue of the
-// previous row tile; `piece(ks)` must not touch acc0 / acc1).  Everything of a step stays in its step.
-template <int NKS, int MTOT, int NB, int RING, typename PIECE>
-__device__ __forceinline__ void mma_rowtile_ring_il(const char* imgl, int m, u32x4 (&A)[RING], const u32x4 (&B)[2][NB],
-                                                    f32x16& acc0, f32x16& acc1, PIECE&& piece) {
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-        const int g = m * NKS + ks, nx = g + RING - 1;
-        if (nx < MTOT * NKS) A[nx % RING] = *reinterpret_cast<const u32x4*>(imgl + nx * 1024);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(A[g % RING]), frag(B[0][ks]), acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(A[g % RING]), frag(B[1][ks]), acc1, 0, 0, 0);
-        piece(ks);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
 template <int NKS, int MTOT, int NB, int RING>
 __device__ __forceinline__ void mma_rowtile_ring(const char* imgl, int m, u32x4 (&A)[RING], const u32x4 (&B)[2][NB],
                                                  f32x16& acc0, f32x16& acc1) {
-    if constexpr ((NCA_EXP & 16777216) != 0) {
-        // (16777216: TIMING ONLY, results wrong -- the matrix work and LDS traffic an fp8 chain would have: per row tile (NKS + 3) / 4 MX
-        // k-steps of 64 features, each two 16-byte fragment reads and one v_mfma_scale_f32_32x32x64_f8f6f4 per column tile, on whatever the
-        // bf16 operand registers hold)
-        constexpr int NK8 = (NKS + 3) / 4;
-        i32x8 a8[2];
-        auto rd8 = [&](int k8) __attribute__((always_inline)) {
-            const u32x4 lo = *reinterpret_cast<const u32x4*>(imgl + ((m * NK8 + k8) * 2) * 1024), hi = *reinterpret_cast<const u32x4*>(imgl + ((m * NK8 + k8) * 2 + 1) * 1024);
-            return (i32x8){(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
-        };
-        a8[0] = rd8(0);
-#pragma unroll
-        for (int k8 = 0; k8 < NK8; ++k8) {
-            if (k8 + 1 < NK8) a8[(k8 + 1) & 1] = rd8(k8 + 1);
-            const u32x4 b0l = B[0][2 * k8], b0h = B[0][2 * k8 + 1], b1l = B[1][2 * k8], b1h = B[1][2 * k8 + 1];
-            const i32x8 b0 = {(int)b0l[0], (int)b0l[1], (int)b0l[2], (int)b0l[3], (int)b0h[0], (int)b0h[1], (int)b0h[2], (int)b0h[3]};
-            const i32x8 b1 = {(int)b1l[0], (int)b1l[1], (int)b1l[2], (int)b1l[3], (int)b1h[0], (int)b1h[1], (int)b1h[2], (int)b1h[3]};
-            acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[k8 & 1], b0, acc0, 0, 0, 0, 127, 0, 127);
-            acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[k8 & 1], b1, acc1, 0, 0, 0, 127, 0, 127);
-            __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x10 | 0x400);
-        }
-        return;
-    }
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
         const int g = m * NKS + ks, nx = g + RING - 1;
@@ -573,24 +442,24 @@ __device__ __forceinline__ void transpose_block8(const u32x4 (&X)[NX], int lc, i
 // per workgroup); the tile loop then has no weight DMA, no counted waits and no workgroup barrier -- the eight waves drift apart
 // and fill each other's epilogue and store slots.  The streaming variant double-buffers one image per stage behind a barrier.
 #ifndef NCA_BF_MINBLOCKS
-#define NCA_BF_MINBLOCKS 2     // (1 with NCA_WAVES=4: up to 512 registers per wave -- the NCA_ONCHIP_NR experiment)
+#define NCA_BF_MINBLOCKS 2     // (1 with NCA_WAVES=4: up to 512 registers per wave)
 #endif
 template <int F, int MODE, bool S8, bool RES>
 __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const NcaFusedArgs a) {
-    constexpr bool ONCHIP = MODE == NCA_KM_BWD_ONCHIP;                        // mode 3 + on-chip dW of the last hidden layer
     constexpr bool NR = MODE == NCA_KM_BWD_NR;                                // from a store with fp8 staging: nothing is recomputed
-    constexpr int RINGK = ONCHIP ? 2 : NCA_BF_RING;                           // A-fragment ring of the layer contractions
-    constexpr bool STORED = MODE == NCA_KM_BWD_STORED || ONCHIP || NR;
-    constexpr bool BWD = MODE == NCA_KM_BWD || STORED;                        // output-layer gradients + dgrad sweep
+    constexpr int RINGK = NCA_BF_RING;                                        // A-fragment ring of the layer contractions
+    static_assert(MODE == NCA_KM_FWD || MODE == NCA_KM_BWD || MODE == NCA_KM_FWD_STORE || NR, "bf16 modes: 0 forward, 1 recompute backward, 2 storing forward, 5 backward from the store");
+    static_assert(MODE != NCA_KM_FWD_STORE || S8, "the bf16 forward store is the 8-bit one (bf16 staging -- round-3 modes 3 / 4 -- was retired in round 4)");
+    constexpr bool BWD = MODE == NCA_KM_BWD || NR;                            // output-layer gradients + dgrad sweep
     constexpr bool STORE = MODE == NCA_KM_BWD || MODE == NCA_KM_FWD_STORE;    // writes the input block and the layer inputs
-    constexpr bool RECOMP = !STORED;                                          // runs the forward layers
+    constexpr bool RECOMP = !NR;                                              // runs the forward layers
     constexpr bool FSTORE = MODE == NCA_KM_FWD_STORE;
     constexpr int MT = BfCfg<F>::MT, KS = BfCfg<F>::KS, KS0 = BfCfg<F>::KS0, KSMAX = BfCfg<F>::KSMAX;
     constexpr int BUF = BfCfg<F>::BUF_BYTES;
     constexpr int HB = 32 * F * 2;                          // bytes of one hidden scratch block (32 samples x F)
     constexpr int EB = (FSTORE && S8) ? 32 * 128 : 32 * NCA_BF_ENCROWS * 2;      // bytes of the input block (fp8 staging: e4m3, nca_bf_ebytes)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    static_assert(!RES || MODE == NCA_KM_FWD || MODE == NCA_KM_FWD_STORE || MODE == NCA_KM_BWD_STORED || NR, "resident images: forward and backward from the store");
+    static_assert(!RES || MODE == NCA_KM_FWD || MODE == NCA_KM_FWD_STORE || NR, "resident images: forward and backward from the store");
     const int wbytes = RES ? a.res_bytes : 2 * BUF;             // weight images: all of them / the double buffer
     constexpr int CONSTB = bf_const_bytes(MODE);
     float* cst = reinterpret_cast<float*>(smem + wbytes);
@@ -598,14 +467,6 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
     // ReLU masks of the recomputed layers: [wave][layer][lane][16 B] (2 bits per packed bf16 pair)
     char* const maskbase = smem + wbytes + CONSTB + NCA_WAVES * 2 * (F + 1) * 4;
     float* const wo_lds = reinterpret_cast<float*>(maskbase);          // mode 5 (no other use of that area there)
-    // NCA_ONCHIP_NR (nca_kernels.hpp): D tiles [wave][column tile][row tile][1 KiB] | H tiles (same) | the four wave tiles' scales
-    constexpr bool OC = NCA_ONCHIP_NR && NR && !RES && S8 && F == 128 && NCA_WAVES == 4;
-    char* const octile = smem + ((2 * BUF + CONSTB + NCA_WAVES * 2 * (F + 1) * 4 + 2 * bf_wo_floats(F) * 4 + 1023) & ~1023);
-    f32x16 ocW[4], ocB;
-    if (OC) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { ocW[0][r] = 0.f; ocW[1][r] = 0.f; ocW[2][r] = 0.f; ocW[3][r] = 0.f; ocB[r] = 0.f; }
-    }
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
     if (S8) s8_mode();
@@ -632,55 +493,18 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
         for (int net = 0; net < a.nnets; ++net)
             for (int i = tid; i < 2 * MT * 16 + 1; i += NCA_NT) wo_lds[net * bf_wo_floats(F) + i] = a.net[net].wo_src[i];
     __syncthreads();
-#if NCA_EXP & 65536
-    // (65536: shader clock of this launch = s_memtime ticks per 100 MHz s_memrealtime tick, printed by one wave at the end)
-    const unsigned long long clk_t0 = __builtin_readcyclecounter(), clk_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
     if (!RES) {
         stage_issue_b(a.stage[0], smem, wave, lane);
         stage_publish_b();
     }
     int cur = 0, si = 0;
 
-    // On-chip weight gradient of the last hidden layer (mode 3, one net per launch): the MT x MT blocks of dW are shared
-    // by the 8 waves (BPW blocks each, same output-row tile), accumulated over every tile this workgroup processes.
-    // Between the exchange phases the accumulators are PARKED in the wave's own slice of the exchange area (it is idle
-    // then): kept in registers they push the dgrad loops over the register budget, and a spill reload that misses the
-    // caches under this kernel's streaming traffic costs microseconds.
-    constexpr int BPW = (MT * MT + NCA_WAVES - 1) / NCA_WAVES;
-    constexpr int XS = 2 * MT * 1024 > BPW * 16 * 256 ? 2 * MT * 1024 : BPW * 16 * 256;     // bytes of a wave's slice (exchange / parking)
-    char* const xch = maskbase;          // exchange area [wave][2 MT fragments][lane][16 B] (the masks live in the store in mode 3)
-    float* const park = reinterpret_cast<float*>(xch + wave * XS) + lane;      // [BPW * 16][64 lanes] floats <= 8 KiB
-    if (ONCHIP) {
-#pragma unroll
-        for (int q = 0; q < BPW * 16; ++q) park[q * 64] = 0.f;
-    }
-
-#if NCA_EXP & 131072
-    // (131072: where a wave's cycles go -- s_memtime stamps between the phases of a tile, summed over the tiles of one wave)
-    unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
-#define NCA_STAMP(k) { const unsigned long long t_ = __builtin_readcyclecounter(); tph[k] += t_ - tlast; tlast = t_; }
-#else
-#define NCA_STAMP(k)
-#endif
-#if NCA_EXP & 8388608
-    // (8388608: timeline of one tile -- s_memtime before / after the MFMA block and after the epilogue of every row tile of the hidden
-    // layers, for each wave of workgroup 0, in the LDS left over behind the resident images; printed at the end with the SIMD each wave
-    // ran on: how the two waves of a SIMD really interleave)
-    unsigned long long* const tl_buf = reinterpret_cast<unsigned long long*>(smem + a.ctr_off + 16) + wave * 36;
-    int tl_n = 0;
-    bool tl_on = false;
-#define NCA_TL() { if (tl_on && tl_n < 36 && lane == 0) tl_buf[tl_n] = __builtin_readcyclecounter(); if (tl_on) ++tl_n; }
-#else
-#define NCA_TL()
-#endif
     const int64_t ngroups = (a.ntiles + NCA_WAVES - 1) / NCA_WAVES;
     // This workgroup's tiles: groups blockIdx.x, blockIdx.x + gridDim.x, ... of 8.  Streaming kernels: wave w takes tile w of every
     // group (the waves meet at every stage's barrier anyway).  Resident images: no barrier couples the waves, and the second wave
     // of a SIMD gets the issue slots the first leaves -- it runs ~25 % slower -- so each wave CLAIMS its next tile from a counter
     // in LDS.  Nothing that is summed across tiles stays in a wave, so the results do not depend on who ran which tile.
-    // (mode 3 keeps per-wave sums of the output layer's gradients across tiles: static there)
-    constexpr bool DYN = RES && MODE != NCA_KM_BWD_STORED;
+    constexpr bool DYN = RES;
     const int64_t my_groups = (int64_t)blockIdx.x < ngroups ? (ngroups - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
     for (int64_t it = 0;; ++it) {
         int64_t grp;
@@ -696,10 +520,6 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
             grp = blockIdx.x + it * gridDim.x;
             if (grp >= ngroups) break;
         }
-#if NCA_EXP & 8388608
-        tl_on = RES && blockIdx.x == 0 && it == 3;
-        tl_n = 0;
-#endif
         const int64_t tile = grp * NCA_WAVES + wslot;          // 64-sample tile
         const bool tvalid = tile < a.ntiles;
         const int64_t tl = tvalid ? tile : a.ntiles - 1;
@@ -715,11 +535,9 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
             valid = tvalid && smp < a.S;
             if (smp >= a.S) smp = a.S - 1;
             n = ray * a.S + smp;
-            const float zz = RECOMP ? ((NCA_EXP & 524288) ? 4.f + 0.01f * lane : a.z[ray * a.zs_r + smp]) : 0.f;       // (524288: no loads in the tile prologue)
+            const float zz = RECOMP ? a.z[ray * a.zs_r + smp] : 0.f;
             if (!RECOMP) {
                 p[0] = p[1] = p[2] = 0.f;
-            } else if (NCA_EXP & 524288) {
-                p[0] = 0.01f * zz; p[1] = -0.02f * zz + 0.001f * (float)(tile & 255); p[2] = zz - 4.5f;
             } else if (a.ray_is_f64) {
                 const double* o = reinterpret_cast<const double*>(a.origins) + ray * 3;
                 const double* d = reinterpret_cast<const double*>(a.dirs) + ray * 3;
@@ -740,9 +558,9 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
         }
         // second launch of a split render: the static net's sigma, written by the first launch
         float ss_other = 0.f;
-        if (!BWD && a.split == 2 && valid && !(NCA_EXP & 524288)) ss_other = a.sig_s[n];
+        if (!BWD && a.split == 2 && valid) ss_other = a.sig_s[n];
         int ph = 0;
-        if (RECOMP && a.phase && !(NCA_EXP & 524288)) ph = a.mode == NCA_MODE_RAYS ? a.phase[ray * a.ps_r + (int64_t)smp * a.ps_s] : a.phase[n];
+        if (RECOMP && a.phase) ph = a.mode == NCA_MODE_RAYS ? a.phase[ray * a.ps_r + (int64_t)smp * a.ps_s] : a.phase[n];
 
         // Scratch: two 32-sample tiles per wave, fragment-major blocks (see nca_bf_tile_bytes).  The input block and the
         // layer inputs live in the H region (indexed by the tile's position in the whole batch when a stored forward
@@ -752,10 +570,9 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
         // regions end in slack slots up to the next multiple of the 8 waves, so the hot loops store without a predicate.
         const int64_t tg = (FSTORE ? tile : tl) + a.tile0;
         char* const t32 = (BWD || STORE) ? reinterpret_cast<char*>(a.scratch) + (tg * 2) * a.rows_total : nullptr;   // rows_total = bytes per 32-sample tile
-        char* const d32 = BWD ? a.dscratch + ((STORED ? tile : tl) * 2) * a.d_total : nullptr;
+        char* const d32 = BWD ? a.dscratch + ((NR ? tile : tl) * 2) * a.d_total : nullptr;
 
         float raw[2] = {0.f, 0.f};
-        NCA_STAMP(0)                            // tile prologue: sample positions
 
 #pragma unroll
         for (int net = 0; net < 2; ++net) {
@@ -769,7 +586,7 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
             const bool lds_mask = MODE == NCA_KM_BWD && a.mask_layers >= y.NL - 1;
             char* const mwave = maskbase + (wave * a.mask_layers) * 1024 + lane * 16;
             // stored forward: ReLU masks [wave tile][net][layer][lane][16 B]
-            char* const mglob = (FSTORE || STORED) ? a.mstore + ((tg * 2 + net + a.net_base) * a.mstore_layers) * 1024 + lane * 16 : nullptr;
+            char* const mglob = (FSTORE || NR) ? a.mstore + ((tg * 2 + net + a.net_base) * a.mstore_layers) * 1024 + lane * 16 : nullptr;
             // Backward from the store: the ReLU masks of layer L travel HBM -> LDS by LDS-DMA into slot L & 1 of the wave's two
             // 1 KiB slots (the constant area is idle here: nothing is encoded), one layer ahead of their use and right behind the
             // weight DMA of a stage, so the stage's counted vmcnt covers them.  (As plain loads into registers they made the
@@ -783,7 +600,6 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
 
             // ================= encoding, lane = sample ===================================================
             u32x4 B[2][KSMAX];
-            u32x4 Q8[2][4], Q8n[2][4];            // NCA_CHAIN8: the previous / this layer's e4m3 bytes per (column tile, row tile)
             if (RECOMP) {
                 float fe[NCA_BF_K0SLOTS];
 #pragma unroll
@@ -841,9 +657,8 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
                         B[0][s][w] = r[0];
                         B[1][s][w] = r[1];
                     }
-                constexpr bool C8E = NCA_CHAIN8 && FSTORE && S8 && RES && F == 128;
                 const bool store_in = STORE && (FSTORE || tvalid) && !(a.share_enc && net + a.net_base == 0);
-                if (store_in || C8E) {
+                if (store_in) {
                     // input block of both column tiles, fragment-major [k-step][lane][16 B]: the layer-0
                     // operands as they sit in registers, then one k-step of one-hot phase slots
 #pragma unroll
@@ -866,8 +681,7 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
                             for (int t = 0; t < 4; ++t) {
                                 const u32x4 lo = t < 3 ? B[c][2 * t] : hot, hi = t < 3 ? B[c][2 * t + 1] : zero;
                                 const u32x4 q = {cvt4_e4m3_pk(lo[0], lo[1], DIV), cvt4_e4m3_pk(lo[2], lo[3], DIV), cvt4_e4m3_pk(hi[0], hi[1], DIV), cvt4_e4m3_pk(hi[2], hi[3], DIV)};
-                                if constexpr (C8E) Q8[c][t] = q;          // (fp8 chain: the input block's bytes are layer 0's operand)
-                                if (store_in) store_nt(blk + t * 1024, q);
+                                store_nt(blk + t * 1024, q);
                             }
                         } else {
 #pragma unroll
@@ -878,7 +692,6 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
                 }
             }
 
-            NCA_STAMP(1)                        // encoding + input block
             // S8: inverse of the power of two by which this tile's output gradients are scaled on their way to e5m2 (the chain
             // itself stays unscaled bf16: the scaling is part of the conversion)
             float inv_s = 1.f;
@@ -889,15 +702,15 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
                     float g;
                     if (a.mode == NCA_MODE_RAYS && !a.g_raw) {
                         const float* gs = net + a.net_base == 0 ? a.g_sig_s : a.g_sig_d;
-                        const double gsig = (NCA_EXP & 32768) ? 1e-6 * lane : (gs ? (double)gs[n] : 0.0);                 // (32768: no loads of the upstream gradients)
-                        const double gp = (NCA_EXP & 32768) ? 1e-7 : a.g_pix[ray] * a.dists[smp];
+                        const double gsig = gs ? (double)gs[n] : 0.0;
+                        const double gp = a.g_pix[ray] * a.dists[smp];
                         const double dsig = a.single ? (gsig - gp * (double)a.scale) : (gsig - gp) * (double)a.scale;
                         g = (float)dsig * act_bwd_b(a.act, raw[net]);
                     } else {
                         g = a.g_raw[n];
                     }
                     if (!valid) g = 0.f;
-                    if (S8 && STORED) {
+                    if (S8 && NR) {
                         // the dgrad chain is linear in g, so the largest |g| of the tile sizes every D_l of the tile: 2^e <= max < 2^(e+1)
                         // is scaled to 2^NCA_D8_LOG2 (exponent arithmetic; an all-zero tile gets the smallest inverse scale)
                         float am = fabsf(g);
@@ -911,7 +724,7 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
                     // g of tile c for BOTH lane halves: [g.lower|g.lower] and [g.upper|g.upper]
                     const float gc[2] = {__shfl(g, lr), __shfl(g, lr + 32)};
                     float* orow = osum + (wave * 2 + net) * (F + 1);
-                    char* const dblk = db + nca_bf_doff(y, y.NL - 1, S8 && STORED);
+                    char* const dblk = db + nca_bf_doff(y, y.NL - 1, S8 && NR);
                     u32x4 Bn[2][2 * MT];
                     if (NR) {
                         // D_{NL-1} = relu'(H_{NL-1}) (Wo x g) feeds the sweep; the block that goes to the weight-gradient kernel is
@@ -966,10 +779,10 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
                         // dWo[f] = sum_n g H[f][n]: reduce-scatter the 16 values over the 32 lanes of each half
                         float v[16];
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) v[i] = (NCA_EXP & 262144) ? 0.f : gc[0] * hv[0][i] + gc[1] * hv[1][i];
+                        for (int i = 0; i < 16; ++i) v[i] = gc[0] * hv[0][i] + gc[1] * hv[1][i];
                         int cnt = 16;
 #pragma unroll
-                        for (int d = (NCA_EXP & (4 | 262144)) ? 0 : 16; d >= 1; d >>= 1) {
+                        for (int d = 16; d >= 1; d >>= 1) {
                             if (cnt >= 2) {
                                 const int hn = cnt / 2;
                                 const bool up = (lr & d) != 0;
@@ -1000,12 +813,7 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
                                 Bn[c][2 * m][u] = pack2(dv[2 * u], dv[2 * u + 1]);
                                 Bn[c][2 * m + 1][u] = pack2(dv[8 + 2 * u], dv[8 + 2 * u + 1]);
                             }
-                            if (S8 && STORED && !ONCHIP && !(NCA_EXP & 1)) {
-                                u32x4 q8;
-#pragma unroll
-                                for (int w = 0; w < 4; ++w) q8[w] = cvt4_e5m2_pk(Bn[c][2 * m + (w >> 1)][2 * (w & 1)], Bn[c][2 * m + (w >> 1)][2 * (w & 1) + 1], inv_s);
-                                store_nt(dblk + c * a.d_total + lane * 16 + m * 1024, q8);
-                            } else if ((STORED || tvalid) && !ONCHIP) {
+                            if (tvalid) {
                                 char* fp2 = dblk + c * a.d_total + lane * 16;
                                 store_nt(fp2 + (2 * m) * 1024, Bn[c][2 * m]);
                                 store_nt(fp2 + (2 * m + 1) * 1024, Bn[c][2 * m + 1]);
@@ -1031,30 +839,16 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
                 raw[net] = a.rstore[((tg * 2 + net + a.net_base) * 64) + lane];
                 last_layer_grads(wo_lds + net * bf_wo_floats(F));
             }
-            if (STORED && !NR) {
-                // the backward from the store recomputes ONE layer, the last: its input is in the store anyway (the wgrad
-                // reads it too), which saves the forward from writing that layer's output and the raw outputs
-                const char* hl = nb + EB + nca_bf_hoff(y, y.NL - 2, a.h8 != 0) + lane * 16;
-                if (y.NL >= 2) mask_dma(y.NL - 2);
-#pragma unroll
-                for (int c = 0; c < 2; ++c)
-#pragma unroll
-                    for (int k = 0; k < 2 * MT; ++k)      // (on chip: plain loads -- the fragments are read again ~40 us later, let the caches keep them)
-                        B[c][k] = (NCA_EXP & 16384) ? (u32x4){0x3f803f80u + (unsigned)lane, 0x3f003f80u, 0x3f803f00u, 0x3e803f80u}        // (no loads of the last layer's input)
-                                  : ONCHIP ? *reinterpret_cast<const u32x4*>(hl + c * a.rows_total + k * 1024) : load_nt(hl + c * a.rows_total + k * 1024);
-            }
-            for (int jj = NR ? y.NL : (STORED ? y.NL - 1 : 0); jj < y.NL; ++jj) {
+            for (int jj = NR ? y.NL : 0; jj < y.NL; ++jj) {
                 const int nsi = (si + 1 == a.nstages) ? 0 : si + 1;
-                if (!RES && !(NCA_EXP & 8)) stage_issue_b(a.stage[nsi], smem + (cur ^ 1) * BUF, wave, lane);
+                if (!RES) stage_issue_b(a.stage[nsi], smem + (cur ^ 1) * BUF, wave, lane);
                 // Resident images: the layer's image offset and k-step count follow from the width alone (build_stages lays the forward
                 // images of the launch's one net back to back: layer 0, then the hidden-width layers; nca_build_layout_bf16).  Read from
                 // the argument block instead -- y.layer[jj], a.stage[si] with run-time indices -- they were two dependent scalar loads
-                // from memory at every layer boundary of every tile, ~1 500 cycles per boundary in the timeline (NCA_EXP 8388608)
-                // NCA_CHAIN8 (nca_layout.hpp): hidden-width layers of the resident storing forward contract e4m3 operands
-                constexpr bool C8 = NCA_CHAIN8 && FSTORE && S8 && RES && F == 128;
-                constexpr int IMG0 = (C8 ? MT * 4 * 1024 : MT * KS0 * 1024) + 2 * MT * 16 * 4, IMGH = (C8 ? MT * 4 * 1024 : MT * KS * 1024) + 2 * MT * 16 * 4;
-                const char* img = (RES && !STORED) ? smem + (jj == 0 ? 0 : IMG0 + (jj - 1) * IMGH) : (RES ? smem + a.stage[si].lds_off : smem + cur * BUF);      // (mode 3 resident: the one recomputed layer's image comes first)
-                const int nks = C8 ? 4 : (jj == 0 ? KS0 : KS);
+                // from memory at every layer boundary of every tile, ~1 500 cycles per boundary in the round-3 timeline
+                constexpr int IMG0 = MT * KS0 * 1024 + 2 * MT * 16 * 4, IMGH = MT * KS * 1024 + 2 * MT * 16 * 4;
+                const char* img = RES ? smem + (jj == 0 ? 0 : IMG0 + (jj - 1) * IMGH) : smem + cur * BUF;
+                const int nks = jj == 0 ? KS0 : KS;
                 const float* tail = reinterpret_cast<const float*>(img + MT * nks * 1024);
                 const bool last = jj == y.NL - 1;
                 const bool h8 = S8 && FSTORE;                                     // fp8 staging: the layer outputs go to the store as e4m3 (the last layer: its mask only)
@@ -1064,14 +858,13 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
                 const char* imgl = img + lane * 16;
                 // One instantiation per (k-step count, last layer?, e4m3 output?): the row-tile loop has no branch in it, so the
                 // scheduler may move the epilogue's vector ALU work (pack, ReLU, mask bits, conversion: ~100 instructions per row
-                // tile) into the shadow of the MFMAs around it (NCA_BF_PIPE: explicitly one row tile behind).
+                // tile) into the shadow of the MFMAs around it.
                 // The storing forward writes unconditionally: a wave without a tile recomputes the batch's last tile and writes
                 // it to the slack tile slots behind the store (store_plan rounds the tile count up to the 8 waves).
                 const bool st_ok = FSTORE ? true : tvalid;
                 auto rowtiles = [&](auto nks_c, auto last_c, auto h8_c) __attribute__((always_inline)) {
                 constexpr int NKS = decltype(nks_c)::value;
                 constexpr bool LAST = decltype(last_c)::value, H8 = decltype(h8_c)::value;
-                constexpr bool NOH = (NCA_EXP & 16) && FSTORE, NOM = (NCA_EXP & 32) && FSTORE;
                 u32x4 A[RINGK];
                 ring_prime<NKS, MT, RINGK>(imgl, A);
                 auto epilogue = [&](int m, f32x16& acc0, f32x16& acc1) __attribute__((always_inline)) {
@@ -1095,7 +888,7 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
                         }
                     }
                     // words 0..7 of a (row tile, column tile): fragment 2m holds accumulator registers 0..7, fragment 2m + 1 registers 8..15
-                    const bool want_mask = STORE && (!LAST || H8) && !NOM;
+                    const bool want_mask = STORE && (!LAST || H8);
 #pragma unroll
                     for (int c = 0; c < 2; ++c) {
                         unsigned w[8];
@@ -1117,18 +910,17 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
                             for (int u = 0; u < 4; ++u) { Bn[c][2 * m][u] = w[u]; Bn[c][2 * m + 1][u] = w[4 + u]; }
                         }
                     }
-                    if (STORE && !LAST && !NOH && H8) {
+                    if (STORE && !LAST && H8) {
                         // e4m3 of the bf16 activations (x 2^NCA_H8_LOG2): byte i = register i, [row tile][lane][16 B]
                         constexpr float DIV = 1.f / (float)(1 << NCA_H8_LOG2);
 #pragma unroll
                         for (int c = 0; c < 2; ++c) {
                             u32x4 q;
 #pragma unroll
-                            for (int w = 0; w < 4; ++w) q[w] = NOM ? Bn[c][2 * m + (w >> 1)][2 * (w & 1)] : cvt4_e4m3_pk(Bn[c][2 * m + (w >> 1)][2 * (w & 1)], Bn[c][2 * m + (w >> 1)][2 * (w & 1) + 1], DIV);
-                            if constexpr (C8) Q8n[c][m < 4 ? m : 0] = q;
+                            for (int w = 0; w < 4; ++w) q[w] = cvt4_e4m3_pk(Bn[c][2 * m + (w >> 1)][2 * (w & 1)], Bn[c][2 * m + (w >> 1)][2 * (w & 1) + 1], DIV);
                             if (st_ok) store_nt(hblk + c * a.rows_total + lane * 16 + m * 1024, q);
                         }
-                    } else if (STORE && !LAST && !NOH) {
+                    } else if (STORE && !LAST) {
                         // the next layer's B-operand fragments exactly as they sit in registers: 1 KiB per
                         // wave instruction, [k-step][lane][16 B] (feature order inside a tile is the
                         // accumulator->operand order; the wgrad un-permutes when it writes dW)
@@ -1142,90 +934,22 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
                         }
                     }
                 };
-                f32x16 pend0, pend1;
-                // NCA_BF_PIPE2: the deferred part of row tile mp's epilogue, piece 0..5 = (column tile, {ReLU, mask bits, e4m3 + store}),
-                // on the packed words where pack_only left them
-                constexpr bool P2 = NCA_BF_PIPE2 && FSTORE && H8 && !LAST && STORE && !NOH && !NOM;
-                auto pack_only = [&](int m, const f32x16& acc0, const f32x16& acc1) __attribute__((always_inline)) {
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        const f32x16& acc = c == 0 ? acc0 : acc1;
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) { Bn[c][2 * m][u] = pack2(acc[2 * u], acc[2 * u + 1]); Bn[c][2 * m + 1][u] = pack2(acc[8 + 2 * u], acc[8 + 2 * u + 1]); }
-                    }
-                };
-                auto deferred = [&](int mp, int piece) __attribute__((always_inline)) {
-                    if (piece >= 6) return;
-                    const int c = piece / 3, part = piece % 3;
-                    if (part < 2) {
-                        unsigned w[8];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) { w[u] = Bn[c][2 * mp][u]; w[4 + u] = Bn[c][2 * mp + 1][u]; }
-                        if (part == 0) {
-                            relu8(w);
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) { Bn[c][2 * mp][u] = w[u]; Bn[c][2 * mp + 1][u] = w[4 + u]; }
-                        } else {
-                            mw[c][mp >> 1] |= mask8(w) << (8 * (mp & 1));
-                        }
-                    } else {
-                        constexpr float DIV = 1.f / (float)(1 << NCA_H8_LOG2);
-                        u32x4 q;
-#pragma unroll
-                        for (int w = 0; w < 4; ++w) q[w] = cvt4_e4m3_pk(Bn[c][2 * mp + (w >> 1)][2 * (w & 1)], Bn[c][2 * mp + (w >> 1)][2 * (w & 1) + 1], DIV);
-                        if (st_ok) store_nt(hblk + c * a.rows_total + lane * 16 + mp * 1024, q);
-                    }
-                };
-                if constexpr (P2) {
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) {
-                        f32x16 acc0, acc1;
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) { const float b = tail[(lh * MT + m) * 16 + i]; acc0[i] = b; acc1[i] = b; }
-                        if (m == 0) mma_rowtile_ring<NKS, MT, KSMAX, RINGK>(imgl, m, A, B, acc0, acc1);
-                        else mma_rowtile_ring_il<NKS, MT, KSMAX, RINGK>(imgl, m, A, B, acc0, acc1, [&](int ks) __attribute__((always_inline)) { deferred(m - 1, ks); });
-                        if (m > 0 && NKS < 6) {
-#pragma unroll
-                            for (int pc = NKS; pc < 6; ++pc) deferred(m - 1, pc);
-                        }
-                        pack_only(m, acc0, acc1);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-#pragma unroll
-                    for (int pc = 0; pc < 6; ++pc) deferred(MT - 1, pc);
-                    return;
-                }
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
                     f32x16 acc0, acc1;
 #pragma unroll
                     for (int i = 0; i < 16; ++i) { const float b = tail[(lh * MT + m) * 16 + i]; acc0[i] = b; acc1[i] = b; }
-                    NCA_TL()
-                    if constexpr (C8) mma_rowtile_c8(imgl, m, Q8, acc0, acc1);
-                    else
-                    if (!(NCA_EXP & 128)) mma_rowtile_ring<NKS, MT, KSMAX, RINGK>(imgl, m, A, B, acc0, acc1);
-                    else { acc0[0] += __builtin_bit_cast(float, B[0][m][0]); acc1[3] += __builtin_bit_cast(float, B[1][m][1]); }       // (128: no MFMAs)
-                    NCA_TL()
-                    if (NCA_BF_PIPE) {
-                        if (m > 0) epilogue(m - 1, pend0, pend1);
-                        pend0 = acc0; pend1 = acc1;
-                    } else {
-                        epilogue(m, acc0, acc1);
-                        __builtin_amdgcn_sched_barrier(0);       // one row tile at a time: without the fence the scheduler overlaps row tiles and spills
-                    }
-                    NCA_TL()
+                    mma_rowtile_ring<NKS, MT, KSMAX, RINGK>(imgl, m, A, B, acc0, acc1);
+                    epilogue(m, acc0, acc1);
+                    __builtin_amdgcn_sched_barrier(0);       // one row tile at a time: without the fence the scheduler overlaps row tiles and spills
                 }
-                if (NCA_BF_PIPE) epilogue(MT - 1, pend0, pend1);
                 };
                 {
                     const std::integral_constant<int, KS0> ks0c{};
                     const std::integral_constant<int, KS> ksc{};
                     const std::true_type yes{};
                     const std::false_type no{};
-                    if constexpr (STORED) {
-                        if (!(NCA_EXP & 262144)) rowtiles(ksc, yes, no);                  // the recomputed last layer (a store exists only for NL >= 2)
-                        else { for (int c = 0; c < 2; ++c) for (int k = 0; k < 2 * MT; ++k) Bn[c][k] = B[c][k]; }      // (262144: no recompute, no dWo)
-                    } else if constexpr (S8 && FSTORE) {
+                    if constexpr (S8 && FSTORE) {
                         if (jj == 0) { if (last) rowtiles(ks0c, yes, yes); else rowtiles(ks0c, no, yes); }
                         else { if (last) rowtiles(ksc, yes, yes); else rowtiles(ksc, no, yes); }
                     } else {
@@ -1233,19 +957,10 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
                         else { if (last) rowtiles(ksc, yes, no); else rowtiles(ksc, no, no); }
                     }
                 }
-                NCA_STAMP(jj == 0 ? 2 : (last ? 4 : 3))        // layer 0 / hidden layers / last layer: MFMAs + epilogue + stores
-                if constexpr (!C8) {          // (fp8 chain: the bf16 words of a layer's output serve its own epilogue only)
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
                     for (int k = 0; k < 2 * MT; ++k) B[c][k] = Bn[c][k];
-                }
-                if constexpr (C8) {
-#pragma unroll
-                    for (int c = 0; c < 2; ++c)
-#pragma unroll
-                        for (int m = 0; m < 4; ++m) Q8[c][m] = Q8n[c][m];
-                }
                 if (lds_mask && !last) {
                     u32x4 mv = {mw[0][0], mw[0][1], mw[1][0], mw[1][1]};
                     *reinterpret_cast<u32x4*>(mwave + jj * 1024) = mv;
@@ -1268,110 +983,15 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
 
                 if (BWD && last) last_layer_grads(tail + 2 * MT * 16);
 
-                if (ONCHIP && last && !(NCA_EXP & 64)) {
-                    // dW_L += D_L * H_{L-1}^T over this workgroup's 8 x 64 samples.  B holds D_L; the layer's input fragments
-                    // (consumed by the recompute above) are read once more.  Both are transposed into rows = samples by
-                    // identity MFMAs (as the wgrad kernel does) and handed round 16 samples per wave at a time.
-                    const char* hl = nb + EB + nca_bf_hoff(y, y.NL - 2, a.h8 != 0) + lane * 16;
-                    const int b0 = wave * BPW;                       // my blocks b0 .. b0 + BPW - 1 of the MT x MT grid
-                    const int mo = b0 / MT, i0 = b0 % MT;
-                    const bool own = b0 < MT * MT;
-                    f32x16 accW[BPW];
-                    // one 32-feature tile (fragments x0, x1) transposed to rows = samples; returns the packed half `s2`
-                    // (16 samples) as an MFMA operand and, if asked, adds the tile's column sums (bias gradient)
-                    const u32x4 E0 = ident_frag(8 * lh, lr), E1 = ident_frag(16 + 8 * lh, lr);      // identity operands, once per phase
-                    auto tr_half = [&](const u32x4& x0, const u32x4& x1, int s2, float& colsum) __attribute__((always_inline)) {
-                        f32x16 zt;
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) zt[i] = 0.f;
-                        // the two halves of a tile come from the SAME products, recomputed on purpose: opaque copies of the
-                        // identity operands keep the compiler from merging them and carrying 16 registers per tile across a round
-                        u32x4 e0 = E0, e1 = E1;
-                        asm volatile("" : "+v"(e0), "+v"(e1));
-                        zt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(x0), frag(e0), zt, 0, 0, 0);
-                        zt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(x1), frag(e1), zt, 0, 0, 0);
-                        colsum = 0.f;
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) colsum += zt[i];
-                        u32x4 r;
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) r[u] = s2 ? pack2(zt[8 + 2 * u], zt[8 + 2 * u + 1]) : pack2(zt[2 * u], zt[2 * u + 1]);
-                        return r;
-                    };
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        // this column tile's input fragments (one request per tile, issued before its rounds)
-                        u32x4 XHc[2 * MT];
-#pragma unroll
-                        for (int k = 0; k < 2 * MT; ++k) XHc[k] = *reinterpret_cast<const u32x4*>(hl + c * a.rows_total + k * 1024);
-#pragma unroll
-                        for (int s2 = 0; s2 < 2; ++s2) {
-                            if (c == 0 && s2 == 0) {
-                                // un-park the accumulators (behind a scheduling fence: loaded any earlier they would sit on top of
-                                // the recompute's live registers), then free the slices for the exchange
-                                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                                for (int j = 0; j < BPW; ++j)
-#pragma unroll
-                                    for (int i = 0; i < 16; ++i) accW[j][i] = park[(j * 16 + i) * 64];
-                                asm volatile("" ::: "memory");        // the fragment stores below reuse the parked slice (other types: keep the order)
-                            }
-                            if (c + s2 > 0) lds_barrier();            // the previous round has been read by everyone (round 0 only touches
-                                                                      // the wave's own slice, which nobody reads before the next barrier)
-                            // nothing of this round may be scheduled above this point: the transposes depend on registers only and
-                            // would otherwise all be hoisted to the top of the phase (4 rounds x 2 MT results alive at once)
-                            __builtin_amdgcn_sched_barrier(0);
-                            char* my = xch + wave * XS + lane * 16;
-#pragma unroll
-                            for (int m = 0; m < MT; ++m) {
-                                // (the transposes run once per half: keeping both halves of all tiles alive costs ~100 registers)
-                                float cs;
-                                *reinterpret_cast<u32x4*>(my + m * 1024) = tr_half(B[c][2 * m], B[c][2 * m + 1], s2, cs);
-                                if (s2 == 0) {
-                                    // bias gradient: column sums of the transposed D tile, kept in the (unused) second-net slot of
-                                    // this wave's output-layer scratch -- another four live registers push the dgrad loops over
-                                    const float bcol = cs + __shfl_xor(cs, 32);
-                                    if (lh == 0) osum[(wave * 2 + 1) * (F + 1) + 32 * m + lr] += bcol;
-                                }
-                            }
-#pragma unroll
-                            for (int m = 0; m < MT; ++m) {
-                                float unused;
-                                *reinterpret_cast<u32x4*>(my + (MT + m) * 1024) = tr_half(XHc[2 * m], XHc[2 * m + 1], s2, unused);
-                            }
-                            lds_barrier();
-                            if (own) {
-#pragma unroll
-                                for (int src = 0; src < NCA_WAVES; ++src) {
-                                    const char* sp = xch + src * XS + lane * 16;
-                                    const u32x4 A = *reinterpret_cast<const u32x4*>(sp + mo * 1024);
-#pragma unroll
-                                    for (int j = 0; j < BPW; ++j) {
-                                        const u32x4 Bf = *reinterpret_cast<const u32x4*>(sp + (MT + i0 + j) * 1024);
-                                        accW[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(A), frag(Bf), accW[j], 0, 0, 0);
-                                    }
-                                }
-                            }
-                        }
-                    }
-                    lds_barrier();                                    // the last round has been read: the slices are free again
-#pragma unroll
-                    for (int j = 0; j < BPW; ++j)
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) park[(j * 16 + i) * 64] = accW[j][i];
-                }
-
                 // at least 4 MT stores follow the weight DMA of every storing stage: H (plus a mask store in the storing
                 // forward, which it then also waits for), or D_{NL-1} on the last layer of both backward modes; the last
                 // layer of the storing forward stores nothing
-                NCA_STAMP(5)                    // masks, raw output, output-layer gradients, on-chip dW
                 if (RES) {}                                             // nothing to publish, nothing to wait for
-                else if ((S8 && FSTORE && h8 && !last) || (S8 && STORED && last && !ONCHIP)) stage_publish_counted<2 * MT>(FSTORE || STORED || tvalid);   // 2 MT 8-bit stores (+ the mask store)
-                else if ((STORE && !last) || (BWD && last && !ONCHIP)) stage_publish_counted<4 * MT>(FSTORE || STORED || tvalid);
+                else if (S8 && FSTORE && h8 && !last) stage_publish_counted<2 * MT>(true);   // 2 MT 8-bit stores (+ the mask store)
+                else if ((STORE && !last) || (BWD && last)) stage_publish_counted<4 * MT>(FSTORE || tvalid);
                 else stage_publish_b();
                 cur ^= 1;
                 si = nsi;
-                NCA_STAMP(6)                    // publish: counted wait + barrier
             }
 
             // ================= backward sweep (dgrad) =====================================================
@@ -1382,17 +1002,6 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
                 u32x4 B2[2][KSMAX];
                 auto sweep_layer = [&](int jj, u32x4 (&Bin)[2][KSMAX], u32x4 (&Bout)[2][KSMAX]) __attribute__((always_inline)) {
                     const int nsi = (si + 1 == a.nstages) ? 0 : si + 1;
-                    const bool oc = OC && a.onchip == 2 && jj == y.NL - 1;          // this step produces D_{NL-2}: the on-chip layer's
-                    if (OC && oc) {
-                        // the on-chip layer's e4m3 input fragments of this wave's tile: store -> H tile (input of layer jj - 1)
-                        const char* hsrc = nb + 32 * 128 + (int64_t)(jj - 2) * 32 * F + lane * 16;
-#pragma unroll
-                        for (int c = 0; c < 2; ++c)
-#pragma unroll
-                            for (int m = 0; m < MT; ++m)
-                                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(hsrc + c * a.rows_total + m * 1024),
-                                                                 (__attribute__((address_space(3))) void*)(octile + 32768 + ((wave * 2 + c) * MT + m) * 1024), 16, 0, 0);
-                    }
                     if (NR) {
                         // this layer's masks were requested before the D stores of the step before (the output layer's step or the
                         // previous iteration): at most those stores are younger
@@ -1401,37 +1010,28 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
                         if (S8 && jj == y.NL - 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
                         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTM) : "memory");
                     }
-                    if (!RES && !(NCA_EXP & 8)) stage_issue_b(a.stage[nsi], smem + (cur ^ 1) * BUF, wave, lane);
-                    if (STORED && jj >= 2) mask_dma(jj - 2);            // for the next iteration; this one's arrived under the previous stage
-                    if (RES && !NR) {
-                        // this layer's masks were requested one layer ago (or before the last layer's input): behind them are at
-                        // most the D stores of that layer and the request just made
-                        constexpr int NST = S8 ? 2 * MT : 4 * MT;
-                        if (jj >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST + 1) : "memory");
-                        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
-                    }
+                    if (!RES) stage_issue_b(a.stage[nsi], smem + (cur ^ 1) * BUF, wave, lane);
+                    if (NR && jj >= 2) mask_dma(jj - 2);            // for the next iteration; this one's arrived under the previous stage
                     // (resident: the transposed images of layers NL-1 .. 1 back to back, one per sweep step -- see the forward)
-                    const char* img = (RES && NR) ? smem + si * (MT * KS * 1024) : (RES ? smem + a.stage[si].lds_off : smem + cur * BUF);
+                    const char* img = RES ? smem + si * (MT * KS * 1024) : smem + cur * BUF;
                     const char* const hblk = nb + EB + (jj - 1) * HB;                       // input of layer jj (mask)
-                    char* const dblk = db + nca_bf_doff(y, jj - 1, S8 && STORED);            // D_{jj-1}
+                    char* const dblk = db + nca_bf_doff(y, jj - 1, S8 && NR);            // D_{jj-1}
                     const bool wr_d = tvalid;
                     u32x4 mv = {0u, 0u, 0u, 0u};
                     if (lds_mask) mv = *reinterpret_cast<const u32x4*>(mwave + (jj - 1) * 1024);
-                    if (STORED) mv = *reinterpret_cast<const u32x4*>(mslot + ((jj - 1) & 1) * 1024 + lane * 16);
-                    const bool bits = lds_mask || STORED;         // mask bits at hand (else: re-read the layer input)
+                    if (NR) mv = *reinterpret_cast<const u32x4*>(mslot + ((jj - 1) & 1) * 1024 + lane * 16);
+                    const bool bits = lds_mask || NR;         // mask bits at hand (else: re-read the layer input)
                     u32x4 A[RINGK];
                     const char* imgl = img + lane * 16;
                     ring_prime<KS, MT, RINGK>(imgl, A);
-                    // software-pipelined like the forward layers: the epilogue of row tile m - 1 (mask, pack, e5m2, stores) shares a
-                    // basic block with the MFMAs of row tile m.  From a store the D blocks are written without a predicate (slack
-                    // tile slots behind the D region take the copies of waves that have no tile)
-                    const bool st_ok = STORED ? true : wr_d;
+                    // From a store the D blocks are written without a predicate (slack tile slots behind the D region take the copies
+                    // of waves that have no tile)
+                    const bool st_ok = NR ? true : wr_d;
                     auto epilogue = [&](int m, const f32x16& acc0, const f32x16& acc1) __attribute__((always_inline)) {
 #pragma unroll
                         for (int c = 0; c < 2; ++c) {
                             const char* hp = hblk + c * a.rows_total + lane * 16;
                             char* dp = dblk + c * a.d_total + lane * 16;
-                            if (NCA_EXP & 8192) dp = a.dscratch + ((blockIdx.x * 8 + wave) * 2 + c) * 4096 + lane * 16;     // (every store of a wave to ONE 8 KiB window)
                             u32x4 q8 = {0u, 0u, 0u, 0u};           // S8: the 16 masked values of this (row tile, column tile) as e5m2 bytes
 #pragma unroll
                             for (int s2 = 0; s2 < 2; ++s2) {
@@ -1447,127 +1047,29 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
                                     const float a0 = c == 0 ? acc0[8 * s2 + 2 * u] : acc1[8 * s2 + 2 * u];
                                     const float a1 = c == 0 ? acc0[8 * s2 + 2 * u + 1] : acc1[8 * s2 + 2 * u + 1];
                                     const unsigned two = bits ? (fld >> (4 * s2 + u)) & 0x00010001u : pos_pk(relu_pk(hw[u]));
-                                    dw[u] = (NCA_EXP & 2) ? pack2(a0, a1) : keep_pk(pack2_pk(a0, a1), two);
+                                    dw[u] = keep_pk(pack2_pk(a0, a1), two);
                                 }
                                 Bout[c][2 * m + s2] = dw;
-                                if ((NCA_EXP & 2) && S8 && STORED) { q8[2 * s2] = dw[0] ^ dw[1]; q8[2 * s2 + 1] = dw[2] ^ dw[3]; }
-                                else if (S8 && STORED) {
+                                if (S8 && NR) {
                                     q8[2 * s2] = cvt4_e5m2_pk(dw[0], dw[1], inv_s);
                                     q8[2 * s2 + 1] = cvt4_e5m2_pk(dw[2], dw[3], inv_s);
-                                } else if (st_ok && !(NCA_EXP & 1)) store_nt(dp + (2 * m + s2) * 1024, dw);
+                                } else if (st_ok) store_nt(dp + (2 * m + s2) * 1024, dw);
                             }
-                            if (OC && oc) {
-                                const u32x4 zero = {0u, 0u, 0u, 0u};
-                                *reinterpret_cast<u32x4*>(octile + ((wave * 2 + c) * MT + m) * 1024 + lane * 16) = tvalid ? q8 : zero;      // (a wave without a tile repeats the last one: no contribution)
-                            } else
-                            if (S8 && STORED && st_ok && !(NCA_EXP & 1)) store_nt(dp + m * 1024, q8);
+                            if (S8 && NR && st_ok) store_nt(dp + m * 1024, q8);
                         }
                     };
-                    f32x16 pend0, pend1;
-                    // NCA_BF_PIPE2 (as in the storing forward): behind the MFMAs of row tile m only the conversions to bf16 run, into
-                    // the next layer's operand slots; mask, e5m2 conversion and the store of row tile m follow in six pieces behind the
-                    // MFMA pairs of row tile m + 1 (from a store with e5m2 staging and the mask bits at hand: the bench path)
-                    constexpr bool P2 = NCA_BF_PIPE2 && S8 && STORED && !(NCA_EXP & (1 | 2 | 128 | 8192));
-                    if constexpr (P2) {
-                        auto pack_only = [&](int m, const f32x16& acc0, const f32x16& acc1) __attribute__((always_inline)) {
-#pragma unroll
-                            for (int c = 0; c < 2; ++c) {
-                                const f32x16& acc = c == 0 ? acc0 : acc1;
-#pragma unroll
-                                for (int u = 0; u < 4; ++u) { Bout[c][2 * m][u] = pack2_pk(acc[2 * u], acc[2 * u + 1]); Bout[c][2 * m + 1][u] = pack2_pk(acc[8 + 2 * u], acc[8 + 2 * u + 1]); }
-                            }
-                        };
-                        auto deferred = [&](int mp, int piece) __attribute__((always_inline)) {
-                            if (piece >= 6) return;
-                            const int c = piece / 3, part = piece % 3;
-                            if (part < 2) {             // fragment 2 mp + part: the masked halves of its four words cleared
-                                const unsigned fld = mv[2 * c + (mp >> 1)] >> (8 * (mp & 1));
-#pragma unroll
-                                for (int u = 0; u < 4; ++u) Bout[c][2 * mp + part][u] = keep_pk(Bout[c][2 * mp + part][u], (fld >> (4 * part + u)) & 0x00010001u);
-                            } else {
-                                u32x4 q8;
-#pragma unroll
-                                for (int s2 = 0; s2 < 2; ++s2) {
-                                    q8[2 * s2] = cvt4_e5m2_pk(Bout[c][2 * mp + s2][0], Bout[c][2 * mp + s2][1], inv_s);
-                                    q8[2 * s2 + 1] = cvt4_e5m2_pk(Bout[c][2 * mp + s2][2], Bout[c][2 * mp + s2][3], inv_s);
-                                }
-                                store_nt(dblk + c * a.d_total + lane * 16 + mp * 1024, q8);
-                            }
-                        };
-#pragma unroll
-                        for (int m = 0; m < MT; ++m) {
-                            f32x16 acc0, acc1;
-#pragma unroll
-                            for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-                            if (m == 0) mma_rowtile_ring<KS, MT, KSMAX, RINGK>(imgl, m, A, Bin, acc0, acc1);
-                            else mma_rowtile_ring_il<KS, MT, KSMAX, RINGK>(imgl, m, A, Bin, acc0, acc1, [&](int ks) __attribute__((always_inline)) { deferred(m - 1, ks); });
-                            if (m > 0 && KS < 6) {
-#pragma unroll
-                                for (int pc = KS; pc < 6; ++pc) deferred(m - 1, pc);
-                            }
-                            pack_only(m, acc0, acc1);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-#pragma unroll
-                        for (int pc = 0; pc < 6; ++pc) deferred(MT - 1, pc);
-                    } else {
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
                         f32x16 acc0, acc1;
 #pragma unroll
                         for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-                        if (!(NCA_EXP & 128)) mma_rowtile_ring<KS, MT, KSMAX, RINGK>(imgl, m, A, Bin, acc0, acc1);
-                        else { acc0[0] = __builtin_bit_cast(float, Bin[0][m][0]); acc1[3] = __builtin_bit_cast(float, Bin[1][m][1]); }
-                        if (NCA_BF_PIPE) {
-                            if (m > 0) epilogue(m - 1, pend0, pend1);
-                            pend0 = acc0; pend1 = acc1;
-                        } else {
-                            epilogue(m, acc0, acc1);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
+                        mma_rowtile_ring<KS, MT, KSMAX, RINGK>(imgl, m, A, Bin, acc0, acc1);
+                        epilogue(m, acc0, acc1);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    if (NCA_BF_PIPE) epilogue(MT - 1, pend0, pend1);
-                    }
-                    NCA_STAMP(3)
-                    if (OC && oc && lane == 0) reinterpret_cast<float*>(octile + 65536)[wave] = inv_s;
-                    if (!RES) stage_publish_counted<(S8 && STORED) ? 2 * MT : 4 * MT>((OC && oc) ? false : st_ok);              // D stores  (on-chip layer: nothing stored, drain the H tile's DMA)
-                    if constexpr (OC) {
-                        if (oc) {
-                            // dW rows 32 wave .. + 31 of the on-chip layer over the workgroup's four wave tiles (wgrad_job_mx, NCA_WGRAD_TR: same operands)
-                            const int troff = (32 * (lr & 1) + 16 * lh + ((lr & 15) >> 1)) * 16 + 8 * ((lr >> 4) & 1);
-                            const int one = lr == 0 ? 0x38383838 : 0;
-                            const i32x8 sel = {one, one, one, one, one, one, one, one};
-#pragma unroll
-                            for (int t = 0; t < 4; ++t) {
-                                i32x8 PA, PB[4];
-#pragma unroll
-                                for (int half = 0; half < 2; ++half) {
-                                    const char* dp = octile + (t * 2 + half) * (MT * 1024) + troff;
-#pragma unroll
-                                    for (int tt = 0; tt < 2; ++tt) {
-                                        const i32x2 v = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) i32x2*)(dp + wave * 1024 + tt * 128));
-                                        PA[4 * half + 2 * tt] = v[0]; PA[4 * half + 2 * tt + 1] = v[1];
-                                    }
-#pragma unroll
-                                    for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-                                        for (int tt = 0; tt < 2; ++tt) {
-                                            const i32x2 v = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) i32x2*)(dp + 32768 + cb * 1024 + tt * 128));
-                                            PB[cb][4 * half + 2 * tt] = v[0]; PB[cb][4 * half + 2 * tt + 1] = v[1];
-                                        }
-                                }
-                                const float sct = reinterpret_cast<const float*>(octile + 65536)[t];
-                                const int sa = (int)(__float_as_uint(sct) >> 23) - NCA_H8_LOG2;
-#pragma unroll
-                                for (int cb = 0; cb < 4; ++cb)
-                                    ocW[cb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(PA, PB[cb], ocW[cb], 1 /* A: e5m2 */, 0 /* B: e4m3 */, 0, sa, 0, 127);
-                                ocB = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(sel, PA, ocB, 0, 1, 0, 127, 0, sa + NCA_H8_LOG2);
-                            }
-                        }
-                    }
+                    if (!RES) stage_publish_counted<(S8 && NR) ? 2 * MT : 4 * MT>(st_ok);              // D stores
                     cur ^= 1;
                     si = nsi;
-                    NCA_STAMP(6)
                 };
                 for (int jj = y.NL - 1; jj >= 1; jj -= 2) {
                     sweep_layer(jj, B, B2);
@@ -1607,68 +1109,7 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
                 if (valid) a.raw_out[n] = raw[0];
             }
         }
-        NCA_STAMP(7)                            // tile epilogue
     }  // tile groups
-#if NCA_EXP & 131072
-    if (lane == 0 && (wave == 0 || wave == 5) && (blockIdx.x == 3 || blockIdx.x == 200)) {
-        unsigned long long tot = 0;
-        for (int k = 0; k < 8; ++k) tot += tph[k];
-        printf("mode %d res %d block %d wave %d: cycles %llu = prologue %.1f%% enc %.1f%% layer0 %.1f%% hidden %.1f%% last %.1f%% tail-of-layer %.1f%% publish %.1f%% epilogue %.1f%%\n", MODE, (int)RES,
-               (int)blockIdx.x, wave, tot, 100.0 * tph[0] / tot, 100.0 * tph[1] / tot, 100.0 * tph[2] / tot, 100.0 * tph[3] / tot, 100.0 * tph[4] / tot, 100.0 * tph[5] / tot,
-               100.0 * tph[6] / tot, 100.0 * tph[7] / tot);
-    }
-#endif
-
-    if constexpr (OC) {
-        if (a.onchip == 2) {
-            // rows 32 wave .. + 31 of the on-chip layer's dW and its bias sums -> this workgroup's slab, natural [o][i] order (wgrad_write)
-            auto unperm = [](int c) { return (c & 0x13) | ((c & 8) >> 1) | ((c & 4) << 1); };
-            float* ws = a.wslab + (int64_t)blockIdx.x * a.wslab_stride;
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb) {
-                const int col = 32 * cb + unperm(lr);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int o = 32 * wave + unperm(nca_rho(i) + 4 * lh);
-                    float* dst = ws + (int64_t)o * F + col;
-                    *dst = a.accumulate ? *dst + ocW[cb][i] : ocW[cb][i];
-                }
-            }
-            if (lh == 0) {
-                float* dst = ws + (int64_t)F * F + 32 * wave + unperm(lr);
-                *dst = a.accumulate ? *dst + ocB[0] : ocB[0];
-            }
-        }
-    }
-    if (ONCHIP) {
-        // dW blocks and bias sums of the on-chip layer -> this workgroup's slab, natural [o][i] order (both indices of a
-        // hidden block are in accumulator->operand order: un-permute them as the wgrad kernel does)
-        auto unperm = [](int c) { return (c & 0x13) | ((c & 8) >> 1) | ((c & 4) << 1); };
-        float* ws = a.wslab + (int64_t)blockIdx.x * a.wslab_stride;
-        const int b0 = wave * BPW;
-        if (b0 < MT * MT) {
-            const int mo = b0 / MT, i0 = b0 % MT;
-#pragma unroll
-            for (int j = 0; j < BPW; ++j) {
-                const int col = 32 * (i0 + j) + unperm(lr);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int o = 32 * mo + unperm(nca_rho(i) + 4 * lh);
-                    const float v = park[(j * 16 + i) * 64];
-                    float* dst = ws + (int64_t)o * F + col;
-                    *dst = a.accumulate ? *dst + v : v;
-                }
-            }
-        }
-        // bias: per-wave column sums -> LDS -> sum over the waves
-        __syncthreads();
-        for (int f = tid; f < F; f += NCA_NT) {          // position f of the accumulator order is feature 32 (f / 32) + unperm(f % 32)
-            float sb = 0.f;
-            for (int w = 0; w < NCA_WAVES; ++w) sb += osum[(w * 2 + 1) * (F + 1) + f];
-            float* dst = ws + (int64_t)F * F + 32 * (f >> 5) + unperm(f & 31);
-            *dst = a.accumulate ? *dst + sb : sb;
-        }
-    }
     if (BWD) {
         __syncthreads();
         for (int i = tid; i < a.nnets * (F + 1); i += NCA_NT) {
@@ -1678,18 +1119,6 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
             *dst = a.accumulate ? *dst + s : s;
         }
     }
-#if NCA_EXP & 8388608
-    if (RES && blockIdx.x == 0 && lane == 0 && (MODE == NCA_KM_FWD_STORE)) {
-        const unsigned simd = __builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11)) & 3;
-        for (int i = 0; i < 36; ++i) printf("TL %d %d %u %d %llu\n", (int)a.net_base, wave, simd, i, tl_buf[i]);
-    }
-#endif
-#if NCA_EXP & 65536
-    if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 131)) {
-        const unsigned long long dt = __builtin_readcyclecounter() - clk_t0, dr = __builtin_amdgcn_s_memrealtime() - clk_r0;
-        printf("mode %d block %d: %llu shader cycles in %.1f us = %.3f GHz\n", MODE, (int)blockIdx.x, dt, dr * 0.01, (double)dt / (dr * 10.0));
-    }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1924,27 +1353,11 @@ __device__ __forceinline__ void dma_piece(const char* src, char* to) {
 // first KiB of its slot, and the fragment bytes are rebuilt on the vector ALU, 4 bytes in 4 instructions: nibble, x 0x204081 &
 // 0x01010101 (one bit per byte), packed 16-bit multiply by the byte.  The nibbles come in mask-bit order, so the rows of dW come
 // out in the order wgrad_write<EXPAND> undoes.  9 B per sample instead of F.
-// NCA_WGRAD_TR: the transposes by the LDS read instead of by MFMAs.  A fragment sits in its ring slot as [lane][16 B] = 16 features of
-// one sample per lane; ds_read_b64_tr_b8 hands lane i of a 16-lane group byte column i of 8 rows whose addresses the group's lanes
-// supply (lane 2q + p: row q, bytes 8p .. 8p+7; tools/ds_tr8_probe.hip), so with rows = 8 consecutive samples and the two byte halves
-// taken from the two lane halves of the fragment, a lane receives 8 consecutive samples of ONE feature -- at the same feature
-// position the identity MFMAs put it (wgrad_write does not change).  Two reads per block and 32-sample tile fill the 16 K bytes
-// a lane takes from that tile (lane half h: samples 16h .. 16h+15; both operands alike, which is all the contraction needs):
-// 32 ds_read_b64_tr_b8 per wave tile replace 16 ds_read_b128, 32 transposing MFMAs and 128 conversions back to bytes.  The bias
-// gradient (column sums of the transposed D tile before) becomes one more MX product per row block: A = a row selector (1.0 in row
-// m), B = the D operand itself, so row m of one extra accumulator collects block m's sums over the 64 samples, scaled like dW.
-// Measured at the bench size (tools/variant_build.sh tr "-DNCA_WGRAD_TR=1"; the fp8-staging oracle tests pass, the loss differs in
-// the 7th digit: another summation order): weight gradient 4.72 - 4.88 -> 4.93 ms, step 13.43 -> 13.70 - 13.88 ms on the same box.
-// The launch is bound by its HBM reads, and what the vector ALU and the small MFMAs no longer do the LDS transpose network and
-// four more MX products do.  Off.
-#ifndef NCA_WGRAD_TR
-#define NCA_WGRAD_TR 0
-#endif
 template <int F, int NTB, bool H8, bool EXPAND = false>
 __device__ __forceinline__ void wgrad_job_mx(const NcaWgradArgs& a, const NcaWgradJob& job, int q, int nsplit, int lane, char* ring) {
     using R = WgradRing<F, NTB, true, H8>;
     constexpr int MT = F / 32, ND_ = EXPAND ? 1 : R::ND, NH_ = R::NH, FR = ND_ + NH_;
-    constexpr int NSLOT = (NCA_EXP & 4194304) ? 2 : (EXPAND ? (F == 128 ? 6 : 4) : 4);       // (an expand tile is 5 KiB: more of them in flight; 4194304: one tile ahead, timing only)
+    constexpr int NSLOT = EXPAND ? (F == 128 ? 6 : 4) : 4;       // (an expand tile is 5 KiB: more of them in flight)
     constexpr int NDMA = (EXPAND ? 3 : ND_) + NH_ + 1;              // vector-memory operations per tile: the fragments and the wave tile's scale
     constexpr int SC0 = NSLOT * FR * 1024;    // the scales' 256 bytes per slot, behind the fragments
     static_assert(SC0 + NSLOT * 256 <= NCA_WGRAD_LDS && NSLOT >= 2, "ring does not fit the wave's LDS share");
@@ -2030,12 +1443,6 @@ __device__ __forceinline__ void wgrad_job_mx(const NcaWgradArgs& a, const NcaWgr
     const long ED0 = ident8<true>(8 * lh, lc), ED1 = ident8<true>(16 + 8 * lh, lc);          // e5m2 identity (D blocks)
     const long EH0 = ident8<false>(8 * lh, lc), EH1 = ident8<false>(16 + 8 * lh, lc);        // e4m3 identity (e4m3 H blocks)
     const u32x4 EB0 = ident_frag(8 * lh, lc), EB1 = ident_frag(16 + 8 * lh, lc);             // bf16 identity (bf16 H blocks)
-    constexpr bool TR = NCA_WGRAD_TR && !EXPAND && MT == 4 && NTB == 4 && H8;       // (an expand job rebuilds its D fragments in registers: it keeps the MFMA transposes, for both operands -- they must agree on the K order)
-    // transposed reads: this lane's row / byte-half inside a fragment (see above); + 1024 per fragment, + 128 for the second 8 samples
-    const int troff = (32 * (lc & 1) + 16 * lh + ((lc & 15) >> 1)) * 16 + 8 * ((lc >> 4) & 1);
-    f32x16 accb;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) accb[r] = 0.f;
     for (int64_t i = 0; i < n; i += 2) {
         i32x8 PA[MT], PB[NTB];
         float sc = 0.f;
@@ -2050,20 +1457,8 @@ __device__ __forceinline__ void wgrad_job_mx(const NcaWgradArgs& a, const NcaWgr
             }
             if (half == 0) sc = *reinterpret_cast<const float*>(ring + SC0 + rslot * 256 + lane * 4);
             const char* slot = ring + rslot * (FR * 1024) + lane * 16;
-            const char* trp = ring + rslot * (FR * 1024) + troff;
             rslot = rslot + 1 == NSLOT ? 0 : rslot + 1;
-            auto tr_block = [&](int frag, i32x8& P) __attribute__((always_inline)) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const i32x2 v = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) i32x2*)(trp + frag * 1024 + t * 128));
-                    P[4 * half + 2 * t] = v[0]; P[4 * half + 2 * t + 1] = v[1];
-                }
-            };
             u32x4 xd[MT];
-            if constexpr (TR) {
-#pragma unroll
-                for (int m = 0; m < MT; ++m) tr_block(m, PA[m]);
-            } else {
             if constexpr (EXPAND) {
                 const char* sm = slot - lane * 12;
                 const unsigned mw[2] = {*reinterpret_cast<const unsigned*>(sm), *reinterpret_cast<const unsigned*>(sm + 256)};
@@ -2101,11 +1496,7 @@ __device__ __forceinline__ void wgrad_job_mx(const NcaWgradArgs& a, const NcaWgr
 #pragma unroll
                 for (int w = 0; w < 4; ++w) PA[m][4 * half + w] = (int)z4_e5m2(z[4 * w], z[4 * w + 1], z[4 * w + 2], z[4 * w + 3]);
             }
-            }
-            if constexpr (TR) {
-#pragma unroll
-                for (int c = 0; c < NTB; ++c) tr_block(ND_ + c, PB[c]);
-            } else if constexpr (H8 && NTB == 4) {                  // H: e4m3 bytes -> transposed bytes
+            if constexpr (H8 && NTB == 4) {                  // H: e4m3 bytes -> transposed bytes
                 u32x4 x[4];
                 f32x16 z[4];
 #pragma unroll
@@ -2147,20 +1538,6 @@ __device__ __forceinline__ void wgrad_job_mx(const NcaWgradArgs& a, const NcaWgr
 #pragma unroll
             for (int c = 0; c < NTB; ++c)
                 acc[m][c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(PA[m], PB[c], acc[m][c], 1 /* A: e5m2 */, 0 /* B: e4m3 */, 0, sa, 0, 127);
-        if constexpr (TR) {
-            // bias sums: row m of accb += sum over the 64 samples of block m (A = 1.0 in row m, B = the D operand, its scale without
-            // the layer inputs' 2^-NCA_H8_LOG2)
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const int one = lc == m ? 0x38383838 : 0;
-                const i32x8 sel = {one, one, one, one, one, one, one, one};
-                accb = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(sel, PA[m], accb, 0 /* A: e4m3 */, 1 /* B: e5m2 */, 0, 127, 0, sa + NCA_H8_LOG2);
-            }
-        }
-    }
-    if constexpr (TR) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m) bsum[m] = lh == 0 ? accb[m] : 0.f;          // (rows 0 .. 3 sit in registers 0 .. 3 of lane half 0)
     }
     wgrad_write<F, NTB, EXPAND>(acc, bsum, job, a.slab + (int64_t)q * a.slab_stride, a.accumulate, lane);
 }
@@ -2210,9 +1587,6 @@ __global__ __launch_bounds__(64, 1) void nca_wgrad_bf16(const NcaWgradArgs a) {
         if (qx >= ns) return;
     }
     const NcaWgradJob job = a.job[jy];
-#if NCA_EXP & 65536
-    const unsigned long long clk_t0 = __builtin_readcyclecounter(), clk_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
     // (at F = 128 the 112-slot input block and a hidden block have the same shape: one body serves both)
     if constexpr (D8) {
         s8_mode();
@@ -2225,13 +1599,6 @@ __global__ __launch_bounds__(64, 1) void nca_wgrad_bf16(const NcaWgradArgs a) {
         else if (F != 128 && job.is_enc) wgrad_job<F, 4, D8, false>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
         else wgrad_job<F, F == 128 ? 4 : F / 32, D8, false>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
     }
-#if NCA_EXP & 65536
-    // (65536: cycles and clock of two waves of a standard job and of an expand job -- the grid is one round, the slowest wave is the launch)
-    if (threadIdx.x == 0 && (qx == 0 || qx == 57) && (jy == 1 || jy == 4)) {
-        const unsigned long long dt = __builtin_readcyclecounter() - clk_t0, dr = __builtin_amdgcn_s_memrealtime() - clk_r0;
-        printf("wgrad job %d split %d: %llu shader cycles in %.1f us = %.3f GHz\n", jy, qx, dt, dr * 0.01, (double)dt / (dr * 10.0));
-    }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2239,11 +1606,10 @@ __global__ __launch_bounds__(64, 1) void nca_wgrad_bf16(const NcaWgradArgs a) {
 // ------------------------------------------------------------------------------------------
 template <int F, int MODE, bool S8, bool RES = false>
 static hipError_t launch_fused_bf_mode(const NcaFusedArgs& a, int grid, hipStream_t st) {
-    constexpr bool bwd = MODE == NCA_KM_BWD || MODE == NCA_KM_BWD_STORED || MODE == NCA_KM_BWD_ONCHIP || MODE == NCA_KM_BWD_NR;
+    constexpr bool bwd = MODE == NCA_KM_BWD || MODE == NCA_KM_BWD_NR;
     size_t lds = (RES ? (size_t)a.res_bytes : 2 * BfCfg<F>::BUF_BYTES) + bf_const_bytes(MODE);
     if (bwd) lds += NCA_WAVES * 2 * (F + 1) * sizeof(float);
     if (MODE == NCA_KM_BWD_NR) lds += 2 * bf_wo_floats(F) * sizeof(float);
-    if (NCA_ONCHIP_NR && MODE == NCA_KM_BWD_NR && !RES && a.onchip == 2) lds = ((lds + 1023) & ~(size_t)1023) + 65536 + 64;          // D tiles, H tiles, scales
     static thread_local NcaFusedArgs b;
     const NcaFusedArgs* pa = &a;
     if (RES) {
@@ -2251,17 +1617,12 @@ static hipError_t launch_fused_bf_mode(const NcaFusedArgs& a, int grid, hipStrea
         b = a;
         b.ctr_off = (int32_t)lds;            // the workgroup's tile counter
         lds += 16;
-        if ((NCA_EXP & 8388608) && MODE == NCA_KM_FWD_STORE && lds + NCA_WAVES * 36 * 8 <= (size_t)NCA_LDS_BYTES) lds += NCA_WAVES * 36 * 8;
         pa = &b;
         const size_t dma_end = (size_t)a.stage[a.nstages - 1].lds_off + a.stage[a.nstages - 1].bytes;       // whole 1 KiB pieces
         if (dma_end > lds) lds = dma_end;
         if (lds > (size_t)NCA_LDS_BYTES) return hipErrorInvalidValue;
     }
     if (MODE == NCA_KM_BWD) lds += (size_t)NCA_WAVES * a.mask_layers * 1024;
-    if (MODE == NCA_KM_BWD_ONCHIP) {      // exchange / parking area: the larger of 2 MT fragments and the wave's parked accumulators
-        constexpr int MT = BfCfg<F>::MT, BPW = (MT * MT + NCA_WAVES - 1) / NCA_WAVES;
-        lds += (size_t)NCA_WAVES * (2 * MT * 1024 > BPW * 16 * 256 ? 2 * MT * 1024 : BPW * 16 * 256);
-    }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_fused_bf16<F, MODE, S8, RES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((nca_fused_bf16<F, MODE, S8, RES>), dim3(grid), dim3(NCA_NT), lds, st, *pa);
     return hipGetLastError();
@@ -2271,8 +1632,7 @@ static hipError_t launch_fused_bf(const NcaFusedArgs& a, int kmode, int grid, hi
     if (a.res_bytes > 0) {         // resident weight images (one net per launch; the host has checked that they fit)
         switch (kmode) {
             case NCA_KM_FWD: return launch_fused_bf_mode<F, NCA_KM_FWD, false, true>(a, grid, st);
-            case NCA_KM_FWD_STORE: return s8 ? launch_fused_bf_mode<F, NCA_KM_FWD_STORE, true, true>(a, grid, st) : launch_fused_bf_mode<F, NCA_KM_FWD_STORE, false, true>(a, grid, st);
-            case NCA_KM_BWD_STORED: return s8 ? hipErrorInvalidValue : launch_fused_bf_mode<F, NCA_KM_BWD_STORED, false, true>(a, grid, st);
+            case NCA_KM_FWD_STORE: return s8 ? launch_fused_bf_mode<F, NCA_KM_FWD_STORE, true, true>(a, grid, st) : hipErrorInvalidValue;        // (the store is the 8-bit one)
             case NCA_KM_BWD_NR: return s8 ? launch_fused_bf_mode<F, NCA_KM_BWD_NR, true, true>(a, grid, st) : launch_fused_bf_mode<F, NCA_KM_BWD_NR, false, true>(a, grid, st);
         }
         return hipErrorInvalidValue;
@@ -2280,17 +1640,14 @@ static hipError_t launch_fused_bf(const NcaFusedArgs& a, int kmode, int grid, hi
     switch (kmode) {
         case NCA_KM_FWD: return launch_fused_bf_mode<F, NCA_KM_FWD, false>(a, grid, st);
         case NCA_KM_BWD: return launch_fused_bf_mode<F, NCA_KM_BWD, false>(a, grid, st);
-        case NCA_KM_FWD_STORE: return s8 ? launch_fused_bf_mode<F, NCA_KM_FWD_STORE, true>(a, grid, st) : launch_fused_bf_mode<F, NCA_KM_FWD_STORE, false>(a, grid, st);
-        // (modes 3 and 4 recompute the last layer from a bf16 block: bf16 staging only; fp8 staging is mode 5)
-        case NCA_KM_BWD_STORED: return s8 ? hipErrorInvalidValue : launch_fused_bf_mode<F, NCA_KM_BWD_STORED, false>(a, grid, st);
-        case NCA_KM_BWD_ONCHIP: return s8 ? hipErrorInvalidValue : launch_fused_bf_mode<F, NCA_KM_BWD_ONCHIP, false>(a, grid, st);
+        case NCA_KM_FWD_STORE: return s8 ? launch_fused_bf_mode<F, NCA_KM_FWD_STORE, true>(a, grid, st) : hipErrorInvalidValue;
         case NCA_KM_BWD_NR: return s8 ? launch_fused_bf_mode<F, NCA_KM_BWD_NR, true>(a, grid, st) : launch_fused_bf_mode<F, NCA_KM_BWD_NR, false>(a, grid, st);
     }
     return hipErrorInvalidValue;
 }
 
 size_t nca_fused_bf16_lds_other(int F, int kmode) {
-    const bool bwd = kmode == NCA_KM_BWD || kmode == NCA_KM_BWD_STORED || kmode == NCA_KM_BWD_ONCHIP || kmode == NCA_KM_BWD_NR;
+    const bool bwd = kmode == NCA_KM_BWD || kmode == NCA_KM_BWD_NR;
     return bf_const_bytes(kmode) + (bwd ? NCA_WAVES * 2 * (F + 1) * sizeof(float) : 0) + (kmode == NCA_KM_BWD_NR ? 2 * bf_wo_floats(F) * sizeof(float) : 0) + 16;       // (+ the tile counter of a resident launch)
 }
 
@@ -2332,5 +1689,3 @@ hipError_t nca_launch_wgrad_bf16(int F, const NcaWgradArgs& a, int nsplit, hipSt
     return hipGetLastError();
 }
 
-// bit 0 NCA_BF_PIPE2, bit 1 NCA_WGRAD_TR, bit 2 NCA_ONCHIP_NR, bit 3 NCA_BF_PIPE, bits 8.. NCA_WAVES: 0x800 is the product build
-int nca_kernels_variant_mask() { return (NCA_BF_PIPE2 ? 1 : 0) | (NCA_WGRAD_TR ? 2 : 0) | (NCA_ONCHIP_NR ? 4 : 0) | (NCA_BF_PIPE ? 8 : 0) | (NCA_WAVES << 8); }

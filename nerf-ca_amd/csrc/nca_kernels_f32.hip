@@ -274,7 +274,10 @@ __device__ __forceinline__ void store_quad(float* p, float a, float b, float c, 
 // next (k-step, row-tile pair) are requested before the current MFMAs issue.
 template <int MT, int KH, int K0>
 __device__ __forceinline__ void x3_sub(const char* __restrict__ sub, const f32x16 (&h)[MT], f32x16 (&acc)[MT]) {
-    constexpr int RG = MT >= 2 ? 2 : 1, NG = MT / RG, NIT = KH * NG;
+#ifndef NCA_X3_RG
+#define NCA_X3_RG 2
+#endif
+    constexpr int RG = MT >= 2 ? NCA_X3_RG : 1, NG = MT / RG, NIT = KH * NG;
     x3_u32x4 A[2][3][RG], B[3];
     auto load = [&](int it, x3_u32x4 (&a)[3][RG]) {
         const int kk = it / NG, m0 = (it % NG) * RG;
@@ -1203,7 +1206,7 @@ __global__ void nca_reduce_f32(const NcaReduceArgs a) {
     // the combination order is fixed, so the result is still bit-reproducible
     float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const float* sp = a.slab + rn.slab_off + le;
-    int64_t stride = a.slab_stride;
+    const int64_t stride = a.slab_stride;
     // rows of this column: the rebuilding jobs of the last F-wide layer may run over more splits than the others
     // (two explicit ranges, W then b, as the scaling below: nothing here assumes the bias follows the weight in the flat buffer)
     const int64_t F2t = (int64_t)rn.F * rn.F;
@@ -1211,12 +1214,6 @@ __global__ void nca_reduce_f32(const NcaReduceArgs a) {
     const bool tail_b = rn.tail_from_sums && le >= rn.tl_b_off && le < rn.tl_b_off + rn.F;
     const bool tail_col = tail_w || tail_b;
     int nsum = tail_col ? a.n_split : a.n_split_std;
-    if (rn.wslab) {
-        // the layer whose weight gradient the dgrad kernel accumulated on chip: one partial per workgroup
-        const int64_t F2 = (int64_t)rn.F * rn.F;
-        if (le >= rn.oc_w_off && le < rn.oc_w_off + F2) { sp = rn.wslab + (le - rn.oc_w_off); stride = rn.wslab_stride; nsum = a.n_wg; }
-        else if (le >= rn.oc_b_off && le < rn.oc_b_off + rn.F) { sp = rn.wslab + F2 + (le - rn.oc_b_off); stride = rn.wslab_stride; nsum = a.n_wg; }
-    }
     int q = 0;
     for (; q + 8 <= nsum; q += 8) {
 #pragma unroll
@@ -1227,7 +1224,7 @@ __global__ void nca_reduce_f32(const NcaReduceArgs a) {
     // the last F-wide layer under tail_from_sums: leave the sum over the splits in slab row 0 (this thread is the only reader of its
     // column) -- nca_reduce_small_f32, launched next, forms dWo from S and s summed over the splits and reads 129 values per output
     // instead of 129 x n_split (it was 83 us of one wave per output walking the slabs: as long at 1 024 rays per step as at 65 536)
-    if (tail_col) a.slab[rn.slab_off + le] = r;          // (tail_from_sums and an on-chip tail layer exclude each other: a tail column is a slab column)
+    if (tail_col) a.slab[rn.slab_off + le] = r;
     // the last F-wide layer's sums were formed without the factor Wo[f] of their output row (nca_layout.hpp)
     if (tail_w) r *= rn.params[rn.wo_off + (le - rn.tl_w_off) / rn.F];
     else if (tail_b) r *= rn.params[rn.wo_off + (le - rn.tl_b_off)];

@@ -374,7 +374,8 @@ hipError_t nca_launch_adam(const NcaAdamArgs& a, hipStream_t st) {
 // jitter one depth each.  Arithmetic in the reference's order and precision (the library is compiled with -ffp-contract=off).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void nca_prepare_batch_k(int64_t R, int S, const int64_t* __restrict__ ids, const double* __restrict__ table,
-                                                           const int64_t* __restrict__ phases, const float* __restrict__ depth, const float* __restrict__ t_rand,
+                                                           const int64_t* __restrict__ phases, int64_t n_rows, int32_t* __restrict__ bad_ids,
+                                                           const float* __restrict__ depth, const float* __restrict__ t_rand,
                                                            double* __restrict__ o, double* __restrict__ d, double* __restrict__ gt, double* __restrict__ w,
                                                            int32_t* __restrict__ ph, float* __restrict__ z, double* __restrict__ dists) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -391,7 +392,11 @@ __global__ __launch_bounds__(256) void nca_prepare_batch_k(int64_t R, int S, con
         dists[k] = k + 1 < S ? (double)__fsub_rn(jitter(k + 1), zk) : 1e-10;
     }
     if (i < R) {
-        const int64_t id = ids[i];
+        int64_t id = ids[i];
+        if (n_rows > 0 && (id < 0 || id >= n_rows)) {          // never reaches memory: clamped, and counted for the caller
+            if (bad_ids) atomicAdd(bad_ids, 1);
+            id = id < 0 ? 0 : n_rows - 1;
+        }
         const double* row = table + id * 12;
 #pragma unroll
         for (int c = 0; c < 3; ++c) { o[i * 3 + c] = row[c]; d[i * 3 + c] = row[3 + c]; }
@@ -400,10 +405,11 @@ __global__ __launch_bounds__(256) void nca_prepare_batch_k(int64_t R, int S, con
         ph[i] = (int32_t)phases[id];
     }
 }
-hipError_t nca_launch_prepare_batch(int64_t R, int S, const int64_t* ids, const double* table, const int64_t* phases, const float* depth, const float* t_rand,
+hipError_t nca_launch_prepare_batch(int64_t R, int S, const int64_t* ids, const double* table, const int64_t* phases, int64_t n_rows, int32_t* bad_ids,
+                                    const float* depth, const float* t_rand,
                                     double* o, double* d, double* gt, double* w, int32_t* ph, float* z, double* dists, hipStream_t st) {
     const int64_t n = R > S ? R : S;
-    hipLaunchKernelGGL(nca_prepare_batch_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, R, S, ids, table, phases, depth, t_rand, o, d, gt, w, ph, z, dists);
+    hipLaunchKernelGGL(nca_prepare_batch_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, R, S, ids, table, phases, n_rows, bad_ids, depth, t_rand, o, d, gt, w, ph, z, dists);
     return hipGetLastError();
 }
 

@@ -25,13 +25,6 @@
 
 enum { NCA_IN_ENC = 0, NCA_IN_HID = 1, NCA_IN_SKIP = 2 };
 
-// EXPERIMENT (off; tools/variant_build_all.sh c8 "-DNCA_CHAIN8=1"): the resident storing forward at width 128 runs the contractions of its
-// hidden-width layers on e4m3 operands (v_mfma_scale_f32_32x32x64_f8f6f4): weights x 2^6 in a second image, layer inputs = the e4m3
-// bytes the epilogue forms for the store anyway.  Everything else -- layer 0, epilogues, store, backward -- is unchanged.
-#ifndef NCA_CHAIN8
-#define NCA_CHAIN8 0
-#endif
-#define NCA_W8_LOG2 6
 struct NcaLayerL {
     int32_t kind;        // NCA_IN_*
     int32_t K;           // natural fan-in
@@ -47,8 +40,6 @@ struct NcaLayerL {
     uint32_t img2_bytes; // x3 hidden layers of width >= 64 likewise: `img` = first half of the k-steps + bias tail, `img2` = the rest (+ Wo tail)
     uint32_t imgT2_off;  // x3: second half of the k-steps of the transposed image
     uint32_t imgT2_bytes;
-    uint32_t img8_off;   // NCA_CHAIN8 (experiment): e4m3 forward image of a hidden-width layer, [row tile][MX k-step][16-byte half][lane][16 B] + the same tails
-    uint32_t img8_bytes;
 };
 
 struct NcaLayout {
@@ -245,14 +236,6 @@ inline int nca_build_layout_bf16(const NcaNet& n, NcaLayout* out, const char** w
         l.imgT_bytes = (uint32_t)y.MT * (uint32_t)(y.F / 16) * 1024u;
         boff += l.imgT_bytes;
         if (l.imgT_bytes > maxb) maxb = l.imgT_bytes;
-    }
-    if (NCA_CHAIN8 && y.F == 128) {
-        for (int jj = 0; jj < y.NL; ++jj) {
-            NcaLayerL& l = y.layer[jj];
-            l.img8_off = boff;
-            l.img8_bytes = (uint32_t)y.MT * 4u * 1024u + tail + (jj == y.NL - 1 ? tail + 16u : 0u);
-            boff += (l.img8_bytes + 1023u) & ~1023u;
-        }
     }
     y.packed_bytes = boff;
     y.max_img_bytes = maxb;

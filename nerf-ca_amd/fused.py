@@ -11,12 +11,48 @@ path with torch ops: if the HIP library is missing these raise.
 from __future__ import annotations
 
 import ctypes as C
+import threading
+import warnings
 from typing import List, Optional, Sequence
 
 import torch
 
 from . import _capi
 from ._capi import NcaNet, NcaRays, check, ptr
+
+
+class PlanScope:
+    """Planner options and the planner's record for ONE caller (a trainer, a test): every ray batch built inside ``with scope:`` carries
+    ``scope.opts`` (NcaRays.plan_opts: they replace the process-wide tunables for those calls only) and has the library write what it
+    decided into ``scope.plan`` (NcaRays.plan_out) -- so two trainers or threads of one process neither change nor read each other's
+    plan.  The batch keeps its scope, so a backward on the autograd engine's thread uses its forward's options.
+
+        with PlanScope(stage_fp8=0) as sc: ...; sc.decided()["bwd_kernel_mode"]
+    """
+    _tls = threading.local()
+
+    def __init__(self, **opts):
+        self.opts = _capi.NcaPlanOpts(**opts)
+        self.plan = _capi.NcaPlan()
+
+    def __enter__(self):
+        stack = getattr(PlanScope._tls, "stack", None)
+        if stack is None:
+            stack = PlanScope._tls.stack = []
+        stack.append(self)
+        return self
+
+    def __exit__(self, *exc):
+        PlanScope._tls.stack.pop()
+        return False
+
+    @staticmethod
+    def current() -> Optional["PlanScope"]:
+        stack = getattr(PlanScope._tls, "stack", None)
+        return stack[-1] if stack else None
+
+    def decided(self) -> dict:
+        return _capi.plan_dict(self.plan)
 
 _ACT = {"softplus": _capi.ACT_SOFTPLUS, "clamp": _capi.ACT_CLAMP}  # anything else -> sigmoid (model_helpers.py:63-70)
 
@@ -227,12 +263,15 @@ class _RayBatch:
                 self.ps_r, self.ps_s = ph.shape[1], 1
             self.ph = ph
         self.act, self.single, self.scale = act_code(act), 1 if single else 0, float(scale)
+        self.scope = PlanScope.current()          # the caller's planner options / record (None: the process-wide ones)
 
     def desc(self, store_format: int = 0) -> NcaRays:
+        sc = self.scope
         return NcaRays(R=self.R, S=self.S, ray_is_f64=1 if self.f64 else 0, origins=ptr(self.o), dirs=ptr(self.d),
                        phase=ptr(self.ph), phase_stride_r=self.ps_r, phase_stride_s=self.ps_s, z=ptr(self.z),
                        z_stride_r=self.z_stride_r, dists=ptr(self.dists), I0=ptr(self.I0), act=self.act,
-                       single_field=self.single, scale=self.scale, store_format=store_format)
+                       single_field=self.single, scale=self.scale, store_format=store_format,
+                       plan_opts=C.addressof(sc.opts) if sc is not None else None, plan_out=C.addressof(sc.plan) if sc is not None else None)
 
 
 # A forward that will be followed by a backward leaves every layer input, the ReLU masks and the raw outputs in a
@@ -240,9 +279,20 @@ class _RayBatch:
 # bf16, 5.9 KB in f32: the store is used when it fits under this limit AND under the device's free memory (below),
 # otherwise the backward recomputes (set to 0 to always recompute).
 STORE_FORWARD_LIMIT_BYTES = 96 << 30
-# how often a backward had to fall back to the recompute path because the store did not fit or could not be allocated:
-# a bench line taken with a non-zero count was not timed on the stored path
+# how often a backward had to fall back to the recompute path because the store did not fit or could not be allocated: a bench line
+# taken with a non-zero count was not timed on the stored path.  Every fallback WARNS (once per size); under NERFCA_STRICT=1 (or
+# STRICT_STORE = True) it is an error -- bench.py runs strict, so that it can never silently time the recompute path.
 STORE_FALLBACKS = 0
+STRICT_STORE: Optional[bool] = None          # None: follow the environment (NERFCA_STRICT=1)
+
+
+def _strict_store() -> bool:
+    import os
+    return bool(STRICT_STORE) if STRICT_STORE is not None else os.environ.get("NERFCA_STRICT") == "1"
+
+
+class StoreFallbackWarning(RuntimeWarning):
+    pass
 
 
 def _usable_bytes(dev) -> int:
@@ -305,6 +355,11 @@ def render_forward_raw(batch: _RayBatch, bs: FieldBinding, bd: Optional[FieldBin
                 store = None
         if sbytes > 0 and store is None:
             STORE_FALLBACKS += 1
+            msg = (f"the forward store of this batch ({sbytes / 2**30:.1f} GiB; limit {store_limit_bytes(dev) / 2**30:.1f} GiB) was not allocated: "
+                   "this backward recomputes the layers (slower; same results in f32, the recompute arithmetic in bf16)")
+            if _strict_store():
+                raise _capi.NcaError(msg + " -- refused under NERFCA_STRICT=1 / fused.STRICT_STORE")
+            warnings.warn(msg, StoreFallbackWarning, stacklevel=2)
     # (the return value names what the forward left in the store -- the planner's choice of staging for this batch; the backward
     # is told through NcaRays.store_format, so a change of the process-wide options in between cannot reinterpret the bytes)
     fmt = check(lib.nca_render_fwd(C.byref(desc), bs.prec,
@@ -313,6 +368,8 @@ def render_forward_raw(batch: _RayBatch, bs: FieldBinding, bd: Optional[FieldBin
                                    ptr(bd.flat) if bd is not None else None,
                                    ptr(pix), ptr(sig_s), ptr(sig_d), ptr(work), wbytes,
                                    ptr(store), store.numel() if store is not None else 0, _stream()))
+    if fmt == _capi.STORE_NONE:
+        store = None          # the planner wrote no store (e.g. the options changed since it was sized): the backward recomputes
     return pix, sig_s, sig_d, (packed_s, packed_d, win_s, four_s, win_d, four_d, store, fmt)
 
 
@@ -551,16 +608,22 @@ def fine_depths_autograd(sig_s, sig_d, z, u, reduce_max=None):
     return _FineDepthsFn.apply(sig_s, sig_d, z, u, reduce_max)
 
 
-def prepare_batch(ids: torch.Tensor, table: torch.Tensor, phases: torch.Tensor, depth: torch.Tensor, t_rand: torch.Tensor):
+def prepare_batch(ids: torch.Tensor, table: torch.Tensor, phases: torch.Tensor, depth: torch.Tensor, t_rand: torch.Tensor,
+                  bad_ids: Optional[torch.Tensor] = None):
     """The per-step ray gather (run_composite.py:262-273) and randomize_depth + interval lengths (model_helpers.py:3-12, 73-74) as ONE
     launch: ``ids`` i64[R] into the resident f64 ray table [N,4,3] and its i64 phase vector -> ``(o, d f64[R,3], gt, w f64[R], ph
-    i32[R], z f32[S], dists f64[S])``.  Bit-identical to the torch ops it replaces."""
+    i32[R], z f32[S], dists f64[S])``.  Bit-identical to the torch ops it replaces.  An id outside the table never reaches memory:
+    it is clamped and counted in ``bad_ids`` (device i32[1], zeroed by the caller; read it when a synchronisation is affordable)."""
     _require_cuda(table, "the ray table")
     dev = table.device
     if table.dtype != torch.float64 or table.dim() != 3 or tuple(table.shape[1:]) != (4, 3) or not table.is_contiguous():
         raise _capi.NcaError("prepare_batch takes the f64 ray table [N, 4, 3]")
     if phases.dtype != torch.int64 or ids.dtype != torch.int64 or not ids.is_contiguous() or not phases.is_contiguous():
         raise _capi.NcaError("prepare_batch takes i64 ray ids and i64 phases")
+    if phases.shape[0] != table.shape[0]:
+        raise _capi.NcaError("prepare_batch: the phase vector has another length than the ray table")
+    if bad_ids is not None and (bad_ids.dtype != torch.int32 or bad_ids.numel() < 1 or bad_ids.device != dev):
+        raise _capi.NcaError("prepare_batch: bad_ids is one i32 on the table's device")
     R, S = ids.shape[0], depth.shape[0]
     dep = depth.detach().to(device=dev, dtype=torch.float32).contiguous()
     tr = t_rand.detach().to(device=dev, dtype=torch.float32).contiguous()
@@ -571,8 +634,8 @@ def prepare_batch(ids: torch.Tensor, table: torch.Tensor, phases: torch.Tensor, 
     ph = torch.empty(R, dtype=torch.int32, device=dev)
     z = torch.empty(S, dtype=torch.float32, device=dev)
     dists = torch.empty(S, dtype=torch.float64, device=dev)
-    check(_capi.lib().nca_prepare_batch(R, S, ptr(ids), ptr(table), ptr(phases), ptr(dep), ptr(tr), ptr(o), ptr(d), ptr(gt), ptr(w), ptr(ph), ptr(z),
-                                        ptr(dists), _stream()))
+    check(_capi.lib().nca_prepare_batch(R, S, ptr(ids), ptr(table), ptr(phases), int(table.shape[0]), ptr(bad_ids), ptr(dep), ptr(tr),
+                                        ptr(o), ptr(d), ptr(gt), ptr(w), ptr(ph), ptr(z), ptr(dists), _stream()))
     return o, d, gt, w, ph, z, dists
 
 

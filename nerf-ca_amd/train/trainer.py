@@ -87,10 +87,28 @@ class _FromRank0(torch.autograd.Function):
         return (g if ctx.rank == 0 else torch.zeros_like(g)), None
 
 
+def _scoped(method):
+    """Run a trainer method inside the trainer's own planner scope (fused.PlanScope): its options apply to the library calls the
+    method makes, and the planner's decisions land in ``trainer.plan_scope`` -- not in (or from) another trainer's."""
+    import functools
+
+    @functools.wraps(method)
+    def wrapper(self, *a, **kw):
+        with self.plan_scope:
+            return method(self, *a, **kw)
+    return wrapper
+
+
 class CompositeTrainer:
     def __init__(self, cfg: TrainConfig, static_model, temp_model, data, device, rank: int = 0, world: int = 1,
                  seed: int = 0, render: Optional[Callable] = None, fused_adam: Optional[bool] = None, fused_loss: Optional[bool] = None,
-                 static_model_fine=None, temp_model_fine=None, fine_sampler: Optional[Callable] = None):
+                 static_model_fine=None, temp_model_fine=None, fine_sampler: Optional[Callable] = None, plan_opts: Optional[dict] = None):
+        """``plan_opts``: this trainer's planner options (keys of ``_capi.NcaPlanOpts``: stage_fp8, stage_fp8_min_tiles,
+        resident_min_tiles, wgrad_rebuild_weight_pct) -- they apply to this trainer's library calls only; ``self.plan()`` is what the
+        planner decided for them."""
+        from ..fused import PlanScope
+        self.plan_scope = PlanScope(**(plan_opts or {}))
+        self._bad_ids = None               # device i32[1]: ray ids outside the table that nca_prepare_batch clamped (checked at the syncing calls)
         self.cfg, self.s, self.t, self.data, self.device = cfg, static_model, temp_model, data, device
         self.s_fine, self.t_fine = static_model_fine, temp_model_fine
         self.n_fine = int(cfg.depth_samples_per_ray_fine)
@@ -99,6 +117,8 @@ class CompositeTrainer:
         self.fine_sampler = fine_sampler or MH._fused.fine_depths      # (sig_s, sig_d, z, u, reduce_max=) -> z_all[R, S + n_fine]
         self.rank, self.world, self.seed = rank, world, seed
         on_cuda = device.type == "cuda" if isinstance(device, torch.device) else str(device).startswith("cuda")
+        if on_cuda:                        # (allocated here, not at first use: the first use may be inside a graph capture)
+            self._bad_ids = torch.zeros(1, dtype=torch.int32, device=device)
         if fused_loss is None:             # default on the GPU: the autograd-free step with the HIP loss kernel (step_fused);
             fused_loss = on_cuda           # fused_loss=False keeps the reference's torch loss functions under autograd
         # (an injected renderer or fine sampler -- the CPU tests' oracle -- runs under autograd: the fused steps call the library)
@@ -238,6 +258,19 @@ class CompositeTrainer:
             self.last_fine_terms_autograd = tf      # (the early stop reads the fine pass's entropy / favor terms, run_composite.py:298-310)
         return loss, pixel, terms
 
+    def plan(self) -> dict:
+        """What the planner decided in THIS trainer's last forward / backward (NcaPlan, include/nerfca_hip.h)."""
+        return self.plan_scope.decided()
+
+    def check_ray_ids(self) -> None:
+        """One device read: raise if a ray id of any step so far fell outside the ray table (the library clamped it)."""
+        if self._bad_ids is not None:
+            n = int(self._bad_ids.item())
+            if n:
+                from .. import _capi
+                raise _capi.NcaError(f"{n} ray ids outside the ray table of {self.data.rays_train.shape[0]} rows reached nca_prepare_batch (clamped, results invalid)")
+
+    @_scoped
     def step(self, n_iter: int):
         if self.fused_loss:
             return self.step_fused(n_iter)
@@ -265,7 +298,7 @@ class CompositeTrainer:
         rt, pt = self.data.rays_train, self.data.phases_train
         if rt.is_cuda and rt.dtype == torch.float64 and pt.dtype == torch.int64 and rt.is_contiguous() and pt.dim() == 1 and my.dtype == torch.int64:
             from ..fused import prepare_batch
-            return prepare_batch(my.contiguous(), rt, pt, self.depth, t_rand)
+            return prepare_batch(my.contiguous(), rt, pt, self.depth, t_rand, bad_ids=self._bad_ids)
         rays = rt.index_select(0, my)
         phases = pt.index_select(0, my)
         o, d, gt, w = rays[:, 0, :], rays[:, 1, :], rays[:, 2, 0], rays[:, 3, 0]
@@ -294,6 +327,11 @@ class CompositeTrainer:
         need = FU.forward_store_bytes(whole, bs, bd)
         limit = FU.store_limit_bytes(self.device)
         micro = n_loc if need <= limit or need == 0 or limit <= 0 else max(1, int(n_loc * (limit / need)))
+        while micro < n_loc and micro > 1:          # (a store's size is not linear in the rays: slack tile slots, alignment -- make sure the micro-batch's really fits)
+            probe = _RayBatch(o[:micro], d[:micro], phases[:micro], self.I0[:micro], z, dists, c.output_activation, False, 1e-2)
+            if FU.forward_store_bytes(probe, bs, bd) <= limit:
+                break
+            micro = max(1, int(micro * 0.9))
         weights = self.loss_weights(n_iter)
         terms = grads_s = grads_d = None
         for m0 in range(0, n_loc, micro):
@@ -313,6 +351,7 @@ class CompositeTrainer:
                 grads_d += gd_m
         return terms, grads_s, grads_d
 
+    @_scoped
     def step_fused(self, n_iter: int):
         """Same step without an autograd graph: fused forward -> fused loss kernel (values + d loss/d(pix,
         sigma)) -> fused backward -> (all-reduce) -> Adam.  Returns (loss, pixel, terms f64[13]) on device;
@@ -469,7 +508,9 @@ class CompositeTrainer:
         return tot
 
     def early_stop(self) -> bool:
-        """Host-side read of the flag (one device sync): call it at the logging cadence, not every step."""
+        """Host-side read of the flag (one device sync): call it at the logging cadence, not every step.  (Also where a ray id
+        outside the table, clamped by the library, surfaces: ``check_ray_ids``.)"""
+        self.check_ray_ids()
         return bool(self.stop_flag) if self.stop_flag is not None else False
 
     # -- the same step as a replayed HIP graph ---------------------------------------------------
@@ -604,6 +645,7 @@ class CompositeTrainer:
         ev.record()
         self._rec_done[k] = ev
 
+    @_scoped
     def step_graph(self, n_iter: int):
         """``step_fused`` with the device work replayed from a captured HIP graph and the library's Adam + LinearLR
         (its own moment buffers: do not interleave with ``step``/``step_fused`` in one run).  Per step the host only
@@ -648,12 +690,14 @@ class CompositeTrainer:
 
     # -- held-out view (run_composite.py:346-413) ------------------------------------------------
     @torch.no_grad()
+    @_scoped
     def evaluate(self, n_iter: int, chunk_rays: int = 65536):
         """The display_every block of the reference: render the held-out view (one fixed depth jitter drawn at set-up,
         run_composite.py:134), the weighted pixel loss with unit weights, all loss terms and ``test_loss`` with this
         iteration's weights, ``test_psnr = -10 log10(test_loss)`` (the reference's definition, :391), and the static /
         dynamic images each field renders on its own (:407-413; un-normalised ``I0 - sum sigma dists``)."""
         c, d, dev = self.cfg, self.data, self.device
+        self.check_ray_ids()
         if getattr(self, "_test_jitter", None) is None:
             self._test_jitter = torch.rand(self.depth.shape, generator=torch.Generator().manual_seed(self.seed * 7919 + 1))
         z = MH.randomize_depth(self.depth, dev, self._test_jitter)

@@ -13,7 +13,7 @@ import torch
 from conftest import nca_option
 from oracle import nerfca_oracle as O
 from test_hip_parity import make_dynamic, make_static
-from test_onchip_bf16 import _hip_grads, _inputs
+from test_recompute_bf16 import _hip_grads, _inputs
 
 pytestmark = pytest.mark.gpu
 
@@ -51,13 +51,13 @@ def _nets(dev, F, early, it_d, gen):
 
 
 # (F, early): 128 x 4 is the bench's net -- its five forward images (155 KiB) fit, and so do the four transposed images of the backward
-# under fp8 staging (128 KiB; bf16 staging adds the recomputed layer's forward image: too much)
+# from the store (128 KiB).  fp8 = 0: no store -- the recompute backward carries both nets' forward AND transposed images: streaming, one launch
 @pytest.mark.parametrize("R,S,F,early", [(8, 16, 32, 1), (33, 50, 64, 3), (64, 192, 128, 4), (7, 500, 128, 4), (300, 70, 128, 2), (40, 130, 64, 0)])
 @pytest.mark.parametrize("it_d", [75000, 30000])
 @pytest.mark.parametrize("fp8", [1, 0])
 def test_resident_equals_streaming_render_and_gradients(dev, R, S, F, early, it_d, fp8):
-    """Training path (forward with a store, backward from it, on-chip layer off so that the backward may run resident) and
-    the plain forward, resident forced vs never: bit-identical outputs and gradients; the forward really took two launches."""
+    """Training path (forward with a store and backward from it; or, fp8 = 0, no store and the recompute backward) and the plain
+    forward, resident forced vs never: bit-identical outputs and gradients; the forward really took two launches."""
     from nerfca_amd import render_rays
     gen = torch.Generator().manual_seed(4100 + R + S)
     s, t = _nets(dev, F, early, it_d, gen)
@@ -65,14 +65,12 @@ def test_resident_equals_streaming_render_and_gradients(dev, R, S, F, early, it_
     dists = O.composite(torch.zeros(R, S, 1), torch.zeros(R, S, 1), I0, d, z)[3]
     got, launches, plain = {}, [], {}
     for name, thr in (("streaming", -1), ("resident", 0)):
-        with nca_option("RESIDENT_MIN_TILES", thr), nca_option("ONCHIP_MIN_TILES", -1), nca_option("STAGE_FP8", fp8), count_launches(launches):
+        with nca_option("RESIDENT_MIN_TILES", thr), nca_option("STAGE_FP8", fp8), count_launches(launches):
             got[name] = _hip_grads(s, t, dev, o, d, ph, I0, z, dists, cp, cs, cd)
         with nca_option("RESIDENT_MIN_TILES", thr), torch.no_grad():
             plain[name] = render_rays(s, t, o.to(dev), d.to(dev), ph.to(dev), I0.to(dev), z.to(dev), dists.to(dev))
     if early > 0:                               # (a net without hidden layers has no store: recompute backward, one launch)
-        # bf16 staging recomputes the last layer: its forward image + the transposed images of 128 x 4 do not fit (one launch, streaming)
-        bwd = 2 if (fp8 or not (F == 128 and early == 4)) else 1
-        assert launches == [(1, 1), (2, bwd)], launches
+        assert launches == [(1, 1), (2, 2 if fp8 else 1)], launches          # (the recompute backward is one streaming launch for both nets)
     for i in range(3):
         assert torch.equal(got["resident"][i], got["streaming"][i]), i
         assert torch.equal(plain["resident"][i], plain["streaming"][i]), i
@@ -81,8 +79,8 @@ def test_resident_equals_streaming_render_and_gradients(dev, R, S, F, early, it_
 
 
 @pytest.mark.parametrize("R,S,F,early", [(16, 100, 128, 4), (9, 64, 64, 2)])
-def test_resident_equals_streaming_with_onchip_layer_and_depth_gradients(dev, R, S, F, early):
-    """Resident forward feeding the on-chip backward (the default pairing at the bench size) and the depth-gradient path."""
+def test_resident_equals_streaming_with_depth_gradients(dev, R, S, F, early):
+    """Resident forward and backward with the depth-gradient path (bf16 output-gradient blocks from an 8-bit staged store)."""
     gen = torch.Generator().manual_seed(4200 + R + S)
     s, t = _nets(dev, F, early, 75000, gen)
     o, d, ph, z, I0, cp, cs, cd = _inputs(R, S, gen)
@@ -90,7 +88,7 @@ def test_resident_equals_streaming_with_onchip_layer_and_depth_gradients(dev, R,
     for want_depth in (False, True):
         got = {}
         for name, thr in (("streaming", -1), ("resident", 0)):
-            with nca_option("RESIDENT_MIN_TILES", thr), nca_option("ONCHIP_MIN_TILES", 0):
+            with nca_option("RESIDENT_MIN_TILES", thr):
                 got[name] = _hip_grads(s, t, dev, o, d, ph, I0, z, dists, cp, cs, cd, want_depth=want_depth)
         for i in range(3):
             assert torch.equal(got["resident"][i], got["streaming"][i]), i

@@ -21,7 +21,7 @@ from conftest import nca_option, rel_err
 from oracle import nerfca_oracle as O
 from test_fp8_stage import _oracle_grads
 from test_hip_parity import BF_GRAD, BF_OUT, make_dynamic, make_static
-from test_onchip_bf16 import _hip_grads, _inputs
+from test_recompute_bf16 import _hip_grads, _inputs
 
 pytestmark = pytest.mark.gpu
 
@@ -210,11 +210,11 @@ def test_fuzz_resident_equals_streaming_and_oracle(dev, R, S, F, early, it_s, it
     t.update_freq_mask_alpha(it_d, 150000)
     got = {}
     for name, thr in (("streaming", -1), ("resident", 0)):
-        with nca_option("RESIDENT_MIN_TILES", thr), nca_option("ONCHIP_MIN_TILES", -1), nca_option("STAGE_FP8", fp8):
+        with nca_option("RESIDENT_MIN_TILES", thr), nca_option("STAGE_FP8", fp8):
             got[name] = _hip_grads(s, t, dev, o, d, ph, I0, z, dists, cp, cs, cd)
     g16 = got["streaming"][3]
     if staged:
-        with nca_option("RESIDENT_MIN_TILES", -1), nca_option("ONCHIP_MIN_TILES", -1), nca_option("STAGE_FP8", 0):
+        with nca_option("RESIDENT_MIN_TILES", -1), nca_option("STAGE_FP8", 0):
             g16 = _hip_grads(s, t, dev, o, d, ph, I0, z, dists, cp, cs, cd)[3]
     for i in range(3):
         assert torch.equal(got["resident"][i], got["streaming"][i]), i

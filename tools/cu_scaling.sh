@@ -1,9 +1,8 @@
 #!/bin/bash
-# Run ON the GPU box: the bench step with every persistent grid sized for 256 / 192 / 128 / 64 compute units (NCA_CUS), for the product
-# library and (if built: tools/elim_build.sh 16) the timing-only build without the forward's H stores.  A kernel bound by what a CU can
+# Run ON the GPU box: the bench step with every persistent grid sized for 256 / 192 / 128 / 64 compute units (NCA_CUS).  A kernel bound by what a CU can
 # issue takes 256/k times longer on k CUs; one bound by something the whole chip shares (power, HBM, fabric) takes less than that.
 # Needs the override build (the shipped library does not read NCA_CUS):  tools/variant_build_all.sh cus "-DNCA_CU_OVERRIDE=1"
-for LIB in _cus _exp16; do
+for LIB in _cus; do
   L=nerf-ca_amd/lib/libnerfca_hip$LIB.so; [ -f $L ] || continue
   for K in 256 192 128 64; do
     NCA_CUS=$K NERFCA_LIB=$PWD/$L timeout -k 10 200 python3 bench.py --eager --steps 6 --warmup 2 --no-extras --no-cpu-baseline > /tmp/cus.json 2>/dev/null || { echo "lib$LIB cus $K failed"; continue; }

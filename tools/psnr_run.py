@@ -5,9 +5,11 @@ Trains the composite model on the synthetic data set of bench.py (40 training im
 same initial weights, ray batches and depth jitter in every arithmetic the library offers --
 
     f32             the parity mode (within 1e-5 of the reference's arithmetic per step, tests/test_hip_parity.py)
-    bf16_bf16stage  bf16 MFMA operands, layer inputs / output gradients cross HBM as bf16 (NCA_OPT_STAGE_FP8 = 0)
-    bf16_fp8stage   bf16 MFMA operands, staged as e4m3 / e5m2 (NCA_OPT_STAGE_FP8 = 1)
-    bf16            bf16 with the planner's own choice of staging for this batch size (the library default)
+    bf16_nostore    bf16 MFMA operands everywhere: no forward store, the backward recomputes the layers, nothing is staged in 8 bits
+                    (NCA_OPT_STAGE_FP8 = 0; until round 3 this option selected a bf16-staged store -- retired: bf16_bf16stage in old records)
+    bf16_fp8stage   bf16 MFMA operands, the forward store staged as e4m3 / e5m2 (NCA_OPT_STAGE_FP8 = 1)
+    bf16            bf16 with the planner's own choice for this batch size (the library default: the 8-bit staged store)
+    f32_kick<eps>   f32 from initial weights moved once by a relative eps (e.g. f32_kick2e-3: one bf16 ulp)
 
 -- and evaluates the held-out view every `--every` steps with CompositeTrainer.evaluate (MSE PSNR and the reference's own
 test_psnr, run_composite.py:391).  One JSON line; run on the GPU box:
@@ -27,7 +29,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-VARIANTS = {"f32": ("f32", None), "bf16": ("bf16", None), "bf16_bf16stage": ("bf16", 0), "bf16_fp8stage": ("bf16", 1),
+VARIANTS = {"f32": ("f32", None), "bf16": ("bf16", None), "bf16_nostore": ("bf16", 0), "bf16_fp8stage": ("bf16", 1),
             # f32 again from initial weights moved by 1e-6 (relative): the run-to-run spread of the parity mode itself, i.e. the
             # resolution of a PSNR comparison at this batch size
             "f32_perturbed": ("f32", None)}
@@ -40,20 +42,21 @@ def run(variant, args, dev, data, log=None, seed=0):
     from nerfca_amd.model.CPPN import CPPN
     from nerfca_amd.model.Temporal import Temporal
     from nerfca_amd.train.trainer import CompositeTrainer, TrainConfig
-    prec, stage = VARIANTS[variant]
-    old = _capi.get_option(_capi.OPT_STAGE_FP8)
-    if stage is not None:
-        _capi.set_option(_capi.OPT_STAGE_FP8, stage)
-    try:
+    kick = None
+    if variant.startswith("f32_kick"):          # f32_kick<eps>: f32 from initial weights moved once by a relative eps (several per run, unlike f32_perturbed)
+        kick, (prec, stage) = float(variant[len("f32_kick"):]), ("f32", None)
+    else:
+        prec, stage = VARIANTS[variant]
+    if True:
         torch.manual_seed(1 + 1000 * seed)
         sdef, tdef = synthetic.net_definitions(dev)
         s, t = CPPN(sdef).to(dev), Temporal(tdef).to(dev)
-        if variant == "f32_perturbed":
+        if variant == "f32_perturbed" or kick is not None:
             with torch.no_grad():
                 g = torch.Generator(device=dev).manual_seed(12345 + seed)
                 for m in (s, t):
                     for prm in m.parameters():
-                        prm.mul_(1.0 + args.perturb * torch.randn(prm.shape, generator=g, device=dev))
+                        prm.mul_(1.0 + (kick if kick is not None else args.perturb) * torch.randn(prm.shape, generator=g, device=dev))
         nerfca_amd.set_precision(prec, s, t)
         # --cross-eval: a second pair of models in the OTHER arithmetic that takes over the trained weights at every evaluation -- separates
         # what an arithmetic costs the training from what it costs the rendering of the held-out view
@@ -65,7 +68,7 @@ def run(variant, args, dev, data, log=None, seed=0):
         # schedules compressed to the length of the run (the reference anneals over 150 k steps of 1 024 rays)
         cfg = TrainConfig(depth_samples_per_ray_coarse=args.samples, img_sample_size=args.rays, static_pos_enc_window_decay_steps=args.steps,
                           temp_pos_enc_window_decay_steps=args.steps, lr_decay_steps=args.steps)
-        tr = CompositeTrainer(cfg, s, t, data, dev, seed=seed)
+        tr = CompositeTrainer(cfg, s, t, data, dev, seed=seed, plan_opts=None if stage is None else {"stage_fp8": stage})
         tr.update_windows(0)
         curve = []
 
@@ -98,18 +101,16 @@ def run(variant, args, dev, data, log=None, seed=0):
         for it in range(args.steps):
             loss, _, _ = step(it)
             if it == 0:
-                fp8_seen[0] = bool(_capi.last_plan().get("stage_fp8"))       # what the planner staged this batch size in
+                fp8_seen[0] = bool(tr.plan().get("stage_fp8"))       # what THIS trainer's planner did (8-bit staged store or none)
             if (it + 1) % args.every == 0:
                 point(it + 1)
         torch.cuda.synchronize()
         if args.jsonl:          # every finished run is on disk at once: a run that is cut off keeps what it has
             with open(args.jsonl, "a") as f:
                 f.write(json.dumps({"variant": variant, "seed": seed, "label": args.label, "library": _capi.build_info(), "rays": args.rays, "samples": args.samples,
-                                    "steps": args.steps, "perturb": args.perturb if variant == "f32_perturbed" else None, "curve": curve}) + "\n")
+                                    "steps": args.steps, "perturb": kick if kick is not None else (args.perturb if variant == "f32_perturbed" else None), "curve": curve}) + "\n")
         return {"curve": curve, "final_train_loss": float(loss), "wall_s_incl_eval": time.perf_counter() - t0, "seed": seed,
                 "stage_fp8_in_effect": None if prec == "f32" else fp8_seen[0]}
-    finally:
-        _capi.set_option(_capi.OPT_STAGE_FP8, old)
 
 
 def gap_statistics(runs, names, tail=1):

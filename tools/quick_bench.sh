@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run ON the GPU box: per-kernel milliseconds of the bench step under the given environment settings, one line each.
-#   tools/quick_bench.sh "NCA_ONCHIP=1" "NCA_ONCHIP=0" ...
+#   tools/quick_bench.sh "NCA_RESIDENT=force" "NCA_RESIDENT=0" "NCA_STAGE_FP8=0" ...
 for E in "$@"; do
   env $E timeout -k 10 200 python3 bench.py --eager --no-extras --no-cpu-baseline --steps 6 --warmup 2 > /tmp/qb.json 2>/tmp/qb.err || { echo "$E: bench failed"; tail -3 /tmp/qb.err; continue; }
   python3 -c "
