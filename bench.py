@@ -488,6 +488,18 @@ def psnr_record(args, dev):
     out["config"] = f"{det}^2 detector x {S} samples/ray, 4 views x 10 phases + 1 held-out view, {R} rays/step, {steps} steps, schedules compressed to the run"
     out["gap_f32_vs_oracle_db"] = out["hip_f32"]["psnr_mse_db"] - out["cpu_oracle"]["psnr_mse_db"]
     out["gap_bf16_vs_f32_db"] = out["hip_bf16"]["psnr_mse_db"] - out["hip_f32"]["psnr_mse_db"]
+    # the multi-seed record at the BENCH batch (replayed from the committed table: five f32 runs of 1 000 steps do not fit a bench
+    # run; tests/test_psnr_gates.py re-measures seeds 0, 1, 2 on every GPU test run): per seed the bf16 gap and what the parity mode
+    # itself moves by when its initial weights are rounded-to-bf16-sized perturbed once -- the resolution of "matched PSNR" there
+    try:
+        tab = json.load(open(os.path.join(ROOT, "profiles", "r04_psnr_bench_batch_seed_table.json")))
+        out["seed_spread"] = {"source": "profiles/r04_psnr_bench_batch_seed_table.json (replayed; DESIGN.md 4.5)", "config": tab["config"], "gate": tab["note"],
+                              "per_seed": {sd: {"f32_psnr_mse_db": v["f32"]["psnr_mse_db"], "bf16_minus_f32_db": v["gap_to_f32_db"]["bf16"]["psnr_mse_db"],
+                                                "f32_kick2e-3_minus_f32_db": v["gap_to_f32_db"]["f32_kick2e-3"]["psnr_mse_db"],
+                                                "within_0.1_db": v["gate"]["plain_0.1_clause"], "within_f32_own_spread": v["gate"]["passes"]}
+                                           for sd, v in tab["seeds"].items()}}
+    except (OSError, ValueError, KeyError):
+        out["seed_spread"] = None
     return out
 
 

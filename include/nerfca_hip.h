@@ -187,9 +187,12 @@ int nca_mlp_fwd(const NcaNet* net, int32_t prec, const void* packed, const float
                 const float* params, int64_t N, const float* pts /*[N,3]*/, const int32_t* phase /*[N] or NULL*/,
                 float* raw /*[N]*/, void* stream);
 int64_t nca_mlp_bwd_workspace(const NcaNet* net, int32_t prec, int64_t N, int64_t max_bytes);
+/* g_latents: NULL, or f32[N, T] (ABI 9): d loss / d latent INPUT of every point -- what autograd hands back through
+ * Temporal.query_time's latent vectors (model/Temporal.py:113-136), one row per point whichever points share a table row; `grads`
+ * still carries the table-row sums in its first P*T floats. */
 int nca_mlp_bwd(const NcaNet* net, int32_t prec, const void* packed, const float* win, const float* four,
                 const float* params, int64_t N, const float* pts, const int32_t* phase, const float* g_raw /*[N]*/,
-                float* grads, void* work, int64_t work_bytes, void* stream);
+                float* grads, float* g_latents, void* work, int64_t work_bytes, void* stream);
 
 /* ---- stand-alone compositing of raw fields: render_volume_density_composite / render_volume_density
  *      (train/model_helpers.py:72-97), as the reference's evaluation code calls them

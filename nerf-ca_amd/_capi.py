@@ -101,7 +101,7 @@ SYMBOLS = {
                                        _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _P]),
     "nca_mlp_fwd": (C.c_int, [C.POINTER(NcaNet), _I32, _P, _P, _P, _P, _I64, _P, _P, _P, _P]),
     "nca_mlp_bwd_workspace": (_I64, [C.POINTER(NcaNet), _I32, _I64, _I64]),
-    "nca_mlp_bwd": (C.c_int, [C.POINTER(NcaNet), _I32, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _I64, _P]),
+    "nca_mlp_bwd": (C.c_int, [C.POINTER(NcaNet), _I32, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "nca_composite_fwd": (C.c_int, [_I64, _I32, _I32, _I32, C.c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
     "nca_composite_bwd": (C.c_int, [_I64, _I32, _I32, _I32, C.c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "nca_loss_workspace": (_I64, [_I64]),

@@ -796,7 +796,7 @@ static void add_jobs_bf16(NcaWgradArgs* w, int net_index, const NcaLayout& y, in
 
 static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t units, int64_t tiles_per_unit, float* const* grads,
                    void* work, int64_t work_bytes, hipStream_t st, const void* store = nullptr, int64_t store_bytes = 0, float* g_depth = nullptr,
-                   int32_t store_format = NCA_STORE_NONE, NcaPlan* plan_out = nullptr) {
+                   int32_t store_format = NCA_STORE_NONE, NcaPlan* plan_out = nullptr, float* g_latents = nullptr) {
     const bool bf = prec == NCA_PREC_BF16;
     NcaPlan g_plan;       // (published at the end; what the last forward decided stays on record)
     memset(&g_plan, 0, sizeof(g_plan));
@@ -969,6 +969,19 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
             else HIPCHK(nca_launch_fused_f32(F, a, stored ? NCA_KM_BWD_STORED : NCA_KM_BWD, p.grid, st));
         }
         if (nr) HIPCHK(nca_launch_sum_tile_records(reinterpret_cast<const char*>(scratch), 2 * p.tile_stride, p.tile_stride - NCA_D8_REC_BYTES, a.ntiles, a.nnets, F, oslab, p.grid, st));
+        if (g_latents) {     // d loss / d latent input per point, from the same D_0 blocks (points mode, one net)
+            NcaLatgradArgs lg;
+            memset(&lg, 0, sizeof(lg));
+            lg.ntiles = bf ? 2 * a.ntiles : a.ntiles;
+            lg.n0 = u0 * wave_samples;
+            lg.N = a.N;
+            lg.T = lays[0].T; lg.Kenc = lays[0].Kenc; lg.ldw = lays[0].layer[0].K; lg.bf16 = bf ? 1 : 0;
+            lg.w0 = binds[0].params + lays[0].layer[0].w_off;
+            lg.dscratch = scratch; lg.d_total = p.tile_stride;
+            lg.drow = a.net[0].drow0 + (bf ? nca_bf_doff(lays[0], 0, false) : 0);
+            lg.g_lat = g_latents;
+            HIPCHK(nca_launch_latgrad_f32(F, lg, st));
+        }
         if (g_depth) {       // d loss / d depth from the D_0 blocks this chunk's dgrad launch just wrote
             NcaZgradArgs zg;
             memset(&zg, 0, sizeof(zg));
@@ -1223,7 +1236,7 @@ extern "C" int64_t nca_mlp_bwd_workspace(const NcaNet* net, int32_t prec, int64_
 
 extern "C" int nca_mlp_bwd(const NcaNet* net, int32_t prec, const void* packed, const float* win, const float* four,
                            const float* params, int64_t N, const float* pts, const int32_t* phase, const float* g_raw,
-                           float* grads, void* work, int64_t work_bytes, void* stream) {
+                           float* grads, float* g_latents, void* work, int64_t work_bytes, void* stream) {
     int rc = check_prec(prec);
     if (rc) return rc;
     if (N <= 0) return fail(NCA_E_INVALID, "empty point batch");
@@ -1236,13 +1249,14 @@ extern "C" int nca_mlp_bwd(const NcaNet* net, int32_t prec, const void* packed, 
     rc = fill_net(binds[0], &a.net[0], prec);
     if (rc) return rc;
     if (a.net[0].lay.T > 0 && !phase) return fail(NCA_E_INVALID, "dynamic net needs phase ids");
+    if (g_latents && a.net[0].lay.T <= 0) return fail(NCA_E_INVALID, "per-point latent gradients of a net without latents");
     a.N = N;
     a.pts = pts;
     a.phase = phase;
     a.g_raw = g_raw;
     float* gr[2] = {grads, nullptr};
     const int ts = tile_samples(prec);
-    return run_bwd(a, prec, binds, (N + ts - 1) / ts, 1, gr, work, work_bytes, (hipStream_t)stream);
+    return run_bwd(a, prec, binds, (N + ts - 1) / ts, 1, gr, work, work_bytes, (hipStream_t)stream, nullptr, 0, nullptr, NCA_STORE_NONE, nullptr, g_latents);
 }
 
 // ---------------------------------------------------------------------------------- losses

@@ -253,6 +253,15 @@ struct NcaZgradArgs {
     NcaZgradNet net[2];
 };
 hipError_t nca_launch_zgrad_f32(const NcaZgradArgs& a, hipStream_t st);
+// d loss / d latent input per point from the D_0 blocks of a point backward's chunk scratch (nca_mlp_bwd with g_latents)
+struct NcaLatgradArgs {
+    int64_t ntiles, n0, N;          // 32-sample tiles of this chunk; index of its first point; points in all
+    int32_t T, Kenc, ldw, bf16;
+    const float* w0;                // natural W0 [F][ldw]
+    const float* dscratch; int64_t d_total, drow;      // as NcaZgradArgs (f32: rows of 32 floats; bf16: bytes)
+    float* g_lat;                   // [N][T]
+};
+hipError_t nca_launch_latgrad_f32(int F, const NcaLatgradArgs& a, hipStream_t st);
 hipError_t nca_launch_pack_f32(const NcaLayout& y, const float* prm, void* out, hipStream_t st);
 hipError_t nca_launch_fused_f32(int F, const NcaFusedArgs& a, int kmode, int grid, hipStream_t st);
 hipError_t nca_launch_wgrad_f32(const NcaWgradArgs& a, int nsplit, hipStream_t st);

@@ -891,6 +891,75 @@ __global__ __launch_bounds__(256) void nca_zgrad_f32(const NcaZgradArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// d loss / d latent INPUT per point (Temporal.query_time with latent vectors that require a gradient, model/Temporal.py:113-136:
+// autograd gives every point its own  W0[:, Kenc .. Kenc + T)^T D_0[:, n]).  One wave per 32-sample tile of the point backward's
+// chunk scratch: lane (r, h) holds its rows of D_0 of sample r (read exactly as nca_zgrad_f32 reads them, f32 quads or bf16
+// fragments), multiplies with the latent columns of W0 staged in LDS, and the two lane halves are added.  T * F / 2 FMAs per lane.
+// ------------------------------------------------------------------------------------------
+template <int F>
+__global__ __launch_bounds__(256) void nca_latgrad_f32(const NcaLatgradArgs a) {
+    constexpr int MT = F / 32;
+    extern __shared__ __attribute__((aligned(16))) float lw[];        // [F][T]: W0[o][Kenc + t]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 31, lh = lane >> 5;
+    for (int i = threadIdx.x; i < F * a.T; i += 256) lw[i] = a.w0[(int64_t)(i / a.T) * a.ldw + a.Kenc + (i % a.T)];
+    __syncthreads();
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < a.ntiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t n = a.n0 + tile * 32 + lr;
+        float D[MT][16];
+        if (a.bf16) {
+            const char* db = reinterpret_cast<const char*>(a.dscratch) + tile * a.d_total + a.drow + lane * 16;
+#pragma unroll
+            for (int ks = 0; ks < 2 * MT; ++ks) {
+                const uint4 w4 = *reinterpret_cast<const uint4*>(db + ks * 1024);
+                const unsigned ww[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    D[ks >> 1][8 * (ks & 1) + 2 * u] = __uint_as_float(ww[u] << 16);
+                    D[ks >> 1][8 * (ks & 1) + 2 * u + 1] = __uint_as_float(ww[u] & 0xffff0000u);
+                }
+            }
+        } else {
+            const float* df = a.dscratch + (tile * a.d_total + a.drow) * 32 + lane * 4;
+#pragma unroll
+            for (int mq = 0; mq < 4 * MT; ++mq) {
+                const float4 dv = *reinterpret_cast<const float4*>(df + mq * 256);
+                D[mq >> 2][4 * (mq & 3)] = dv.x; D[mq >> 2][4 * (mq & 3) + 1] = dv.y;
+                D[mq >> 2][4 * (mq & 3) + 2] = dv.z; D[mq >> 2][4 * (mq & 3) + 3] = dv.w;
+            }
+        }
+        for (int t = 0; t < a.T; ++t) {
+            float s = 0.f;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int row = 32 * m + (i & 3) + 8 * (i >> 2) + 4 * lh;          // accumulator register i of row tile m (both scratch formats)
+                    s = fmaf(lw[row * a.T + t], D[m][i], s);
+                }
+            s += __shfl_xor(s, 32);
+            if (lh == 0 && n < a.N) a.g_lat[n * a.T + t] = s;
+        }
+    }
+}
+template <int F>
+static hipError_t launch_latgrad(const NcaLatgradArgs& a, hipStream_t st) {
+    const int lds = F * a.T * (int)sizeof(float);
+    int64_t blocks = (a.ntiles + 3) / 4;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(nca_latgrad_f32<F>, dim3((unsigned)blocks), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+hipError_t nca_launch_latgrad_f32(int F, const NcaLatgradArgs& a, hipStream_t st) {
+    switch (F) {
+        case 32: return launch_latgrad<32>(a, st);
+        case 64: return launch_latgrad<64>(a, st);
+        case 128: return launch_latgrad<128>(a, st);
+    }
+    return hipErrorInvalidValue;
+}
+
 template <int F>
 static hipError_t launch_zgrad(const NcaZgradArgs& a, hipStream_t st) {
     const int lds = 16 * (F / 32) * 64 * 4 * (int)sizeof(float);

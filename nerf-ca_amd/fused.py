@@ -720,7 +720,7 @@ class _PointsFn(torch.autograd.Function):
         grads = torch.empty(binding.flat.numel(), dtype=torch.float32, device=pts.device)
         work, wbytes = _alloc_workspace(lambda cap: check(lib.nca_mlp_bwd_workspace(C.byref(binding.net), binding.prec, N, cap)), pts.device)
         check(lib.nca_mlp_bwd(C.byref(binding.net), binding.prec, ptr(packed), ptr(win), ptr(four), ptr(binding.flat), N,
-                              ptr(pts), ptr(phase), ptr(g), ptr(grads), ptr(work), wbytes, _stream()))
+                              ptr(pts), ptr(phase), ptr(g), ptr(grads), None, ptr(work), wbytes, _stream()))
         binding.last_grad = grads
         return (None, None, None, *binding.split_grads(grads))
 
@@ -739,10 +739,12 @@ def eval_points(model, pts: torch.Tensor, phase: Optional[torch.Tensor] = None) 
 
 
 class _PointsLatentsFn(torch.autograd.Function):
-    """raw[n] = net(points[n], table[ids[n]]) with a caller-supplied latent table in place of the module's time_latents."""
+    """raw[n] = net(points[n], table[ids[n]]) with a caller-supplied latent table in place of the module's time_latents.  ``lat`` =
+    the latent vector of every point ([N, T]; table[ids[n]] == lat[n]): it is only here so that autograd routes the PER-POINT latent
+    gradient the library returns (nca_mlp_bwd's g_latents) to wherever each point's vector came from."""
 
     @staticmethod
-    def forward(ctx, binding: FieldBinding, pts, ids, table, *params):
+    def forward(ctx, binding: FieldBinding, pts, ids, table, lat, *params):
         lib = _capi.lib()
         packed = binding.ensure_packed()
         win, four = binding.module._enc_buffers()
@@ -762,22 +764,22 @@ class _PointsLatentsFn(torch.autograd.Function):
         N = pts.shape[0]
         g = _f32c(g_raw).reshape(-1)
         grads = torch.empty(binding.flat.numel(), dtype=torch.float32, device=pts.device)
+        g_lat = torch.empty((N, binding.net.T), dtype=torch.float32, device=pts.device) if ctx.needs_input_grad[4] else None
         work, wbytes = _alloc_workspace(lambda cap: check(lib.nca_mlp_bwd_workspace(C.byref(binding.net), binding.prec, N, cap)), pts.device)
         check(lib.nca_mlp_bwd(C.byref(binding.net), binding.prec, ptr(packed), ptr(win), ptr(four), ptr(prm), N, ptr(pts), ptr(ids), ptr(g), ptr(grads),
-                              ptr(work), wbytes, _stream()))
-        g_table = grads[: ctx.n_lat].clone().view(-1, binding.net.T) if ctx.needs_input_grad[3] else None
+                              ptr(g_lat), ptr(work), wbytes, _stream()))
         grads[: ctx.n_lat] = 0.0                            # the table is not the module's time_latents
-        return (None, None, None, g_table, *binding.split_grads(grads))
+        return (None, None, None, None, g_lat, *binding.split_grads(grads))
 
 
 def eval_points_with_latents(model, pts: torch.Tensor, latents: torch.Tensor) -> torch.Tensor:
     """Temporal.query_time: f32[n,3], latent vectors f32[n,T] -> f32[n,1].
 
-    The distinct latent vectors of the call become rows of temporary latent tables (P rows per launch) and the kernels' own
-    latent-table gradient (the sum over the points that use a row) is handed to the FIRST point that carries that vector.  That is
-    the reference's autograd gradient (Temporal.py:113-136) whenever equal rows are one autograd value -- an expanded / repeated /
-    indexed smaller table, which is how forward_composite itself builds them (Temporal.py:147-149) -- or all rows differ; a leaf tensor
-    with repeated rows would get the sum on one of them and is refused."""
+    The kernels gather latents from a table by id, so the distinct latent vectors of the call become rows of temporary latent tables
+    (P rows per launch).  Gradients with respect to the passed vectors are PER POINT, as the reference's autograd gives them
+    (Temporal.py:113-136): the backward returns W0[:, latent columns]^T D_0 of every point (nca_mlp_bwd's g_latents) and autograd adds
+    them up wherever rows share a source -- an expanded / indexed smaller table, a leaf with repeated rows, or equal rows that come
+    from different tensors alike."""
     _require_cuda(pts, "query points")
     binding: FieldBinding = model._binding
     T, P = binding.net.T, binding.net.P
@@ -790,20 +792,14 @@ def eval_points_with_latents(model, pts: torch.Tensor, latents: torch.Tensor) ->
     if p.shape[0] == 0:
         return torch.empty((0, 1), dtype=torch.float32, device=p.device)
     uniq, inv = torch.unique(lat, dim=0, return_inverse=True)
-    if want_lat:
-        if latents.is_leaf and uniq.shape[0] != lat.shape[0]:
-            raise _capi.NcaError("query_time: a leaf tensor of latent vectors with repeated rows: the per-row gradients of equal rows are not provided "
-                                 "(pass the distinct vectors and index / expand them, as forward_composite does)")
-        # first point of every distinct vector
-        first = torch.full((uniq.shape[0],), lat.shape[0], dtype=torch.int64, device=p.device).scatter_reduce(
-            0, inv, torch.arange(lat.shape[0], device=p.device), reduce="amin")
     out = torch.zeros((p.shape[0], 1), dtype=torch.float32, device=p.device)
     for u0 in range(0, uniq.shape[0], P):                   # one temporary table of P rows per launch
         sel = ((inv >= u0) & (inv < u0 + P)).nonzero().flatten()
-        rows = lat_g.index_select(0, first[u0:u0 + P]) if want_lat else uniq[u0:u0 + P]
+        rows = uniq[u0:u0 + P]
         table = torch.cat([rows, torch.zeros((P - rows.shape[0], T), dtype=torch.float32, device=p.device)]) if rows.shape[0] < P else rows
         ids = (inv.index_select(0, sel) - u0).to(torch.int32).contiguous()
-        vals = _PointsLatentsFn.apply(binding, p.index_select(0, sel).contiguous(), ids, table, *binding.params())
+        lat_sel = lat_g.index_select(0, sel) if want_lat else lat.index_select(0, sel)
+        vals = _PointsLatentsFn.apply(binding, p.index_select(0, sel).contiguous(), ids, table, lat_sel, *binding.params())
         out = out.index_put((sel,), vals)
     return out
 

@@ -184,42 +184,66 @@ def test_query_time_with_latent_vectors(golden, dev):
         assert torch.equal(t.query_time(x.to(dev), t.time_latents[ts.long().to(dev)]), t.forward_composite(x.to(dev), ts.to(dev)))
 
 
-def test_query_time_latent_vector_gradients(golden, dev):
-    """Gradients with respect to the latent vectors passed to query_time (plain autograd in the reference, Temporal.py:113-136):
-    a pool of 23 vectors indexed per point, as forward_composite builds its own (:147-149), against autograd through the oracle;
-    a leaf with repeated rows is refused."""
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_query_time_latent_vector_gradients(golden, dev, prec):
+    """Gradients with respect to the latent vectors passed to query_time (plain autograd in the reference, Temporal.py:113-136) are
+    PER POINT (nca_mlp_bwd's g_latents): a pool of 23 vectors indexed per point, as forward_composite builds its own (:147-149); a
+    LEAF with repeated rows (every row its own gradient -- refused until round 3); equal rows that come from two different tensors
+    (each source gets its own points' gradient, not the sum -- ADVICE r3); all rows distinct.  Against autograd through the oracle."""
     from oracle import nerfca_oracle as O
-    from nerfca_amd import _capi
+    from nerfca_amd import set_precision
     g = golden("mlps")
     pd = g.prefixed("d_F64_e4_l0_p_")
     t = make_dynamic(pd, dev, F=64, early=4, late=0, T=8)
+    set_precision(prec, t)
+    tol = 1e-5 if prec == "f32" else 3e-2
     t.update_freq_mask_alpha(60000, 150000)
     x = g["x"]
     n = x.shape[0]
     gen = torch.Generator().manual_seed(6)
     pool = torch.rand(23, 8, generator=gen)
     pick = torch.randint(0, 23, (n,), generator=gen)
-    sd = O.NetSpec(num_filters=64, num_time_dim=8)
+    sd = O.NetSpec(num_filters=64, num_time_dim=8, emulate_bf16=(prec == "bf16"))
     win = O.freq_mask_alpha(12, 60000, 150000, 1)[0]
+
+    def oracle(lat_rows):
+        yo = O.mlp({k: v.clone() for k, v in pd.items()}, sd, torch.cat([O.encode(x[: lat_rows.shape[0]], sd, win), lat_rows], -1))
+        (yo * g["gout"][: lat_rows.shape[0]]).sum().backward()
+        return yo.detach()
+
+    def hip(lat_rows):
+        y = t.query_time(x[: lat_rows.shape[0]].to(dev), lat_rows)
+        (y * g["gout"][: lat_rows.shape[0]].to(dev)).sum().backward()
+        return y.detach().cpu()
+
+    # (1) an indexed pool
     pool_o = pool.clone().requires_grad_(True)
-    yo = O.mlp({k: v.clone() for k, v in pd.items()}, sd, torch.cat([O.encode(x, sd, win), pool_o[pick]], -1))
-    (yo * g["gout"]).sum().backward()
+    yo = oracle(pool_o[pick])
     pool_d = pool.to(dev).requires_grad_(True)
-    y = t.query_time(x.to(dev), pool_d[pick.to(dev)])
-    assert rel_err(y.detach().cpu(), yo.detach()) < 1e-5
-    (y * g["gout"].to(dev)).sum().backward()
-    assert rel_err(pool_d.grad.cpu(), pool_o.grad) < 1e-5
-    leaf = pool[pick].to(dev).requires_grad_(True)
-    with pytest.raises(_capi.NcaError, match="repeated rows"):
-        t.query_time(x.to(dev), leaf)
-    # all rows distinct: every point owns its gradient
+    y = hip(pool_d[pick.to(dev)])
+    assert rel_err(y, yo) < (1e-5 if prec == "f32" else 2e-3)
+    assert rel_err(pool_d.grad.cpu(), pool_o.grad) < tol
+    # (2) a leaf with repeated rows: one gradient row per point
+    leaf_o = pool[pick].clone().requires_grad_(True)
+    oracle(leaf_o)
+    leaf_d = pool[pick].to(dev).requires_grad_(True)
+    hip(leaf_d)
+    assert rel_err(leaf_d.grad.cpu(), leaf_o.grad) < tol
+    # (3) equal rows from two autograd sources: cat([a, a.clone()]) -- each source keeps the gradient of ITS points
+    half = n // 2
+    a_o, b_o = pool[pick[:half]].clone().requires_grad_(True), pool[pick[:half]].clone().requires_grad_(True)
+    oracle(torch.cat([a_o, b_o]))
+    a_d, b_d = pool[pick[:half]].to(dev).requires_grad_(True), pool[pick[:half]].to(dev).requires_grad_(True)
+    hip(torch.cat([a_d, b_d]))
+    assert rel_err(a_d.grad.cpu(), a_o.grad) < tol and rel_err(b_d.grad.cpu(), b_o.grad) < tol
+    assert not torch.equal(a_d.grad, b_d.grad)
+    # (4) all rows distinct
     m = min(n, 16)
     lat_o = torch.rand(m, 8, generator=gen).requires_grad_(True)
-    yo2 = O.mlp({k: v.clone() for k, v in pd.items()}, sd, torch.cat([O.encode(x[:m], sd, win), lat_o], -1))
-    (yo2 * g["gout"][:m]).sum().backward()
+    oracle(lat_o)
     lat_d = lat_o.detach().to(dev).requires_grad_(True)
-    (t.query_time(x[:m].to(dev), lat_d) * g["gout"][:m].to(dev)).sum().backward()
-    assert rel_err(lat_d.grad.cpu(), lat_o.grad) < 1e-5
+    hip(lat_d)
+    assert rel_err(lat_d.grad.cpu(), lat_o.grad) < tol
 
 
 def test_magix_shape_full_size_step(dev):

@@ -10,6 +10,8 @@ same initial weights, ray batches and depth jitter in every arithmetic the libra
     bf16_fp8stage   bf16 MFMA operands, the forward store staged as e4m3 / e5m2 (NCA_OPT_STAGE_FP8 = 1)
     bf16            bf16 with the planner's own choice for this batch size (the library default: the 8-bit staged store)
     f32_kick<eps>   f32 from initial weights moved once by a relative eps (e.g. f32_kick2e-3: one bf16 ulp)
+    f32_resample    f32 from the SAME initial weights with another stream of ray batches and depth jitter (the trainer's seed + 7919):
+                    what the mini-batch sampling alone moves the result by
 
 -- and evaluates the held-out view every `--every` steps with CompositeTrainer.evaluate (MSE PSNR and the reference's own
 test_psnr, run_composite.py:391).  One JSON line; run on the GPU box:
@@ -43,7 +45,10 @@ def run(variant, args, dev, data, log=None, seed=0):
     from nerfca_amd.model.Temporal import Temporal
     from nerfca_amd.train.trainer import CompositeTrainer, TrainConfig
     kick = None
-    if variant.startswith("f32_kick"):          # f32_kick<eps>: f32 from initial weights moved once by a relative eps (several per run, unlike f32_perturbed)
+    batch_seed = seed + (7919 if variant == "f32_resample" else 0)
+    if variant == "f32_resample":
+        prec, stage = "f32", None
+    elif variant.startswith("f32_kick"):          # f32_kick<eps>: f32 from initial weights moved once by a relative eps (several per run, unlike f32_perturbed)
         kick, (prec, stage) = float(variant[len("f32_kick"):]), ("f32", None)
     else:
         prec, stage = VARIANTS[variant]
@@ -68,7 +73,7 @@ def run(variant, args, dev, data, log=None, seed=0):
         # schedules compressed to the length of the run (the reference anneals over 150 k steps of 1 024 rays)
         cfg = TrainConfig(depth_samples_per_ray_coarse=args.samples, img_sample_size=args.rays, static_pos_enc_window_decay_steps=args.steps,
                           temp_pos_enc_window_decay_steps=args.steps, lr_decay_steps=args.steps)
-        tr = CompositeTrainer(cfg, s, t, data, dev, seed=seed, plan_opts=None if stage is None else {"stage_fp8": stage})
+        tr = CompositeTrainer(cfg, s, t, data, dev, seed=batch_seed, plan_opts=None if stage is None else {"stage_fp8": stage})
         tr.update_windows(0)
         curve = []
 
