@@ -275,6 +275,28 @@ def test_fp8_stage_at_natural_resident_threshold_vs_oracle(dev):
             assert l2 < 2e-2, (k, l2)
     print(f"fp8 staging, resident plan at {R} x {S}: worst gradient distance from the emulating oracle {worst:.2e} (max-norm), {worst_l2:.2e} (relative L2), "
           f"projection coefficient within {worst_scale:.2e} of 1")
+    # The same question for the other bf16 plan that ships: no forward store (stage_fp8 = 0, given per call) --
+    # resident two-launch forward, recompute backward with bf16 operands everywhere -- against the oracle that rounds to bf16 only.
+    from nerfca_amd import fused
+    go16 = _oracle_grads(ps, ss, pd, sd, win, win, o, d, ph, I0, z, cp, cs, cd, False, fp8=False, ray_chunk=512)[4]
+    with fused.PlanScope(stage_fp8=0) as sc:
+        p0, a0, b0, g0 = _hip_grads(s, t, dev, o, d, ph, I0, z, dists, cp, cs, cd)
+    assert sc.decided()["bwd_kernel_mode"] == 1 and sc.decided()["fwd_store_format"] == 0 and sc.decided()["fwd_resident"] == 1, sc.decided()
+    assert torch.equal(p0, pr) and torch.equal(a0, ar) and torch.equal(b0, br)
+    w16 = l16 = s16 = 0.0
+    for k in go16:
+        e = rel_err(g0[k].cpu(), go16[k])
+        w16 = max(w16, e)
+        assert e < BF_GRAD, (k, e)
+        x, y = g0[k].detach().cpu().double().flatten(), go16[k].detach().double().flatten()
+        if y.numel() >= 64:
+            scale = float((x * y).sum() / (y * y).sum())
+            l2 = float((x - y).norm() / y.norm())
+            l16, s16 = max(l16, l2), max(s16, abs(scale - 1.0))
+            assert abs(scale - 1.0) < 5e-3, (k, scale)
+            assert l2 < 2e-2, (k, l2)
+    print(f"no store (recompute backward, bf16 operands) at {R} x {S}: worst distance from the bf16-emulating oracle {w16:.2e} (max-norm), {l16:.2e} (relative L2), "
+          f"projection coefficient within {s16:.2e} of 1")
 
 
 def test_parity_mode_at_scale_vs_f64_oracle(dev):
