@@ -340,86 +340,85 @@ def measure(args, prec, stage_fp8, data, dev, rank, world, use_pg, steps, warmup
     from nerfca_amd import _capi
     from nerfca_amd import fused as fused_mod
     fused_mod.STRICT_STORE = True
-    if True:
-        tr = make_trainer(args, prec, data, dev, rank, world, use_pg, plan_opts=None if stage_fp8 is None else {"stage_fp8": stage_fp8})
+    tr = make_trainer(args, prec, data, dev, rank, world, use_pg, plan_opts=None if stage_fp8 is None else {"stage_fp8": stage_fp8})
 
-        def barrier():
-            torch.cuda.synchronize()
-            if use_pg:
-                torch.distributed.barrier()
-            torch.cuda.synchronize()
+    def barrier():
+        torch.cuda.synchronize()
+        if use_pg:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
 
-        base_iter = 75000    # steady state: half of the frequency bands open
-        step = tr.step_graph if args.graph else tr.step
-        fallbacks0 = fused_mod.STORE_FALLBACKS
-        for i in range(warmup):
+    base_iter = 75000    # steady state: half of the frequency bands open
+    step = tr.step_graph if args.graph else tr.step
+    fallbacks0 = fused_mod.STORE_FALLBACKS
+    for i in range(warmup):
+        step(base_iter + i)
+    barrier()
+    _capi.timing_reset()
+    _capi.timing_enable(not args.graph)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss, _, _ = step(base_iter + warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    loss = float(loss)
+    plan = tr.plan()            # of this trainer's last backward (graph: of the capture)
+    sustained = None
+    if sustained_steps >= 200 and args.graph:
+        for i in range(sustained_steps - 100):
             step(base_iter + i)
         barrier()
-        _capi.timing_reset()
-        _capi.timing_enable(not args.graph)
-        t0 = time.perf_counter()
-        for i in range(steps):
-            loss, _, _ = step(base_iter + warmup + i)
+        ts = time.perf_counter()
+        for i in range(100):
+            step(base_iter + i)
         barrier()
-        dt = time.perf_counter() - t0
-        loss = float(loss)
-        plan = tr.plan()            # of this trainer's last backward (graph: of the capture)
-        sustained = None
-        if sustained_steps >= 200 and args.graph:
-            for i in range(sustained_steps - 100):
-                step(base_iter + i)
-            barrier()
-            ts = time.perf_counter()
-            for i in range(100):
-                step(base_iter + i)
-            barrier()
-            sustained = {"ms_per_step": (time.perf_counter() - ts) * 10.0, "over": f"the last 100 of {sustained_steps} further graph-replayed steps (back to back after the timed region)",
-                         "rays_per_s": rays_per_rank(args, world) * world * 100 / (time.perf_counter() - ts),
-                         "in_kernel_clock": "profiles/r03_clock_probe.txt (tools/clock_probe.sh: the diagnostic build that stamps s_memtime / s_memrealtime; no stamp executes in this build)"}
-        timed_steps, eager_dt = steps, dt
-        eager_ms = None
-        if args.graph:       # events cannot be recorded inside a replayed graph: time the same kernels eagerly, outside dt
-            timed_steps = max(1, min(args.kernel_steps, steps))
-            tr.step(base_iter)          # (untimed: the eager step's first pass allocates its own store, and first-touch page mapping shows in the kernels)
-            tr.step(base_iter + 1)
-            barrier()
-            _capi.timing_reset()
-            _capi.timing_enable(True)
-            te = time.perf_counter()
-            for i in range(timed_steps):
-                tr.step(base_iter + i)
-            barrier()
-            eager_dt = time.perf_counter() - te
-            eager_ms = eager_dt / timed_steps * 1e3       # the same step with host-launched kernels and torch's Adam
-            plan = tr.plan()
-        _capi.timing_enable(False)
-        if use_pg:
-            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-            torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-            dt = float(tmax.item())
-        kern = kernel_table(args, timed_steps, plan, world)
+        sustained = {"ms_per_step": (time.perf_counter() - ts) * 10.0, "over": f"the last 100 of {sustained_steps} further graph-replayed steps (back to back after the timed region)",
+                     "rays_per_s": rays_per_rank(args, world) * world * 100 / (time.perf_counter() - ts),
+                     "in_kernel_clock": "profiles/r03_clock_probe.txt (tools/clock_probe.sh: the diagnostic build that stamps s_memtime / s_memrealtime; no stamp executes in this build)"}
+    timed_steps, eager_dt = steps, dt
+    eager_ms = None
+    if args.graph:       # events cannot be recorded inside a replayed graph: time the same kernels eagerly, outside dt
+        timed_steps = max(1, min(args.kernel_steps, steps))
+        tr.step(base_iter)          # (untimed: the eager step's first pass allocates its own store, and first-touch page mapping shows in the kernels)
+        tr.step(base_iter + 1)
+        barrier()
         _capi.timing_reset()
-        fp8 = bool(plan.get("stage_fp8"))
-        label = "f32" if prec == "f32" else ("bf16+fp8stage" if fp8 else "bf16")
-        rec = {"value": rays_per_rank(args, world) * world * steps / dt, "unit": "rays/s", "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "dtype": label,
-               "arithmetic": {"f32": "f32 (hidden layers on the bf16 matrix cores from exact 3-way splits): 1e-5 relative vs the reference's f32 path per step (tests/test_hip_parity.py)",
-                              "bf16": "bf16 MFMA operands everywhere, f32 accumulation, f32 master weights; no forward store: the backward recomputes the layers, nothing is staged in 8 bits",
-                              "bf16+fp8stage": "bf16 MFMA operands for the MLP contractions (forward and dgrad), f32 accumulation, f32 master weights; the layer inputs (e4m3) and output "
-                                               "gradients (e5m2, per-tile power-of-two scale) cross HBM in 8 bits and the weight gradient contracts them on the MX-fp8 matrix path; PSNR-gated "
-                                               "(tests/test_psnr_gates.py)"}[label],
-               "hip_graph": bool(args.graph), "eager_ms_per_step": eager_ms, "kernel_table_steps": timed_steps, "final_loss": loss,
-               "plan": {"stage_fp8": fp8, "backward": BWD_MODES.get(plan.get("bwd_kernel_mode"), str(plan.get("bwd_kernel_mode"))),
-                        "resident_weight_images": {"fwd": bool(plan.get("fwd_resident")), "bwd": bool(plan.get("bwd_resident"))},
-                        "ray_chunks": plan.get("chunks"),
-                        "wgrad": {"jobs": plan.get("wgrad_jobs"), "splits": plan.get("wgrad_splits"), "splits_rebuild_jobs": plan.get("wgrad_splits_rebuild")},
-                        "launches_per_step": {k: (kern[k]["launches"] // max(timed_steps, 1)) for k in ("fwd", "bwd_dgrad", "bwd_wgrad")}},
-               "roofline": roofline_of(args, prec, kern, eager_dt, plan, dt / steps * 1e3, world),
-               "store_fallbacks": fused_mod.STORE_FALLBACKS - fallbacks0}       # > 0: some backward ran on the recompute path (store did not fit)
-        if sustained:
-            rec["sustained"] = sustained
-        del tr
-        torch.cuda.empty_cache()
-        return rec
+        _capi.timing_enable(True)
+        te = time.perf_counter()
+        for i in range(timed_steps):
+            tr.step(base_iter + i)
+        barrier()
+        eager_dt = time.perf_counter() - te
+        eager_ms = eager_dt / timed_steps * 1e3       # the same step with host-launched kernels and torch's Adam
+        plan = tr.plan()
+    _capi.timing_enable(False)
+    if use_pg:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+    kern = kernel_table(args, timed_steps, plan, world)
+    _capi.timing_reset()
+    fp8 = bool(plan.get("stage_fp8"))
+    label = "f32" if prec == "f32" else ("bf16+fp8stage" if fp8 else "bf16")
+    rec = {"value": rays_per_rank(args, world) * world * steps / dt, "unit": "rays/s", "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "dtype": label,
+           "arithmetic": {"f32": "f32 (hidden layers on the bf16 matrix cores from exact 3-way splits): 1e-5 relative vs the reference's f32 path per step (tests/test_hip_parity.py)",
+                          "bf16": "bf16 MFMA operands everywhere, f32 accumulation, f32 master weights; no forward store: the backward recomputes the layers, nothing is staged in 8 bits",
+                          "bf16+fp8stage": "bf16 MFMA operands for the MLP contractions (forward and dgrad), f32 accumulation, f32 master weights; the layer inputs (e4m3) and output "
+                                           "gradients (e5m2, per-tile power-of-two scale) cross HBM in 8 bits and the weight gradient contracts them on the MX-fp8 matrix path; PSNR-gated "
+                                           "(tests/test_psnr_gates.py)"}[label],
+           "hip_graph": bool(args.graph), "eager_ms_per_step": eager_ms, "kernel_table_steps": timed_steps, "final_loss": loss,
+           "plan": {"stage_fp8": fp8, "backward": BWD_MODES.get(plan.get("bwd_kernel_mode"), str(plan.get("bwd_kernel_mode"))),
+                    "resident_weight_images": {"fwd": bool(plan.get("fwd_resident")), "bwd": bool(plan.get("bwd_resident"))},
+                    "ray_chunks": plan.get("chunks"),
+                    "wgrad": {"jobs": plan.get("wgrad_jobs"), "splits": plan.get("wgrad_splits"), "splits_rebuild_jobs": plan.get("wgrad_splits_rebuild")},
+                    "launches_per_step": {k: (kern[k]["launches"] // max(timed_steps, 1)) for k in ("fwd", "bwd_dgrad", "bwd_wgrad")}},
+           "roofline": roofline_of(args, prec, kern, eager_dt, plan, dt / steps * 1e3, world),
+           "store_fallbacks": fused_mod.STORE_FALLBACKS - fallbacks0}       # > 0: some backward ran on the recompute path (store did not fit)
+    if sustained:
+        rec["sustained"] = sustained
+    del tr
+    torch.cuda.empty_cache()
+    return rec
 
 
 def psnr_record(args, dev):

@@ -317,12 +317,20 @@ class CompositeTrainer:
         lo, hi = (R * self.rank) // self.world, (R * (self.rank + 1)) // self.world
         my = ids[lo:hi]
         o, d, gt, w, phases, z, dists = self._prepare(my, self.draw_jitter(n_iter))
+        return self._micro_batched(o, d, gt, w, phases, z, dists, R, self.loss_weights(n_iter), None)
+
+    def _micro_batched(self, o, d, gt, w, phases, z, dists, R, weights, weights_dev):
+        """Fused forward -> loss kernel -> fused backward of this rank's rays, over as many ray micro-batches as keep the forward
+        store under the limit; ``(terms, grads_s, grads_d)`` summed.  Also the body of the captured graph step (the number of
+        micro-batches is fixed at capture, like everything else about the step's structure)."""
+        from ..fused import _RayBatch, fused_losses, render_backward_raw, render_forward_raw
+        c = self.cfg
         bs, bd = self.s._binding, self.t._binding
         # Rays are independent given the weights and every loss term is a sum over rays (times the GLOBAL 1/R), so the
         # step may run over ray micro-batches and add up: that keeps the forward store (the tensors autograd would keep)
         # under fused.STORE_FORWARD_LIMIT_BYTES at any batch size instead of falling back to the recompute backward.
         from .. import fused as FU
-        n_loc = hi - lo
+        n_loc = o.shape[0]
         whole = _RayBatch(o, d, phases, self.I0[:n_loc], z, dists, c.output_activation, False, 1e-2)
         need = FU.forward_store_bytes(whole, bs, bd)
         limit = FU.store_limit_bytes(self.device)
@@ -332,13 +340,13 @@ class CompositeTrainer:
             if FU.forward_store_bytes(probe, bs, bd) <= limit:
                 break
             micro = max(1, int(micro * 0.9))
-        weights = self.loss_weights(n_iter)
+        self.micro_batches = (n_loc + micro - 1) // micro
         terms = grads_s = grads_d = None
         for m0 in range(0, n_loc, micro):
             m1 = min(n_loc, m0 + micro)
             batch = whole if micro == n_loc else _RayBatch(o[m0:m1], d[m0:m1], phases[m0:m1], self.I0[: m1 - m0], z, dists, c.output_activation, False, 1e-2)
             pix, sig_s, sig_d, keep = render_forward_raw(batch, bs, bd, for_backward=True)
-            t_m, g_pix, g_s, g_d = fused_losses(pix, gt[m0:m1], w[m0:m1], sig_s, sig_d, dists, c, weights, inv_R=1.0 / R)
+            t_m, g_pix, g_s, g_d = fused_losses(pix, gt[m0:m1], w[m0:m1], sig_s, sig_d, dists, c, weights, inv_R=1.0 / R, weights_dev=weights_dev)
             gs_m, gd_m = render_backward_raw(batch, bs, bd, keep, g_pix, g_s, g_d)
             del keep
             if terms is None:
@@ -560,11 +568,9 @@ class CompositeTrainer:
 
         def front():
             o, d, gt, w, phases, z, dists = self._prepare(self._ids_buf, rec32[:S])
-            batch = _RayBatch(o, d, phases, self.I0[: hi - lo], z, dists, c.output_activation, False, 1e-2)
-            pix, sig_s, sig_d, keep = render_forward_raw(batch, bs, bd, for_backward=True)
-            terms, g_pix, g_s, g_d = fused_losses(pix, gt, w, sig_s, sig_d, dists, c, (0.0, 0.0, 0.0, 0.0), inv_R=1.0 / R,
-                                                  weights_dev=rec64)
-            grads_s, grads_d = render_backward_raw(batch, bs, bd, keep, g_pix, g_s, g_d)
+            # (one micro-batch at the bench size; several where the whole batch's forward store would not fit -- BASELINE configs[3]'s
+            # 512^2 x 256 in f32 keeps 376 GiB -- instead of the recompute backward the graph step silently fell back to until round 3)
+            terms, grads_s, grads_d = self._micro_batched(o, d, gt, w, phases, z, dists, R, (0.0, 0.0, 0.0, 0.0), rec64)
             out["terms"] = terms
             out["flat"] = torch.cat([grads_d, grads_s, torch.stack([terms[8], terms[5]]).to(torch.float32)])                    # (+ the early-stop pair)
 

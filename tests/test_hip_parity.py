@@ -1518,17 +1518,22 @@ def test_stored_forward_backward_equals_recompute(dev, prec, it_d, R, S, F, earl
 
 
 @pytest.mark.parametrize("prec", ["f32", "bf16"])
-def test_fused_step_over_ray_micro_batches(dev, prec):
-    """When the forward store of the whole batch would exceed fused.STORE_FORWARD_LIMIT_BYTES, step_fused runs the batch as
-    ray micro-batches (forward with store -> loss kernel with the GLOBAL 1/R -> backward) and adds up gradients and
-    loss terms: same loss, same terms, same parameters after the optimiser steps as the single-batch step."""
+@pytest.mark.parametrize("graph", [False, True])
+def test_fused_step_over_ray_micro_batches(dev, prec, graph):
+    """When the forward store of the whole batch would exceed fused.STORE_FORWARD_LIMIT_BYTES, step_fused -- and the graph-replayed
+    step, whose captured body is the same micro-batch loop (until round 3 it fell back to the recompute backward there, silently) --
+    runs the batch as ray micro-batches (forward with store -> loss kernel with the GLOBAL 1/R -> backward) and adds up gradients and
+    loss terms: same loss, same terms, same parameters after the optimiser steps as the single-batch step, under fused.STRICT_STORE
+    (a store that does not fit is an error, not a fallback)."""
     from nerfca_amd import fused, set_precision, synthetic
     from nerfca_amd.model.CPPN import CPPN
     from nerfca_amd.model.Temporal import Temporal
     from nerfca_amd.train.trainer import CompositeTrainer, TrainConfig
     data = synthetic.make_dataset(16, 48, dev, views=synthetic.TRAIN_VIEWS[:2], n_phases=3, F=32)
     outs = []
-    saved = fused.STORE_FORWARD_LIMIT_BYTES
+    saved = fused.STORE_FORWARD_LIMIT_BYTES, fused.STRICT_STORE
+    fused.STRICT_STORE = True
+    micro = []
     try:
         for limit in (96 << 30, 1 << 20):        # 512 rays x 48 samples need ~3 MB (bf16) / ~6 MB (f32) of store
             fused.STORE_FORWARD_LIMIT_BYTES = limit
@@ -1540,10 +1545,12 @@ def test_fused_step_over_ray_micro_batches(dev, prec):
                               l1_weight_start=1e-3, l1_weight_end=1e-3, occl_weight_start=1e-2, dynamic_entro_weight_start=1e-3,
                               favor_s_weight_start=1e-3, entro_mask_thre=1e-6)
             tr = CompositeTrainer(cfg, s, t, data, dev, seed=5, fused_loss=True)
-            rec = [tr.step_fused(1000 + it)[2].cpu().clone() for it in range(3)]
+            rec = [(tr.step_graph if graph else tr.step_fused)(1000 + it)[2].cpu().clone() for it in range(3)]
             outs.append((rec, torch.cat([p.detach().flatten() for p in tr.params]).cpu()))
+            micro.append(tr.micro_batches)
     finally:
-        fused.STORE_FORWARD_LIMIT_BYTES = saved
+        fused.STORE_FORWARD_LIMIT_BYTES, fused.STRICT_STORE = saved
+    assert micro[0] == 1 and micro[1] > 1, micro
     tol = 1e-5 if prec == "f32" else 1e-3
     for a, b in zip(outs[0][0], outs[1][0]):
         assert torch.allclose(a, b, rtol=tol, atol=1e-12), (a, b)

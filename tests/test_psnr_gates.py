@@ -56,57 +56,84 @@ def psnr_run():
     return mod
 
 
-def per_seed_gate(psnr_run, args, dev, data, seeds, label):
-    """Runs f32 and bf16 per seed, the f32 kick only where a gap reaches 0.1 dB; asserts the gate; returns the table."""
-    table = []
-    for sd in seeds:
-        f32 = psnr_run.run("f32", args, dev, data, seed=sd)
-        bf = psnr_run.run("bf16", args, dev, data, seed=sd)
-        assert bf["stage_fp8_in_effect"] is True, "the planner's default is the 8-bit staged store at every batch size"
-        for r in (f32, bf):
-            assert r["curve"][-1]["psnr_mse_db"] - r["curve"][0]["psnr_mse_db"] > 25.0, (sd, r["curve"])
-        gap = {k: bf["curve"][-1][k] - f32["curve"][-1][k] for k in KEYS}
-        row = {"seed": sd, "f32": {k: f32["curve"][-1][k] for k in KEYS}, "gap_bf16": gap, "f32_kick_moves": None, "wall": (f32["wall_s_incl_eval"], bf["wall_s_incl_eval"])}
-        row["f32_resample_moves"] = None
-        if max(abs(g) for g in gap.values()) >= 0.1:
-            kick = psnr_run.run(KICK, args, dev, data, seed=sd)
-            row["f32_kick_moves"] = {k: kick["curve"][-1][k] - f32["curve"][-1][k] for k in KEYS}
-            if any(abs(gap[k]) >= 0.1 + abs(row["f32_kick_moves"][k]) for k in KEYS):
-                rs = psnr_run.run("f32_resample", args, dev, data, seed=sd)
-                row["f32_resample_moves"] = {k: rs["curve"][-1][k] - f32["curve"][-1][k] for k in KEYS}
-        table.append(row)
-        print(f"[{label}] seed {sd}: f32 {row['f32'][KEYS[0]]:.3f} dB, bf16 - f32 = " + " / ".join(f"{gap[k]:+.3f}" for k in KEYS)
-              + (" dB; f32 moved by 2e-3 once: " + " / ".join(f"{row['f32_kick_moves'][k]:+.3f}" for k in KEYS) + " dB" if row["f32_kick_moves"] else " dB")
-              + ("; f32 on other mini-batches: " + " / ".join(f"{row['f32_resample_moves'][k]:+.3f}" for k in KEYS) + " dB" if row["f32_resample_moves"] else ""), flush=True)
-    for row in table:
-        for k in KEYS:
-            allow = 0.1 + max(abs(row["f32_kick_moves"][k]) if row["f32_kick_moves"] else 0.0, abs(row["f32_resample_moves"][k]) if row["f32_resample_moves"] else 0.0)
-            assert abs(row["gap_bf16"][k]) < allow, (label, row["seed"], k, row)
-    return table
+_ROWS = {}          # (label, seed) -> row: the per-seed tests fill it, the summary tests read it
 
 
-@pytest.mark.timeout(1100)
-def test_bf16_psnr_gate_at_bench_configuration_per_seed(dev, psnr_run):
-    """1 000 graph-replayed steps of 65 536 rays x 192 samples on the 256^2 data set (40 training images, one held-out view), seeds
-    0, 1, 2: f32 against the bf16 mode as the bench runs it (8-bit staged store, resident kernels, mode-5 backward)."""
-    from nerfca_amd import synthetic
-    args = SimpleNamespace(steps=1000, every=1000, rays=65536, samples=192, det=256, graph=True, perturb=1e-6, cross_eval=False, jsonl="", label="gate")
-    data = synthetic.make_dataset(256, 192, dev, views=synthetic.TRAIN_VIEWS)
-    table = per_seed_gate(psnr_run, args, dev, data, [0, 1, 2], "65 536 x 192")
-    # at least one seed of the three is resolved by the plain 0.1 dB clause on both definitions (seed 2 on record: -0.02 dB)
-    assert any(r["f32_kick_moves"] is None for r in table), table
-    # and the throughput mode is the faster one by a wide margin (13.5 vs 81 ms per step on record)
-    assert all(r["wall"][1] < 0.35 * r["wall"][0] for r in table), [r["wall"] for r in table]
-
-
-@pytest.mark.timeout(900)
-def test_psnr_gate_at_reference_default_batch_per_seed(dev, psnr_run):
-    """1 024 rays x 500 samples per step, 5 000 graph-replayed steps, five seeds: the per-seed gate, and the mean gap of the five within
-    0.1 dB on both PSNR definitions."""
-    from nerfca_amd import synthetic
-    args = SimpleNamespace(steps=5000, every=5000, rays=1024, samples=500, det=256, graph=True, perturb=1e-6, cross_eval=False, jsonl="", label="gate")
-    data = synthetic.make_dataset(256, 500, dev, views=synthetic.TRAIN_VIEWS)
-    table = per_seed_gate(psnr_run, args, dev, data, [0, 1, 2, 3, 4], "1 024 x 500")
+def seed_row(psnr_run, args, dev, data, sd, label):
+    """f32 and bf16 for one seed, the f32 kick only where a gap reaches 0.1 dB, f32 on other mini-batches only where the kick does not
+    explain it; asserts the per-seed gate and keeps the row.  (One test per seed: a test is silent while it runs, and the GPU
+    harness takes seven silent minutes for a hang.)"""
+    f32 = psnr_run.run("f32", args, dev, data, seed=sd)
+    bf = psnr_run.run("bf16", args, dev, data, seed=sd)
+    assert bf["stage_fp8_in_effect"] is True, "the planner's default is the 8-bit staged store at every batch size"
+    for r in (f32, bf):
+        assert r["curve"][-1]["psnr_mse_db"] - r["curve"][0]["psnr_mse_db"] > 25.0, (sd, r["curve"])
+    gap = {k: bf["curve"][-1][k] - f32["curve"][-1][k] for k in KEYS}
+    row = {"seed": sd, "f32": {k: f32["curve"][-1][k] for k in KEYS}, "gap_bf16": gap, "f32_kick_moves": None, "f32_resample_moves": None,
+           "wall": (f32["wall_s_incl_eval"], bf["wall_s_incl_eval"])}
+    if max(abs(g) for g in gap.values()) >= 0.1:
+        kick = psnr_run.run(KICK, args, dev, data, seed=sd)
+        row["f32_kick_moves"] = {k: kick["curve"][-1][k] - f32["curve"][-1][k] for k in KEYS}
+        if any(abs(gap[k]) >= 0.1 + abs(row["f32_kick_moves"][k]) for k in KEYS):
+            rs = psnr_run.run("f32_resample", args, dev, data, seed=sd)
+            row["f32_resample_moves"] = {k: rs["curve"][-1][k] - f32["curve"][-1][k] for k in KEYS}
+    _ROWS[(label, sd)] = row
+    print(f"[{label}] seed {sd}: f32 {row['f32'][KEYS[0]]:.3f} dB, bf16 - f32 = " + " / ".join(f"{gap[k]:+.3f}" for k in KEYS)
+          + (" dB; f32 moved by 2e-3 once: " + " / ".join(f"{row['f32_kick_moves'][k]:+.3f}" for k in KEYS) + " dB" if row["f32_kick_moves"] else " dB")
+          + ("; f32 on other mini-batches: " + " / ".join(f"{row['f32_resample_moves'][k]:+.3f}" for k in KEYS) + " dB" if row["f32_resample_moves"] else ""), flush=True)
     for k in KEYS:
-        assert abs(statistics.mean(r["gap_bf16"][k] for r in table)) < 0.1, (k, [r["gap_bf16"][k] for r in table])
-    assert statistics.mean(r["wall"][1] for r in table) < statistics.mean(r["wall"][0] for r in table)
+        allow = 0.1 + max(abs(row["f32_kick_moves"][k]) if row["f32_kick_moves"] else 0.0, abs(row["f32_resample_moves"][k]) if row["f32_resample_moves"] else 0.0)
+        assert abs(gap[k]) < allow, (label, sd, k, row)
+    return row
+
+
+BENCH_SEEDS, SMALL_SEEDS = [0, 1, 2], [0, 1, 2, 3, 4]
+
+
+@pytest.fixture(scope="module")
+def bench_data(dev):
+    from nerfca_amd import synthetic
+    return synthetic.make_dataset(256, 192, dev, views=synthetic.TRAIN_VIEWS)
+
+
+@pytest.fixture(scope="module")
+def small_data(dev):
+    from nerfca_amd import synthetic
+    return synthetic.make_dataset(256, 500, dev, views=synthetic.TRAIN_VIEWS)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("seed", BENCH_SEEDS)
+def test_bf16_psnr_gate_at_bench_configuration_per_seed(dev, psnr_run, bench_data, seed):
+    """1 000 graph-replayed steps of 65 536 rays x 192 samples on the 256^2 data set (40 training images, one held-out view): f32
+    against the bf16 mode as the bench runs it (8-bit staged store, resident kernels, mode-5 backward).  Seed 1 is the worst of the five
+    on record (profiles/r04_psnr_bench_batch_seed_table.json)."""
+    args = SimpleNamespace(steps=1000, every=1000, rays=65536, samples=192, det=256, graph=True, perturb=1e-6, cross_eval=False, jsonl="", label="gate")
+    row = seed_row(psnr_run, args, dev, bench_data, seed, "65 536 x 192")
+    assert row["wall"][1] < 0.35 * row["wall"][0], row["wall"]          # the throughput mode is the faster one by a wide margin (13.5 vs 81 ms per step on record)
+
+
+def test_bench_configuration_gate_summary():
+    """At least one of the three seeds is resolved by the plain 0.1 dB clause on both definitions (seed 2 on record: -0.02 dB)."""
+    rows = [_ROWS.get(("65 536 x 192", sd)) for sd in BENCH_SEEDS]
+    if any(r is None for r in rows):
+        pytest.skip("the per-seed tests did not all run in this session")
+    assert any(r["f32_kick_moves"] is None for r in rows), rows
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("seed", SMALL_SEEDS)
+def test_psnr_gate_at_reference_default_batch_per_seed(dev, psnr_run, small_data, seed):
+    """1 024 rays x 500 samples per step (train/composite.txt:25,40), 5 000 graph-replayed steps: the per-seed gate."""
+    args = SimpleNamespace(steps=5000, every=5000, rays=1024, samples=500, det=256, graph=True, perturb=1e-6, cross_eval=False, jsonl="", label="gate")
+    seed_row(psnr_run, args, dev, small_data, seed, "1 024 x 500")
+
+
+def test_reference_default_batch_gate_summary():
+    """The mean of the five gaps within 0.1 dB on both PSNR definitions, and bf16 the faster one on average."""
+    rows = [_ROWS.get(("1 024 x 500", sd)) for sd in SMALL_SEEDS]
+    if any(r is None for r in rows):
+        pytest.skip("the per-seed tests did not all run in this session")
+    for k in KEYS:
+        assert abs(statistics.mean(r["gap_bf16"][k] for r in rows)) < 0.1, (k, [r["gap_bf16"][k] for r in rows])
+    assert statistics.mean(r["wall"][1] for r in rows) < statistics.mean(r["wall"][0] for r in rows)

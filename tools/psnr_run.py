@@ -52,70 +52,69 @@ def run(variant, args, dev, data, log=None, seed=0):
         kick, (prec, stage) = float(variant[len("f32_kick"):]), ("f32", None)
     else:
         prec, stage = VARIANTS[variant]
-    if True:
-        torch.manual_seed(1 + 1000 * seed)
-        sdef, tdef = synthetic.net_definitions(dev)
-        s, t = CPPN(sdef).to(dev), Temporal(tdef).to(dev)
-        if variant == "f32_perturbed" or kick is not None:
+    torch.manual_seed(1 + 1000 * seed)
+    sdef, tdef = synthetic.net_definitions(dev)
+    s, t = CPPN(sdef).to(dev), Temporal(tdef).to(dev)
+    if variant == "f32_perturbed" or kick is not None:
+        with torch.no_grad():
+            g = torch.Generator(device=dev).manual_seed(12345 + seed)
+            for m in (s, t):
+                for prm in m.parameters():
+                    prm.mul_(1.0 + (kick if kick is not None else args.perturb) * torch.randn(prm.shape, generator=g, device=dev))
+    nerfca_amd.set_precision(prec, s, t)
+    # --cross-eval: a second pair of models in the OTHER arithmetic that takes over the trained weights at every evaluation -- separates
+    # what an arithmetic costs the training from what it costs the rendering of the held-out view
+    shadow = None
+    if args.cross_eval:
+        s2, t2 = CPPN(sdef).to(dev), Temporal(tdef).to(dev)
+        nerfca_amd.set_precision("f32" if prec == "bf16" else "bf16", s2, t2)
+        shadow = (s2, t2)
+    # schedules compressed to the length of the run (the reference anneals over 150 k steps of 1 024 rays)
+    cfg = TrainConfig(depth_samples_per_ray_coarse=args.samples, img_sample_size=args.rays, static_pos_enc_window_decay_steps=args.steps,
+                      temp_pos_enc_window_decay_steps=args.steps, lr_decay_steps=args.steps)
+    tr = CompositeTrainer(cfg, s, t, data, dev, seed=batch_seed, plan_opts=None if stage is None else {"stage_fp8": stage})
+    tr.update_windows(0)
+    curve = []
+
+    def point(it):
+        tr.update_windows(it)
+        e = tr.evaluate(it)
+        curve.append({"step": it, "psnr_mse_db": float(e["test_psnr_mse"]), "test_psnr_reference_def_db": float(e["test_psnr"]), "test_loss": float(e["test_loss"])})
+        if shadow is not None:
             with torch.no_grad():
-                g = torch.Generator(device=dev).manual_seed(12345 + seed)
-                for m in (s, t):
-                    for prm in m.parameters():
-                        prm.mul_(1.0 + (kick if kick is not None else args.perturb) * torch.randn(prm.shape, generator=g, device=dev))
-        nerfca_amd.set_precision(prec, s, t)
-        # --cross-eval: a second pair of models in the OTHER arithmetic that takes over the trained weights at every evaluation -- separates
-        # what an arithmetic costs the training from what it costs the rendering of the held-out view
-        shadow = None
-        if args.cross_eval:
-            s2, t2 = CPPN(sdef).to(dev), Temporal(tdef).to(dev)
-            nerfca_amd.set_precision("f32" if prec == "bf16" else "bf16", s2, t2)
-            shadow = (s2, t2)
-        # schedules compressed to the length of the run (the reference anneals over 150 k steps of 1 024 rays)
-        cfg = TrainConfig(depth_samples_per_ray_coarse=args.samples, img_sample_size=args.rays, static_pos_enc_window_decay_steps=args.steps,
-                          temp_pos_enc_window_decay_steps=args.steps, lr_decay_steps=args.steps)
-        tr = CompositeTrainer(cfg, s, t, data, dev, seed=batch_seed, plan_opts=None if stage is None else {"stage_fp8": stage})
-        tr.update_windows(0)
-        curve = []
+                for dst, src in zip(shadow, (tr.s, tr.t)):
+                    for pd, ps in zip(dst.parameters(), src.parameters()):
+                        pd.copy_(ps)
+            own = (tr.s, tr.t)
+            tr.s, tr.t = shadow
+            try:
+                tr.update_windows(it)
+                e2 = tr.evaluate(it)
+            finally:
+                tr.s, tr.t = own
+            curve[-1]["other_arithmetic_psnr_mse_db"] = float(e2["test_psnr_mse"])
+            curve[-1]["other_arithmetic_test_psnr_reference_def_db"] = float(e2["test_psnr"])
+        if log:
+            print(f"[psnr_run] {variant} step {it}: {curve[-1]['psnr_mse_db']:.3f} dB", file=log, flush=True)
 
-        def point(it):
-            tr.update_windows(it)
-            e = tr.evaluate(it)
-            curve.append({"step": it, "psnr_mse_db": float(e["test_psnr_mse"]), "test_psnr_reference_def_db": float(e["test_psnr"]), "test_loss": float(e["test_loss"])})
-            if shadow is not None:
-                with torch.no_grad():
-                    for dst, src in zip(shadow, (tr.s, tr.t)):
-                        for pd, ps in zip(dst.parameters(), src.parameters()):
-                            pd.copy_(ps)
-                own = (tr.s, tr.t)
-                tr.s, tr.t = shadow
-                try:
-                    tr.update_windows(it)
-                    e2 = tr.evaluate(it)
-                finally:
-                    tr.s, tr.t = own
-                curve[-1]["other_arithmetic_psnr_mse_db"] = float(e2["test_psnr_mse"])
-                curve[-1]["other_arithmetic_test_psnr_reference_def_db"] = float(e2["test_psnr"])
-            if log:
-                print(f"[psnr_run] {variant} step {it}: {curve[-1]['psnr_mse_db']:.3f} dB", file=log, flush=True)
-
-        point(0)
-        step = tr.step_graph if args.graph else tr.step
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        fp8_seen = [None]
-        for it in range(args.steps):
-            loss, _, _ = step(it)
-            if it == 0:
-                fp8_seen[0] = bool(tr.plan().get("stage_fp8"))       # what THIS trainer's planner did (8-bit staged store or none)
-            if (it + 1) % args.every == 0:
-                point(it + 1)
-        torch.cuda.synchronize()
-        if args.jsonl:          # every finished run is on disk at once: a run that is cut off keeps what it has
-            with open(args.jsonl, "a") as f:
-                f.write(json.dumps({"variant": variant, "seed": seed, "label": args.label, "library": _capi.build_info(), "rays": args.rays, "samples": args.samples,
-                                    "steps": args.steps, "perturb": kick if kick is not None else (args.perturb if variant == "f32_perturbed" else None), "curve": curve}) + "\n")
-        return {"curve": curve, "final_train_loss": float(loss), "wall_s_incl_eval": time.perf_counter() - t0, "seed": seed,
-                "stage_fp8_in_effect": None if prec == "f32" else fp8_seen[0]}
+    point(0)
+    step = tr.step_graph if args.graph else tr.step
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fp8_seen = [None]
+    for it in range(args.steps):
+        loss, _, _ = step(it)
+        if it == 0:
+            fp8_seen[0] = bool(tr.plan().get("stage_fp8"))       # what THIS trainer's planner did (8-bit staged store or none)
+        if (it + 1) % args.every == 0:
+            point(it + 1)
+    torch.cuda.synchronize()
+    if args.jsonl:          # every finished run is on disk at once: a run that is cut off keeps what it has
+        with open(args.jsonl, "a") as f:
+            f.write(json.dumps({"variant": variant, "seed": seed, "label": args.label, "library": _capi.build_info(), "rays": args.rays, "samples": args.samples,
+                                "steps": args.steps, "perturb": kick if kick is not None else (args.perturb if variant == "f32_perturbed" else None), "curve": curve}) + "\n")
+    return {"curve": curve, "final_train_loss": float(loss), "wall_s_incl_eval": time.perf_counter() - t0, "seed": seed,
+            "stage_fp8_in_effect": None if prec == "f32" else fp8_seen[0]}
 
 
 def gap_statistics(runs, names, tail=1):
