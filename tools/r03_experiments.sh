@@ -10,6 +10,8 @@
 #   tools/r03_experiments.sh elim 16 32 128                    # ./_r03/tools/elim_build.sh 16 32 128   (timing-only builds)
 #   tools/r03_experiments.sh variant p2 "-DNCA_BF_PIPE2=1"     # ./_r03/tools/variant_build.sh p2 "-DNCA_BF_PIPE2=1"
 #   tools/r03_experiments.sh variant_all c8 "-DNCA_CHAIN8=1"   # ./_r03/tools/variant_build_all.sh ...
+#   tools/r03_experiments.sh patch tools/r03_c8_l0bf.patch     # apply a patch to ./_r03 first (this one: round 4's "layer 0 on bf16" form of the
+#                                                              #  fp8 chain, then: variant_all c8l0 "-DNCA_CHAIN8=1 -DNCA_C8_L0BF=1")
 # then, ON the GPU box:   cd _r03 && bash tools/ab_bench.sh 20 default p2      (its bench.py, its library, its ABI 8)
 set -e
 cd "$(dirname "$0")/.."
@@ -21,6 +23,7 @@ case "$1" in
   elim) shift; ( cd _r03 && tools/elim_build.sh "$@" ) ;;
   variant) shift; ( cd _r03 && tools/variant_build.sh "$@" ) ;;
   variant_all) shift; ( cd _r03 && tools/variant_build_all.sh "$@" ) ;;
+  patch) ( cd _r03 && git apply "../$2" && echo "applied $2" ) ;;
   "") ;;
   *) echo "usage: see the head of this script"; exit 1 ;;
 esac
