@@ -31,7 +31,7 @@ typedef float f32x4e __attribute__((ext_vector_type(4)));
 // features, 2: hidden-layer weights, 4: hidden activations (after ReLU), 8: output gradients of the dgrad chain, 16: layer-0 weights
 // -- each rounded to NCA_ABL_MANT significant bits (8 = bf16, 11 = f16's precision without its range) --, 32: the layer inputs as the
 // weight-gradient kernel reads them (what is STORED; the chain keeps f32) to 4 significant bits (e4m3's), 64: the stored output
-// gradients to 3 (e5m2's).
+// gradients to 3 (e5m2's), 128: the TRANSPOSED weight images only (what the dgrad chain multiplies with) to 4 bits (e4m3's).
 #ifndef NCA_ABL
 #define NCA_ABL 0
 #endif
@@ -41,7 +41,7 @@ typedef float f32x4e __attribute__((ext_vector_type(4)));
 template <int BIT>
 __device__ __forceinline__ float abl(float x) {
     if constexpr ((NCA_ABL & BIT) != 0) {
-        constexpr int MANT = BIT == 32 ? 4 : (BIT == 64 ? 3 : NCA_ABL_MANT), DROP = 24 - MANT;
+        constexpr int MANT = (BIT == 32 || BIT == 128) ? 4 : (BIT == 64 ? 3 : NCA_ABL_MANT), DROP = 24 - MANT;
         const unsigned u = __float_as_uint(x);
         return __uint_as_float((u + ((1u << (DROP - 1)) - 1u) + ((u >> DROP) & 1u)) & ~((1u << DROP) - 1u));     // round to nearest even
     } else return x;
@@ -138,7 +138,7 @@ __global__ void nca_pack_f32(NcaLayout y, const float* __restrict__ prm_, float*
                             if (!tr) { w0 = prm[l.w_off + o * l.K + k0]; w1 = prm[l.w_off + o * l.K + k1]; }
                             else {
                                 const int col0 = l.kind == NCA_IN_SKIP ? y.K0 : 0;
-                                w0 = prm[l.w_off + k0 * l.K + col0 + o]; w1 = prm[l.w_off + k1 * l.K + col0 + o];
+                                w0 = abl<128>(prm[l.w_off + k0 * l.K + col0 + o]); w1 = abl<128>(prm[l.w_off + k1 * l.K + col0 + o]);
                             }
                             v = __uint_as_float(x3_piece(w0, pc) | (x3_piece(w1, pc) << 16));
                         } else if (!tr) {
