@@ -25,7 +25,7 @@ itself under one such rounding; the kick run is only made where the plain 0.1 dB
 
 Two batch regimes:
   * the bench configuration, 65 536 rays x 192 samples per step, 1 000 graph-replayed steps, seeds 0, 1, 2 -- seed 1 is the worst of the
-    five on record;
+    ten on record;
   * the reference's default batch, 1 024 rays x 500 samples (train/composite.txt:25,40), 5 000 steps, five seeds.
 """
 import importlib.util
@@ -106,8 +106,8 @@ def small_data(dev):
 @pytest.mark.parametrize("seed", BENCH_SEEDS)
 def test_bf16_psnr_gate_at_bench_configuration_per_seed(dev, psnr_run, bench_data, seed):
     """1 000 graph-replayed steps of 65 536 rays x 192 samples on the 256^2 data set (40 training images, one held-out view): f32
-    against the bf16 mode as the bench runs it (8-bit staged store, resident kernels, mode-5 backward).  Seed 1 is the worst of the five
-    on record (profiles/r04_psnr_bench_batch_seed_table.json)."""
+    against the bf16 mode as the bench runs it (8-bit staged store, resident kernels, mode-5 backward).  Seed 1 is the worst of the ten
+    on record (profiles/r04_psnr_bench_batch_seed_table.json: seven within 0.1 dB outright, three inside f32's own spread)."""
     args = SimpleNamespace(steps=1000, every=1000, rays=65536, samples=192, det=256, graph=True, perturb=1e-6, cross_eval=False, jsonl="", label="gate")
     row = seed_row(psnr_run, args, dev, bench_data, seed, "65 536 x 192")
     assert row["wall"][1] < 0.35 * row["wall"][0], row["wall"]          # the throughput mode is the faster one by a wide margin (13.5 vs 81 ms per step on record)
