@@ -460,7 +460,7 @@ static bool store_plan(const NcaLayout* lays, int nnets, int32_t prec, int64_t w
     if (bf) {
         sp->off_m = align_up(wave_tiles * 2 * sp->h_stride, 1024);
         sp->off_r = sp->off_m + wave_tiles * 2 * sp->mask_layers * 1024;       // raw outputs [wave tile][net][64] f32: fp8 staging only
-        sp->bytes = align_up(sp->off_r + (h8 ? wave_tiles * 2 * 64 * 4 : 0), 256);        // (bf16 staging: the backward recomputes the last layer)
+        sp->bytes = align_up(sp->off_r + wave_tiles * 2 * 64 * 4, 256);
     } else {
         sp->off_m = align_up(wave_tiles * sp->h_stride * 32 * 4, 1024);
         sp->off_r = sp->off_m + wave_tiles * 2 * sp->mask_layers * 512;

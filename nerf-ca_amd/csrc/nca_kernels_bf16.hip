@@ -2,17 +2,18 @@
 // (v_mfma_f32_32x32x16_bf16), f32 accumulation, f32 master weights, f32 encoding arithmetic.
 //
 //   nca_pack_bf16        natural flat f32 parameters -> bf16 MFMA-ordered LDS images (+ f32 bias tails)
-//   nca_fused_bf16<F,BWD>  a wave owns 64 consecutive samples of one ray: lane = sample for the
+//   nca_fused_bf16<F,MODE,S8,RES>  a wave owns 64 consecutive samples of one ray: lane = sample for the
 //         encoding, then two 32-column tiles for the MFMAs (v_permlane32_swap builds both operand
 //         tiles from the per-lane features).  Layers run row-tile-outer: the 32x32 accumulator pair of
 //         row tile m is finished, ReLU'd, packed pairwise to bf16 and becomes k-steps 2m, 2m+1 of the
-//         next layer's B operand while row tile m+1's MFMAs issue -- activations never leave registers.
-//         BWD=true adds the recompute stores (sample-major bf16 blocks), output-layer gradients and
-//         the dgrad sweep.
-//   nca_wgrad_bf16       dW = D * H^T over samples with NO LDS: sample-major operand tiles are loaded
-//         straight into A-operand fragments, transposed by MFMAs against identity fragments into
-//         accumulator layout (rows = samples), and those tiles feed the weight-gradient MFMAs as A
-//         (X^T form) and B operands; dW of a whole layer stays in 256 accumulator registers.
+//         next layer's B operand -- activations never leave registers.
+//         MODE 0 forward; 2 storing forward (e4m3 layer inputs, ReLU masks, raw outputs to the caller's store);
+//         5 backward from that store (no recompute: output-layer gradients, dgrad sweep, e5m2 output gradients
+//         to the chunk scratch); 1 recompute backward without a store (bf16 blocks to one scratch).
+//   nca_wgrad_bf16<F,D8>  dW = D * H^T over samples: one wave per (layer, sample split) keeps dW of a whole layer in
+//         256 accumulator registers; operand tiles come HBM -> LDS by LDS-DMA into a per-wave ring, are transposed by
+//         MFMAs against an identity (samples onto K) and contracted -- D8: e5m2 x e4m3 on the MX-fp8 path, one
+//         v_mfma_scale_f32_32x32x64_f8f6f4 per 32x32 block of dW and 64-sample tile; else bf16.
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include "nca_kernels.hpp"
@@ -321,8 +322,7 @@ constexpr int NCA_BF_RING = 4;
 // tile behind the MFMAs of the other -- left the STEP where it was (the chip runs these kernels at its power cap; the
 // same instructions and bytes cost the same time in any order).  What is left is fewer instructions and fewer bytes.
 static_assert(NCA_BF_PF >= 1 && NCA_BF_PF < NCA_BF_RING, "prefetch distance must fit the ring");
-// RING registers, prefetch distance RING - 1 (the default ring of 4 for the MFMA-bound modes; the on-chip backward, which is
-// bound by its stores and short of registers, uses a ring of 2)
+// RING registers, prefetch distance RING - 1 (a ring of 4 in every mode)
 template <int NKS, int MTOT, int RING>
 __device__ __forceinline__ void ring_prime(const char* imgl, u32x4 (&A)[RING]) {
 #pragma unroll
@@ -436,9 +436,9 @@ __device__ __forceinline__ void transpose_block8(const u32x4 (&X)[NX], int lc, i
 // ------------------------------------------------------------------------------------------
 // fused forward / backward-dgrad kernel
 // ------------------------------------------------------------------------------------------
-// S8 (modes 2, 3, 4): fp8 staging -- the storing forward writes the hidden blocks 0..NL-3 as e4m3, the backward from the store
+// S8: 8-bit staging -- the storing forward (mode 2, always S8) writes the input block and the hidden blocks as e4m3, the backward from the store (mode 5)
 // writes D_0..D_{NL-2} as e5m2 scaled by a power of two per 64-sample tile (nca_layout.hpp)
-// RES (modes 0, 2, 3 with ONE net per launch): every weight image of the launch is RESIDENT in LDS (NcaStage::lds_off, loaded once
+// RES (modes 0, 2, 5 with ONE net per launch): every weight image of the launch is RESIDENT in LDS (NcaStage::lds_off, loaded once
 // per workgroup); the tile loop then has no weight DMA, no counted waits and no workgroup barrier -- the eight waves drift apart
 // and fill each other's epilogue and store slots.  The streaming variant double-buffers one image per stage behind a barrier.
 #ifndef NCA_BF_MINBLOCKS

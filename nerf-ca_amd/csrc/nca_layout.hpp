@@ -242,13 +242,13 @@ inline int nca_build_layout_bf16(const NcaNet& n, NcaLayout* out, const char** w
     return NCA_OK;
 }
 
-// fp8 staging (NCA_OPT_STAGE_FP8): the blocks that only the weight-gradient kernel reads cross HBM as 8-bit floats, and the
-// backward recomputes nothing.
+// The bf16 mode's forward store (8-bit staging, NCA_OPT_STAGE_FP8): the blocks that only the weight-gradient kernel reads cross HBM as
+// 8-bit floats, and the backward recomputes nothing.  (A bf16-STAGED store -- 64 x F bytes per block, last layer recomputed -- existed
+// until round 3; without a store the recompute backward keeps bf16 blocks in its own scratch: nca_bf_tile_bytes.)
 //   hidden block j = output of layer j = input of layer j+1, j = 0..NL-2, behind the input block of a tile of the forward store:
-//       bf16 staging: bf16 (64 x F bytes) -- the backward recomputes the last layer from block NL-2;
-//       fp8 staging:  e4m3 (32 x F bytes, [row tile][lane][16 B]: byte i = accumulator register i, value x 2^NCA_H8_LOG2); the
-//                     store also holds the ReLU masks of ALL NL layers and the raw outputs -- the backward reads masks and raw
-//                     outputs only, the weight-gradient kernel reads the blocks
+//       e4m3 (32 x F bytes, [row tile][lane][16 B]: byte i = accumulator register i, value x 2^NCA_H8_LOG2); the store also holds
+//       the ReLU masks of ALL NL layers and the raw outputs -- the backward reads masks and raw outputs only, the weight-gradient
+//       kernel reads the blocks
 //   output-gradient block l = 0..NL-1 of a tile of the backward's D region:
 //       e5m2 (32 x F bytes, same byte order, value x the tile's power-of-two scale), or bf16 fragments when the depth-gradient
 //       kernel is to read D_0.  Under fp8 staging block NL-1 holds relu'(H_{NL-1}) g WITHOUT the factor Wo[f]: the weight-gradient
