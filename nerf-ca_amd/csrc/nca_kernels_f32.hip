@@ -32,6 +32,10 @@ typedef float f32x4e __attribute__((ext_vector_type(4)));
 // -- each rounded to NCA_ABL_MANT significant bits (8 = bf16, 11 = f16's precision without its range) --, 32: the layer inputs as the
 // weight-gradient kernel reads them (what is STORED; the chain keeps f32) to 4 significant bits (e4m3's), 64: the stored output
 // gradients to 3 (e5m2's), 128: the TRANSPOSED weight images only (what the dgrad chain multiplies with) to 4 bits (e4m3's).
+// 256 / 512: the stored hidden-layer inputs / output gradients as SIX-bit floats (e2m3 / e3m2, the MX fp6 / bf6 formats) under one
+// power-of-two scale per lane and pair of row tiles (32 values: what one v_cvt_scalef32_pk32_{fp6,bf6} would convert) -- DESIGN.md 7's
+// 6-bit staging, asked of the PSNR gate before any kernel is written.  (Not the last hidden layer's output, which the f32 backward
+// reads back into its chain, and not the encoded input block: those keep bit 32's treatment.)
 #ifndef NCA_ABL
 #define NCA_ABL 0
 #endif
@@ -46,7 +50,7 @@ __device__ __forceinline__ float abl(float x) {
         return __uint_as_float((u + ((1u << (DROP - 1)) - 1u) + ((u >> DROP) & 1u)) & ~((1u << DROP) - 1u));     // round to nearest even
     } else return x;
 }
-int nca_kernels_ablation_mask() { return NCA_ABL | (NCA_ABL ? NCA_ABL_MANT << 8 : 0); }
+int nca_kernels_ablation_mask() { return NCA_ABL | (NCA_ABL ? NCA_ABL_MANT << 16 : 0); }
 
 // x3 split (see the x3 section below): exact three-way bf16 split of f32 values
 typedef float x3_f32x2 __attribute__((ext_vector_type(2)));
@@ -309,8 +313,52 @@ __device__ __forceinline__ void x3_sub(const char* __restrict__ sub, const f32x1
         __builtin_amdgcn_sched_barrier(0);
     }
 }
+// NCA_ABL bits 256 / 512: a group of 32 values (two row tiles of one lane; 16 at width 32) as fp6 under one power-of-two scale:
+// BF6 = false: e2m3 (magnitudes 0, 1/8 .. 7/8, 1 .. 7.5), BF6 = true: e3m2 (0, 1/16 .. 3/16, 1/4 .. 28); round to nearest even,
+// saturating; the scale puts the group's maximum into the top binade (one binade up if it would round past the largest value).
+template <bool BF6, int N>
+__device__ __forceinline__ void abl_fp6_group(const f32x16 (&h)[N], f32x16 (&q)[N]) {
+    constexpr int TOP = BF6 ? 4 : 2, MBITS = BF6 ? 2 : 3, EMIN = BF6 ? -2 : 0;
+    constexpr float VMAX = BF6 ? 28.f : 7.5f, LIMIT = BF6 ? 30.f : 7.75f;
+    float gmax = 0.f;
+#pragma unroll
+    for (int m = 0; m < N; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) gmax = fmaxf(gmax, fabsf(h[m][i]));
+    int e = (int)((__float_as_uint(gmax) >> 23) & 255u) - 127 - TOP;
+    if (e < -120) e = -120;                                       // (zero / denormal groups: everything rounds to 0 below)
+    if (gmax * __uint_as_float((unsigned)(127 - e) << 23) >= LIMIT) ++e;
+    const float s = __uint_as_float((unsigned)(127 + e) << 23), inv = __uint_as_float((unsigned)(127 - e) << 23);
+#pragma unroll
+    for (int m = 0; m < N; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float v = fabsf(h[m][i]) * inv;                 // exact (power of two)
+            int ev = (int)((__float_as_uint(v) >> 23) & 255u) - 127;
+            if (ev < EMIN) ev = EMIN;
+            const float step = __uint_as_float((unsigned)(127 + ev - MBITS) << 23), istep = __uint_as_float((unsigned)(127 - ev + MBITS) << 23);
+            float r = rintf(v * istep) * step;
+            if (r > VMAX) r = VMAX;
+            q[m][i] = copysignf(r * s, h[m][i]);
+        }
+}
 template <int MT, int ABL_BIT>
 __device__ __forceinline__ void x3_store_block(float* st, const f32x16 (&h)[MT]) {
+    if constexpr ((ABL_BIT == 32 && (NCA_ABL & 256) != 0) || (ABL_BIT == 64 && (NCA_ABL & 512) != 0)) {
+        constexpr int G = MT >= 2 ? 2 : 1;
+#pragma unroll
+        for (int m0 = 0; m0 < MT; m0 += G) {
+            f32x16 in[G], q[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) in[g] = h[m0 + g];
+            abl_fp6_group<ABL_BIT == 64, G>(in, q);
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) store_quad(st + ((m0 + g) * 4 + k) * 256, q[g][4 * k], q[g][4 * k + 1], q[g][4 * k + 2], q[g][4 * k + 3]);
+        }
+        return;
+    }
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -828,6 +876,8 @@ __global__ __launch_bounds__(NCA_NT, NCA_F32_MINBLOCKS) void nca_fused_f32(const
                 if (tvalid) {     // D_0 has no consumer in this kernel: stored here, drains under the next net / tile
                     float* dd = df;
                     asm volatile("" : "+v"(dd));
+                    if constexpr ((NCA_ABL & 512) != 0) x3_store_block<MT, 64>(dd, hprev);
+                    else
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
 #pragma unroll
