@@ -515,9 +515,10 @@ def main():
     if not (0 <= rank < world and 0 <= local < world):
         raise SystemExit(f"RANK={rank} / LOCAL_RANK={local} outside a world of {world}")
     if args.dry_run:       # nothing below this line has run: no HIP call, no process group
-        print(json.dumps({"rank": rank, "world": world, "local_rank": local, "device": f"cuda:{local}", "backend": "nccl" if world > 1 else None,
-                          "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}", "scaling": args.scaling,
-                          "rays_per_rank": rays_per_rank(args, world), "global_rays_per_step": rays_per_rank(args, world) * world}), flush=True)
+        # (ONE write per rank, newline included: eight ranks share the launcher's pipe, and print()'s separate newline let two records land on one line)
+        os.write(1, (json.dumps({"rank": rank, "world": world, "local_rank": local, "device": f"cuda:{local}", "backend": "nccl" if world > 1 else None,
+                                 "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}", "scaling": args.scaling,
+                                 "rays_per_rank": rays_per_rank(args, world), "global_rays_per_step": rays_per_rank(args, world) * world}) + "\n").encode())
         return
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)

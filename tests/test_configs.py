@@ -13,7 +13,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _json_lines(text):
-    return [json.loads(l) for l in text.splitlines() if l.startswith("{")]
+    """Every JSON object of the output, also when two ranks' records share a line (the ranks write to one pipe)."""
+    out, dec = [], json.JSONDecoder()
+    for l in text.splitlines():
+        i = l.find("{")
+        while i >= 0:
+            try:
+                obj, end = dec.raw_decode(l, i)
+            except json.JSONDecodeError:
+                break
+            out.append(obj)
+            i = l.find("{", end)
+    return out
 
 
 @pytest.mark.timeout(300)
