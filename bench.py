@@ -499,6 +499,18 @@ def psnr_record(args, dev):
                                            for sd, v in tab["seeds"].items()}}
     except (OSError, ValueError, KeyError):
         out["seed_spread"] = None
+    # ... and the same five seeds over 4 000 steps (replayed likewise)
+    try:
+        runs = {}
+        for l in open(os.path.join(ROOT, "profiles", "r04_psnr_bench_batch_long.jsonl")):
+            r = json.loads(l)
+            runs[(r["variant"], str(r["seed"]))] = r["curve"][-1]["psnr_mse_db"]
+        out["long_runs"] = {"source": "profiles/r04_psnr_bench_batch_long.jsonl (replayed)", "steps": 4000,
+                            "per_seed": {sd: {"f32_psnr_mse_db": v, "bf16_minus_f32_db": runs[("bf16", sd)] - v,
+                                              "f32_kick2e-3_minus_f32_db": (runs[("f32_kick2e-3", sd)] - v) if ("f32_kick2e-3", sd) in runs else None}
+                                         for (var, sd), v in sorted(runs.items()) if var == "f32"}}
+    except (OSError, ValueError, KeyError):
+        out["long_runs"] = None
     return out
 
 
