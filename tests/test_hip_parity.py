@@ -441,7 +441,8 @@ def test_fused_loss_kernel_vs_reference(golden, dev, dtn):
     ref = {"loss": loss, "pixel": pixel, "blendw": t[0], "sigma_s_max": t[1], "sigma_d_max": t[2], "favor_s": t[3], "s_entropy": t[4],
            "s_entropy_sum": t[5], "d_entropy": t[6], "d_entropy_sum": t[7], "d_occl": t[8], "s_l1": t[9], "s_l2": t[10]}
     for k, v in ref.items():
-        assert abs(got[k] - float(v)) <= 2e-6 * abs(float(v)) + 1e-12, (k, got[k], float(v))
+        v = float(v.detach()) if torch.is_tensor(v) else float(v)
+        assert abs(got[k] - v) <= 2e-6 * abs(v) + 1e-12, (k, got[k], v)
     assert rel_err(g_pix.cpu(), po.grad) < 1e-9
     assert rel_err(g_s.cpu(), ao.grad) < TOL and rel_err(g_d.cpu(), bo.grad) < TOL
 
