@@ -374,7 +374,7 @@ def measure(args, prec, stage_fp8, data, dev, rank, world, use_pg, steps, warmup
         barrier()
         sustained = {"ms_per_step": (time.perf_counter() - ts) * 10.0, "over": f"the last 100 of {sustained_steps} further graph-replayed steps (back to back after the timed region)",
                      "rays_per_s": rays_per_rank(args, world) * world * 100 / (time.perf_counter() - ts),
-                     "in_kernel_clock": "profiles/r03_clock_probe.txt (tools/clock_probe.sh: the diagnostic build that stamps s_memtime / s_memrealtime; no stamp executes in this build)"}
+                     "in_kernel_clock": "profiles/r03_clock_probe.txt (round 3's diagnostic build that stamps s_memtime / s_memrealtime -- tools/r03_experiments.sh; no stamp executes in this build)"}
     timed_steps, eager_dt = steps, dt
     eager_ms = None
     if args.graph:       # events cannot be recorded inside a replayed graph: time the same kernels eagerly, outside dt

@@ -319,7 +319,7 @@ enum {
     NCA_OPT_WGRAD_REBUILD_WEIGHT_PCT = 4, /* fp8 staging: the weight-gradient launch is ONE round of one-wave jobs, so its slowest wave is
                                      the launch; the jobs that rebuild their output-gradient block from mask bits take more cycles per
                                      tile than the others and get this many percent of the others' sample splits (100 .. 200; default
-                                     115 = the cycle ratio measured on MI355X, tools/clock_probe.sh; initial value from NCA_WGRAD_W).
+                                     115 = the cycle ratio measured on MI355X with round 3's clock-probe build, tools/r03_experiments.sh; initial value from NCA_WGRAD_W).
                                      A constant rather than a calibration at first use: the splits fix the summation order, and with it
                                      the bits of the gradient -- tools/calibrate_wgrad.py times the candidates on a given box */
     NCA_OPT_COUNT
@@ -346,7 +346,7 @@ typedef struct NcaPlan {
 } NcaPlan;
 int nca_last_plan(NcaPlan* out);
 /* Static description of the build: target, ABI, and the timing-experiment mask the kernels were compiled with ("NCA_EXP=0" in
- * every shipped library; tools/elim_build.sh makes the others, whose results are wrong by construction). */
+ * every shipped library; the timing-only builds of rounds 2 - 3, whose results are wrong by construction, come from the tag r03-kernels: tools/r03_experiments.sh). */
 const char* nca_build_info(void);
 
 /* ---- in-library kernel timing (HIP events on the launch stream), used by bench.py -------- */

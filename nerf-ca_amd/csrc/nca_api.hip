@@ -663,7 +663,7 @@ static int plan_bwd(const NcaLayout* lays, int nnets, int32_t prec, int64_t unit
     int nsplit = ((bf ? 4 : 2) * cus) / (p->njobs > 0 ? p->njobs : 1);
     if (nsplit < 1) nsplit = 1;
     // The jobs of the last hidden layers under e5m2 staging rebuild their D block on the vector ALU: 1.15 x the cycles per tile of
-    // the others (measured, tools/clock_probe.sh).  The grid is ONE round of one-wave workgroups, so the slowest wave is the launch:
+    // the others (measured with round 3's clock-probe build, tools/r03_experiments.sh).  The grid is ONE round of one-wave workgroups, so the slowest wave is the launch:
     // those jobs get W x the splits (NCA_OPT_WGRAD_REBUILD_WEIGHT_PCT, default 1.15).  Their extra slab rows hold NOTHING in every other job's columns and are never read there (NcaReduceArgs::n_split_std).
     int nsplit_x = nsplit;
     if (bf && stored && d8 && nr && p->njobs > nnets) {

@@ -274,7 +274,7 @@ size_t nca_fused_bf16_lds_other(int F, int kmode);
 hipError_t nca_launch_sum_tile_records(const char* dregion, int64_t wave_tile_bytes, int64_t dscale_off, int64_t ntiles, int nnets, int F, float* oslab, int n_wg,
                                        hipStream_t st);
 hipError_t nca_launch_wgrad_bf16(int F, const NcaWgradArgs& a, int nsplit, hipStream_t st);
-// the timing-experiment mask the bf16 kernels were compiled with (0 in every shipped library; tools/elim_build.sh)
+// the timing-experiment mask the bf16 kernels were compiled with (0 in every shipped library; round 3's timing-only builds: tools/r03_experiments.sh elim)
 int nca_kernels_exp_mask();
 int nca_kernels_variant_mask();
 // rounding-ablation mask of the f32 kernels (NCA_ABL; 0 in every shipped library)

@@ -368,8 +368,9 @@ def test_on_disk_schema_loader_and_log_records(tmp_path):
 
 
 def test_shipped_library_is_not_a_timing_build():
-    """tools/elim_build.sh makes libraries whose kernels leave work out (NCA_EXP != 0: results wrong by construction, timing only).
-    The library the package loads must be the product build."""
+    """Timing-only libraries (round 3's tools/elim_build.sh, built from the tag r03-kernels by tools/r03_experiments.sh: NCA_EXP != 0,
+    kernels that leave work out, results wrong by construction), A/B variants and rounding-ablation builds say what they are in
+    nca_build_info().  The library the package loads must be the product build."""
     from nerfca_amd import _capi
     info = _capi.build_info()
     assert "NCA_EXP=0" in info and f"abi={_capi.ABI_VERSION}" in info and "gfx950" in info, info

@@ -2,7 +2,7 @@
 # A/B builds of the bf16 kernels with other values of their tuning macros (NCA_BF_PF, NCA_BF_MINBLOCKS ...; the round-2 / round-3
 # experiment macros are gone from these sources: tools/r03_experiments.sh builds those from the tag r03-kernels):
 #   tools/variant_build.sh pf2 "-DNCA_BF_PF=2"  [name2 "flags2" ...]   ->  nerf-ca_amd/lib/libnerfca_hip_<name>.so
-# Run a bench or the tests against one with NERFCA_LIB=<path>.  These are CORRECT libraries (unlike tools/elim_build.sh's): a variant
+# Run a bench or the tests against one with NERFCA_LIB=<path>.  These are CORRECT libraries (unlike the timing-only builds of tools/r03_experiments.sh elim): a variant
 # that wins becomes the default in the source.  The other objects come from the regular build.
 set -e
 cd "$(dirname "$0")/.."
