@@ -421,3 +421,61 @@ def test_flat_buffer_of_padded_and_biasless_nets():
         assert float(b.flat[~mask].min()) == 1.5 and float(b.flat[mask].abs().max()) == 0.0
     with pytest.raises(_capi.NcaError, match="128"):
         CPPN(dict(sdef, num_filters=256))
+
+
+def test_planner_host_arithmetic_through_the_c_abi():
+    """What the planner decides before any launch is host arithmetic and needs no GPU: the size of the forward store
+    (nca_render_store_bytes: 8-bit staged in bf16, f32 blocks in f32), the per-call options (NcaRays.plan_opts) against the
+    process-wide ones, and the refusal of values outside an option's range -- through the C ABI, with pointers that are never read."""
+    import ctypes as C
+    from nerfca_amd import _capi
+    L = _capi.lib()
+    dummy = C.c_void_p(0x1000)            # non-NULL is all these entry points check of the ray pointers
+
+    def rays(R, S, single=0, opts=None):
+        r = _capi.NcaRays(R=R, S=S, ray_is_f64=1, origins=dummy, dirs=dummy, phase=dummy, phase_stride_r=0, phase_stride_s=0, z=dummy, z_stride_r=0,
+                          dists=dummy, I0=dummy, act=_capi.ACT_SOFTPLUS, single_field=single, scale=1e-2, store_format=0, plan_opts=None, plan_out=None)
+        if opts is not None:
+            r.plan_opts = C.cast(C.pointer(opts), C.c_void_p)
+        return r
+
+    net_s = _capi.NcaNet(F=128, n_hidden=4, n_late=0, enc_mode=_capi.ENC_BANDS, L=12, T=0, P=0)
+    net_d = _capi.NcaNet(F=128, n_hidden=4, n_late=0, enc_mode=_capi.ENC_BANDS, L=12, T=8, P=10)
+
+    def store(R, S, prec, opts=None, single=0):
+        r = rays(R, S, single, opts)
+        return L.nca_render_store_bytes(C.byref(r), C.byref(net_s), None if single else C.byref(net_d), prec)
+
+    # the bench batch: 65 536 rays x 192 samples = 196 608 wave tiles of 64 samples.  Per 32-sample tile and net: a 4 KiB e4m3 input
+    # block + four 4 KiB hidden blocks; per wave tile and net: five 1 KiB mask fragments and 64 raw outputs
+    tiles = 65536 * 3
+    b16 = store(65536, 192, _capi.PREC_BF16)
+    per_tile = 2 * (2 * (4096 + 4 * 4096)) + 2 * 5 * 1024 + 2 * 64 * 4
+    assert per_tile * tiles <= b16 <= per_tile * (tiles + 8) + 4096, (b16, per_tile * tiles)          # (slack tile slots up to the 8 waves, alignment)
+    f32 = store(65536, 192, _capi.PREC_F32)
+    assert 3.0 < f32 / b16 < 4.5, (f32, b16)                        # 4-byte blocks of every layer input against 1-byte ones
+    assert store(1, 1, _capi.PREC_BF16) > 0 and store(2048, 192, _capi.PREC_BF16) < store(4096, 192, _capi.PREC_BF16)
+    assert store(64, 64, _capi.PREC_BF16, single=1) < store(64, 64, _capi.PREC_BF16)
+
+    # per-call options win over the process-wide value and do not touch it
+    before = _capi.get_option(_capi.OPT_STAGE_FP8)
+    assert store(65536, 192, _capi.PREC_BF16, _capi.NcaPlanOpts(stage_fp8=0)) == 0              # "no forward store": the backward will recompute
+    assert store(65536, 192, _capi.PREC_F32, _capi.NcaPlanOpts(stage_fp8=0)) == f32               # (a bf16 option: the f32 store is not its business)
+    assert store(1024, 500, _capi.PREC_BF16, _capi.NcaPlanOpts(stage_fp8=-1, stage_fp8_min_tiles=10 ** 9)) == 0
+    assert store(1024, 500, _capi.PREC_BF16, _capi.NcaPlanOpts(stage_fp8=-1, stage_fp8_min_tiles=8000)) > 0
+    assert _capi.get_option(_capi.OPT_STAGE_FP8) == before and store(65536, 192, _capi.PREC_BF16) == b16
+
+    # values outside an option's range are refused, per call and process-wide, with a message; so are unknown options and empty batches
+    for bad in (_capi.NcaPlanOpts(stage_fp8=2), _capi.NcaPlanOpts(wgrad_rebuild_weight_pct=99), _capi.NcaPlanOpts(stage_fp8_min_tiles=-1), _capi.NcaPlanOpts(resident_min_tiles=-2)):
+        assert store(64, 64, _capi.PREC_BF16, bad) == -1 and b"takes" in L.nca_last_error()          # NCA_E_INVALID
+    with pytest.raises(_capi.NcaError):
+        _capi.set_option(_capi.OPT_WGRAD_REBUILD_WEIGHT_PCT, 250)
+    with pytest.raises(_capi.NcaError):
+        _capi.set_option(0, 1)                      # the retired option's slot
+    with pytest.raises(_capi.NcaError):
+        _capi.NcaPlanOpts(onchip_min_tiles=0)       # ... and its name
+    assert store(0, 64, _capi.PREC_BF16) < 0 and b"empty" in L.nca_last_error()
+    # a net the kernels do not have is an explicit error, not a size
+    wide = _capi.NcaNet(F=256, n_hidden=4, n_late=0, enc_mode=_capi.ENC_BANDS, L=12, T=0, P=0)
+    r = rays(64, 64, 1)
+    assert L.nca_render_store_bytes(C.byref(r), C.byref(wide), None, _capi.PREC_BF16) < 0 and b"32, 64 or 128" in L.nca_last_error()
