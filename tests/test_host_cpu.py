@@ -479,3 +479,30 @@ def test_planner_host_arithmetic_through_the_c_abi():
     wide = _capi.NcaNet(F=256, n_hidden=4, n_late=0, enc_mode=_capi.ENC_BANDS, L=12, T=0, P=0)
     r = rays(64, 64, 1)
     assert L.nca_render_store_bytes(C.byref(r), C.byref(wide), None, _capi.PREC_BF16) < 0 and b"32, 64 or 128" in L.nca_last_error()
+
+
+def test_plan_scope_is_a_per_thread_stack():
+    """fused.PlanScope: the innermost scope of THIS thread is the current one; another thread sees none of them (a second trainer on
+    its own thread neither inherits nor disturbs the first one's options), and leaving a scope restores the one around it."""
+    import threading
+    from nerfca_amd import _capi, fused
+    assert fused.PlanScope.current() is None
+    seen = {}
+    with fused.PlanScope(stage_fp8=0) as outer:
+        assert fused.PlanScope.current() is outer and outer.opts.stage_fp8 == 0 and outer.opts.resident_min_tiles == _capi.OPT_UNSET
+        with fused.PlanScope(resident_min_tiles=-1) as inner:
+            assert fused.PlanScope.current() is inner and inner.opts.stage_fp8 == _capi.OPT_UNSET
+
+            def other():
+                seen["none"] = fused.PlanScope.current()
+                with fused.PlanScope(stage_fp8=1) as mine:
+                    seen["mine"] = fused.PlanScope.current() is mine
+                seen["after"] = fused.PlanScope.current()
+            t = threading.Thread(target=other)
+            t.start()
+            t.join()
+            assert fused.PlanScope.current() is inner
+        assert fused.PlanScope.current() is outer
+    assert fused.PlanScope.current() is None
+    assert seen == {"none": None, "mine": True, "after": None}
+    assert set(outer.decided()) >= {"fwd_store_format", "bwd_kernel_mode", "stage_fp8", "wave_tiles"} and all(v == 0 for v in outer.decided().values())
