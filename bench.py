@@ -499,7 +499,7 @@ def psnr_record(args, dev):
                                            for sd, v in tab["seeds"].items()}}
     except (OSError, ValueError, KeyError):
         out["seed_spread"] = None
-    # ... and the same five seeds over 4 000 steps (replayed likewise)
+    # ... and ten seeds over 4 000 steps (replayed likewise)
     try:
         runs = {}
         for l in open(os.path.join(ROOT, "profiles", "r04_psnr_bench_batch_long.jsonl")):
