@@ -16,7 +16,9 @@
 set -e
 cd "$(dirname "$0")/.."
 if [ ! -d _r03 ]; then
-  git worktree add --detach _r03 r03-kernels > /dev/null
+  # (the tag names commit 86ee5bb, the last commit of round 3's kernels: used directly where a clone did not bring the tag along)
+  REV=r03-kernels; git rev-parse -q --verify "$REV^{commit}" > /dev/null || REV=86ee5bb4897b4d4f37e23bd602f48dc8e3332020
+  git worktree add --detach _r03 $REV > /dev/null
 fi
 ( cd _r03 && make -j4 > /dev/null && echo "_r03: round-3 product library built ($(git -C . rev-parse --short HEAD))" )
 case "$1" in
