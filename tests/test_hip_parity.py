@@ -517,7 +517,7 @@ def test_fused_loss_kernel_dists_gradient(golden, dev, dtn, unit_mse):
     (gd_ref,) = torch.autograd.grad(loss, do)
     out = fused_losses(pix.detach().to(dev), gt.to(dev), wpix.to(dev), a.to(dev), b.to(dev), dists.to(dev), args, weights, unit_mse=unit_mse,
                        want_dists_grad=True)
-    assert abs(float(out[0][0]) - float(loss)) <= 2e-6 * abs(float(loss))
+    assert abs(float(out[0][0]) - float(loss.detach())) <= 2e-6 * abs(float(loss.detach()))
     assert rel_err(out[4].cpu(), gd_ref) < TOL, rel_err(out[4].cpu(), gd_ref)
 
 
