@@ -613,7 +613,7 @@ def test_trainer_with_fine_pass_vs_oracle(dev):
         return float(tot.detach()), [{k: v.grad for k, v in p.items()} for p in P]
 
     ref_loss, ref = oracle_grads(detach=True, z_all=seen["z_all"])     # the very depths the trainer rendered at
-    assert abs(float(loss) - ref_loss) <= 1e-5 * abs(ref_loss)
+    assert abs(float(loss.detach()) - ref_loss) <= 1e-5 * abs(ref_loss)
     for m, rg, name in zip((s, t, sf, tf), ref, ("static", "dynamic", "static_fine", "dynamic_fine")):
         for k, p in m.named_parameters():
             if float(rg[k].abs().max()) == 0.0:
