@@ -540,7 +540,7 @@ def test_fused_step_equals_autograd_step(dev):
         loss = None
         for it in range(3):
             loss = tr.step(1000 + it)[0]
-        outs.append((float(loss), torch.cat([p.detach().flatten() for p in tr.params]).cpu()))
+        outs.append((float(loss.detach()), torch.cat([p.detach().flatten() for p in tr.params]).cpu()))
     assert abs(outs[0][0] - outs[1][0]) <= 1e-6 * abs(outs[0][0])
     assert rel_err(outs[1][1], outs[0][1]) < 1e-5
 

@@ -337,7 +337,7 @@ def test_trainer_with_odd_widths(dev, prec):
         first = None
         for it in range(3):
             loss, _, _ = step(1000 + it)
-            first = float(loss) if first is None else first
+            first = float(loss.detach()) if first is None else first
         assert torch.isfinite(loss)
         losses[mode] = first
         for m in (s, t):
