@@ -411,6 +411,7 @@ def measure(args, prec, stage_fp8, data, dev, rank, world, use_pg, steps, warmup
                     "resident_weight_images": {"fwd": bool(plan.get("fwd_resident")), "bwd": bool(plan.get("bwd_resident"))},
                     "ray_chunks": plan.get("chunks"),
                     "wgrad": {"jobs": plan.get("wgrad_jobs"), "splits": plan.get("wgrad_splits"), "splits_rebuild_jobs": plan.get("wgrad_splits_rebuild")},
+                    "overlap": {"cus": plan.get("overlap_cus"), "forked": bool(plan.get("overlap_forked"))},
                     "launches_per_step": {k: (kern[k]["launches"] // max(timed_steps, 1)) for k in ("fwd", "bwd_dgrad", "bwd_wgrad")}},
            "roofline": roofline_of(args, prec, kern, eager_dt, plan, dt / steps * 1e3, world),
            "store_fallbacks": fused_mod.STORE_FALLBACKS - fallbacks0}       # > 0: some backward ran on the recompute path (store did not fit)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NCA_ABI_VERSION 9
+#define NCA_ABI_VERSION 10
 
 enum {
     NCA_OK = 0,
@@ -79,7 +79,9 @@ typedef struct NcaPlanOpts {
     int64_t stage_fp8_min_tiles;      /* NCA_OPT_STAGE_FP8_MIN_TILES      */
     int64_t resident_min_tiles;       /* NCA_OPT_RESIDENT_MIN_TILES       */
     int64_t wgrad_rebuild_weight_pct; /* NCA_OPT_WGRAD_REBUILD_WEIGHT_PCT */
+    int64_t overlap_cus;              /* NCA_OPT_OVERLAP_CUS (ABI 10)     */
 } NcaPlanOpts;
+#define NCA_PLAN_OPTS_INIT {NCA_OPT_UNSET, NCA_OPT_UNSET, NCA_OPT_UNSET, NCA_OPT_UNSET, NCA_OPT_UNSET}   /* "every field unset": a zeroed struct is NOT that (0 is a value of every option) */
 struct NcaPlan;
 
 /* A batch of rays and the per-step sampling state: the arguments of
@@ -322,6 +324,16 @@ enum {
                                      115 = the cycle ratio measured on MI355X with round 3's clock-probe build, tools/r03_experiments.sh; initial value from NCA_WGRAD_W).
                                      A constant rather than a calibration at first use: the splits fix the summation order, and with it
                                      the bits of the gradient -- tools/calibrate_wgrad.py times the candidates on a given box */
+    NCA_OPT_OVERLAP_CUS = 5,      /* bf16 mode, backward from the 8-bit staged store of a two-net ray batch with resident weight images (the bench path):
+                                     the static net's weight-gradient launch (HBM-bound) runs BESIDE the dynamic net's dgrad launch (issue-bound) on
+                                     a second stream of the library -- fork and join are events on the caller's stream, so a stream capture records
+                                     both branches.  The value is the number of compute units whose wave slots the overlapped weight-gradient launch
+                                     is sized for (its one-round grid); the dgrad launch beside it gets the others.  A compute unit holds a workgroup
+                                     of EITHER kernel (both take more than half of its LDS), so the two grids add up to the chip whichever is
+                                     dispatched first.  The dynamic net's weight gradient follows the join on the whole chip.  0 = off: one
+                                     weight-gradient launch for both nets after both dgrad launches (ABI <= 9).  The value fixes the split of the
+                                     sample sums, hence the bits of the gradient (run to run they are identical either way).  Initial value from
+                                     NCA_OVERLAP_CUS; nca_last_plan().overlap_cus says what ran */
     NCA_OPT_COUNT
 };
 int nca_get_option(int32_t opt, int64_t* value);
@@ -342,7 +354,10 @@ typedef struct NcaPlan {
     int32_t wgrad_jobs, wgrad_splits, wgrad_splits_rebuild;
     int32_t chunks;               /* ray chunks of that backward                                                        */
     int64_t wave_tiles;           /* wave tiles of the whole batch of the last call                                     */
-    int64_t reserved[4];
+    int32_t overlap_cus;          /* NCA_OPT_OVERLAP_CUS as that backward ran it (0: one weight-gradient launch for both nets)   */
+    int32_t overlap_forked;       /* 1: the overlapped launch went to the library's second stream; 0: the same launches in a row on the caller's
+                                     (the second stream did not exist yet and the caller's stream was capturing)                  */
+    int64_t reserved[3];
 } NcaPlan;
 int nca_last_plan(NcaPlan* out);
 /* Static description of the build: target, ABI, and the timing-experiment mask the kernels were compiled with ("NCA_EXP=0" in

@@ -15,11 +15,12 @@ LIB_PATH = os.environ.get("NERFCA_LIB") or os.path.join(_HERE, "lib", "libnerfca
 ENC_NONE, ENC_BANDS, ENC_FOURIER = 0, 1, 2
 ACT_SIGMOID, ACT_SOFTPLUS, ACT_CLAMP = 0, 1, 2
 PREC_F32, PREC_BF16 = 0, 1
-ABI_VERSION = 9
+ABI_VERSION = 10
 OPT_STAGE_FP8 = 1          # (0 is reserved: the retired bf16-staged backward's on-chip threshold)
 OPT_RESIDENT_MIN_TILES = 2
 OPT_STAGE_FP8_MIN_TILES = 3
 OPT_WGRAD_REBUILD_WEIGHT_PCT = 4
+OPT_OVERLAP_CUS = 5
 STORE_NONE, STORE_F32, STORE_FP8, STORE_KIND_MASK, STORE_SHARED_ENC = 0, 1, 3, 15, 16       # (2 was the retired bf16-staged store)
 OPT_UNSET = -(1 << 63)     # NCA_OPT_UNSET: "use the process-wide value" in an NcaPlanOpts field
 K_PACK, K_FWD, K_BWD_DGRAD, K_BWD_WGRAD, K_BWD_REDUCE, K_LOSS, K_ADAM = 0, 1, 2, 3, 4, 5, 6
@@ -36,7 +37,8 @@ class NcaNet(C.Structure):
 
 class NcaPlanOpts(C.Structure):
     """Per-call planner options (NcaRays.plan_opts): a field other than OPT_UNSET replaces the process-wide tunable for that call."""
-    _fields_ = [("stage_fp8", C.c_int64), ("stage_fp8_min_tiles", C.c_int64), ("resident_min_tiles", C.c_int64), ("wgrad_rebuild_weight_pct", C.c_int64)]
+    _fields_ = [("stage_fp8", C.c_int64), ("stage_fp8_min_tiles", C.c_int64), ("resident_min_tiles", C.c_int64), ("wgrad_rebuild_weight_pct", C.c_int64),
+                ("overlap_cus", C.c_int64)]
 
     def __init__(self, **kw):
         super().__init__()
@@ -73,7 +75,7 @@ class NcaAdam(C.Structure):
 class NcaPlan(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("fwd_store_format", "fwd_launches", "fwd_resident", "bwd_kernel_mode", "bwd_resident", "bwd_launches_per_chunk",
                                          "bwd_onchip", "stage_fp8", "wgrad_jobs", "wgrad_splits", "wgrad_splits_rebuild", "chunks")] + \
-               [("wave_tiles", C.c_int64), ("reserved", C.c_int64 * 4)]
+               [("wave_tiles", C.c_int64), ("overlap_cus", C.c_int32), ("overlap_forked", C.c_int32), ("reserved", C.c_int64 * 3)]
 
 
 class NcaError(RuntimeError):

@@ -94,6 +94,33 @@ int num_cus() {
     }
     return n;
 }
+
+// A second stream of the calling thread for the one place where two launches of a backward are independent AND bound by different things:
+// the static net's weight gradient (HBM-bound, ready once that net's dgrad launch is done) and the dynamic net's dgrad launch
+// (issue-bound) -- NCA_OPT_OVERLAP_CUS.  Fork and join are events on the caller's stream, so inside a stream capture the side stream
+// joins the capture and the captured graph carries the two branches.  Created at the thread's first overlapped backward OUTSIDE a
+// capture (creating a stream inside a global-mode capture would fail it); until it exists the same launches run in a row on the caller's stream --
+// the results do not depend on it.
+struct Fork { hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; bool tried = false; };
+Fork* fork_get(hipStream_t st) {
+    static thread_local Fork f;
+    if (!f.tried) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+        f.tried = true;
+        hipStream_t s = nullptr;
+        hipEvent_t a = nullptr, b = nullptr;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&a, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&b, hipEventDisableTiming) == hipSuccess) {
+            f.side = s; f.ev_fork = a; f.ev_join = b;
+        } else {
+            if (s) (void)hipStreamDestroy(s);
+            if (a) (void)hipEventDestroy(a);
+            (void)hipGetLastError();
+        }
+    }
+    return f.side ? &f : nullptr;
+}
 }  // namespace
 
 extern "C" int nca_timing_enable(int32_t on) {
@@ -136,16 +163,21 @@ void opt_init_locked() {
     if (e && (e[0] == '0' || e[0] == '1')) g_opt[NCA_OPT_STAGE_FP8] = e[0] - '0';
     e = getenv("NCA_WGRAD_W");
     if (e && atoi(e) >= 100 && atoi(e) <= 200) g_opt[NCA_OPT_WGRAD_REBUILD_WEIGHT_PCT] = atoi(e);
+    e = getenv("NCA_OVERLAP_CUS");
+    if (e && atoi(e) >= 0) g_opt[NCA_OPT_OVERLAP_CUS] = atoi(e);
     g_opt_init = true;
 }
 // default of NCA_OPT_STAGE_FP8_MIN_TILES: see stage_fp8_for()
 constexpr int64_t STAGE_FP8_DEFAULT_MIN_TILES = 0;
+// default of NCA_OPT_OVERLAP_CUS (the sweep on MI355X)
+constexpr int64_t OVERLAP_CUS_DEFAULT = 0;
 // per-call options of the entry point this thread is in (NcaRays.plan_opts; CallOpts below sets and clears it)
 thread_local const NcaPlanOpts* t_call_opts = nullptr;
 int64_t opt_value(int opt) {
     if (t_call_opts) {
         const int64_t c = opt == NCA_OPT_STAGE_FP8 ? t_call_opts->stage_fp8 : opt == NCA_OPT_STAGE_FP8_MIN_TILES ? t_call_opts->stage_fp8_min_tiles
-                        : opt == NCA_OPT_RESIDENT_MIN_TILES ? t_call_opts->resident_min_tiles : opt == NCA_OPT_WGRAD_REBUILD_WEIGHT_PCT ? t_call_opts->wgrad_rebuild_weight_pct : NCA_OPT_UNSET;
+                        : opt == NCA_OPT_RESIDENT_MIN_TILES ? t_call_opts->resident_min_tiles : opt == NCA_OPT_WGRAD_REBUILD_WEIGHT_PCT ? t_call_opts->wgrad_rebuild_weight_pct
+                        : opt == NCA_OPT_OVERLAP_CUS ? t_call_opts->overlap_cus : NCA_OPT_UNSET;
         if (c != NCA_OPT_UNSET) return c;
     }
     std::lock_guard<std::mutex> lk(g_omu);
@@ -155,6 +187,7 @@ int64_t opt_value(int opt) {
         if (opt == NCA_OPT_STAGE_FP8) v = -1;                                            // by batch size (threshold 0: always)
         if (opt == NCA_OPT_STAGE_FP8_MIN_TILES) v = STAGE_FP8_DEFAULT_MIN_TILES;
         if (opt == NCA_OPT_WGRAD_REBUILD_WEIGHT_PCT) v = 115;
+        if (opt == NCA_OPT_OVERLAP_CUS) v = OVERLAP_CUS_DEFAULT;
         if (opt == NCA_OPT_RESIDENT_MIN_TILES) v = (int64_t)8 * NCA_WAVES * num_cus();    // (at 4 tiles per wave -- the reference's 1 024 x 500 batch -- resident and streaming tie)
     }
     return v;
@@ -185,14 +218,15 @@ static int check_option_value(int32_t opt, int64_t value) {
     if (opt == NCA_OPT_STAGE_FP8 && value != 0 && value != 1 && value != -1) return fail(NCA_E_INVALID, "NCA_OPT_STAGE_FP8 takes 0 (no forward store), 1 (always) or -1 (by batch size)");
     if (opt == NCA_OPT_STAGE_FP8_MIN_TILES && value < 0) return fail(NCA_E_INVALID, "NCA_OPT_STAGE_FP8_MIN_TILES takes a tile count >= 0");
     if (opt == NCA_OPT_WGRAD_REBUILD_WEIGHT_PCT && (value < 100 || value > 200)) return fail(NCA_E_INVALID, "NCA_OPT_WGRAD_REBUILD_WEIGHT_PCT takes 100 .. 200");
+    if (opt == NCA_OPT_OVERLAP_CUS && (value < 0 || value > 4096)) return fail(NCA_E_INVALID, "NCA_OPT_OVERLAP_CUS takes 0 (off) or a number of compute units");
     return NCA_OK;
 }
 namespace {
 int check_plan_opts(const NcaPlanOpts* o) {
     if (!o) return NCA_OK;
-    const int64_t v[4] = {o->stage_fp8, o->stage_fp8_min_tiles, o->resident_min_tiles, o->wgrad_rebuild_weight_pct};
-    const int32_t k[4] = {NCA_OPT_STAGE_FP8, NCA_OPT_STAGE_FP8_MIN_TILES, NCA_OPT_RESIDENT_MIN_TILES, NCA_OPT_WGRAD_REBUILD_WEIGHT_PCT};
-    for (int i = 0; i < 4; ++i)
+    const int64_t v[5] = {o->stage_fp8, o->stage_fp8_min_tiles, o->resident_min_tiles, o->wgrad_rebuild_weight_pct, o->overlap_cus};
+    const int32_t k[5] = {NCA_OPT_STAGE_FP8, NCA_OPT_STAGE_FP8_MIN_TILES, NCA_OPT_RESIDENT_MIN_TILES, NCA_OPT_WGRAD_REBUILD_WEIGHT_PCT, NCA_OPT_OVERLAP_CUS};
+    for (int i = 0; i < 5; ++i)
         if (v[i] != NCA_OPT_UNSET) { int rc = check_option_value(k[i], v[i]); if (rc) return rc; }
     return NCA_OK;
 }
@@ -633,14 +667,20 @@ struct BwdPlan {
     int64_t tiles_per_unit;    // wave tiles (32 samples f32 / 64 samples bf16) per unit
     int64_t bytes_total;
     int64_t off_slab, off_oslab, off_scratch;
+    // NCA_OPT_OVERLAP_CUS (two nets, bf16 mode 5, resident, e5m2 staging): one weight-gradient launch PER NET -- net 0's runs beside net 1's
+    // dgrad launch on ovl_cus compute units, net 1's after the join on the whole chip; 0 = one launch for both nets after both dgrad launches
+    int ovl_cus;
+    int ns_net[2], nx_net[2];   // splits of the regular / the rebuilding jobs of each net's launch
+    int grid_net[2];            // workgroups of each net's dgrad launch
 };
 
 static int64_t scratch_rows(const NcaLayout& y) { return y.K0rows_pad + (int64_t)(y.NL - 1) * y.F + (int64_t)y.NL * y.F; }
 
 // d8: bf16 backward from a store with fp8 staging (D_0..D_{NL-2} as e5m2 + one inverse-scale record per tile)
 static int plan_bwd(const NcaLayout* lays, int nnets, int32_t prec, int64_t units, int64_t tiles_per_unit, int64_t budget, BwdPlan* p,
-                    bool stored = false, bool d8 = false, bool nr = false) {
+                    bool stored = false, bool d8 = false, bool nr = false, int ovl_cus = 0) {
     const bool bf = prec == NCA_PREC_BF16;
+    p->ovl_cus = 0;
     p->tile_stride = 0;
     p->slab_stride = 0;
     p->njobs = 0;
@@ -666,6 +706,7 @@ static int plan_bwd(const NcaLayout* lays, int nnets, int32_t prec, int64_t unit
     // the others (measured with round 3's clock-probe build, tools/r03_experiments.sh).  The grid is ONE round of one-wave workgroups, so the slowest wave is the launch:
     // those jobs get W x the splits (NCA_OPT_WGRAD_REBUILD_WEIGHT_PCT, default 1.15).  Their extra slab rows hold NOTHING in every other job's columns and are never read there (NcaReduceArgs::n_split_std).
     int nsplit_x = nsplit;
+    int slab_rows = 0;          // rows of the split slab: the most splits any job of any launch of this plan runs over
     if (bf && stored && d8 && nr && p->njobs > nnets) {
         const double W = 0.01 * (double)opt_value(NCA_OPT_WGRAD_REBUILD_WEIGHT_PCT);
         int ns = (int)((4.0 * cus) / ((p->njobs - nnets) + nnets * W));
@@ -674,8 +715,23 @@ static int plan_bwd(const NcaLayout* lays, int nnets, int32_t prec, int64_t unit
         while ((p->njobs - nnets) * ns + nnets * nx > 4 * cus && nx > ns) --nx;
         nsplit = ns;
         nsplit_x = nx;
+        // one launch per net: net 0's on ovl_cus compute units (beside net 1's dgrad launch on the others), net 1's on all of them
+        if (ovl_cus >= 8 && ovl_cus <= cus - 8 && nnets == 2 && lays[0].NL > 1 && lays[1].NL > 1) {
+            p->ovl_cus = ovl_cus;
+            for (int n = 0; n < 2; ++n) {
+                const int slots = 4 * (n == 0 ? ovl_cus : cus), nj = lays[n].NL;
+                int s0 = (int)(slots / ((nj - 1) + W));
+                if (s0 < 1) s0 = 1;
+                int x0 = (int)(W * s0);
+                while ((nj - 1) * s0 + x0 > slots && x0 > s0) --x0;
+                p->ns_net[n] = s0;
+                p->nx_net[n] = x0;
+                if (x0 > slab_rows) slab_rows = x0;
+            }
+        }
     }
-    const int64_t slab_bytes = align_up((int64_t)nsplit_x * p->slab_stride * 4, 256);
+    if (nsplit_x > slab_rows) slab_rows = nsplit_x;
+    const int64_t slab_bytes = align_up((int64_t)slab_rows * p->slab_stride * 4, 256);
     const int64_t oslab_bytes = align_up((int64_t)cus * 2 * (F + 1) * 4, 256);
     // bf16 backward from a store: slack tile slots behind the D region, for the waves of the last group that have no tile
     const int64_t dslack = (bf && stored) ? (int64_t)(NCA_WAVES - 1) * 2 * p->tile_stride : 0;
@@ -700,6 +756,11 @@ static int plan_bwd(const NcaLayout* lays, int nnets, int32_t prec, int64_t unit
     p->n_split_x = nsplit_x;
     const int64_t ngroups = (tiles + NCA_WAVES - 1) / NCA_WAVES;
     p->grid = (int)(ngroups < cus ? ngroups : cus);
+    if (p->ovl_cus) {
+        // (the overlapped plan is for batches that fill the chip many times over: a launch whose clamps bite runs the plain plan)
+        if (ktiles < 8 * (int64_t)slab_rows || ngroups < cus) p->ovl_cus = 0;
+        else { p->grid_net[0] = cus; p->grid_net[1] = cus - p->ovl_cus; }
+    }
     p->off_slab = 0;
     p->off_oslab = slab_bytes;
     p->off_scratch = slab_bytes + oslab_bytes;
@@ -854,8 +915,12 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     }
     const bool per_net_launch = res3;
     BwdPlan p;
-    int rc = plan_bwd(lays, a.nnets, prec, units, tiles_per_unit, work_bytes, &p, stored, d8, nr);
+    // (the overlapped plan: resident one-net launches of a ray batch with e5m2 staging -- the bench path; nothing else forks)
+    const int ovl_opt = (per_net_launch && d8 && nr && a.mode == NCA_MODE_RAYS && !g_latents) ? (int)opt_value(NCA_OPT_OVERLAP_CUS) : 0;
+    int rc = plan_bwd(lays, a.nnets, prec, units, tiles_per_unit, work_bytes, &p, stored, d8, nr, ovl_opt);
     if (rc) return rc;
+    const bool ovl = p.ovl_cus > 0;
+    Fork* fk = ovl ? fork_get(st) : nullptr;
     if (!work || work_bytes < p.bytes_total) return fail(NCA_E_WORKSPACE, "backward workspace %lld < %lld bytes", (long long)work_bytes, (long long)p.bytes_total);
     char* wb = static_cast<char*>(work);
     float* slab = reinterpret_cast<float*>(wb + p.off_slab);
@@ -937,8 +1002,23 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     g_plan.stage_fp8 = h8 ? 1 : 0;
     g_plan.bwd_launches_per_chunk = (bf && stored && per_net_launch) ? a.nnets : 1;
     g_plan.wgrad_jobs = w.njobs;
-    g_plan.wgrad_splits = p.n_split;
-    g_plan.wgrad_splits_rebuild = p.n_split_x;
+    g_plan.wgrad_splits = ovl ? p.ns_net[1] : p.n_split;
+    g_plan.wgrad_splits_rebuild = ovl ? p.nx_net[1] : p.n_split_x;
+    g_plan.overlap_cus = p.ovl_cus;
+    g_plan.overlap_forked = fk ? 1 : 0;
+    // the weight-gradient launch of net n alone (overlapped plan): its jobs, its splits
+    auto wgrad_net = [&](int n, hipStream_t ws, int waves_per_wg) -> hipError_t {
+        static thread_local NcaWgradArgs w1;
+        w1 = w;
+        w1.njobs = 0;
+        for (int j = 0; j < w.njobs; ++j)
+            if (w.job[j].net == n) w1.job[w1.njobs++] = w.job[j];
+        w1.nsplit_std = p.ns_net[n];
+        w1.nsplit_x = p.nx_net[n];
+        Span sp(NCA_K_BWD_WGRAD, ws);
+        return nca_launch_wgrad_bf16(F, w1, p.nx_net[n], ws, waves_per_wg);
+    };
+    static const int ovl_nw = getenv("NCA_OVERLAP_NW") && atoi(getenv("NCA_OVERLAP_NW")) == 1 ? 1 : 4;
     int chunk = 0;
     for (int64_t u0 = 0; u0 < units; u0 += p.units_per_chunk, ++chunk) {
         const int64_t nu = (u0 + p.units_per_chunk <= units) ? p.units_per_chunk : units - u0;
@@ -960,15 +1040,36 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
                 rc = build_stages(&one, b1, true, 1);
                 if (rc) return rc;
                 if (res3) g_plan.bwd_resident = plan_resident(&one, km) ? 1 : 0;        // (does not fit: the streaming kernel, still one net per launch)
-                Span sp(NCA_K_BWD_DGRAD, st);
-                HIPCHK(nca_launch_fused_bf16(F, one, km, p.grid, st, d8));
+                {
+                    Span sp(NCA_K_BWD_DGRAD, st);
+                    HIPCHK(nca_launch_fused_bf16(F, one, km, ovl ? p.grid_net[n] : p.grid, st, d8));
+                }
+                if (ovl && n == 0) {
+                    // FORK: net 0's output gradients are complete -- its weight gradient (HBM-bound, p.ovl_cus compute units' worth of
+                    // one-round waves) runs beside net 1's dgrad launch (issue-bound, the other compute units)
+                    w.rows_total = p.tile_stride;
+                    w.tile0_b = u0 * tiles_per_unit * 2;
+                    w.ntiles = a.ntiles * 2;
+                    w.accumulate = chunk > 0;
+                    hipStream_t ws = st;
+                    if (fk) {
+                        HIPCHK(hipEventRecord(fk->ev_fork, st));
+                        HIPCHK(hipStreamWaitEvent(fk->side, fk->ev_fork, 0));
+                        ws = fk->side;
+                    }
+                    HIPCHK(wgrad_net(0, ws, ovl_nw));
+                    if (fk) HIPCHK(hipEventRecord(fk->ev_join, fk->side));
+                }
             }
         } else {
             Span sp(NCA_K_BWD_DGRAD, st);
             if (bf) HIPCHK(nca_launch_fused_bf16(F, a, stored ? (nr ? NCA_KM_BWD_NR : NCA_KM_BWD_STORED) : NCA_KM_BWD, p.grid, st, d8));
             else HIPCHK(nca_launch_fused_f32(F, a, stored ? NCA_KM_BWD_STORED : NCA_KM_BWD, p.grid, st));
         }
-        if (nr) HIPCHK(nca_launch_sum_tile_records(reinterpret_cast<const char*>(scratch), 2 * p.tile_stride, p.tile_stride - NCA_D8_REC_BYTES, a.ntiles, a.nnets, F, oslab, p.grid, st));
+        if (nr && ovl) {        // (each net's partial rows are those of ITS dgrad launch's workgroups)
+            for (int n = 0; n < a.nnets; ++n)
+                HIPCHK(nca_launch_sum_tile_records(reinterpret_cast<const char*>(scratch), 2 * p.tile_stride, p.tile_stride - NCA_D8_REC_BYTES, a.ntiles, n, n + 1, F, oslab, p.grid_net[n], st));
+        } else if (nr) HIPCHK(nca_launch_sum_tile_records(reinterpret_cast<const char*>(scratch), 2 * p.tile_stride, p.tile_stride - NCA_D8_REC_BYTES, a.ntiles, 0, a.nnets, F, oslab, p.grid, st));
         if (g_latents) {     // d loss / d latent input per point, from the same D_0 blocks (points mode, one net)
             NcaLatgradArgs lg;
             memset(&lg, 0, sizeof(lg));
@@ -1011,7 +1112,11 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
         w.tile0_b = stored ? u0 * tiles_per_unit * (bf ? 2 : 1) : 0;      // in 32-sample tiles
         w.ntiles = bf ? a.ntiles * 2 : a.ntiles;
         w.accumulate = chunk > 0;
-        {
+        if (ovl) {
+            // JOIN, then net 1's weight gradient on the whole chip
+            if (fk) HIPCHK(hipStreamWaitEvent(st, fk->ev_join, 0));
+            HIPCHK(wgrad_net(1, st, 1));
+        } else {
             Span sp(NCA_K_BWD_WGRAD, st);
             if (bf) {
                 if (w.njobs) {
@@ -1030,9 +1135,6 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     memset(&r, 0, sizeof(r));
     r.slab = slab;
     r.slab_stride = p.slab_stride;
-    r.n_split = bf ? p.n_split_x : p.n_split;
-    r.n_split_std = p.n_split;
-    r.n_wg = p.grid;
     r.oslab = oslab;
     r.oslab_stride = 2 * (F + 1);
     for (int n = 0; n < a.nnets; ++n) {
@@ -1050,6 +1152,9 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
         rn.tail_from_sums = nr ? 1 : 0;
         rn.tl_w_off = lays[n].layer[lays[n].NL - 1].w_off;
         rn.tl_b_off = lays[n].layer[lays[n].NL - 1].b_off;
+        rn.n_split = ovl ? p.nx_net[n] : (bf ? p.n_split_x : p.n_split);
+        rn.n_split_std = ovl ? p.ns_net[n] : p.n_split;
+        rn.n_wg = ovl ? p.grid_net[n] : p.grid;
     }
     {
         Span sp(NCA_K_BWD_REDUCE, st);
@@ -1089,7 +1194,7 @@ extern "C" int64_t nca_render_bwd_workspace(const NcaRays* rays, const NcaNet* n
     if (rc) return rc;
     int64_t need = p.bytes_total;
     if (prec == NCA_PREC_BF16) {       // from a store: a record per tile, e5m2 or (depth gradients) bf16 output-gradient blocks
-        rc = plan_bwd(lays, nn, prec, rays->R, (rays->S + ts - 1) / ts, max_bytes, &p, true, true, true);
+        rc = plan_bwd(lays, nn, prec, rays->R, (rays->S + ts - 1) / ts, max_bytes, &p, true, true, true, (int)opt_value(NCA_OPT_OVERLAP_CUS));
         if (rc) return rc;
         if (p.bytes_total > need) need = p.bytes_total;
         rc = plan_bwd(lays, nn, prec, rays->R, (rays->S + ts - 1) / ts, max_bytes, &p, true, false, true);

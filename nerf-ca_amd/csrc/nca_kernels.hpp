@@ -147,6 +147,12 @@ struct NcaReduceNet {
     int32_t tail_from_sums; // bf16 with fp8 staging: the slabs hold S = sum relu' g H^T and s = sum relu' g of the LAST F-wide layer
     int32_t pad;            // (nca_layout.hpp): its gradients are Wo[f] S, Wo[f] s, and dWo[f] = <bf16(W[f]), S[f]> + b[f] s[f]
     int64_t tl_w_off, tl_b_off;   // natural offsets of that layer's W (F*F) and b (F)
+    // per net, because the two nets' weight-gradient launches may be sized differently (one of them runs beside the other net's dgrad
+    // launch on part of the chip, NCA_OPT_OVERLAP_CUS):
+    int32_t n_split;        // slab rows of the columns the rebuilding (`expand`) jobs write -- the last F-wide layer under tail_from_sums
+    int32_t n_split_std;    // slab rows of every other column (<= n_split; the rows beyond hold nothing for them and are never read)
+    int32_t n_wg;           // workgroups of this net's dgrad launch = rows of oslab that hold its output-layer partials
+    int32_t pad2;
 };
 
 struct NcaReduceArgs {
@@ -155,9 +161,6 @@ struct NcaReduceArgs {
     float* slab;             // (not const: nca_reduce_f32 / nca_onehot_sum_f32 leave sums over the splits in slab row 0 for nca_reduce_small_f32,
                              //  which must be launched after them on the same stream)
     int64_t slab_stride;
-    int32_t n_split, n_wg;   // n_split: slab rows of the columns the rebuilding (`expand`) jobs write -- the last F-wide layer under tail_from_sums
-    int32_t n_split_std;     // slab rows of every other column (<= n_split; the rows beyond hold nothing for them and are never read)
-    int32_t pad_;
     const float* oslab;
     int64_t oslab_stride;
     NcaReduceNet net[2];
@@ -271,9 +274,13 @@ hipError_t nca_launch_fused_bf16(int F, const NcaFusedArgs& a, int kmode, int gr
 // LDS bytes a fused bf16 launch of this mode needs NEXT TO its weight images (constants, output-layer partials)
 size_t nca_fused_bf16_lds_other(int F, int kmode);
 // mode 5: adds the per-tile sums of d loss / d raw in the tile records (fixed order) into the workgroups' output-bias slots of oslab
-hipError_t nca_launch_sum_tile_records(const char* dregion, int64_t wave_tile_bytes, int64_t dscale_off, int64_t ntiles, int nnets, int F, float* oslab, int n_wg,
+// (nets net0 .. net1 - 1 of the tile records; n_wg = the workgroups of THEIR dgrad launch)
+hipError_t nca_launch_sum_tile_records(const char* dregion, int64_t wave_tile_bytes, int64_t dscale_off, int64_t ntiles, int net0, int net1, int F, float* oslab, int n_wg,
                                        hipStream_t st);
-hipError_t nca_launch_wgrad_bf16(int F, const NcaWgradArgs& a, int nsplit, hipStream_t st);
+// waves_per_wg: 1 = one-wave workgroups (four share a CU's LDS); 4 = one 256-thread workgroup per CU (e5m2 staging only) -- the same
+// waves doing the same work, but a CU then holds EITHER this kernel or a fused kernel's workgroup, whichever order two concurrent
+// launches are dispatched in
+hipError_t nca_launch_wgrad_bf16(int F, const NcaWgradArgs& a, int nsplit, hipStream_t st, int waves_per_wg = 1);
 // the timing-experiment mask the bf16 kernels were compiled with (0 in every shipped library; round 3's timing-only builds: tools/r03_experiments.sh elim)
 int nca_kernels_exp_mask();
 int nca_kernels_variant_mask();

@@ -604,11 +604,17 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
                 float fe[NCA_BF_K0SLOTS];
 #pragma unroll
                 for (int i = 0; i < NCA_BF_K0SLOTS; ++i) fe[i] = 0.f;
+                // The counts the unrolled slot loops below compare against, re-read from their registers per tile: as loop invariants the
+                // compiler forms all ~50 comparison masks ONCE, ahead of the tile loop, parks them in lanes of a vector register (they
+                // do not fit the scalar file) and fetches each with a v_readlane per tile -- a vector issue slot apiece in a kernel that
+                // is bound by those (tools/isa_spills.py); compared per tile they are scalar-ALU instructions and live in no register.
+                int encL = y.L, encT = y.T;
+                asm volatile("" : "+s"(encL), "+s"(encT));
                 if (y.enc_mode == NCA_ENC_FOURIER) {
                     // [sin(2 pi x g_i), cos(2 pi x g_i)] interleaved into slots 2i, 2i+1 (model/CPPN.py:115-118)
 #pragma unroll
                     for (int i = 0; i < NCA_BF_K0SLOTS / 2; ++i) {
-                        if (i < 3 * y.L) {
+                        if (i < 3 * encL) {
                             const int c = i % 3;
                             const float pc = c == 0 ? p[0] : (c == 1 ? p[1] : p[2]);
                             const float v = __fmul_rn(__fmul_rn(6.283185482025146484375f, pc), cnet[NCA_CONST_WIN + i]);
@@ -624,7 +630,7 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
                     for (int c = 0; c < 3; ++c) sincosf(p[c], &sn[c], &cs[c]);
 #pragma unroll
                     for (int k = 0; k < 15; ++k) {
-                        if (k < y.L) {
+                        if (k < encL) {
                             const float w = cnet[k];
 #pragma unroll
                             for (int c = 0; c < 3; ++c) {
@@ -637,11 +643,11 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
                         }
                     }
                 }
-                if (y.T > 0) {
-                    const float* lat = cnet + NCA_CONST_WIN + NCA_CONST_FOUR + phc * y.T;
+                if (encT > 0) {
+                    const float* lat = cnet + NCA_CONST_WIN + NCA_CONST_FOUR + phc * encT;
 #pragma unroll
                     for (int t = 0; t < 16; ++t)
-                        if (t < y.T) fe[NCA_BF_LAT_SLOT + t] = lat[t];
+                        if (t < encT) fe[NCA_BF_LAT_SLOT + t] = lat[t];
                 }
                 unsigned fp[NCA_BF_K0SLOTS / 2];
 #pragma unroll
@@ -1546,10 +1552,10 @@ __device__ __forceinline__ void wgrad_job_mx(const NcaWgradArgs& a, const NcaWgr
 // in the tile records (f32[2] behind the inverse scales) -- added in TILE order (workgroup b: tiles b, b + grid, ...; fixed tree),
 // whichever wave ran which tile, into workgroup b's bias slot of the output-layer partials (the dgrad launch before it left the
 // slots' shares at 0; the reduce kernel adds the slots up).
-__global__ __launch_bounds__(256) void nca_sum_tile_records(const char* dregion, int64_t wave_tile_bytes, int64_t dscale_off, int64_t ntiles, int nnets, int F,
+__global__ __launch_bounds__(256) void nca_sum_tile_records(const char* dregion, int64_t wave_tile_bytes, int64_t dscale_off, int64_t ntiles, int net0, int net1, int F,
                                                             float* oslab) {
     __shared__ float part[256];
-    for (int net = 0; net < nnets; ++net) {
+    for (int net = net0; net < net1; ++net) {
         float s = 0.f;
         for (int64_t t = (int64_t)threadIdx.x * gridDim.x + blockIdx.x; t < ntiles; t += 256 * (int64_t)gridDim.x)
             s += reinterpret_cast<const float*>(dregion + t * wave_tile_bytes + dscale_off)[2 + net];
@@ -1563,20 +1569,25 @@ __global__ __launch_bounds__(256) void nca_sum_tile_records(const char* dregion,
         __syncthreads();
     }
 }
-// n_wg: the workgroups of the dgrad launch = rows of oslab
-hipError_t nca_launch_sum_tile_records(const char* dregion, int64_t wave_tile_bytes, int64_t dscale_off, int64_t ntiles, int nnets, int F, float* oslab, int n_wg,
+// n_wg: the workgroups of the dgrad launch of nets net0 .. net1 - 1 = the rows of oslab that hold their partials
+hipError_t nca_launch_sum_tile_records(const char* dregion, int64_t wave_tile_bytes, int64_t dscale_off, int64_t ntiles, int net0, int net1, int F, float* oslab, int n_wg,
                                        hipStream_t st) {
-    hipLaunchKernelGGL(nca_sum_tile_records, dim3(n_wg), dim3(256), 0, st, dregion, wave_tile_bytes, dscale_off, ntiles, nnets, F, oslab);
+    hipLaunchKernelGGL(nca_sum_tile_records, dim3(n_wg), dim3(256), 0, st, dregion, wave_tile_bytes, dscale_off, ntiles, net0, net1, F, oslab);
     return hipGetLastError();
 }
 
-template <int F, bool D8>
-__global__ __launch_bounds__(64, 1) void nca_wgrad_bf16(const NcaWgradArgs a) {
+// NW waves per workgroup (e5m2 staging: 1 or 4; each wave is its own (job, split) with its own ring -- nothing is shared, there is no barrier)
+template <int F, bool D8, int NW = 1>
+__global__ __launch_bounds__(64 * NW, 1) void nca_wgrad_bf16(const NcaWgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char wring[];
+    static_assert(NW == 1 || D8, "several waves per workgroup: the compact (job, split) grid of e5m2 staging");
+    const int wave = NW > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : 0;
+    const int lane = NW > 1 ? (int)threadIdx.x & 63 : (int)threadIdx.x;
+    char* ring = wring + wave * NCA_WGRAD_LDS;
     // e5m2 staging: a 1-D grid of exactly the working (job, split) pairs, job after job -- expand jobs have nsplit_x splits, the others
     // nsplit_std.  (A 2-D grid with idle workgroups does not do: the grid must fit ONE round of the chip's 4 x CUs slots, workgroups go
     // to the XCDs round-robin, and idle ones unbalance that by enough to push a few working ones into a second round: 8.5 instead of 4.6 ms.)
-    int jy = blockIdx.y, qx = blockIdx.x, ns = gridDim.x;
+    int jy = blockIdx.y, qx = (int)blockIdx.x * NW + wave, ns = gridDim.x;
     if constexpr (D8) {
         jy = 0;
         for (;; ++jy) {
@@ -1590,14 +1601,14 @@ __global__ __launch_bounds__(64, 1) void nca_wgrad_bf16(const NcaWgradArgs a) {
     // (at F = 128 the 112-slot input block and a hidden block have the same shape: one body serves both)
     if constexpr (D8) {
         s8_mode();
-        if (job.expand) wgrad_job_mx<F, F / 32, true, true>(a, job, qx, ns, threadIdx.x, wring);
-        else if (F != 128 && job.is_enc && job.h8) wgrad_job_mx<F, 4, true>(a, job, qx, ns, threadIdx.x, wring);
-        else wgrad_job_mx<F, F / 32, true>(a, job, qx, ns, threadIdx.x, wring);         // (e5m2 D blocks come with e4m3 H blocks)
+        if (job.expand) wgrad_job_mx<F, F / 32, true, true>(a, job, qx, ns, lane, ring);
+        else if (F != 128 && job.is_enc && job.h8) wgrad_job_mx<F, 4, true>(a, job, qx, ns, lane, ring);
+        else wgrad_job_mx<F, F / 32, true>(a, job, qx, ns, lane, ring);         // (e5m2 D blocks come with e4m3 H blocks)
     } else {
-        if (F != 128 && job.is_enc && job.h8) wgrad_job<F, 4, D8, true>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
-        else if (job.h8) wgrad_job<F, F / 32, D8, true>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
-        else if (F != 128 && job.is_enc) wgrad_job<F, 4, D8, false>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
-        else wgrad_job<F, F == 128 ? 4 : F / 32, D8, false>(a, job, blockIdx.x, gridDim.x, threadIdx.x, wring);
+        if (F != 128 && job.is_enc && job.h8) wgrad_job<F, 4, D8, true>(a, job, blockIdx.x, gridDim.x, lane, ring);
+        else if (job.h8) wgrad_job<F, F / 32, D8, true>(a, job, blockIdx.x, gridDim.x, lane, ring);
+        else if (F != 128 && job.is_enc) wgrad_job<F, 4, D8, false>(a, job, blockIdx.x, gridDim.x, lane, ring);
+        else wgrad_job<F, F == 128 ? 4 : F / 32, D8, false>(a, job, blockIdx.x, gridDim.x, lane, ring);
     }
 }
 
@@ -1667,19 +1678,32 @@ hipError_t nca_launch_pack_bf16(const NcaLayout& y, const float* prm, void* out,
     return hipGetLastError();
 }
 
-hipError_t nca_launch_wgrad_bf16(int F, const NcaWgradArgs& a, int nsplit, hipStream_t st) {
+hipError_t nca_launch_wgrad_bf16(int F, const NcaWgradArgs& a, int nsplit, hipStream_t st, int waves_per_wg) {
     const bool d8 = a.njobs > 0 && a.job[0].d8 != 0;          // one format for every D block of a launch
     for (int j = 0; j < a.njobs; ++j)
         if ((a.job[j].d8 != 0) != d8 || (d8 && !a.job[j].h8)) return hipErrorInvalidValue;
     if (d8 && (a.ntiles & 1)) return hipErrorInvalidValue;        // whole wave tiles (two 32-sample tiles share a scale and an MFMA)
+    if (waves_per_wg != 1 && !(waves_per_wg == 4 && d8)) return hipErrorInvalidValue;
     dim3 grid(nsplit, a.njobs), block(64);
-    if (d8) {          // one workgroup per working (job, split) pair
+    if (d8) {          // one wave per working (job, split) pair
         if (a.nsplit_std <= 0 || a.nsplit_x < a.nsplit_std) return hipErrorInvalidValue;
         int total = 0;
         for (int j = 0; j < a.njobs; ++j) total += a.job[j].expand ? a.nsplit_x : a.nsplit_std;
-        grid = dim3(total, 1);
+        grid = dim3((total + waves_per_wg - 1) / waves_per_wg, 1);
     }
-    constexpr int L = NCA_WGRAD_LDS;          // the wave's ring of tile slots: four one-wave workgroups share a CU's 160 KiB
+    constexpr int L = NCA_WGRAD_LDS;          // the wave's ring of tile slots: four waves (four one-wave workgroups, or one workgroup of four) share a CU's 160 KiB
+    if (waves_per_wg == 4) {
+        switch (F) {
+            case 32: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_wgrad_bf16<32, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * L);
+                     hipLaunchKernelGGL((nca_wgrad_bf16<32, true, 4>), grid, dim3(256), 4 * L, st, a); break;
+            case 64: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_wgrad_bf16<64, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * L);
+                     hipLaunchKernelGGL((nca_wgrad_bf16<64, true, 4>), grid, dim3(256), 4 * L, st, a); break;
+            case 128: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_wgrad_bf16<128, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * L);
+                      hipLaunchKernelGGL((nca_wgrad_bf16<128, true, 4>), grid, dim3(256), 4 * L, st, a); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     switch (F) {
         case 32: if (d8) hipLaunchKernelGGL((nca_wgrad_bf16<32, true>), grid, block, L, st, a); else hipLaunchKernelGGL((nca_wgrad_bf16<32, false>), grid, block, L, st, a); break;
         case 64: if (d8) hipLaunchKernelGGL((nca_wgrad_bf16<64, true>), grid, block, L, st, a); else hipLaunchKernelGGL((nca_wgrad_bf16<64, false>), grid, block, L, st, a); break;
@@ -1688,4 +1712,3 @@ hipError_t nca_launch_wgrad_bf16(int F, const NcaWgradArgs& a, int nsplit, hipSt
     }
     return hipGetLastError();
 }
-

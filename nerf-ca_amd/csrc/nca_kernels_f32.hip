@@ -1263,7 +1263,7 @@ __global__ void nca_reduce_f32(const NcaReduceArgs a) {
     const bool tail_w = rn.tail_from_sums && le >= rn.tl_w_off && le < rn.tl_w_off + F2t;
     const bool tail_b = rn.tail_from_sums && le >= rn.tl_b_off && le < rn.tl_b_off + rn.F;
     const bool tail_col = tail_w || tail_b;
-    int nsum = tail_col ? a.n_split : a.n_split_std;
+    int nsum = tail_col ? rn.n_split : rn.n_split_std;
     int q = 0;
     for (; q + 8 <= nsum; q += 8) {
 #pragma unroll
@@ -1312,7 +1312,7 @@ __global__ __launch_bounds__(256) void nca_reduce_small_f32(const NcaReduceArgs 
                 }
                 if (lane == 0) s = fmaf(rn.params[rn.tl_b_off + k], a.slab[rn.slab_off + rn.tl_b_off + k], s);
             } else {
-                for (int w = lane; w < a.n_wg; w += 64) s += a.oslab[(int64_t)w * a.oslab_stride + net * (rn.F + 1) + k];
+                for (int w = lane; w < rn.n_wg; w += 64) s += a.oslab[(int64_t)w * a.oslab_stride + net * (rn.F + 1) + k];
             }
             out = rn.grads + rn.wo_off + k;
         }
@@ -1332,11 +1332,11 @@ __global__ void nca_onehot_sum_f32(const NcaReduceArgs a) {
         float* p0 = a.slab + rn.onehot_off + e;
         float s4[4] = {0.f, 0.f, 0.f, 0.f};
         int q = 0;
-        for (; q + 4 <= a.n_split_std; q += 4) {         // (the one-hot block belongs to the layer-0 jobs)
+        for (; q + 4 <= rn.n_split_std; q += 4) {         // (the one-hot block belongs to the layer-0 jobs)
 #pragma unroll
             for (int u = 0; u < 4; ++u) s4[u] += p0[(int64_t)(q + u) * a.slab_stride];
         }
-        for (; q < a.n_split_std; ++q) s4[0] += p0[(int64_t)q * a.slab_stride];
+        for (; q < rn.n_split_std; ++q) s4[0] += p0[(int64_t)q * a.slab_stride];
         *p0 = (s4[0] + s4[1]) + (s4[2] + s4[3]);
     }
 }

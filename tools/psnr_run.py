@@ -9,7 +9,9 @@ same initial weights, ray batches and depth jitter in every arithmetic the libra
                     (NCA_OPT_STAGE_FP8 = 0; until round 3 this option selected a bf16-staged store -- retired: bf16_bf16stage in old records)
     bf16_fp8stage   bf16 MFMA operands, the forward store staged as e4m3 / e5m2 (NCA_OPT_STAGE_FP8 = 1)
     bf16            bf16 with the planner's own choice for this batch size (the library default: the 8-bit staged store)
-    f32_kick<eps>   f32 from initial weights moved once by a relative eps (e.g. f32_kick2e-3: one bf16 ulp)
+    f32_kick<eps>   f32 from initial weights moved once by a relative eps N(0, 1) (e.g. f32_kick2e-3: the round-4 control)
+    f32_bf16init    f32 from initial weights ROUNDED TO BF16 once (round to nearest even: at most 2^-9 relative, 1.1e-3 rms) -- the
+                    smallest thing the bf16 mode does to the weights, done once, to the parity mode
     f32_resample    f32 from the SAME initial weights with another stream of ray batches and depth jitter (the trainer's seed + 7919):
                     what the mini-batch sampling alone moves the result by
 
@@ -17,7 +19,7 @@ same initial weights, ray batches and depth jitter in every arithmetic the libra
 test_psnr, run_composite.py:391).  One JSON line; run on the GPU box:
 
     python tools/psnr_run.py --steps 300 --every 100 > gpurun_out/psnr.json                                  # bench batch
-    python tools/psnr_run.py --rays 1024 --samples 500 --steps 5000 --every 500 --variants f32,bf16_bf16stage,bf16_fp8stage
+    python tools/psnr_run.py --rays 1024 --samples 500 --steps 5000 --every 500 --variants f32,bf16_nostore,bf16_fp8stage
                                                                              # the reference's default batch (composite.txt:25,40)
 """
 import argparse
@@ -46,7 +48,7 @@ def run(variant, args, dev, data, log=None, seed=0):
     from nerfca_amd.train.trainer import CompositeTrainer, TrainConfig
     kick = None
     batch_seed = seed + (7919 if variant == "f32_resample" else 0)
-    if variant == "f32_resample":
+    if variant in ("f32_resample", "f32_bf16init"):
         prec, stage = "f32", None
     elif variant.startswith("f32_kick"):          # f32_kick<eps>: f32 from initial weights moved once by a relative eps (several per run, unlike f32_perturbed)
         kick, (prec, stage) = float(variant[len("f32_kick"):]), ("f32", None)
@@ -61,6 +63,11 @@ def run(variant, args, dev, data, log=None, seed=0):
             for m in (s, t):
                 for prm in m.parameters():
                     prm.mul_(1.0 + (kick if kick is not None else args.perturb) * torch.randn(prm.shape, generator=g, device=dev))
+    if variant == "f32_bf16init":
+        with torch.no_grad():
+            for m in (s, t):
+                for prm in m.parameters():
+                    prm.copy_(prm.to(torch.bfloat16).to(prm.dtype))
     nerfca_amd.set_precision(prec, s, t)
     # --cross-eval: a second pair of models in the OTHER arithmetic that takes over the trained weights at every evaluation -- separates
     # what an arithmetic costs the training from what it costs the rendering of the held-out view
