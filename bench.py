@@ -11,7 +11,10 @@ torch.distributed.run it is one of the ranks.
 
 One "step" = one pass of the hot path over one batch: ray gather (GPU-resident table), fused
 forward, all losses, fused backward, (all-reduce), Adam + LinearLR.  Inputs are resident in HBM when
-the timed region starts.  Weak scaling: every rank renders --rays rays per step.
+the timed region starts.  Multi-GPU: STRONG scaling by default -- one global batch of --rays rays per step, split N ways, one
+all-reduce of the flat gradient (BASELINE configs[2]); the same run also times the weak-scaled step (--rays per rank) and
+reports it beside the headline.  The N = 1 line carries `predicted_scaling`: the measured single-GPU step at rays / N for N = 2, 4, 8
+with the step's collective in place (a one-rank RCCL group: two graph segments with the all-reduce between them).
 
 Rank 0 prints ONE JSON line.  `dtype` names the arithmetic of the timed step as the library's planner ran it:
 "bf16+fp8stage" = bf16 MLP contractions whose layer inputs / output gradients cross HBM as e4m3 / e5m2 on their way to the
@@ -83,13 +86,16 @@ def parse(argv=None):
     ap.add_argument("--sustained-steps", type=int, default=500, help="further graph steps after the timed region; the last 100 are timed (0: skip)")
     ap.add_argument("--kernel-steps", type=int, default=8, help="steps of the eager pass that times the kernels")
     ap.add_argument("--psnr-steps", type=int, default=100, help="steps of the PSNR record (64^2 detector, 256 rays/step; 0: skip)")
+    ap.add_argument("--configs3-steps", type=int, default=3, help="timed steps of the BASELINE configs[3] sub-record (MAGIX geometry, 8 sequences x 10 phases of 512^2, "
+                    "256 samples per ray, f32, one full detector = 262 144 rays per step; 0: skip)")
     ap.add_argument("--dry-run", action="store_true", help="rendezvous bookkeeping only: without RANK in the environment print the launch this process would "
                     "make (and make it, so that every rank reports); as a rank print {rank, world, local_rank, device index} and exit BEFORE anything touches the GPU")
     ap.add_argument("--views", type=int, default=4)
     ap.add_argument("--torch-losses", action="store_true", help="losses + autograd in torch ops instead of the fused loss kernel")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak (default): every rank renders --rays rays per step; strong: ONE global batch of --rays rays is split N ways "
-                         "(SURVEY.md 8e's partitioning: rank g takes ids [g R/N, (g+1) R/N) of the same id vector)")
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
+                    help="strong (default; BASELINE configs[2], SURVEY.md 8e's partitioning): ONE global batch of --rays rays is split N ways -- rank g takes "
+                         "ids [g R/N, (g+1) R/N) of the same id vector; weak: every rank renders --rays rays per step.  At N = 1 they are the same run.  "
+                         "With N > 1 the line carries the other mode as a sub-record (`weak_scaling` / `strong_scaling`) measured in the same run")
     args = ap.parse_args(argv)
     args.graph = not args.eager            # the whole step as one captured HIP graph unless --eager
     if args.scaling == "strong" and args.rays % max(args.gpus, 1):
@@ -235,7 +241,7 @@ def unfused_gpu_baseline(args, data):
             "sample": f"{steps} full training steps of {R} rays x {args.samples} samples with unfused PyTorch-ROCm ops, {dt:.2f} s"}
 
 
-def make_trainer(args, prec, data, dev, rank, world, use_pg, plan_opts=None):
+def make_trainer(args, prec, data, dev, rank, world, use_pg, plan_opts=None, global_rays=None):
     import nerfca_amd
     from nerfca_amd import synthetic
     from nerfca_amd.model.CPPN import CPPN
@@ -245,7 +251,7 @@ def make_trainer(args, prec, data, dev, rank, world, use_pg, plan_opts=None):
     sdef, tdef = synthetic.net_definitions(dev)
     s, t = CPPN(sdef).to(dev), Temporal(tdef).to(dev)
     nerfca_amd.set_precision(prec, s, t)
-    cfg = TrainConfig(depth_samples_per_ray_coarse=args.samples, img_sample_size=rays_per_rank(args, world) * world)
+    cfg = TrainConfig(depth_samples_per_ray_coarse=args.samples, img_sample_size=global_rays if global_rays is not None else rays_per_rank(args, world) * world)
     tr = CompositeTrainer(cfg, s, t, data, dev, rank=rank, world=world, seed=0, fused_loss=not args.torch_losses, plan_opts=plan_opts)
     tr.always_allreduce = use_pg
     return tr
@@ -337,9 +343,18 @@ def measure(args, prec, stage_fp8, data, dev, rank, world, use_pg, steps, warmup
     trainer runs with that value of NCA_OPT_STAGE_FP8 as ITS planner option (per trainer: nothing process-wide is touched).  Returns
     the record's fields (value, ms_per_step, dtype label, plan, roofline, ...).  A forward store that cannot be allocated is an
     error here (fused.STRICT_STORE): the bench never silently times the recompute path."""
+    from nerfca_amd import fused as fused_mod
+    strict0 = fused_mod.STRICT_STORE
+    fused_mod.STRICT_STORE = True
+    try:
+        return _measure(args, prec, stage_fp8, data, dev, rank, world, use_pg, steps, warmup, sustained_steps)
+    finally:
+        fused_mod.STRICT_STORE = strict0
+
+
+def _measure(args, prec, stage_fp8, data, dev, rank, world, use_pg, steps, warmup, sustained_steps):
     from nerfca_amd import _capi
     from nerfca_amd import fused as fused_mod
-    fused_mod.STRICT_STORE = True
     tr = make_trainer(args, prec, data, dev, rank, world, use_pg, plan_opts=None if stage_fp8 is None else {"stage_fp8": stage_fp8})
 
     def barrier():
@@ -417,9 +432,103 @@ def measure(args, prec, stage_fp8, data, dev, rank, world, use_pg, steps, warmup
            "store_fallbacks": fused_mod.STORE_FALLBACKS - fallbacks0}       # > 0: some backward ran on the recompute path (store did not fit)
     if sustained:
         rec["sustained"] = sustained
+    tr.check_ray_ids()          # (one device read: a ray id outside the table would have been clamped by nca_prepare_batch -- never silently)
     del tr
     torch.cuda.empty_cache()
     return rec
+
+
+def quick_step_ms(args, prec, data, dev, rank, world, use_pg, global_rays, steps=30, warmup=5):
+    """ms per graph-replayed step of a trainer whose GLOBAL batch is `global_rays` (this rank renders its 1 / world of it), max over ranks."""
+    tr = make_trainer(args, prec, data, dev, rank, world, use_pg, global_rays=global_rays)
+    tr.always_allreduce = use_pg
+    for i in range(warmup):
+        tr.step_graph(75000 + i)
+    torch.cuda.synchronize()
+    if use_pg:
+        torch.distributed.barrier()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        tr.step_graph(75000 + warmup + i)
+    torch.cuda.synchronize()
+    if use_pg:
+        torch.distributed.barrier()
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if use_pg and world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+    tr.check_ray_ids()
+    del tr
+    torch.cuda.empty_cache()
+    return dt / steps * 1e3
+
+
+def predicted_scaling(args, data, dev, step_ms_1gpu):
+    """What one node's strong-scaled run can be PREDICTED from on a single GPU (no 8-GPU node was available to any round): the
+    measured step of ONE rank's share of the global batch, rays / N for N = 2, 4, 8, with everything a rank does per step in place --
+    including the step's collective, as a one-rank RCCL process group (two captured graph segments with the all-reduce of the 152 916
+    floats between them; on one rank the collective moves no bytes over xGMI, so the links' own time is an estimate, stated apart)."""
+    import socket
+    import torch.distributed as dist
+    out = {"basis": "measured on ONE MI355X: graph-replayed step of a rank's share (rays / N) of the global batch under a one-rank RCCL process group "
+                    "(graph segment -> all_reduce(SUM) of the flat gradient + the early-stop pair -> graph segment with the library Adam)",
+           "global_rays": args.rays, "step_ms_1gpu_no_collective": step_ms_1gpu}
+    own_pg = False
+    try:
+        if not dist.is_initialized():
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                port = s.getsockname()[1]
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+            own_pg = True
+        steps = {}
+        for n in (1, 2, 4, 8):
+            if args.rays % n:
+                continue
+            steps[n] = quick_step_ms(args, args.prec, data, dev, 0, 1, True, args.rays // n)
+        out["step_ms_with_one_rank_collective"] = {str(n): v for n, v in steps.items()}
+        out["collective_overhead_ms_1gpu"] = steps[1] - step_ms_1gpu            # graph split + one-rank all-reduce launch, measured
+        # 152 916 f32 = 0.61 MB: on 8 ranks a direct reduce-scatter + all-gather moves 7/8 of it each way over 7 links of ~153 GB/s -- ~1 us of
+        # bandwidth; the collective is latency-bound (two hops of a few us each plus RCCL's launch), estimated, NOT measured here
+        out["xgmi_allreduce_estimate_ms"] = 0.04
+        out["predicted_speedup_vs_1gpu"] = {str(n): steps[1] / (steps[n] + (out["xgmi_allreduce_estimate_ms"] if n > 1 else 0.0)) for n in steps}
+        out["predicted_rays_per_s"] = {str(n): args.rays / ((steps[n] + (out["xgmi_allreduce_estimate_ms"] if n > 1 else 0.0)) * 1e-3) for n in steps}
+        out["note"] = ("a rank's kernels see rays / N rays: at N = 8 that is 8 192 rays x 192 samples = 24 576 wave tiles, 12 per wave of the persistent grids "
+                       "(resident kernels: threshold 16 384); what does not shrink with N is the per-step fixed part -- batch preparation, weight packing, "
+                       "loss finish, reductions over the split slabs, Adam: ~0.15 ms -- and the collective")
+    except Exception as e:          # (a box without RCCL for one rank: the record says so instead of failing the bench line)
+        out["error"] = f"{type(e).__name__}: {e}"
+    finally:
+        if own_pg:
+            dist.destroy_process_group()
+    return out
+
+
+def configs3_record(args, dev):
+    """BASELINE configs[3] -- "MAGIX 4D phantom, 8 angiogram sequences, 512^2 x 256 samples, fp32, 1 x MI355X" -- as a short leg of the
+    default line, so that it is timed by whoever runs the bench: synthetic data of that shape (MAGIX cone beam DSD 2000 / DSO 600 mm,
+    8 views x 10 phases of 512^2, 256 samples per ray), the f32 parity mode, one full detector (262 144 rays) per graph-replayed step.
+    The forward store of the whole batch would be ~380 GB: the step runs as ray micro-batches under the 96 GB store limit."""
+    import argparse
+    from nerfca_amd import synthetic
+    a3 = argparse.Namespace(**vars(args))
+    a3.det, a3.samples, a3.rays, a3.views, a3.prec, a3.kernel_steps, a3.scaling = 512, 256, 262144, 8, "f32", 1, "strong"
+    torch.cuda.empty_cache()
+    t0 = time.perf_counter()
+    data = synthetic.make_dataset(a3.det, a3.samples, dev, views=synthetic.TRAIN_VIEWS_8, geometry="magix")
+    build_s = time.perf_counter() - t0
+    rec = measure(a3, "f32", None, data, dev, 0, 1, False, args.configs3_steps, 1)
+    out = {"workload": "BASELINE configs[3]: MAGIX geometry, 8 views x 10 phases of 512^2, 256 samples/ray, 262 144 rays/step (one full detector), f32, fwd+losses+bwd+Adam",
+           "value": rec["value"], "unit": "rays/s", "ms_per_step": rec["ms_per_step"], "steps": rec["steps"], "warmup": rec["warmup"], "dtype": rec["dtype"],
+           "hip_graph": rec["hip_graph"], "final_loss": rec["final_loss"], "plan": rec["plan"], "roofline_step": rec["roofline"]["step"],
+           "per_kernel": rec["roofline"]["per_kernel"], "store_fallbacks": rec["store_fallbacks"], "dataset_build_s": build_s,
+           "ray_table_rows": int(data.rays_train.shape[0])}
+    del data
+    torch.cuda.empty_cache()
+    return out
 
 
 def psnr_record(args, dev):
@@ -551,6 +660,15 @@ def main():
     data = synthetic.make_dataset(args.det, args.samples, dev, views=views)
     main_rec = measure(args, args.prec, None, data, dev, rank, world, use_pg, args.steps, args.warmup,
                        sustained_steps=args.sustained_steps if (world == 1 and not args.no_extras) else 0)
+    other_rec = None
+    if world > 1 and not args.no_extras:
+        # the other scaling mode in the same run, every rank taking part: strong = one global batch of --rays split N ways, weak = --rays per rank
+        other = "weak" if args.scaling == "strong" else "strong"
+        g_rays = args.rays * world if other == "weak" else args.rays
+        if g_rays % world == 0:
+            ms = quick_step_ms(args, args.prec, data, dev, rank, world, use_pg, g_rays)
+            other_rec = {"scaling": other, "ms_per_step": ms, "value": g_rays / (ms * 1e-3), "unit": "rays/s", "global_rays_per_step": g_rays,
+                         "rays_per_step_per_gpu": g_rays // world, "steps": 30, "warmup": 5}
 
     if rank == 0:
         out = {"metric": f"training rays/sec ({args.det}^2 det, {args.samples} samples/ray)", "value": main_rec["value"], "unit": "rays/s",
@@ -567,8 +685,12 @@ def main():
                "kernel_table_steps": main_rec["kernel_table_steps"], "store_fallbacks": main_rec["store_fallbacks"]}
         if "sustained" in main_rec:
             out["sustained"] = main_rec["sustained"]
+        if other_rec is not None:
+            out[other_rec["scaling"] + "_scaling"] = other_rec
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, data)
+        if world == 1 and not args.no_extras and args.prec == "bf16":
+            out["predicted_scaling"] = predicted_scaling(args, data, dev, main_rec["ms_per_step"])
         if world == 1 and not args.no_extras:
             if args.unfused_gpu_rays > 0:
                 out["unfused_gpu_baseline"] = unfused_gpu_baseline(args, data)
@@ -585,6 +707,8 @@ def main():
                                  for k, r in (("f32", out.get("f32")), ("bf16", out.get("bf16_pure")), (main_rec["dtype"], main_rec)) if r}
             if args.psnr_steps > 0:
                 out["psnr"] = psnr_record(args, dev)
+            if args.configs3_steps > 0 and args.prec == "bf16":
+                out["configs3"] = configs3_record(args, dev)
         print(json.dumps(out))
     if use_pg:
         torch.distributed.destroy_process_group()

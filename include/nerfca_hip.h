@@ -80,8 +80,9 @@ typedef struct NcaPlanOpts {
     int64_t resident_min_tiles;       /* NCA_OPT_RESIDENT_MIN_TILES       */
     int64_t wgrad_rebuild_weight_pct; /* NCA_OPT_WGRAD_REBUILD_WEIGHT_PCT */
     int64_t overlap_cus;              /* NCA_OPT_OVERLAP_CUS (ABI 10)     */
+    int64_t bf16_store;               /* NCA_OPT_BF16_STORE (ABI 10)      */
 } NcaPlanOpts;
-#define NCA_PLAN_OPTS_INIT {NCA_OPT_UNSET, NCA_OPT_UNSET, NCA_OPT_UNSET, NCA_OPT_UNSET, NCA_OPT_UNSET}   /* "every field unset": a zeroed struct is NOT that (0 is a value of every option) */
+#define NCA_PLAN_OPTS_INIT {NCA_OPT_UNSET, NCA_OPT_UNSET, NCA_OPT_UNSET, NCA_OPT_UNSET, NCA_OPT_UNSET, NCA_OPT_UNSET}   /* "every field unset": a zeroed struct is NOT that (0 is a value of every option) */
 struct NcaPlan;
 
 /* A batch of rays and the per-step sampling state: the arguments of
@@ -118,6 +119,9 @@ enum {
     NCA_STORE_F32 = 1,        /* f32 mode: every layer input, ReLU masks, raw outputs                         */
     NCA_STORE_RESERVED2 = 2,  /* (ABI <= 8: bf16 mode with bf16 staging -- retired; never returned, refused by the backward)          */
     NCA_STORE_FP8 = 3,        /* bf16 mode: layer inputs as e4m3, masks of all layers, raw outputs               */
+    NCA_STORE_BF16 = 4,       /* bf16 mode with NCA_OPT_STAGE_FP8 = 0 (ABI 10): layer inputs as bf16 fragments, masks of all layers, raw
+                                 outputs -- nothing in 8 bits, nothing recomputed: the backward writes bf16 output gradients and the
+                                 weight gradient contracts bf16 x bf16                                                */
     NCA_STORE_KIND_MASK = 15,
     NCA_STORE_SHARED_ENC = 16 /* flag: both nets share one stored input block (same encoding vectors)          */
 };
@@ -228,16 +232,30 @@ typedef struct NcaLoss {
                                 fine pass differentiates through the interval lengths of ray 0 (train/model_helpers.py:150); needs the
                                 three gradient outputs and `dists_work`                                                    */
     double* dists_work;      /* DEVICE f64[R * S] scratch for g_dists (per-ray contributions, summed over rays in a fixed order) */
+    const double* term_grads;/* NULL, or DEVICE f64[11] (ABI 10): TERM-GRADIENT MODE -- the backward of compute_losses as an autograd function
+                                (train/model_helpers.py:250-262).  Element i is the upstream gradient of the reference's i-th return value
+                                [blendw mean, sigma_s max, sigma_d max, favor, s_entropy, s_sum, d_entropy, d_sum, occl, l1, l2] (the maxima are
+                                computed under no_grad there: their entries are ignored); g_sig_s / g_sig_d (and g_dists) then are
+                                sum_i term_grads[i] d term_i / d sigma -- every term, not only the six the training loss weights.  There is
+                                no pixel term in this mode: pix, gt and g_pix may be NULL (weighted_MSELoss is nca_weighted_sq_err);
+                                the four weights above and weights_dev are not read                                                          */
 } NcaLoss;
 enum { NCA_T_LOSS = 0, NCA_T_PIXEL, NCA_T_BLENDW, NCA_T_SIG_S_MAX, NCA_T_SIG_D_MAX, NCA_T_FAVOR, NCA_T_S_ENTROPY, NCA_T_S_SUM,
        NCA_T_D_ENTROPY, NCA_T_D_SUM, NCA_T_OCCL, NCA_T_L1, NCA_T_L2, NCA_T_COUNT };
 int64_t nca_loss_workspace(int64_t R);
-/* terms f64[NCA_T_COUNT]; gradients g_pix f64[R], g_sig_s/g_sig_d f32[R,S] (all three NULL = values only).
+/* terms f64[NCA_T_COUNT]; gradients g_pix f64[R], g_sig_s/g_sig_d f32[R,S] (all three NULL = values only; term-gradient mode: g_pix NULL).
  * pix, gt, wpix are f64[R]; sig_s, sig_d f32[R,S]; dists f64[S]. */
 int nca_loss_fwd_bwd(const NcaLoss* desc, const double* pix, const double* gt, const double* wpix,
                      const float* sig_s, const float* sig_d, const double* dists,
                      double* terms, double* g_pix, float* g_sig_s, float* g_sig_d,
                      void* work, int64_t work_bytes, void* stream);
+
+/* weighted_MSELoss.forward (train/model_helpers.py:284-288): out[r] = (pred[r] - gt[r])^2 * w[r] (the caller takes the mean,
+ * train/run_composite.py:287) and its backward; all arrays of one dtype, f64 (is_f64 = 1: what the real script's f64 ray table gives) or
+ * f32; g_pred / g_gt / g_w may each be NULL. */
+int nca_weighted_sq_err(int64_t R, int32_t is_f64, const void* pred, const void* gt, const void* w, void* out, void* stream);
+int nca_weighted_sq_err_bwd(int64_t R, int32_t is_f64, const void* pred, const void* gt, const void* w, const void* g_out,
+                            void* g_pred, void* g_gt, void* g_w, void* stream);
 
 /* ---- fine-pass depths: the sampling half of the hierarchical pass of obtain_train_predictions_iter
  *      (train/model_helpers.py:131-148) with sample_pdf (:162-187): weights = |jump of sigma_s + sigma_d| / batch-wide
@@ -334,6 +352,12 @@ enum {
                                      weight-gradient launch for both nets after both dgrad launches (ABI <= 9).  The value fixes the split of the
                                      sample sums, hence the bits of the gradient (run to run they are identical either way).  Initial value from
                                      NCA_OVERLAP_CUS; nca_last_plan().overlap_cus says what ran */
+    NCA_OPT_BF16_STORE = 6,       /* bf16 mode, batches for which the 8-bit staged store is off (NCA_OPT_STAGE_FP8 = 0, or below its threshold): 1 (default) =
+                                     the forward may still leave a store, with the layer inputs as BF16 fragments (NCA_STORE_BF16; masks of every layer
+                                     and raw outputs as in the 8-bit store) -- the backward then recomputes nothing (mode 5), writes bf16 output
+                                     gradients and the weight gradient contracts bf16 x bf16: BASELINE configs[1] "as written", nothing in 8 bits;
+                                     0 = no store, the backward recomputes the layers (mode 1; also what runs when the caller passes no store).
+                                     Initial value from NCA_BF16_STORE */
     NCA_OPT_COUNT
 };
 int nca_get_option(int32_t opt, int64_t* value);

@@ -21,7 +21,8 @@ OPT_RESIDENT_MIN_TILES = 2
 OPT_STAGE_FP8_MIN_TILES = 3
 OPT_WGRAD_REBUILD_WEIGHT_PCT = 4
 OPT_OVERLAP_CUS = 5
-STORE_NONE, STORE_F32, STORE_FP8, STORE_KIND_MASK, STORE_SHARED_ENC = 0, 1, 3, 15, 16       # (2 was the retired bf16-staged store)
+OPT_BF16_STORE = 6
+STORE_NONE, STORE_F32, STORE_FP8, STORE_BF16, STORE_KIND_MASK, STORE_SHARED_ENC = 0, 1, 3, 4, 15, 16       # (2 was round 3's bf16-staged store: retired)
 OPT_UNSET = -(1 << 63)     # NCA_OPT_UNSET: "use the process-wide value" in an NcaPlanOpts field
 K_PACK, K_FWD, K_BWD_DGRAD, K_BWD_WGRAD, K_BWD_REDUCE, K_LOSS, K_ADAM = 0, 1, 2, 3, 4, 5, 6
 KERNEL_KINDS = {"pack": K_PACK, "fwd": K_FWD, "bwd_dgrad": K_BWD_DGRAD, "bwd_wgrad": K_BWD_WGRAD, "bwd_reduce": K_BWD_REDUCE,
@@ -38,7 +39,7 @@ class NcaNet(C.Structure):
 class NcaPlanOpts(C.Structure):
     """Per-call planner options (NcaRays.plan_opts): a field other than OPT_UNSET replaces the process-wide tunable for that call."""
     _fields_ = [("stage_fp8", C.c_int64), ("stage_fp8_min_tiles", C.c_int64), ("resident_min_tiles", C.c_int64), ("wgrad_rebuild_weight_pct", C.c_int64),
-                ("overlap_cus", C.c_int64)]
+                ("overlap_cus", C.c_int64), ("bf16_store", C.c_int64)]
 
     def __init__(self, **kw):
         super().__init__()
@@ -64,7 +65,7 @@ class NcaLoss(C.Structure):
     _fields_ = [("R", C.c_int64), ("S", C.c_int32), ("use_weighting", C.c_int32), ("skew", C.c_double), ("mask_thre", C.c_double),
                 ("weighted_thresh", C.c_double), ("w_favor", C.c_double), ("w_dent", C.c_double), ("w_occl", C.c_double),
                 ("w_l1", C.c_double), ("inv_R", C.c_double), ("weights_dev", C.c_void_p), ("unit_mse", C.c_int32), ("reserved", C.c_int32),
-                ("g_dists", C.c_void_p), ("dists_work", C.c_void_p)]
+                ("g_dists", C.c_void_p), ("dists_work", C.c_void_p), ("term_grads", C.c_void_p)]
 
 
 class NcaAdam(C.Structure):
@@ -108,6 +109,8 @@ SYMBOLS = {
     "nca_composite_bwd": (C.c_int, [_I64, _I32, _I32, _I32, C.c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "nca_loss_workspace": (_I64, [_I64]),
     "nca_loss_fwd_bwd": (C.c_int, [C.POINTER(NcaLoss), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
+    "nca_weighted_sq_err": (C.c_int, [_I64, _I32, _P, _P, _P, _P, _P]),
+    "nca_weighted_sq_err_bwd": (C.c_int, [_I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "nca_fine_depths_workspace": (_I64, [_I64]),
     "nca_fine_depths": (C.c_int, [_I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "nca_fine_depths_bwd": (C.c_int, [_I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

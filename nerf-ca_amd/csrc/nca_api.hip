@@ -165,6 +165,8 @@ void opt_init_locked() {
     if (e && atoi(e) >= 100 && atoi(e) <= 200) g_opt[NCA_OPT_WGRAD_REBUILD_WEIGHT_PCT] = atoi(e);
     e = getenv("NCA_OVERLAP_CUS");
     if (e && atoi(e) >= 0) g_opt[NCA_OPT_OVERLAP_CUS] = atoi(e);
+    e = getenv("NCA_BF16_STORE");
+    if (e && (e[0] == '0' || e[0] == '1')) g_opt[NCA_OPT_BF16_STORE] = e[0] - '0';
     g_opt_init = true;
 }
 // default of NCA_OPT_STAGE_FP8_MIN_TILES: see stage_fp8_for()
@@ -177,7 +179,7 @@ int64_t opt_value(int opt) {
     if (t_call_opts) {
         const int64_t c = opt == NCA_OPT_STAGE_FP8 ? t_call_opts->stage_fp8 : opt == NCA_OPT_STAGE_FP8_MIN_TILES ? t_call_opts->stage_fp8_min_tiles
                         : opt == NCA_OPT_RESIDENT_MIN_TILES ? t_call_opts->resident_min_tiles : opt == NCA_OPT_WGRAD_REBUILD_WEIGHT_PCT ? t_call_opts->wgrad_rebuild_weight_pct
-                        : opt == NCA_OPT_OVERLAP_CUS ? t_call_opts->overlap_cus : NCA_OPT_UNSET;
+                        : opt == NCA_OPT_OVERLAP_CUS ? t_call_opts->overlap_cus : opt == NCA_OPT_BF16_STORE ? t_call_opts->bf16_store : NCA_OPT_UNSET;
         if (c != NCA_OPT_UNSET) return c;
     }
     std::lock_guard<std::mutex> lk(g_omu);
@@ -188,6 +190,7 @@ int64_t opt_value(int opt) {
         if (opt == NCA_OPT_STAGE_FP8_MIN_TILES) v = STAGE_FP8_DEFAULT_MIN_TILES;
         if (opt == NCA_OPT_WGRAD_REBUILD_WEIGHT_PCT) v = 115;
         if (opt == NCA_OPT_OVERLAP_CUS) v = OVERLAP_CUS_DEFAULT;
+        if (opt == NCA_OPT_BF16_STORE) v = 1;
         if (opt == NCA_OPT_RESIDENT_MIN_TILES) v = (int64_t)8 * NCA_WAVES * num_cus();    // (at 4 tiles per wave -- the reference's 1 024 x 500 batch -- resident and streaming tie)
     }
     return v;
@@ -219,14 +222,15 @@ static int check_option_value(int32_t opt, int64_t value) {
     if (opt == NCA_OPT_STAGE_FP8_MIN_TILES && value < 0) return fail(NCA_E_INVALID, "NCA_OPT_STAGE_FP8_MIN_TILES takes a tile count >= 0");
     if (opt == NCA_OPT_WGRAD_REBUILD_WEIGHT_PCT && (value < 100 || value > 200)) return fail(NCA_E_INVALID, "NCA_OPT_WGRAD_REBUILD_WEIGHT_PCT takes 100 .. 200");
     if (opt == NCA_OPT_OVERLAP_CUS && (value < 0 || value > 4096)) return fail(NCA_E_INVALID, "NCA_OPT_OVERLAP_CUS takes 0 (off) or a number of compute units");
+    if (opt == NCA_OPT_BF16_STORE && value != 0 && value != 1) return fail(NCA_E_INVALID, "NCA_OPT_BF16_STORE takes 0 (no store without 8-bit staging: recompute) or 1");
     return NCA_OK;
 }
 namespace {
 int check_plan_opts(const NcaPlanOpts* o) {
     if (!o) return NCA_OK;
-    const int64_t v[5] = {o->stage_fp8, o->stage_fp8_min_tiles, o->resident_min_tiles, o->wgrad_rebuild_weight_pct, o->overlap_cus};
-    const int32_t k[5] = {NCA_OPT_STAGE_FP8, NCA_OPT_STAGE_FP8_MIN_TILES, NCA_OPT_RESIDENT_MIN_TILES, NCA_OPT_WGRAD_REBUILD_WEIGHT_PCT, NCA_OPT_OVERLAP_CUS};
-    for (int i = 0; i < 5; ++i)
+    const int64_t v[6] = {o->stage_fp8, o->stage_fp8_min_tiles, o->resident_min_tiles, o->wgrad_rebuild_weight_pct, o->overlap_cus, o->bf16_store};
+    const int32_t k[6] = {NCA_OPT_STAGE_FP8, NCA_OPT_STAGE_FP8_MIN_TILES, NCA_OPT_RESIDENT_MIN_TILES, NCA_OPT_WGRAD_REBUILD_WEIGHT_PCT, NCA_OPT_OVERLAP_CUS, NCA_OPT_BF16_STORE};
+    for (int i = 0; i < 6; ++i)
         if (v[i] != NCA_OPT_UNSET) { int rc = check_option_value(k[i], v[i]); if (rc) return rc; }
     return NCA_OK;
 }
@@ -468,10 +472,12 @@ struct StorePlan {
     int32_t mask_layers;
 };
 // wave_tiles: 64-sample tiles (bf16) / 32-sample tiles (f32)
-static bool store_plan(const NcaLayout* lays, int nnets, int32_t prec, int64_t wave_tiles, StorePlan* sp, bool share_enc = false) {
+// h8 (bf16 mode): the 8-bit staged store (layer inputs as e4m3) or the bf16 store (layer inputs as bf16 fragments: NCA_STORE_BF16); both
+// hold the masks of every layer and the raw outputs -- the backward from either recomputes nothing
+static bool store_plan(const NcaLayout* lays, int nnets, int32_t prec, int64_t wave_tiles, StorePlan* sp, bool share_enc = false, bool h8 = true) {
     if (nnets == 2 && lays[0].F != lays[1].F) return false;
     const bool bf = prec == NCA_PREC_BF16;
-    const bool h8 = bf;          // the bf16 mode's store is the 8-bit one
+    if (!bf) h8 = false;
     const int64_t EB = nca_bf_ebytes(bf && h8);
     // bf16: slack tile slots up to the next multiple of the 8 waves of a workgroup -- a wave without a tile writes there, so
     // that the storing forward's hot loops need no store predicate
@@ -482,7 +488,7 @@ static bool store_plan(const NcaLayout* lays, int nnets, int32_t prec, int64_t w
         sp->row0[n] = sp->h_stride;
         if (bf) sp->h_stride += EB + nca_bf_hbytes(lays[n], h8);                      // inputs of layers 0 .. NL-1
         else sp->h_stride += lays[n].K0rows_pad + (int64_t)lays[n].NL * lays[n].F;
-        const int ml = (bf && h8) ? lays[n].NL : lays[n].NL - 1;        // fp8 staging: the masks of every layer (the backward recomputes none)
+        const int ml = bf ? lays[n].NL : lays[n].NL - 1;        // bf16 mode: the masks of every layer (the backward recomputes none)
         if (ml > sp->mask_layers) sp->mask_layers = ml;
     }
     if (share_enc) {      // [dynamic: input block + hidden blocks][static: hidden blocks only]
@@ -493,7 +499,7 @@ static bool store_plan(const NcaLayout* lays, int nnets, int32_t prec, int64_t w
     }
     if (bf) {
         sp->off_m = align_up(wave_tiles * 2 * sp->h_stride, 1024);
-        sp->off_r = sp->off_m + wave_tiles * 2 * sp->mask_layers * 1024;       // raw outputs [wave tile][net][64] f32: fp8 staging only
+        sp->off_r = sp->off_m + wave_tiles * 2 * sp->mask_layers * 1024;       // raw outputs [wave tile][net][64] f32
         sp->bytes = align_up(sp->off_r + wave_tiles * 2 * 64 * 4, 256);
     } else {
         sp->off_m = align_up(wave_tiles * sp->h_stride * 32 * 4, 1024);
@@ -517,8 +523,10 @@ extern "C" int64_t nca_render_store_bytes(const NcaRays* rays, const NcaNet* net
     StorePlan sp;
     const int ts = tile_samples(prec);
     const int64_t wave_tiles = rays->R * ((rays->S + ts - 1) / ts);
-    if (prec == NCA_PREC_BF16 && !stage_fp8_for(wave_tiles)) return 0;          // NCA_OPT_STAGE_FP8 says: no store, the backward recomputes
-    if (!store_plan(lays, nn, prec, wave_tiles, &sp)) return 0;
+    // bf16 mode: the 8-bit staged store, or -- NCA_OPT_STAGE_FP8 says "nothing in 8 bits" for this batch -- the bf16 store
+    const bool h8 = prec == NCA_PREC_BF16 && stage_fp8_for(wave_tiles);
+    if (prec == NCA_PREC_BF16 && !h8 && opt_value(NCA_OPT_BF16_STORE) == 0) return 0;          // no store at all: the backward will recompute
+    if (!store_plan(lays, nn, prec, wave_tiles, &sp, false, h8)) return 0;
     return sp.bytes;          // (the layout with one input block per net: a shared one needs less)
 }
 
@@ -595,15 +603,18 @@ extern "C" int nca_render_fwd(const NcaRays* rays, int32_t prec,
     a.sig_d = sig_d;
     int kmode = NCA_KM_FWD;
     int store_format = NCA_STORE_NONE;
-    // bf16 with NCA_OPT_STAGE_FP8 saying "no store" for this batch: the buffer is left untouched and the return value says so (0)
-    if (store && prec == NCA_PREC_BF16 && !stage_fp8_for(a.ntiles)) store = nullptr;
+    // bf16 with neither store allowed for this batch (NCA_OPT_STAGE_FP8 off, NCA_OPT_BF16_STORE = 0): the buffer is left untouched and the
+    // return value says so (0) -- the backward recomputes
+    if (store && prec == NCA_PREC_BF16 && !stage_fp8_for(a.ntiles) && opt_value(NCA_OPT_BF16_STORE) == 0) store = nullptr;
     if (store) {
         NcaLayout lays[2] = {a.net[0].lay, a.net[1].lay};
         StorePlan spl;
         a.share_enc = can_share_enc(a, prec) ? 1 : 0;
-        a.h8 = prec == NCA_PREC_BF16 ? 1 : 0;
-        store_format = (prec == NCA_PREC_BF16 ? NCA_STORE_FP8 : NCA_STORE_F32) | (a.share_enc ? NCA_STORE_SHARED_ENC : 0);
-        if (!store_plan(lays, a.nnets, prec, a.ntiles, &spl, a.share_enc != 0))
+        // bf16 mode: layer inputs as e4m3 (the 8-bit staged store) or, with NCA_OPT_STAGE_FP8 saying "nothing in 8 bits" for this batch,
+        // as bf16 fragments (NCA_STORE_BF16) -- the return value tells the backward which
+        a.h8 = (prec == NCA_PREC_BF16 && stage_fp8_for(a.ntiles)) ? 1 : 0;
+        store_format = (prec != NCA_PREC_BF16 ? NCA_STORE_F32 : a.h8 ? NCA_STORE_FP8 : NCA_STORE_BF16) | (a.share_enc ? NCA_STORE_SHARED_ENC : 0);
+        if (!store_plan(lays, a.nnets, prec, a.ntiles, &spl, a.share_enc != 0, a.h8 != 0))
             return fail(NCA_E_UNSUPPORTED, "a forward store needs nets of one width with at least one hidden layer");
         if (store_bytes < spl.bytes) return fail(NCA_E_WORKSPACE, "forward store %lld < %lld bytes", (long long)store_bytes, (long long)spl.bytes);
         kmode = NCA_KM_FWD_STORE;
@@ -878,8 +889,8 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     // The store's format is what the forward that wrote it reported (NcaRays.store_format), never this call's reading of the options
     if (stored) {
         const int kind = store_format & NCA_STORE_KIND_MASK;
-        const int want = bf ? NCA_STORE_FP8 : NCA_STORE_F32;
-        if ((store_format & ~(NCA_STORE_KIND_MASK | NCA_STORE_SHARED_ENC)) || kind != want)
+        const bool kind_ok = bf ? (kind == NCA_STORE_FP8 || kind == NCA_STORE_BF16) : kind == NCA_STORE_F32;
+        if ((store_format & ~(NCA_STORE_KIND_MASK | NCA_STORE_SHARED_ENC)) || !kind_ok)
             return fail(NCA_E_INVALID, "rays->store_format = %d does not name a store of this precision: pass the value nca_render_fwd returned when it wrote the store "
                                        "(0 = it wrote none: pass store = NULL)", store_format);
         const bool shared = (store_format & NCA_STORE_SHARED_ENC) != 0;
@@ -887,16 +898,18 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
             return fail(NCA_E_INVALID, "the store was written with %s input block, but the encoding vectors of this call say otherwise: pass the backward the SAME window / coefficient pointers as the forward",
                         shared ? "one shared" : "one per net");
     }
-    const bool h8 = bf && stored;          // the bf16 mode's store: layer inputs as e4m3, masks of every layer, raw outputs
+    // the bf16 mode's stores: layer inputs as e4m3 (8-bit staged: the output gradients then cross HBM as e5m2) or as bf16 fragments
+    // (NCA_STORE_BF16: bf16 output gradients, the bf16 x bf16 weight-gradient jobs); both hold the masks of every layer and the raw outputs
+    const bool h8 = bf && stored && (store_format & NCA_STORE_KIND_MASK) == NCA_STORE_FP8;
     const bool d8 = h8 && !g_depth;
     a.h8 = h8 ? 1 : 0;
     if (stored) {
         a.share_enc = (store_format & NCA_STORE_SHARED_ENC) ? 1 : 0;
-        if (!store_plan(lays, a.nnets, prec, units * tiles_per_unit, &spl, a.share_enc != 0)) return fail(NCA_E_UNSUPPORTED, "no forward store exists for this configuration");
+        if (!store_plan(lays, a.nnets, prec, units * tiles_per_unit, &spl, a.share_enc != 0, h8)) return fail(NCA_E_UNSUPPORTED, "no forward store exists for this configuration");
         if (store_bytes < spl.bytes) return fail(NCA_E_WORKSPACE, "forward store %lld < %lld bytes", (long long)store_bytes, (long long)spl.bytes);
     }
     // the store holds every layer's output, masks and raw outputs -- mode 5, nothing recomputed
-    const bool nr = h8;
+    const bool nr = bf && stored;
     // one launch per net with that net's weight images resident in LDS
     const int64_t res_min = opt_value(NCA_OPT_RESIDENT_MIN_TILES);
     bool res3 = bf && stored && res_min >= 0 && units * tiles_per_unit >= res_min;
@@ -1355,6 +1368,9 @@ extern "C" int nca_mlp_bwd(const NcaNet* net, int32_t prec, const void* packed, 
     if (rc) return rc;
     if (a.net[0].lay.T > 0 && !phase) return fail(NCA_E_INVALID, "dynamic net needs phase ids");
     if (g_latents && a.net[0].lay.T <= 0) return fail(NCA_E_INVALID, "per-point latent gradients of a net without latents");
+    if (g_latents)       // (a skip layer reads [enc, latents, hidden] again: its W[:, latent columns]^T D term is not formed here)
+        for (int j = 0; j < a.net[0].lay.NL; ++j)
+            if (a.net[0].lay.layer[j].kind == NCA_IN_SKIP) return fail(NCA_E_UNSUPPORTED, "per-point latent gradients of a net with a skip layer (the table-row sums in `grads` are complete)");
     a.N = N;
     a.pts = pts;
     a.phase = phase;
@@ -1376,9 +1392,13 @@ extern "C" int nca_loss_fwd_bwd(const NcaLoss* d, const double* pix, const doubl
                                 void* work, int64_t work_bytes, void* stream) {
     if (!d) return fail(NCA_E_INVALID, "loss descriptor is NULL");
     if (d->R <= 0 || d->S <= 0) return fail(NCA_E_INVALID, "empty ray batch");
-    if (!pix || !gt || !wpix || !sig_s || !sig_d || !dists || !terms) return fail(NCA_E_INVALID, "a loss input pointer is NULL");
+    const bool tgm = d->term_grads != nullptr;       // term-gradient mode: no pixel term -- pix / gt / g_pix may be NULL
+    if ((!tgm && (!pix || !gt)) || !wpix || !sig_s || !sig_d || !dists || !terms) return fail(NCA_E_INVALID, "a loss input pointer is NULL");
+    if ((pix == nullptr) != (gt == nullptr)) return fail(NCA_E_INVALID, "pix and gt: both or neither");
+    if (tgm && d->weights_dev) return fail(NCA_E_INVALID, "term_grads and weights_dev exclude each other");
     const bool any = g_pix || g_sig_s || g_sig_d;
-    if (any && !(g_pix && g_sig_s && g_sig_d)) return fail(NCA_E_INVALID, "give all three gradient outputs or none");
+    if (any && !((g_pix || !pix) && g_sig_s && g_sig_d)) return fail(NCA_E_INVALID, "give all three gradient outputs or none (g_pix may be NULL where pix is)");
+    if (g_pix && !pix) return fail(NCA_E_INVALID, "g_pix without pix");
     const int64_t need = nca_loss_workspace(d->R);
     if (!work || work_bytes < need) return fail(NCA_E_WORKSPACE, "loss workspace %lld < %lld bytes", (long long)work_bytes, (long long)need);
     NcaLossArgs a;
@@ -1393,8 +1413,25 @@ extern "C" int nca_loss_fwd_bwd(const NcaLoss* d, const double* pix, const doubl
     if (d->g_dists && !(any && d->dists_work)) return fail(NCA_E_INVALID, "g_dists needs the three gradient outputs and dists_work (f64[R * S])");
     a.g_dists = d->g_dists;
     a.dists_work = d->g_dists ? d->dists_work : nullptr;
+    a.term_grads = d->term_grads;
     Span sp(NCA_K_LOSS, (hipStream_t)stream);
     HIPCHK(nca_launch_loss(a, (hipStream_t)stream));
+    return NCA_OK;
+}
+
+extern "C" int nca_weighted_sq_err(int64_t R, int32_t is_f64, const void* pred, const void* gt, const void* w, void* out, void* stream) {
+    if (R <= 0) return fail(NCA_E_INVALID, "empty ray batch");
+    if (!pred || !gt || !w || !out) return fail(NCA_E_INVALID, "a pointer is NULL");
+    Span sp(NCA_K_LOSS, (hipStream_t)stream);
+    HIPCHK(nca_launch_wsqerr(R, is_f64 != 0, pred, gt, w, out, (hipStream_t)stream));
+    return NCA_OK;
+}
+extern "C" int nca_weighted_sq_err_bwd(int64_t R, int32_t is_f64, const void* pred, const void* gt, const void* w, const void* g_out,
+                                       void* g_pred, void* g_gt, void* g_w, void* stream) {
+    if (R <= 0) return fail(NCA_E_INVALID, "empty ray batch");
+    if (!pred || !gt || !w || !g_out) return fail(NCA_E_INVALID, "a pointer is NULL");
+    Span sp(NCA_K_LOSS, (hipStream_t)stream);
+    HIPCHK(nca_launch_wsqerr_bwd(R, is_f64 != 0, pred, gt, w, g_out, g_pred, g_gt, g_w, (hipStream_t)stream));
     return NCA_OK;
 }
 

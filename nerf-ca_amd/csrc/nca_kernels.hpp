@@ -179,6 +179,7 @@ struct NcaLossArgs {
     double* partials;
     double* g_dists;      // [S] or null
     double* dists_work;   // [R * S] per-ray d loss / d dists
+    const double* term_grads;   // null, or DEVICE f64[11]: term-gradient mode (NcaLoss.term_grads)
 };
 struct NcaCompositeArgs {
     int64_t R;
@@ -190,6 +191,8 @@ struct NcaCompositeArgs {
 };
 hipError_t nca_launch_composite(const NcaCompositeArgs& a, bool bwd, hipStream_t st);
 hipError_t nca_launch_loss(const NcaLossArgs& a, hipStream_t st);
+hipError_t nca_launch_wsqerr(int64_t R, bool f64, const void* pred, const void* gt, const void* w, void* out, hipStream_t st);
+hipError_t nca_launch_wsqerr_bwd(int64_t R, bool f64, const void* pred, const void* gt, const void* w, const void* g_out, void* g_pred, void* g_gt, void* g_w, hipStream_t st);
 struct NcaAdamArgs {
     double lr, beta1, beta2, eps, lr_end_factor;
     int64_t lr_total_iters;

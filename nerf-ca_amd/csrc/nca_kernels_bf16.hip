@@ -449,7 +449,8 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
     constexpr bool NR = MODE == NCA_KM_BWD_NR;                                // from a store with fp8 staging: nothing is recomputed
     constexpr int RINGK = NCA_BF_RING;                                        // A-fragment ring of the layer contractions
     static_assert(MODE == NCA_KM_FWD || MODE == NCA_KM_BWD || MODE == NCA_KM_FWD_STORE || NR, "bf16 modes: 0 forward, 1 recompute backward, 2 storing forward, 5 backward from the store");
-    static_assert(MODE != NCA_KM_FWD_STORE || S8, "the bf16 forward store is the 8-bit one (bf16 staging -- round-3 modes 3 / 4 -- was retired in round 4)");
+    // (MODE 2 with !S8: the BF16 store of round 5 -- layer inputs as bf16 fragments, masks of every layer, raw outputs: what mode 5 and
+    // the bf16 weight-gradient jobs need when nothing may be staged in 8 bits, NCA_STORE_BF16)
     constexpr bool BWD = MODE == NCA_KM_BWD || NR;                            // output-layer gradients + dgrad sweep
     constexpr bool STORE = MODE == NCA_KM_BWD || MODE == NCA_KM_FWD_STORE;    // writes the input block and the layer inputs
     constexpr bool RECOMP = !NR;                                              // runs the forward layers
@@ -894,7 +895,7 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
                         }
                     }
                     // words 0..7 of a (row tile, column tile): fragment 2m holds accumulator registers 0..7, fragment 2m + 1 registers 8..15
-                    const bool want_mask = STORE && (!LAST || H8);
+                    const bool want_mask = STORE && (!LAST || FSTORE);          // a forward store holds the masks of EVERY layer (mode 5 recomputes none)
 #pragma unroll
                     for (int c = 0; c < 2; ++c) {
                         unsigned w[8];
@@ -971,7 +972,7 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
                     u32x4 mv = {mw[0][0], mw[0][1], mw[1][0], mw[1][1]};
                     *reinterpret_cast<u32x4*>(mwave + jj * 1024) = mv;
                 }
-                if (FSTORE && (!last || S8)) {
+                if (FSTORE) {
                     u32x4 mv = {mw[0][0], mw[0][1], mw[1][0], mw[1][1]};
                     store_nt(mglob + jj * 1024, mv);
                 }
@@ -983,8 +984,8 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
                     const float r0 = part[0] + __shfl_xor(part[0], 32) + bo;
                     const float r1 = part[1] + __shfl_xor(part[1], 32) + bo;
                     raw[net] = lh ? r1 : r0;
-                    // fp8 staging: the raw output goes to the store as well ([wave tile][net][64] f32), the backward recomputes nothing
-                    if (FSTORE && S8) a.rstore[((tg * 2 + net + a.net_base) * 64) + lane] = raw[net];
+                    // the raw output goes to the store as well ([wave tile][net][64] f32): the backward from a store recomputes nothing
+                    if (FSTORE) a.rstore[((tg * 2 + net + a.net_base) * 64) + lane] = raw[net];
                 }
 
                 if (BWD && last) last_layer_grads(tail + 2 * MT * 16);
@@ -1643,7 +1644,7 @@ static hipError_t launch_fused_bf(const NcaFusedArgs& a, int kmode, int grid, hi
     if (a.res_bytes > 0) {         // resident weight images (one net per launch; the host has checked that they fit)
         switch (kmode) {
             case NCA_KM_FWD: return launch_fused_bf_mode<F, NCA_KM_FWD, false, true>(a, grid, st);
-            case NCA_KM_FWD_STORE: return s8 ? launch_fused_bf_mode<F, NCA_KM_FWD_STORE, true, true>(a, grid, st) : hipErrorInvalidValue;        // (the store is the 8-bit one)
+            case NCA_KM_FWD_STORE: return s8 ? launch_fused_bf_mode<F, NCA_KM_FWD_STORE, true, true>(a, grid, st) : launch_fused_bf_mode<F, NCA_KM_FWD_STORE, false, true>(a, grid, st);
             case NCA_KM_BWD_NR: return s8 ? launch_fused_bf_mode<F, NCA_KM_BWD_NR, true, true>(a, grid, st) : launch_fused_bf_mode<F, NCA_KM_BWD_NR, false, true>(a, grid, st);
         }
         return hipErrorInvalidValue;
@@ -1651,7 +1652,7 @@ static hipError_t launch_fused_bf(const NcaFusedArgs& a, int kmode, int grid, hi
     switch (kmode) {
         case NCA_KM_FWD: return launch_fused_bf_mode<F, NCA_KM_FWD, false>(a, grid, st);
         case NCA_KM_BWD: return launch_fused_bf_mode<F, NCA_KM_BWD, false>(a, grid, st);
-        case NCA_KM_FWD_STORE: return s8 ? launch_fused_bf_mode<F, NCA_KM_FWD_STORE, true>(a, grid, st) : hipErrorInvalidValue;
+        case NCA_KM_FWD_STORE: return s8 ? launch_fused_bf_mode<F, NCA_KM_FWD_STORE, true>(a, grid, st) : launch_fused_bf_mode<F, NCA_KM_FWD_STORE, false>(a, grid, st);
         case NCA_KM_BWD_NR: return s8 ? launch_fused_bf_mode<F, NCA_KM_BWD_NR, true>(a, grid, st) : launch_fused_bf_mode<F, NCA_KM_BWD_NR, false>(a, grid, st);
     }
     return hipErrorInvalidValue;

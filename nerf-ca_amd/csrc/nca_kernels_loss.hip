@@ -37,9 +37,14 @@ __global__ __launch_bounds__(LOSS_NT) void nca_loss_rays(const NcaLossArgs a) {
     for (int i = 0; i < NPART; ++i) part[i] = 0.0;
     float mx_s = 0.f, mx_d = 0.f;
 
-    // this step's weights: by value, or from the device vector a graph replay refreshes
-    const double w_favor = a.weights_dev ? a.weights_dev[0] : a.w_favor, w_dent = a.weights_dev ? a.weights_dev[1] : a.w_dent;
-    const double w_occl = a.weights_dev ? a.weights_dev[2] : a.w_occl, w_l1 = a.weights_dev ? a.weights_dev[3] : a.w_l1;
+    // this step's weights: by value, or from the device vector a graph replay refreshes -- or, term-gradient mode (a.term_grads: the
+    // backward of compute_losses as an autograd function), the upstream gradient of each of the reference's eleven return values
+    // [blendw, max_s, max_d, favor, s_entropy, s_sum, d_entropy, d_sum, occl, l1, l2] (the maxima carry none, model_helpers.py:189-198)
+    const bool tgm = a.term_grads != nullptr;
+    const double w_favor = tgm ? a.term_grads[3] : (a.weights_dev ? a.weights_dev[0] : a.w_favor), w_dent = tgm ? a.term_grads[6] : (a.weights_dev ? a.weights_dev[1] : a.w_dent);
+    const double w_occl = tgm ? a.term_grads[8] : (a.weights_dev ? a.weights_dev[2] : a.w_occl), w_l1 = tgm ? a.term_grads[9] : (a.weights_dev ? a.weights_dev[3] : a.w_l1);
+    const double w_l2 = tgm ? a.term_grads[10] : w_l1;
+    const double w_bw = tgm ? a.term_grads[0] : 0.0, w_sent = tgm ? a.term_grads[4] : 0.0, w_ssum = tgm ? a.term_grads[5] : 0.0, w_dsum = tgm ? a.term_grads[7] : 0.0;
     if (r < a.R) {
         const float* ss = a.sig_s + r * a.S;
         const float* sd = a.sig_d + r * a.S;
@@ -63,7 +68,7 @@ __global__ __launch_bounds__(LOSS_NT) void nca_loss_rays(const NcaLossArgs a) {
         Ms = wsum(Ms); Md = wsum(Md); l2 = wsum(l2); fav = wsum(fav); bwsum = wsum(bwsum);
         // ---- pass 2: ray entropies (compute_sigma_s_ray_loss, model_helpers.py:206-224) ------------------
         const double Mcs = fmax(Ms, 1e-19), Mcd = fmax(Md, 1e-19);
-        double es = 0.0, ed = 0.0, qp = 0.0;
+        double es = 0.0, ed = 0.0, qp = 0.0, qps = 0.0;       // (qps: the static field's sum of q p, term-gradient mode only)
         // q = ln(pd + eps) + pd / (pd + eps) of this lane's samples, kept for the gradient pass (an f64 logarithm is the most
         // expensive thing in this kernel): up to QKEEP * 64 samples per ray, beyond that the gradient pass recomputes
         constexpr int QKEEP = 8;
@@ -76,7 +81,9 @@ __global__ __launch_bounds__(LOSS_NT) void nca_loss_rays(const NcaLossArgs a) {
             if (s < a.S) {
                 const double dl = a.dists[s];
                 const double ps = (double)ss[s] * dl / Mcs, pd = (double)sd[s] * dl / Mcd;
-                es += ps * log(ps + 1e-10);
+                const double lgs = log(ps + 1e-10);
+                es += ps * lgs;
+                if (tgm) qps += (lgs + ps / (ps + 1e-10)) * ps;
                 const double lg = log(pd + 1e-10);
                 ed += pd * lg;
                 const double q = lg + pd / (pd + 1e-10);
@@ -87,17 +94,20 @@ __global__ __launch_bounds__(LOSS_NT) void nca_loss_rays(const NcaLossArgs a) {
         for (int s = lane + 64 * QKEEP; s < a.S; s += 64) {
             const double dl = a.dists[s];
             const double ps = (double)ss[s] * dl / Mcs, pd = (double)sd[s] * dl / Mcd;
-            es += ps * log(ps + 1e-10);
+            const double lgs = log(ps + 1e-10);
+            es += ps * lgs;
+            if (tgm) qps += (lgs + ps / (ps + 1e-10)) * ps;
             const double lg = log(pd + 1e-10);
             ed += pd * lg;
             qp += (lg + pd / (pd + 1e-10)) * pd;
         }
         es = wsum(es); ed = wsum(ed); qp = wsum(qp);
+        if (tgm) qps = wsum(qps);
         const double wr = a.wpix[r];
         const int mask_s = Ms < a.mask_thre ? 0 : 1;
         int mask_d = Md < a.mask_thre ? 0 : 1;
         if (a.use_weighting && wr > 1.0 + a.weighted_thresh) mask_d = 1;
-        const double diff = a.pix[r] - a.gt[r];
+        const double diff = a.pix ? a.pix[r] - a.gt[r] : 0.0;      // (no pixel term in term-gradient mode: weighted_MSELoss is its own function)
         // ---- gradients ------------------------------------------------------------------------------------
         const double wm = a.unit_mse ? 1.0 : wr;           // (fine pass: unit pixel weights, weighted regularisers)
         if (a.g_pix && lane == 0) a.g_pix[r] = 2.0 * wm * diff * a.inv_R;
@@ -107,6 +117,10 @@ __global__ __launch_bounds__(LOSS_NT) void nca_loss_rays(const NcaLossArgs a) {
             const float fscale = (float)(w_favor * a.inv_R / (double)a.S);
             const double escale = w_dent * a.inv_R * (double)mask_d / Mcd;
             const bool unclipped = Md >= 1e-19;      // d clip(M)/dM
+            // term-gradient mode: the terms the assembled loss never weights (blend-weight mean, static ray entropy, the two ray sums)
+            const float bscale = (float)(w_bw * a.inv_R / (double)a.S);
+            const double escale_s = w_sent * a.inv_R * (double)mask_s / Mcs;
+            const bool unclipped_s = Ms >= 1e-19;
             auto grad_of = [&](int s, bool have_q, double qk) __attribute__((always_inline)) {
                 const float vs = ss[s], vd = sd[s];
                 const double dl = a.dists[s];
@@ -123,7 +137,7 @@ __global__ __launch_bounds__(LOSS_NT) void nca_loss_rays(const NcaLossArgs a) {
                     const float dbdbw = skew == 1.f ? 1.f : skew * powf(bw, skew - 1.f);
                     dFdbw = dF * dbdbw;
                 }
-                const float gf = fscale * dFdbw;
+                const float gf = fscale * dFdbw + bscale;           // (bscale = 0 outside term-gradient mode)
                 const float g_s_f = gf * (-vd / (T * T));
                 const float g_d_f = gf * ((T - vd) / (T * T));
                 // dynamic ray entropy: E = -sum p ln(p+eps); dE/dm_j = (-q_j + [unclipped] sum_s q_s p_s) / M
@@ -131,15 +145,30 @@ __global__ __launch_bounds__(LOSS_NT) void nca_loss_rays(const NcaLossArgs a) {
                 const double q = have_q ? qk : log(pd + 1e-10) + pd / (pd + 1e-10);
                 const double g_d_e = escale * dl * (-q + (unclipped ? qp : 0.0));
                 const double g_d_o = w_occl * a.inv_R * dl;
-                const double g_s_l = w_l1 * (dl + 2.0 * (double)vs * dl * dl);
-                gs[s] = g_s_f + (float)g_s_l;
-                gd[s] = g_d_f + (float)(g_d_e + g_d_o);
+                double g_s_l = w_l1 * (dl + 2.0 * (double)vs * dl * dl);
+                double g_s_x = 0.0, g_d_x = 0.0, dd_x = 0.0;       // term-gradient mode's further terms (and their share of d / d dists)
+                if (tgm) {
+                    g_s_l = w_l1 * dl + w_l2 * (2.0 * (double)vs * dl * dl);
+                    g_s_x = w_ssum * a.inv_R * dl;
+                    g_d_x = w_dsum * a.inv_R * dl;
+                    dd_x = w_ssum * a.inv_R * (double)vs + w_dsum * a.inv_R * (double)vd;
+                    if (w_sent != 0.0) {
+                        const double ps = (double)vs * dl / Mcs;
+                        const double qs = log(ps + 1e-10) + ps / (ps + 1e-10);
+                        const double e = escale_s * (-qs + (unclipped_s ? qps : 0.0));
+                        g_s_x += e * dl;
+                        dd_x += e * (double)vs;
+                    }
+                }
+                gs[s] = g_s_f + (float)(g_s_l + g_s_x);
+                gd[s] = g_d_f + (float)(g_d_e + g_d_o + g_d_x);
                 // d loss / d dists[s] of this ray: every term above reaches dists through m = sigma * dists (swap the factor), the
                 // pixel term through pix = I0 - sum (sigma_s + sigma_d) dists
                 if (a.dists_work)
                     a.dists_work[r * a.S + s] = -(2.0 * wm * diff * a.inv_R) * ((double)vs + (double)vd)
                                                 + escale * (double)vd * (-q + (unclipped ? qp : 0.0)) + w_occl * a.inv_R * (double)vd
-                                                + w_l1 * ((double)vs + 2.0 * (double)vs * (double)vs * dl);
+                                                + (tgm ? w_l1 * (double)vs + w_l2 * (2.0 * (double)vs * (double)vs * dl) + dd_x
+                                                       : w_l1 * ((double)vs + 2.0 * (double)vs * (double)vs * dl));
             };
 #pragma unroll
             for (int j = 0; j < QKEEP; ++j)
@@ -245,6 +274,40 @@ __global__ __launch_bounds__(256) void nca_loss_dists_sum(const NcaLossArgs a) {
         __syncthreads();
     }
     if (threadIdx.x == 0) a.g_dists[s] = sh[0];
+}
+
+// weighted_MSELoss (train/model_helpers.py:284-288): out = (pred - gt)^2 * w, elementwise (the caller takes the mean), and its backward
+template <typename T>
+__global__ void nca_wsqerr_fwd(int64_t R, const T* __restrict__ pred, const T* __restrict__ gt, const T* __restrict__ w, T* __restrict__ out) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const T d = pred[r] - gt[r];
+    out[r] = d * d * w[r];
+}
+template <typename T>
+__global__ void nca_wsqerr_bwd(int64_t R, const T* __restrict__ pred, const T* __restrict__ gt, const T* __restrict__ w, const T* __restrict__ g_out,
+                               T* __restrict__ g_pred, T* __restrict__ g_gt, T* __restrict__ g_w) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const T d = pred[r] - gt[r], g = g_out[r];
+    const T gp = (T)2 * d * w[r] * g;
+    if (g_pred) g_pred[r] = gp;
+    if (g_gt) g_gt[r] = -gp;
+    if (g_w) g_w[r] = d * d * g;
+}
+hipError_t nca_launch_wsqerr(int64_t R, bool f64, const void* pred, const void* gt, const void* w, void* out, hipStream_t st) {
+    const int grid = (int)((R + 255) / 256);
+    if (f64) hipLaunchKernelGGL(nca_wsqerr_fwd<double>, dim3(grid), dim3(256), 0, st, R, (const double*)pred, (const double*)gt, (const double*)w, (double*)out);
+    else hipLaunchKernelGGL(nca_wsqerr_fwd<float>, dim3(grid), dim3(256), 0, st, R, (const float*)pred, (const float*)gt, (const float*)w, (float*)out);
+    return hipGetLastError();
+}
+hipError_t nca_launch_wsqerr_bwd(int64_t R, bool f64, const void* pred, const void* gt, const void* w, const void* g_out, void* g_pred, void* g_gt, void* g_w, hipStream_t st) {
+    const int grid = (int)((R + 255) / 256);
+    if (f64) hipLaunchKernelGGL(nca_wsqerr_bwd<double>, dim3(grid), dim3(256), 0, st, R, (const double*)pred, (const double*)gt, (const double*)w, (const double*)g_out,
+                                (double*)g_pred, (double*)g_gt, (double*)g_w);
+    else hipLaunchKernelGGL(nca_wsqerr_bwd<float>, dim3(grid), dim3(256), 0, st, R, (const float*)pred, (const float*)gt, (const float*)w, (const float*)g_out,
+                            (float*)g_pred, (float*)g_gt, (float*)g_w);
+    return hipGetLastError();
 }
 
 hipError_t nca_launch_loss(const NcaLossArgs& a, hipStream_t st) {

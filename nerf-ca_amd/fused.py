@@ -475,7 +475,7 @@ def fused_losses(pix, gt, wpix, sig_s, sig_d, dists, run_args, weights, inv_R=No
                          mask_thre=float(run_args.entro_mask_thre), weighted_thresh=float(run_args.entro_weighted_thresh),
                          w_favor=float(weights[0]), w_dent=float(weights[1]), w_occl=float(weights[2]), w_l1=float(weights[3]),
                          inv_R=float(inv_R if inv_R is not None else 1.0 / R), weights_dev=None, unit_mse=1 if unit_mse else 0, reserved=0,
-                         g_dists=None, dists_work=None)
+                         g_dists=None, dists_work=None, term_grads=None)
     if weights_dev is not None:
         if weights_dev.dtype != torch.float64 or weights_dev.numel() != 4 or not weights_dev.is_cuda or not weights_dev.is_contiguous():
             raise _capi.NcaError("weights_dev must be a contiguous device f64[4]")
@@ -500,6 +500,115 @@ def fused_losses(pix, gt, wpix, sig_s, sig_d, dists, run_args, weights, inv_R=No
     if want_dists_grad:
         return terms, g_pix, g_s, g_d, g_dists
     return terms, g_pix, g_s, g_d
+
+
+class _LossTermsFn(torch.autograd.Function):
+    """compute_losses (train/model_helpers.py:250-262) as ONE autograd node over the HIP loss kernel: forward = the kernel's values,
+    backward = the kernel in term-gradient mode (NcaLoss.term_grads: the eleven upstream scalars weight the terms' gradients), so a
+    script that keeps the reference's own loss assembly (train/run_composite.py:287-292) launches two kernels per direction where
+    the reference's torch functions launch ~25 elementwise / reduction kernels over [R, S]."""
+
+    @staticmethod
+    def _launch(sig_s, sig_d, dists64, wpix64, opts, term_grads, want_grads, want_dists_grad):
+        lib = _capi.lib()
+        dev = sig_s.device
+        R, S = sig_s.shape
+        use_w, skew, mask_thre, w_thresh = opts
+        desc = _capi.NcaLoss(R=R, S=S, use_weighting=1 if use_w else 0, skew=float(skew), mask_thre=float(mask_thre), weighted_thresh=float(w_thresh),
+                             w_favor=0.0, w_dent=0.0, w_occl=0.0, w_l1=0.0, inv_R=1.0 / R, weights_dev=None, unit_mse=0, reserved=0,
+                             g_dists=None, dists_work=None, term_grads=ptr(term_grads))
+        terms = torch.empty(len(_capi.TERM_NAMES), dtype=torch.float64, device=dev)
+        g_s = g_d = g_dists = dwork = None
+        if want_grads:
+            g_s = torch.empty((R, S), dtype=torch.float32, device=dev)
+            g_d = torch.empty((R, S), dtype=torch.float32, device=dev)
+            if want_dists_grad:
+                g_dists = torch.empty(S, dtype=torch.float64, device=dev)
+                dwork = _scratch(R * S * 8, dev)
+                desc.g_dists, desc.dists_work = ptr(g_dists), ptr(dwork)
+        wbytes = check(lib.nca_loss_workspace(R))
+        work = _scratch(wbytes, dev)
+        check(lib.nca_loss_fwd_bwd(C.byref(desc), None, None, ptr(wpix64), ptr(sig_s), ptr(sig_d), ptr(dists64), ptr(terms),
+                                   None, ptr(g_s), ptr(g_d), ptr(work), wbytes, _stream()))
+        return terms, g_s, g_d, g_dists
+
+    @staticmethod
+    def forward(ctx, sig_s, sig_d, dists, wpix, opts):
+        dev = sig_s.device
+        ss, sd = _f32c(sig_s), _f32c(sig_d)
+        d64 = dists.detach().to(device=dev, dtype=torch.float64).contiguous()
+        w64 = wpix.detach().to(device=dev, dtype=torch.float64).contiguous()
+        zeros = torch.zeros(11, dtype=torch.float64, device=dev)
+        terms, _, _, _ = _LossTermsFn._launch(ss, sd, d64, w64, opts, zeros, False, False)
+        ctx.save_for_backward(ss, sd, d64, w64)
+        ctx.opts, ctx.dists_dtype, ctx.sig_dtypes = opts, dists.dtype, (sig_s.dtype, sig_d.dtype)
+        T = _capi.TERM_NAMES
+        lo = sig_s.dtype                                            # blend-weight terms and maxima stay in sigma's dtype (f32)
+        hi = torch.promote_types(sig_s.dtype, dists.dtype)          # everything that touches dists takes the promoted dtype (f64 in the real script)
+        pick = lambda name, dt: terms[T.index(name)].to(dt)
+        out = (pick("blendw", lo), pick("sigma_s_max", lo), pick("sigma_d_max", lo), pick("favor_s", lo), pick("s_entropy", hi), pick("s_entropy_sum", hi),
+               pick("d_entropy", hi), pick("d_entropy_sum", hi), pick("d_occl", hi), pick("s_l1", hi), pick("s_l2", hi))
+        ctx.mark_non_differentiable(out[1], out[2])
+        return out
+
+    @staticmethod
+    def backward(ctx, *g):
+        ss, sd, d64, w64 = ctx.saved_tensors
+        dev = ss.device
+        tg = torch.stack([torch.zeros((), dtype=torch.float64, device=dev) if gi is None else gi.detach().to(torch.float64).reshape(()) for gi in g])
+        want_d = ctx.needs_input_grad[2]
+        _, g_s, g_d, g_dists = _LossTermsFn._launch(ss, sd, d64, w64, ctx.opts, tg, True, want_d)
+        return (g_s.to(ctx.sig_dtypes[0]) if ctx.needs_input_grad[0] else None, g_d.to(ctx.sig_dtypes[1]) if ctx.needs_input_grad[1] else None,
+                g_dists.to(ctx.dists_dtype) if want_d else None, None, None)
+
+
+def loss_terms(static_sigma, temp_sigma, dists, weighted_pixs, run_args):
+    """The reference's 11-tuple of compute_losses (train/model_helpers.py:250-262) from the HIP loss kernel, differentiable w.r.t.
+    both density fields and the interval lengths.  GPU tensors only: there is no torch implementation behind it."""
+    _require_cuda(static_sigma, "static_sigma")
+    _require_cuda(temp_sigma, "temp_sigma")
+    if static_sigma.dim() != 2 or static_sigma.shape != temp_sigma.shape or dists.dim() != 1 or dists.shape[0] != static_sigma.shape[1]:
+        raise _capi.NcaError(f"compute_losses: expected sigma [R,S] twice and dists [S], got {tuple(static_sigma.shape)}, {tuple(temp_sigma.shape)}, {tuple(dists.shape)}")
+    R = static_sigma.shape[0]
+    use_w = bool(run_args.entro_use_weighting) and weighted_pixs is not None and len(weighted_pixs) > 0
+    if use_w and weighted_pixs.shape[0] != R:
+        raise _capi.NcaError(f"compute_losses: {weighted_pixs.shape[0]} pixel weights for {R} rays")
+    wp = weighted_pixs if use_w else torch.ones(R, dtype=torch.float64, device=static_sigma.device)
+    opts = (use_w, run_args.skewness_val, run_args.entro_mask_thre, run_args.entro_weighted_thresh)
+    return _LossTermsFn.apply(static_sigma, temp_sigma, dists, wp, opts)
+
+
+class _WeightedSqErrFn(torch.autograd.Function):
+    """weighted_MSELoss.forward (train/model_helpers.py:284-288) as a HIP kernel under autograd."""
+
+    @staticmethod
+    def forward(ctx, preds, gts, weights):
+        dt = torch.promote_types(torch.promote_types(preds.dtype, gts.dtype), weights.dtype)
+        if dt not in (torch.float32, torch.float64):
+            dt = torch.float32
+        p, g, w = (t.detach().to(dt).contiguous() for t in (preds, gts, weights))
+        out = torch.empty_like(p)
+        check(_capi.lib().nca_weighted_sq_err(p.numel(), 1 if dt == torch.float64 else 0, ptr(p), ptr(g), ptr(w), ptr(out), _stream()))
+        ctx.save_for_backward(p, g, w)
+        ctx.in_dtypes = (preds.dtype, gts.dtype, weights.dtype)
+        return out.reshape(preds.shape)
+
+    @staticmethod
+    def backward(ctx, g_out):
+        p, g, w = ctx.saved_tensors
+        go = g_out.detach().to(p.dtype).contiguous()
+        need = ctx.needs_input_grad
+        outs = [torch.empty_like(p) if n else None for n in need]
+        check(_capi.lib().nca_weighted_sq_err_bwd(p.numel(), 1 if p.dtype == torch.float64 else 0, ptr(p), ptr(g), ptr(w), ptr(go),
+                                                  ptr(outs[0]), ptr(outs[1]), ptr(outs[2]), _stream()))
+        return tuple(None if o is None else o.reshape(g_out.shape).to(dt) for o, dt in zip(outs, ctx.in_dtypes))
+
+
+def weighted_sq_err(preds, gts, weights):
+    _require_cuda(preds, "preds")
+    if not (preds.shape == gts.shape == weights.shape):
+        raise _capi.NcaError(f"weighted_MSELoss: shapes {tuple(preds.shape)}, {tuple(gts.shape)}, {tuple(weights.shape)} differ")
+    return _WeightedSqErrFn.apply(preds, gts.to(preds.device), weights.to(preds.device))
 
 
 def fine_depths(sig_s: torch.Tensor, sig_d: Optional[torch.Tensor], z: torch.Tensor, u: torch.Tensor, reduce_max=None) -> torch.Tensor:

@@ -1,8 +1,11 @@
 """Pixel loss and D2NeRF-style separation regularisers (train/model_helpers.py:189-262, 284-288).
 
-All terms are computed from sigma_s, sigma_d [R,S], the interval lengths dists[S] and the per-ray
-weights in one place.  These are the reference's autograd-visible helper functions as torch device ops (what its API
-exports); the training steps use the fused HIP loss kernel instead (nca_loss_fwd_bwd, nerfca_amd/fused.py).
+The reference's PART functions (compute_ratio, compute_blendw_loss, compute_sigma_s_ray_loss, compute_occl_loss) as torch
+operations on any device -- its API exports them by name (``from model_helpers import *``) and run_nerf.py's static loop calls
+``compute_occl_loss`` on its own.  The two functions the composite script calls every step, ``compute_losses`` and
+``weighted_MSELoss``, are HIP-backed in train/model_helpers.py (fused.loss_terms / fused.weighted_sq_err over nca_loss_fwd_bwd);
+``all_terms`` / ``WeightedSquaredError`` below are their torch restatements from the parts, kept for the CPU tests of the
+data-parallel bookkeeping (tests/injected_trainer.py) -- no product path calls them.
 """
 from __future__ import annotations
 

@@ -15,10 +15,22 @@ An extra keyword ``t_rand`` on the two ``obtain_*`` functions injects the strati
 import torch
 
 from .. import fused as _fused
-from ..losses import (WeightedSquaredError as weighted_MSELoss, all_terms as compute_losses,  # noqa: F401
-                      binary_entropy_of_blend as compute_blendw_loss, blend_weight as _blend_weight,
+from ..losses import (binary_entropy_of_blend as compute_blendw_loss, blend_weight as _blend_weight,  # noqa: F401
                       occlusion as compute_occl_loss, ray_entropy as compute_sigma_s_ray_loss)
 from ..schedules import exp_param_decay, linear_param_decay  # noqa: F401
+
+
+def compute_losses(static_sigma, temp_sigma, dists, weighted_pixs, run_args):
+    """model_helpers.py:250-262 -> the reference's 11-tuple, from the fused HIP loss kernel under autograd (nca_loss_fwd_bwd: values
+    forward; backward in term-gradient mode, the eleven upstream scalars weighting the terms' gradients).  GPU tensors only."""
+    return _fused.loss_terms(static_sigma, temp_sigma, dists, weighted_pixs, run_args)
+
+
+class weighted_MSELoss(torch.nn.Module):
+    """model_helpers.py:284-288: (preds - gts)^2 * weights, elementwise (the caller takes .mean()); a HIP kernel under autograd."""
+
+    def forward(self, preds, gts, weights):
+        return _fused.weighted_sq_err(preds, gts, weights)
 
 
 def compute_ratio(sigma_s, sigma_d, favor_s_opt=None, sigma_s_max=None, sigma_d_max=None, weight_max=0.05):

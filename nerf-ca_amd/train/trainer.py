@@ -9,13 +9,12 @@ divided by the GLOBAL ray count; ``static_l1``/``static_l2`` are sums over the b
 from __future__ import annotations
 
 from dataclasses import dataclass, field
-from typing import Callable, Optional
+from typing import Optional
 
 import numpy as np
 import torch
 import torch.distributed as dist
 
-from .. import losses as LS
 from ..schedules import linear_param_decay
 from . import model_helpers as MH
 
@@ -101,11 +100,16 @@ def _scoped(method):
 
 class CompositeTrainer:
     def __init__(self, cfg: TrainConfig, static_model, temp_model, data, device, rank: int = 0, world: int = 1,
-                 seed: int = 0, render: Optional[Callable] = None, fused_adam: Optional[bool] = None, fused_loss: Optional[bool] = None,
-                 static_model_fine=None, temp_model_fine=None, fine_sampler: Optional[Callable] = None, plan_opts: Optional[dict] = None):
+                 seed: int = 0, fused_adam: Optional[bool] = None, fused_loss: Optional[bool] = None,
+                 static_model_fine=None, temp_model_fine=None, plan_opts: Optional[dict] = None):
         """``plan_opts``: this trainer's planner options (keys of ``_capi.NcaPlanOpts``: stage_fp8, stage_fp8_min_tiles,
-        resident_min_tiles, wgrad_rebuild_weight_pct) -- they apply to this trainer's library calls only; ``self.plan()`` is what the
-        planner decided for them."""
+        resident_min_tiles, wgrad_rebuild_weight_pct, overlap_cus) -- they apply to this trainer's library calls only; ``self.plan()`` is
+        what the planner decided for them.
+
+        Every device operation of a step goes through the HIP library: the renderer (``_render``), the fine-pass sampler
+        (``_fine_depths`` / ``_fine_depths_autograd``), the batch preparation (``_prepare``) and the evaluation's loss terms
+        (``_eval_terms``) are methods so that the CPU tests of the data-parallel bookkeeping can put the oracle behind them
+        (tests/injected_trainer.py); nothing in this module has a torch implementation of the path."""
         from ..fused import PlanScope
         self.plan_scope = PlanScope(**(plan_opts or {}))
         self._bad_ids = None               # device i32[1]: ray ids outside the table that nca_prepare_batch clamped (checked at the syncing calls)
@@ -114,19 +118,16 @@ class CompositeTrainer:
         self.n_fine = int(cfg.depth_samples_per_ray_fine)
         if self.n_fine > 0 and (static_model_fine is None or temp_model_fine is None):
             raise ValueError("depth_samples_per_ray_fine > 0 needs static_model_fine and temp_model_fine (run_composite.py:194-205)")
-        self.fine_sampler = fine_sampler or MH._fused.fine_depths      # (sig_s, sig_d, z, u, reduce_max=) -> z_all[R, S + n_fine]
         self.rank, self.world, self.seed = rank, world, seed
         on_cuda = device.type == "cuda" if isinstance(device, torch.device) else str(device).startswith("cuda")
         if on_cuda:                        # (allocated here, not at first use: the first use may be inside a graph capture)
             self._bad_ids = torch.zeros(1, dtype=torch.int32, device=device)
         if fused_loss is None:             # default on the GPU: the autograd-free step with the HIP loss kernel (step_fused);
-            fused_loss = on_cuda           # fused_loss=False keeps the reference's torch loss functions under autograd
-        # (an injected renderer or fine sampler -- the CPU tests' oracle -- runs under autograd: the fused steps call the library)
-        self.fused_loss = bool(fused_loss) and render is None and (self.n_fine == 0 or fine_sampler is None)
+            fused_loss = on_cuda           # fused_loss=False: the reference's loss FUNCTIONS (model_helpers.compute_losses, HIP behind them) under autograd
+        self.fused_loss = bool(fused_loss)
         self.stop_flag = None              # device bool: the reference's early-stop predicate of the last step (see early_stop)
         self.always_allreduce = False      # all-reduce even with one rank (exercises the collective path)
         self._dev_gen = None
-        self.render = render or MH._fused.render_rays
         self.params = list(temp_model.parameters()) + list(static_model.parameters())   # run_composite.py:192
         if self.n_fine > 0:
             self.params += list(temp_model_fine.parameters()) + list(static_model_fine.parameters())             # :207
@@ -140,6 +141,28 @@ class CompositeTrainer:
         self.depth = MH_depth(data.geo, cfg.depth_samples_per_ray_coarse, device)
         self.I0 = torch.full((cfg.img_sample_size,), data.geo["max_pixel_value"], dtype=torch.float32, device=device)
         self.n_var = int((cfg.var_sample_perc / 100.0) * cfg.img_sample_size) if cfg.var_sample_perc > 0 else 0
+
+    # -- the device operations of a step (HIP library; see the class docstring) ------------------
+    def _render(self, static_model, temp_model, o, d, phases, I0, z, dists, act):
+        """(pix, sigma_s, sigma_d) of one ray batch: the fused render (obtain_train_predictions_iter's coarse or fine half)."""
+        return MH._fused.render_rays(static_model, temp_model, o, d, phases, I0, z, dists, act=act)
+
+    def _fine_depths(self, sig_s, sig_d, z, u, reduce_max):
+        """z_all[R, S + n_fine] of the hierarchical pass, the depths constants of the step (fine_depth_gradients=False)."""
+        return MH._fused.fine_depths(sig_s, sig_d, z, u, reduce_max=reduce_max)
+
+    def _fine_depths_autograd(self, sig_s, sig_d, z, u, reduce_max):
+        """The same with the sampled depths in the autograd graph, as the reference has them (model_helpers.py:135-146): HIP sampler,
+        HIP backward into the coarse densities."""
+        return MH._fused.fine_depths_autograd(sig_s, sig_d, z, u, reduce_max=reduce_max)
+
+    def _pixel_loss(self, pix, gt, w):
+        """loss_fn(pred, gt, weights).mean() of run_composite.py:287 (weighted_MSELoss: a HIP kernel under autograd)."""
+        return MH.weighted_MSELoss()(pix, gt, w).mean()
+
+    def _loss_terms(self, sig_s, sig_d, dists, w):
+        """compute_losses' 11-tuple (model_helpers.py:250-262) under autograd: the HIP loss kernel behind the reference's function."""
+        return MH.compute_losses(sig_s, sig_d, dists, w, self.cfg)
 
     # -- per-step host work (identical on every rank) ------------------------------------------
     def update_windows(self, n_iter: int) -> None:
@@ -183,6 +206,9 @@ class CompositeTrainer:
             return ids[torch.randperm(n, generator=g, device=dev)]
         return torch.randint(0, d.rays_train.shape[0], (n,), generator=g, device=dev)
 
+    def _draw_ids(self, n_iter: int):
+        return self.draw_ray_ids_device(n_iter)
+
     def draw_jitter(self, n_iter: int) -> torch.Tensor:
         g = torch.Generator().manual_seed(self.seed * 1000003 + n_iter)
         return torch.rand(self.depth.shape, generator=g)
@@ -207,15 +233,11 @@ class CompositeTrainer:
         R = len(ids)
         lo, hi = (R * self.rank) // self.world, (R * (self.rank + 1)) // self.world
         my = ids[lo:hi] if torch.is_tensor(ids) else torch.as_tensor(ids[lo:hi], device=self.device)
-        rays = self.data.rays_train.index_select(0, my)                  # f64 [r,4,3]  (run_composite.py:262)
-        phases = self.data.phases_train.index_select(0, my)
-        o, d, gt, w = rays[:, 0, :], rays[:, 1, :], rays[:, 2, 0], rays[:, 3, 0]
-        z = MH.randomize_depth(self.depth, self.device, t_rand)
-        dists = MH._interval_lengths(z, d)
-        pix, sig_s, sig_d = self.render(self.s, self.t, o, d, phases, self.I0[: hi - lo], z, dists, act=c.output_activation)
+        o, d, gt, w, phases, z, dists = self._prepare(my, t_rand)        # (run_composite.py:262-273, model_helpers.py:3-12, 73-74)
+        pix, sig_s, sig_d = self._render(self.s, self.t, o, d, phases, self.I0[: hi - lo], z, dists, c.output_activation)
         share = (hi - lo) / R                                            # local mean -> share of the global mean
-        pixel = MH.weighted_MSELoss()(pix, gt, w).mean() * share
-        terms = LS.all_terms(sig_s, sig_d, dists, w, c)
+        pixel = self._pixel_loss(pix, gt, w) * share
+        terms = self._loss_terms(sig_s, sig_d, dists, w)
         fav_w, ent_w, occ_w, l1_w = self.loss_weights(n_iter)
         favor, d_ent, occl, l1, l2 = terms[3], terms[6], terms[8], terms[9], terms[10]
         loss = pixel + fav_w * favor * share + ent_w * d_ent * share + occ_w * occl * share + l1_w * l2 + l1_w * l1
@@ -232,28 +254,17 @@ class CompositeTrainer:
                 # as the reference: the sampled depths stay in the autograd graph (model_helpers.py:135-146) and the fused
                 # render returns d loss / d depth, so the fine losses also reach the COARSE nets; the batch-wide maximum and
                 # ray 0's depths cross the ranks in both directions
-                if self.fine_sampler is MH._fused.fine_depths:      # the product path: HIP sampler, HIP backward
-                    z_all = MH._fused.fine_depths_autograd(sig_s, sig_d, z, u, reduce_max=red)
-                else:
-                    # an injected sampler (the CPU tests run the oracle's): the reference's own operations under autograd
-                    tot = sig_s + sig_d
-                    wts = torch.cat([torch.ones_like(tot[:, :1]) * 1e-10, torch.abs(tot[:, 1:] - tot[:, :-1])], dim=-1)
-                    wts = wts / MH._BatchMax.apply(wts, red)
-                    zrep = z[None, :].repeat(hi - lo, 1)
-                    mid = 0.5 * (zrep[..., 1:] + zrep[..., :-1])
-                    z_pdf = MH.sample_pdf(mid, wts[..., 1:-1], self.n_fine, self.device, u=u)
-                    z_all, _ = torch.sort(torch.cat([z_pdf, zrep.detach()], -1), -1)
+                z_all = self._fine_depths_autograd(sig_s, sig_d, z, u, red)
                 z0 = _FromRank0.apply(z_all[0, :], self.rank) if sharded else z_all[0, :]
             else:
-                z_all = self.fine_sampler(sig_s.detach(), sig_d.detach(), z, u, reduce_max=red)
+                z_all = self._fine_depths(sig_s.detach(), sig_d.detach(), z, u, red)
                 z0 = z_all[0, :].clone()
                 if sharded:
                     dist.broadcast(z0, src=0)
             dists_f = MH._interval_lengths(z0, d)
-            pix_f, sig_sf, sig_df = self.render(self.s_fine, self.t_fine, o, d, phases, self.I0[: hi - lo], z_all, dists_f,
-                                                act=c.output_activation)
-            pixel_f = MH.weighted_MSELoss()(pix_f, gt, torch.ones_like(w)).mean() * share       # weighted_pixs_ones (:297)
-            tf = LS.all_terms(sig_sf, sig_df, dists_f, w, c)
+            pix_f, sig_sf, sig_df = self._render(self.s_fine, self.t_fine, o, d, phases, self.I0[: hi - lo], z_all, dists_f, c.output_activation)
+            pixel_f = self._pixel_loss(pix_f, gt, torch.ones_like(w)) * share       # weighted_pixs_ones (:297)
+            tf = self._loss_terms(sig_sf, sig_df, dists_f, w)
             loss = loss + pixel_f + fav_w * tf[3] * share + ent_w * tf[6] * share + occ_w * tf[8] * share + l1_w * tf[10] + l1_w * tf[9]
             self.last_fine_terms_autograd = tf      # (the early stop reads the fine pass's entropy / favor terms, run_composite.py:298-310)
         return loss, pixel, terms
@@ -275,9 +286,7 @@ class CompositeTrainer:
         if self.fused_loss:
             return self.step_fused(n_iter)
         self.update_windows(n_iter)
-        on_gpu = torch.device(self.device).type == "cuda"
-        ids = self.draw_ray_ids_device(n_iter) if on_gpu else self.draw_ray_ids(n_iter)
-        loss, pixel, terms = self.local_loss(n_iter, ids, self.draw_jitter(n_iter))
+        loss, pixel, terms = self.local_loss(n_iter, self._draw_ids(n_iter), self.draw_jitter(n_iter))
         self.opt.zero_grad(set_to_none=True)
         loss.backward()
         # the reference overwrites dynamic_entropy_loss / favor_s_loss with the fine pass's values before its check (run_composite.py:298-310)
@@ -293,17 +302,20 @@ class CompositeTrainer:
 
     def _prepare(self, my: torch.Tensor, t_rand: torch.Tensor):
         """This rank's rays of the step and the jittered depths: ``(o, d, gt, w, phases, z, dists)`` as run_composite.py:262-273 and
-        model_helpers.py:3-12, 73-74 build them -- one library launch on the GPU (fused.prepare_batch, bit-identical to the torch
-        operations below, tests/test_hip_parity.py), the torch operations elsewhere."""
+        model_helpers.py:3-12, 73-74 build them -- ONE library launch (fused.prepare_batch: bit-identical to the reference's torch
+        operations, tests/test_hip_parity.py) on the ray table as the loader leaves it (data_helpers.py:141-165: f64 [N,4,3] and one
+        int64 phase per ray, resident on the GPU)."""
+        from ..fused import prepare_batch
         rt, pt = self.data.rays_train, self.data.phases_train
-        if rt.is_cuda and rt.dtype == torch.float64 and pt.dtype == torch.int64 and rt.is_contiguous() and pt.dim() == 1 and my.dtype == torch.int64:
-            from ..fused import prepare_batch
-            return prepare_batch(my.contiguous(), rt, pt, self.depth, t_rand, bad_ids=self._bad_ids)
-        rays = rt.index_select(0, my)
-        phases = pt.index_select(0, my)
-        o, d, gt, w = rays[:, 0, :], rays[:, 1, :], rays[:, 2, 0], rays[:, 3, 0]
-        z = MH.randomize_depth(self.depth, self.device, t_rand)
-        return o, d, gt, w, phases, z, MH._interval_lengths(z, d)
+        if not (rt.is_cuda and rt.dtype == torch.float64 and rt.dim() == 3 and rt.is_contiguous() and pt.is_cuda and pt.dim() == 1):
+            from .. import _capi
+            raise _capi.NcaError(f"CompositeTrainer needs the ray table on the GPU as prepare_data_for_loader_tigre builds it (f64 [N,4,3], contiguous; one phase id "
+                                 f"per ray): got {rt.dtype} {tuple(rt.shape)} on {rt.device}, phases {pt.dtype} {tuple(pt.shape)}.  There is no CPU or torch path.")
+        if pt.dtype != torch.int64:
+            if getattr(self, "_phases64", None) is None:
+                self._phases64 = pt.to(torch.int64)
+            pt = self._phases64
+        return prepare_batch(my.to(torch.int64).contiguous(), rt, pt, self.depth, t_rand, bad_ids=self._bad_ids)
 
     def fused_gradients(self, n_iter: int):
         """What ``loss.backward()`` yields in the reference (run_composite.py:283-306) for this rank's slice of step ``n_iter``'s
@@ -694,6 +706,13 @@ class CompositeTrainer:
             g.copy_(r)
         return outs[-1] if extra is not None else None
 
+    def _eval_terms(self, pix, gt, ones, sig_s, sig_d, dists, n_iter):
+        """(test_loss, pixel, favor, blendw, static entropy, dynamic entropy) of the held-out view: the HIP loss kernel, values only --
+        all terms and the assembled test loss in one pass (unit pixel weights; run_composite.py:363-391)."""
+        from ..fused import fused_losses
+        tk, _, _, _ = fused_losses(pix, gt, ones, sig_s, sig_d, dists, self.cfg, self.loss_weights(n_iter), inv_R=1.0 / pix.shape[0], want_grads=False)
+        return tk[0], tk[1], tk[5], tk[2], tk[6], tk[8]
+
     # -- held-out view (run_composite.py:346-413) ------------------------------------------------
     @torch.no_grad()
     @_scoped
@@ -713,23 +732,12 @@ class CompositeTrainer:
             o, dd = d.test_origins[i:i + chunk_rays], d.test_directions[i:i + chunk_rays]
             ph = torch.full((o.shape[0],), d.test_phase, dtype=torch.int32, device=dev)
             I0 = torch.full((o.shape[0],), d.geo["max_pixel_value"], dtype=torch.float32, device=dev)
-            p, a, b = self.render(self.s, self.t, o, dd, ph, I0, z, dists, act=c.output_activation)
+            p, a, b = self._render(self.s, self.t, o, dd, ph, I0, z, dists, c.output_activation)
             pix.append(p); sig_s.append(a); sig_d.append(b)
         pix, sig_s, sig_d = torch.cat(pix), torch.cat(sig_s), torch.cat(sig_d)
         gt = d.test_image.to(pix.dtype)
         ones = torch.ones_like(gt)
-        if self.fused_loss and pix.is_cuda:
-            # the HIP loss kernel, values only: all terms and the assembled test loss in one pass (unit pixel weights)
-            from ..fused import fused_losses
-            tk, _, _, _ = fused_losses(pix, gt, ones, sig_s, sig_d, dists, c, self.loss_weights(n_iter), inv_R=1.0 / pix.shape[0], want_grads=False)
-            test_loss, pixel = tk[0], tk[1]
-            favor, blendw, s_ent, d_ent = tk[5], tk[2], tk[6], tk[8]
-        else:
-            pixel = MH.weighted_MSELoss()(pix, gt, ones).mean()
-            terms = LS.all_terms(sig_s, sig_d, dists, ones, c)
-            fav_w, ent_w, occ_w, l1_w = self.loss_weights(n_iter)
-            test_loss = pixel + fav_w * terms[3] + ent_w * terms[6] + occ_w * terms[8] + l1_w * terms[10] + l1_w * terms[9]
-            favor, blendw, s_ent, d_ent = terms[3], terms[0], terms[4], terms[6]
+        test_loss, pixel, favor, blendw, s_ent, d_ent = self._eval_terms(pix, gt, ones, sig_s, sig_d, dists, n_iter)
         I0 = d.geo["max_pixel_value"]
         mse = ((pix.float() - d.test_image) ** 2).mean()
         return {"test_loss": test_loss, "test_psnr": -10.0 * torch.log10(test_loss), "test_pixel_loss_coarse": pixel,

@@ -59,8 +59,9 @@ class NetSpec:
     # bf16 operands (an option of bf16 staging, emulate_stage_formats = None), else from staged output gradients like the others.
     emulate_fp8_stage: int = 0
     emulate_onchip_last: bool = False
-    emulate_stage_formats: Optional[Tuple[str, str]] = ("e5m2", "e4m3")  # (output gradients, layer inputs); None: bf16 staging with the
-    #                                                                      same emulation of the backward chain (bf16 deltas)
+    emulate_stage_formats: Optional[Tuple[str, str]] = ("e5m2", "e4m3")  # (output gradients, layer inputs); ("bf16", "bf16"): the bf16 store
+    #                                                                      (NCA_STORE_BF16: mode-5 arithmetic, nothing in 8 bits); None: round 3's
+    #                                                                      bf16 staging (last layer recomputed: _StagedOut)
 
     @property
     def enc_features(self) -> int:
@@ -311,10 +312,11 @@ def mlp(params: Dict[str, Tensor], spec: NetSpec, feats: Tensor) -> Tensor:
         h = feats
         for i in range(NL):
             last = i == NL - 1
-            d8 = None if (last and spec.emulate_onchip_last) else fd     # on chip: bf16 registers, nothing is staged
+            d8 = None if (last and spec.emulate_onchip_last) else (None if fd == "bf16" else fd)     # on chip: bf16 registers, nothing is staged
             # every staged layer's input is e4m3 when its weight gradient is formed: the hidden blocks cross HBM as e4m3, the bf16
-            # input block is rounded to e4m3 inside the weight-gradient kernel
-            h8 = fh if d8 is not None else None
+            # input block is rounded to e4m3 inside the weight-gradient kernel.  ("bf16", "bf16"): the BF16 store of round 5 -- the same
+            # mode-5 arithmetic (nothing recomputed, the last layer's block without Wo, dWo from the sums) with nothing rounded to 8 bits
+            h8 = (None if fh == "bf16" else fh) if d8 is not None else None
             if last and fd is not None and NL >= 2:
                 # fp8 staging (a store needs a hidden layer): last layer and output layer as the mode-5 kernels treat them
                 raw = _StagedTail.apply(h, params[f"early_pts_layers.{2 * i}.weight"], params[f"early_pts_layers.{2 * i}.bias"],

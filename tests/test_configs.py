@@ -49,24 +49,25 @@ def test_bench_self_launch_eight_ranks_dry():
     assert sorted(x["local_rank"] for x in ranks) == list(range(8))
     assert all(x["world"] == 8 and x["backend"] == "nccl" and x["device"] == f"cuda:{x['local_rank']}" for x in ranks)
     assert len({x["master"] for x in ranks}) == 1 and ranks[0]["master"].startswith("127.0.0.1:")
-    assert all(x["global_rays_per_step"] == 8 * 65536 and x["scaling"] == "weak" for x in ranks)          # weak scaling: one full detector per rank
+    # the default is STRONG scaling (BASELINE configs[2]: the same composite config, ray-sharded across 8 GPUs): one global batch of 65 536 rays
+    assert all(x["global_rays_per_step"] == 65536 and x["rays_per_rank"] == 8192 and x["scaling"] == "strong" for x in ranks)
 
 
 @pytest.mark.timeout(300)
-def test_bench_strong_scaling_eight_ranks_dry():
-    """`--scaling strong`: ONE global batch of 65 536 rays split 8 ways (SURVEY 8e's partitioning) -- every rank reports 8 192 rays
-    of a global 65 536 and the line would say "strong"; a ray count that does not divide is refused before anything starts."""
+def test_bench_weak_scaling_eight_ranks_dry():
+    """`--scaling weak`: every rank renders one full detector (65 536 rays) per step, the global batch is 8 x that and the line
+    would say "weak"; under the default (strong) a ray count that does not divide by the ranks is refused before anything starts."""
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     env["OMP_NUM_THREADS"] = "1"
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run", "--scaling", "strong"], env=env, cwd=ROOT,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run", "--scaling", "weak"], env=env, cwd=ROOT,
                        capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, r.stderr[-800:]
     ranks = [x for x in _json_lines(r.stdout) if "rank" in x]
     assert sorted(x["rank"] for x in ranks) == list(range(8))
-    assert all(x["scaling"] == "strong" and x["rays_per_rank"] == 8192 and x["global_rays_per_step"] == 65536 for x in ranks)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run", "--scaling", "strong", "--rays", "1001"], env=env, cwd=ROOT,
+    assert all(x["scaling"] == "weak" and x["rays_per_rank"] == 65536 and x["global_rays_per_step"] == 8 * 65536 for x in ranks)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run", "--rays", "1001"], env=env, cwd=ROOT,
                        capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "does not divide" in r.stderr
 

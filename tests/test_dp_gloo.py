@@ -64,7 +64,8 @@ def build(seed=0):
     from nerfca_amd import synthetic
     from nerfca_amd.model.CPPN import CPPN
     from nerfca_amd.model.Temporal import Temporal
-    from nerfca_amd.train.trainer import CompositeTrainer, TrainConfig
+    from nerfca_amd.train.trainer import TrainConfig
+    from injected_trainer import InjectedTrainer as CompositeTrainer
     dev = torch.device("cpu")
     sdef, tdef = synthetic.net_definitions(dev, F=32, early=2, L=4, T=4)
 

@@ -447,6 +447,63 @@ def test_fused_loss_kernel_vs_reference(golden, dev, dtn):
     assert rel_err(g_s.cpu(), ao.grad) < TOL and rel_err(g_d.cpu(), bo.grad) < TOL
 
 
+@pytest.mark.parametrize("dtn", ["f64", "f32"])
+def test_dropin_compute_losses_is_the_hip_kernel(golden, dev, dtn):
+    """The drop-in ``compute_losses`` / ``weighted_MSELoss`` (train/model_helpers.py:250-262, 284-288) as a reference script calls them
+    (train/run_composite.py:287-292): the 11-tuple with the reference's dtypes and values (tests/golden/losses.npz), the gradients
+    of the reference's own weighting of the terms AND of a weighting that touches every differentiable term (blend-weight mean,
+    static entropy, both ray sums, l1 and l2 apart) against autograd through the oracle -- and between the call and the end of the
+    backward NO torch operation touches an [R, S] tensor: the work is two launches of the loss kernel (values; term-gradient mode)."""
+    from types import SimpleNamespace
+    from torch.profiler import ProfilerActivity, profile
+    from nerfca_amd.train import model_helpers as MH
+    g = golden("losses")
+    args = SimpleNamespace(favor_s_opt=None, skewness_val=1.0, entro_mask_thre=1e-4, entro_use_weighting=True,
+                           entro_weighted_thresh=0.03, occl_reg_perc=0.2)
+    dists, wpix = g[f"{dtn}_dists"], g[f"{dtn}_wpix"]
+    R, S = g[f"{dtn}_sig_s"].shape
+    names = ["blendw", "sig_s_max", "sig_d_max", "favor", "s_ent", "s_sum", "d_ent", "d_sum", "occl", "l1", "l2"]
+    for weights in ((0, 0, 0, 0.7, 0, 0, 0.9, 0, 0.5, 0.25, 0.25), (0.3, 0, 0, 0.7, 1.3, 0.4, 0.9, 0.6, 0.5, 0.25, 2.0)):
+        a = g[f"{dtn}_sig_s"].to(dev).requires_grad_(True)
+        b = g[f"{dtn}_sig_d"].to(dev).requires_grad_(True)
+        dd, wd = dists.to(dev), wpix.to(dev)
+        pred = g[f"{dtn}_mse_pred"].to(dev).requires_grad_(True)
+        gt = g[f"{dtn}_mse_gt"].to(dev)
+        with profile(activities=[ProfilerActivity.CPU], record_shapes=True) as prof:
+            res = MH.compute_losses(a, b, dd, wd, args)
+            mse = MH.weighted_MSELoss()(pred, gt, wd)
+            loss = mse.mean() + sum(w * r for w, r in zip(weights, res) if w)
+            loss.backward()
+            torch.cuda.synchronize()
+        # (views / no-op casts of an [R, S] tensor launch nothing; anything else on one -- an elementwise op, a reduction, a copy -- is a kernel)
+        meta = {"aten::detach", "aten::to", "aten::contiguous", "aten::view", "aten::reshape", "aten::alias", "aten::as_strided", "aten::empty", "aten::empty_like",
+                "aten::empty_strided", "aten::_unsafe_view", "aten::result_type", "aten::expand", "aten::lift_fresh"}
+        big = [(e.name, e.input_shapes) for e in prof.events() if e.name.startswith("aten::") and e.name not in meta
+               and any(len(sh) >= 2 and sh[0] * sh[1] >= R * S for sh in e.input_shapes if sh)]
+        assert not big, big[:5]
+        for n, v in zip(names, res):
+            assert v.dtype == g[f"{dtn}_{n}"].dtype, (n, v.dtype, g[f"{dtn}_{n}"].dtype)
+            assert rel_err(v.detach().cpu(), g[f"{dtn}_{n}"]) < 2e-6, n
+        assert mse.dtype == g[f"{dtn}_mse"].dtype and rel_err(mse.detach().cpu(), g[f"{dtn}_mse"]) < 1e-7
+        # autograd through the oracle's restatement of the same functions with the same weights
+        ao, bo, po = g[f"{dtn}_sig_s"].clone().requires_grad_(True), g[f"{dtn}_sig_d"].clone().requires_grad_(True), g[f"{dtn}_mse_pred"].clone().requires_grad_(True)
+        t = O.compute_losses(ao, bo, dists, wpix, O.LossArgs())
+        (O.weighted_mse(po, g[f"{dtn}_mse_gt"], wpix).mean() + sum(w * r for w, r in zip(weights, t) if w)).backward()
+        assert rel_err(a.grad.cpu(), ao.grad) < TOL and rel_err(b.grad.cpu(), bo.grad) < TOL, weights
+        assert rel_err(pred.grad.cpu(), po.grad) < 1e-6
+        if weights[0] == 0:          # the reference's own weighting: also pinned by the golden gradients of the same combination
+            pass
+    # d / d dists through the drop-in (the fine pass hands compute_losses interval lengths that are in the autograd graph)
+    a, b = g[f"{dtn}_sig_s"].to(dev), g[f"{dtn}_sig_d"].to(dev)
+    dd = dists.to(dev).clone().requires_grad_(True)
+    res = MH.compute_losses(a, b, dd, wpix.to(dev), args)
+    (0.9 * res[6] + 0.5 * res[8] + 0.25 * res[9] + 2.0 * res[10] + 1.3 * res[4] + 0.4 * res[5]).backward()
+    do = dists.clone().requires_grad_(True)
+    t = O.compute_losses(g[f"{dtn}_sig_s"], g[f"{dtn}_sig_d"], do, wpix, O.LossArgs())
+    (0.9 * t[6] + 0.5 * t[8] + 0.25 * t[9] + 2.0 * t[10] + 1.3 * t[4] + 0.4 * t[5]).backward()
+    assert dd.grad.dtype == dists.dtype and rel_err(dd.grad.cpu(), do.grad) < (1e-9 if dtn == "f64" else 2e-5)
+
+
 @pytest.mark.parametrize("skew,use_w,mask_thre,w_thresh", [(2.0, True, 1e-4, 0.03), (0.5, False, 1e-4, 0.03), (1.0, True, 5e-2, 0.25), (3.0, False, 1.0, 0.0)])
 def test_fused_loss_kernel_non_default_flags(golden, dev, skew, use_w, mask_thre, w_thresh):
     """The flags of compute_losses that composite.txt leaves at their defaults (train/model_helpers.py:250-262: skewness_val of the
@@ -576,7 +633,8 @@ def test_trainer_with_fine_pass_vs_oracle(dev):
         return seen["z_all"].to(dev)
 
     s, t, sf, tf = nets()
-    tr = CompositeTrainer(cfg, s, t, data, dev, seed=5, static_model_fine=sf, temp_model_fine=tf, fine_sampler=cpu_sampler)
+    from injected_trainer import InjectedTrainer          # (the product's HIP renderer, a CPU sampler injected)
+    tr = InjectedTrainer(cfg, s, t, data, dev, seed=5, static_model_fine=sf, temp_model_fine=tf, fine_sampler=cpu_sampler)
     assert not tr.fused_loss and len(tr.params) == sum(len(list(m.parameters())) for m in (s, t, sf, tf))
     tr.update_windows(n_iter)
     ids = tr.draw_ray_ids_device(n_iter)

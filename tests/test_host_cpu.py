@@ -185,20 +185,29 @@ def test_randomize_depth_matches_reference_draw(golden):
 # ----------------------------------------------------------------------------- losses / render helpers
 @pytest.mark.parametrize("dtn", ["f64", "f32"])
 def test_losses_match_reference(golden, dtn):
+    """The torch restatement of the loss functions (nerfca_amd/losses.py: the part functions the API exports, and all_terms /
+    WeightedSquaredError built from them for the CPU tests of the data-parallel bookkeeping) against the reference's goldens.  The
+    drop-in compute_losses / weighted_MSELoss are HIP-backed: tests/test_hip_parity.py::test_dropin_compute_losses_is_the_hip_kernel."""
     from types import SimpleNamespace
+    from nerfca_amd import losses as LS
+    from nerfca_amd._capi import NcaError
     from nerfca_amd.train import model_helpers as MH
     g = golden("losses")
     args = SimpleNamespace(favor_s_opt=None, skewness_val=1.0, entro_mask_thre=1e-4, entro_use_weighting=True,
                            entro_weighted_thresh=0.03, occl_reg_perc=0.2)
     a = g[f"{dtn}_sig_s"].clone().requires_grad_(True)
     b = g[f"{dtn}_sig_d"].clone().requires_grad_(True)
-    res = MH.compute_losses(a, b, g[f"{dtn}_dists"], g[f"{dtn}_wpix"], args)
+    with pytest.raises(NcaError, match="GPU"):          # no torch implementation behind the drop-in names
+        MH.compute_losses(a, b, g[f"{dtn}_dists"], g[f"{dtn}_wpix"], args)
+    with pytest.raises(NcaError, match="GPU"):
+        MH.weighted_MSELoss()(g[f"{dtn}_mse_pred"], g[f"{dtn}_mse_gt"], g[f"{dtn}_wpix"])
+    res = LS.all_terms(a, b, g[f"{dtn}_dists"], g[f"{dtn}_wpix"], args)
     names = ["blendw", "sig_s_max", "sig_d_max", "favor", "s_ent", "s_sum", "d_ent", "d_sum", "occl", "l1", "l2"]
     for n, v in zip(names, res):
         assert rel_err(v, g[f"{dtn}_{n}"]) < 1e-6, n
     (0.7 * res[3] + 1.3 * res[4] + 0.9 * res[6] + 0.5 * res[8] + 0.25 * res[9] + 2.0 * res[10]).backward()
     assert rel_err(a.grad, g[f"{dtn}_g_sig_s"]) < 1e-6 and rel_err(b.grad, g[f"{dtn}_g_sig_d"]) < 1e-6
-    assert torch.equal(MH.weighted_MSELoss()(g[f"{dtn}_mse_pred"], g[f"{dtn}_mse_gt"], g[f"{dtn}_wpix"]), g[f"{dtn}_mse"])
+    assert torch.equal(LS.WeightedSquaredError()(g[f"{dtn}_mse_pred"], g[f"{dtn}_mse_gt"], g[f"{dtn}_wpix"]), g[f"{dtn}_mse"])
     assert rel_err(MH.compute_occl_loss(b, g[f"{dtn}_dists"], 0.2, use_back=True), g[f"{dtn}_occl_back"]) < 1e-6
 
 
@@ -459,14 +468,22 @@ def test_planner_host_arithmetic_through_the_c_abi():
 
     # per-call options win over the process-wide value and do not touch it
     before = _capi.get_option(_capi.OPT_STAGE_FP8)
-    assert store(65536, 192, _capi.PREC_BF16, _capi.NcaPlanOpts(stage_fp8=0)) == 0              # "no forward store": the backward will recompute
-    assert store(65536, 192, _capi.PREC_F32, _capi.NcaPlanOpts(stage_fp8=0)) == f32               # (a bf16 option: the f32 store is not its business)
-    assert store(1024, 500, _capi.PREC_BF16, _capi.NcaPlanOpts(stage_fp8=-1, stage_fp8_min_tiles=10 ** 9)) == 0
+    # stage_fp8 = 0 = "nothing in 8 bits": the BF16 store (round 5, NCA_STORE_BF16) -- per 32-sample tile and net a 7 KiB bf16 input
+    # block (one shared here? no: sized for one per net) + four 8 KiB hidden blocks; masks and raw outputs as before
+    bf = store(65536, 192, _capi.PREC_BF16, _capi.NcaPlanOpts(stage_fp8=0))
+    per_tile_bf = 2 * (2 * (7168 + 4 * 8192)) + 2 * 5 * 1024 + 2 * 64 * 4
+    assert per_tile_bf * tiles <= bf <= per_tile_bf * (tiles + 8) + 4096, (bf, per_tile_bf * tiles)
+    assert store(65536, 192, _capi.PREC_BF16, _capi.NcaPlanOpts(stage_fp8=0, bf16_store=0)) == 0              # "no forward store": the backward will recompute
+    assert store(65536, 192, _capi.PREC_BF16, _capi.NcaPlanOpts(bf16_store=0)) == b16                            # (the 8-bit store is not that option's business)
+    assert store(65536, 192, _capi.PREC_F32, _capi.NcaPlanOpts(stage_fp8=0, bf16_store=0)) == f32               # (bf16 options: the f32 store is not their business)
+    assert store(1024, 500, _capi.PREC_BF16, _capi.NcaPlanOpts(stage_fp8=-1, stage_fp8_min_tiles=10 ** 9, bf16_store=0)) == 0
+    assert store(1024, 500, _capi.PREC_BF16, _capi.NcaPlanOpts(stage_fp8=-1, stage_fp8_min_tiles=10 ** 9)) > store(1024, 500, _capi.PREC_BF16)   # below the threshold: the bf16 store
     assert store(1024, 500, _capi.PREC_BF16, _capi.NcaPlanOpts(stage_fp8=-1, stage_fp8_min_tiles=8000)) > 0
     assert _capi.get_option(_capi.OPT_STAGE_FP8) == before and store(65536, 192, _capi.PREC_BF16) == b16
 
     # values outside an option's range are refused, per call and process-wide, with a message; so are unknown options and empty batches
-    for bad in (_capi.NcaPlanOpts(stage_fp8=2), _capi.NcaPlanOpts(wgrad_rebuild_weight_pct=99), _capi.NcaPlanOpts(stage_fp8_min_tiles=-1), _capi.NcaPlanOpts(resident_min_tiles=-2)):
+    for bad in (_capi.NcaPlanOpts(stage_fp8=2), _capi.NcaPlanOpts(wgrad_rebuild_weight_pct=99), _capi.NcaPlanOpts(stage_fp8_min_tiles=-1), _capi.NcaPlanOpts(resident_min_tiles=-2),
+                _capi.NcaPlanOpts(bf16_store=2), _capi.NcaPlanOpts(overlap_cus=-1)):
         assert store(64, 64, _capi.PREC_BF16, bad) == -1 and b"takes" in L.nca_last_error()          # NCA_E_INVALID
     with pytest.raises(_capi.NcaError):
         _capi.set_option(_capi.OPT_WGRAD_REBUILD_WEIGHT_PCT, 250)

@@ -2,33 +2,34 @@
 BASELINE.json: "... at matched PSNR").  Every leg trains the composite model on the synthetic data set from the same initial
 weights, ray batches and depth jitter; f32 is the mode that is within 1e-5 of the reference's arithmetic per step
 (tests/test_hip_parity.py), `test_psnr` = -10 log10(test loss) is the reference's own definition (train/run_composite.py:391),
-`psnr_mse` = -10 log10(MSE of the held-out view).
+`psnr_mse` = -10 log10(MSE of the held-out view).  Both definitions are gated everywhere.
 
-THE GATE IS PER SEED (round 4; rounds 2 / 3 gated one seed, or the mean over seeds): for every seed and both PSNR definitions
+ROUND 5: the gate is a regression detector again.  What changed against round 4's
+"|bf16 - f32| < 0.1 dB + |f32_kick - f32|" (unsigned, uncapped: 1.68 dB allowed on seed 1):
 
-    |bf16 - f32| < 0.1 dB,      or, where that fails,      |bf16 - f32| < 0.1 dB + max(|f32_kick - f32|, |f32_resample - f32|)
-
-with f32_kick = the SAME parity mode started from initial weights moved ONCE by a relative 2e-3 -- one unit in the last place of
-bf16, i.e. what rounding the initial weights to bf16 a single time does -- and f32_resample = the same parity mode from the SAME
-initial weights on another stream of ray batches and depth jitter (what the mini-batch sampling alone moves the result by; it is
-only run where the kick does not already explain the gap -- in practice at the small batch, where the 8-bit staged operands add
-per-step gradient noise of the same kind as the sampling noise of 1 024-ray batches).  The second clause is not a loophole but the
-resolution of the comparison (profiles/r04_psnr_bench_batch_ensemble.jsonl, profiles/r04_psnr_ablation_seed1.jsonl): at the bench
-batch the held-out PSNR after a fixed number of steps is, on some seeds, not a well-conditioned function of the arithmetic at the
-1e-3 level -- the f32 mode itself ends 0.28 / 0.55 / 1.58 dB lower on seeds 3 / 0 / 1 when its initial weights are moved by 2e-3 (and
-0.00 - 0.02 dB on seeds 2 and 4), it is bit-stable against a move of 1e-6, and on seed 1 EVERY single rounding of the bf16 mode
-switched on alone in the f32 kernels (input features, layer-0 weights, hidden weights, hidden activations, the 8-bit staged
-weight-gradient operands; tools/ablation_build.sh) lands on the same lower branch as the kick does, while rounding everything to 11
-or 16 bits, and the dgrad chain alone to 8, stays on the upper one.  Where f32 is itself reproducible to 0.02 dB under the kick (seeds
-2 and 4), bf16 is within 0.03 dB of it.  No arithmetic with 8-bit mantissas can be held closer to the f32 trajectory than f32 holds
-itself under one such rounding; the kick run is only made where the plain 0.1 dB clause fails (it costs an f32 training run).
-
-Two batch regimes:
-  * the bench configuration, 65 536 rays x 192 samples per step, 1 000 graph-replayed steps, seeds 0, 1, 2 -- seed 1 is the worst of the
-    ten on record;
-  * the reference's default batch, 1 024 rays x 500 samples (train/composite.txt:25,40), 5 000 steps, five seeds.
+  * STRICT seeds.  A seed on which BOTH f32 controls end within 0.05 dB of the unperturbed f32 run is a seed on which the f32
+    trajectory is well-conditioned; there the bf16 mode must end within **0.05 dB** of f32.  On record: seeds 2 and 4 (and the
+    summary test asserts that at least these two were gated this way).
+  * BRANCH seeds.  Where a control moves f32 by more than 0.05 dB the seed has a second attractor within one bf16 ulp of the
+    initial weights (seeds 0, 1, 3).  There the bf16 mode must END ON one of f32's own end points: within
+    **0.1 dB of the unperturbed f32 run or of one of the two control runs** -- a signed, capped statement (seed 1: bf16 ends
+    0.04 - 0.05 dB from both controls, 1.5 dB below the unperturbed run; an arithmetic that ended anywhere else -- e.g. round 3's
+    fp8-chain experiment, -0.16 dB on seed 4 -- fails).
+  * The CONTROLS are f32 from initial weights moved ONCE: `f32_bf16init` = rounded to bf16 (round to nearest even, <= 2^-9
+    relative: the smallest thing the bf16 mode does to the weights), and `f32_kick2e-3` = times (1 + 2e-3 N(0,1)) (round 4's
+    control; about twice a bf16 rounding's rms).  Both are chosen in advance and evaluated for every seed; the "other mini-batches"
+    control of round 4 is gone.
+  * ENSEMBLE at the bench batch: the mean over five seeds of (bf16 - f32) lies within mean +- standard deviation of the kick
+    control's (f32_kick - f32) over the same seeds, and above -0.6 dB.
+  * The reference's default batch (1 024 x 500) is sampling-noise dominated (other mini-batches move f32 by 0.2 - 0.7 dB per seed,
+    profiles/r04_psnr_gates.txt): it carries a SIGNED MEAN gate (|mean over five seeds| < 0.1 dB) and a per-seed cap of 0.4 dB --
+    named for what it is, a relaxed per-seed gate.
+  * The f32 runs are CACHED (tests/golden/psnr_f32_controls.json, tools/psnr_cache.py): the parity mode is bit-reproducible, its
+    end points are data.  The cache is keyed by a hash of the f32 kernel sources (other sources: the controls run live) and ONE
+    cached control is re-run live per session and compared to 0.002 dB.  The summary tests FAIL when a per-seed row is missing.
 """
 import importlib.util
+import json
 import os
 import statistics
 from types import SimpleNamespace
@@ -38,8 +39,9 @@ import torch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KICK = "f32_kick2e-3"
 KEYS = ("psnr_mse_db", "test_psnr_reference_def_db")
+CONTROLS = ("f32_kick2e-3", "f32_bf16init")
+STRICT_DB, BRANCH_DB, STABLE_DB = 0.05, 0.1, 0.05
 
 
 @pytest.fixture(scope="module")
@@ -48,46 +50,57 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.fixture(scope="module")
-def psnr_run():
-    spec = importlib.util.spec_from_file_location("psnr_run", os.path.join(ROOT, "tools", "psnr_run.py"))
+def _load(name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "tools", name + ".py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
 
 
+@pytest.fixture(scope="module")
+def psnr_run():
+    return _load("psnr_run")
+
+
+@pytest.fixture(scope="module")
+def cache():
+    """entries of tests/golden/psnr_f32_controls.json when they were taken on THESE f32 kernel sources, else {} (controls run live)."""
+    pc = _load("psnr_cache")
+    try:
+        d = json.load(open(pc.OUT))
+    except (OSError, ValueError):
+        return {"entries": {}, "valid": False, "key": pc.key}
+    ok = d.get("f32_sources_sha") == pc.f32_sources_sha()
+    if not ok:
+        print(f"[psnr gates] the cached f32 controls were taken on other kernel sources ({d.get('f32_sources_sha')} != {pc.f32_sources_sha()}): running them live", flush=True)
+    return {"entries": d["entries"] if ok else {}, "valid": ok, "key": pc.key}
+
+
 _ROWS = {}          # (label, seed) -> row: the per-seed tests fill it, the summary tests read it
+_LIVE = {}
 
 
-def seed_row(psnr_run, args, dev, data, sd, label):
-    """f32 and bf16 for one seed, the f32 kick only where a gap reaches 0.1 dB, f32 on other mini-batches only where the kick does not
-    explain it; asserts the per-seed gate and keeps the row.  (One test per seed: a test is silent while it runs, and the GPU
-    harness takes seven silent minutes for a hang.)"""
-    f32 = psnr_run.run("f32", args, dev, data, seed=sd)
-    bf = psnr_run.run("bf16", args, dev, data, seed=sd)
-    assert bf["stage_fp8_in_effect"] is True, "the planner's default is the 8-bit staged store at every batch size"
-    for r in (f32, bf):
-        assert r["curve"][-1]["psnr_mse_db"] - r["curve"][0]["psnr_mse_db"] > 25.0, (sd, r["curve"])
-    gap = {k: bf["curve"][-1][k] - f32["curve"][-1][k] for k in KEYS}
-    row = {"seed": sd, "f32": {k: f32["curve"][-1][k] for k in KEYS}, "gap_bf16": gap, "f32_kick_moves": None, "f32_resample_moves": None,
-           "wall": (f32["wall_s_incl_eval"], bf["wall_s_incl_eval"])}
-    if max(abs(g) for g in gap.values()) >= 0.1:
-        kick = psnr_run.run(KICK, args, dev, data, seed=sd)
-        row["f32_kick_moves"] = {k: kick["curve"][-1][k] - f32["curve"][-1][k] for k in KEYS}
-        if any(abs(gap[k]) >= 0.1 + abs(row["f32_kick_moves"][k]) for k in KEYS):
-            rs = psnr_run.run("f32_resample", args, dev, data, seed=sd)
-            row["f32_resample_moves"] = {k: rs["curve"][-1][k] - f32["curve"][-1][k] for k in KEYS}
-    _ROWS[(label, sd)] = row
-    print(f"[{label}] seed {sd}: f32 {row['f32'][KEYS[0]]:.3f} dB, bf16 - f32 = " + " / ".join(f"{gap[k]:+.3f}" for k in KEYS)
-          + (" dB; f32 moved by 2e-3 once: " + " / ".join(f"{row['f32_kick_moves'][k]:+.3f}" for k in KEYS) + " dB" if row["f32_kick_moves"] else " dB")
-          + ("; f32 on other mini-batches: " + " / ".join(f"{row['f32_resample_moves'][k]:+.3f}" for k in KEYS) + " dB" if row["f32_resample_moves"] else ""), flush=True)
-    for k in KEYS:
-        allow = 0.1 + max(abs(row["f32_kick_moves"][k]) if row["f32_kick_moves"] else 0.0, abs(row["f32_resample_moves"][k]) if row["f32_resample_moves"] else 0.0)
-        assert abs(gap[k]) < allow, (label, sd, k, row)
-    return row
+def end_point(psnr_run, cache, args, dev, data, variant, sd):
+    """The last evaluation of an f32 run: from the cache, or live (and remembered for the session)."""
+    k = cache["key"](args.rays, args.samples, args.steps, variant, sd)
+    if k in cache["entries"]:
+        return dict(cache["entries"][k], cached=True)
+    if k not in _LIVE:
+        r = psnr_run.run(variant, args, dev, data, seed=sd)
+        _LIVE[k] = dict({kk: r["curve"][-1][kk] for kk in KEYS}, cached=False, wall=r["wall_s_incl_eval"])
+    return _LIVE[k]
 
 
-BENCH_SEEDS, SMALL_SEEDS = [0, 1, 2], [0, 1, 2, 3, 4]
+def bench_args():
+    return SimpleNamespace(steps=1000, every=1000, rays=65536, samples=192, det=256, graph=True, perturb=1e-6, cross_eval=False, jsonl="", label="gate")
+
+
+def small_args():
+    return SimpleNamespace(steps=5000, every=5000, rays=1024, samples=500, det=256, graph=True, perturb=1e-6, cross_eval=False, jsonl="", label="gate")
+
+
+BENCH_SEEDS, SMALL_SEEDS = [0, 1, 2, 3, 4], [0, 1, 2, 3, 4]
+STRICT_ON_RECORD = {2, 4}          # |both controls - f32| <= 0.02 dB in profiles/r05_psnr_f32_controls.jsonl and r04_psnr_bench_batch_seed_table.json
 
 
 @pytest.fixture(scope="module")
@@ -102,38 +115,86 @@ def small_data(dev):
     return synthetic.make_dataset(256, 500, dev, views=synthetic.TRAIN_VIEWS)
 
 
-@pytest.mark.timeout(600)
+@pytest.mark.timeout(900)
 @pytest.mark.parametrize("seed", BENCH_SEEDS)
-def test_bf16_psnr_gate_at_bench_configuration_per_seed(dev, psnr_run, bench_data, seed):
-    """1 000 graph-replayed steps of 65 536 rays x 192 samples on the 256^2 data set (40 training images, one held-out view): f32
-    against the bf16 mode as the bench runs it (8-bit staged store, resident kernels, mode-5 backward).  Seed 1 is the worst of the ten
-    on record (profiles/r04_psnr_bench_batch_seed_table.json: seven within 0.1 dB outright, three inside f32's own spread)."""
-    args = SimpleNamespace(steps=1000, every=1000, rays=65536, samples=192, det=256, graph=True, perturb=1e-6, cross_eval=False, jsonl="", label="gate")
-    row = seed_row(psnr_run, args, dev, bench_data, seed, "65 536 x 192")
-    assert row["wall"][1] < 0.35 * row["wall"][0], row["wall"]          # the throughput mode is the faster one by a wide margin (13.5 vs 81 ms per step on record)
+def test_bf16_psnr_gate_at_bench_configuration_per_seed(dev, psnr_run, cache, bench_data, seed):
+    """1 000 graph-replayed steps of 65 536 rays x 192 samples on the 256^2 data set (40 training images, one held-out view): the bf16
+    mode as the bench runs it (8-bit staged store, resident kernels, mode-5 backward), live, against the f32 run and its two controls."""
+    args = bench_args()
+    bf = psnr_run.run("bf16", args, dev, bench_data, seed=seed)
+    assert bf["stage_fp8_in_effect"] is True, "the planner's default is the 8-bit staged store at every batch size"
+    assert bf["curve"][-1]["psnr_mse_db"] - bf["curve"][0]["psnr_mse_db"] > 25.0, (seed, bf["curve"])
+    f32 = end_point(psnr_run, cache, args, dev, bench_data, "f32", seed)
+    ctl = {v: end_point(psnr_run, cache, args, dev, bench_data, v, seed) for v in CONTROLS}
+    gap = {k: bf["curve"][-1][k] - f32[k] for k in KEYS}
+    moves = {v: {k: ctl[v][k] - f32[k] for k in KEYS} for v in CONTROLS}
+    stable = all(abs(moves[v][k]) <= STABLE_DB for v in CONTROLS for k in KEYS)
+    row = {"seed": seed, "f32": {k: f32[k] for k in KEYS}, "gap_bf16": gap, "moves": moves, "strict": stable, "bf16_wall": bf["wall_s_incl_eval"],
+           "cached": f32["cached"] and all(c["cached"] for c in ctl.values())}
+    _ROWS[("65 536 x 192", seed)] = row
+    print(f"[65 536 x 192] seed {seed} ({'STRICT' if stable else 'BRANCH'}{', cached controls' if row['cached'] else ''}): f32 {f32[KEYS[0]]:.3f} dB, bf16 - f32 = "
+          + " / ".join(f"{gap[k]:+.3f}" for k in KEYS) + " dB; " + "; ".join(f"{v} - f32 = " + " / ".join(f"{moves[v][k]:+.3f}" for k in KEYS) for v in CONTROLS), flush=True)
+    for k in KEYS:
+        if stable:
+            assert abs(gap[k]) < STRICT_DB, ("strict", seed, k, row)
+        else:
+            nearest = min([abs(gap[k])] + [abs(gap[k] - moves[v][k]) for v in CONTROLS])
+            assert nearest < BRANCH_DB, ("branch", seed, k, row)
 
 
 def test_bench_configuration_gate_summary():
-    """At least one of the three seeds is resolved by the plain 0.1 dB clause on both definitions (seed 2 on record: -0.02 dB)."""
+    """Every seed ran; the seeds that are stable on record were gated STRICT; the ensemble mean of the bf16 gaps lies inside the kick
+    control's own mean +- standard deviation, and above -0.6 dB."""
     rows = [_ROWS.get(("65 536 x 192", sd)) for sd in BENCH_SEEDS]
-    if any(r is None for r in rows):
-        pytest.skip("the per-seed tests did not all run in this session")
-    assert any(r["f32_kick_moves"] is None for r in rows), rows
+    assert all(r is not None for r in rows), "a per-seed test of the bench configuration did not run (or failed) in this session: " + str([sd for sd, r in zip(BENCH_SEEDS, rows) if r is None])
+    strict = {r["seed"] for r in rows if r["strict"]}
+    assert STRICT_ON_RECORD <= strict, (strict, "the seeds whose f32 trajectory is reproducible under both controls must carry the 0.05 dB gate")
+    for k in KEYS:
+        g = [r["gap_bf16"][k] for r in rows]
+        c = [r["moves"]["f32_kick2e-3"][k] for r in rows]
+        m, mc, sc = statistics.mean(g), statistics.mean(c), statistics.stdev(c)
+        print(f"[65 536 x 192] {k}: mean(bf16 - f32) = {m:+.3f} dB over seeds {BENCH_SEEDS}; f32_kick2e-3 - f32: mean {mc:+.3f}, sd {sc:.3f}", flush=True)
+        assert mc - sc <= m <= mc + sc, (k, g, c)
+        assert m > -0.6, (k, g)
 
 
-@pytest.mark.timeout(600)
+def test_cached_f32_control_reproduces_live(dev, psnr_run, cache, bench_data):
+    """Spot check of the cache: ONE cached f32 run (seed 2 at the bench batch) re-run live ends where the cache says, to 0.002 dB on
+    both definitions -- and the bf16 mode is the faster one by a wide margin (13 vs 80 ms per step on record)."""
+    args = bench_args()
+    k = cache["key"](args.rays, args.samples, args.steps, "f32", 2)
+    if k not in cache["entries"]:
+        pytest.skip("no valid cache for these kernel sources: the controls of this session ran live anyway")
+    r = psnr_run.run("f32", args, dev, bench_data, seed=2)
+    for kk in KEYS:
+        assert abs(r["curve"][-1][kk] - cache["entries"][k][kk]) < 0.002, (kk, r["curve"][-1], cache["entries"][k])
+    row = _ROWS.get(("65 536 x 192", 2))
+    if row is not None:
+        assert row["bf16_wall"] < 0.35 * r["wall_s_incl_eval"], (row["bf16_wall"], r["wall_s_incl_eval"])
+
+
+@pytest.mark.timeout(900)
 @pytest.mark.parametrize("seed", SMALL_SEEDS)
-def test_psnr_gate_at_reference_default_batch_per_seed(dev, psnr_run, small_data, seed):
-    """1 024 rays x 500 samples per step (train/composite.txt:25,40), 5 000 graph-replayed steps: the per-seed gate."""
-    args = SimpleNamespace(steps=5000, every=5000, rays=1024, samples=500, det=256, graph=True, perturb=1e-6, cross_eval=False, jsonl="", label="gate")
-    seed_row(psnr_run, args, dev, small_data, seed, "1 024 x 500")
+def test_psnr_gate_at_reference_default_batch_per_seed(dev, psnr_run, cache, small_data, seed):
+    """1 024 rays x 500 samples per step (train/composite.txt:25,40), 5 000 graph-replayed steps: the RELAXED per-seed gate of the
+    sampling-noise-dominated regime, |bf16 - f32| < 0.4 dB on both definitions (the mean over the seeds is gated below)."""
+    args = small_args()
+    bf = psnr_run.run("bf16", args, dev, small_data, seed=seed)
+    assert bf["stage_fp8_in_effect"] is True
+    assert bf["curve"][-1]["psnr_mse_db"] - bf["curve"][0]["psnr_mse_db"] > 25.0, (seed, bf["curve"])
+    f32 = end_point(psnr_run, cache, args, dev, small_data, "f32", seed)
+    gap = {k: bf["curve"][-1][k] - f32[k] for k in KEYS}
+    _ROWS[("1 024 x 500", seed)] = {"seed": seed, "f32": {k: f32[k] for k in KEYS}, "gap_bf16": gap, "cached": f32["cached"]}
+    print(f"[1 024 x 500] seed {seed}{' (cached f32)' if f32['cached'] else ''}: f32 {f32[KEYS[0]]:.3f} dB, bf16 - f32 = " + " / ".join(f"{gap[k]:+.3f}" for k in KEYS) + " dB", flush=True)
+    for k in KEYS:
+        assert abs(gap[k]) < 0.4, (seed, k, gap)
 
 
 def test_reference_default_batch_gate_summary():
-    """The mean of the five gaps within 0.1 dB on both PSNR definitions, and bf16 the faster one on average."""
+    """The SIGNED mean of the five gaps within 0.1 dB on both PSNR definitions."""
     rows = [_ROWS.get(("1 024 x 500", sd)) for sd in SMALL_SEEDS]
-    if any(r is None for r in rows):
-        pytest.skip("the per-seed tests did not all run in this session")
+    assert all(r is not None for r in rows), "a per-seed test of the reference's default batch did not run (or failed) in this session: " + str([sd for sd, r in zip(SMALL_SEEDS, rows) if r is None])
     for k in KEYS:
-        assert abs(statistics.mean(r["gap_bf16"][k] for r in rows)) < 0.1, (k, [r["gap_bf16"][k] for r in rows])
-    assert statistics.mean(r["wall"][1] for r in rows) < statistics.mean(r["wall"][0] for r in rows)
+        m = statistics.mean(r["gap_bf16"][k] for r in rows)
+        print(f"[1 024 x 500] {k}: mean(bf16 - f32) = {m:+.3f} dB over seeds {SMALL_SEEDS}", flush=True)
+        assert abs(m) < 0.1, (k, [r["gap_bf16"][k] for r in rows])

@@ -276,6 +276,48 @@ def test_magix_shape_full_size_step(dev):
     assert bool(torch.isfinite(outs[0][1]).all()) and float(outs[0][1].abs().max()) > 0
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
+    # A 1/256 subsample of that step's rays (MAGIX geometry, 256 samples per ray, f32) against the ORACLE: the loss, the pixel term,
+    # every loss term and the first-layer gradients of both nets.  The oracle runs twice: in f32 (the reference's arithmetic) and in
+    # f64 (what it approximates); gradients are gated at max(1e-5, 3 x the f32 oracle's own distance from f64), as everywhere
+    # (ReLU masks near zero flip under any f32 rounding, tests/test_hip_parity.py).
+    from nerfca_amd import _capi
+    from oracle import nerfca_oracle as O
+    torch.manual_seed(1)
+    sdef, tdef = synthetic.net_definitions(dev)
+    s, t = CPPN(sdef).to(dev), Temporal(tdef).to(dev)
+    R_sub, n_iter = 1024, 75000
+    full = CompositeTrainer(TrainConfig(depth_samples_per_ray_coarse=256, img_sample_size=262144), s, t, data, dev, seed=0)
+    ids = full.draw_ray_ids_device(n_iter)[::256].contiguous()
+    assert ids.shape[0] == R_sub
+    tr = CompositeTrainer(TrainConfig(depth_samples_per_ray_coarse=256, img_sample_size=R_sub), s, t, data, dev, seed=0)
+    tr.draw_ray_ids_device = lambda it: ids
+    terms, grads_s, grads_d = tr.fused_gradients(n_iter)
+    got = dict(zip(_capi.TERM_NAMES, terms.cpu().tolist()))
+    gs = dict(zip([n for n, _ in s.named_parameters()], s._binding.split_grads(grads_s)))
+    gd = dict(zip([n for n, _ in t.named_parameters()], t._binding.split_grads(grads_d)))
+    rays, ph = data.rays_train.cpu().index_select(0, ids.cpu()), data.phases_train.cpu().index_select(0, ids.cpu())
+    o, d, gt, w = rays[:, 0, :], rays[:, 1, :], rays[:, 2, 0], rays[:, 3, 0]
+    I0 = torch.full((R_sub,), float(data.geo["max_pixel_value"]))
+    z = O.stratified_depths(O.depth_values(data.geo["near_thresh"], data.geo["far_thresh"], 256), tr.draw_jitter(n_iter))
+    ss, sd = O.NetSpec(num_filters=128), O.NetSpec(num_filters=128, num_time_dim=8)
+
+    def oracle(dt):
+        ot = O.OracleTrainer({k: v.detach().cpu().to(dt) for k, v in s.state_dict().items()}, ss, {k: v.detach().cpu().to(dt) for k, v in t.state_dict().items()}, sd)
+        loss, pixel, tt = ot.step(n_iter, o, d, ph[:, None].repeat(1, 256), I0, z.to(dt) if dt == torch.float64 else z, gt, w)
+        return loss, pixel, tt, ot
+    l64, p64, t64, o64 = oracle(torch.float64)
+    _, _, _, o32 = oracle(torch.float32)
+    ref = {"loss": l64, "pixel": p64, "blendw": t64[0], "favor_s": t64[3], "s_entropy": t64[4], "s_entropy_sum": t64[5], "d_entropy": t64[6],
+           "d_entropy_sum": t64[7], "d_occl": t64[8], "s_l1": t64[9], "s_l2": t64[10]}
+    for k, v in ref.items():
+        v = float(v.detach())
+        assert abs(got[k] - v) <= 2e-5 * abs(v) + 1e-12, (k, got[k], v)
+    for name, mine, p64s, p32s in (("static", gs, o64.ps, o32.ps), ("dynamic", gd, o64.pd, o32.pd)):
+        for key in ("early_pts_layers.0.weight", "early_pts_layers.0.bias"):
+            g64, g32 = p64s[key].grad.double(), p32s[key].grad.double()
+            tol = max(1e-5, 3 * rel_err(g32, g64))
+            assert rel_err(mine[key].cpu().double(), g64) < tol, (name, key, rel_err(mine[key].cpu().double(), g64), tol)
+
 
 @pytest.mark.parametrize("prec", ["f32", "bf16"])
 def test_graph_step_with_fine_pass_matches_fused_step(dev, prec):

@@ -167,7 +167,9 @@ def main():
     from nerfca_amd import synthetic
     from nerfca_amd.model.CPPN import CPPN
     from nerfca_amd.model.Temporal import Temporal
-    from nerfca_amd.train.trainer import CompositeTrainer, TrainConfig
+    from nerfca_amd.train.trainer import TrainConfig
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from injected_trainer import InjectedTrainer as CompositeTrainer          # (the renderer is this file's torch model of the arithmetic)
     dev = torch.device(args.device)
     f32r = make_render(Arith("f32"), False)
     data = synthetic.make_dataset(args.det, args.samples, dev, views=synthetic.TRAIN_VIEWS, n_phases=4, F=64,
@@ -183,12 +185,12 @@ def main():
             cfg = TrainConfig(depth_samples_per_ray_coarse=args.samples, img_sample_size=args.rays, static_pos_enc_window_decay_steps=args.steps,
                               temp_pos_enc_window_decay_steps=args.steps, lr_decay_steps=args.steps)
             s, t = s.to(dev), t.to(dev)
-            tr = CompositeTrainer(cfg, s, t, data, dev, seed=seed, render=make_render(ar, False), fused_adam=False, fused_loss=False)
+            tr = CompositeTrainer(cfg, s, t, data, dev, seed=seed, render=make_render(ar, False), fused_adam=False)
             tr.update_windows(0)
             t0 = time.perf_counter()
             for it in range(args.steps):
                 tr.step(it)
-            tr.render = f32r                 # evaluate every run with the same (f32) renderer
+            tr._inj_render = f32r            # evaluate every run with the same (f32) renderer
             ev = tr.evaluate(args.steps)
             res.append({"seed": seed, "psnr_mse_db": float(ev["test_psnr_mse"]), "test_psnr_db": float(ev["test_psnr"]), "wall_s": time.perf_counter() - t0})
             print(name, res[-1], file=sys.stderr, flush=True)
