@@ -55,7 +55,7 @@ PEAK_HBM_GBPS = 8000.0
 # of 2500 TFLOP/s / 8 TB/s = 312 FLOP/B: that kernel's roofline is the HBM one.
 WGRAD_FP8_BYTES_PER_SAMPLE = 2 * (4 * 256 + 128 + 20)
 PEAK_F32_ON_BF16_PIPE = 2500.0 / 6.0
-PROFILE_TAGS = ("r04", "r03", "r02", "r01")          # committed PMC summaries, newest first
+PROFILE_TAGS = ("r05", "r04", "r03", "r02", "r01")          # committed PMC summaries, newest first
 FLOP_STEP = FLOP_FWD + FLOP_DGRAD + FLOP_WGRAD            # 870 912 FLOP per sample of a training step
 # the pipe a precision's contractions run on: the f32 mode's hidden layers are six bf16 products per f32 product
 PIPE_PEAK_TFLOPS = {"f32": PEAK_F32_ON_BF16_PIPE, "bf16": 2500.0}
@@ -334,7 +334,8 @@ def roofline_of(args, prec, kern, eager_dt, plan, ms_per_step, world=1):
 
 
 BWD_MODES = {1: "mode 1: recompute backward (no forward store)", 3: "mode 3: from the forward's f32 store",
-             5: "mode 5: from the forward's 8-bit staged store, nothing recomputed"}
+             5: "mode 5: from the forward's store (8-bit staged, or bf16 where nothing may be staged in 8 bits), nothing recomputed"}
+STORE_NAMES = {0: "none", 1: "f32", 3: "8-bit staged (e4m3 layer inputs)", 4: "bf16 (bf16 layer inputs)"}
 
 
 def measure(args, prec, stage_fp8, data, dev, rank, world, use_pg, steps, warmup, sustained_steps=0):
@@ -417,12 +418,15 @@ def _measure(args, prec, stage_fp8, data, dev, rank, world, use_pg, steps, warmu
     label = "f32" if prec == "f32" else ("bf16+fp8stage" if fp8 else "bf16")
     rec = {"value": rays_per_rank(args, world) * world * steps / dt, "unit": "rays/s", "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "dtype": label,
            "arithmetic": {"f32": "f32 (hidden layers on the bf16 matrix cores from exact 3-way splits): 1e-5 relative vs the reference's f32 path per step (tests/test_hip_parity.py)",
-                          "bf16": "bf16 MFMA operands everywhere, f32 accumulation, f32 master weights; no forward store: the backward recomputes the layers, nothing is staged in 8 bits",
+                          "bf16": "bf16 MFMA operands everywhere (forward, dgrad chain AND weight gradient), f32 accumulation, f32 master weights; nothing is staged in 8 bits: "
+                                  "the forward leaves layer inputs as bf16 fragments + ReLU masks + raw outputs (the bf16 store), the backward recomputes nothing and writes bf16 "
+                                  "output gradients (or, where the store does not fit, recomputes the layers: see plan.backward)",
                           "bf16+fp8stage": "bf16 MFMA operands for the MLP contractions (forward and dgrad), f32 accumulation, f32 master weights; the layer inputs (e4m3) and output "
                                            "gradients (e5m2, per-tile power-of-two scale) cross HBM in 8 bits and the weight gradient contracts them on the MX-fp8 matrix path; PSNR-gated "
                                            "(tests/test_psnr_gates.py)"}[label],
            "hip_graph": bool(args.graph), "eager_ms_per_step": eager_ms, "kernel_table_steps": timed_steps, "final_loss": loss,
            "plan": {"stage_fp8": fp8, "backward": BWD_MODES.get(plan.get("bwd_kernel_mode"), str(plan.get("bwd_kernel_mode"))),
+                    "forward_store": STORE_NAMES.get(plan.get("fwd_store_format", 0) & 15, str(plan.get("fwd_store_format"))),
                     "resident_weight_images": {"fwd": bool(plan.get("fwd_resident")), "bwd": bool(plan.get("bwd_resident"))},
                     "ray_chunks": plan.get("chunks"),
                     "wgrad": {"jobs": plan.get("wgrad_jobs"), "splits": plan.get("wgrad_splits"), "splits_rebuild_jobs": plan.get("wgrad_splits_rebuild")},
@@ -698,8 +702,15 @@ def main():
             # the other precisions side by side, each through the same (graph-replayed) step
             if args.prec == "bf16" and args.pure_steps > 0 and main_rec["plan"]["stage_fp8"]:
                 out["bf16_pure"] = measure(args, "bf16", 0, data, dev, 0, 1, False, args.pure_steps, args.warmup)
-                out["bf16_pure"]["note"] = ("BASELINE configs[1] as written: bf16 everywhere, nothing staged in 8 bits (stage_fp8 = 0: no forward store, recompute backward; "
-                                            "the bf16-STAGED store of rounds 1-3 was retired in round 4, DESIGN.md 4.5)")
+                out["bf16_pure"]["note"] = ("BASELINE configs[1] as written: bf16 operands in every contraction, nothing staged in 8 bits (stage_fp8 = 0: the bf16 store of round 5 -- "
+                                            "NCA_STORE_BF16 -- and the mode-5 backward from it; DESIGN.md 4.7)")
+                bp = out["bf16_pure"]
+                # BASELINE.json configs[1] says "bf16": the record of the arithmetic that is bf16 and nothing narrower, at the top level beside
+                # the headline (whose `dtype` says "bf16+fp8stage": PSNR-gated, but 8-bit on its way to the weight-gradient kernel)
+                out["baseline_config_dtype"] = {"dtype": "bf16", "config": "BASELINE.json configs[1] as written (run_composite XCAT 4-view, 256^2 x 192 samples, bf16, 1 x MI355X)",
+                                                "value": bp["value"], "unit": "rays/s", "ms_per_step": bp["ms_per_step"], "steps": bp["steps"], "plan": bp["plan"],
+                                                "roofline": {k: bp["roofline"].get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "avg_launch_ms")},
+                                                "roofline_step": bp["roofline"]["step"], "per_kernel": bp["roofline"]["per_kernel"], "record": "bf16_pure"}
             if args.prec != "f32" and args.f32_steps > 0:
                 out["f32"] = measure(args, "f32", None, data, dev, 0, 1, False, args.f32_steps, args.f32_warmup)
             out["precisions"] = {k: {"rays_per_s": r["value"], "ms_per_step": r["ms_per_step"], "steps": r["steps"], "roofline_frac": r["roofline"]["frac"],

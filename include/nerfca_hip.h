@@ -9,7 +9,8 @@
  * Conventions
  *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless it says "host";
  *   - buffers are caller-owned, contiguous, 16-byte aligned; the library allocates nothing that
- *     outlives a call except a small pool of timing events (nca_timing_*);
+ *     outlives a call except a small pool of timing events (nca_timing_*) and, per calling thread, one side stream with two events
+ *     (NCA_OPT_OVERLAP_CUS: created at the first overlapped backward, never otherwise);
  *   - kernels are enqueued on `stream` (a hipStream_t passed as void*) and the call returns
  *     without synchronising; no exceptions cross the ABI;
  *   - return value 0 = ok, negative = error (NCA_E_*); nca_last_error() gives the message of the
@@ -50,7 +51,10 @@ enum { NCA_ACT_SIGMOID = 0, NCA_ACT_SOFTPLUS = 1, NCA_ACT_CLAMP = 2 };
 
 /* arithmetic of the MLP contractions */
 enum {
-    NCA_PREC_F32 = 0, /* f32 MFMA (v_mfma_f32_32x32x2_f32): parity mode, 1e-5 rel vs reference */
+    NCA_PREC_F32 = 0, /* parity mode, 1e-5 rel vs the reference: f32 operands and f32 accumulation; the hidden-layer contractions run on
+                         the bf16 matrix cores from EXACT three-way bf16 splits of both operands (six v_mfma_f32_32x32x16_bf16 per f32
+                         product block: the dropped products are below an f32 FMA chain's own rounding), layer 0 and the output layer on
+                         v_mfma_f32_32x32x2_f32 */
     NCA_PREC_BF16 = 1 /* bf16 MFMA operands, f32 accumulate: throughput mode                  */
 };
 

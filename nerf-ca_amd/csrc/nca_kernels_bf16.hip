@@ -610,7 +610,9 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
                 // do not fit the scalar file) and fetches each with a v_readlane per tile -- a vector issue slot apiece in a kernel that
                 // is bound by those (tools/isa_spills.py); compared per tile they are scalar-ALU instructions and live in no register.
                 int encL = y.L, encT = y.T;
+#ifndef NCA_AB_ENC_HOISTED          // (A/B build of round 5 only: tools/variant_build.sh enchoist "-DNCA_AB_ENC_HOISTED" = the round-4 code)
                 asm volatile("" : "+s"(encL), "+s"(encT));
+#endif
                 if (y.enc_mode == NCA_ENC_FOURIER) {
                     // [sin(2 pi x g_i), cos(2 pi x g_i)] interleaved into slots 2i, 2i+1 (model/CPPN.py:115-118)
 #pragma unroll

@@ -47,7 +47,8 @@ class Temporal(FieldBase):
         forward_composite; on its own it evaluates the field at latents that are not rows of ``time_latents``, e.g. a cardiac
         phase interpolated between two frames).  The kernels gather latents from a table by id, so the distinct vectors
         become temporary tables of ``fixed_frame_ids`` rows each (one launch per table).  Gradients reach the network
-        weights; the passed vectors themselves are constants here."""
+        weights AND the passed vectors, per point as autograd gives them (nca_mlp_bwd's ``g_latents``: W0[:, latent columns]^T D_0 of
+        every point) -- vectors that require a gradient (a learned or interpolated latent) get it."""
         if self.num_late_layers > 0:
             raise UnboundLocalError("local variable 'outputs' referenced before assignment "
                                     "(num_late_layers > 0 has no output in the reference, Temporal.py:128-135)")

@@ -83,7 +83,7 @@ def test_fp8_stage_vs_emulating_oracle(dev, R, S, F, early, it_d):
     try:
         with count_dgrad_launches(launches):
             p8, a8, b8, g8 = _hip_grads(s, t, dev, o, d, ph, I0, z, dists, cp, cs, cd)
-        with nca_option("STAGE_FP8", 0):          # no store: the recompute backward, nothing in 8 bits
+        with nca_option("STAGE_FP8", 0), nca_option("BF16_STORE", 0):          # no store: the recompute backward, nothing in 8 bits
             p16, a16, b16, g16 = _hip_grads(s, t, dev, o, d, ph, I0, z, dists, cp, cs, cd)
         fused.BWD_WORKSPACE_BYTES = 24 << 20
         pc, ac, bc, gc = _hip_grads(s, t, dev, o, d, ph, I0, z, dists, cp, cs, cd)
@@ -150,7 +150,7 @@ def test_fp8_stage_with_depth_gradients(dev):
     o, d, ph, z, I0, cp, cs, cd = _inputs(R, S, gen)
     dists = O.ray_dists(z, torch.float64)
     _, _, _, gz = _hip_grads(s, t, dev, o, d, ph, I0, z, dists, cp, cs, cd, want_depth=True)
-    with nca_option("STAGE_FP8", 0):
+    with nca_option("STAGE_FP8", 0), nca_option("BF16_STORE", 0):
         _, _, _, gz16 = _hip_grads(s, t, dev, o, d, ph, I0, z, dists, cp, cs, cd, want_depth=True)
     _, _, _, g8 = _hip_grads(s, t, dev, o, d, ph, I0, z, dists, cp, cs, cd)
     assert rel_err(gz["depth"], gz16["depth"]) < 2e-6
@@ -178,7 +178,7 @@ def test_fp8_stage_full_size_step(dev):
         s, t = CPPN(sdef).to(dev), Temporal(tdef).to(dev)
         nerfca_amd.set_precision("bf16", s, t)
         tr = CompositeTrainer(TrainConfig(depth_samples_per_ray_coarse=192, img_sample_size=65536), s, t, data, dev, seed=0)
-        with nca_option("STAGE_FP8", fp8):
+        with nca_option("STAGE_FP8", fp8), nca_option("BF16_STORE", 0):
             _, _, terms = tr.step_fused(75000)
         res.append((terms.clone(), torch.cat([p.grad.flatten() for p in tr.params]).clone()))
     assert torch.equal(res[0][0], res[1][0])

@@ -95,7 +95,7 @@ def test_small_batches_and_other_paths_do_not_fork(dev):
     assert p1["overlap_cus"] == 0, p1
     for k, v in base[3].items():
         assert torch.equal(got[3][k], v), k
-    got, p2 = _run(dev, s, t, inputs, dists, 96, {"stage_fp8": 0})           # the recompute backward: one launch, nothing to overlap
+    got, p2 = _run(dev, s, t, inputs, dists, 96, {"stage_fp8": 0, "bf16_store": 0})           # the recompute backward: one launch, nothing to overlap
     assert p2["overlap_cus"] == 0 and p2["bwd_kernel_mode"] == 1, p2
 
 

@@ -111,7 +111,7 @@ def test_no_store_recompute_backward_vs_emulating_oracle(dev, R, S, F, early, it
     saved = fused.BWD_WORKSPACE_BYTES
     res, plans = {}, {}
     try:
-        for name, ws, opts in (("default", 6 << 30, {}), ("no_store", 6 << 30, {"stage_fp8": 0}), ("no_store_chunks", 24 << 20, {"stage_fp8": 0})):
+        for name, ws, opts in (("default", 6 << 30, {}), ("no_store", 6 << 30, {"stage_fp8": 0, "bf16_store": 0}), ("no_store_chunks", 24 << 20, {"stage_fp8": 0, "bf16_store": 0})):
             fused.BWD_WORKSPACE_BYTES = ws
             with fused.PlanScope(**opts) as sc:
                 res[name] = _hip_grads(s, t, dev, o, d, ph, I0, z, dists, cp, cs, cd)
@@ -150,7 +150,7 @@ def test_no_store_with_depth_gradients(dev, F, R, S):
     o, d, ph, z, I0, cp, cs, cd = _inputs(R, S, gen)
     dists = O.ray_dists(z, torch.float64)
     res = {}
-    for name, opts in (("default", {}), ("no_store", {"stage_fp8": 0})):
+    for name, opts in (("default", {}), ("no_store", {"stage_fp8": 0, "bf16_store": 0})):
         with fused.PlanScope(**opts) as sc:
             res[name] = _hip_grads(s, t, dev, o, d, ph, I0, z, dists, cp, cs, cd, want_depth=True)
         assert sc.decided()["bwd_kernel_mode"] == (5 if name == "default" else 1), sc.decided()
@@ -161,7 +161,7 @@ def test_no_store_with_depth_gradients(dev, F, R, S):
 
 def test_two_trainers_keep_their_own_planner_options(dev):
     """Per-trainer planner options: two trainers of one process, one with the default plan and one with
-    `plan_opts={"stage_fp8": 0}`, stepped alternately -- each runs ITS plan every time (its own record says so), the process-wide
+    `plan_opts={"stage_fp8": 0, "bf16_store": 0}`, stepped alternately -- each runs ITS plan every time (its own record says so), the process-wide
     option is never written, and each trainer's trajectory is bit-identical to the one it takes when it runs alone."""
     import nerfca_amd
     from nerfca_amd import _capi, synthetic
@@ -188,9 +188,9 @@ def test_two_trainers_keep_their_own_planner_options(dev):
                     assert tr.plan()["bwd_kernel_mode"] == want, (k, tr.plan())
         return [torch.stack(o) for o in out], [torch.cat([p.detach().flatten() for p in tr.params]).clone() for tr in trs]
 
-    both_l, both_p = run([trainer(None), trainer({"stage_fp8": 0})])
+    both_l, both_p = run([trainer(None), trainer({"stage_fp8": 0, "bf16_store": 0})])
     a_l, a_p = run([trainer(None)])
-    b_l, b_p = run([trainer({"stage_fp8": 0})])
+    b_l, b_p = run([trainer({"stage_fp8": 0, "bf16_store": 0})])
     assert _capi.get_option(_capi.OPT_STAGE_FP8) == -1
     assert torch.equal(both_l[0], a_l[0]) and torch.equal(both_p[0], a_p[0])
     assert torch.equal(both_l[1], b_l[0]) and torch.equal(both_p[1], b_p[0])

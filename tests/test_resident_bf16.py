@@ -65,7 +65,7 @@ def test_resident_equals_streaming_render_and_gradients(dev, R, S, F, early, it_
     dists = O.composite(torch.zeros(R, S, 1), torch.zeros(R, S, 1), I0, d, z)[3]
     got, launches, plain = {}, [], {}
     for name, thr in (("streaming", -1), ("resident", 0)):
-        with nca_option("RESIDENT_MIN_TILES", thr), nca_option("STAGE_FP8", fp8), count_launches(launches):
+        with nca_option("RESIDENT_MIN_TILES", thr), nca_option("STAGE_FP8", fp8), nca_option("BF16_STORE", 0), count_launches(launches):
             got[name] = _hip_grads(s, t, dev, o, d, ph, I0, z, dists, cp, cs, cd)
         with nca_option("RESIDENT_MIN_TILES", thr), torch.no_grad():
             plain[name] = render_rays(s, t, o.to(dev), d.to(dev), ph.to(dev), I0.to(dev), z.to(dev), dists.to(dev))

@@ -210,11 +210,11 @@ def test_fuzz_resident_equals_streaming_and_oracle(dev, R, S, F, early, it_s, it
     t.update_freq_mask_alpha(it_d, 150000)
     got = {}
     for name, thr in (("streaming", -1), ("resident", 0)):
-        with nca_option("RESIDENT_MIN_TILES", thr), nca_option("STAGE_FP8", fp8):
+        with nca_option("RESIDENT_MIN_TILES", thr), nca_option("STAGE_FP8", fp8), nca_option("BF16_STORE", 0):
             got[name] = _hip_grads(s, t, dev, o, d, ph, I0, z, dists, cp, cs, cd)
     g16 = got["streaming"][3]
     if staged:
-        with nca_option("RESIDENT_MIN_TILES", -1), nca_option("STAGE_FP8", 0):
+        with nca_option("RESIDENT_MIN_TILES", -1), nca_option("STAGE_FP8", 0), nca_option("BF16_STORE", 0):
             g16 = _hip_grads(s, t, dev, o, d, ph, I0, z, dists, cp, cs, cd)[3]
     for i in range(3):
         assert torch.equal(got["resident"][i], got["streaming"][i]), i
@@ -279,7 +279,7 @@ def test_fp8_stage_at_natural_resident_threshold_vs_oracle(dev):
     # resident two-launch forward, recompute backward with bf16 operands everywhere -- against the oracle that rounds to bf16 only.
     from nerfca_amd import fused
     go16 = _oracle_grads(ps, ss, pd, sd, win, win, o, d, ph, I0, z, cp, cs, cd, False, fp8=False, ray_chunk=512)[4]
-    with fused.PlanScope(stage_fp8=0) as sc:
+    with fused.PlanScope(stage_fp8=0, bf16_store=0) as sc:
         p0, a0, b0, g0 = _hip_grads(s, t, dev, o, d, ph, I0, z, dists, cp, cs, cd)
     assert sc.decided()["bwd_kernel_mode"] == 1 and sc.decided()["fwd_store_format"] == 0 and sc.decided()["fwd_resident"] == 1, sc.decided()
     assert torch.equal(p0, pr) and torch.equal(a0, ar) and torch.equal(b0, br)

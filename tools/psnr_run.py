@@ -5,8 +5,9 @@ Trains the composite model on the synthetic data set of bench.py (40 training im
 same initial weights, ray batches and depth jitter in every arithmetic the library offers --
 
     f32             the parity mode (within 1e-5 of the reference's arithmetic per step, tests/test_hip_parity.py)
-    bf16_nostore    bf16 MFMA operands everywhere: no forward store, the backward recomputes the layers, nothing is staged in 8 bits
-                    (NCA_OPT_STAGE_FP8 = 0; until round 3 this option selected a bf16-staged store -- retired: bf16_bf16stage in old records)
+    bf16_store      bf16 MFMA operands everywhere, nothing in 8 bits: the forward leaves the BF16 store (layer inputs as bf16 fragments, masks, raw
+                    outputs), the backward recomputes nothing and writes bf16 output gradients (NCA_OPT_STAGE_FP8 = 0; round 5)
+    bf16_nostore    the same arithmetic constraints without any store: the backward recomputes the layers (NCA_OPT_STAGE_FP8 = 0, NCA_OPT_BF16_STORE = 0)
     bf16_fp8stage   bf16 MFMA operands, the forward store staged as e4m3 / e5m2 (NCA_OPT_STAGE_FP8 = 1)
     bf16            bf16 with the planner's own choice for this batch size (the library default: the 8-bit staged store)
     f32_kick<eps>   f32 from initial weights moved once by a relative eps N(0, 1) (e.g. f32_kick2e-3: the round-4 control)
@@ -33,7 +34,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-VARIANTS = {"f32": ("f32", None), "bf16": ("bf16", None), "bf16_nostore": ("bf16", 0), "bf16_fp8stage": ("bf16", 1),
+VARIANTS = {"f32": ("f32", None), "bf16": ("bf16", None), "bf16_store": ("bf16", {"stage_fp8": 0}), "bf16_nostore": ("bf16", {"stage_fp8": 0, "bf16_store": 0}),
+            "bf16_fp8stage": ("bf16", {"stage_fp8": 1}),
             # f32 again from initial weights moved by 1e-6 (relative): the run-to-run spread of the parity mode itself, i.e. the
             # resolution of a PSNR comparison at this batch size
             "f32_perturbed": ("f32", None)}
@@ -79,7 +81,7 @@ def run(variant, args, dev, data, log=None, seed=0):
     # schedules compressed to the length of the run (the reference anneals over 150 k steps of 1 024 rays)
     cfg = TrainConfig(depth_samples_per_ray_coarse=args.samples, img_sample_size=args.rays, static_pos_enc_window_decay_steps=args.steps,
                       temp_pos_enc_window_decay_steps=args.steps, lr_decay_steps=args.steps)
-    tr = CompositeTrainer(cfg, s, t, data, dev, seed=batch_seed, plan_opts=None if stage is None else {"stage_fp8": stage})
+    tr = CompositeTrainer(cfg, s, t, data, dev, seed=batch_seed, plan_opts=stage)
     tr.update_windows(0)
     curve = []
 
