@@ -295,7 +295,9 @@ int nca_fine_depths_given_max(int64_t R, int32_t S, int32_t n_fine, const float*
  *      table f64[N,4,3] (rows: origin, direction, pixel x3, weight x3); phases i64[N]; ids i64[R].
  *      n_rows = N: an id outside [0, N) does not reach memory -- it is clamped into the table and, if `bad_ids` (device i32[1],
  *      caller-zeroed, may be NULL) is given, counted there; the caller reads the counter when it can afford a synchronisation
- *      (CompositeTrainer.early_stop() / evaluate() do, and raise).  n_rows <= 0 = unknown: ids are trusted as in ABI <= 8.
+ *      (CompositeTrainer.early_stop() / evaluate() do, and raise; bench.py checks at the end of every timed record).  With bad_ids = NULL the
+ *      clamping is SILENT: the step trains on row 0 or row N - 1 instead of failing as NumPy's IndexError does in the reference -- pass the
+ *      counter.  n_rows <= 0 = unknown: ids are trusted as in ABI <= 8.
  *      Outputs: o, d f64[R,3]; gt, w f64[R]; ph i32[R]; z f32[S]; dists f64[S].  depth / t_rand f32[S].  ------------------------------ */
 int nca_prepare_batch(int64_t R, int32_t S, const int64_t* ids, const double* table, const int64_t* phases, int64_t n_rows, int32_t* bad_ids,
                       const float* depth, const float* t_rand,

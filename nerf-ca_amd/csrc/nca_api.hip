@@ -972,12 +972,17 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     for (int n = 0; n < a.nnets; ++n) { slab_off[n] = soff; soff += lays[n].n_params; }
     for (int n = 0; n < a.nnets; ++n) { onehot_off[n] = soff; soff += (int64_t)lays[n].F * lays[n].P; }
 
+    // the last hidden layer's output-gradient block is rebuilt by its weight-gradient job from the forward's mask bits (one byte / word per
+    // sample instead of the block): with the 8-bit staged output gradients, and with bf16 ones out of the bf16 store -- not on the
+    // depth-gradient path of the 8-bit store (bf16 D blocks beside e4m3 layer inputs: no such job) and not for points (per-point latents)
+    const bool expand_last = nr && (d8 || (!h8 && !g_depth && !g_latents));
+    a.expand_last = (expand_last && !d8) ? 1 : 0;
     static thread_local NcaWgradArgs w;
     memset(&w, 0, sizeof(w));
     for (int n = 0; n < a.nnets; ++n) {
         if (bf) add_jobs_bf16(&w, n, lays[n], a.net[n].row0, a.net[n].drow0, slab_off[n], onehot_off[n],
                               stored && a.share_enc && n == 0 ? a.net[1].row0 : a.net[n].row0, h8, d8,
-                              p.tile_stride - NCA_D8_REC_BYTES, nr && d8 ? lays[n].NL - 1 : -1, spl.mask_layers);
+                              p.tile_stride - NCA_D8_REC_BYTES, expand_last ? lays[n].NL - 1 : -1, spl.mask_layers);
         else add_jobs_f32(&w, lays[n], a.net[n].row0, a.net[n].drow0, slab_off[n], onehot_off[n]);
     }
     w.scratch = scratch;

@@ -94,6 +94,8 @@ struct NcaFusedArgs {
     int32_t res_total;   // host only: bytes of all images of the launch laid back to back (build_stages)
     int32_t split;       // bf16 forward, rays mode, one net per launch: 1 = static net (writes sig_s only), 2 = dynamic net (reads
                          // sig_s, writes sig_d and the per-tile ray sums)
+    int32_t expand_last; // mode 5 with bf16 output gradients (the bf16 store): the last hidden layer's block is not written -- one word per
+                         // sample, bf16(g) in both halves, where it would start; the weight-gradient job rebuilds it from the mask bits
     int32_t raw_only;    // rays mode, forward: write the raw net output to raw_out[n] instead of compositing
                          // (rays mode, backward: a non-null g_raw replaces the compositing chain rule)
     NcaNetArgs net[2];

@@ -761,7 +761,7 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
                                         if (!S8) ds[u] = keep_pk(gpk[c], on);
                                     }
                                     Bn[c][2 * m + s2] = dw;
-                                    if (!S8) store_nt(dblk + c * a.d_total + lane * 16 + (2 * m + s2) * 1024, ds);
+                                    if (!S8 && !a.expand_last) store_nt(dblk + c * a.d_total + lane * 16 + (2 * m + s2) * 1024, ds);
                                 }
                             }
                         }
@@ -771,6 +771,10 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
                             // the sample's 32-sample tile would start: u32[32], half lh of the wave writes tile lh
                             const unsigned gb = lh ? gpk[1] : gpk[0];
                             *reinterpret_cast<unsigned*>(dblk + lh * a.d_total + lr * 4) = cvt4_e5m2_pk(gb, gb, inv_s) & 0x00ff00ffu;
+                        } else if (a.expand_last) {
+                            // bf16 output gradients with the last block rebuilt likewise (the bf16 store): bf16(g) in both halves of a word
+                            // per sample, where the block of the sample's 32-sample tile would start (wgrad_job, EXPAND)
+                            *reinterpret_cast<unsigned*>(dblk + lh * a.d_total + lr * 4) = lh ? gpk[1] : gpk[0];
                         }
                     }
 #pragma unroll
@@ -1016,7 +1020,8 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
                         // previous iteration): at most those stores are younger
                         // (S8: the output layer's step stores one word per lane and lane 0's record, not a block)
                         constexpr int NSTM = S8 ? 2 * MT : 4 * MT;
-                        if (S8 && jj == y.NL - 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                        // (the output layer's step may have stored a whole bf16 block -- the depth-gradient path -- or one word per lane: 2 covers both)
+                        if (jj == y.NL - 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
                         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTM) : "memory");
                     }
                     if (!RES) stage_issue_b(a.stage[nsi], smem + (cur ^ 1) * BUF, wave, lane);
@@ -1192,11 +1197,20 @@ struct WgradRing {
 };
 constexpr int NCA_WGRAD_LDS = 36 * 1024;
 
-template <int F, int NTB, bool D8, bool H8>
+// EXPAND (bf16 output gradients, the last hidden layer's job of a backward from the bf16 store): the job's D block relu'(H_{NL-1}) g is
+// NOT read -- per sample it holds one distinct value, bf16(g), at the features whose mask bit is set.  A tile brings the lane's two mask
+// words (8 B of the forward's store) and the sample's word (bf16(g) in both halves; left by the dgrad kernel where the block would
+// start) by three 4-byte LDS-DMAs into the first KiB of its slot and rebuilds the eight fragments as the dgrad kernel formed them
+// (keep_pk on the packed pair): 12 B per sample instead of 2 F.
+template <int F, int NTB, bool D8, bool H8, bool EXPAND = false>
 __device__ __forceinline__ void wgrad_job(const NcaWgradArgs& a, const NcaWgradJob& job, int q, int nsplit, int lane, char* ring) {
     using R = WgradRing<F, NTB, D8, H8>;
-    constexpr int MT = F / 32, ND_ = R::ND, NH_ = R::NH, FR = R::FR, NSLOT = R::NSLOT;
-    static_assert(R::BYTES <= NCA_WGRAD_LDS, "ring does not fit the wave's LDS share");
+    static_assert(!EXPAND || (!D8 && !H8), "the rebuilt block is a bf16 one (e5m2: wgrad_job_mx)");
+    constexpr int MT = F / 32, ND_ = R::ND, NH_ = R::NH;
+    constexpr int FR = EXPAND ? 1 + NH_ : R::FR;                       // 1 KiB pieces of a slot: an expand tile's D part is three 256-byte rows
+    constexpr int NDMA = EXPAND ? 3 + NH_ : R::FR;                     // vector-memory operations per tile
+    constexpr int NSLOT = EXPAND ? (FR <= 8 ? 4 : (FR <= 12 ? 3 : 2)) : R::NSLOT;
+    static_assert(NSLOT * FR * 1024 <= NCA_WGRAD_LDS && (NSLOT - 1) * NDMA <= 63, "ring does not fit the wave's LDS share / counted wait");
     constexpr float HINV = 1.f / (float)(1 << NCA_H8_LOG2);
     const int lc = lane & 31, lh = lane >> 5;
     const int64_t per = (a.ntiles + nsplit - 1) / nsplit;
@@ -1221,37 +1235,69 @@ __device__ __forceinline__ void wgrad_job(const NcaWgradArgs& a, const NcaWgradJ
         const char* dp = base + t * a.rows_total + job.d_row0 + lane * 16;            // rows_total = bytes per 32-sample tile
         const char* bp = base_b + (t + a.tile0_b) * a.rows_total_b + job.b_row0 + lane * 16;
         char* dst = ring + slot * (FR * 1024);
+        constexpr int DP = EXPAND ? 1 : ND_;                               // 1 KiB pieces of the slot's D part
+        if constexpr (EXPAND) {
+            // the lane's two mask words of this 32-sample tile (column tile t & 1 of wave tile t >> 1 of the store) and the sample's word
+            const char* mp = a.mask + ((t + a.tile0_b) >> 1) * a.mask_stride + job.mask_off + lane * 16 + ((t + a.tile0_b) & 1) * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)mp, (__attribute__((address_space(3))) void*)dst, 4, 0, 2);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)mp, (__attribute__((address_space(3))) void*)(dst + 252), 4, 4, 2);   // (LDS dst + 256)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + t * a.rows_total + job.d_row0 + (lane & 31) * 4),
+                                             (__attribute__((address_space(3))) void*)(dst + 512), 4, 0, 2);
+        } else {
 #pragma unroll
-        for (int s = 0; s < ND_; ++s)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dp + s * 1024),
-                                             (__attribute__((address_space(3))) void*)(dst + s * 1024), 16, 0, 2);
+            for (int s = 0; s < ND_; ++s)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dp + s * 1024),
+                                                 (__attribute__((address_space(3))) void*)(dst + s * 1024), 16, 0, 2);
+        }
 #pragma unroll
         for (int s = 0; s < NH_; ++s)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bp + ((H8 || s * 32 + 32 <= brow) ? s : 0) * 1024),
-                                             (__attribute__((address_space(3))) void*)(dst + (ND_ + s) * 1024), 16, 0, 2);
+                                             (__attribute__((address_space(3))) void*)(dst + (DP + s) * 1024), 16, 0, 2);
     };
     auto scale_of = [&](int64_t t) {      // the wave tile's inverse scale sits in the first of its two 32-sample records
         return D8 ? reinterpret_cast<const float*>(base + (t & ~(int64_t)1) * a.rows_total + job.dscale_off)[job.net] : 1.f;
     };
+    // NSLOT tiles are in flight while a tile is contracted: a tile's fragments go to registers FIRST (its slot is then free), the tile
+    // NSLOT ahead is issued into that slot, and only then the transposes and MFMAs run.  (Until round 5 the next tile was issued at the
+    // top of the iteration, into the slot of the tile before: NSLOT - 1 in flight -- with the two 16 KiB slots of a bf16 x bf16 job ONE
+    // tile per wave, 64 KiB per CU: the job ran at what that much in flight pulls at ~2.5 us of loaded latency, 6.1 TB/s, not at what
+    // the memory delivers to reads.)
     const int64_t n = t1 > t0 ? t1 - t0 : 0;
 #pragma unroll
-    for (int p = 0; p < NSLOT - 1; ++p)
+    for (int p = 0; p < NSLOT; ++p)
         if (p < n) issue(t0 + p, p);
     float sc = n > 0 ? scale_of(t0) : 1.f;
     for (int64_t i = 0; i < n; ++i) {
         const float nsc = i + 1 < n ? scale_of(t0 + i + 1) : 1.f;
-        if (i + NSLOT - 1 < n) {
-            issue(t0 + i + NSLOT - 1, (int)((i + NSLOT - 1) % NSLOT));       // into the slot tile i - 1 was read from (its reads have been consumed)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSLOT - 1) * FR) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        // tiles i + 1 .. i + NSLOT - 1 are younger than tile i: in the steady state exactly (NSLOT - 1) NDMA operations may stay outstanding
+        if (i + NSLOT - 1 < n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSLOT - 1) * NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const char* slot = ring + (int)(i % NSLOT) * (FR * 1024) + lane * 16;
+        constexpr int DP = EXPAND ? 1 : ND_;
         u32x4 XD[ND_], XH[NH_];
+        if constexpr (EXPAND) {
+            const char* sm = slot - lane * 12;
+            const unsigned mw[2] = {*reinterpret_cast<const unsigned*>(sm), *reinterpret_cast<const unsigned*>(sm + 256)};
+            const unsigned g2 = *reinterpret_cast<const unsigned*>(sm + 512);
+            // fragment 2m + s2, word u: the packed pair's two mask bits sit 16 apart in the field of row tile m (as the dgrad kernel formed it)
 #pragma unroll
-        for (int s = 0; s < ND_; ++s) XD[s] = *reinterpret_cast<const u32x4*>(slot + s * 1024);
+            for (int m = 0; m < MT; ++m) {
+                const unsigned fld = mw[m >> 1] >> (8 * (m & 1));
 #pragma unroll
-        for (int s = 0; s < NH_; ++s) XH[s] = (H8 || s * 32 + 32 <= brow) ? *reinterpret_cast<const u32x4*>(slot + (ND_ + s) * 1024) : (u32x4){0, 0, 0, 0};
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) XD[2 * m + s2][u] = keep_pk(g2, (fld >> (4 * s2 + u)) & 0x00010001u);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < ND_; ++s) XD[s] = *reinterpret_cast<const u32x4*>(slot + s * 1024);
+        }
+#pragma unroll
+        for (int s = 0; s < NH_; ++s) XH[s] = (H8 || s * 32 + 32 <= brow) ? *reinterpret_cast<const u32x4*>(slot + (DP + s) * 1024) : (u32x4){0, 0, 0, 0};
+        if (i + NSLOT < n) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the slot's reads have returned: it may be overwritten
+            issue(t0 + i + NSLOT, (int)(i % NSLOT));
+        }
         u32x4 TD[MT][2], TH[NTB][2];
         if constexpr (D8) transpose_block8<MT, ND_, true, true>(XD, lc, lh, H8 ? sc * HINV : sc, TD, &bsum);      // (an e4m3 partner's scale rides along)
         else transpose_block<MT>(XD, lc, lh, TD, &bsum);
@@ -1611,6 +1657,7 @@ __global__ __launch_bounds__(64 * NW, 1) void nca_wgrad_bf16(const NcaWgradArgs 
         if (F != 128 && job.is_enc && job.h8) wgrad_job<F, 4, D8, true>(a, job, blockIdx.x, gridDim.x, lane, ring);
         else if (job.h8) wgrad_job<F, F / 32, D8, true>(a, job, blockIdx.x, gridDim.x, lane, ring);
         else if (F != 128 && job.is_enc) wgrad_job<F, 4, D8, false>(a, job, blockIdx.x, gridDim.x, lane, ring);
+        else if (job.expand) { if constexpr (!D8) wgrad_job<F, F / 32, false, false, true>(a, job, blockIdx.x, gridDim.x, lane, ring); }     // (a hidden block: F / 32 column tiles)
         else wgrad_job<F, F == 128 ? 4 : F / 32, D8, false>(a, job, blockIdx.x, gridDim.x, lane, ring);
     }
 }
