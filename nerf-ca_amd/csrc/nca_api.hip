@@ -1036,7 +1036,7 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
         Span sp(NCA_K_BWD_WGRAD, ws);
         return nca_launch_wgrad_bf16(F, w1, p.nx_net[n], ws, waves_per_wg);
     };
-    static const int ovl_nw = getenv("NCA_OVERLAP_NW") && atoi(getenv("NCA_OVERLAP_NW")) == 1 ? 1 : 4;
+    constexpr int ovl_nw = 4;          // (one 256-thread workgroup per CU: a CU holds EITHER kernel whichever is dispatched first)
     int chunk = 0;
     for (int64_t u0 = 0; u0 < units; u0 += p.units_per_chunk, ++chunk) {
         const int64_t nu = (u0 + p.units_per_chunk <= units) ? p.units_per_chunk : units - u0;
@@ -1133,7 +1133,7 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
         if (ovl) {
             // JOIN, then net 1's weight gradient on the whole chip
             if (fk) HIPCHK(hipStreamWaitEvent(st, fk->ev_join, 0));
-            HIPCHK(wgrad_net(1, st, 1));
+            HIPCHK(wgrad_net(1, st, 4));
         } else {
             Span sp(NCA_K_BWD_WGRAD, st);
             if (bf) {
@@ -1144,7 +1144,11 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
                     // kernels sum every column over the rows its job wrote -- NcaReduceArgs::n_split_std -- so nothing has to be
                     // cleared.  A hipMemsetAsync of those rows used to stand here: captured into a HIP graph it left them unwritten
                     // and the replayed step added whatever the memory held to the gradient, tools/determinism_probe.py)
-                    HIPCHK(nca_launch_wgrad_bf16(F, w, p.n_split_x, st));
+                    // the same one-wave (job, split) units as 256-thread workgroups, one per CU instead of four one-wave
+                    // workgroups -- placement is then the same every launch (one-wave workgroups go round the XCDs and land unevenly from
+                    // launch to launch): weight gradient 4.77 +- 0.09 -> 4.68 +- 0.01 ms, step 13.23 -> 13.13 ms over eight alternating runs
+                    // on one box (profiles/r05_ab_wgrad_workgroups.txt); the bits do not change
+                    HIPCHK(nca_launch_wgrad_bf16(F, w, p.n_split_x, st, 4));
                 }
             } else HIPCHK(nca_launch_wgrad_f32(w, p.n_split, st));
         }

@@ -610,9 +610,7 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
                 // do not fit the scalar file) and fetches each with a v_readlane per tile -- a vector issue slot apiece in a kernel that
                 // is bound by those (tools/isa_spills.py); compared per tile they are scalar-ALU instructions and live in no register.
                 int encL = y.L, encT = y.T;
-#ifndef NCA_AB_ENC_HOISTED          // (A/B build of round 5 only: tools/variant_build.sh enchoist "-DNCA_AB_ENC_HOISTED" = the round-4 code)
                 asm volatile("" : "+s"(encL), "+s"(encT));
-#endif
                 if (y.enc_mode == NCA_ENC_FOURIER) {
                     // [sin(2 pi x g_i), cos(2 pi x g_i)] interleaved into slots 2i, 2i+1 (model/CPPN.py:115-118)
 #pragma unroll
@@ -1257,21 +1255,19 @@ __device__ __forceinline__ void wgrad_job(const NcaWgradArgs& a, const NcaWgradJ
     auto scale_of = [&](int64_t t) {      // the wave tile's inverse scale sits in the first of its two 32-sample records
         return D8 ? reinterpret_cast<const float*>(base + (t & ~(int64_t)1) * a.rows_total + job.dscale_off)[job.net] : 1.f;
     };
-    // NSLOT tiles are in flight while a tile is contracted: a tile's fragments go to registers FIRST (its slot is then free), the tile
-    // NSLOT ahead is issued into that slot, and only then the transposes and MFMAs run.  (Until round 5 the next tile was issued at the
-    // top of the iteration, into the slot of the tile before: NSLOT - 1 in flight -- with the two 16 KiB slots of a bf16 x bf16 job ONE
-    // tile per wave, 64 KiB per CU: the job ran at what that much in flight pulls at ~2.5 us of loaded latency, 6.1 TB/s, not at what
-    // the memory delivers to reads.)
     const int64_t n = t1 > t0 ? t1 - t0 : 0;
 #pragma unroll
-    for (int p = 0; p < NSLOT; ++p)
+    for (int p = 0; p < NSLOT - 1; ++p)
         if (p < n) issue(t0 + p, p);
     float sc = n > 0 ? scale_of(t0) : 1.f;
     for (int64_t i = 0; i < n; ++i) {
         const float nsc = i + 1 < n ? scale_of(t0 + i + 1) : 1.f;
-        // tiles i + 1 .. i + NSLOT - 1 are younger than tile i: in the steady state exactly (NSLOT - 1) NDMA operations may stay outstanding
-        if (i + NSLOT - 1 < n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSLOT - 1) * NDMA) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (i + NSLOT - 1 < n) {
+            issue(t0 + i + NSLOT - 1, (int)((i + NSLOT - 1) % NSLOT));       // into the slot tile i - 1 was read from (its reads have been consumed)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSLOT - 1) * NDMA) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         const char* slot = ring + (int)(i % NSLOT) * (FR * 1024) + lane * 16;
         constexpr int DP = EXPAND ? 1 : ND_;
         u32x4 XD[ND_], XH[NH_];
@@ -1294,10 +1290,6 @@ __device__ __forceinline__ void wgrad_job(const NcaWgradArgs& a, const NcaWgradJ
         }
 #pragma unroll
         for (int s = 0; s < NH_; ++s) XH[s] = (H8 || s * 32 + 32 <= brow) ? *reinterpret_cast<const u32x4*>(slot + (DP + s) * 1024) : (u32x4){0, 0, 0, 0};
-        if (i + NSLOT < n) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the slot's reads have returned: it may be overwritten
-            issue(t0 + i + NSLOT, (int)(i % NSLOT));
-        }
         u32x4 TD[MT][2], TH[NTB][2];
         if constexpr (D8) transpose_block8<MT, ND_, true, true>(XD, lc, lh, H8 ? sc * HINV : sc, TD, &bsum);      // (an e4m3 partner's scale rides along)
         else transpose_block<MT>(XD, lc, lh, TD, &bsum);
@@ -1629,7 +1621,7 @@ hipError_t nca_launch_sum_tile_records(const char* dregion, int64_t wave_tile_by
 template <int F, bool D8, int NW = 1>
 __global__ __launch_bounds__(64 * NW, 1) void nca_wgrad_bf16(const NcaWgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char wring[];
-    static_assert(NW == 1 || D8, "several waves per workgroup: the compact (job, split) grid of e5m2 staging");
+    // (NW > 1: the compact 1-D grid of working (job, split) pairs in both cases)
     const int wave = NW > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : 0;
     const int lane = NW > 1 ? (int)threadIdx.x & 63 : (int)threadIdx.x;
     char* ring = wring + wave * NCA_WGRAD_LDS;
@@ -1645,6 +1637,11 @@ __global__ __launch_bounds__(64 * NW, 1) void nca_wgrad_bf16(const NcaWgradArgs 
             qx -= ns;
         }
         if (qx >= ns) return;
+    } else if constexpr (NW > 1) {          // bf16 output gradients: every job runs over nsplit_std splits
+        ns = a.nsplit_std;
+        jy = qx / ns;
+        qx -= jy * ns;
+        if (jy >= a.njobs) return;
     }
     const NcaWgradJob job = a.job[jy];
     // (at F = 128 the 112-slot input block and a hidden block have the same shape: one body serves both)
@@ -1654,11 +1651,11 @@ __global__ __launch_bounds__(64 * NW, 1) void nca_wgrad_bf16(const NcaWgradArgs 
         else if (F != 128 && job.is_enc && job.h8) wgrad_job_mx<F, 4, true>(a, job, qx, ns, lane, ring);
         else wgrad_job_mx<F, F / 32, true>(a, job, qx, ns, lane, ring);         // (e5m2 D blocks come with e4m3 H blocks)
     } else {
-        if (F != 128 && job.is_enc && job.h8) wgrad_job<F, 4, D8, true>(a, job, blockIdx.x, gridDim.x, lane, ring);
-        else if (job.h8) wgrad_job<F, F / 32, D8, true>(a, job, blockIdx.x, gridDim.x, lane, ring);
-        else if (F != 128 && job.is_enc) wgrad_job<F, 4, D8, false>(a, job, blockIdx.x, gridDim.x, lane, ring);
-        else if (job.expand) { if constexpr (!D8) wgrad_job<F, F / 32, false, false, true>(a, job, blockIdx.x, gridDim.x, lane, ring); }     // (a hidden block: F / 32 column tiles)
-        else wgrad_job<F, F == 128 ? 4 : F / 32, D8, false>(a, job, blockIdx.x, gridDim.x, lane, ring);
+        if (F != 128 && job.is_enc && job.h8) wgrad_job<F, 4, D8, true>(a, job, qx, ns, lane, ring);
+        else if (job.h8) wgrad_job<F, F / 32, D8, true>(a, job, qx, ns, lane, ring);
+        else if (F != 128 && job.is_enc) wgrad_job<F, 4, D8, false>(a, job, qx, ns, lane, ring);
+        else if (job.expand) { if constexpr (!D8) wgrad_job<F, F / 32, false, false, true>(a, job, qx, ns, lane, ring); }     // (a hidden block: F / 32 column tiles)
+        else wgrad_job<F, F == 128 ? 4 : F / 32, D8, false>(a, job, qx, ns, lane, ring);
     }
 }
 
@@ -1733,25 +1730,31 @@ hipError_t nca_launch_wgrad_bf16(int F, const NcaWgradArgs& a, int nsplit, hipSt
     for (int j = 0; j < a.njobs; ++j)
         if ((a.job[j].d8 != 0) != d8 || (d8 && !a.job[j].h8)) return hipErrorInvalidValue;
     if (d8 && (a.ntiles & 1)) return hipErrorInvalidValue;        // whole wave tiles (two 32-sample tiles share a scale and an MFMA)
-    if (waves_per_wg != 1 && !(waves_per_wg == 4 && d8)) return hipErrorInvalidValue;
+    if (waves_per_wg != 1 && waves_per_wg != 4) return hipErrorInvalidValue;
     dim3 grid(nsplit, a.njobs), block(64);
     if (d8) {          // one wave per working (job, split) pair
         if (a.nsplit_std <= 0 || a.nsplit_x < a.nsplit_std) return hipErrorInvalidValue;
         int total = 0;
         for (int j = 0; j < a.njobs; ++j) total += a.job[j].expand ? a.nsplit_x : a.nsplit_std;
         grid = dim3((total + waves_per_wg - 1) / waves_per_wg, 1);
+    } else if (waves_per_wg == 4) {
+        if (a.nsplit_std != nsplit) return hipErrorInvalidValue;
+        grid = dim3((nsplit * a.njobs + 3) / 4, 1);
     }
     constexpr int L = NCA_WGRAD_LDS;          // the wave's ring of tile slots: four waves (four one-wave workgroups, or one workgroup of four) share a CU's 160 KiB
     if (waves_per_wg == 4) {
+#define NCA_WG4(FF, DD)                                                                                                                            \
+    do {                                                                                                                                           \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_wgrad_bf16<FF, DD, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * L); \
+        hipLaunchKernelGGL((nca_wgrad_bf16<FF, DD, 4>), grid, dim3(256), 4 * L, st, a);                                                            \
+    } while (0)
         switch (F) {
-            case 32: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_wgrad_bf16<32, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * L);
-                     hipLaunchKernelGGL((nca_wgrad_bf16<32, true, 4>), grid, dim3(256), 4 * L, st, a); break;
-            case 64: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_wgrad_bf16<64, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * L);
-                     hipLaunchKernelGGL((nca_wgrad_bf16<64, true, 4>), grid, dim3(256), 4 * L, st, a); break;
-            case 128: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_wgrad_bf16<128, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * L);
-                      hipLaunchKernelGGL((nca_wgrad_bf16<128, true, 4>), grid, dim3(256), 4 * L, st, a); break;
+            case 32: if (d8) NCA_WG4(32, true); else NCA_WG4(32, false); break;
+            case 64: if (d8) NCA_WG4(64, true); else NCA_WG4(64, false); break;
+            case 128: if (d8) NCA_WG4(128, true); else NCA_WG4(128, false); break;
             default: return hipErrorInvalidValue;
         }
+#undef NCA_WG4
         return hipGetLastError();
     }
     switch (F) {

@@ -1,12 +1,12 @@
 #!/bin/bash
 # Run ON the GPU box: the graph-replayed bench step under NCA_OPT_OVERLAP_CUS = each value given (0 = the plain plan: one
 # weight-gradient launch for both nets after both dgrad launches), one line per value.
-#   bash tools/overlap_sweep.sh [steps=30] 0 64 96 128 ...      (a value "96w1" = 96 compute units with one-wave workgroups)
+#   bash tools/overlap_sweep.sh [steps=30] 0 64 96 128 ...
 STEPS=${1:-30}; shift
 mkdir -p gpurun_out
 for V in "$@"; do
-  CUS=${V%w1}; NW=4; [ "$V" != "$CUS" ] && NW=1
-  NCA_OVERLAP_CUS=$CUS NCA_OVERLAP_NW=$NW timeout -k 10 300 python3 bench.py --steps $STEPS --warmup 5 --no-extras --no-cpu-baseline > gpurun_out/ovl_$V.json 2> gpurun_out/ovl_$V.err
+  CUS=$V
+  NCA_OVERLAP_CUS=$CUS timeout -k 10 300 python3 bench.py --steps $STEPS --warmup 5 --no-extras --no-cpu-baseline > gpurun_out/ovl_$V.json 2> gpurun_out/ovl_$V.err
   rc=$?
   [ $rc -ge 124 ] && { echo "$V: killed ($rc)"; exit $rc; }
   python3 - "$V" <<'PY'
