@@ -54,6 +54,9 @@ PEAK_HBM_GBPS = 8000.0
 # from 16 B of mask bits and 4 B: 2 nets x (4 x 256 + 128 + 20) B.  303 104 FLOP over those bytes = 129 FLOP/B, below the ridge
 # of 2500 TFLOP/s / 8 TB/s = 312 FLOP/B: that kernel's roofline is the HBM one.
 WGRAD_FP8_BYTES_PER_SAMPLE = 2 * (4 * 256 + 128 + 20)
+# ... and out of the bf16 store (nothing in 8 bits): per sample and net four bf16 block pairs (2 x 256 B each), the 224-byte bf16 input block
+# and, for the last hidden layer's rebuilt block, 16 B of mask bits + 4 B: 2 nets x (4 x 512 + 224 + 20) -- 66 FLOP/B, far below the ridge
+WGRAD_BF16_BYTES_PER_SAMPLE = 2 * (4 * 512 + 224 + 20)
 PEAK_F32_ON_BF16_PIPE = 2500.0 / 6.0
 PROFILE_TAGS = ("r05", "r04", "r03", "r02", "r01")          # committed PMC summaries, newest first
 FLOP_STEP = FLOP_FWD + FLOP_DGRAD + FLOP_WGRAD            # 870 912 FLOP per sample of a training step
@@ -309,9 +312,10 @@ def roofline_of(args, prec, kern, eager_dt, plan, ms_per_step, world=1):
         roof["frac_of_f32_mfma_peak"] = kern[dom]["tflops"] / PEAK_TFLOPS["f32"] if kern[dom]["tflops"] else None
         roof["peak_note"] = "2 500 / 6 TFLOP/s: the hidden layers run as six bf16 products per f32 product on the bf16 matrix cores (exact 3-way split)"
     wg = kern["bwd_wgrad"]
-    if prec == "bf16" and fp8 and wg["avg_ms"]:
-        # the weight-gradient kernel's own roofline is the HBM one (see WGRAD_FP8_BYTES_PER_SAMPLE)
-        nbytes = WGRAD_FP8_BYTES_PER_SAMPLE * n_step
+    bf16_store = prec == "bf16" and not fp8 and (plan.get("fwd_store_format", 0) & 15) == 4
+    if prec == "bf16" and (fp8 or bf16_store) and wg["avg_ms"]:
+        # the weight-gradient kernel's own roofline is the HBM one (see WGRAD_FP8_BYTES_PER_SAMPLE / WGRAD_BF16_BYTES_PER_SAMPLE)
+        nbytes = (WGRAD_FP8_BYTES_PER_SAMPLE if fp8 else WGRAD_BF16_BYTES_PER_SAMPLE) * n_step
         gbps = nbytes / (wg["avg_ms"] * 1e-3) / 1e9
         hbm = {"bound": "hbm", "kernel": "bwd_wgrad", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
                "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": wg["avg_ms"],
@@ -327,7 +331,7 @@ def roofline_of(args, prec, kern, eager_dt, plan, ms_per_step, world=1):
                               "avg_launch_ms": kern[k]["avg_ms"], "ms_per_step": kern[k]["ms_per_step"],
                               "traffic": traffic_rec["kernels"][k]["hbm_bytes_per_launch"] if traffic_rec and k in traffic_rec.get("kernels", {}) else None}
                           for k in ("fwd", "bwd_dgrad", "bwd_wgrad")}
-    if prec == "bf16" and fp8 and wg["avg_ms"]:
+    if prec == "bf16" and (fp8 or bf16_store) and wg["avg_ms"]:
         roof["per_kernel"]["bwd_wgrad"].update({"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
                                                 "mfma_frac": wg["tflops"] / peak})
     return roof
@@ -665,7 +669,7 @@ def main():
     main_rec = measure(args, args.prec, None, data, dev, rank, world, use_pg, args.steps, args.warmup,
                        sustained_steps=args.sustained_steps if (world == 1 and not args.no_extras) else 0)
     other_rec = None
-    if world > 1 and not args.no_extras:
+    if (world > 1 or os.environ.get("NERFCA_FORCE_PG") == "1") and not args.no_extras:          # (the env switch: the multi-rank legs on a one-GPU box)
         # the other scaling mode in the same run, every rank taking part: strong = one global batch of --rays split N ways, weak = --rays per rank
         other = "weak" if args.scaling == "strong" else "strong"
         g_rays = args.rays * world if other == "weak" else args.rays
@@ -709,7 +713,7 @@ def main():
                 # the headline (whose `dtype` says "bf16+fp8stage": PSNR-gated, but 8-bit on its way to the weight-gradient kernel)
                 out["baseline_config_dtype"] = {"dtype": "bf16", "config": "BASELINE.json configs[1] as written (run_composite XCAT 4-view, 256^2 x 192 samples, bf16, 1 x MI355X)",
                                                 "value": bp["value"], "unit": "rays/s", "ms_per_step": bp["ms_per_step"], "steps": bp["steps"], "plan": bp["plan"],
-                                                "roofline": {k: bp["roofline"].get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "avg_launch_ms")},
+                                                "roofline": {k: bp["roofline"].get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "algorithmic_bytes_per_launch", "mfma", "traffic", "traffic_source", "avg_launch_ms")},
                                                 "roofline_step": bp["roofline"]["step"], "per_kernel": bp["roofline"]["per_kernel"], "record": "bf16_pure"}
             if args.prec != "f32" and args.f32_steps > 0:
                 out["f32"] = measure(args, "f32", None, data, dev, 0, 1, False, args.f32_steps, args.f32_warmup)
