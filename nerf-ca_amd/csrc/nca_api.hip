@@ -218,7 +218,7 @@ extern "C" int nca_get_option(int32_t opt, int64_t* value) {
 static int check_option_value(int32_t opt, int64_t value) {
     if (opt < 0 || opt >= NCA_OPT_COUNT || opt == NCA_OPT_RESERVED0) return fail(NCA_E_INVALID, "option %d out of range", opt);
     if (opt == NCA_OPT_RESIDENT_MIN_TILES && value < -1) return fail(NCA_E_INVALID, "NCA_OPT_RESIDENT_MIN_TILES takes -1 (never), 0 (always) or a tile count");
-    if (opt == NCA_OPT_STAGE_FP8 && value != 0 && value != 1 && value != -1) return fail(NCA_E_INVALID, "NCA_OPT_STAGE_FP8 takes 0 (no forward store), 1 (always) or -1 (by batch size)");
+    if (opt == NCA_OPT_STAGE_FP8 && value != 0 && value != 1 && value != -1) return fail(NCA_E_INVALID, "NCA_OPT_STAGE_FP8 takes 0 (nothing staged in 8 bits), 1 (always) or -1 (by batch size)");
     if (opt == NCA_OPT_STAGE_FP8_MIN_TILES && value < 0) return fail(NCA_E_INVALID, "NCA_OPT_STAGE_FP8_MIN_TILES takes a tile count >= 0");
     if (opt == NCA_OPT_WGRAD_REBUILD_WEIGHT_PCT && (value < 100 || value > 200)) return fail(NCA_E_INVALID, "NCA_OPT_WGRAD_REBUILD_WEIGHT_PCT takes 100 .. 200");
     if (opt == NCA_OPT_OVERLAP_CUS && (value < 0 || value > 4096)) return fail(NCA_E_INVALID, "NCA_OPT_OVERLAP_CUS takes 0 (off) or a number of compute units");
