@@ -91,6 +91,8 @@ def parse(argv=None):
     ap.add_argument("--psnr-steps", type=int, default=100, help="steps of the PSNR record (64^2 detector, 256 rays/step; 0: skip)")
     ap.add_argument("--configs3-steps", type=int, default=3, help="timed steps of the BASELINE configs[3] sub-record (MAGIX geometry, 8 sequences x 10 phases of 512^2, "
                     "256 samples per ray, f32, one full detector = 262 144 rays per step; 0: skip)")
+    ap.add_argument("--latency-steps", type=int, default=200, help="timed steps of the latency-regime sub-record (the reference's default batch: 1 024 rays x 500 "
+                    "samples per step, train/composite.txt:25,40; bf16 and f32, graph-replayed; 0: skip)")
     ap.add_argument("--dry-run", action="store_true", help="rendezvous bookkeeping only: without RANK in the environment print the launch this process would "
                     "make (and make it, so that every rank reports); as a rank print {rank, world, local_rank, device index} and exit BEFORE anything touches the GPU")
     ap.add_argument("--views", type=int, default=4)
@@ -539,6 +541,25 @@ def configs3_record(args, dev):
     return out
 
 
+def latency_record(args, dev):
+    """BASELINE.md 3.3's second batch size: the reference's DEFAULT batch, 1 024 rays x 500 samples per step (train/composite.txt:25,40) --
+    0.45 TFLOP per step, where launch count and per-step fixed work matter as much as the kernels.  Graph-replayed step, bf16 (the
+    planner's default: 8-bit staged store, streaming kernels below the resident threshold) and f32."""
+    import argparse
+    from nerfca_amd import synthetic
+    a = argparse.Namespace(**vars(args))
+    a.rays, a.samples, a.scaling = 1024, 500, "strong"
+    data = synthetic.make_dataset(a.det, a.samples, dev, views=synthetic.TRAIN_VIEWS)
+    out = {"workload": "run_composite defaults: 1 024 rays x 500 samples per step (train/composite.txt:25,40), 256^2 detector, 4 views x 10 phases, fwd+losses+bwd+Adam, graph-replayed",
+           "rays_per_step": a.rays, "samples_per_ray": a.samples, "steps": args.latency_steps}
+    for prec in ("bf16", "f32"):
+        ms = quick_step_ms(a, prec, data, dev, 0, 1, False, a.rays, steps=args.latency_steps, warmup=20)
+        out[prec] = {"ms_per_step": ms, "rays_per_s": a.rays / (ms * 1e-3), "step_tflops": FLOP_STEP * a.rays * a.samples / (ms * 1e-3) / 1e12}
+    del data
+    torch.cuda.empty_cache()
+    return out
+
+
 def psnr_record(args, dev):
     """Held-out-view PSNR after `--psnr-steps` steps from identical initial weights, ray batches and depth jitter: HIP f32,
     HIP bf16 and the CPU oracle (reference-equivalent torch ops).  64^2 detector x --samples, 256 rays per step: a size the
@@ -724,6 +745,8 @@ def main():
                 out["psnr"] = psnr_record(args, dev)
             if args.configs3_steps > 0 and args.prec == "bf16":
                 out["configs3"] = configs3_record(args, dev)
+            if args.latency_steps > 0 and args.prec == "bf16":
+                out["latency_regime"] = latency_record(args, dev)
         print(json.dumps(out))
     if use_pg:
         torch.distributed.destroy_process_group()

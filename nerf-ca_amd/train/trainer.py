@@ -678,10 +678,11 @@ class CompositeTrainer:
         if getattr(self, "_graphs", None) is None:
             self._graph_setup()
         lo, hi = self._slice
-        self._ids_buf.copy_(self.draw_ray_ids_device(n_iter)[lo:hi])
+        self._ids_buf.copy_(self._ids_for(n_iter)[lo:hi])
         if self.n_fine > 0:
             self._u_buf.copy_(self.draw_fine_u(n_iter)[lo:hi], non_blocking=False)       # sample_pdf's uniform draws of this step
         self._write_record(n_iter)
+        self._prefetch_ids(n_iter + 1)          # (before the replay: the dozen small kernels of the draw run beside the graph's first kernels)
         self._graphs[0].replay()
         if len(self._graphs) > 1:
             if self.world > 1 or self.always_allreduce:
@@ -693,6 +694,31 @@ class CompositeTrainer:
         # the last two floats of the flat buffer: [dynamic entropy, favor], summed over the ranks by the gradient all-reduce
         self._note_early_stop(n_iter, self._graph_out["flat"][-2:] if n_iter >= self.cfg.static_pos_enc_window_decay_steps else None)
         return terms[0], terms[1], terms
+
+    def _prefetch_ids(self, n_iter: int) -> None:
+        """Draw the ray ids of iteration ``n_iter`` on a side stream.  The importance sampling of run_composite.py:250-260 is a dozen small
+        launches (two index draws, a concatenation, a random permutation = a radix sort, gathers) that depend on nothing of the step
+        before: drawn between two graph replays on the replay's stream they are ~75 us of nothing else happening -- 10 % of a step at the
+        reference's default batch of 1 024 rays, 0.5 % at 65 536 (profiles/r05_small_batch_trace.txt).  ``_ids_for`` hands the
+        prefetched vector out if the caller does ask for that iteration next (same generator, same seed: the same ids either way)."""
+        if getattr(self, "_ids_stream", None) is None:
+            self._ids_stream = torch.cuda.Stream(device=self.device)
+            self._ids_stream.wait_stream(torch.cuda.current_stream())       # (once: the id tables were created on the caller's stream)
+        with torch.cuda.stream(self._ids_stream):
+            ids = self.draw_ray_ids_device(n_iter)
+            ev = torch.cuda.Event()
+            ev.record()
+        self._ids_prefetch = (n_iter, ids, ev)
+
+    def _ids_for(self, n_iter: int) -> torch.Tensor:
+        pf, self._ids_prefetch = getattr(self, "_ids_prefetch", None), None
+        if pf is not None and pf[0] == n_iter:
+            _, ids, ev = pf
+            cur = torch.cuda.current_stream()
+            cur.wait_event(ev)
+            ids.record_stream(cur)          # (allocated on the side stream, consumed here)
+            return ids
+        return self.draw_ray_ids_device(n_iter)
 
     def allreduce_grads(self, extra=None):
         """ONE all-reduce(SUM) over a flat f32 buffer of every gradient (152 914 floats by default); ``extra`` (a small f32
