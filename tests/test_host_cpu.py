@@ -523,3 +523,21 @@ def test_plan_scope_is_a_per_thread_stack():
     assert fused.PlanScope.current() is None
     assert seen == {"none": None, "mine": True, "after": None}
     assert set(outer.decided()) >= {"fwd_store_format", "bwd_kernel_mode", "stage_fp8", "wave_tiles"} and all(v == 0 for v in outer.decided().values())
+
+
+def test_psnr_control_cache_is_current():
+    """tests/golden/psnr_f32_controls.json (the cached f32 control runs of tests/test_psnr_gates.py) was taken on THESE f32 kernel sources and
+    holds every entry the gates ask for: an edit of the f32 / loss kernels that forgets to re-take the controls (tools/psnr_run.py on the GPU
+    box, then tools/psnr_cache.py) fails here, in the CPU suite, instead of silently turning the GPU gates into live f32 runs."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("psnr_cache", os.path.join(ROOT, "tools", "psnr_cache.py"))
+    pc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pc)
+    d = json.load(open(pc.OUT))
+    assert d["f32_sources_sha"] == pc.f32_sources_sha(), "re-take the f32 controls: the f32 / loss kernel sources changed"
+    for sd in range(5):
+        for v in ("f32", "f32_kick2e-3", "f32_bf16init"):
+            e = d["entries"][pc.key(65536, 192, 1000, v, sd)]
+            assert 60.0 < e["psnr_mse_db"] < 90.0 and 50.0 < e["test_psnr_reference_def_db"] < 90.0, (v, sd, e)
+        assert pc.key(1024, 500, 5000, "f32", sd) in d["entries"]
