@@ -4,8 +4,8 @@ The reference's PART functions (compute_ratio, compute_blendw_loss, compute_sigm
 operations on any device -- its API exports them by name (``from model_helpers import *``) and run_nerf.py's static loop calls
 ``compute_occl_loss`` on its own.  The two functions the composite script calls every step, ``compute_losses`` and
 ``weighted_MSELoss``, are HIP-backed in train/model_helpers.py (fused.loss_terms / fused.weighted_sq_err over nca_loss_fwd_bwd);
-``all_terms`` / ``WeightedSquaredError`` below are their torch restatements from the parts, kept for the CPU tests of the
-data-parallel bookkeeping (tests/injected_trainer.py) -- no product path calls them.
+their torch restatements from the parts live with the CPU tests of the data-parallel bookkeeping (tests/injected_trainer.py:
+``all_terms`` / ``weighted_sq_err``) -- nothing in this package assembles the 11-tuple in torch.
 """
 from __future__ import annotations
 
@@ -52,23 +52,3 @@ def occlusion(sigma, dists, reg_perc=0.1, use_back=False):
     back = run > (1 - reg_perc) * run[-1] if use_back else torch.ones_like(front)
     m = (front | back).to(sigma.dtype if sigma.dtype == dists.dtype else dists.dtype)
     return (sigma * dists * m).sum(dim=-1).mean()
-
-
-def all_terms(static_sigma, temp_sigma, dists, weighted_pixs, run_args):
-    """compute_losses, model_helpers.py:250-262: the reference's 11-tuple."""
-    bw, top_s, top_d = blend_weight(static_sigma, temp_sigma)
-    favor = binary_entropy_of_blend(bw, skewness=run_args.skewness_val)
-    s_ent, s_sum = ray_entropy(static_sigma, dists, mask_threshold=run_args.entro_mask_thre)
-    d_ent, d_sum = ray_entropy(temp_sigma, dists, mask_threshold=run_args.entro_mask_thre,
-                               use_weighting=run_args.entro_use_weighting, weighted_pixs=weighted_pixs,
-                               weighted_thresh=run_args.entro_weighted_thresh)
-    occl = occlusion(temp_sigma, dists, run_args.occl_reg_perc)
-    mass = static_sigma * dists
-    return bw.mean(), top_s, top_d, favor, s_ent, s_sum, d_ent, d_sum, occl, mass.sum(), (mass ** 2).sum()
-
-
-class WeightedSquaredError(torch.nn.Module):
-    """weighted_MSELoss, model_helpers.py:284-288 (the caller takes .mean())."""
-
-    def forward(self, preds, gts, weights):
-        return (preds - gts) ** 2 * weights

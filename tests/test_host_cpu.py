@@ -185,11 +185,11 @@ def test_randomize_depth_matches_reference_draw(golden):
 # ----------------------------------------------------------------------------- losses / render helpers
 @pytest.mark.parametrize("dtn", ["f64", "f32"])
 def test_losses_match_reference(golden, dtn):
-    """The torch restatement of the loss functions (nerfca_amd/losses.py: the part functions the API exports, and all_terms /
-    WeightedSquaredError built from them for the CPU tests of the data-parallel bookkeeping) against the reference's goldens.  The
+    """The torch restatement of the loss functions (nerfca_amd/losses.py: the part functions the API exports; tests/injected_trainer.py:
+    all_terms / weighted_sq_err built from them for the CPU tests of the data-parallel bookkeeping) against the reference's goldens.  The
     drop-in compute_losses / weighted_MSELoss are HIP-backed: tests/test_hip_parity.py::test_dropin_compute_losses_is_the_hip_kernel."""
     from types import SimpleNamespace
-    from nerfca_amd import losses as LS
+    import injected_trainer as IT
     from nerfca_amd._capi import NcaError
     from nerfca_amd.train import model_helpers as MH
     g = golden("losses")
@@ -201,13 +201,13 @@ def test_losses_match_reference(golden, dtn):
         MH.compute_losses(a, b, g[f"{dtn}_dists"], g[f"{dtn}_wpix"], args)
     with pytest.raises(NcaError, match="GPU"):
         MH.weighted_MSELoss()(g[f"{dtn}_mse_pred"], g[f"{dtn}_mse_gt"], g[f"{dtn}_wpix"])
-    res = LS.all_terms(a, b, g[f"{dtn}_dists"], g[f"{dtn}_wpix"], args)
+    res = IT.all_terms(a, b, g[f"{dtn}_dists"], g[f"{dtn}_wpix"], args)
     names = ["blendw", "sig_s_max", "sig_d_max", "favor", "s_ent", "s_sum", "d_ent", "d_sum", "occl", "l1", "l2"]
     for n, v in zip(names, res):
         assert rel_err(v, g[f"{dtn}_{n}"]) < 1e-6, n
     (0.7 * res[3] + 1.3 * res[4] + 0.9 * res[6] + 0.5 * res[8] + 0.25 * res[9] + 2.0 * res[10]).backward()
     assert rel_err(a.grad, g[f"{dtn}_g_sig_s"]) < 1e-6 and rel_err(b.grad, g[f"{dtn}_g_sig_d"]) < 1e-6
-    assert torch.equal(LS.WeightedSquaredError()(g[f"{dtn}_mse_pred"], g[f"{dtn}_mse_gt"], g[f"{dtn}_wpix"]), g[f"{dtn}_mse"])
+    assert torch.equal(IT.weighted_sq_err(g[f"{dtn}_mse_pred"], g[f"{dtn}_mse_gt"], g[f"{dtn}_wpix"]), g[f"{dtn}_mse"])
     assert rel_err(MH.compute_occl_loss(b, g[f"{dtn}_dists"], 0.2, use_back=True), g[f"{dtn}_occl_back"]) < 1e-6
 
 
