@@ -505,6 +505,62 @@ def test_dropin_compute_losses_is_the_hip_kernel(golden, dev, dtn):
 
 
 @pytest.mark.parametrize("skew,use_w,mask_thre,w_thresh", [(2.0, True, 1e-4, 0.03), (0.5, False, 1e-4, 0.03), (1.0, True, 5e-2, 0.25), (3.0, False, 1.0, 0.0)])
+def test_dropin_compute_losses_non_default_flags(golden, dev, skew, use_w, mask_thre, w_thresh):
+    """The drop-in compute_losses at the flags composite.txt leaves at their defaults (skewness_val, entro_use_weighting /
+    entro_weighted_thresh, entro_mask_thre), every differentiable term weighted: values and gradients against autograd through the
+    oracle's restatement (f64 oracle; the f32 oracle's own distance from it sets the tolerance where ReLU-free but cancellation-heavy
+    terms make it larger than 1e-5); an EMPTY weighted_pixs (the reference's default argument) switches the weighting off."""
+    from types import SimpleNamespace
+    from nerfca_amd.train import model_helpers as MH
+    g = golden("losses")
+    args = SimpleNamespace(favor_s_opt=None, skewness_val=skew, entro_mask_thre=mask_thre, entro_use_weighting=use_w,
+                           entro_weighted_thresh=w_thresh, occl_reg_perc=0.2)
+    largs = O.LossArgs(skewness_val=skew, entro_mask_thre=mask_thre, entro_use_weighting=use_w, entro_weighted_thresh=w_thresh)
+    a0, b0, dists, wpix = g["f32_sig_s"], g["f32_sig_d"], g["f32_dists"], g["f32_wpix"]
+    weights = (0.3, 0, 0, 0.7, 1.3, 0.4, 0.9, 0.6, 0.5, 0.25, 2.0)
+
+    def oracle(dt):
+        ao, bo = a0.to(dt).clone().requires_grad_(True), b0.to(dt).clone().requires_grad_(True)
+        t = O.compute_losses(ao, bo, dists.to(dt), wpix, largs)
+        sum(w * r for w, r in zip(weights, t) if w).backward()
+        return t, ao.grad.double(), bo.grad.double()
+
+    t32, gs32, gd32 = oracle(torch.float32)
+    t64, gs64, gd64 = oracle(torch.float64)
+    a, b = a0.to(dev).requires_grad_(True), b0.to(dev).requires_grad_(True)
+    res = MH.compute_losses(a, b, dists.to(dev), wpix.to(dev), args)
+    sum(w * r for w, r in zip(weights, res) if w).backward()
+    for i, (r, r64, r32) in enumerate(zip(res, t64, t32)):
+        v, v64, v32 = float(r.detach()), float(r64.detach()), float(r32.detach())
+        assert abs(v - v64) <= max(2e-6 * abs(v64), 3 * abs(v32 - v64)) + 1e-12, (i, v, v64, v32)
+    assert rel_err(a.grad.cpu().double(), gs64) < max(TOL, 3 * rel_err(gs32, gs64)) and rel_err(b.grad.cpu().double(), gd64) < max(TOL, 3 * rel_err(gd32, gd64))
+    if use_w:        # no pixel weights given: the masks come from the ray sums alone (compute_sigma_s_ray_loss's default argument)
+        res0 = MH.compute_losses(a0.to(dev), b0.to(dev), dists.to(dev), (), args)
+        ref0 = O.compute_losses(a0, b0, dists, wpix, O.LossArgs(skewness_val=skew, entro_mask_thre=mask_thre, entro_use_weighting=False, entro_weighted_thresh=w_thresh))
+        for r, rr in zip(res0, ref0):
+            assert abs(float(r) - float(rr)) <= 2e-6 * abs(float(rr)) + 1e-12
+
+
+def test_dropin_weighted_mse_dtypes(dev):
+    """weighted_MSELoss on mixed dtypes (f64 predictions from an f64 ray table, f32 targets / weights): the result and the gradients take
+    torch's promoted dtype and values; weights that require a gradient get theirs."""
+    from nerfca_amd.train import model_helpers as MH
+    gen = torch.Generator().manual_seed(3)
+    p64 = torch.randn(257, generator=gen, dtype=torch.float64)
+    gt32, w32 = torch.randn(257, generator=gen), torch.rand(257, generator=gen) + 1.0
+    for p, gt, w in ((p64, gt32, w32), (p64.float(), gt32, w32), (p64, gt32.double(), w32.double())):
+        pd, wd = p.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+        out = MH.weighted_MSELoss()(pd, gt.to(dev), wd)
+        po, wo = p.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        ref = (po - gt) ** 2 * wo
+        assert out.dtype == ref.dtype and rel_err(out.detach().cpu(), ref.detach()) < 1e-6
+        out.mean().backward()
+        ref.mean().backward()
+        assert pd.grad.dtype == p.dtype and rel_err(pd.grad.cpu(), po.grad) < 1e-6
+        assert wd.grad.dtype == w.dtype and rel_err(wd.grad.cpu(), wo.grad) < 1e-6
+
+
+@pytest.mark.parametrize("skew,use_w,mask_thre,w_thresh", [(2.0, True, 1e-4, 0.03), (0.5, False, 1e-4, 0.03), (1.0, True, 5e-2, 0.25), (3.0, False, 1.0, 0.0)])
 def test_fused_loss_kernel_non_default_flags(golden, dev, skew, use_w, mask_thre, w_thresh):
     """The flags of compute_losses that composite.txt leaves at their defaults (train/model_helpers.py:250-262: skewness_val of the
     blend-weight entropy, entro_use_weighting / entro_weighted_thresh and entro_mask_thre of the ray entropies) at other values:
