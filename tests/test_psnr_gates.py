@@ -142,6 +142,28 @@ def test_bf16_psnr_gate_at_bench_configuration_per_seed(dev, psnr_run, cache, be
             assert nearest < BRANCH_DB, ("branch", seed, k, row)
 
 
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("seed", BENCH_SEEDS)
+def test_bf16_as_written_psnr_gate_per_seed(dev, psnr_run, cache, bench_data, seed):
+    """The same per-seed gate for BASELINE configs[1] "bf16" as written (`stage_fp8 = 0`: bf16 operands in every contraction, the bf16
+    store, nothing in 8 bits).  On record (profiles/r05_psnr_bf16_store.jsonl): +0.011 / -0.015 dB on the STRICT seeds 2 and 4, -0.088 /
+    -1.576 / -0.034 dB on seeds 0 / 1 / 3 (seed 1 on the controls' branch to the digit, seed 3 on the unperturbed run's)."""
+    args = bench_args()
+    bf = psnr_run.run("bf16_store", args, dev, bench_data, seed=seed)
+    assert bf["stage_fp8_in_effect"] is False
+    f32 = end_point(psnr_run, cache, args, dev, bench_data, "f32", seed)
+    ctl = {v: end_point(psnr_run, cache, args, dev, bench_data, v, seed) for v in CONTROLS}
+    gap = {k: bf["curve"][-1][k] - f32[k] for k in KEYS}
+    moves = {v: {k: ctl[v][k] - f32[k] for k in KEYS} for v in CONTROLS}
+    stable = all(abs(moves[v][k]) <= STABLE_DB for v in CONTROLS for k in KEYS)
+    print(f"[65 536 x 192, bf16 as written] seed {seed} ({'STRICT' if stable else 'BRANCH'}): bf16 - f32 = " + " / ".join(f"{gap[k]:+.3f}" for k in KEYS) + " dB", flush=True)
+    for k in KEYS:
+        if stable:
+            assert abs(gap[k]) < STRICT_DB, ("strict", seed, k, gap)
+        else:
+            assert min([abs(gap[k])] + [abs(gap[k] - moves[v][k]) for v in CONTROLS]) < BRANCH_DB, ("branch", seed, k, gap, moves)
+
+
 def test_bench_configuration_gate_summary():
     """Every seed ran; the seeds that are stable on record were gated STRICT; the ensemble mean of the bf16 gaps lies inside the kick
     control's own mean +- standard deviation, and above -0.6 dB."""
