@@ -315,7 +315,11 @@ class CompositeTrainer:
             if getattr(self, "_phases64", None) is None:
                 self._phases64 = pt.to(torch.int64)
             pt = self._phases64
-        return prepare_batch(my.to(torch.int64).contiguous(), rt, pt, self.depth, t_rand, bad_ids=self._bad_ids)
+        out = prepare_batch(my.to(torch.int64).contiguous(), rt, pt, self.depth, t_rand, bad_ids=self._bad_ids)
+        import os
+        if os.environ.get("NERFCA_STRICT") == "1" and not torch.cuda.is_current_stream_capturing():
+            self.check_ray_ids()            # (host-launched steps under NERFCA_STRICT: an id outside the table raises at once, as NumPy's IndexError does in the reference)
+        return out
 
     def fused_gradients(self, n_iter: int):
         """What ``loss.backward()`` yields in the reference (run_composite.py:283-306) for this rank's slice of step ``n_iter``'s
