@@ -16,18 +16,19 @@ all-reduce of the flat gradient (BASELINE configs[2]); the same run also times t
 reports it beside the headline.  The N = 1 line carries `predicted_scaling`: the measured single-GPU step at rays / N for N = 2, 4, 8
 with the step's collective in place (a one-rank RCCL group: two graph segments with the all-reduce between them).
 
-Rank 0 prints ONE JSON line.  `dtype` names the arithmetic of the timed step as the library's planner ran it:
-"bf16+fp8stage" = bf16 MLP contractions whose layer inputs / output gradients cross HBM as e4m3 / e5m2 on their way to the
-weight-gradient kernel (which contracts them on the MX-fp8 matrix path), "bf16" = the same with bf16 staging, "f32" = the 1e-5
-parity mode.  `roofline` is for the kernel with the largest share of the step, measured with HIP events on the launch stream
-inside the library (nca_timing_*) over an eager pass of the same step (events cannot be recorded inside a replayed graph: the
-table decomposes `eager_ms_per_step`, which it sums to at most); `cpu_baseline` is the CPU oracle (reference-equivalent torch CPU
-ops) on a bounded sample.  At N = 1 the line also carries the other two precisions side by side, each through the same
-graph-replayed step with its own kernel table and roofline -- `bf16_pure` (stage_fp8 = 0: BASELINE configs[1] as written -- bf16
-operands everywhere, no 8-bit staged store, the backward recomputes the layers) and `f32` (>= 20 steps after 5 warm-up) --, `sustained` (ms per step over the last 100 of --sustained-steps further graph
-steps: the chip lowers its clock as it heats), `unfused_gpu_baseline` (the reference-equivalent torch ops run op by op on the
-same GPU: the denominator of the north star's >= 10x) and `psnr` (held-out PSNR of HIP f32, HIP bf16 and the CPU oracle after
-equal steps from identical weights and batches; train/run_composite.py:391 defines test_psnr).  --no-extras drops those.
+Rank 0 writes the FULL record (every sub-record and kernel table) to gpurun_out/bench_full.json (--full-record) and prints, as the LAST
+stdout line, ONE compact JSON object under 4 KB (`headline_line`): the contract's keys, `roofline`, `cpu_baseline`, and three numbers per
+extra leg.  `dtype` names the arithmetic of the timed step as the library's planner ran it: "bf16+fp8stage" = bf16 MLP contractions whose
+layer inputs / output gradients cross HBM as e4m3 / e5m2 on their way to the weight-gradient kernel (which contracts them on the MX-fp8
+matrix path), "bf16" = the same with bf16 staging, "f32" = the 1e-5 parity mode.  `roofline` is for the kernel with the largest share of
+the step, measured with HIP events on the launch stream inside the library (nca_timing_*) over an eager pass of the same step (events
+cannot be recorded inside a replayed graph: the table decomposes `eager_ms_per_step`); fractions are named by their denominator --
+`mfma_frac` (dense MFMA peak of the pipe the contractions run on: 2 500 TFLOP/s bf16; 2 500 / 6 for the f32 mode, whose hidden layers are six
+bf16 products per f32 product) and `hbm_frac` (8 TB/s).  `cpu_baseline` is the CPU oracle (reference-equivalent torch CPU ops) on a bounded
+sample.  At N = 1 the default run also times: `baseline_config_dtype` (stage_fp8 = 0: BASELINE configs[1] as written -- bf16 operands
+everywhere, nothing in 8 bits), `f32`, `latency_regime` (the reference's default batch, 1 024 rays x 500 samples), `configs3` (MAGIX 512^2 x
+256, f32), `sustained` and `unfused_gpu_baseline` (the reference-equivalent torch ops run op by op on the same GPU: the denominator of the
+north star's >= 10x).  --no-extras drops those; --psnr-steps N and --predicted-scaling add their records to the full record.
 """
 import argparse
 import hashlib
@@ -58,7 +59,7 @@ WGRAD_FP8_BYTES_PER_SAMPLE = 2 * (4 * 256 + 128 + 20)
 # and, for the last hidden layer's rebuilt block, 16 B of mask bits + 4 B: 2 nets x (4 x 512 + 224 + 20) -- 66 FLOP/B, far below the ridge
 WGRAD_BF16_BYTES_PER_SAMPLE = 2 * (4 * 512 + 224 + 20)
 PEAK_F32_ON_BF16_PIPE = 2500.0 / 6.0
-PROFILE_TAGS = ("r05", "r04", "r03", "r02", "r01")          # committed PMC summaries, newest first
+PROFILE_TAGS = ("r06", "r05", "r04", "r03", "r02", "r01")          # committed PMC summaries, newest first
 FLOP_STEP = FLOP_FWD + FLOP_DGRAD + FLOP_WGRAD            # 870 912 FLOP per sample of a training step
 # the pipe a precision's contractions run on: the f32 mode's hidden layers are six bf16 products per f32 product
 PIPE_PEAK_TFLOPS = {"f32": PEAK_F32_ON_BF16_PIPE, "bf16": 2500.0}
@@ -88,7 +89,12 @@ def parse(argv=None):
     ap.add_argument("--pure-steps", type=int, default=20, help="timed steps of the bf16_pure sub-record (bf16 staging; 0: skip)")
     ap.add_argument("--sustained-steps", type=int, default=500, help="further graph steps after the timed region; the last 100 are timed (0: skip)")
     ap.add_argument("--kernel-steps", type=int, default=8, help="steps of the eager pass that times the kernels")
-    ap.add_argument("--psnr-steps", type=int, default=100, help="steps of the PSNR record (64^2 detector, 256 rays/step; 0: skip)")
+    ap.add_argument("--psnr-steps", type=int, default=0, help="steps of the PSNR record of the FULL record (64^2 detector, 256 rays/step, HIP f32 / HIP bf16 / CPU oracle; "
+                    "0 = skip, the default: the PSNR evidence is tests/test_psnr_gates.py)")
+    ap.add_argument("--predicted-scaling", action="store_true", help="add `predicted_scaling` to the full record: the measured one-GPU step of a rank's share (rays / N, N = 2, 4, 8) "
+                    "under a one-rank RCCL group; the links' time in it is an ESTIMATE")
+    ap.add_argument("--full-record", default=None, help="where the full record goes (default: gpurun_out/bench_full.json under the repository root); the LAST stdout "
+                    "line is the compact headline record (< 4 KB) whatever this says")
     ap.add_argument("--configs3-steps", type=int, default=3, help="timed steps of the BASELINE configs[3] sub-record (MAGIX geometry, 8 sequences x 10 phases of 512^2, "
                     "256 samples per ray, f32, one full detector = 262 144 rays per step; 0: skip)")
     ap.add_argument("--latency-steps", type=int, default=200, help="timed steps of the latency-regime sub-record (the reference's default batch: 1 024 rays x 500 "
@@ -612,7 +618,7 @@ def psnr_record(args, dev):
     for it in range(steps):
         ids = tr.draw_ray_ids_device(it).cpu()
         rays, ph = table.index_select(0, ids), phases.index_select(0, ids)
-        zj = O.stratified_depths(z0, tr.draw_jitter(it))
+        zj = O.stratified_depths(z0, tr.draw_jitter(it).cpu())
         ot.step(it, rays[:, 0, :], rays[:, 1, :], ph[:, None].repeat(1, S), I0, zj, rays[:, 2, 0], rays[:, 3, 0])
     cpu_s = time.perf_counter() - t0
     hip_f32 = out.pop("_hip_f32_params")
@@ -626,31 +632,106 @@ def psnr_record(args, dev):
     out["config"] = f"{det}^2 detector x {S} samples/ray, 4 views x 10 phases + 1 held-out view, {R} rays/step, {steps} steps, schedules compressed to the run"
     out["gap_f32_vs_oracle_db"] = out["hip_f32"]["psnr_mse_db"] - out["cpu_oracle"]["psnr_mse_db"]
     out["gap_bf16_vs_f32_db"] = out["hip_bf16"]["psnr_mse_db"] - out["hip_f32"]["psnr_mse_db"]
-    # the multi-seed record at the BENCH batch (replayed from the committed table: five f32 runs of 1 000 steps do not fit a bench
-    # run; tests/test_psnr_gates.py re-measures seeds 0, 1, 2 on every GPU test run): per seed the bf16 gap and what the parity mode
-    # itself moves by when its initial weights are rounded-to-bf16-sized perturbed once -- the resolution of "matched PSNR" there
-    try:
-        tab = json.load(open(os.path.join(ROOT, "profiles", "r04_psnr_bench_batch_seed_table.json")))
-        out["seed_spread"] = {"source": "profiles/r04_psnr_bench_batch_seed_table.json (replayed; DESIGN.md 4.5)", "config": tab["config"], "gate": tab["note"],
-                              "per_seed": {sd: {"f32_psnr_mse_db": v["f32"]["psnr_mse_db"], "bf16_minus_f32_db": v["gap_to_f32_db"]["bf16"]["psnr_mse_db"],
-                                                "f32_kick2e-3_minus_f32_db": v["gap_to_f32_db"]["f32_kick2e-3"]["psnr_mse_db"],
-                                                "within_0.1_db": v["gate"]["plain_0.1_clause"], "within_f32_own_spread": v["gate"]["passes"]}
-                                           for sd, v in tab["seeds"].items()}}
-    except (OSError, ValueError, KeyError):
-        out["seed_spread"] = None
-    # ... and ten seeds over 4 000 steps (replayed likewise)
-    try:
-        runs = {}
-        for l in open(os.path.join(ROOT, "profiles", "r04_psnr_bench_batch_long.jsonl")):
-            r = json.loads(l)
-            runs[(r["variant"], str(r["seed"]))] = r["curve"][-1]["psnr_mse_db"]
-        out["long_runs"] = {"source": "profiles/r04_psnr_bench_batch_long.jsonl (replayed)", "steps": 4000,
-                            "per_seed": {sd: {"f32_psnr_mse_db": v, "bf16_minus_f32_db": runs[("bf16", sd)] - v,
-                                              "f32_kick2e-3_minus_f32_db": (runs[("f32_kick2e-3", sd)] - v) if ("f32_kick2e-3", sd) in runs else None}
-                                         for (var, sd), v in sorted(runs.items()) if var == "f32"}}
-    except (OSError, ValueError, KeyError):
-        out["long_runs"] = None
     return out
+
+
+def _r(x, sig=6):
+    """Floats of the compact line with `sig` significant digits (the full record keeps every digit)."""
+    if isinstance(x, float):
+        return float(f"{x:.{sig}g}")
+    if isinstance(x, dict):
+        return {k: _r(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, sig) for v in x]
+    return x
+
+
+def _kernel_fracs(roof):
+    """{kernel: {bound, mfma_frac | hbm_frac, avg_launch_ms}}: ONE key per denominator -- `mfma_frac` divides algorithmic FLOP/s by the dense
+    MFMA peak of the pipe the contractions run on, `hbm_frac` divides algorithmic bytes/s by the 8 TB/s HBM peak; never one under the other's name."""
+    out = {}
+    for k, v in (roof.get("per_kernel") or {}).items():
+        e = {"bound": v["bound"], "avg_launch_ms": v["avg_launch_ms"]}
+        if v["bound"] == "hbm":
+            e["hbm_frac"] = v["frac"]
+            e["mfma_frac"] = v.get("mfma_frac")
+        else:
+            e["mfma_frac"] = v["frac"]
+        out[k] = e
+    return out
+
+
+def precision_summary(rec):
+    """Three numbers per precision for the compact line: throughput, step time, and the whole step's fraction of the MFMA peak."""
+    return {"rays_per_s": rec["value"], "ms_per_step": rec["ms_per_step"], "step_mfma_frac": rec["roofline"]["step"]["frac"]}
+
+
+def write_full_record(args, out):
+    """The full record (every sub-record, every kernel table) goes to a FILE; stdout ends with the compact line the driver parses."""
+    path = args.full_record or os.path.join(ROOT, "gpurun_out", "bench_full.json")
+    try:
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(out, f)
+            f.write("\n")
+        return os.path.relpath(path, ROOT)
+    except OSError as e:          # (a read-only tree: the compact line still goes out)
+        print(f"bench.py: full record not written ({e})", file=sys.stderr)
+        return None
+
+
+HEADLINE_LIMIT_BYTES = 4000
+
+
+def headline_line(out, full_path=None):
+    """The LAST stdout line: the bench contract's keys plus `roofline` and `cpu_baseline`, under HEADLINE_LIMIT_BYTES (round 5's 24.6 KB line was
+    not parsed by the driver).  Everything else is in the full record (`full_record`).  tests/test_host_cpu.py checks size, keys and json.loads."""
+    cfg = out["config"]
+    roof = out["roofline"]
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = {"workload": cfg["workload"], "rays_per_step_per_gpu": cfg["rays_per_step_per_gpu"], "global_rays_per_step": cfg["global_rays_per_step"],
+                      "samples_per_ray": cfg["samples_per_ray"], "parallelism": cfg["parallelism"], "hip_graph": cfg["hip_graph"], "stage_fp8": cfg["stage_fp8"],
+                      "launches_per_step": cfg["launches_per_step"]}
+    line["roofline"] = {"bound": roof["bound"], "kernel": roof["kernel"], "achieved": roof["achieved"], "peak": roof["peak"], "unit": roof["unit"], "frac": roof["frac"],
+                        "traffic": roof.get("traffic"), "avg_launch_ms": roof["avg_launch_ms"], "launches": roof["launches"],
+                        "step": {k: roof["step"][k] for k in ("achieved", "peak", "unit", "frac")}, "kernels": _kernel_fracs(roof)}
+    if roof.get("traffic_source"):
+        line["roofline"]["traffic_source"] = roof["traffic_source"]["file"]
+    if "cpu_baseline" in out:
+        line["cpu_baseline"] = {k: out["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind", "sample")}
+    b = out.get("baseline_config_dtype")
+    if b:
+        line["baseline_config_dtype"] = {"dtype": b["dtype"], "value": b["value"], "unit": b["unit"], "ms_per_step": b["ms_per_step"], "steps": b["steps"],
+                                         "step_mfma_frac": b["roofline_step"]["frac"],
+                                         "kernels": {k: {kk: vv for kk, vv in v.items() if kk != "avg_launch_ms"} for k, v in _kernel_fracs({"per_kernel": b["per_kernel"]}).items()}}
+    if out.get("precisions"):
+        line["precisions"] = out["precisions"]
+    lat = out.get("latency_regime")
+    if lat:
+        line["latency_regime"] = {"rays_per_step": lat["rays_per_step"], "samples_per_ray": lat["samples_per_ray"], "steps": lat["steps"],
+                                  **{p: {"ms_per_step": lat[p]["ms_per_step"], "rays_per_s": lat[p]["rays_per_s"]} for p in ("bf16", "f32") if p in lat}}
+    c3 = out.get("configs3")
+    if c3:
+        line["configs3"] = {"dtype": c3["dtype"], "rays_per_step": 262144, "samples_per_ray": 256, "value": c3["value"], "unit": c3["unit"], "ms_per_step": c3["ms_per_step"],
+                            "steps": c3["steps"], "step_mfma_frac": c3["roofline_step"]["frac"]}
+    for k in ("vs_unfused_gpu", "rccl_ranks", "store_fallbacks"):
+        if out.get(k) is not None:
+            line[k] = out[k]
+    for k in ("weak_scaling", "strong_scaling"):
+        if k in out:
+            line[k] = {kk: out[k][kk] for kk in ("scaling", "ms_per_step", "value", "unit", "global_rays_per_step", "rays_per_step_per_gpu")}
+    if out.get("sustained"):
+        line["sustained_ms_per_step"] = out["sustained"]["ms_per_step"]
+    line["full_record"] = full_path
+    text = json.dumps(_r(line), separators=(",", ":"))
+    if len(text) > HEADLINE_LIMIT_BYTES:          # (never let the line outgrow the driver's parser again: shed the optional parts, largest first)
+        for k in ("baseline_config_dtype", "latency_regime", "configs3", "precisions", "weak_scaling", "strong_scaling"):
+            if k in line:
+                line[k] = "see full_record"
+                text = json.dumps(_r(line), separators=(",", ":"))
+                if len(text) <= HEADLINE_LIMIT_BYTES:
+                    break
+    return text
 
 
 def main():
@@ -718,7 +799,7 @@ def main():
             out[other_rec["scaling"] + "_scaling"] = other_rec
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, data)
-        if world == 1 and not args.no_extras and args.prec == "bf16":
+        if world == 1 and not args.no_extras and args.prec == "bf16" and args.predicted_scaling:
             out["predicted_scaling"] = predicted_scaling(args, data, dev, main_rec["ms_per_step"])
         if world == 1 and not args.no_extras:
             if args.unfused_gpu_rays > 0:
@@ -738,16 +819,15 @@ def main():
                                                 "roofline_step": bp["roofline"]["step"], "per_kernel": bp["roofline"]["per_kernel"], "record": "bf16_pure"}
             if args.prec != "f32" and args.f32_steps > 0:
                 out["f32"] = measure(args, "f32", None, data, dev, 0, 1, False, args.f32_steps, args.f32_warmup)
-            out["precisions"] = {k: {"rays_per_s": r["value"], "ms_per_step": r["ms_per_step"], "steps": r["steps"], "roofline_frac": r["roofline"]["frac"],
-                                     "roofline_kernel": r["roofline"]["kernel"], "roofline_step_frac": r["roofline"]["step"]["frac"]}
-                                 for k, r in (("f32", out.get("f32")), ("bf16", out.get("bf16_pure")), (main_rec["dtype"], main_rec)) if r}
+            out["precisions"] = {k: precision_summary(r) for k, r in (("f32", out.get("f32")), ("bf16", out.get("bf16_pure")), (main_rec["dtype"], main_rec)) if r}
             if args.psnr_steps > 0:
                 out["psnr"] = psnr_record(args, dev)
             if args.configs3_steps > 0 and args.prec == "bf16":
                 out["configs3"] = configs3_record(args, dev)
             if args.latency_steps > 0 and args.prec == "bf16":
                 out["latency_regime"] = latency_record(args, dev)
-        print(json.dumps(out))
+        path = write_full_record(args, out)
+        print(headline_line(out, path), flush=True)
     if use_pg:
         torch.distributed.destroy_process_group()
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NCA_ABI_VERSION 10
+#define NCA_ABI_VERSION 11
 
 enum {
     NCA_OK = 0,
@@ -142,12 +142,18 @@ int64_t nca_packed_bytes(const NcaNet* net, int32_t prec);
 /* Re-order the flat natural parameters into the LDS images the kernels stream
  * (run before every forward: optimisers update the parameters in place). */
 int nca_pack_weights(const NcaNet* net, const float* params, void* packed, int32_t prec, void* stream);
+/* The same for the two nets of a composite render in ONE launch (ABI 11): at the reference's default batch (1 024 rays x 500 samples,
+ * train/composite.txt:25,40) a step is ~0.7 ms and every launch of a few microseconds counts. */
+int nca_pack_weights2(const NcaNet* net_a, const float* params_a, void* packed_a,
+                      const NcaNet* net_b, const float* params_b, void* packed_b, int32_t prec, void* stream);
 
 /* ---- ray path: replaces obtain_train_predictions_iter/_static + get_predictions_* +
  *      render_volume_density[_composite] (train/model_helpers.py:28-160) ------------------ */
 
 /* Forward.  net_d/packed_d/win_d may be NULL when rays->single_field == 1.
- *   pix   f64[R]    = I0 - sum_s (sigma_s + sigma_d) * dists
+ *   pix   f64[R]    = I0 - sum_s (sigma_s + sigma_d) * dists.  NULL (ABI 11; composite or single-field renders of nets of one width): the
+ *         forward leaves only the per-tile ray sums in `work` -- f64[R][nchunk], nchunk = ceil(S / 64) in bf16, ceil(S / 32) in f32 -- and
+ *         the caller hands them to nca_loss_fwd_bwd (NcaLoss.ray_part), which forms pix itself: one launch less per step.
  *   sig_s f32[R,S], sig_d f32[R,S]  (activation * scale; un-scaled in single_field mode)
  *   work  scratch of nca_render_fwd_workspace() bytes.
  *   store NULL, or a caller-owned buffer of nca_render_store_bytes() bytes: the forward then also leaves there what the
@@ -243,6 +249,16 @@ typedef struct NcaLoss {
                                 sum_i term_grads[i] d term_i / d sigma -- every term, not only the six the training loss weights.  There is
                                 no pixel term in this mode: pix, gt and g_pix may be NULL (weighted_MSELoss is nca_weighted_sq_err);
                                 the four weights above and weights_dev are not read                                                          */
+    /* ABI 11 -- a zeroed tail keeps ABI 10 behaviour */
+    const double* ray_part;  /* NULL, or DEVICE f64[R][ray_nchunk]: the per-tile ray sums a forward called with pix = NULL left in its workspace;
+                                the loss kernel then forms pix[r] = I0[r] - sum_c ray_part[r][c] itself (same order as the forward's own kernel:
+                                bit-identical) and, if pix_out is given, stores it.  The `pix` argument of nca_loss_fwd_bwd is then ignored  */
+    const float* ray_I0;     /* DEVICE f32[R] (with ray_part)                                                                               */
+    double* pix_out;         /* NULL or DEVICE f64[R] (with ray_part)                                                                       */
+    int32_t ray_nchunk;
+    int32_t reserved2;
+    float* terms_f32;        /* NULL, or DEVICE f32[NCA_T_COUNT]: the terms once more, rounded to f32 -- what rides behind the flat gradient in a
+                                sharded step's ONE all-reduce (train/run_composite.py:310: the early-stop pair is terms 8 and 5)             */
 } NcaLoss;
 enum { NCA_T_LOSS = 0, NCA_T_PIXEL, NCA_T_BLENDW, NCA_T_SIG_S_MAX, NCA_T_SIG_D_MAX, NCA_T_FAVOR, NCA_T_S_ENTROPY, NCA_T_S_SUM,
        NCA_T_D_ENTROPY, NCA_T_D_SUM, NCA_T_OCCL, NCA_T_L1, NCA_T_L2, NCA_T_COUNT };
@@ -303,17 +319,75 @@ int nca_prepare_batch(int64_t R, int32_t S, const int64_t* ids, const double* ta
                       const float* depth, const float* t_rand,
                       double* o, double* d, double* gt, double* w, int32_t* ph, float* z, double* dists, void* stream);
 
+/* ---- per-step batch sampling and schedules ON THE DEVICE (ABI 11): the importance sampling of train/run_composite.py:250-260
+ *      (img_sample_size - n_var ids drawn with replacement from the non-variance rays, n_var from the variance rays, shuffled; or
+ *      uniform over the table when var_sample_perc == 0), the stratified depth jitter's uniform draw (train/model_helpers.py:8), the
+ *      FreeNeRF band windows (model/CPPN.py:144-159) and the four loss weights (linear_param_decay, train/model_helpers.py:264-269;
+ *      train/run_composite.py:276-279) as functions of (seed, iteration): counter-based Philox4x32-10 streams (csrc/nca_rng.hpp), so a rank
+ *      draws only ITS slots of the global batch and a captured HIP graph replays a whole training run with NO host work per step -- the
+ *      iteration is n_iter + *iter_dev (iter_dev: DEVICE i64[1] or NULL).  The reference's own host draws (NumPy's global generator) are not
+ *      reproducible by anyone; what is reproduced is their distribution -- exactly n_var variance slots in a uniformly random arrangement,
+ *      i.i.d. uniform draws per slot -- and callers that hold the reference's draws inject them (ids_in / t_rand_in).  ------------------ */
+typedef struct NcaSampler {
+    uint64_t seed;
+    int64_t n_iter;             /* iteration = n_iter + (iter_dev ? *iter_dev : 0)                                        */
+    const int64_t* iter_dev;
+    int64_t R_global;           /* img_sample_size: slots of the GLOBAL batch (the arrangement is drawn over all of them) */
+    int64_t n_var;              /* slots that draw from var_ids (int(var_sample_perc / 100 * img_sample_size)); 0: every slot draws from [0, n_rows) */
+    const int64_t* var_ids;     /* DEVICE i64[n_var_ids]     (train/data_helpers.py: var_ray_ids)                          */
+    int64_t n_var_ids;
+    const int64_t* non_var_ids; /* DEVICE i64[n_non_var_ids]                                                              */
+    int64_t n_non_var_ids;
+    int64_t n_rows;             /* rows of the ray table                                                                  */
+} NcaSampler;
+/* ids i64[R] = the ray ids of slots slot0 .. slot0 + R - 1 of the global batch */
+int nca_draw_ray_ids(const NcaSampler* s, int64_t slot0, int64_t R, int64_t* ids, void* stream);
+/* out f32[n]: uniform [0, 1) draws of stream `stream_id` (2 = the depth jitter; >= 16 free for callers) of the sampler's iteration */
+int nca_draw_uniform(const NcaSampler* s, int32_t stream_id, int64_t n, float* out, void* stream);
+
+enum { NCA_WINDOW_NONE = 0, NCA_WINDOW_FREE = 1 };
+typedef struct NcaWindowSched {
+    int32_t kind;               /* NCA_WINDOW_FREE: update_freq_mask_alpha (model/CPPN.py:144-159) -- bands below the moving pointer 1, the band under
+                                   it the fractional part, the rest 1e-8, everything 1 from decay_steps on; bit-identical to the host schedule */
+    int32_t L;                  /* pos_enc_basis */
+    int32_t window_start;       /* pos_enc_window_start */
+    int32_t reserved;
+    int64_t decay_steps;        /* *_pos_enc_window_decay_steps */
+    float* out;                 /* DEVICE f32[L] */
+} NcaWindowSched;
+typedef struct NcaWeightSched { double start, end; int64_t steps, delay; } NcaWeightSched;   /* linear_param_decay(iter, start, end, steps, delay) */
+typedef struct NcaSchedules {
+    int32_t n_windows;          /* 0 .. 4 */
+    int32_t reserved;
+    NcaWindowSched window[4];
+    NcaWeightSched weight[4];   /* favor_s, dynamic entropy, occlusion, l1 (train/run_composite.py:276-279) */
+    double* weights_out;        /* NULL or DEVICE f64[4]: NcaLoss.weights_dev of the step */
+} NcaSchedules;
+/* nca_prepare_batch with everything that changes from step to step made on the device, ONE launch: ids (drawn, or ids_in), the gather, the
+ * jitter draw (or t_rand_in) with the jittered depths and interval lengths, the band windows and loss weights of the iteration.
+ *   ids_in / t_rand_in  NULL = draw; else the caller's i64[R] / f32[S] (parity tests inject the reference's own draws)
+ *   ids_out / t_rand_out  NULL, or where the drawn values are also stored
+ *   sched  NULL = no schedules; the other arguments as nca_prepare_batch */
+int nca_begin_step(const NcaSampler* s, int64_t slot0, int64_t R, int32_t S, const NcaSchedules* sched,
+                   const int64_t* ids_in, const float* t_rand_in,
+                   const double* table, const int64_t* phases, int32_t* bad_ids, const float* depth,
+                   double* o, double* d, double* gt, double* w, int32_t* ph, float* z, double* dists,
+                   int64_t* ids_out, float* t_rand_out, void* stream);
+
 /* ---- optimiser: torch.optim.Adam(lr) + LinearLR(start_factor=1, end_factor, total_iters) of
  *      train/run_composite.py:209-215, 307-308, as one launch over up to NCA_ADAM_MAX_SEG flat buffers.
- *      `step` is a DEVICE counter = optimiser steps taken so far: the kernel uses t = *step + 1 for the
- *      bias corrections and lr = cfg.lr * factor(*step) (the scheduler is stepped after the optimiser
- *      in the reference), then increments it, so a captured graph replays the whole schedule. -------- */
+ *      `step` is DEVICE i64[2] (ABI 11; both zero before the first call): step[0] = optimiser steps taken so far -- the kernel uses
+ *      t = step[0] + 1 for the bias corrections and lr = cfg.lr * factor(step[0]) (the scheduler is stepped after the optimiser in the
+ *      reference), and the LAST workgroup to finish increments it (step[1] counts the finished workgroups of the launch and is zero again
+ *      when it ends: one launch instead of an update and a one-thread tick), so a captured graph replays the whole schedule.
+ *      NcaAdam.iter_counter (DEVICE i64[1] or NULL) is incremented with it: the training iteration nca_begin_step reads. -------- */
 enum { NCA_ADAM_MAX_SEG = 4 };
 typedef struct NcaAdam {
     double lr;               /* base learning rate                                              */
     double beta1, beta2, eps;/* torch defaults 0.9, 0.999, 1e-8; no weight decay, no amsgrad    */
     double lr_end_factor;    /* LinearLR end_factor (1.0 = constant lr)                         */
     int64_t lr_total_iters;  /* LinearLR total_iters                                            */
+    int64_t* iter_counter;   /* ABI 11: NULL, or DEVICE i64[1] incremented together with step[0]  */
 } NcaAdam;
 /* n, params, grads, exp_avg, exp_avg_sq: HOST arrays of n_seg entries (device pointers, f32). */
 int nca_adam_step(const NcaAdam* cfg, int32_t n_seg, const int64_t* n, float* const* params, const float* const* grads,

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("NERFCA_LIB") or os.path.join(_HERE, "lib", "libnerfca
 ENC_NONE, ENC_BANDS, ENC_FOURIER = 0, 1, 2
 ACT_SIGMOID, ACT_SOFTPLUS, ACT_CLAMP = 0, 1, 2
 PREC_F32, PREC_BF16 = 0, 1
-ABI_VERSION = 10
+ABI_VERSION = 11
 OPT_STAGE_FP8 = 1          # (0 is reserved: the retired bf16-staged backward's on-chip threshold)
 OPT_RESIDENT_MIN_TILES = 2
 OPT_STAGE_FP8_MIN_TILES = 3
@@ -23,6 +23,8 @@ OPT_WGRAD_REBUILD_WEIGHT_PCT = 4
 OPT_OVERLAP_CUS = 5
 OPT_BF16_STORE = 6
 STORE_NONE, STORE_F32, STORE_FP8, STORE_BF16, STORE_KIND_MASK, STORE_SHARED_ENC = 0, 1, 3, 4, 15, 16       # (2 was round 3's bf16-staged store: retired)
+WINDOW_NONE, WINDOW_FREE = 0, 1          # NcaWindowSched.kind
+RNG_STREAM_IDS, RNG_STREAM_PERM, RNG_STREAM_JITTER, RNG_STREAM_USER = 0, 1, 2, 16
 OPT_UNSET = -(1 << 63)     # NCA_OPT_UNSET: "use the process-wide value" in an NcaPlanOpts field
 K_PACK, K_FWD, K_BWD_DGRAD, K_BWD_WGRAD, K_BWD_REDUCE, K_LOSS, K_ADAM = 0, 1, 2, 3, 4, 5, 6
 KERNEL_KINDS = {"pack": K_PACK, "fwd": K_FWD, "bwd_dgrad": K_BWD_DGRAD, "bwd_wgrad": K_BWD_WGRAD, "bwd_reduce": K_BWD_REDUCE,
@@ -65,12 +67,33 @@ class NcaLoss(C.Structure):
     _fields_ = [("R", C.c_int64), ("S", C.c_int32), ("use_weighting", C.c_int32), ("skew", C.c_double), ("mask_thre", C.c_double),
                 ("weighted_thresh", C.c_double), ("w_favor", C.c_double), ("w_dent", C.c_double), ("w_occl", C.c_double),
                 ("w_l1", C.c_double), ("inv_R", C.c_double), ("weights_dev", C.c_void_p), ("unit_mse", C.c_int32), ("reserved", C.c_int32),
-                ("g_dists", C.c_void_p), ("dists_work", C.c_void_p), ("term_grads", C.c_void_p)]
+                ("g_dists", C.c_void_p), ("dists_work", C.c_void_p), ("term_grads", C.c_void_p),
+                # ABI 11 (zero = ABI 10 behaviour): pix formed by the loss kernel from the forward's per-tile ray sums; the terms once more as f32
+                ("ray_part", C.c_void_p), ("ray_I0", C.c_void_p), ("pix_out", C.c_void_p), ("ray_nchunk", C.c_int32), ("reserved2", C.c_int32),
+                ("terms_f32", C.c_void_p)]
 
 
 class NcaAdam(C.Structure):
     _fields_ = [("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
-                ("lr_end_factor", C.c_double), ("lr_total_iters", C.c_int64)]
+                ("lr_end_factor", C.c_double), ("lr_total_iters", C.c_int64), ("iter_counter", C.c_void_p)]
+
+
+class NcaSampler(C.Structure):
+    """The per-step batch sampler on the device (include/nerfca_hip.h: counter-based Philox streams of (seed, iteration))."""
+    _fields_ = [("seed", C.c_uint64), ("n_iter", C.c_int64), ("iter_dev", C.c_void_p), ("R_global", C.c_int64), ("n_var", C.c_int64),
+                ("var_ids", C.c_void_p), ("n_var_ids", C.c_int64), ("non_var_ids", C.c_void_p), ("n_non_var_ids", C.c_int64), ("n_rows", C.c_int64)]
+
+
+class NcaWindowSched(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("L", C.c_int32), ("window_start", C.c_int32), ("reserved", C.c_int32), ("decay_steps", C.c_int64), ("out", C.c_void_p)]
+
+
+class NcaWeightSched(C.Structure):
+    _fields_ = [("start", C.c_double), ("end", C.c_double), ("steps", C.c_int64), ("delay", C.c_int64)]
+
+
+class NcaSchedules(C.Structure):
+    _fields_ = [("n_windows", C.c_int32), ("reserved", C.c_int32), ("window", NcaWindowSched * 4), ("weight", NcaWeightSched * 4), ("weights_out", C.c_void_p)]
 
 
 class NcaPlan(C.Structure):
@@ -93,6 +116,7 @@ SYMBOLS = {
     "nca_param_count": (_I64, [C.POINTER(NcaNet)]),
     "nca_packed_bytes": (_I64, [C.POINTER(NcaNet), _I32]),
     "nca_pack_weights": (C.c_int, [C.POINTER(NcaNet), _P, _P, _I32, _P]),
+    "nca_pack_weights2": (C.c_int, [C.POINTER(NcaNet), _P, _P, C.POINTER(NcaNet), _P, _P, _I32, _P]),
     "nca_render_fwd_workspace": (_I64, [C.POINTER(NcaRays)]),
     "nca_render_store_bytes": (_I64, [C.POINTER(NcaRays), C.POINTER(NcaNet), C.POINTER(NcaNet), _I32]),
     "nca_render_fwd": (C.c_int, [C.POINTER(NcaRays), _I32, C.POINTER(NcaNet), _P, _P, _P, C.POINTER(NcaNet), _P, _P, _P, _P,
@@ -118,6 +142,10 @@ SYMBOLS = {
     "nca_fine_weight_max": (C.c_int, [_I64, _I32, _P, _P, _P, _P, _I64, _P]),
     "nca_fine_depths_given_max": (C.c_int, [_I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _P]),
     "nca_prepare_batch": (C.c_int, [_I64, _I32, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "nca_draw_ray_ids": (C.c_int, [C.POINTER(NcaSampler), _I64, _I64, _P, _P]),
+    "nca_draw_uniform": (C.c_int, [C.POINTER(NcaSampler), _I32, _I64, _P, _P]),
+    "nca_begin_step": (C.c_int, [C.POINTER(NcaSampler), _I64, _I64, _I32, C.POINTER(NcaSchedules), _P, _P, _P, _P, _P, _P,
+                                 _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "nca_adam_step": (C.c_int, [C.POINTER(NcaAdam), _I32, C.POINTER(_I64), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P),
                                 _P, _P]),
     "nca_get_option": (C.c_int, [_I32, C.POINTER(_I64)]),

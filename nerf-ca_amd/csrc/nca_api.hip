@@ -335,6 +335,22 @@ extern "C" int nca_pack_weights(const NcaNet* net, const float* params, void* pa
     return NCA_OK;
 }
 
+extern "C" int nca_pack_weights2(const NcaNet* net_a, const float* params_a, void* packed_a,
+                                 const NcaNet* net_b, const float* params_b, void* packed_b, int32_t prec, void* stream) {
+    NcaLayout ya, yb;
+    int rc = check_prec(prec);
+    if (rc) return rc;
+    rc = layout_of(net_a, &ya, prec);
+    if (rc != NCA_OK) return rc;
+    rc = layout_of(net_b, &yb, prec);
+    if (rc != NCA_OK) return rc;
+    if (!params_a || !packed_a || !params_b || !packed_b) return fail(NCA_E_INVALID, "params/packed is NULL");
+    Span sp(NCA_K_PACK, (hipStream_t)stream);
+    if (prec == NCA_PREC_BF16) HIPCHK(nca_launch_pack2_bf16(ya, params_a, packed_a, yb, params_b, packed_b, (hipStream_t)stream));
+    else HIPCHK(nca_launch_pack2_f32(ya, params_a, packed_a, yb, params_b, packed_b, (hipStream_t)stream));
+    return NCA_OK;
+}
+
 // ---------------------------------------------------------------------------------- helpers
 static inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
@@ -547,7 +563,7 @@ extern "C" int nca_render_fwd(const NcaRays* rays, int32_t prec,
     if (rc) return rc;
     rc = check_prec(prec);
     if (rc) return rc;
-    if (!pix || !sig_s || (!rays->single_field && !sig_d)) return fail(NCA_E_INVALID, "an output pointer is NULL");
+    if (!sig_s || (!rays->single_field && !sig_d)) return fail(NCA_E_INVALID, "an output pointer is NULL");
     if (!rays->single_field && !net_d) return fail(NCA_E_INVALID, "composite render needs the dynamic net");
     const int64_t need = nca_render_fwd_workspace(rays);
     if (!work || work_bytes < need) return fail(NCA_E_WORKSPACE, "forward workspace %lld < %lld bytes", (long long)work_bytes, (long long)need);
@@ -574,6 +590,7 @@ extern "C" int nca_render_fwd(const NcaRays* rays, int32_t prec,
     hipStream_t st = (hipStream_t)stream;
     if (a.nnets == 2 && a.net[0].lay.F != a.net[1].lay.F) {
         if (store) return fail(NCA_E_UNSUPPORTED, "a forward store needs nets of one width");
+        if (!pix) return fail(NCA_E_UNSUPPORTED, "pix = NULL (ray sums left to the loss kernel) needs nets of one width");
         g_plan.fwd_launches = 2;
         publish_plan(g_plan, true, rays->plan_out);
         // nets of different width: one fused launch per net writes the raw field into its sigma buffer,
@@ -661,7 +678,7 @@ extern "C" int nca_render_fwd(const NcaRays* rays, int32_t prec,
         else HIPCHK(nca_launch_fused_f32(a.net[0].lay.F, a, kmode, grid, st));
         g_plan.fwd_launches = 1;
     }
-    HIPCHK(nca_launch_pix_f32(rays->R, a.nchunk, rays->I0, a.part, pix, st));
+    if (pix) HIPCHK(nca_launch_pix_f32(rays->R, a.nchunk, rays->I0, a.part, pix, st));       // (NULL: the loss kernel forms pix from a.part, NcaLoss.ray_part)
     g_plan.fwd_store_format = store_format;
     publish_plan(g_plan, true, rays->plan_out);
     return store_format;
@@ -1037,6 +1054,7 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
         return nca_launch_wgrad_bf16(F, w1, p.nx_net[n], ws, waves_per_wg);
     };
     constexpr int ovl_nw = 4;          // (one 256-thread workgroup per CU: a CU holds EITHER kernel whichever is dispatched first)
+    const bool one_chunk = units <= p.units_per_chunk;
     int chunk = 0;
     for (int64_t u0 = 0; u0 < units; u0 += p.units_per_chunk, ++chunk) {
         const int64_t nu = (u0 + p.units_per_chunk <= units) ? p.units_per_chunk : units - u0;
@@ -1087,7 +1105,8 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
         if (nr && ovl) {        // (each net's partial rows are those of ITS dgrad launch's workgroups)
             for (int n = 0; n < a.nnets; ++n)
                 HIPCHK(nca_launch_sum_tile_records(reinterpret_cast<const char*>(scratch), 2 * p.tile_stride, p.tile_stride - NCA_D8_REC_BYTES, a.ntiles, n, n + 1, F, oslab, p.grid_net[n], st));
-        } else if (nr) HIPCHK(nca_launch_sum_tile_records(reinterpret_cast<const char*>(scratch), 2 * p.tile_stride, p.tile_stride - NCA_D8_REC_BYTES, a.ntiles, 0, a.nnets, F, oslab, p.grid, st));
+        } else if (nr && !one_chunk) HIPCHK(nca_launch_sum_tile_records(reinterpret_cast<const char*>(scratch), 2 * p.tile_stride, p.tile_stride - NCA_D8_REC_BYTES, a.ntiles, 0, a.nnets, F, oslab, p.grid, st));
+        // (one chunk: the records are summed by extra workgroups of the reduce launch below -- the D region is still this chunk's then)
         if (g_latents) {     // d loss / d latent input per point, from the same D_0 blocks (points mode, one net)
             NcaLatgradArgs lg;
             memset(&lg, 0, sizeof(lg));
@@ -1177,6 +1196,11 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
         rn.n_split = ovl ? p.nx_net[n] : (bf ? p.n_split_x : p.n_split);
         rn.n_split_std = ovl ? p.ns_net[n] : p.n_split;
         rn.n_wg = ovl ? p.grid_net[n] : p.grid;
+    }
+    if (nr && !ovl && one_chunk) {
+        r.rec_region = reinterpret_cast<const char*>(scratch);
+        r.rec_tile_bytes = 2 * p.tile_stride; r.rec_off = p.tile_stride - NCA_D8_REC_BYTES; r.rec_ntiles = units * tiles_per_unit;
+        r.rec_net0 = 0; r.rec_net1 = a.nnets; r.rec_F = F; r.rec_nwg = p.grid; r.rec_oslab = oslab;
     }
     {
         Span sp(NCA_K_BWD_REDUCE, st);
@@ -1402,6 +1426,11 @@ extern "C" int nca_loss_fwd_bwd(const NcaLoss* d, const double* pix, const doubl
     if (!d) return fail(NCA_E_INVALID, "loss descriptor is NULL");
     if (d->R <= 0 || d->S <= 0) return fail(NCA_E_INVALID, "empty ray batch");
     const bool tgm = d->term_grads != nullptr;       // term-gradient mode: no pixel term -- pix / gt / g_pix may be NULL
+    if (d->ray_part) {           // pix is formed by the kernel from the forward's per-tile ray sums
+        if (tgm) return fail(NCA_E_INVALID, "ray_part and term_grads exclude each other");
+        if (!d->ray_I0 || d->ray_nchunk <= 0 || !gt) return fail(NCA_E_INVALID, "ray_part needs ray_I0, ray_nchunk > 0 and gt");
+        pix = d->pix_out ? d->pix_out : reinterpret_cast<const double*>(d->ray_part);          // (non-null marker: the kernel reads ray_part, never this)
+    }
     if ((!tgm && (!pix || !gt)) || !wpix || !sig_s || !sig_d || !dists || !terms) return fail(NCA_E_INVALID, "a loss input pointer is NULL");
     if ((pix == nullptr) != (gt == nullptr)) return fail(NCA_E_INVALID, "pix and gt: both or neither");
     if (tgm && d->weights_dev) return fail(NCA_E_INVALID, "term_grads and weights_dev exclude each other");
@@ -1423,6 +1452,9 @@ extern "C" int nca_loss_fwd_bwd(const NcaLoss* d, const double* pix, const doubl
     a.g_dists = d->g_dists;
     a.dists_work = d->g_dists ? d->dists_work : nullptr;
     a.term_grads = d->term_grads;
+    a.ray_part = d->ray_part; a.ray_I0 = d->ray_I0; a.pix_out = d->pix_out; a.ray_nchunk = d->ray_nchunk; a.pad2_ = 0;
+    a.terms_f32 = d->terms_f32;
+    if (a.ray_part) a.pix = nullptr;
     Span sp(NCA_K_LOSS, (hipStream_t)stream);
     HIPCHK(nca_launch_loss(a, (hipStream_t)stream));
     return NCA_OK;
@@ -1545,6 +1577,64 @@ extern "C" int nca_prepare_batch(int64_t R, int32_t S, const int64_t* ids, const
     return NCA_OK;
 }
 
+// ---------------------------------------------------------------------------------- device-side sampling and schedules
+static int check_sampler(const NcaSampler* s) {
+    if (!s) return fail(NCA_E_INVALID, "sampler is NULL");
+    if (s->R_global <= 0) return fail(NCA_E_INVALID, "sampler: R_global = %lld", (long long)s->R_global);
+    if (s->n_var < 0 || s->n_var > s->R_global) return fail(NCA_E_INVALID, "sampler: n_var = %lld outside [0, R_global]", (long long)s->n_var);
+    if (s->n_var > 0 && s->n_var_ids > 0) {
+        if (!s->var_ids || !s->non_var_ids || s->n_non_var_ids <= 0)
+            return fail(NCA_E_INVALID, "sampler: importance sampling needs both id tables (var %lld, non-var %lld ids)", (long long)s->n_var_ids, (long long)s->n_non_var_ids);
+    } else if (s->n_rows <= 0) return fail(NCA_E_INVALID, "sampler: uniform sampling needs n_rows > 0");
+    return NCA_OK;
+}
+extern "C" int nca_draw_ray_ids(const NcaSampler* s, int64_t slot0, int64_t R, int64_t* ids, void* stream) {
+    int rc = check_sampler(s);
+    if (rc) return rc;
+    if (R <= 0 || slot0 < 0 || slot0 + R > s->R_global) return fail(NCA_E_INVALID, "slots [%lld, %lld) outside the global batch of %lld", (long long)slot0, (long long)(slot0 + R), (long long)s->R_global);
+    if (!ids) return fail(NCA_E_INVALID, "ids is NULL");
+    HIPCHK(nca_launch_draw_ray_ids(*s, slot0, R, ids, (hipStream_t)stream));
+    return NCA_OK;
+}
+extern "C" int nca_draw_uniform(const NcaSampler* s, int32_t stream_id, int64_t n, float* out, void* stream) {
+    if (!s || !out) return fail(NCA_E_INVALID, "a pointer is NULL");
+    if (n <= 0 || stream_id < 0 || stream_id > 255) return fail(NCA_E_INVALID, "n = %lld, stream %d (0 .. 255)", (long long)n, stream_id);
+    HIPCHK(nca_launch_draw_uniform(*s, stream_id, n, out, (hipStream_t)stream));
+    return NCA_OK;
+}
+extern "C" int nca_begin_step(const NcaSampler* s, int64_t slot0, int64_t R, int32_t S, const NcaSchedules* sched,
+                              const int64_t* ids_in, const float* t_rand_in,
+                              const double* table, const int64_t* phases, int32_t* bad_ids, const float* depth,
+                              double* o, double* d, double* gt, double* w, int32_t* ph, float* z, double* dists,
+                              int64_t* ids_out, float* t_rand_out, void* stream) {
+    if (!s) return fail(NCA_E_INVALID, "sampler is NULL");
+    if (R <= 0 || S <= 0) return fail(NCA_E_INVALID, "empty ray batch (R=%lld, S=%d)", (long long)R, S);
+    if (!ids_in) {
+        int rc = check_sampler(s);
+        if (rc) return rc;
+        if (slot0 < 0 || slot0 + R > s->R_global) return fail(NCA_E_INVALID, "slots [%lld, %lld) outside the global batch of %lld", (long long)slot0, (long long)(slot0 + R), (long long)s->R_global);
+    }
+    if (!table || !phases || !depth || !o || !d || !gt || !w || !ph || !z || !dists) return fail(NCA_E_INVALID, "a pointer is NULL");
+    NcaBeginArgs a;
+    memset(&a, 0, sizeof(a));
+    a.s = *s; a.slot0 = slot0; a.R = R; a.S = S;
+    if (sched) {
+        if (sched->n_windows < 0 || sched->n_windows > 4) return fail(NCA_E_INVALID, "n_windows = %d", sched->n_windows);
+        for (int i = 0; i < sched->n_windows; ++i) {
+            const NcaWindowSched& ws = sched->window[i];
+            if (ws.kind != NCA_WINDOW_NONE && ws.kind != NCA_WINDOW_FREE) return fail(NCA_E_UNSUPPORTED, "window schedule %d: kind %d", i, ws.kind);
+            if (ws.kind == NCA_WINDOW_FREE && (ws.L < 1 || ws.L > 64 || ws.decay_steps <= 0 || !ws.out)) return fail(NCA_E_INVALID, "window schedule %d: L = %d, decay_steps = %lld", i, ws.L, (long long)ws.decay_steps);
+        }
+        if (sched->weights_out)
+            for (int i = 0; i < 4; ++i) if (sched->weight[i].steps <= 0) return fail(NCA_E_INVALID, "weight schedule %d: steps = %lld", i, (long long)sched->weight[i].steps);
+        a.sch = *sched;
+    }
+    a.ids_in = ids_in; a.t_rand_in = t_rand_in; a.table = table; a.phases = phases; a.bad_ids = bad_ids; a.depth = depth;
+    a.o = o; a.d = d; a.gt = gt; a.w = w; a.ph = ph; a.z = z; a.dists = dists; a.ids_out = ids_out; a.t_rand_out = t_rand_out;
+    HIPCHK(nca_launch_begin_step(a, (hipStream_t)stream));
+    return NCA_OK;
+}
+
 // ---------------------------------------------------------------------------------- optimiser
 extern "C" int nca_adam_step(const NcaAdam* cfg, int32_t n_seg, const int64_t* n, float* const* params, const float* const* grads,
                              float* const* exp_avg, float* const* exp_avg_sq, int64_t* step, void* stream) {
@@ -1555,7 +1645,7 @@ extern "C" int nca_adam_step(const NcaAdam* cfg, int32_t n_seg, const int64_t* n
     NcaAdamArgs a{};
     a.lr = cfg->lr; a.beta1 = cfg->beta1; a.beta2 = cfg->beta2; a.eps = cfg->eps;
     a.lr_end_factor = cfg->lr_end_factor; a.lr_total_iters = cfg->lr_total_iters;
-    a.n_seg = n_seg; a.step = step;
+    a.n_seg = n_seg; a.step = step; a.iter_counter = cfg->iter_counter;
     for (int s = 0; s < n_seg; ++s) {
         if (n[s] <= 0 || !params[s] || !grads[s] || !exp_avg[s] || !exp_avg_sq[s]) return fail(NCA_E_INVALID, "Adam segment %d is empty or NULL", s);
         a.n[s] = n[s]; a.params[s] = params[s]; a.grads[s] = grads[s]; a.exp_avg[s] = exp_avg[s]; a.exp_avg_sq[s] = exp_avg_sq[s];

@@ -166,7 +166,31 @@ struct NcaReduceArgs {
     const float* oslab;
     int64_t oslab_stride;
     NcaReduceNet net[2];
+    // the tile records of a one-chunk backward from a store (mode 5), summed into oslab's output-bias slots by extra workgroups of the FIRST
+    // reduce launch instead of a launch of their own (rec_region == null: nothing to do / nca_sum_tile_records ran per chunk)
+    const char* rec_region;
+    int64_t rec_tile_bytes, rec_off, rec_ntiles;
+    int32_t rec_net0, rec_net1, rec_F, rec_nwg;
+    float* rec_oslab;
 };
+// body of nca_sum_tile_records (bf16 TU) / of the first reduce launch's extra workgroups (f32 TU): workgroup `wg` of `n_wg` adds the per-tile sums of
+// d loss / d raw (tile order: thread t takes tiles t * n_wg + wg, + 256 n_wg, ...; then a fixed tree) to its output-bias slot of oslab
+__device__ __forceinline__ void nca_tile_record_sum(const char* dregion, int64_t wave_tile_bytes, int64_t dscale_off, int64_t ntiles, int net0, int net1, int F,
+                                                    float* oslab, int wg, int n_wg, float* part /* __shared__ float[256] */) {
+    for (int net = net0; net < net1; ++net) {
+        float s = 0.f;
+        for (int64_t t = (int64_t)threadIdx.x * n_wg + wg; t < ntiles; t += 256 * (int64_t)n_wg)
+            s += reinterpret_cast<const float*>(dregion + t * wave_tile_bytes + dscale_off)[2 + net];
+        part[threadIdx.x] = s;
+        __syncthreads();
+        for (int d = 128; d >= 1; d >>= 1) {
+            if ((int)threadIdx.x < d) part[threadIdx.x] += part[threadIdx.x + d];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) oslab[(int64_t)wg * 2 * (F + 1) + net * (F + 1) + F] += part[0];
+        __syncthreads();
+    }
+}
 
 struct NcaLossArgs {
     int64_t R;
@@ -182,6 +206,11 @@ struct NcaLossArgs {
     double* g_dists;      // [S] or null
     double* dists_work;   // [R * S] per-ray d loss / d dists
     const double* term_grads;   // null, or DEVICE f64[11]: term-gradient mode (NcaLoss.term_grads)
+    const double* ray_part;     // null, or the forward's per-tile ray sums [R][ray_nchunk]: pix is formed here (NcaLoss.ray_part)
+    const float* ray_I0;
+    double* pix_out;
+    int32_t ray_nchunk, pad2_;
+    float* terms_f32;           // null, or f32[13]: the terms once more as floats
 };
 struct NcaCompositeArgs {
     int64_t R;
@@ -201,12 +230,27 @@ struct NcaAdamArgs {
     int32_t n_seg;
     int64_t n[4];
     float* params[4]; const float* grads[4]; float* exp_avg[4]; float* exp_avg_sq[4];
-    int64_t* step;
+    int64_t* step;           // i64[2]: steps taken, arrival counter of the launch's workgroups
+    int64_t* iter_counter;   // null, or incremented with step[0]
 };
 hipError_t nca_launch_adam(const NcaAdamArgs& a, hipStream_t st);
 hipError_t nca_launch_prepare_batch(int64_t R, int S, const int64_t* ids, const double* table, const int64_t* phases, int64_t n_rows, int32_t* bad_ids,
                                     const float* depth, const float* t_rand,
                                     double* o, double* d, double* gt, double* w, int32_t* ph, float* z, double* dists, hipStream_t st);
+// nca_begin_step: nca_prepare_batch + the device-side draws and schedules (include/nerfca_hip.h)
+struct NcaBeginArgs {
+    NcaSampler s;
+    int64_t slot0, R;
+    int32_t S, pad;
+    NcaSchedules sch;
+    const int64_t* ids_in; const float* t_rand_in;
+    const double* table; const int64_t* phases; int32_t* bad_ids; const float* depth;
+    double* o; double* d; double* gt; double* w; int32_t* ph; float* z; double* dists;
+    int64_t* ids_out; float* t_rand_out;
+};
+hipError_t nca_launch_begin_step(const NcaBeginArgs& a, hipStream_t st);
+hipError_t nca_launch_draw_ray_ids(const NcaSampler& s, int64_t slot0, int64_t R, int64_t* ids, hipStream_t st);
+hipError_t nca_launch_draw_uniform(const NcaSampler& s, int stream_id, int64_t n, float* out, hipStream_t st);
 struct NcaFineArgs {
     int64_t R;
     int32_t S, n_fine;
@@ -271,6 +315,9 @@ struct NcaLatgradArgs {
 };
 hipError_t nca_launch_latgrad_f32(int F, const NcaLatgradArgs& a, hipStream_t st);
 hipError_t nca_launch_pack_f32(const NcaLayout& y, const float* prm, void* out, hipStream_t st);
+// both nets of a composite render in one launch (blockIdx.y = net)
+hipError_t nca_launch_pack2_f32(const NcaLayout& ya, const float* prm_a, void* out_a, const NcaLayout& yb, const float* prm_b, void* out_b, hipStream_t st);
+hipError_t nca_launch_pack2_bf16(const NcaLayout& ya, const float* prm_a, void* out_a, const NcaLayout& yb, const float* prm_b, void* out_b, hipStream_t st);
 hipError_t nca_launch_fused_f32(int F, const NcaFusedArgs& a, int kmode, int grid, hipStream_t st);
 hipError_t nca_launch_wgrad_f32(const NcaWgradArgs& a, int nsplit, hipStream_t st);
 hipError_t nca_launch_reduce_f32(const NcaReduceArgs& a, hipStream_t st);

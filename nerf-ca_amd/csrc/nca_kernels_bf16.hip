@@ -170,7 +170,7 @@ __device__ __forceinline__ float relu1(float x) { return __int_as_float(max(__fl
 // ------------------------------------------------------------------------------------------
 // pack
 // ------------------------------------------------------------------------------------------
-__global__ void nca_pack_bf16(NcaLayout y, const float* __restrict__ prm, unsigned* __restrict__ out) {
+__device__ __forceinline__ void pack_bf16_body(const NcaLayout& y, const float* __restrict__ prm, unsigned* __restrict__ out) {
     const uint32_t total = y.packed_bytes / 4u;
     for (uint32_t wd = blockIdx.x * blockDim.x + threadIdx.x; wd < total; wd += gridDim.x * blockDim.x) {
         unsigned v = 0u;
@@ -227,6 +227,10 @@ __global__ void nca_pack_bf16(NcaLayout y, const float* __restrict__ prm, unsign
         out[wd] = v;
     }
 }
+__global__ void nca_pack_bf16(NcaLayout y, const float* __restrict__ prm, unsigned* __restrict__ out) { pack_bf16_body(y, prm, out); }
+// both nets of a composite render in one launch: blockIdx.y = net
+struct NcaPack2ArgsB { NcaLayout y[2]; const float* prm[2]; void* out[2]; };
+__global__ void nca_pack2_bf16(NcaPack2ArgsB a) { pack_bf16_body(a.y[blockIdx.y], a.prm[blockIdx.y], static_cast<unsigned*>(a.out[blockIdx.y])); }
 
 // ------------------------------------------------------------------------------------------
 // shared device helpers
@@ -1596,19 +1600,7 @@ __device__ __forceinline__ void wgrad_job_mx(const NcaWgradArgs& a, const NcaWgr
 __global__ __launch_bounds__(256) void nca_sum_tile_records(const char* dregion, int64_t wave_tile_bytes, int64_t dscale_off, int64_t ntiles, int net0, int net1, int F,
                                                             float* oslab) {
     __shared__ float part[256];
-    for (int net = net0; net < net1; ++net) {
-        float s = 0.f;
-        for (int64_t t = (int64_t)threadIdx.x * gridDim.x + blockIdx.x; t < ntiles; t += 256 * (int64_t)gridDim.x)
-            s += reinterpret_cast<const float*>(dregion + t * wave_tile_bytes + dscale_off)[2 + net];
-        part[threadIdx.x] = s;
-        __syncthreads();
-        for (int d = 128; d >= 1; d >>= 1) {
-            if ((int)threadIdx.x < d) part[threadIdx.x] += part[threadIdx.x + d];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) oslab[(int64_t)blockIdx.x * 2 * (F + 1) + net * (F + 1) + F] += part[0];
-        __syncthreads();
-    }
+    nca_tile_record_sum(dregion, wave_tile_bytes, dscale_off, ntiles, net0, net1, F, oslab, (int)blockIdx.x, (int)gridDim.x, part);
 }
 // n_wg: the workgroups of the dgrad launch of nets net0 .. net1 - 1 = the rows of oslab that hold their partials
 hipError_t nca_launch_sum_tile_records(const char* dregion, int64_t wave_tile_bytes, int64_t dscale_off, int64_t ntiles, int net0, int net1, int F, float* oslab, int n_wg,
@@ -1718,6 +1710,14 @@ hipError_t nca_launch_fused_bf16(int F, const NcaFusedArgs& a, int kmode, int gr
     return hipErrorInvalidValue;
 }
 
+hipError_t nca_launch_pack2_bf16(const NcaLayout& ya, const float* prm_a, void* out_a, const NcaLayout& yb, const float* prm_b, void* out_b, hipStream_t st) {
+    NcaPack2ArgsB a;
+    a.y[0] = ya; a.y[1] = yb; a.prm[0] = prm_a; a.prm[1] = prm_b; a.out[0] = out_a; a.out[1] = out_b;
+    const int total = (int)((ya.packed_bytes > yb.packed_bytes ? ya.packed_bytes : yb.packed_bytes) / 4u);
+    const int grid = (total + 255) / 256;
+    hipLaunchKernelGGL(nca_pack2_bf16, dim3(grid > 1024 ? 1024 : grid, 2), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
 hipError_t nca_launch_pack_bf16(const NcaLayout& y, const float* prm, void* out, hipStream_t st) {
     const int total = (int)(y.packed_bytes / 4u);
     const int grid = (total + 255) / 256;

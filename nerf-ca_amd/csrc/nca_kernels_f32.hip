@@ -16,6 +16,7 @@
 // of one ray (lane&31 = sample, lane>>5 = k-half), a 32x32 accumulator tile per 32 features.  A
 // layer's output registers are the next layer's B operand in place (see nca_layout.hpp).
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <cstdlib>
 #include "nca_kernels.hpp"
 
@@ -78,7 +79,7 @@ __device__ __forceinline__ unsigned x3_piece(float w, int p) {
 // ------------------------------------------------------------------------------------------
 // pack
 // ------------------------------------------------------------------------------------------
-__global__ void nca_pack_f32(NcaLayout y, const float* __restrict__ prm_, float* __restrict__ out) {
+__device__ __forceinline__ void pack_f32_body(const NcaLayout& y, const float* __restrict__ prm_, float* __restrict__ out) {
 #if NCA_ABL & (2 | 16)
     // (ablation: weights of the F-wide layers as the bf16 mode sees them; biases, Wo and bo stay f32 there too)
     struct Rounded {
@@ -207,6 +208,10 @@ __global__ void nca_pack_f32(NcaLayout y, const float* __restrict__ prm_, float*
         out[e] = v;
     }
 }
+__global__ void nca_pack_f32(NcaLayout y, const float* __restrict__ prm, float* __restrict__ out) { pack_f32_body(y, prm, out); }
+// both nets of a composite render in one launch: blockIdx.y = net
+struct NcaPack2Args { NcaLayout y[2]; const float* prm[2]; void* out[2]; };
+__global__ void nca_pack2_f32(NcaPack2Args a) { pack_f32_body(a.y[blockIdx.y], a.prm[blockIdx.y], static_cast<float*>(a.out[blockIdx.y])); }
 
 // ------------------------------------------------------------------------------------------
 // device helpers
@@ -491,7 +496,10 @@ __device__ __forceinline__ void stage_publish_counted(bool stores_issued) {
 #ifndef NCA_F32_MINBLOCKS
 #define NCA_F32_MINBLOCKS 2     // (1 with NCA_WAVES=4: one 512-register wave per SIMD -- tools/variant_build_all.sh, timing experiment)
 #endif
-template <int F, int MODE, bool X3>
+// SKIP: some net of the launch has a skip layer (CPPN with num_late_layers > 0, model/CPPN.py:53-58, 102-106): its encoded-input pass runs with the
+// previous layer's output live.  The nets the reference ships have none; their instantiation (SKIP = false) has no encoding inside the
+// hidden-layer loop and needs no spill for it (profiles/r06_kernel_resources.txt).
+template <int F, int MODE, bool X3, bool SKIP>
 __global__ __launch_bounds__(NCA_NT, NCA_F32_MINBLOCKS) void nca_fused_f32(const NcaFusedArgs a) {
     constexpr bool BWD = MODE == NCA_KM_BWD || MODE == NCA_KM_BWD_STORED;
     constexpr bool STORE = MODE == NCA_KM_BWD || MODE == NCA_KM_FWD_STORE;
@@ -676,129 +684,30 @@ __global__ __launch_bounds__(NCA_NT, NCA_F32_MINBLOCKS) void nca_fused_f32(const
             };
 
             // ================= forward (recompute) ==========================================
-            for (int jj = 0; RECOMP && jj < y.NL; ++jj) {
-                const NcaLayerL& l = y.layer[jj];
-                // DMA the next image into the other buffer while this layer computes
-                const int nsi = (si + 1 == a.nstages) ? 0 : si + 1;
-                int nsi_final = nsi;
-                stage_issue(a.stage[nsi], smem + (cur ^ 1) * BUF, wave, lane);
-                const float* img = reinterpret_cast<const float*>(smem + cur * BUF);
-                const float* imgl = img + lane * MT;
-                // bias tail: behind the k-steps of this image (a skip layer's first image holds only its encoded part)
-                const bool x3h = X3 && l.kind == NCA_IN_HID;     // this layer's contraction runs on the bf16 matrix cores (x3)
-                constexpr int X3_SUB = 3 * MT * (MT >= 2 ? MT : 2 * MT) * 256;          // floats of fragments in an x3 sub-stage
-                const float* tail = img + (x3h ? X3_SUB : (l.kind == NCA_IN_SKIP ? l.ksteps_enc : l.ksteps) * 64 * MT);
-                const float* wo_tail = tail + 2 * MT * 16;     // Wo, bo (last layer); re-pointed for two-stage layers below
-
-                f32x16 acc[MT];
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[m][i] = tail[(lh * MT + m) * 16 + i];
-
-                if (l.kind != NCA_IN_HID) {
-                    float* const henc = hc;   // rows [0, K0rows_pad)
-                    enc_steps(y, p, cwin, cfour, lat, [&](int s, float fa, float fb) {
-                        const float bop = abl<1>(lh ? fb : fa);
-                        float av[MT];
-                        load_a<MT>(imgl + s * 64 * MT, av);
-#pragma unroll
-                        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bop, acc[m], 0, 0, 0);
-                        if (STORE && jj == 0 && tvalid) {
-                            int ia, ib;
-                            nca_enc_pair(y, s, &ia, &ib);
-                            const int row = lh ? ib : ia;
-                            if (row >= 0) __builtin_nontemporal_store(abl<32>(bop), henc + row * 32);
-                        }
-                    });
-                    if (STORE && jj == 0 && y.P > 0 && tvalid) {
-                        // one-hot phase rows: their "weight gradient" is sum_n [phase_n = p] D0[:, n]
-                        for (int pp = lh; pp < y.P; pp += 2) __builtin_nontemporal_store((pp == phc) ? 1.f : 0.f, henc + (y.K0 + pp) * 32);
+            // One layer.  FIRST (layer 0, always an encoded-input layer) is its own instantiation, called ahead of the loop over the
+            // others: inside ONE loop over all layers the previous layer's output (hprev, 16 MT registers that layer 0 never reads) is
+            // live across the loop header and sits in registers through the f64 encoding of layer 0 -- that, not the contractions,
+            // is where the f32 kernels spilled 56 - 119 VGPRs (tools/isa_spills.py: the scratch operations sit between the chains).
+            if (RECOMP) {
+                if constexpr (SKIP) {          // (a net with a skip layer encodes inside the loop anyway: one loop over all layers, as before round 6)
+                    for (int jj = 0; jj < y.NL; ++jj) {
+                        constexpr bool FIRST = false;
+#define NCA_LAYER_KIND l.kind
+#include "nca_f32_layer.inc"
+#undef NCA_LAYER_KIND
                     }
+                } else {
+                    // (the lambda is defined HERE, not ahead of the branch: a by-reference closure that exists in the SKIP instantiation too --
+                    // even unused -- takes the addresses of hprev / raw / cur / si and cost that kernel 306 instead of 119 spilled registers)
+                    auto forward_layer = [&](int jj, auto first_c) __attribute__((always_inline)) {
+                        constexpr bool FIRST = decltype(first_c)::value;
+#define NCA_LAYER_KIND (FIRST ? (int)NCA_IN_ENC : (int)NCA_IN_HID)          /* layer 0 is the encoded-input layer by construction (nca_build_layout); without a skip layer every other one is hidden-width */
+#include "nca_f32_layer.inc"
+#undef NCA_LAYER_KIND
+                    };
+                    forward_layer(0, std::true_type{});
+                    for (int jj = 1; jj < y.NL; ++jj) forward_layer(jj, std::false_type{});
                 }
-                if (l.kind == NCA_IN_SKIP) {
-                    // second stage of the skip layer: publish the hidden-part image, prefetch the one after it
-                    stage_publish();
-                    cur ^= 1;
-                    si = nsi;
-                    const int nsi2 = (si + 1 == a.nstages) ? 0 : si + 1;
-                    stage_issue(a.stage[nsi2], smem + (cur ^ 1) * BUF, wave, lane);
-                    const float* img2 = reinterpret_cast<const float*>(smem + cur * BUF);
-                    hidden_steps<MT>(img2 + lane * MT, hprev, acc, hf + (y.K0rows_pad + (jj - 1) * F) * 32, STORE && tvalid); // stores H_{jj-1}
-                    wo_tail = img2 + (l.ksteps - l.ksteps_enc) * 64 * MT;
-                    nsi_final = nsi2;
-                } else if (x3h) {
-                    constexpr int KH = MT >= 2 ? MT : 2 * MT;          // k-steps per sub-stage
-                    if (STORE && tvalid) x3_store_block<MT, 32>(hf + (y.K0rows_pad + (jj - 1) * F) * 32, hprev);                  // H_{jj-1}
-                    x3_sub<MT, KH, 0>(reinterpret_cast<const char*>(img) + lane * 16, hprev, acc);
-                    if (MT >= 2) {
-                        // second sub-stage (the other half of the k-steps): publish its image, prefetch the one after it.  The
-                        // H stores above are younger than this sub-stage's DMA: wait for the DMA, not for them
-                        if (STORE) stage_publish_counted<4 * MT>(tvalid);
-                        else stage_publish();
-                        cur ^= 1;
-                        si = nsi;
-                        const int nsi2 = (si + 1 == a.nstages) ? 0 : si + 1;
-                        stage_issue(a.stage[nsi2], smem + (cur ^ 1) * BUF, wave, lane);
-                        const float* img2 = reinterpret_cast<const float*>(smem + cur * BUF);
-                        x3_sub<MT, KH, KH>(reinterpret_cast<const char*>(img2) + lane * 16, hprev, acc);
-                        wo_tail = img2 + X3_SUB;
-                        nsi_final = nsi2;
-                    }
-                } else if (l.kind != NCA_IN_ENC) {
-                    hidden_steps<MT>(imgl, hprev, acc, hf + (y.K0rows_pad + (jj - 1) * F) * 32, STORE && tvalid);          // stores H_{jj-1}
-                }
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) hprev[m][i] = abl<4>(fmaxf(acc[m][i], 0.f));
-
-                if (((MODE == NCA_KM_BWD && a.mask_layers > 0) || FSTORE) && jj + 1 < y.NL) {
-                    // ReLU mask of this layer's output for the dgrad sweep: bit 16 (m & 1) + i of word m >> 1 <-> acc[m][i]
-                    unsigned mw[2] = {0u, 0u};
-#pragma unroll
-                    for (int m = 0; m < MT; ++m)
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) mw[m >> 1] |= (hprev[m][i] > 0.f ? 1u : 0u) << (16 * (m & 1) + i);
-                    if (FSTORE) { if (tvalid) __builtin_nontemporal_store(((unsigned long long)mw[1] << 32) | mw[0], reinterpret_cast<unsigned long long*>(mglob + jj * 512)); }
-                    else *reinterpret_cast<uint2*>(maskbase + ((wave * a.mask_layers + jj) * 64 + lane) * 8) = make_uint2(mw[0], mw[1]);
-                }
-                if (jj == y.NL - 1) {
-                    // output layer F -> 1 from the image tail (model/CPPN.py:108)
-                    const float* wo = wo_tail;
-                    float part = 0.f;
-#pragma unroll
-                    for (int m = 0; m < MT; ++m)
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) part = fmaf(wo[(lh * MT + m) * 16 + i], hprev[m][i], part);
-                    part += __shfl_xor(part, 32);
-                    raw[net] = part + wo[2 * MT * 16];
-                    if (FSTORE && tvalid) {
-                        // what the backward from the store cannot get from a later contraction: the last hidden layer's
-                        // output (block NL-1 of the H region) and the raw output
-                        float* hl = hf + (y.K0rows_pad + (y.NL - 1) * F) * 32;
-                        asm volatile("" : "+v"(hl));
-#pragma unroll
-                        for (int m = 0; m < MT; ++m)
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) store_quad(hl + (m * 4 + q) * 256, abl<32>(hprev[m][4 * q]), abl<32>(hprev[m][4 * q + 1]), abl<32>(hprev[m][4 * q + 2]), abl<32>(hprev[m][4 * q + 3]));
-                        if (lh == 0) __builtin_nontemporal_store(raw[net], rglob);
-                    }
-
-                    if (MODE == NCA_KM_BWD) last_layer_grads(wo);
-                }
-
-                // hidden layers of the storing modes: at least 4 MT stores (H_{jj-1}, inside the contraction) follow the DMA
-                // (x3 layers of two sub-stages issued their last DMA AFTER those stores: plain wait)
-                if (STORE && l.kind == NCA_IN_HID && !(x3h && MT >= 2)) stage_publish_counted<4 * MT>(tvalid);
-                else if (FSTORE && x3h && MT >= 2) {
-                    // younger than the second sub-stage's DMA: the mask store, or (last layer) the H_last quads + the raw output
-                    if (jj + 1 < y.NL) stage_publish_counted<1>(tvalid);
-                    else stage_publish_counted<4 * MT + 1>(tvalid);
-                }
-                else stage_publish();
-                cur ^= 1;
-                si = nsi_final;
             }
 
             if (STORED) {
@@ -1244,8 +1153,8 @@ __global__ __launch_bounds__(256, 2) void nca_wgrad_f32x3(const NcaWgradArgs a) 
 // ------------------------------------------------------------------------------------------
 // reduce: natural flat gradients from the split slabs (fixed summation order)
 // ------------------------------------------------------------------------------------------
-__global__ void nca_reduce_f32(const NcaReduceArgs a) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void reduce_body(const NcaReduceArgs& a, int64_t blk) {
+    const int64_t e = blk * 256 + threadIdx.x;
     if (e >= a.n_total) return;
     const int net = e < a.n_params[0] ? 0 : 1;
     const int64_t le = net == 0 ? e : e - a.n_params[0];
@@ -1323,8 +1232,8 @@ __global__ __launch_bounds__(256) void nca_reduce_small_f32(const NcaReduceArgs 
 }
 
 // Dsum[f][p] = sum over splits of the one-hot block, written in place into slab 0 (fixed order)
-__global__ void nca_onehot_sum_f32(const NcaReduceArgs a) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void onehot_body(const NcaReduceArgs& a, int64_t blk) {
+    const int64_t e = blk * 256 + threadIdx.x;
     for (int net = 0; net < 2; ++net) {
         const NcaReduceNet& rn = a.net[net];
         const int64_t cnt = (int64_t)rn.F * rn.P;
@@ -1341,6 +1250,18 @@ __global__ void nca_onehot_sum_f32(const NcaReduceArgs a) {
     }
 }
 
+// ONE launch for the three independent sums of a backward's tail: workgroups [0, nb_red) sum the split slabs into the natural gradients,
+// [nb_red, nb_red + nb_hot) sum the one-hot block over the splits, the rest (a one-chunk backward from a store) add the tile records'
+// output-bias sums to oslab.  nca_reduce_small_f32, launched next, reads what all three left.  (At the reference's default batch a step is
+// ~0.7 ms: three launches of ~5 us each were 2 % of it.)
+__global__ __launch_bounds__(256) void nca_reduce_f32(const NcaReduceArgs a, int nb_red, int nb_hot) {
+    __shared__ float part[256];
+    const int b = blockIdx.x;
+    if (b < nb_red) reduce_body(a, b);
+    else if (b < nb_red + nb_hot) onehot_body(a, b - nb_red);
+    else nca_tile_record_sum(a.rec_region, a.rec_tile_bytes, a.rec_off, a.rec_ntiles, a.rec_net0, a.rec_net1, a.rec_F, a.rec_oslab, b - nb_red - nb_hot, a.rec_nwg, part);
+}
+
 // pix[r] = I0[r] - sum_c part[r][c]   (model_helpers.py:82 / 95)
 __global__ void nca_pix_f32(int64_t R, int nchunk, const float* __restrict__ I0, const double* __restrict__ part, double* __restrict__ pix) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1353,8 +1274,8 @@ __global__ void nca_pix_f32(int64_t R, int nchunk, const float* __restrict__ I0,
 // ------------------------------------------------------------------------------------------
 // launchers (called from nca_api.cpp)
 // ------------------------------------------------------------------------------------------
-template <int F, int MODE, bool X3>
-static hipError_t launch_fused_mode(const NcaFusedArgs& a_in, int grid, hipStream_t st) {
+template <int F, int MODE, bool X3, bool SKIP>
+static hipError_t launch_fused_mode_s(const NcaFusedArgs& a_in, int grid, hipStream_t st) {
     constexpr bool bwd = MODE == NCA_KM_BWD || MODE == NCA_KM_BWD_STORED;
     NcaFusedArgs a = a_in;
     // constant area sized to the latents actually present (the cap of 2048 floats per net is rarely needed) ...
@@ -1373,9 +1294,16 @@ static hipError_t launch_fused_mode(const NcaFusedArgs& a_in, int grid, hipStrea
         if (ml > 0 && lds + need <= 160 * 1024) { a.mask_layers = ml; lds += need; }
     }
     if (MODE == NCA_KM_BWD_STORED) lds += 2 * (2 * FusedCfg<F>::MT * 16 + 16) * sizeof(float);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_fused_f32<F, MODE, X3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((nca_fused_f32<F, MODE, X3>), dim3(grid), dim3(NCA_NT), lds, st, a);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_fused_f32<F, MODE, X3, SKIP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((nca_fused_f32<F, MODE, X3, SKIP>), dim3(grid), dim3(NCA_NT), lds, st, a);
     return hipGetLastError();
+}
+template <int F, int MODE, bool X3>
+static hipError_t launch_fused_mode(const NcaFusedArgs& a, int grid, hipStream_t st) {
+    bool skip = false;
+    for (int n = 0; n < a.nnets; ++n)
+        for (int j = 0; j < a.net[n].lay.NL; ++j) skip = skip || a.net[n].lay.layer[j].kind == NCA_IN_SKIP;
+    return skip ? launch_fused_mode_s<F, MODE, X3, true>(a, grid, st) : launch_fused_mode_s<F, MODE, X3, false>(a, grid, st);
 }
 template <int F, bool X3>
 static hipError_t launch_fused_x(const NcaFusedArgs& a, int kmode, int grid, hipStream_t st) {
@@ -1409,6 +1337,15 @@ hipError_t nca_launch_pack_f32(const NcaLayout& y, const float* prm, void* out, 
     return hipGetLastError();
 }
 
+hipError_t nca_launch_pack2_f32(const NcaLayout& ya, const float* prm_a, void* out_a, const NcaLayout& yb, const float* prm_b, void* out_b, hipStream_t st) {
+    NcaPack2Args a;
+    a.y[0] = ya; a.y[1] = yb; a.prm[0] = prm_a; a.prm[1] = prm_b; a.out[0] = out_a; a.out[1] = out_b;
+    const int total = (int)((ya.packed_bytes > yb.packed_bytes ? ya.packed_bytes : yb.packed_bytes) / 4u);
+    const int grid = (total + 255) / 256;
+    hipLaunchKernelGGL(nca_pack2_f32, dim3(grid > 1024 ? 1024 : grid, 2), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
 hipError_t nca_launch_wgrad_f32(const NcaWgradArgs& a, int nsplit, hipStream_t st) {
     static const bool plain = getenv("NCA_WGRAD_F32") != nullptr && getenv("NCA_WGRAD_F32")[0] == 'p';   // NCA_WGRAD_F32=plain: A/B switch
     if (!plain) {
@@ -1426,9 +1363,8 @@ hipError_t nca_launch_wgrad_f32(const NcaWgradArgs& a, int nsplit, hipStream_t s
 hipError_t nca_launch_reduce_f32(const NcaReduceArgs& a, hipStream_t st) {
     int64_t hot = 0;
     for (int n = 0; n < 2; ++n) if (a.net[n].grads && (int64_t)a.net[n].F * a.net[n].P > hot) hot = (int64_t)a.net[n].F * a.net[n].P;
-    if (hot > 0) hipLaunchKernelGGL(nca_onehot_sum_f32, dim3((int)((hot + 255) / 256)), dim3(256), 0, st, a);
-    const int grid = (int)((a.n_total + 255) / 256);
-    hipLaunchKernelGGL(nca_reduce_f32, dim3(grid), dim3(256), 0, st, a);
+    const int nb_hot = (int)((hot + 255) / 256), nb_red = (int)((a.n_total + 255) / 256), nb_rec = a.rec_region ? a.rec_nwg : 0;
+    hipLaunchKernelGGL(nca_reduce_f32, dim3(nb_red + nb_hot + nb_rec), dim3(256), 0, st, a, nb_red, nb_hot);
     int64_t small = 0;
     for (int n = 0; n < 2; ++n) if (a.net[n].grads) small += a.net[n].lat_count + a.net[n].F + 1;
     if (small > 0) hipLaunchKernelGGL(nca_reduce_small_f32, dim3((int)((small + 3) / 4)), dim3(256), 0, st, a);

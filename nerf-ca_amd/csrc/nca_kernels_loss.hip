@@ -11,6 +11,7 @@
 // one finishing block, all in fixed order (bit-reproducible, no atomics).
 #include <hip/hip_runtime.h>
 #include "nca_kernels.hpp"
+#include "nca_rng.hpp"
 
 #define LOSS_WAVES 4
 #define LOSS_NT (64 * LOSS_WAVES)
@@ -107,7 +108,15 @@ __global__ __launch_bounds__(LOSS_NT) void nca_loss_rays(const NcaLossArgs a) {
         const int mask_s = Ms < a.mask_thre ? 0 : 1;
         int mask_d = Md < a.mask_thre ? 0 : 1;
         if (a.use_weighting && wr > 1.0 + a.weighted_thresh) mask_d = 1;
-        const double diff = a.pix ? a.pix[r] - a.gt[r] : 0.0;      // (no pixel term in term-gradient mode: weighted_MSELoss is its own function)
+        // pix: the caller's, or formed here from the forward's per-tile ray sums (same order as nca_pix_f32: bit-identical)
+        double pix_r = 0.0;
+        if (a.ray_part) {
+            double sum = 0.0;
+            for (int c = 0; c < a.ray_nchunk; ++c) sum += a.ray_part[r * a.ray_nchunk + c];
+            pix_r = (double)a.ray_I0[r] - sum;
+            if (a.pix_out && lane == 0) a.pix_out[r] = pix_r;
+        } else if (a.pix) pix_r = a.pix[r];
+        const double diff = (a.ray_part || a.pix) ? pix_r - a.gt[r] : 0.0;      // (no pixel term in term-gradient mode: weighted_MSELoss is its own function)
         // ---- gradients ------------------------------------------------------------------------------------
         const double wm = a.unit_mse ? 1.0 : wr;           // (fine pass: unit pixel weights, weighted regularisers)
         if (a.g_pix && lane == 0) a.g_pix[r] = 2.0 * wm * diff * a.inv_R;
@@ -257,6 +266,8 @@ __global__ __launch_bounds__(LOSS_FIN_NT) void nca_loss_finish(const NcaLossArgs
         const double w_favor = a.weights_dev ? a.weights_dev[0] : a.w_favor, w_dent = a.weights_dev ? a.weights_dev[1] : a.w_dent;
         const double w_occl = a.weights_dev ? a.weights_dev[2] : a.w_occl, w_l1 = a.weights_dev ? a.weights_dev[3] : a.w_l1;
         t[T_LOSS] = t[T_PIXEL] + w_favor * t[T_FAVOR] + w_dent * t[T_DENT] + w_occl * t[T_OCCL] + w_l1 * t[T_L2] + w_l1 * t[T_L1];
+        if (a.terms_f32)
+            for (int k = 0; k < T_COUNT; ++k) a.terms_f32[k] = (float)t[k];
     }
 }
 
@@ -418,8 +429,20 @@ __global__ __launch_bounds__(256) void nca_adam_k(const NcaAdamArgs a) {
         m[i] = mi; v[i] = vi;
         p[i] = p[i] - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
     }
+    // the tick: every workgroup read step[0] when it started; the last one to finish increments it (and the training iteration), and
+    // leaves the arrival counter step[1] at zero for the next launch -- one launch instead of an update and a one-thread kernel
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned total = gridDim.x * gridDim.y;
+        unsigned* arrived = reinterpret_cast<unsigned*>(a.step + 1);
+        if (atomicAdd(arrived, 1u) == total - 1u) {
+            *arrived = 0u;
+            a.step[0] = done + 1;
+            if (a.iter_counter) *a.iter_counter += 1;
+        }
+    }
 }
-__global__ void nca_adam_tick(int64_t* step) { *step += 1; }
 
 hipError_t nca_launch_adam(const NcaAdamArgs& a, hipStream_t st) {
     int64_t nmax = 0;
@@ -427,7 +450,6 @@ hipError_t nca_launch_adam(const NcaAdamArgs& a, hipStream_t st) {
     int gx = (int)((nmax + 255) / 256);
     gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
     hipLaunchKernelGGL(nca_adam_k, dim3(gx, a.n_seg), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(nca_adam_tick, dim3(1), dim3(1), 0, st, a.step);
     return hipGetLastError();
 }
 
@@ -473,6 +495,115 @@ hipError_t nca_launch_prepare_batch(int64_t R, int S, const int64_t* ids, const 
                                     double* o, double* d, double* gt, double* w, int32_t* ph, float* z, double* dists, hipStream_t st) {
     const int64_t n = R > S ? R : S;
     hipLaunchKernelGGL(nca_prepare_batch_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, R, S, ids, table, phases, n_rows, bad_ids, depth, t_rand, o, d, gt, w, ph, z, dists);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Per-step sampling and schedules on the device (include/nerfca_hip.h "per-step batch sampling"; csrc/nca_rng.hpp): the importance
+// sampling of run_composite.py:250-260, the jitter draw of model_helpers.py:8, the FreeNeRF windows of CPPN.py:144-159 and the
+// four linear_param_decay weights of run_composite.py:276-279, all as functions of (seed, iteration).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t sampler_iter(const NcaSampler& s) { return s.n_iter + (s.iter_dev ? *s.iter_dev : (int64_t)0); }
+
+// the ray id of slot `slot` of the global batch
+__device__ __forceinline__ int64_t draw_ray_id(const NcaSampler& s, int64_t it, int64_t slot, int half, const NcaPermKeys& keys) {
+    const NcaU4 r = nca_rng_words(s.seed, it, NCA_RNG_STREAM_IDS, (uint64_t)slot);
+    if (s.n_var > 0 && s.n_var_ids > 0) {
+        const bool var = nca_perm((uint64_t)slot, (uint64_t)s.R_global, half, keys) < (uint64_t)s.n_var;
+        return var ? s.var_ids[nca_rng_below(r.x, r.y, (uint64_t)s.n_var_ids)] : s.non_var_ids[nca_rng_below(r.x, r.y, (uint64_t)s.n_non_var_ids)];
+    }
+    return (int64_t)nca_rng_below(r.x, r.y, (uint64_t)s.n_rows);
+}
+
+__global__ __launch_bounds__(256) void nca_draw_ray_ids_k(const NcaSampler s, int64_t slot0, int64_t R, int64_t* __restrict__ ids) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= R) return;
+    const int64_t it = sampler_iter(s);
+    const NcaPermKeys keys = nca_perm_keys(s.seed, it);
+    ids[i] = draw_ray_id(s, it, slot0 + i, nca_perm_half_bits((uint64_t)s.R_global), keys);
+}
+__global__ __launch_bounds__(256) void nca_draw_uniform_k(const NcaSampler s, int stream_id, int64_t n, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    out[i] = nca_rng_unit(nca_rng_words(s.seed, sampler_iter(s), stream_id, (uint64_t)i).x);
+}
+hipError_t nca_launch_draw_ray_ids(const NcaSampler& s, int64_t slot0, int64_t R, int64_t* ids, hipStream_t st) {
+    hipLaunchKernelGGL(nca_draw_ray_ids_k, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, s, slot0, R, ids);
+    return hipGetLastError();
+}
+hipError_t nca_launch_draw_uniform(const NcaSampler& s, int stream_id, int64_t n, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(nca_draw_uniform_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s, stream_id, n, out);
+    return hipGetLastError();
+}
+
+// update_freq_mask_alpha (model/CPPN.py:144-159; nerf-ca_amd/schedules.py:freq_mask): element k of the band window at iteration `it`, in the
+// host schedule's arithmetic -- pointer = (L * it) / max + start in f64, clip to [1e-8, 1 - 1e-8] in f64, rounded to f32
+__device__ __forceinline__ float free_window_at(const NcaWindowSched& w, int64_t it, int k) {
+    if (it >= w.decay_steps) return 1.f;
+    const double pointer = (double)((int64_t)w.L * it) / (double)w.decay_steps + (double)w.window_start;
+    const int64_t whole = (int64_t)pointer;
+    double m = k < whole ? 1.0 : (k == whole ? pointer - (double)whole : 0.0);
+    m = fmin(fmax(m, 1e-8), 1.0 - 1e-8);
+    return (float)m;
+}
+// linear_param_decay (train/model_helpers.py:264-269) in the host's f64 arithmetic
+__device__ __forceinline__ double linear_decay_at(const NcaWeightSched& w, int64_t it) {
+    if (it < w.delay) return 0.0;
+    const double a = fmin((double)(it - w.delay) / (double)w.steps, 1.0);
+    return (1.0 - a) * w.start + a * w.end;
+}
+
+__global__ __launch_bounds__(256) void nca_begin_step_k(const NcaBeginArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t it = sampler_iter(a.s);
+    const int S = a.S;
+    auto t_of = [&](int k) { return a.t_rand_in ? a.t_rand_in[k] : nca_rng_unit(nca_rng_words(a.s.seed, it, NCA_RNG_STREAM_JITTER, (uint64_t)k).x); };
+    auto jitter = [&](int k, float t) {
+        // mid = 0.5 * (z[1:] + z[:-1]); hi = cat(mid, z[-1:]); lo = cat(z[:1], mid); z' = lo + (hi - lo) * t   (model_helpers.py:3-12)
+        const float hi = k + 1 < S ? __fmul_rn(0.5f, __fadd_rn(a.depth[k + 1], a.depth[k])) : a.depth[S - 1];
+        const float lo = k > 0 ? __fmul_rn(0.5f, __fadd_rn(a.depth[k], a.depth[k - 1])) : a.depth[0];
+        return __fadd_rn(lo, __fmul_rn(__fsub_rn(hi, lo), t));
+    };
+    if (i < S) {
+        const int k = (int)i;
+        const float tk = t_of(k);
+        const float zk = jitter(k, tk);
+        a.z[k] = zk;
+        a.dists[k] = k + 1 < S ? (double)__fsub_rn(jitter(k + 1, t_of(k + 1)), zk) : 1e-10;
+        if (a.t_rand_out) a.t_rand_out[k] = tk;
+    }
+    if (blockIdx.x == gridDim.x - 1) {        // schedules: the last workgroup's threads (windows: 64 per vector; weights: threads 0..3 of the last 64)
+        const int t = threadIdx.x;
+        if (t < 64 * a.sch.n_windows) {
+            const NcaWindowSched& w = a.sch.window[t >> 6];
+            const int k = t & 63;
+            if (w.kind == NCA_WINDOW_FREE && w.out && k < w.L) w.out[k] = free_window_at(w, it, k);
+        }
+        if (a.sch.weights_out && t >= 252) a.sch.weights_out[t - 252] = linear_decay_at(a.sch.weight[t - 252], it);
+    }
+    if (i < a.R) {
+        int64_t id;
+        if (a.ids_in) id = a.ids_in[i];
+        else {
+            const NcaPermKeys keys = nca_perm_keys(a.s.seed, it);
+            id = draw_ray_id(a.s, it, a.slot0 + i, nca_perm_half_bits((uint64_t)a.s.R_global), keys);
+        }
+        if (a.ids_out) a.ids_out[i] = id;
+        if (a.s.n_rows > 0 && (id < 0 || id >= a.s.n_rows)) {          // never reaches memory: clamped, and counted for the caller
+            if (a.bad_ids) atomicAdd(a.bad_ids, 1);
+            id = id < 0 ? 0 : a.s.n_rows - 1;
+        }
+        const double* row = a.table + id * 12;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { a.o[i * 3 + c] = row[c]; a.d[i * 3 + c] = row[3 + c]; }
+        a.gt[i] = row[6];
+        a.w[i] = row[9];
+        a.ph[i] = (int32_t)a.phases[id];
+    }
+}
+hipError_t nca_launch_begin_step(const NcaBeginArgs& a, hipStream_t st) {
+    const int64_t n = a.R > a.S ? a.R : a.S;
+    hipLaunchKernelGGL(nca_begin_step_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

@@ -221,6 +221,24 @@ class FieldBinding:
         check(lib.nca_pack_weights(C.byref(self.net), ptr(self.flat), ptr(self.packed), self.prec, _stream()))
         return self.packed
 
+    @staticmethod
+    def ensure_packed_pair(bs: "FieldBinding", bd: "FieldBinding"):
+        """``ensure_packed`` of both nets of a composite render in ONE launch (nca_pack_weights2)."""
+        if bs.prec != bd.prec or bs is bd:
+            return bs.ensure_packed(), bd.ensure_packed()
+        lib = _capi.lib()
+        for b in (bs, bd):
+            if not b._is_flat():
+                b.reflatten()
+            _require_cuda(b.flat, "network parameters")
+            if b.packed is None or b.packed.device != b.flat.device:
+                expect = check(lib.nca_param_count(C.byref(b.net)))
+                if expect != b.flat.numel():
+                    raise _capi.NcaError(f"parameter count mismatch: module has {b.flat.numel()}, descriptor expects {expect}")
+                b.packed = torch.empty(check(lib.nca_packed_bytes(C.byref(b.net), b.prec)), dtype=torch.uint8, device=b.flat.device)
+        check(lib.nca_pack_weights2(C.byref(bs.net), ptr(bs.flat), ptr(bs.packed), C.byref(bd.net), ptr(bd.flat), ptr(bd.packed), bs.prec, _stream()))
+        return bs.packed, bd.packed
+
     def split_grads(self, gflat: torch.Tensor) -> List[torch.Tensor]:
         out = []
         for off, (pad, shp) in zip(self._offsets, self._pads):
@@ -325,20 +343,32 @@ def forward_store_bytes(batch: _RayBatch, bs: FieldBinding, bd: Optional[FieldBi
     return check(_capi.lib().nca_render_store_bytes(C.byref(desc), C.byref(bs.net), C.byref(bd.net) if bd is not None else None, bs.prec))
 
 
-def render_forward_raw(batch: _RayBatch, bs: FieldBinding, bd: Optional[FieldBinding], for_backward: bool = False):
+class RaySums:
+    """What a forward called with ``want_pix=False`` returns in place of pix: the per-tile ray sums it left in its workspace (f64[R][nchunk])
+    and the rays' I0 -- ``fused_losses`` hands them to the loss kernel, which forms pix itself (one launch less per step)."""
+
+    def __init__(self, part: torch.Tensor, nchunk: int, I0: torch.Tensor):
+        self.part, self.nchunk, self.I0 = part, nchunk, I0
+
+
+def render_forward_raw(batch: _RayBatch, bs: FieldBinding, bd: Optional[FieldBinding], for_backward: bool = False, want_pix: bool = True):
     """Fused forward without autograd: returns (pix f64[R], sigma_s, sigma_d | None, keep) where ``keep``
     pins the packed weights / encoding buffers (and, with ``for_backward``, the forward store) the matching
-    backward must see."""
+    backward must see.  ``want_pix=False`` (nets of one width): pix is a ``RaySums`` for ``fused_losses`` instead of a tensor."""
     lib = _capi.lib()
     dev = batch.o.device
-    packed_s = bs.ensure_packed()
-    packed_d = bd.ensure_packed() if bd is not None else None
+    if bd is not None:
+        packed_s, packed_d = FieldBinding.ensure_packed_pair(bs, bd)
+    else:
+        packed_s, packed_d = bs.ensure_packed(), None
     win_s, four_s = bs.module._enc_buffers()
     win_d, four_d = bd.module._enc_buffers() if bd is not None else (None, None)
     if bd is not None and win_s is not None and win_d is not None and win_s.data_ptr() != win_d.data_ptr() and _same_window(bs, bd):
         win_d = win_s      # one vector for both nets: the library then stores the encoded input once (see share_enc)
     R, S = batch.R, batch.S
-    pix = torch.empty(R, dtype=torch.float64, device=dev)
+    if bd is not None and bd.net.F != bs.net.F:
+        want_pix = True          # (nets of different width composite in a kernel of their own)
+    pix = torch.empty(R, dtype=torch.float64, device=dev) if want_pix else None
     sig_s = torch.empty((R, S), dtype=torch.float32, device=dev)
     sig_d = torch.empty((R, S), dtype=torch.float32, device=dev) if bd is not None else None
     desc = batch.desc()
@@ -370,19 +400,27 @@ def render_forward_raw(batch: _RayBatch, bs: FieldBinding, bd: Optional[FieldBin
                                    ptr(store), store.numel() if store is not None else 0, _stream()))
     if fmt == _capi.STORE_NONE:
         store = None          # the planner wrote no store (e.g. the options changed since it was sized): the backward recomputes
+    if not want_pix:
+        tile = 64 if bs.prec == _capi.PREC_BF16 else 32
+        pix = RaySums(work, (S + tile - 1) // tile, batch.I0)
     return pix, sig_s, sig_d, (packed_s, packed_d, win_s, four_s, win_d, four_d, store, fmt)
 
 
-def render_backward_raw(batch: _RayBatch, bs: FieldBinding, bd: Optional[FieldBinding], keep, g_pix, g_sig_s, g_sig_d, want_depth_grad: bool = False):
+def render_backward_raw(batch: _RayBatch, bs: FieldBinding, bd: Optional[FieldBinding], keep, g_pix, g_sig_s, g_sig_d, want_depth_grad: bool = False,
+                        out_s: Optional[torch.Tensor] = None, out_d: Optional[torch.Tensor] = None):
     """Fused backward (recompute + dgrad + wgrad + reduce): returns flat f32 gradients per net (and, with ``want_depth_grad``,
-    d loss / d depth f32[R,S] as a third value: the f32 path's nca_render_bwd_depth)."""
+    d loss / d depth f32[R,S] as a third value: the f32 path's nca_render_bwd_depth).  ``out_s`` / ``out_d``: caller-owned contiguous f32
+    buffers the gradients are written into (slices of ONE flat buffer: the step's all-reduce and Adam then need no concatenation)."""
     lib = _capi.lib()
     packed_s, packed_d, win_s, four_s, win_d, four_d, store, fmt = keep
     dev = batch.o.device
     gp = torch.zeros(batch.R, dtype=torch.float64, device=dev) if g_pix is None else g_pix.detach().to(torch.float64).contiguous()
     gs, gd = _f32c(g_sig_s), _f32c(g_sig_d)
-    grads_s = torch.empty(bs.flat.numel(), dtype=torch.float32, device=dev)
-    grads_d = torch.empty(bd.flat.numel(), dtype=torch.float32, device=dev) if bd is not None else None
+    for o_, b_ in ((out_s, bs), (out_d, bd)):
+        if o_ is not None and (b_ is None or o_.numel() != b_.flat.numel() or o_.dtype != torch.float32 or not o_.is_contiguous() or o_.device != dev):
+            raise _capi.NcaError("out_s / out_d must be contiguous f32 buffers of the nets' flat parameter counts on the rays' device")
+    grads_s = out_s if out_s is not None else torch.empty(bs.flat.numel(), dtype=torch.float32, device=dev)
+    grads_d = (out_d if out_d is not None else torch.empty(bd.flat.numel(), dtype=torch.float32, device=dev)) if bd is not None else None
     desc = batch.desc(store_format=fmt if store is not None else 0)
     net_d = C.byref(bd.net) if bd is not None else None
     work, wbytes = _alloc_workspace(lambda cap: check(lib.nca_render_bwd_workspace(C.byref(desc), C.byref(bs.net), net_d, bs.prec, cap)), dev)
@@ -453,7 +491,7 @@ class _RenderFn(torch.autograd.Function):
 
 
 def fused_losses(pix, gt, wpix, sig_s, sig_d, dists, run_args, weights, inv_R=None, want_grads=True, weights_dev=None, unit_mse=False,
-                 want_dists_grad=False):
+                 want_dists_grad=False, terms_f32: Optional[torch.Tensor] = None, pix_out: Optional[torch.Tensor] = None):
     """weighted MSE + compute_losses + the loss assembly of run_composite.py:287-292 in one HIP pass.
 
     ``weights`` = (favor_s_weight, dynamic_entro_weight, occl_weight, l1_weight) of this step.
@@ -469,7 +507,9 @@ def fused_losses(pix, gt, wpix, sig_s, sig_d, dists, run_args, weights, inv_R=No
     dev = sig_s.device
     R, S = sig_s.shape
     f64 = lambda t: t.detach().to(device=dev, dtype=torch.float64).contiguous()
-    pix, gt, wpix, dists = f64(pix), f64(gt), f64(wpix), f64(dists)
+    sums = pix if isinstance(pix, RaySums) else None
+    pix = None if sums is not None else f64(pix)
+    gt, wpix, dists = f64(gt), f64(wpix), f64(dists)
     ss, sd = _f32c(sig_s), _f32c(sig_d)
     desc = _capi.NcaLoss(R=R, S=S, use_weighting=1 if run_args.entro_use_weighting else 0, skew=float(run_args.skewness_val),
                          mask_thre=float(run_args.entro_mask_thre), weighted_thresh=float(run_args.entro_weighted_thresh),
@@ -480,6 +520,18 @@ def fused_losses(pix, gt, wpix, sig_s, sig_d, dists, run_args, weights, inv_R=No
         if weights_dev.dtype != torch.float64 or weights_dev.numel() != 4 or not weights_dev.is_cuda or not weights_dev.is_contiguous():
             raise _capi.NcaError("weights_dev must be a contiguous device f64[4]")
         desc.weights_dev = ptr(weights_dev)
+    if sums is not None:
+        if sums.part.numel() * sums.part.element_size() < R * sums.nchunk * 8 or sums.I0.shape[0] != R:
+            raise _capi.NcaError("RaySums does not belong to this batch")
+        desc.ray_part, desc.ray_I0, desc.ray_nchunk = ptr(sums.part), ptr(sums.I0), int(sums.nchunk)
+        if pix_out is not None:
+            if pix_out.dtype != torch.float64 or pix_out.numel() != R or not pix_out.is_contiguous() or pix_out.device != dev:
+                raise _capi.NcaError("pix_out must be a contiguous device f64[R]")
+            desc.pix_out = ptr(pix_out)
+    if terms_f32 is not None:
+        if terms_f32.dtype != torch.float32 or terms_f32.numel() != len(_capi.TERM_NAMES) or not terms_f32.is_contiguous() or terms_f32.device != dev:
+            raise _capi.NcaError("terms_f32 must be a contiguous device f32[13]")
+        desc.terms_f32 = ptr(terms_f32)
     terms = torch.empty(len(_capi.TERM_NAMES), dtype=torch.float64, device=dev)
     g_pix = g_s = g_d = None
     if want_grads:
@@ -748,23 +800,102 @@ def prepare_batch(ids: torch.Tensor, table: torch.Tensor, phases: torch.Tensor, 
     return o, d, gt, w, ph, z, dists
 
 
+class BatchSampler:
+    """The per-step batch sampler on the device (include/nerfca_hip.h "per-step batch sampling"): the importance sampling of
+    run_composite.py:250-260 and the uniform draws of the depth jitter as counter-based Philox streams of (seed, iteration) -- any slot
+    range of the global batch can be drawn on its own, and with ``iter_dev`` (device i64[1]) the iteration is read on the device, so a
+    captured graph replays consecutive steps without host work."""
+
+    def __init__(self, seed: int, R_global: int, n_var: int, var_ids, non_var_ids, n_rows: int, device):
+        self.device = device
+        as_dev = lambda a: torch.as_tensor(a, dtype=torch.int64).to(device).contiguous()
+        self.var_ids = as_dev(var_ids) if var_ids is not None and len(var_ids) > 0 else None
+        self.non_var_ids = as_dev(non_var_ids) if non_var_ids is not None and len(non_var_ids) > 0 else None
+        if self.var_ids is None:
+            n_var = 0
+        self.seed, self.R_global, self.n_var, self.n_rows = int(seed), int(R_global), int(n_var), int(n_rows)
+
+    def desc(self, n_iter: int, iter_dev: Optional[torch.Tensor] = None) -> "_capi.NcaSampler":
+        return _capi.NcaSampler(seed=self.seed & ((1 << 64) - 1), n_iter=int(n_iter), iter_dev=ptr(iter_dev), R_global=self.R_global, n_var=self.n_var,
+                                var_ids=ptr(self.var_ids), n_var_ids=0 if self.var_ids is None else self.var_ids.numel(),
+                                non_var_ids=ptr(self.non_var_ids), n_non_var_ids=0 if self.non_var_ids is None else self.non_var_ids.numel(),
+                                n_rows=self.n_rows)
+
+    def ray_ids(self, n_iter: int, slot0: int = 0, count: Optional[int] = None) -> torch.Tensor:
+        count = self.R_global - slot0 if count is None else count
+        ids = torch.empty(count, dtype=torch.int64, device=self.device)
+        d = self.desc(n_iter)
+        check(_capi.lib().nca_draw_ray_ids(C.byref(d), slot0, count, ptr(ids), _stream()))
+        return ids
+
+    def uniform(self, n_iter: int, n: int, stream_id: int = _capi.RNG_STREAM_JITTER) -> torch.Tensor:
+        out = torch.empty(n, dtype=torch.float32, device=self.device)
+        d = self.desc(n_iter)
+        check(_capi.lib().nca_draw_uniform(C.byref(d), stream_id, n, ptr(out), _stream()))
+        return out
+
+
+def begin_step(sampler: BatchSampler, n_iter: int, slot0: int, R: int, table: torch.Tensor, phases: torch.Tensor, depth: torch.Tensor,
+               iter_dev: Optional[torch.Tensor] = None, schedules: Optional["_capi.NcaSchedules"] = None, ids_in: Optional[torch.Tensor] = None,
+               t_rand_in: Optional[torch.Tensor] = None, bad_ids: Optional[torch.Tensor] = None, want_draws: bool = False):
+    """``prepare_batch`` with everything that changes from step to step made on the device in ONE launch (nca_begin_step): the ids of slots
+    ``slot0 .. slot0 + R - 1`` of the global batch (or ``ids_in``), the gather, the jitter draw (or ``t_rand_in``) with the jittered depths and
+    interval lengths, and -- ``schedules`` -- the band windows and loss weights of the iteration, written where the descriptor says.  Returns
+    ``(o, d, gt, w, ph, z, dists)`` and, with ``want_draws``, also ``ids`` and ``t_rand`` as drawn."""
+    _require_cuda(table, "the ray table")
+    dev = table.device
+    if table.dtype != torch.float64 or table.dim() != 3 or tuple(table.shape[1:]) != (4, 3) or not table.is_contiguous():
+        raise _capi.NcaError("begin_step takes the f64 ray table [N, 4, 3]")
+    if phases.dtype != torch.int64 or not phases.is_contiguous() or phases.shape[0] != table.shape[0]:
+        raise _capi.NcaError("begin_step takes one i64 phase per row of the ray table")
+    if ids_in is not None and (ids_in.dtype != torch.int64 or not ids_in.is_contiguous() or ids_in.shape[0] != R or ids_in.device != dev):
+        raise _capi.NcaError("ids_in must be a contiguous device i64[R]")
+    S = depth.shape[0]
+    dep = depth.detach().to(device=dev, dtype=torch.float32).contiguous()
+    tr = None if t_rand_in is None else t_rand_in.detach().to(device=dev, dtype=torch.float32).contiguous()
+    o = torch.empty((R, 3), dtype=torch.float64, device=dev)
+    d = torch.empty((R, 3), dtype=torch.float64, device=dev)
+    gt = torch.empty(R, dtype=torch.float64, device=dev)
+    w = torch.empty(R, dtype=torch.float64, device=dev)
+    ph = torch.empty(R, dtype=torch.int32, device=dev)
+    z = torch.empty(S, dtype=torch.float32, device=dev)
+    dists = torch.empty(S, dtype=torch.float64, device=dev)
+    ids_out = torch.empty(R, dtype=torch.int64, device=dev) if want_draws else None
+    t_out = torch.empty(S, dtype=torch.float32, device=dev) if want_draws else None
+    sd = sampler.desc(n_iter, iter_dev)
+    sd.n_rows = int(table.shape[0])
+    check(_capi.lib().nca_begin_step(C.byref(sd), slot0, R, S, C.byref(schedules) if schedules is not None else None, ptr(ids_in), ptr(tr),
+                                     ptr(table), ptr(phases), ptr(bad_ids), ptr(dep), ptr(o), ptr(d), ptr(gt), ptr(w), ptr(ph), ptr(z), ptr(dists),
+                                     ptr(ids_out), ptr(t_out), _stream()))
+    if want_draws:
+        return (o, d, gt, w, ph, z, dists), ids_out, t_out
+    return o, d, gt, w, ph, z, dists
+
+
 class FusedAdam:
     """torch.optim.Adam(lr) + LinearLR(1 -> end_factor over total_iters) of run_composite.py:209-215 as ONE library
     launch over the flat parameter buffers of the given models (order as given).  The step counter lives on the
     device, so the launch can be captured in a HIP graph and replayed; ``grads`` are flat f32 tensors per model."""
 
-    def __init__(self, models: Sequence[torch.nn.Module], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, end_factor=1.0, total_iters=0):
+    def __init__(self, models: Sequence[torch.nn.Module], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, end_factor=1.0, total_iters=0,
+                 iter_counter: Optional[torch.Tensor] = None):
+        """``iter_counter``: a device i64[1] the kernel increments together with its step count (the training iteration a captured step's
+        ``nca_begin_step`` reads)."""
         self.bindings = [m._binding for m in models]
         for b in self.bindings:
             if not b._is_flat():
                 b.reflatten()
             _require_cuda(b.flat, "network parameters")
         dev = self.bindings[0].flat.device
+        if iter_counter is not None and (iter_counter.dtype != torch.int64 or iter_counter.numel() != 1 or iter_counter.device != dev):
+            raise _capi.NcaError("iter_counter must be a device i64[1]")
+        self.iter_counter = iter_counter
         self.cfg = _capi.NcaAdam(lr=float(lr), beta1=float(betas[0]), beta2=float(betas[1]), eps=float(eps),
-                                 lr_end_factor=float(end_factor), lr_total_iters=int(total_iters))
+                                 lr_end_factor=float(end_factor), lr_total_iters=int(total_iters), iter_counter=ptr(iter_counter))
         self.exp_avg = [torch.zeros_like(b.flat) for b in self.bindings]
         self.exp_avg_sq = [torch.zeros_like(b.flat) for b in self.bindings]
-        self.step_count = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._step = torch.zeros(2, dtype=torch.int64, device=dev)      # [steps taken, the launch's arrival counter (zero between launches)]
+        self.step_count = self._step[:1]
 
     def step(self, grads: Sequence[torch.Tensor]) -> None:
         k = len(self.bindings)
@@ -776,7 +907,7 @@ class FusedAdam:
         arr = lambda ts: (C.c_void_p * k)(*[t.data_ptr() for t in ts])
         n = (C.c_int64 * k)(*[b.flat.numel() for b in self.bindings])
         check(_capi.lib().nca_adam_step(C.byref(self.cfg), k, n, arr([b.flat for b in self.bindings]), arr(grads), arr(self.exp_avg),
-                                        arr(self.exp_avg_sq), ptr(self.step_count), _stream()))
+                                        arr(self.exp_avg_sq), ptr(self._step), _stream()))
         for b in self.bindings:          # (bias slots of a net without biases stay zero)
             b.zero_gaps(b.flat)
 

@@ -125,6 +125,12 @@ class CompositeTrainer:
         if fused_loss is None:             # default on the GPU: the autograd-free step with the HIP loss kernel (step_fused);
             fused_loss = on_cuda           # fused_loss=False: the reference's loss FUNCTIONS (model_helpers.compute_losses, HIP behind them) under autograd
         self.fused_loss = bool(fused_loss)
+        import os
+        # A ray id outside the table raises in the reference (NumPy's IndexError, run_composite.py:262).  The library clamps and counts; the
+        # host-launched steps read the counter EVERY step (one device read beside ~20 launches) and raise; NERFCA_STRICT=0 defers the check to
+        # the syncing calls (early_stop / evaluate), which is also what the graph-replayed step does (nothing may synchronise inside it).
+        self.strict_ids = os.environ.get("NERFCA_STRICT", "1") != "0"
+        self.sampler = None                # fused.BatchSampler: the device-side Philox streams of (seed, iteration) -- created at first use on the GPU
         self.stop_flag = None              # device bool: the reference's early-stop predicate of the last step (see early_stop)
         self.always_allreduce = False      # all-reduce even with one rank (exercises the collective path)
         self._dev_gen = None
@@ -187,31 +193,43 @@ class CompositeTrainer:
             return ids
         return rng.integers(low=0, high=d.rays_train.shape[0], size=c.img_sample_size)
 
+    def _sampler(self):
+        """The device-side sampler of this trainer (fused.BatchSampler): ids and jitter are functions of (seed, iteration, slot)."""
+        if self.sampler is None:
+            from ..fused import BatchSampler
+            c, d = self.cfg, self.data
+            use_var = c.var_sample_perc > 0 and len(d.var_ray_ids) > 0
+            self.sampler = BatchSampler(self.seed, c.img_sample_size, self.n_var if use_var else 0, d.var_ray_ids if use_var else None,
+                                        d.non_var_ray_ids if use_var else None, int(d.rays_train.shape[0]), self.device)
+        return self.sampler
+
     def draw_ray_ids_device(self, n_iter: int) -> torch.Tensor:
-        """The same importance sampling (run_composite.py:250-260) drawn ON the GPU with a per-step seeded
-        device generator: identical stream on every rank, no host RNG / shuffle / H2D copy per step.
-        ``choice`` with replacement = uniform integer indices into the id tables; shuffle = randperm."""
-        c, d, dev = self.cfg, self.data, self.device
-        if self._dev_gen is None:
-            self._dev_gen = torch.Generator(device=dev)
-            self._var_dev = torch.as_tensor(d.var_ray_ids, device=dev)
-            self._non_var_dev = torch.as_tensor(d.non_var_ray_ids, device=dev)
-        g = self._dev_gen
-        g.manual_seed(self.seed * 1000003 + n_iter)
-        n = c.img_sample_size
-        if c.var_sample_perc > 0 and len(d.var_ray_ids) > 0:
-            a = self._non_var_dev[torch.randint(len(d.non_var_ray_ids), (n - self.n_var,), generator=g, device=dev)]
-            b = self._var_dev[torch.randint(len(d.var_ray_ids), (self.n_var,), generator=g, device=dev)]
-            ids = torch.cat([a, b])
-            return ids[torch.randperm(n, generator=g, device=dev)]
-        return torch.randint(0, d.rays_train.shape[0], (n,), generator=g, device=dev)
+        """The importance sampling of run_composite.py:250-260 drawn ON the GPU by the library (nca_draw_ray_ids): the ids of the GLOBAL
+        batch of iteration ``n_iter`` -- img_sample_size - n_var i.i.d. uniform draws from the non-variance rays and n_var from the variance
+        rays in a uniformly random arrangement (csrc/nca_rng.hpp) -- identical on every rank, no host RNG / shuffle / H2D copy.  The
+        graph-replayed step draws the same ids inside its first kernel (nca_begin_step)."""
+        return self._sampler().ray_ids(n_iter)
 
     def _draw_ids(self, n_iter: int):
         return self.draw_ray_ids_device(n_iter)
 
     def draw_jitter(self, n_iter: int) -> torch.Tensor:
+        """randomize_depth's uniform draw t_rand f32[S] of iteration ``n_iter`` (model_helpers.py:8): on the GPU the library's jitter stream
+        (a device tensor; the graph step draws the same values in nca_begin_step), on the CPU (the injected tests) a seeded torch draw."""
+        on_cuda = torch.device(self.device).type == "cuda"
+        if on_cuda:
+            return self._sampler().uniform(n_iter, int(self.depth.shape[0]))
         g = torch.Generator().manual_seed(self.seed * 1000003 + n_iter)
         return torch.rand(self.depth.shape, generator=g)
+
+    def _draws_injected(self) -> bool:
+        """A test (or a caller replaying the reference's own draws) replaced ``draw_ray_ids_device`` / ``draw_jitter`` / ``_draw_ids``: the
+        graph step then takes the ids and the jitter from those methods (copied per step) instead of drawing them on the device."""
+        cls = CompositeTrainer
+        for name in ("draw_ray_ids_device", "draw_jitter", "_draw_ids", "loss_weights", "update_windows"):
+            if name in self.__dict__ or getattr(type(self), name) is not getattr(cls, name):
+                return True
+        return False
 
     def draw_fine_u(self, n_iter: int) -> torch.Tensor:
         """sample_pdf's uniform draw for the GLOBAL batch (model_helpers.py:170), from a per-step seeded CPU generator so
@@ -311,14 +329,10 @@ class CompositeTrainer:
             from .. import _capi
             raise _capi.NcaError(f"CompositeTrainer needs the ray table on the GPU as prepare_data_for_loader_tigre builds it (f64 [N,4,3], contiguous; one phase id "
                                  f"per ray): got {rt.dtype} {tuple(rt.shape)} on {rt.device}, phases {pt.dtype} {tuple(pt.shape)}.  There is no CPU or torch path.")
-        if pt.dtype != torch.int64:
-            if getattr(self, "_phases64", None) is None:
-                self._phases64 = pt.to(torch.int64)
-            pt = self._phases64
+        pt = self._phases_i64()
         out = prepare_batch(my.to(torch.int64).contiguous(), rt, pt, self.depth, t_rand, bad_ids=self._bad_ids)
-        import os
-        if os.environ.get("NERFCA_STRICT") == "1" and not torch.cuda.is_current_stream_capturing():
-            self.check_ray_ids()            # (host-launched steps under NERFCA_STRICT: an id outside the table raises at once, as NumPy's IndexError does in the reference)
+        if self.strict_ids and not getattr(self, "_in_graph_setup", False) and not torch.cuda.is_current_stream_capturing():
+            self.check_ray_ids()            # (host-launched steps: an id outside the table raises at once, as NumPy's IndexError does in the reference)
         return out
 
     def fused_gradients(self, n_iter: int):
@@ -335,10 +349,12 @@ class CompositeTrainer:
         o, d, gt, w, phases, z, dists = self._prepare(my, self.draw_jitter(n_iter))
         return self._micro_batched(o, d, gt, w, phases, z, dists, R, self.loss_weights(n_iter), None)
 
-    def _micro_batched(self, o, d, gt, w, phases, z, dists, R, weights, weights_dev):
+    def _micro_batched(self, o, d, gt, w, phases, z, dists, R, weights, weights_dev, flat_out=None):
         """Fused forward -> loss kernel -> fused backward of this rank's rays, over as many ray micro-batches as keep the forward
         store under the limit; ``(terms, grads_s, grads_d)`` summed.  Also the body of the captured graph step (the number of
-        micro-batches is fixed at capture, like everything else about the step's structure)."""
+        micro-batches is fixed at capture, like everything else about the step's structure).  ``flat_out``: the step's ONE flat f32 buffer
+        ``[dynamic net's gradient | static net's | the 13 terms as f32]`` -- the gradients and the terms are then written straight into it
+        (what the all-reduce and the library's Adam read: no concatenation, no conversion kernels)."""
         from ..fused import _RayBatch, fused_losses, render_backward_raw, render_forward_raw
         c = self.cfg
         bs, bd = self.s._binding, self.t._binding
@@ -358,6 +374,15 @@ class CompositeTrainer:
             micro = max(1, int(micro * 0.9))
         self.micro_batches = (n_loc + micro - 1) // micro
         terms = grads_s = grads_d = None
+        nd, ns = bd.flat.numel(), bs.flat.numel()
+        if flat_out is not None and micro == n_loc:
+            # the whole rank's batch in one pass: the forward leaves pix to the loss kernel (its per-tile ray sums), the loss kernel writes the
+            # terms behind the gradients, the backward writes the gradients in place
+            sums, sig_s, sig_d, keep = render_forward_raw(whole, bs, bd, for_backward=True, want_pix=False)
+            terms, g_pix, g_s, g_d = fused_losses(sums, gt, w, sig_s, sig_d, dists, c, weights, inv_R=1.0 / R, weights_dev=weights_dev,
+                                                  terms_f32=flat_out[nd + ns:nd + ns + 13])
+            grads_s, grads_d = render_backward_raw(whole, bs, bd, keep, g_pix, g_s, g_d, out_s=flat_out[nd:nd + ns], out_d=flat_out[:nd])
+            return terms, grads_s, grads_d
         for m0 in range(0, n_loc, micro):
             m1 = min(n_loc, m0 + micro)
             batch = whole if micro == n_loc else _RayBatch(o[m0:m1], d[m0:m1], phases[m0:m1], self.I0[: m1 - m0], z, dists, c.output_activation, False, 1e-2)
@@ -373,6 +398,10 @@ class CompositeTrainer:
                 terms[3:5] = mx
                 grads_s += gs_m
                 grads_d += gd_m
+        if flat_out is not None:
+            flat_out[:nd].copy_(grads_d)
+            flat_out[nd:nd + ns].copy_(grads_s)
+            flat_out[nd + ns:nd + ns + 13].copy_(terms)
         return terms, grads_s, grads_d
 
     @_scoped
@@ -538,39 +567,90 @@ class CompositeTrainer:
         return bool(self.stop_flag) if self.stop_flag is not None else False
 
     # -- the same step as a replayed HIP graph ---------------------------------------------------
+    def _device_schedules(self):
+        """The step's schedules as the library computes them on the device (nca_begin_step), or None where one of them has no device form:
+        the FreeNeRF windows of every net (free_windowed; encodings without a schedule keep their constant vector) and the four
+        linear_param_decay loss weights.  Returns (NcaSchedules, window vectors per net, weights f64[4])."""
+        from .. import _capi
+        c, dev = self.cfg, self.device
+        nets = [(self.s, c.static_pos_enc, c.static_pos_enc_window_decay_steps), (self.t, c.temp_pos_enc, c.temp_pos_enc_window_decay_steps)]
+        sch = _capi.NcaSchedules()
+        wins, slot = [], {}
+        for m, enc, steps in nets:
+            L = int(m.pos_enc_basis)
+            if enc == "nerfies_windowed":
+                return None                # (cosine easing in torch's f32 arithmetic on the host: no bit-identical device form)
+            if m._binding.net.enc_mode != _capi.ENC_BANDS or L <= 0:
+                wins.append(None)
+                continue
+            if enc == "free_windowed":
+                key = (L, int(steps), int(m.pos_enc_window_start))
+                if key not in slot:        # identical schedules share ONE vector: the forward then stores the encoded input once
+                    if len(slot) >= 4 or L > 64:
+                        return None
+                    vec = torch.zeros(L, dtype=torch.float32, device=dev)
+                    k = len(slot)
+                    sch.window[k].kind, sch.window[k].L, sch.window[k].window_start = _capi.WINDOW_FREE, L, int(m.pos_enc_window_start)
+                    sch.window[k].decay_steps, sch.window[k].out = int(steps), vec.data_ptr()
+                    slot[key] = vec
+                wins.append(slot[key])
+            else:                          # plain bands: all ones, no schedule
+                wins.append(m._band_window().detach().to(device=dev, dtype=torch.float32).contiguous().clone())
+        sch.n_windows = len(slot)
+        weights = torch.zeros(4, dtype=torch.float64, device=dev)
+        for k, (w0, w1, delay) in enumerate(((c.favor_s_weight_start, c.favor_s_weight_end, c.favor_s_weight_delay_steps),
+                                             (c.dynamic_entro_weight_start, c.dynamic_entro_weight_end, 0),
+                                             (c.occl_weight_start, c.occl_weight_end, c.favor_s_weight_delay_steps),
+                                             (c.l1_weight_start, c.l1_weight_end, 0))):
+            sch.weight[k].start, sch.weight[k].end, sch.weight[k].steps, sch.weight[k].delay = float(w0), float(w1), int(c.hyperparam_decay_steps), int(delay)
+        sch.weights_out = weights.data_ptr()
+        return sch, wins, weights
+
     def _graph_setup(self) -> None:
-        """Capture gather -> jitter -> fused forward -> loss kernel -> fused backward (-> all-reduce) -> Adam+LinearLR
-        once.  Everything that changes from step to step reaches the kernels through device memory: the ray ids,
-        one small host-pinned record (depth jitter, the two band windows, the four loss weights) copied per step,
-        and the optimiser's device-side step counter."""
-        from ..fused import FusedAdam, _RayBatch, fused_losses, render_backward_raw, render_forward_raw
+        """Capture gather -> jitter -> fused forward -> loss kernel -> fused backward (-> all-reduce) -> Adam+LinearLR once.
+
+        DEVICE mode (the default): everything that changes from step to step is MADE on the device by the step's first kernel
+        (nca_begin_step) from the iteration counter the library's Adam increments -- ray ids, depth jitter, band windows, loss weights --
+        so a replay needs no host work at all.  RECORD mode (draws injected by a test or a caller, the hierarchical pass, schedules without
+        a device form): the ray ids and one small host-pinned record (depth jitter, band windows, loss weights) are copied per step."""
+        from ..fused import FusedAdam, begin_step
         c, dev = self.cfg, self.device
         S = self.depth.shape[0]
         Ls, Ld = self.s.pos_enc_basis, self.t.pos_enc_basis
         fine = self.n_fine > 0
         if fine and self.world > 1:
             raise RuntimeError("the graph-replayed hierarchical step runs on one rank (step_graph routes the sharded case to the host-launched step)")
+        dsched = None if (fine or self._draws_injected()) else self._device_schedules()
+        self._device_mode = dsched is not None
         Lsf, Ldf = (self.s_fine.pos_enc_basis, self.t_fine.pos_enc_basis) if fine else (0, 0)
         nf = S + Ls + Ld + Lsf + Ldf
         off64 = (4 * nf + 7) // 8 * 8
         self._rec_layout = (S, Ls, Ld, off64)
         self._rec_fine = (Lsf, Ldf)
-        self._rec_host = [torch.empty(off64 + 32, dtype=torch.uint8).pin_memory() for _ in range(4)]
-        self._rec_done = [None] * 4
-        self._rec_dev = torch.zeros(off64 + 32, dtype=torch.uint8, device=dev)
-        rec32 = self._rec_dev[: 4 * nf].view(torch.float32)
-        rec64 = self._rec_dev[off64:].view(torch.float64)
+        rec32 = rec64 = None
+        if not self._device_mode:
+            self._rec_host = [torch.empty(off64 + 32, dtype=torch.uint8).pin_memory() for _ in range(4)]
+            self._rec_done = [None] * 4
+            self._rec_dev = torch.zeros(off64 + 32, dtype=torch.uint8, device=dev)
+            rec32 = self._rec_dev[: 4 * nf].view(torch.float32)
+            rec64 = self._rec_dev[off64:].view(torch.float64)
         R = c.img_sample_size
         lo, hi = (R * self.rank) // self.world, (R * (self.rank + 1)) // self.world
         self._slice = (lo, hi)
         self._ids_buf = torch.zeros(hi - lo, dtype=torch.int64, device=dev)
+        self._iter_dev = torch.zeros(1, dtype=torch.int64, device=dev)       # the iteration the next replay runs (device mode)
+        self._graph_iter = None
         # (every tensor the captured kernels read must outlive the graph: a local that dies with this function hands its memory
         # back to the allocator and the replays read whatever the next owner wrote there -- tests/test_configs.py)
         nets = [self.t, self.s] + ([self.t_fine, self.s_fine] if fine else [])           # self.params order
-        self.adam = FusedAdam(nets, lr=c.lr, end_factor=c.lr_end_factor, total_iters=c.lr_decay_steps)
+        self.adam = FusedAdam(nets, lr=c.lr, end_factor=c.lr_end_factor, total_iters=c.lr_decay_steps, iter_counter=self._iter_dev)
         bs, bd = self.s._binding, self.t._binding
         split = self.world > 1 or self.always_allreduce
         out = {}
+        nd, ns = bd.flat.numel(), bs.flat.numel()
+        # the step's ONE flat buffer: [gradients in self.params order | the 13 loss terms as f32] -- what the all-reduce sums and Adam reads
+        self._flat = torch.zeros(sum(b.flat.numel() for b in self.adam.bindings) + 13, dtype=torch.float32, device=dev)
+        out["flat"] = self._flat
         if fine:
             self._u_buf = torch.zeros((hi - lo, self.n_fine), dtype=torch.float32, device=dev)
 
@@ -580,38 +660,51 @@ class CompositeTrainer:
             total = terms.clone()
             total[0] = terms[0] + terms_f[0]
             out["terms"], out["terms_f"] = total, terms_f
-            out["flat"] = torch.cat([g for _, _, g in order] + [torch.stack([terms_f[8], terms_f[5]]).to(torch.float32)])       # (+ the early-stop pair)
+            self._flat.copy_(torch.cat([g for _, _, g in order] + [terms_f.to(torch.float32)]))       # (+ the fine pass's terms: the early-stop pair is among them)
 
         def front():
-            o, d, gt, w, phases, z, dists = self._prepare(self._ids_buf, rec32[:S])
+            if self._device_mode:
+                prep = begin_step(self._sampler(), 0, lo, hi - lo, self.data.rays_train, self._phases_i64(), self.depth, iter_dev=self._iter_dev,
+                                  schedules=self._sched, bad_ids=self._bad_ids)
+                wdev = self._weights_dev
+            else:
+                prep = self._prepare(self._ids_buf, rec32[:S])
+                wdev = rec64
+            o, d, gt, w, phases, z, dists = prep
             # (one micro-batch at the bench size; several where the whole batch's forward store would not fit -- BASELINE configs[3]'s
             # 512^2 x 256 in f32 keeps 376 GiB -- instead of the recompute backward the graph step silently fell back to until round 3)
-            terms, grads_s, grads_d = self._micro_batched(o, d, gt, w, phases, z, dists, R, (0.0, 0.0, 0.0, 0.0), rec64)
+            terms, _, _ = self._micro_batched(o, d, gt, w, phases, z, dists, R, (0.0, 0.0, 0.0, 0.0), wdev, flat_out=self._flat)
             out["terms"] = terms
-            out["flat"] = torch.cat([grads_d, grads_s, torch.stack([terms[8], terms[5]]).to(torch.float32)])                    # (+ the early-stop pair)
 
         def back():
             off, gs = 0, []
             for b in self.adam.bindings:
-                gs.append(out["flat"][off:off + b.flat.numel()])
+                gs.append(self._flat[off:off + b.flat.numel()])
                 off += b.flat.numel()
             self.adam.step(gs)
 
         if fine:
             front = front_fine
 
-        bs.static_window = rec32[S:S + Ls] if Ls > 0 else None
-        bd.static_window = rec32[S + Ls:S + Ls + Ld] if Ld > 0 else None
-        if (Ls == Ld and Ls > 0 and c.static_pos_enc == c.temp_pos_enc and c.static_pos_enc_window_decay_steps == c.temp_pos_enc_window_decay_steps
-                and getattr(self.s, "pos_enc_window_start", None) == getattr(self.t, "pos_enc_window_start", None)):
-            bd.static_window = bs.static_window     # identical schedules: one vector, the encoded input is stored once
+        if self._device_mode:
+            self._sched, wins, self._weights_dev = dsched
+            self._win_dev = wins
+            bs.static_window, bd.static_window = wins[0], wins[1]
+        else:
+            bs.static_window = rec32[S:S + Ls] if Ls > 0 else None
+            bd.static_window = rec32[S + Ls:S + Ls + Ld] if Ld > 0 else None
+            if (Ls == Ld and Ls > 0 and c.static_pos_enc == c.temp_pos_enc and c.static_pos_enc_window_decay_steps == c.temp_pos_enc_window_decay_steps
+                    and getattr(self.s, "pos_enc_window_start", None) == getattr(self.t, "pos_enc_window_start", None)):
+                bd.static_window = bs.static_window     # identical schedules: one vector, the encoded input is stored once
         if fine:
             bsf, bdf = self.s_fine._binding, self.t_fine._binding
             o0 = S + Ls + Ld
             bsf.static_window = rec32[o0:o0 + Lsf] if Lsf > 0 else None
             bdf.static_window = rec32[o0 + Lsf:o0 + Lsf + Ldf] if Ldf > 0 else None
+        self._in_graph_setup = True
         try:
-            self._write_record(0)
+            if not self._device_mode:
+                self._write_record(0)
             saved = [b.flat.clone() for b in self.adam.bindings]
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream())
@@ -624,11 +717,18 @@ class CompositeTrainer:
                 b.flat.copy_(keep_flat)
             for t in self.adam.exp_avg + self.adam.exp_avg_sq:
                 t.zero_()
-            self.adam.step_count.zero_()
+            self.adam._step.zero_()
+            self._iter_dev.zero_()
             self._graphs = []
             g1 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1):
                 front()
+                if split and self._capture_collective():
+                    # the step's ONE collective inside the graph (torch records RCCL collectives issued on a capturing stream): a sharded step
+                    # is then one replay -- front, all-reduce, Adam -- instead of two graphs with a host-issued collective between them
+                    dist.all_reduce(self._flat, op=dist.ReduceOp.SUM)
+                    split = False
+                    self._collective_captured = True
                 if not split:
                     back()
             self._graphs.append(g1)
@@ -638,13 +738,30 @@ class CompositeTrainer:
                     back()
                 self._graphs.append(g2)
         finally:
+            self._in_graph_setup = False
             bs.static_window = bd.static_window = None
             if fine:
                 self.s_fine._binding.static_window = self.t_fine._binding.static_window = None
         self._graph_out = out
 
+    def _capture_collective(self) -> bool:
+        """Whether the gradient all-reduce is recorded INTO the step graph: with the RCCL backend (NERFCA_GRAPH_COLLECTIVE=0: two graph
+        segments with a host-issued collective between them, the round-5 structure; gloo collectives run on the host and cannot be captured)."""
+        import os
+        if os.environ.get("NERFCA_GRAPH_COLLECTIVE", "1") == "0" or not dist.is_initialized():
+            return False
+        return dist.get_backend() == "nccl"
+
+    def _phases_i64(self) -> torch.Tensor:
+        pt = self.data.phases_train
+        if pt.dtype != torch.int64:
+            if getattr(self, "_phases64", None) is None:
+                self._phases64 = pt.to(torch.int64)
+            pt = self._phases64
+        return pt
+
     def _write_record(self, n_iter: int) -> None:
-        """Fill the next pinned record with this step's host-side scalars and enqueue its copy to the device."""
+        """RECORD mode: fill the next pinned record with this step's host-side scalars and enqueue its copy to the device."""
         S, Ls, Ld, off64 = self._rec_layout
         k = n_iter % len(self._rec_host)
         if self._rec_done[k] is not None:
@@ -670,33 +787,45 @@ class CompositeTrainer:
     @_scoped
     def step_graph(self, n_iter: int):
         """``step_fused`` with the device work replayed from a captured HIP graph and the library's Adam + LinearLR
-        (its own moment buffers: do not interleave with ``step``/``step_fused`` in one run).  Per step the host only
-        draws the ray ids, fills one pinned record and launches the graph.  Returns (loss, pixel, terms) as
-        ``step_fused`` does; the tensors are overwritten by the next call."""
+        (its own moment buffers: do not interleave with ``step``/``step_fused`` in one run).  In DEVICE mode (see ``_graph_setup``) the host
+        launches the graph and nothing else: ids, jitter, windows and loss weights of iteration ``n_iter`` are made by the graph's first kernel
+        from a device counter that the graph's Adam increments (a call that is not the successor of the previous one sets the counter first).
+        Returns (loss, pixel, terms) as ``step_fused`` does; the tensors are overwritten by the next call.  The modules' own schedule state
+        (``freq_mask_alpha``) is NOT advanced per step in DEVICE mode: ``update_windows(n)`` before ``evaluate`` / ``save``, as callers do."""
         if self.n_fine > 0 and self.world > 1:
             # The hierarchical step under ray sharding has four collectives between its kernels (the sampler's batch-wide maximum,
             # ray 0's depths, and both again on the way back): nothing long enough to replay is left between them.  Same step,
             # launched from the host, torch Adam.
             return self._step_fused_fine(n_iter)
-        self.update_windows(n_iter)
         if getattr(self, "_graphs", None) is None:
+            self.update_windows(n_iter)
             self._graph_setup()
-        lo, hi = self._slice
-        self._ids_buf.copy_(self._ids_for(n_iter)[lo:hi])
-        if self.n_fine > 0:
-            self._u_buf.copy_(self.draw_fine_u(n_iter)[lo:hi], non_blocking=False)       # sample_pdf's uniform draws of this step
-        self._write_record(n_iter)
-        self._prefetch_ids(n_iter + 1)          # (before the replay: the dozen small kernels of the draw run beside the graph's first kernels)
+        if self._device_mode:
+            if self._graph_iter != n_iter:
+                self._iter_dev.fill_(n_iter)
+        else:
+            self.update_windows(n_iter)
+            lo, hi = self._slice
+            self._ids_buf.copy_(self._ids_for(n_iter)[lo:hi])
+            if self.n_fine > 0:
+                self._u_buf.copy_(self.draw_fine_u(n_iter)[lo:hi], non_blocking=False)       # sample_pdf's uniform draws of this step
+            self._write_record(n_iter)
+            self._prefetch_ids(n_iter + 1)          # (before the replay: the small kernels of the draw run beside the graph's first kernels)
+        self._graph_iter = n_iter + 1
         self._graphs[0].replay()
         if len(self._graphs) > 1:
             if self.world > 1 or self.always_allreduce:
-                dist.all_reduce(self._graph_out["flat"], op=dist.ReduceOp.SUM)
+                dist.all_reduce(self._flat, op=dist.ReduceOp.SUM)
             self._graphs[1].replay()
         terms = self._graph_out["terms"]
         if self.n_fine > 0:
             self.last_fine_terms = self._graph_out["terms_f"]
-        # the last two floats of the flat buffer: [dynamic entropy, favor], summed over the ranks by the gradient all-reduce
-        self._note_early_stop(n_iter, self._graph_out["flat"][-2:] if n_iter >= self.cfg.static_pos_enc_window_decay_steps else None)
+        # the tail of the flat buffer: the 13 terms as f32, summed over the ranks by the gradient all-reduce; [dynamic entropy, favor] = 8, 5
+        if n_iter >= self.cfg.static_pos_enc_window_decay_steps:
+            tail = self._flat[-13:]
+            self._note_early_stop(n_iter, torch.stack([tail[8], tail[5]]))
+        else:
+            self._note_early_stop(n_iter, None)
         return terms[0], terms[1], terms
 
     def _prefetch_ids(self, n_iter: int) -> None:
@@ -814,6 +943,8 @@ class StaticTrainer:
     draw_ray_ids = CompositeTrainer.draw_ray_ids
     draw_ray_ids_device = CompositeTrainer.draw_ray_ids_device
     draw_jitter = CompositeTrainer.draw_jitter
+    _sampler = CompositeTrainer._sampler
+    sampler = None
 
     def loss_on(self, n_iter: int, origins, directions, I0, gt, w, t_rand, share: float = 1.0):
         """Loss of one ray set (run_nerf.py:218-226); ``share`` = local / global ray count under sharding."""

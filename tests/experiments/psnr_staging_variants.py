@@ -104,7 +104,7 @@ def main():
         for it in range(steps):
             ids = tr.draw_ray_ids_device(it).cpu()
             rays, ph = table.index_select(0, ids), phases.index_select(0, ids)
-            zj = O.stratified_depths(z0, tr.draw_jitter(it))
+            zj = O.stratified_depths(z0, tr.draw_jitter(it).cpu())
             ot.step(it, rays[:, 0, :], rays[:, 1, :], ph[:, None].repeat(1, S), I0, zj, rays[:, 2, 0], rays[:, 3, 0])
             if it % 25 == 24:
                 print(f"  {name}: step {it + 1}, {time.perf_counter() - t0:.0f} s", file=sys.stderr, flush=True)

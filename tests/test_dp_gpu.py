@@ -43,11 +43,11 @@ def _run(rank, world, mode, prec, device_index=0):
         if mode == "graphfine":    # step_graph with a fine pass: one rank replays a graph, sharded ranks run the host-launched step
             tr.step_graph(2000 + it)
             if it == 0:
-                grads = (tr._graph_out["flat"][:-2] if getattr(tr, "_graphs", None) else torch.cat([p.grad.flatten() for p in tr.params])).clone()
+                grads = (tr._graph_out["flat"][:-13] if getattr(tr, "_graphs", None) else torch.cat([p.grad.flatten() for p in tr.params])).clone()
         elif mode == "graph":      # bench.py's default step: two captured graphs with the gradient all-reduce between them
             tr.step_graph(2000 + it)
             if it == 0:
-                grads = tr._graph_out["flat"].clone()            # [dynamic | static] = the order of tr.params
+                grads = tr._graph_out["flat"][:-13].clone()      # [dynamic | static] = the order of tr.params (behind them: the 13 loss terms as f32)
         else:
             tr.step(2000 + it)
             if it == 0:

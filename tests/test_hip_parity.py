@@ -703,7 +703,7 @@ def test_trainer_with_fine_pass_vs_oracle(dev):
     ph = data.phases_train.cpu().index_select(0, ids.cpu())
     o, d, gt, w = rays[:, 0, :], rays[:, 1, :], rays[:, 2, 0], rays[:, 3, 0]
     I0 = torch.full((R,), float(data.geo["max_pixel_value"]))
-    z = O.stratified_depths(O.depth_values(data.geo["near_thresh"], data.geo["far_thresh"], S), t_rand)
+    z = O.stratified_depths(O.depth_values(data.geo["near_thresh"], data.geo["far_thresh"], S), t_rand.cpu())
     specs = [O.NetSpec(num_filters=64), O.NetSpec(num_filters=64, num_time_dim=8), O.NetSpec(num_filters=32), O.NetSpec(num_filters=32, num_time_dim=8)]
     win = O.freq_mask_alpha(12, n_iter, 150000, 1)[0]
     u = tr.draw_fine_u(n_iter)

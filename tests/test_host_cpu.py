@@ -541,3 +541,73 @@ def test_psnr_control_cache_is_current():
             e = d["entries"][pc.key(65536, 192, 1000, v, sd)]
             assert 60.0 < e["psnr_mse_db"] < 90.0 and 50.0 < e["test_psnr_reference_def_db"] < 90.0, (v, sd, e)
         assert pc.key(1024, 500, 5000, "f32", sd) in d["entries"]
+
+
+def test_bench_headline_line_is_compact_and_parseable():
+    """bench.py's LAST stdout line is what the driver parses (round 5's 24.6 KB line came back `parsed: null`): built from a canned FULL record
+    of a real run, it must stay under 4 000 bytes (the driver's tail is 8 KB), be one line of valid JSON, carry the bench contract's keys with
+    `roofline` and `cpu_baseline`, and name every fraction by its denominator."""
+    import glob
+    import json
+    import bench
+    canned = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[5-9]_bench_full.json")))[-1]
+    full = json.loads(open(canned).read().strip().splitlines()[-1])
+    text = bench.headline_line(full, "gpurun_out/bench_full.json")
+    assert "\n" not in text and len(text.encode()) < bench.HEADLINE_LIMIT_BYTES <= 4000, len(text)
+    line = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline", "full_record"):
+        assert k in line, k
+    assert line["vs_baseline"] is None and line["unit"] == "rays/s" and line["data"] == "synthetic"
+    for k in ("workload", "rays_per_step_per_gpu", "samples_per_ray", "parallelism", "hip_graph"):
+        assert k in line["config"], k
+    assert "model" not in line["config"]
+    roof = line["roofline"]
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "step"):
+        assert k in roof, k
+    assert roof["bound"] in ("hbm", "mfma") and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-4
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in line["cpu_baseline"], k
+    assert abs(line["value"] - full["value"]) <= 1e-5 * full["value"] and abs(line["ms_per_step"] - full["ms_per_step"]) <= 1e-5 * full["ms_per_step"]
+    # one key per denominator: an HBM-bound kernel reports hbm_frac, an MFMA-bound one mfma_frac; nothing is called roofline_frac
+    for kern in roof["kernels"].values():
+        assert ("hbm_frac" in kern) == (kern["bound"] == "hbm") and "mfma_frac" in kern
+    assert "roofline_frac" not in json.dumps({k: v for k, v in line.items() if k != "precisions"})
+    # a record bloated with every optional leg still fits: the optional parts are shed, the contract's keys never
+    fat = dict(full)
+    fat["config"] = dict(full["config"], workload=full["config"]["workload"] + " " + "x" * 1500)
+    fat["precisions"] = {f"p{i}": {"rays_per_s": 1.0, "ms_per_step": 1.0, "step_mfma_frac": 0.1, "pad": "y" * 200} for i in range(8)}
+    t2 = bench.headline_line(fat, None)
+    assert len(t2.encode()) < bench.HEADLINE_LIMIT_BYTES and "roofline" in json.loads(t2) and "cpu_baseline" in json.loads(t2)
+
+
+def test_philox_restatement_known_answers_and_sampler_distribution():
+    """tests/philox_ref.py (the checker of the device-side batch sampler, csrc/nca_rng.hpp) against Random123's published known-answer vectors
+    for Philox4x32-10, and the sampler's distribution: the keyed Feistel map is a bijection of [0, n) for any n, a batch holds EXACTLY n_var
+    variance-ray ids in an arrangement whose per-slot frequency is 1/2 at var_sample_perc = 50 (run_composite.py:250-260: two draws with
+    replacement, concatenated and shuffled), a slice of slots equals the same slots of the whole draw."""
+    import numpy as np
+    import philox_ref as P
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = P.philox4x32_10(*[[c] for c in ctr], *key)
+        assert tuple(int(g[0]) for g in got) == want
+    for n in (1, 2, 3, 37, 1000, 1024, 65536, 70001):
+        assert sorted(P.perm(np.arange(n), n, P.perm_keys(12345, 77)).tolist()) == list(range(n)), n
+    var, non = np.arange(100, 800), np.arange(800, 5000)
+    freq = np.zeros(1024)
+    for it in range(200):
+        ids = P.ray_ids(3, it, 1024, 512, var, non, 5000)
+        is_var = ids < 800
+        assert int(is_var.sum()) == 512 and ids.min() >= 100 and ids.max() < 5000
+        freq += is_var
+    assert abs(freq.mean() / 200 - 0.5) < 1e-12 and freq.min() / 200 > 0.33 and freq.max() / 200 < 0.67       # (sd of a slot's frequency: 0.035)
+    whole = P.ray_ids(9, 4, 1024, 128, var, non, 5000)
+    assert np.array_equal(P.ray_ids(9, 4, 1024, 128, var, non, 5000, slot0=512, count=256), whole[512:768])
+    assert not np.array_equal(whole, P.ray_ids(9, 5, 1024, 128, var, non, 5000))
+    u = P.ray_ids(9, 4, 4096, 0, None, None, 5000)                  # var_sample_perc == 0: uniform over the table (run_composite.py:260)
+    assert u.min() >= 0 and u.max() < 5000 and abs(u.mean() - 2500) < 150
+    t = P.uniform(9, 4, 4096)
+    assert t.dtype == np.float32 and t.min() >= 0.0 and t.max() < 1.0 and abs(t.mean() - 0.5) < 0.03

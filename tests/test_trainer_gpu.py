@@ -298,7 +298,7 @@ def test_magix_shape_full_size_step(dev):
     rays, ph = data.rays_train.cpu().index_select(0, ids.cpu()), data.phases_train.cpu().index_select(0, ids.cpu())
     o, d, gt, w = rays[:, 0, :], rays[:, 1, :], rays[:, 2, 0], rays[:, 3, 0]
     I0 = torch.full((R_sub,), float(data.geo["max_pixel_value"]))
-    z = O.stratified_depths(O.depth_values(data.geo["near_thresh"], data.geo["far_thresh"], 256), tr.draw_jitter(n_iter))
+    z = O.stratified_depths(O.depth_values(data.geo["near_thresh"], data.geo["far_thresh"], 256), tr.draw_jitter(n_iter).cpu())
     ss, sd = O.NetSpec(num_filters=128), O.NetSpec(num_filters=128, num_time_dim=8)
 
     def oracle(dt):

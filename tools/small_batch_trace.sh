@@ -10,7 +10,7 @@ import csv, glob
 f = glob.glob("gpurun_out/sb_trace/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "prepare_batch" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "prepare_batch" in r["Kernel_Name"] or "begin_step" in r["Kernel_Name"]]
 a, b = idx[-12], idx[-11]
 t0 = int(rows[a]["Start_Timestamp"])
 print("kernels of one graph-replayed step at 1 024 rays x 500 samples (us from the step's first kernel; rocprofv3 --kernel-trace)")
