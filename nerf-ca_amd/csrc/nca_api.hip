@@ -102,8 +102,13 @@ int num_cus() {
 // capture (creating a stream inside a global-mode capture would fail it); until it exists the same launches run in a row on the caller's stream --
 // the results do not depend on it.
 struct Fork { hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; bool tried = false; };
+// one per (calling thread, device): a thread that drives several devices gets a side stream on each
 Fork* fork_get(hipStream_t st) {
-    static thread_local Fork f;
+    static thread_local std::vector<Fork> forks;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return nullptr;
+    if ((size_t)dev >= forks.size()) forks.resize(dev + 1);
+    Fork& f = forks[dev];
     if (!f.tried) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
@@ -121,6 +126,17 @@ Fork* fork_get(hipStream_t st) {
     }
     return f.side ? &f : nullptr;
 }
+// A fork that is open when the backward leaves early (an error between fork and join) is joined here: the caller's stream waits for the
+// side stream, so a stream capture never ends with an unjoined branch (which would fail EndCapture with an unrelated message).
+struct ForkScope {
+    Fork* f = nullptr; hipStream_t st = nullptr; bool open = false;
+    ~ForkScope() {
+        if (f && open) {
+            (void)hipEventRecord(f->ev_join, f->side);
+            (void)hipStreamWaitEvent(st, f->ev_join, 0);
+        }
+    }
+};
 }  // namespace
 
 extern "C" int nca_timing_enable(int32_t on) {
@@ -951,6 +967,8 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     if (rc) return rc;
     const bool ovl = p.ovl_cus > 0;
     Fork* fk = ovl ? fork_get(st) : nullptr;
+    ForkScope fscope;
+    fscope.f = fk; fscope.st = st;
     if (!work || work_bytes < p.bytes_total) return fail(NCA_E_WORKSPACE, "backward workspace %lld < %lld bytes", (long long)work_bytes, (long long)p.bytes_total);
     char* wb = static_cast<char*>(work);
     float* slab = reinterpret_cast<float*>(wb + p.off_slab);
@@ -1092,6 +1110,7 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
                         HIPCHK(hipEventRecord(fk->ev_fork, st));
                         HIPCHK(hipStreamWaitEvent(fk->side, fk->ev_fork, 0));
                         ws = fk->side;
+                        fscope.open = true;
                     }
                     HIPCHK(wgrad_net(0, ws, ovl_nw));
                     if (fk) HIPCHK(hipEventRecord(fk->ev_join, fk->side));
@@ -1151,7 +1170,7 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
         w.accumulate = chunk > 0;
         if (ovl) {
             // JOIN, then net 1's weight gradient on the whole chip
-            if (fk) HIPCHK(hipStreamWaitEvent(st, fk->ev_join, 0));
+            if (fk) { HIPCHK(hipStreamWaitEvent(st, fk->ev_join, 0)); fscope.open = false; }
             HIPCHK(wgrad_net(1, st, 4));
         } else {
             Span sp(NCA_K_BWD_WGRAD, st);
@@ -1240,9 +1259,15 @@ extern "C" int64_t nca_render_bwd_workspace(const NcaRays* rays, const NcaNet* n
     if (rc) return rc;
     int64_t need = p.bytes_total;
     if (prec == NCA_PREC_BF16) {       // from a store: a record per tile, e5m2 or (depth gradients) bf16 output-gradient blocks
-        rc = plan_bwd(lays, nn, prec, rays->R, (rays->S + ts - 1) / ts, max_bytes, &p, true, true, true, (int)opt_value(NCA_OPT_OVERLAP_CUS));
-        if (rc) return rc;
-        if (p.bytes_total > need) need = p.bytes_total;
+        // (run_bwd takes the overlapped plan only where it is eligible -- resident one-net launches of a ray batch -- and the plain one otherwise; under a
+        // byte budget the two chunk differently, so the query covers both)
+        const int ovl_opts[2] = {(int)opt_value(NCA_OPT_OVERLAP_CUS), 0};
+        for (int k = 0; k < 2; ++k) {
+            if (k == 1 && ovl_opts[0] == 0) break;
+            rc = plan_bwd(lays, nn, prec, rays->R, (rays->S + ts - 1) / ts, max_bytes, &p, true, true, true, ovl_opts[k]);
+            if (rc) return rc;
+            if (p.bytes_total > need) need = p.bytes_total;
+        }
         rc = plan_bwd(lays, nn, prec, rays->R, (rays->S + ts - 1) / ts, max_bytes, &p, true, false, true);
         if (rc) return rc;
         if (p.bytes_total > need) need = p.bytes_total;

@@ -447,8 +447,11 @@ __global__ __launch_bounds__(256) void nca_adam_k(const NcaAdamArgs a) {
 hipError_t nca_launch_adam(const NcaAdamArgs& a, hipStream_t st) {
     int64_t nmax = 0;
     for (int s = 0; s < a.n_seg; ++s) nmax = a.n[s] > nmax ? a.n[s] : nmax;
-    int gx = (int)((nmax + 255) / 256);
-    gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
+    // few, fat workgroups: the launch ends with ONE same-address atomic per workgroup (the arrival count of the in-kernel tick), and those
+    // serialise at ~25 ns each -- 602 of them were 15 us of a 20 us launch at the default nets' 77 056 parameters (profiles/r06_small_batch_trace.txt);
+    // 32 workgroups per segment move the same 1.2 MB in ~4 us
+    int gx = (int)((nmax + 2047) / 2048);
+    gx = gx < 1 ? 1 : (gx > 32 ? 32 : gx);
     hipLaunchKernelGGL(nca_adam_k, dim3(gx, a.n_seg), dim3(256), 0, st, a);
     return hipGetLastError();
 }
@@ -503,7 +506,13 @@ hipError_t nca_launch_prepare_batch(int64_t R, int S, const int64_t* ids, const 
 // sampling of run_composite.py:250-260, the jitter draw of model_helpers.py:8, the FreeNeRF windows of CPPN.py:144-159 and the
 // four linear_param_decay weights of run_composite.py:276-279, all as functions of (seed, iteration).
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ int64_t sampler_iter(const NcaSampler& s) { return s.n_iter + (s.iter_dev ? *s.iter_dev : (int64_t)0); }
+// (wave-uniform by construction -- one address for every lane -- and told so: everything that depends only on (seed, iteration), the
+// permutation keys above all, then runs on the scalar ALU once per wave instead of per lane)
+__device__ __forceinline__ int64_t sampler_iter(const NcaSampler& s) {
+    int64_t d = s.iter_dev ? *s.iter_dev : (int64_t)0;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(uint64_t)d), hi = __builtin_amdgcn_readfirstlane((unsigned)((uint64_t)d >> 32));
+    return s.n_iter + (int64_t)(((uint64_t)hi << 32) | lo);
+}
 
 // the ray id of slot `slot` of the global batch
 __device__ __forceinline__ int64_t draw_ray_id(const NcaSampler& s, int64_t it, int64_t slot, int half, const NcaPermKeys& keys) {

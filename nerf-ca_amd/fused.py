@@ -623,9 +623,15 @@ def loss_terms(static_sigma, temp_sigma, dists, weighted_pixs, run_args):
         raise _capi.NcaError(f"compute_losses: expected sigma [R,S] twice and dists [S], got {tuple(static_sigma.shape)}, {tuple(temp_sigma.shape)}, {tuple(dists.shape)}")
     R = static_sigma.shape[0]
     use_w = bool(run_args.entro_use_weighting) and weighted_pixs is not None and len(weighted_pixs) > 0
-    if use_w and weighted_pixs.shape[0] != R:
+    if use_w and weighted_pixs.shape[0] > R:
         raise _capi.NcaError(f"compute_losses: {weighted_pixs.shape[0]} pixel weights for {R} rays")
     wp = weighted_pixs if use_w else torch.ones(R, dtype=torch.float64, device=static_sigma.device)
+    if use_w and wp.shape[0] < R:
+        # fewer weights than rays: the reference fills weighted_mask[:len] and leaves the rest 0 (train/model_helpers.py:216-219) --
+        # a weight of 0 is never "> 1 + weighted_thresh"
+        wp = torch.cat([wp.to(static_sigma.device), torch.zeros(R - wp.shape[0], dtype=wp.dtype, device=static_sigma.device)])
+    # (run_args.occl_reg_perc has no effect, here as in the reference: compute_occl_loss ORs an all-ones back mask into the front mask
+    # unless use_back is passed, and compute_losses never passes it -- train/model_helpers.py:236-246, 256)
     opts = (use_w, run_args.skewness_val, run_args.entro_mask_thre, run_args.entro_weighted_thresh)
     return _LossTermsFn.apply(static_sigma, temp_sigma, dists, wp, opts)
 
@@ -658,9 +664,15 @@ class _WeightedSqErrFn(torch.autograd.Function):
 
 def weighted_sq_err(preds, gts, weights):
     _require_cuda(preds, "preds")
+    gts, weights = gts.to(preds.device), weights.to(preds.device)
     if not (preds.shape == gts.shape == weights.shape):
-        raise _capi.NcaError(f"weighted_MSELoss: shapes {tuple(preds.shape)}, {tuple(gts.shape)}, {tuple(weights.shape)} differ")
-    return _WeightedSqErrFn.apply(preds, gts.to(preds.device), weights.to(preds.device))
+        # the reference's expression broadcasts ((preds - gts) ** 2 * weights, train/model_helpers.py:287): expand to the common shape
+        # (views: autograd sums the gradient back over the broadcast dimensions)
+        try:
+            preds, gts, weights = torch.broadcast_tensors(preds, gts, weights)
+        except RuntimeError as e:
+            raise _capi.NcaError(f"weighted_MSELoss: shapes {tuple(preds.shape)}, {tuple(gts.shape)}, {tuple(weights.shape)} do not broadcast") from e
+    return _WeightedSqErrFn.apply(preds, gts, weights)
 
 
 def fine_depths(sig_s: torch.Tensor, sig_d: Optional[torch.Tensor], z: torch.Tensor, u: torch.Tensor, reduce_max=None) -> torch.Tensor:

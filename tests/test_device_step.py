@@ -293,3 +293,34 @@ def test_host_launched_step_raises_on_a_ray_id_outside_the_table(dev):
     tr2.step(0)                                   # deferred ...
     with pytest.raises(_capi.NcaError, match="outside the ray table"):
         tr2.early_stop()                          # ... to the next syncing call
+
+
+def test_dropin_losses_accept_what_the_reference_accepts(dev):
+    """compute_losses with FEWER pixel weights than rays (the reference fills weighted_mask[:len] and leaves the rest 0,
+    train/model_helpers.py:216-219) and weighted_MSELoss with broadcastable shapes (its expression broadcasts, :287): values and gradients
+    against the reference's torch expressions (tests/injected_trainer.py restates compute_losses from the part functions)."""
+    from injected_trainer import all_terms
+    from nerfca_amd.train import model_helpers as MH
+    from nerfca_amd.train.trainer import TrainConfig
+    g = torch.Generator().manual_seed(5)
+    R, S = 40, 30
+    cfg = TrainConfig(entro_mask_thre=0.5, entro_weighted_thresh=0.03)
+    a = (torch.rand(R, S, generator=g) * 0.2).to(dev).requires_grad_(True)
+    b = (torch.rand(R, S, generator=g) * 0.2).to(dev).requires_grad_(True)
+    dists = (torch.rand(S, generator=g) * 0.01 + 0.01).double().to(dev)
+    w_short = (torch.rand(R - 13, generator=g) * 0.2 + 0.95).double().to(dev)          # some above 1.03, some below
+    got = MH.compute_losses(a, b, dists, w_short, cfg)
+    a2, b2 = a.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    want = all_terms(a2, b2, dists, w_short, cfg)
+    for x, y in zip(got, want):
+        assert rel_err(x.detach().cpu(), y.detach().cpu()) < 1e-6
+    (got[6] * 3.0 + got[3]).backward()
+    (want[6] * 3.0 + want[3]).backward()
+    assert rel_err(b.grad.cpu(), b2.grad.cpu()) < 1e-5 and rel_err(a.grad.cpu(), a2.grad.cpu()) < 1e-5
+    p = torch.rand(R, generator=g).double().to(dev).requires_grad_(True)
+    gt = torch.rand(R, generator=g).double().to(dev)
+    wscalar = torch.tensor([1.7], dtype=torch.float64, device=dev)
+    out = MH.weighted_MSELoss()(p, gt, wscalar)
+    assert out.shape == (R,) and torch.allclose(out, (p - gt) ** 2 * wscalar, rtol=1e-14, atol=0)
+    out.mean().backward()
+    assert torch.allclose(p.grad, (2 * (p - gt) * wscalar / R).detach(), rtol=1e-12, atol=0)

@@ -25,8 +25,20 @@ ROUND 5: the gate is a regression detector again.  Wh
     profiles/r04_psnr_gates.txt): it carries a SIGNED MEAN gate (|mean over five seeds| < 0.1 dB) and a per-seed cap of 0.4 dB --
     named for what it is, a relaxed per-seed gate.
   * The f32 runs are CACHED (tests/golden/psnr_f32_controls.json, tools/psnr_cache.py): the parity mode is bit-reproducible, its
-    end points are data.  The cache is keyed by a hash of the f32 kernel sources (other sources: the controls run live) and ONE
-    cached control is re-run live per session and compared to 0.002 dB.  The summary tests FAIL when a per-seed row is missing.
+    end points are data.  The cache is keyed by a hash of EVERY source the f32 trajectory depends on (all kernel sources and headers,
+    trainer.py, fused.py, schedules.py, synthetic.py, psnr_run.py); a stale cache FAILS the gates (round 6: it used to fall back to live
+    controls with a print).  Per session TWO cached entries chosen by the date -- one at the bench batch (any variant, any seed) and one
+    at the reference's default batch -- are re-run live and compared to 0.002 dB.  The summary tests FAIL when a per-seed row is missing.
+
+ROUND 6:
+  * ENSEMBLE, replacing "inside the kick control's mean +- sd and above -0.6 dB": (a) the bf16 mode must not land on a LOWER branch (more
+    than 0.1 dB below the unperturbed f32 run) on more seeds than the worse of the two controls does; (b) its mean gap must not be more than
+    0.15 dB below the lower of the two controls' mean moves.  An arithmetic that systematically pushes runs onto the worse attractor fails (a);
+    one that is uniformly worse by a few tenths of a dB fails (b).
+  * The same per-seed rows, summary and ensemble rule for bf16 AS WRITTEN (`bf16_store`): a missing or failed seed is detected.
+  * One bf16 test whose reference is NOT the oracle's emulation of the kernels' roundings: `test_bf16_parameters_track_f32_on_a_strict_seed`
+    (200 steps of both arithmetics from identical weights on the same batches: max |delta parameter| / max |parameter| under a stated bound).
+  * The literal "within 0.1 dB of fp32" holds on the STRICT seeds only; on BRANCH seeds it is "within 0.1 dB of one of f32's own end points".
 """
 import importlib.util
 import json
@@ -64,16 +76,14 @@ def psnr_run():
 
 @pytest.fixture(scope="module")
 def cache():
-    """entries of tests/golden/psnr_f32_controls.json when they were taken on THESE f32 kernel sources, else {} (controls run live)."""
+    """entries of tests/golden/psnr_f32_controls.json; a cache taken on other sources than these FAILS the gates (re-take the controls:
+    tools/psnr_run.py --jsonl on the GPU box, then tools/psnr_cache.py)."""
     pc = _load("psnr_cache")
-    try:
-        d = json.load(open(pc.OUT))
-    except (OSError, ValueError):
-        return {"entries": {}, "valid": False, "key": pc.key}
-    ok = d.get("f32_sources_sha") == pc.f32_sources_sha()
-    if not ok:
-        print(f"[psnr gates] the cached f32 controls were taken on other kernel sources ({d.get('f32_sources_sha')} != {pc.f32_sources_sha()}): running them live", flush=True)
-    return {"entries": d["entries"] if ok else {}, "valid": ok, "key": pc.key}
+    d = json.load(open(pc.OUT))
+    if d.get("f32_sources_sha") != pc.f32_sources_sha():
+        pytest.fail(f"tests/golden/psnr_f32_controls.json was taken on other sources ({d.get('f32_sources_sha')} != {pc.f32_sources_sha()}): "
+                    "the f32 controls of the PSNR gates are stale -- re-take them (tools/psnr_run.py --jsonl ..., tools/psnr_cache.py)")
+    return {"entries": d["entries"], "valid": True, "key": pc.key}
 
 
 _ROWS = {}          # (label, seed) -> row: the per-seed tests fill it, the summary tests read it
@@ -100,7 +110,8 @@ def small_args():
 
 
 BENCH_SEEDS, SMALL_SEEDS = [0, 1, 2, 3, 4], [0, 1, 2, 3, 4]
-STRICT_ON_RECORD = {2, 4}          # |both controls - f32| <= 0.02 dB in profiles/r05_psnr_f32_controls.jsonl and r04_psnr_bench_batch_seed_table.json
+# (which seeds are STRICT is a property of the batches: rounds 4 / 5 had seeds 2 and 4 under the torch-generator draws; the device sampler of round 6
+# draws other batches -- profiles/r06_psnr_gates.txt names the seeds that are STRICT now; the summary requires at least two)
 
 
 @pytest.fixture(scope="module")
@@ -156,6 +167,8 @@ def test_bf16_as_written_psnr_gate_per_seed(dev, psnr_run, cache, bench_data, se
     gap = {k: bf["curve"][-1][k] - f32[k] for k in KEYS}
     moves = {v: {k: ctl[v][k] - f32[k] for k in KEYS} for v in CONTROLS}
     stable = all(abs(moves[v][k]) <= STABLE_DB for v in CONTROLS for k in KEYS)
+    _ROWS[("65 536 x 192 as written", seed)] = {"seed": seed, "f32": {k: f32[k] for k in KEYS}, "gap_bf16": gap, "moves": moves, "strict": stable,
+                                                "bf16_wall": bf["wall_s_incl_eval"], "cached": True}
     print(f"[65 536 x 192, bf16 as written] seed {seed} ({'STRICT' if stable else 'BRANCH'}): bf16 - f32 = " + " / ".join(f"{gap[k]:+.3f}" for k in KEYS) + " dB", flush=True)
     for k in KEYS:
         if stable:
@@ -164,35 +177,99 @@ def test_bf16_as_written_psnr_gate_per_seed(dev, psnr_run, cache, bench_data, se
             assert min([abs(gap[k])] + [abs(gap[k] - moves[v][k]) for v in CONTROLS]) < BRANCH_DB, ("branch", seed, k, gap, moves)
 
 
-def test_bench_configuration_gate_summary():
-    """Every seed ran; the seeds that are stable on record were gated STRICT; the ensemble mean of the bf16 gaps lies inside the kick
-    control's own mean +- standard deviation, and above -0.6 dB."""
-    rows = [_ROWS.get(("65 536 x 192", sd)) for sd in BENCH_SEEDS]
-    assert all(r is not None for r in rows), "a per-seed test of the bench configuration did not run (or failed) in this session: " + str([sd for sd, r in zip(BENCH_SEEDS, rows) if r is None])
+LOWER_BRANCH_DB, ENSEMBLE_MARGIN_DB = 0.1, 0.15
+
+
+def _ensemble_gate(label):
+    """Every seed ran; the seeds that are stable on record were gated STRICT; the bf16 mode is on a lower branch on no more seeds than the worse
+    control, and its mean gap is not more than ENSEMBLE_MARGIN_DB below the lower of the controls' mean moves."""
+    rows = [_ROWS.get((label, sd)) for sd in BENCH_SEEDS]
+    assert all(r is not None for r in rows), f"a per-seed test of [{label}] did not run (or failed) in this session: " + str([sd for sd, r in zip(BENCH_SEEDS, rows) if r is None])
     strict = {r["seed"] for r in rows if r["strict"]}
-    assert STRICT_ON_RECORD <= strict, (strict, "the seeds whose f32 trajectory is reproducible under both controls must carry the 0.05 dB gate")
+    assert len(strict) >= 2, (strict, "at least two seeds must carry the 0.05 dB gate: the f32 trajectory has to be reproducible under both controls somewhere")
     for k in KEYS:
         g = [r["gap_bf16"][k] for r in rows]
-        c = [r["moves"]["f32_kick2e-3"][k] for r in rows]
-        m, mc, sc = statistics.mean(g), statistics.mean(c), statistics.stdev(c)
-        print(f"[65 536 x 192] {k}: mean(bf16 - f32) = {m:+.3f} dB over seeds {BENCH_SEEDS}; f32_kick2e-3 - f32: mean {mc:+.3f}, sd {sc:.3f}", flush=True)
-        assert mc - sc <= m <= mc + sc, (k, g, c)
-        assert m > -0.6, (k, g)
+        ctl = {v: [r["moves"][v][k] for r in rows] for v in CONTROLS}
+        low_bf = sum(x < -LOWER_BRANCH_DB for x in g)
+        low_ctl = {v: sum(x < -LOWER_BRANCH_DB for x in c) for v, c in ctl.items()}
+        m, mc = statistics.mean(g), {v: statistics.mean(c) for v, c in ctl.items()}
+        print(f"[{label}] {k}: mean(bf16 - f32) = {m:+.3f} dB over seeds {BENCH_SEEDS}, on a lower branch on {low_bf} seeds; controls: "
+              + "; ".join(f"{v} mean {mc[v]:+.3f}, lower branch on {low_ctl[v]}" for v in CONTROLS), flush=True)
+        assert low_bf <= max(low_ctl.values()), (k, "bf16 lands below f32 on more seeds than either control", g, ctl)
+        assert m >= min(mc.values()) - ENSEMBLE_MARGIN_DB, (k, g, ctl)
+
+
+def test_bench_configuration_gate_summary():
+    _ensemble_gate("65 536 x 192")
+
+
+def test_bf16_as_written_gate_summary():
+    _ensemble_gate("65 536 x 192 as written")
+
+
+def _todays_pick(n):
+    import datetime
+    import random
+    return random.Random(datetime.date.today().toordinal()).randrange(n)
 
 
 def test_cached_f32_control_reproduces_live(dev, psnr_run, cache, bench_data):
-    """Spot check of the cache: ONE cached f32 run (seed 2 at the bench batch) re-run live ends where the cache says, to 0.002 dB on
-    both definitions -- and the bf16 mode is the faster one by a wide margin (13 vs 80 ms per step on record)."""
+    """Spot check of the cache: ONE cached entry at the bench batch, chosen by the date among all three f32 variants and all five seeds (round
+    5 always re-ran seed 2 of the unperturbed run), re-run live ends where the cache says, to 0.002 dB on both definitions."""
     args = bench_args()
-    k = cache["key"](args.rays, args.samples, args.steps, "f32", 2)
-    if k not in cache["entries"]:
-        pytest.skip("no valid cache for these kernel sources: the controls of this session ran live anyway")
-    r = psnr_run.run("f32", args, dev, bench_data, seed=2)
+    cands = [(v, sd) for v in ("f32",) + CONTROLS for sd in BENCH_SEEDS]
+    variant, sd = cands[_todays_pick(len(cands))]
+    k = cache["key"](args.rays, args.samples, args.steps, variant, sd)
+    assert k in cache["entries"], k
+    r = psnr_run.run(variant, args, dev, bench_data, seed=sd)
+    print(f"[cache spot check] {k}: live {r['curve'][-1][KEYS[0]]:.4f} dB, cached {cache['entries'][k][KEYS[0]]:.4f} dB", flush=True)
     for kk in KEYS:
-        assert abs(r["curve"][-1][kk] - cache["entries"][k][kk]) < 0.002, (kk, r["curve"][-1], cache["entries"][k])
-    row = _ROWS.get(("65 536 x 192", 2))
-    if row is not None:
+        assert abs(r["curve"][-1][kk] - cache["entries"][k][kk]) < 0.002, (k, kk, r["curve"][-1], cache["entries"][k])
+    row = _ROWS.get(("65 536 x 192", sd))
+    if row is not None:          # ... and the bf16 mode is the faster one by a wide margin (13 vs 76 ms per step on record)
         assert row["bf16_wall"] < 0.35 * r["wall_s_incl_eval"], (row["bf16_wall"], r["wall_s_incl_eval"])
+
+
+def test_cached_small_batch_control_reproduces_live(dev, psnr_run, cache, small_data):
+    """The same for ONE entry at the reference's default batch (1 024 x 500, 5 000 steps; the seed chosen by the date)."""
+    args = small_args()
+    sd = SMALL_SEEDS[_todays_pick(len(SMALL_SEEDS))]
+    k = cache["key"](args.rays, args.samples, args.steps, "f32", sd)
+    assert k in cache["entries"], k
+    r = psnr_run.run("f32", args, dev, small_data, seed=sd)
+    for kk in KEYS:
+        assert abs(r["curve"][-1][kk] - cache["entries"][k][kk]) < 0.002, (k, kk, r["curve"][-1], cache["entries"][k])
+
+
+PARAM_TRACK_BOUND = 0.05          # max |bf16 parameter - f32 parameter| / max |f32 parameter| after 200 steps (measured: see profiles/r06_psnr_gates.txt)
+
+
+def test_bf16_parameters_track_f32_on_a_strict_seed(dev, psnr_run, bench_data):
+    """A bf16 test whose reference is the f32 PARITY MODE (1e-5 of the reference's arithmetic per step), not the oracle's emulation of the
+    kernels' roundings: 200 graph-replayed steps of both arithmetics from identical initial weights on the same batches (seed 2: a seed whose
+    f32 trajectory is reproducible under both controls) -- the parameter vectors stay within PARAM_TRACK_BOUND of each other, max-norm."""
+    import nerfca_amd
+    from nerfca_amd import synthetic
+    from nerfca_amd.model.CPPN import CPPN
+    from nerfca_amd.model.Temporal import Temporal
+    from nerfca_amd.train.trainer import CompositeTrainer, TrainConfig
+    steps, seed = 200, 2
+    params = {}
+    for prec in ("f32", "bf16"):
+        torch.manual_seed(1 + 1000 * seed)
+        sdef, tdef = synthetic.net_definitions(dev)
+        s, t = CPPN(sdef).to(dev), Temporal(tdef).to(dev)
+        nerfca_amd.set_precision(prec, s, t)
+        cfg = TrainConfig(depth_samples_per_ray_coarse=192, img_sample_size=65536, static_pos_enc_window_decay_steps=1000, temp_pos_enc_window_decay_steps=1000, lr_decay_steps=1000)
+        tr = CompositeTrainer(cfg, s, t, bench_data, dev, seed=seed)
+        for it in range(steps):
+            tr.step_graph(it)
+        tr.check_ray_ids()
+        params[prec] = torch.cat([p.detach().flatten() for p in tr.params]).double().cpu()
+    dev_rel = float((params["bf16"] - params["f32"]).abs().max() / params["f32"].abs().max())
+    moved = float((params["f32"] - params["f32"].mean()).abs().max())
+    print(f"[param tracking] seed {seed}, {steps} steps at 65 536 x 192: max |bf16 - f32| / max |f32| = {dev_rel:.4e}", flush=True)
+    assert moved > 0 and dev_rel < PARAM_TRACK_BOUND, dev_rel
 
 
 @pytest.mark.timeout(900)
