@@ -611,3 +611,42 @@ def test_philox_restatement_known_answers_and_sampler_distribution():
     assert u.min() >= 0 and u.max() < 5000 and abs(u.mean() - 2500) < 150
     t = P.uniform(9, 4, 4096)
     assert t.dtype == np.float32 and t.min() >= 0.0 and t.max() < 1.0 and abs(t.mean() - 0.5) < 0.03
+
+
+def test_rng_header_compiled_for_the_host_equals_the_numpy_restatement(tmp_path):
+    """csrc/nca_rng.hpp is host-compilable: the SAME header the sampler kernels include, built with g++, against tests/philox_ref.py -- Philox
+    words, the keyed bijection, the slot -> ray-id rule -- so that the CPU suite pins the restatement the GPU tests compare the kernels with."""
+    import ctypes as C
+    import subprocess
+    import numpy as np
+    import philox_ref as P
+    src = tmp_path / "rng.cpp"
+    src.write_text('''#include "nca_rng.hpp"
+extern "C" void words(unsigned long long seed, long long it, int stream, unsigned long long idx, unsigned* o) { NcaU4 r = nca_rng_words(seed, it, stream, idx); o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = r.w; }
+extern "C" unsigned long long perm1(unsigned long long i, unsigned long long n, unsigned long long seed, long long it) { return nca_perm(i, n, nca_perm_half_bits(n), nca_perm_keys(seed, it)); }
+extern "C" unsigned long long below(unsigned lo, unsigned hi, unsigned long long n) { return nca_rng_below(lo, hi, n); }
+extern "C" float unit(unsigned w) { return nca_rng_unit(w); }
+''')
+    so = tmp_path / "rng.so"
+    subprocess.run(["g++", "-O2", "-shared", "-fPIC", "-I", os.path.join(ROOT, "nerf-ca_amd", "csrc"), str(src), "-o", str(so)], check=True)
+    L = C.CDLL(str(so))
+    L.perm1.restype = L.below.restype = C.c_ulonglong
+    L.perm1.argtypes = [C.c_ulonglong, C.c_ulonglong, C.c_ulonglong, C.c_longlong]
+    L.below.argtypes = [C.c_uint, C.c_uint, C.c_ulonglong]
+    L.words.argtypes = [C.c_ulonglong, C.c_longlong, C.c_int, C.c_ulonglong, C.POINTER(C.c_uint)]
+    L.unit.restype, L.unit.argtypes = C.c_float, [C.c_uint]
+    seed, it = (1 << 40) + 12345, (1 << 33) + 77
+    idx = np.array([0, 1, 5, 1 << 20, (1 << 35) + 3], dtype=np.uint64)
+    for stream in (P.STREAM_IDS, P.STREAM_PERM, P.STREAM_JITTER):
+        ref = P.rng_words(seed, it, stream, idx)
+        for k, i in enumerate(idx.tolist()):
+            out = (C.c_uint * 4)()
+            L.words(seed, it, stream, i, out)
+            assert [int(r[k]) for r in ref] == list(out), (stream, i)
+            assert np.float32(L.unit(out[0])) == P.unit(np.array([out[0]]))[0]
+            for n in (7, 5000, (1 << 40) + 1):
+                assert L.below(out[0], out[1], n) == int(P.below([out[0]], [out[1]], n)[0])
+    for n in (1, 2, 37, 1000, 65536):
+        ref = P.perm(np.arange(n), n, P.perm_keys(seed, it))
+        got = [L.perm1(i, n, seed, it) for i in range(min(n, 2000))]
+        assert ref[: len(got)].tolist() == got, n
