@@ -537,7 +537,7 @@ def test_psnr_control_cache_is_current():
     d = json.load(open(pc.OUT))
     assert d["f32_sources_sha"] == pc.f32_sources_sha(), "re-take the f32 controls: the f32 / loss kernel sources changed"
     for sd in range(5):
-        for v in ("f32", "f32_kick2e-3", "f32_bf16init"):
+        for v in ("f32", "f32_kick2e-3", "f32_kick4e-3", "f32_bf16init"):
             e = d["entries"][pc.key(65536, 192, 1000, v, sd)]
             assert 60.0 < e["psnr_mse_db"] < 90.0 and 50.0 < e["test_psnr_reference_def_db"] < 90.0, (v, sd, e)
         assert pc.key(1024, 500, 5000, "f32", sd) in d["entries"]

@@ -9,12 +9,12 @@ OUT=gpurun_out/prof_$PREC${2:-}
 mkdir -p $OUT
 export TMPDIR=/tmp
 STEPS=20; [ "$PREC" = f32 ] && STEPS=8
-python3 bench.py --prec $PREC --steps $STEPS --warmup 3 --no-extras --pure-steps 0 > $OUT/bench.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --prec $PREC --steps 6 --warmup 2 --no-cpu-baseline --no-extras --eager > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+python3 bench.py --prec $PREC --steps $STEPS --warmup 3 --no-extras --pure-steps 0 --full-record $OUT/bench_full.json > $OUT/bench.json 2> $OUT/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --prec $PREC --steps 6 --warmup 2 --no-cpu-baseline --no-extras --eager --full-record $OUT/bench_under_rocprof_full.json > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -- python3 bench.py --prec $PREC --steps 2 --warmup 1 --no-cpu-baseline --no-extras --eager > /dev/null 2> $OUT/pmc_$C.err
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -- python3 bench.py --prec $PREC --steps 2 --warmup 1 --no-cpu-baseline --no-extras --eager --full-record $OUT/pmc_run_full.json > /dev/null 2> $OUT/pmc_$C.err
 done
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_COEXEC_CYCLES SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE \
-  --kernel-trace --output-format csv -d $OUT/pmc_SQ -- python3 bench.py --prec $PREC --steps 2 --warmup 1 --no-cpu-baseline --no-extras --eager > /dev/null 2> $OUT/pmc_SQ.err
+  --kernel-trace --output-format csv -d $OUT/pmc_SQ -- python3 bench.py --prec $PREC --steps 2 --warmup 1 --no-cpu-baseline --no-extras --eager --full-record $OUT/pmc_run_full.json > /dev/null 2> $OUT/pmc_SQ.err
 find $OUT -name "*.csv" | sort
 tail -c 400 $OUT/bench.json

@@ -50,9 +50,13 @@ def find(pattern):
     return max(hits, key=os.path.getmtime)        # gpurun merges runs into the same directory: take the newest
 
 
-bench = last_json_line(os.path.join(src, "bench.json"))
+# (round 6: bench.py's stdout ends with the compact headline line; the FULL record -- every kernel table -- is the file it was told to write)
+full = os.path.join(src, "bench_full.json")
+bench = json.load(open(full)) if os.path.exists(full) else last_json_line(os.path.join(src, "bench.json"))
 json.dump(bench, open(os.path.join(dst, f"{tag}_{prec}{suffix}_bench.json"), "w"))
-json.dump(last_json_line(os.path.join(src, "bench_under_rocprof.json")), open(os.path.join(dst, f"{tag}_{prec}{suffix}_bench_under_rocprof.json"), "w"))
+full_r = os.path.join(src, "bench_under_rocprof_full.json")
+json.dump(json.load(open(full_r)) if os.path.exists(full_r) else last_json_line(os.path.join(src, "bench_under_rocprof.json")),
+          open(os.path.join(dst, f"{tag}_{prec}{suffix}_bench_under_rocprof.json"), "w"))
 with open(find("stats/**/*kernel_stats.csv")) as f, open(os.path.join(dst, f"{tag}_{prec}{suffix}_bench_kernel_stats.csv"), "w") as g:
     g.write(f.read())
 
