@@ -303,37 +303,45 @@ def mlp(params: Dict[str, Tensor], spec: NetSpec, feats: Tensor) -> Tensor:
     With ``spec.emulate_bf16`` (used only to test the bf16 HIP kernels) the MFMA operands are rounded
     to bf16 exactly where the kernel rounds them: layer inputs (encoded features, ReLU outputs) and
     weights of the F-wide layers; biases, accumulation and the F->1 output layer stay f32."""
-    if spec.emulate_bf16 and spec.emulate_fp8_stage > 0:
+    def wide_layers():
+        """(weight key, bias key, takes the skip input cat[feats, h]) of every F-wide layer in order (CPPN.py:98-106)."""
+        out = [(f"early_pts_layers.{2 * i}.weight", f"early_pts_layers.{2 * i}.bias", False) for i in range(spec.num_early_layers + 1)]
         if spec.num_late_layers > 0:
-            raise NotImplementedError
-        NL = spec.num_early_layers + 1
+            if spec.num_time_dim > 0:
+                raise UnboundLocalError("Temporal with num_late_layers > 0 has no output in the reference (Temporal.py:128-135)")
+            out.append(("skip_connection.0.weight", "skip_connection.0.bias", True))
+            out += [(f"late_pts_layers.{2 * i}.weight", f"late_pts_layers.{2 * i}.bias", False) for i in range(spec.num_late_layers - 1)]
+        return out
+
+    if spec.emulate_bf16 and spec.emulate_fp8_stage > 0:
+        layers = wide_layers()
+        NL = len(layers)
         state: dict = {}
         fd, fh = spec.emulate_stage_formats or (None, None)
         h = feats
-        for i in range(NL):
+        for i, (wk, bk, skip) in enumerate(layers):
             last = i == NL - 1
             d8 = None if (last and spec.emulate_onchip_last) else (None if fd == "bf16" else fd)     # on chip: bf16 registers, nothing is staged
             # every staged layer's input is e4m3 when its weight gradient is formed: the hidden blocks cross HBM as e4m3, the bf16
             # input block is rounded to e4m3 inside the weight-gradient kernel.  ("bf16", "bf16"): the BF16 store of round 5 -- the same
             # mode-5 arithmetic (nothing recomputed, the last layer's block without Wo, dWo from the sums) with nothing rounded to 8 bits
             h8 = (None if fh == "bf16" else fh) if d8 is not None else None
+            x = torch.cat([feats, h], dim=-1) if skip else h          # (a skip layer's weight gradient is two jobs over the same two stored blocks)
             if last and fd is not None and NL >= 2:
                 # fp8 staging (a store needs a hidden layer): last layer and output layer as the mode-5 kernels treat them
-                raw = _StagedTail.apply(h, params[f"early_pts_layers.{2 * i}.weight"], params[f"early_pts_layers.{2 * i}.bias"],
-                                        params["output_linear.0.weight"], params["output_linear.0.bias"], state, d8, h8)
+                raw = _StagedTail.apply(x, params[wk], params[bk], params["output_linear.0.weight"], params["output_linear.0.bias"], state, d8, h8)
                 break
-            h = torch.relu(_StagedLinear.apply(h, params[f"early_pts_layers.{2 * i}.weight"], params[f"early_pts_layers.{2 * i}.bias"], state, d8, h8, i == 0))
+            h = torch.relu(_StagedLinear.apply(x, params[wk], params[bk], state, d8, h8, i == 0))
         else:
             raw = _StagedOut.apply(h, params["output_linear.0.weight"], params["output_linear.0.bias"])
         if raw.requires_grad:      # d loss / d raw arrives before the layers' backward runs: fix the tile scales there
             raw.register_hook(lambda g: state.__setitem__("scale", _tile_scales(g, spec.emulate_fp8_stage)))
         return raw
     if spec.emulate_bf16:
-        if spec.num_late_layers > 0:
-            raise NotImplementedError
         h = feats
-        for i in range(spec.num_early_layers + 1):
-            h = torch.relu(TF.linear(_q(h), _q(params[f"early_pts_layers.{2 * i}.weight"]), params[f"early_pts_layers.{2 * i}.bias"]))
+        for wk, bk, skip in wide_layers():
+            x = torch.cat([feats, h], dim=-1) if skip else h
+            h = torch.relu(TF.linear(_q(x), _q(params[wk]), params[bk]))
         return TF.linear(h, params["output_linear.0.weight"], params["output_linear.0.bias"])
     h = feats
     for i in range(spec.num_early_layers + 1):
