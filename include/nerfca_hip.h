@@ -66,7 +66,7 @@ enum {
 typedef struct NcaNet {
     int32_t F;        /* num_filters: 32, 64 or 128                          */
     int32_t n_hidden; /* num_early_layers (F->F layers after the input layer) */
-    int32_t n_late;   /* num_late_layers (CPPN only; skip connection)         */
+    int32_t n_late;   /* num_late_layers (CPPN only; skip connection); both precisions since ABI 11 */
     int32_t enc_mode; /* NCA_ENC_*                                            */
     int32_t L;        /* pos_enc_basis                                        */
     int32_t T;        /* num_time_dim; 0 for the static net                   */

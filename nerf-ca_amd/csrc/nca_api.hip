@@ -438,6 +438,7 @@ static bool plan_resident(NcaFusedArgs* a, int kmode) {
         return false;
     }
     if (a->nstages <= 0) return false;
+    if (nca_has_skip(a->net[0].lay)) return false;          // (a skip layer's two images take both halves of the streaming kernels' double buffer)
     const uint32_t dma_end = a->stage[a->nstages - 1].lds_off + a->stage[a->nstages - 1].bytes;   // the DMA moves whole 1 KiB pieces
     const size_t other = nca_fused_bf16_lds_other(a->net[0].lay.F, kmode);
     const size_t need = tight + other > dma_end ? tight + other : dma_end;
@@ -751,16 +752,18 @@ static int plan_bwd(const NcaLayout* lays, int nnets, int32_t prec, int64_t unit
     // those jobs get W x the splits (NCA_OPT_WGRAD_REBUILD_WEIGHT_PCT, default 1.15).  Their extra slab rows hold NOTHING in every other job's columns and are never read there (NcaReduceArgs::n_split_std).
     int nsplit_x = nsplit;
     int slab_rows = 0;          // rows of the split slab: the most splits any job of any launch of this plan runs over
-    if (bf && stored && d8 && nr && p->njobs > nnets) {
+    int nexp = 0;          // rebuilding jobs: one per net, two where the last layer is a skip layer (its encoded and its hidden part)
+    for (int n = 0; n < nnets; ++n) nexp += lays[n].layer[lays[n].NL - 1].kind == NCA_IN_SKIP ? 2 : 1;
+    if (bf && stored && d8 && nr && p->njobs > nexp) {
         const double W = 0.01 * (double)opt_value(NCA_OPT_WGRAD_REBUILD_WEIGHT_PCT);
-        int ns = (int)((4.0 * cus) / ((p->njobs - nnets) + nnets * W));
+        int ns = (int)((4.0 * cus) / ((p->njobs - nexp) + nexp * W));
         if (ns < 1) ns = 1;
         int nx = (int)(W * ns);
-        while ((p->njobs - nnets) * ns + nnets * nx > 4 * cus && nx > ns) --nx;
+        while ((p->njobs - nexp) * ns + nexp * nx > 4 * cus && nx > ns) --nx;
         nsplit = ns;
         nsplit_x = nx;
         // one launch per net: net 0's on ovl_cus compute units (beside net 1's dgrad launch on the others), net 1's on all of them
-        if (ovl_cus >= 8 && ovl_cus <= cus - 8 && nnets == 2 && lays[0].NL > 1 && lays[1].NL > 1) {
+        if (ovl_cus >= 8 && ovl_cus <= cus - 8 && nnets == 2 && lays[0].NL > 1 && lays[1].NL > 1 && nexp == 2) {
             p->ovl_cus = ovl_cus;
             for (int n = 0; n < 2; ++n) {
                 const int slots = 4 * (n == 0 ? ovl_cus : cus), nj = lays[n].NL;
@@ -853,8 +856,10 @@ static void add_jobs_f32(NcaWgradArgs* w, const NcaLayout& y, int64_t row0, int6
 
 // net_off: byte offset of the net's input/H blocks in a tile of the H region; d_off: of its D blocks in a tile of the D region
 // h8 / d8: formats of the store's hidden blocks and of this launch's D blocks (fp8 staging)
+// part: 0 = the layer's (only) job; for a skip layer 1 = its encoded part (D_j x input block -> columns 0 .. K0 - 1 of the weight, and the bias), 2 = its hidden
+// part (D_j x H_{j-1} -> columns K0 ..): the two stored blocks cat[encoded input, h] is made of (model/CPPN.py:102-104)
 static void make_job_bf16(NcaWgradJob& g, const NcaLayout& y, int j, int64_t net_off, int64_t d_off, int64_t slab_off, int64_t onehot_off, int64_t enc_off,
-                          bool h8, bool d8) {
+                          bool h8, bool d8, int part = 0) {
     const int64_t EB = nca_bf_ebytes(h8);
     const NcaLayerL& l = y.layer[j];
     memset(&g, 0, sizeof(g));
@@ -866,14 +871,15 @@ static void make_job_bf16(NcaWgradJob& g, const NcaLayout& y, int j, int64_t net
     g.out_col0 = 0;
     g.bias_off = slab_off + l.b_off;
     g.onehot_off = onehot_off;
-    if (j == 0) {
+    if (part == 2) g.bias_off = -1;          // (the encoded-part job of the layer carries the bias)
+    if (j == 0 || part == 1) {
         g.is_enc = 1;
         g.b_row0 = enc_off;          // the input block (the other net's when it is shared)
         g.b_row_bytes = NCA_BF_ENCROWS * 2;
         g.h8 = h8 ? 1 : 0;           // fp8 staging: the input block is stored as e4m3 as well
         g.ncols_w = y.Kenc;
         g.T = y.T;
-        g.P = y.P;
+        g.P = part == 1 ? 0 : y.P;   // (the one-hot phase rows belong to layer 0's job; a net with a skip layer has no latents anyway)
         g.fourier_L = y.enc_mode == NCA_ENC_FOURIER ? y.L : 0;
     } else {
         g.is_enc = 0;
@@ -883,18 +889,22 @@ static void make_job_bf16(NcaWgradJob& g, const NcaLayout& y, int j, int64_t net
         g.ncols_w = y.F;
         g.T = 0;
         g.P = 0;
+        if (part == 2) g.out_col0 = y.K0;
     }
 }
 static void add_jobs_bf16(NcaWgradArgs* w, int net_index, const NcaLayout& y, int64_t net_off, int64_t d_off, int64_t slab_off, int64_t onehot_off, int64_t enc_off,
                           bool h8, bool d8, int64_t dscale_off, int expand_layer = -1, int mask_layers = 0) {
     for (int j = 0; j < y.NL; ++j) {
-        NcaWgradJob& g = w->job[w->njobs++];
-        make_job_bf16(g, y, j, net_off, d_off, slab_off, onehot_off, enc_off, h8, d8);
-        g.net = net_index;
-        g.dscale_off = dscale_off;
-        if (j == expand_layer) {      // mode 5, e5m2: the block is rebuilt from the forward's mask bits (nca_kernels.hpp)
-            g.expand = 1;
-            g.mask_off = ((int64_t)net_index * mask_layers + j) * 1024;
+        const bool skip = y.layer[j].kind == NCA_IN_SKIP;
+        for (int part = skip ? 1 : 0; part <= (skip ? 2 : 0); ++part) {
+            NcaWgradJob& g = w->job[w->njobs++];
+            make_job_bf16(g, y, j, net_off, d_off, slab_off, onehot_off, enc_off, h8, d8, part);
+            g.net = net_index;
+            g.dscale_off = dscale_off;
+            if (j == expand_layer) {      // mode 5, e5m2: the block is rebuilt from the forward's mask bits (nca_kernels.hpp)
+                g.expand = 1;
+                g.mask_off = ((int64_t)net_index * mask_layers + j) * 1024;
+            }
         }
     }
 }
@@ -989,7 +999,8 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
                 const int64_t EB = 32 * (int64_t)NCA_BF_ENCROWS * 2, HB = 32 * (int64_t)y.F * 2;
                 if (stored) { a.net[n].row0 = spl.row0[n]; a.net[n].drow0 = doff; doff += nca_bf_dbytes(y, d8); }
                 else a.net[n].drow0 = a.net[n].row0 + EB + (int64_t)(y.NL - 1) * HB;
-                a.net[n].wo_src = reinterpret_cast<const float*>(pk + ll.img_off + (int64_t)y.MT * ll.ksteps * 1024) + 2 * y.MT * 16;
+                if (ll.kind == NCA_IN_SKIP) a.net[n].wo_src = reinterpret_cast<const float*>(pk + ll.img2_off + (int64_t)y.MT * (y.F / 16) * 1024);     // behind the k-steps of its second image
+                else a.net[n].wo_src = reinterpret_cast<const float*>(pk + ll.img_off + (int64_t)y.MT * ll.ksteps * 1024) + 2 * y.MT * 16;
             } else {
                 if (stored) { a.net[n].row0 = spl.row0[n]; a.net[n].drow0 = doff; doff += (int64_t)y.NL * y.F; }
                 else a.net[n].drow0 = a.net[n].row0 + y.K0rows_pad + (int64_t)(y.NL - 1) * y.F;
@@ -1212,6 +1223,7 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
         rn.tail_from_sums = nr ? 1 : 0;
         rn.tl_w_off = lays[n].layer[lays[n].NL - 1].w_off;
         rn.tl_b_off = lays[n].layer[lays[n].NL - 1].b_off;
+        rn.tl_K = lays[n].layer[lays[n].NL - 1].K;          // (F, or K0 + F where that layer is a skip layer)
         rn.n_split = ovl ? p.nx_net[n] : (bf ? p.n_split_x : p.n_split);
         rn.n_split_std = ovl ? p.ns_net[n] : p.n_split;
         rn.n_wg = ovl ? p.grid_net[n] : p.grid;

@@ -147,7 +147,7 @@ struct NcaReduceNet {
     int32_t F, T, P, K0, Kenc, w0_off;
     int64_t lat_count, wo_off;
     int32_t tail_from_sums; // bf16 with fp8 staging: the slabs hold S = sum relu' g H^T and s = sum relu' g of the LAST F-wide layer
-    int32_t pad;            // (nca_layout.hpp): its gradients are Wo[f] S, Wo[f] s, and dWo[f] = <bf16(W[f]), S[f]> + b[f] s[f]
+    int32_t tl_K;           // (nca_layout.hpp): its gradients are Wo[f] S, Wo[f] s, and dWo[f] = <bf16(W[f]), S[f]> + b[f] s[f]; tl_K = that layer's fan-in
     int64_t tl_w_off, tl_b_off;   // natural offsets of that layer's W (F*F) and b (F)
     // per net, because the two nets' weight-gradient launches may be sized differently (one of them runs beside the other net's dgrad
     // launch on part of the chip, NCA_OPT_OVERLAP_CUS):

@@ -177,18 +177,21 @@ __device__ __forceinline__ void pack_bf16_body(const NcaLayout& y, const float* 
         const uint32_t byte = wd * 4u;
         for (int j = 0; j < y.NL; ++j) {
             const NcaLayerL& l = y.layer[j];
+            const bool skip = l.kind == NCA_IN_SKIP;
+            // image 1: the whole layer -- or, of a skip layer, its encoded part (layer-0 slots) -- + the bias tail (+ [Wo | bo] on a last layer that is not a skip layer)
             if (byte >= l.img_off && byte < l.img_off + l.img_bytes) {
-                const uint32_t wbytes = (uint32_t)y.MT * (uint32_t)l.ksteps * 1024u;
+                const int nks = skip ? l.ksteps_enc : l.ksteps;
+                const uint32_t wbytes = (uint32_t)y.MT * (uint32_t)nks * 1024u;
                 const uint32_t off = byte - l.img_off;
                 const uint32_t tail = 2u * (uint32_t)y.MT * 16u;   // floats
                 if (off < wbytes) {
                     float two[2];
                     for (int e2 = 0; e2 < 2; ++e2) {
                         const uint32_t e = off / 2u + e2;            // bf16 element index
-                        const int jj = e % 8, lane = (e / 8) % 64, ks = (e / 512) % l.ksteps, m = e / (512 * l.ksteps);
+                        const int jj = e % 8, lane = (e / 8) % 64, ks = (e / 512) % nks, m = e / (512 * nks);
                         const int r = lane & 31, h = lane >> 5;
                         int k;
-                        if (j == 0) k = nca_bf_slot_to_nat(y, 16 * ks + 8 * h + jj);
+                        if (j == 0 || skip) k = nca_bf_slot_to_nat(y, 16 * ks + 8 * h + jj);
                         else k = nca_bf_kidx_hidden(ks, h, jj);
                         two[e2] = k >= 0 ? prm[l.w_off + (32 * m + r) * l.K + k] : 0.f;
                     }
@@ -199,7 +202,7 @@ __device__ __forceinline__ void pack_bf16_body(const NcaLayout& y, const float* 
                     if (q < tail) {
                         const int i = q % 16, m = (q / 16) % y.MT, h = q / (16 * y.MT);
                         f = prm[l.b_off + 32 * m + nca_rho(i) + 4 * h];
-                    } else if (j == y.NL - 1) {
+                    } else if (j == y.NL - 1 && !skip) {
                         q -= tail;
                         if (q < tail) {
                             const int i = q % 16, m = (q / 16) % y.MT, h = q / (16 * y.MT);
@@ -211,15 +214,43 @@ __device__ __forceinline__ void pack_bf16_body(const NcaLayout& y, const float* 
                     v = __builtin_bit_cast(unsigned, f);
                 }
             }
+            // image 2 of a skip layer: its hidden part (columns K0 .. K0 + F - 1 of the natural weight) (+ [Wo | bo] on the last layer)
+            if (skip && byte >= l.img2_off && byte < l.img2_off + l.img2_bytes) {
+                const int KS = y.F / 16;
+                const uint32_t wbytes = (uint32_t)y.MT * (uint32_t)KS * 1024u;
+                const uint32_t off = byte - l.img2_off;
+                const uint32_t tail = 2u * (uint32_t)y.MT * 16u;
+                if (off < wbytes) {
+                    float two[2];
+                    for (int e2 = 0; e2 < 2; ++e2) {
+                        const uint32_t e = off / 2u + e2;
+                        const int jj = e % 8, lane = (e / 8) % 64, ks = (e / 512) % KS, m = e / (512 * KS);
+                        const int r = lane & 31, h = lane >> 5;
+                        two[e2] = prm[l.w_off + (32 * m + r) * l.K + y.K0 + nca_bf_kidx_hidden(ks, h, jj)];
+                    }
+                    v = pack2(two[0], two[1]);
+                } else if (j == y.NL - 1) {
+                    uint32_t q = (off - wbytes) / 4u;
+                    float f = 0.f;
+                    if (q < tail) {
+                        const int i = q % 16, m = (q / 16) % y.MT, h = q / (16 * y.MT);
+                        f = prm[y.wo_off + 32 * m + nca_rho(i) + 4 * h];
+                    } else if (q == tail) {
+                        f = prm[y.bo_off];
+                    }
+                    v = __builtin_bit_cast(unsigned, f);
+                }
+            }
             if (l.imgT_bytes && byte >= l.imgT_off && byte < l.imgT_off + l.imgT_bytes) {
                 const uint32_t off = byte - l.imgT_off;
                 const int KS = y.F / 16;
+                const int col0 = skip ? y.K0 : 0;             // (a skip layer: the transposed image of its hidden part)
                 float two[2];
                 for (int e2 = 0; e2 < 2; ++e2) {
                     const uint32_t e = off / 2u + e2;
                     const int jj = e % 8, lane = (e / 8) % 64, ks = (e / 512) % KS, m = e / (512 * KS);
                     const int r = lane & 31, h = lane >> 5;
-                    two[e2] = prm[l.w_off + nca_bf_kidx_hidden(ks, h, jj) * l.K + 32 * m + r];
+                    two[e2] = prm[l.w_off + nca_bf_kidx_hidden(ks, h, jj) * l.K + col0 + 32 * m + r];
                 }
                 v = pack2(two[0], two[1]);
             }
@@ -348,6 +379,17 @@ __device__ __forceinline__ void mma_rowtile_ring(const char* imgl, int m, u32x4 
     }
 }
 
+// acc0/acc1 += A(row tile m of an image of NKS k-steps) * B without the ring: the two images of a skip layer (SKIP instantiations)
+template <int NKS, int NB>
+__device__ __forceinline__ void mma_rowtile_plain(const char* imgl, int m, const u32x4 (&B)[2][NB], f32x16& acc0, f32x16& acc1) {
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        const u32x4 A = *reinterpret_cast<const u32x4*>(imgl + (m * NKS + ks) * 1024);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(A), frag(B[0][ks]), acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(A), frag(B[1][ks]), acc1, 0, 0, 0);
+    }
+}
+
 // identity fragment of k-step s for the transposing product Z = X^T * E: element j of lane (c,h) is
 // E[k = 16s + 8h + j][column c of the 32-wide output tile tcol] = 1 iff 32*tcol + c == that k.
 __device__ __forceinline__ u32x4 ident_frag(int kbase, int lc) {
@@ -448,8 +490,13 @@ __device__ __forceinline__ void transpose_block8(const u32x4 (&X)[NX], int lc, i
 #ifndef NCA_BF_MINBLOCKS
 #define NCA_BF_MINBLOCKS 2     // (1 with NCA_WAVES=4: up to 512 registers per wave)
 #endif
-template <int F, int MODE, bool S8, bool RES>
+// SKIP (streaming kernels only): some net of the launch has a skip layer (CPPN with num_late_layers > 0, model/CPPN.py:53-58, 102-106) -- that
+// layer reads cat[encoded input, h]: the encoding is formed again (the registers cannot hold it across the early layers), its two images
+// (encoded part, hidden part) occupy BOTH halves of the LDS double buffer while the layer computes, and the next layer's image arrives after
+// it.  The nets the reference ships have none; their instantiations (SKIP = false) hold none of this.
+template <int F, int MODE, bool S8, bool RES, bool SKIP = false>
 __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const NcaFusedArgs a) {
+    static_assert(!(SKIP && RES), "a net with a skip layer runs the streaming kernels");
     constexpr bool NR = MODE == NCA_KM_BWD_NR;                                // from a store with fp8 staging: nothing is recomputed
     constexpr int RINGK = NCA_BF_RING;                                        // A-fragment ring of the layer contractions
     static_assert(MODE == NCA_KM_FWD || MODE == NCA_KM_BWD || MODE == NCA_KM_FWD_STORE || NR, "bf16 modes: 0 forward, 1 recompute backward, 2 storing forward, 5 backward from the store");
@@ -604,8 +651,9 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
             };
 
             // ================= encoding, lane = sample ===================================================
+            // (a lambda: layer 0 calls it once per tile and net; a skip layer -- SKIP instantiations -- calls it again for its encoded part)
             u32x4 B[2][KSMAX];
-            if (RECOMP) {
+            auto encode = [&](u32x4 (&B)[2][KSMAX], const bool allow_store) __attribute__((always_inline)) {
                 float fe[NCA_BF_K0SLOTS];
 #pragma unroll
                 for (int i = 0; i < NCA_BF_K0SLOTS; ++i) fe[i] = 0.f;
@@ -668,7 +716,7 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
                         B[0][s][w] = r[0];
                         B[1][s][w] = r[1];
                     }
-                const bool store_in = STORE && (FSTORE || tvalid) && !(a.share_enc && net + a.net_base == 0);
+                const bool store_in = allow_store && STORE && (FSTORE || tvalid) && !(a.share_enc && net + a.net_base == 0);
                 if (store_in) {
                     // input block of both column tiles, fragment-major [k-step][lane][16 B]: the layer-0
                     // operands as they sit in registers, then one k-step of one-hot phase slots
@@ -701,7 +749,8 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
                         }
                     }
                 }
-            }
+            };
+            if (RECOMP) encode(B, true);
 
             // S8: inverse of the power of two by which this tile's output gradients are scaled on their way to e5m2 (the chain
             // itself stays unscaled bf16: the scaling is part of the conversion)
@@ -856,6 +905,8 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
             }
             for (int jj = NR ? y.NL : 0; jj < y.NL; ++jj) {
                 const int nsi = (si + 1 == a.nstages) ? 0 : si + 1;
+                // (a skip layer: the stage after its first image is its own second image -- both halves of the double buffer hold this layer)
+                const bool skipl = SKIP && y.layer[jj].kind == NCA_IN_SKIP;
                 if (!RES) stage_issue_b(a.stage[nsi], smem + (cur ^ 1) * BUF, wave, lane);
                 // Resident images: the layer's image offset and k-step count follow from the width alone (build_stages lays the forward
                 // images of the launch's one net back to back: layer 0, then the hidden-width layers; nca_build_layout_bf16).  Read from
@@ -863,9 +914,19 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
                 // from memory at every layer boundary of every tile, ~1 500 cycles per boundary in the round-3 timeline
                 constexpr int IMG0 = MT * KS0 * 1024 + 2 * MT * 16 * 4, IMGH = MT * KS * 1024 + 2 * MT * 16 * 4;
                 const char* img = RES ? smem + (jj == 0 ? 0 : IMG0 + (jj - 1) * IMGH) : smem + cur * BUF;
-                const int nks = jj == 0 ? KS0 : KS;
+                const int nks = (jj == 0 || skipl) ? KS0 : KS;
                 const float* tail = reinterpret_cast<const float*>(img + MT * nks * 1024);
+                // [Wo | bo]: behind the bias tail -- of a skip layer: behind the k-steps of its second image
+                const char* img2 = smem + (cur ^ 1) * BUF;
+                const float* wo_tail = skipl ? reinterpret_cast<const float*>(img2 + MT * KS * 1024) : tail + 2 * MT * 16;
                 const bool last = jj == y.NL - 1;
+                u32x4 Benc[2][KSMAX];
+                if constexpr (SKIP) {
+                    if (skipl) {
+                        encode(Benc, false);           // the layer-0 operand once more (nothing is stored: the input block is in the store already)
+                        stage_publish_b();             // the second image has landed
+                    }
+                }
                 const bool h8 = S8 && FSTORE;                                     // fp8 staging: the layer outputs go to the store as e4m3 (the last layer: its mask only)
                 char* const hblk = STORE ? nb + EB + nca_bf_hoff(y, jj, S8 && FSTORE) : nullptr;          // input block of layer jj+1
                 u32x4 Bn[2][2 * MT];
@@ -877,17 +938,17 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
                 // The storing forward writes unconditionally: a wave without a tile recomputes the batch's last tile and writes
                 // it to the slack tile slots behind the store (store_plan rounds the tile count up to the 8 waves).
                 const bool st_ok = FSTORE ? true : tvalid;
-                auto rowtiles = [&](auto nks_c, auto last_c, auto h8_c) __attribute__((always_inline)) {
+                auto rowtiles = [&](auto nks_c, auto last_c, auto h8_c, auto skl_c) __attribute__((always_inline)) {
                 constexpr int NKS = decltype(nks_c)::value;
-                constexpr bool LAST = decltype(last_c)::value, H8 = decltype(h8_c)::value;
+                constexpr bool LAST = decltype(last_c)::value, H8 = decltype(h8_c)::value, SKL = decltype(skl_c)::value;
                 u32x4 A[RINGK];
-                ring_prime<NKS, MT, RINGK>(imgl, A);
+                if constexpr (!SKL) ring_prime<NKS, MT, RINGK>(imgl, A);
                 auto epilogue = [&](int m, f32x16& acc0, f32x16& acc1) __attribute__((always_inline)) {
                     if (LAST) {
                         // the output layer's dot product takes the f32 activations
 #pragma unroll
                         for (int i = 0; i < 16; ++i) { acc0[i] = relu1(acc0[i]); acc1[i] = relu1(acc1[i]); }
-                        const float* wo = tail + 2 * MT * 16;
+                        const float* wo = wo_tail;
 #pragma unroll
                         for (int i = 0; i < 16; ++i) {
                             const float w = wo[(lh * MT + m) * 16 + i];
@@ -954,7 +1015,10 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
                     f32x16 acc0, acc1;
 #pragma unroll
                     for (int i = 0; i < 16; ++i) { const float b = tail[(lh * MT + m) * 16 + i]; acc0[i] = b; acc1[i] = b; }
-                    mma_rowtile_ring<NKS, MT, KSMAX, RINGK>(imgl, m, A, B, acc0, acc1);
+                    if constexpr (SKL) {       // cat[encoded input, h]: the encoded part from the first image, the hidden part from the second
+                        mma_rowtile_plain<KS0, KSMAX>(imgl, m, Benc, acc0, acc1);
+                        mma_rowtile_plain<KS, KSMAX>(img2 + lane * 16, m, B, acc0, acc1);
+                    } else mma_rowtile_ring<NKS, MT, KSMAX, RINGK>(imgl, m, A, B, acc0, acc1);
                     epilogue(m, acc0, acc1);
                     __builtin_amdgcn_sched_barrier(0);       // one row tile at a time: without the fence the scheduler overlaps row tiles and spills
                 }
@@ -964,12 +1028,21 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
                     const std::integral_constant<int, KS> ksc{};
                     const std::true_type yes{};
                     const std::false_type no{};
-                    if constexpr (S8 && FSTORE) {
-                        if (jj == 0) { if (last) rowtiles(ks0c, yes, yes); else rowtiles(ks0c, no, yes); }
-                        else { if (last) rowtiles(ksc, yes, yes); else rowtiles(ksc, no, yes); }
+                    bool done_skip = false;
+                    if constexpr (SKIP) {
+                        if (skipl) {
+                            done_skip = true;
+                            if constexpr (S8 && FSTORE) { if (last) rowtiles(ks0c, yes, yes, yes); else rowtiles(ks0c, no, yes, yes); }
+                            else { if (last) rowtiles(ks0c, yes, no, yes); else rowtiles(ks0c, no, no, yes); }
+                        }
+                    }
+                    if (done_skip) {}
+                    else if constexpr (S8 && FSTORE) {
+                        if (jj == 0) { if (last) rowtiles(ks0c, yes, yes, no); else rowtiles(ks0c, no, yes, no); }
+                        else { if (last) rowtiles(ksc, yes, yes, no); else rowtiles(ksc, no, yes, no); }
                     } else {
-                        if (jj == 0) { if (last) rowtiles(ks0c, yes, no); else rowtiles(ks0c, no, no); }
-                        else { if (last) rowtiles(ksc, yes, no); else rowtiles(ksc, no, no); }
+                        if (jj == 0) { if (last) rowtiles(ks0c, yes, no, no); else rowtiles(ks0c, no, no, no); }
+                        else { if (last) rowtiles(ksc, yes, no, no); else rowtiles(ksc, no, no, no); }
                     }
                 }
 #pragma unroll
@@ -986,7 +1059,7 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
                 }
 
                 if (last) {
-                    const float* wo = tail + 2 * MT * 16;
+                    const float* wo = wo_tail;
                     const float bo = wo[2 * MT * 16];
                     // column tile c of lane (r,h) is sample 32c + r: sum the two halves, then lane = sample picks its tile
                     const float r0 = part[0] + __shfl_xor(part[0], 32) + bo;
@@ -996,11 +1069,21 @@ __global__ __launch_bounds__(NCA_NT, NCA_BF_MINBLOCKS) void nca_fused_bf16(const
                     if (FSTORE) a.rstore[((tg * 2 + net + a.net_base) * 64) + lane] = raw[net];
                 }
 
-                if (BWD && last) last_layer_grads(tail + 2 * MT * 16);
+                if (BWD && last) last_layer_grads(wo_tail);
 
                 // at least 4 MT stores follow the weight DMA of every storing stage: H (plus a mask store in the storing
                 // forward, which it then also waits for), or D_{NL-1} on the last layer of both backward modes; the last
                 // layer of the storing forward stores nothing
+                if (skipl) {
+                    // both halves of the double buffer held this layer: once every wave is through with them, the next stage's image goes where
+                    // the first image was (no prefetch across a skip layer)
+                    lds_barrier();
+                    const int nsi2 = (nsi + 1 == a.nstages) ? 0 : nsi + 1;
+                    stage_issue_b(a.stage[nsi2], smem + cur * BUF, wave, lane);
+                    stage_publish_b();
+                    si = nsi2;
+                    continue;
+                }
                 if (RES) {}                                             // nothing to publish, nothing to wait for
                 else if (S8 && FSTORE && h8 && !last) stage_publish_counted<2 * MT>(true);   // 2 MT 8-bit stores (+ the mask store)
                 else if ((STORE && !last) || (BWD && last)) stage_publish_counted<4 * MT>(FSTORE || tvalid);
@@ -1165,7 +1248,7 @@ __device__ __forceinline__ void wgrad_write(const f32x16 (&acc)[F / 32][NTB], co
                     else if (slot >= NCA_BF_LAT_SLOT && slot < NCA_BF_LAT_SLOT + job.T) dst = slab + job.out_off + (int64_t)o * job.out_ld + job.ncols_w + (slot - NCA_BF_LAT_SLOT);
                     else if (slot >= NCA_BF_HOT_SLOT && slot < NCA_BF_HOT_SLOT + job.P) dst = slab + job.onehot_off + o * job.P + (slot - NCA_BF_HOT_SLOT);
                 } else if (slot < job.ncols_w) {
-                    dst = slab + job.out_off + (int64_t)o * job.out_ld + slot;
+                    dst = slab + job.out_off + (int64_t)o * job.out_ld + job.out_col0 + slot;      // (out_col0: the hidden part of a skip layer's weight)
                 }
                 if (dst) *dst = accumulate ? *dst + acc[m][c][i] : acc[m][c][i];
             }
@@ -1639,14 +1722,17 @@ __global__ __launch_bounds__(64 * NW, 1) void nca_wgrad_bf16(const NcaWgradArgs 
     // (at F = 128 the 112-slot input block and a hidden block have the same shape: one body serves both)
     if constexpr (D8) {
         s8_mode();
-        if (job.expand) wgrad_job_mx<F, F / 32, true, true>(a, job, qx, ns, lane, ring);
+        // (a rebuilding job over the INPUT block: the encoded part of a last layer that is a skip layer -- four 32-slot tiles whatever the width)
+        if (job.expand) { if (F != 128 && job.is_enc) wgrad_job_mx<F, 4, true, true>(a, job, qx, ns, lane, ring); else wgrad_job_mx<F, F / 32, true, true>(a, job, qx, ns, lane, ring); }
         else if (F != 128 && job.is_enc && job.h8) wgrad_job_mx<F, 4, true>(a, job, qx, ns, lane, ring);
         else wgrad_job_mx<F, F / 32, true>(a, job, qx, ns, lane, ring);         // (e5m2 D blocks come with e4m3 H blocks)
     } else {
-        if (F != 128 && job.is_enc && job.h8) wgrad_job<F, 4, D8, true>(a, job, qx, ns, lane, ring);
+        if (job.expand) {          // (bf16 output gradients: a hidden block has F / 32 column tiles, the input block -- a skip layer's encoded part -- four)
+            if constexpr (!D8) { if (job.is_enc) wgrad_job<F, 4, false, false, true>(a, job, qx, ns, lane, ring); else wgrad_job<F, F / 32, false, false, true>(a, job, qx, ns, lane, ring); }
+        }
+        else if (F != 128 && job.is_enc && job.h8) wgrad_job<F, 4, D8, true>(a, job, qx, ns, lane, ring);
         else if (job.h8) wgrad_job<F, F / 32, D8, true>(a, job, qx, ns, lane, ring);
         else if (F != 128 && job.is_enc) wgrad_job<F, 4, D8, false>(a, job, qx, ns, lane, ring);
-        else if (job.expand) { if constexpr (!D8) wgrad_job<F, F / 32, false, false, true>(a, job, qx, ns, lane, ring); }     // (a hidden block: F / 32 column tiles)
         else wgrad_job<F, F == 128 ? 4 : F / 32, D8, false>(a, job, qx, ns, lane, ring);
     }
 }
@@ -1654,8 +1740,8 @@ __global__ __launch_bounds__(64 * NW, 1) void nca_wgrad_bf16(const NcaWgradArgs 
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-template <int F, int MODE, bool S8, bool RES = false>
-static hipError_t launch_fused_bf_mode(const NcaFusedArgs& a, int grid, hipStream_t st) {
+template <int F, int MODE, bool S8, bool RES = false, bool SKIP = false>
+static hipError_t launch_fused_bf_mode_s(const NcaFusedArgs& a, int grid, hipStream_t st) {
     constexpr bool bwd = MODE == NCA_KM_BWD || MODE == NCA_KM_BWD_NR;
     size_t lds = (RES ? (size_t)a.res_bytes : 2 * BfCfg<F>::BUF_BYTES) + bf_const_bytes(MODE);
     if (bwd) lds += NCA_WAVES * 2 * (F + 1) * sizeof(float);
@@ -1673,9 +1759,22 @@ static hipError_t launch_fused_bf_mode(const NcaFusedArgs& a, int grid, hipStrea
         if (lds > (size_t)NCA_LDS_BYTES) return hipErrorInvalidValue;
     }
     if (MODE == NCA_KM_BWD) lds += (size_t)NCA_WAVES * a.mask_layers * 1024;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_fused_bf16<F, MODE, S8, RES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((nca_fused_bf16<F, MODE, S8, RES>), dim3(grid), dim3(NCA_NT), lds, st, *pa);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nca_fused_bf16<F, MODE, S8, RES, SKIP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((nca_fused_bf16<F, MODE, S8, RES, SKIP>), dim3(grid), dim3(NCA_NT), lds, st, *pa);
     return hipGetLastError();
+}
+template <int F, int MODE, bool S8, bool RES = false>
+static hipError_t launch_fused_bf_mode(const NcaFusedArgs& a, int grid, hipStream_t st) {
+    bool skip = false;
+    for (int n = 0; n < a.nnets; ++n) skip = skip || nca_has_skip(a.net[n].lay);
+    if constexpr (RES || MODE == NCA_KM_BWD_NR) {
+        // (resident images: the planner never chooses them for a net with a skip layer; the backward from a store runs no forward layer --
+        // its sweep takes the skip layer's hidden-part image like any other)
+        if (RES && skip) return hipErrorInvalidValue;
+        return launch_fused_bf_mode_s<F, MODE, S8, RES, false>(a, grid, st);
+    } else {
+        return skip ? launch_fused_bf_mode_s<F, MODE, S8, false, true>(a, grid, st) : launch_fused_bf_mode_s<F, MODE, S8, false, false>(a, grid, st);
+    }
 }
 template <int F>
 static hipError_t launch_fused_bf(const NcaFusedArgs& a, int kmode, int grid, hipStream_t st, bool s8) {

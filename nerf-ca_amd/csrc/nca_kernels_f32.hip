@@ -1168,7 +1168,7 @@ __device__ __forceinline__ void reduce_body(const NcaReduceArgs& a, int64_t blk)
     const int64_t stride = a.slab_stride;
     // rows of this column: the rebuilding jobs of the last F-wide layer may run over more splits than the others
     // (two explicit ranges, W then b, as the scaling below: nothing here assumes the bias follows the weight in the flat buffer)
-    const int64_t F2t = (int64_t)rn.F * rn.F;
+    const int64_t F2t = (int64_t)rn.F * rn.tl_K;
     const bool tail_w = rn.tail_from_sums && le >= rn.tl_w_off && le < rn.tl_w_off + F2t;
     const bool tail_b = rn.tail_from_sums && le >= rn.tl_b_off && le < rn.tl_b_off + rn.F;
     const bool tail_col = tail_w || tail_b;
@@ -1185,7 +1185,7 @@ __device__ __forceinline__ void reduce_body(const NcaReduceArgs& a, int64_t blk)
     // instead of 129 x n_split (it was 83 us of one wave per output walking the slabs: as long at 1 024 rays per step as at 65 536)
     if (tail_col) a.slab[rn.slab_off + le] = r;
     // the last F-wide layer's sums were formed without the factor Wo[f] of their output row (nca_layout.hpp)
-    if (tail_w) r *= rn.params[rn.wo_off + (le - rn.tl_w_off) / rn.F];
+    if (tail_w) r *= rn.params[rn.wo_off + (le - rn.tl_w_off) / rn.tl_K];
     else if (tail_b) r *= rn.params[rn.wo_off + (le - rn.tl_b_off)];
     *out = r;
 }
@@ -1214,10 +1214,10 @@ __global__ __launch_bounds__(256) void nca_reduce_small_f32(const NcaReduceArgs 
                 // dWo[k] = sum_kk bf16(W[k][kk]) S[k][kk] + b[k] s[k], S and s summed over the splits (nca_layout.hpp); the forward
                 // multiplied with the bf16-rounded weights, so those are the ones the identity holds for
                 // (S[k][.] and s[k] summed over the splits sit in slab row 0: nca_reduce_f32 left them there)
-                const float* wrow = rn.params + rn.tl_w_off + (int64_t)k * rn.F;
-                for (int kk = lane; kk < rn.F; kk += 64) {
+                const float* wrow = rn.params + rn.tl_w_off + (int64_t)k * rn.tl_K;
+                for (int kk = lane; kk < rn.tl_K; kk += 64) {
                     const float wq = __uint_as_float(((__float_as_uint(wrow[kk]) + 0x7fffu + ((__float_as_uint(wrow[kk]) >> 16) & 1u)) & 0xffff0000u));
-                    s = fmaf(wq, a.slab[rn.slab_off + rn.tl_w_off + (int64_t)k * rn.F + kk], s);
+                    s = fmaf(wq, a.slab[rn.slab_off + rn.tl_w_off + (int64_t)k * rn.tl_K + kk], s);
                 }
                 if (lane == 0) s = fmaf(rn.params[rn.tl_b_off + k], a.slab[rn.slab_off + rn.tl_b_off + k], s);
             } else {

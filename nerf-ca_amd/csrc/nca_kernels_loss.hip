@@ -422,6 +422,7 @@ __global__ __launch_bounds__(256) void nca_adam_k(const NcaAdamArgs a) {
     const float* __restrict__ g = a.grads[seg];
     float* __restrict__ m = a.exp_avg[seg];
     float* __restrict__ v = a.exp_avg_sq[seg];
+#pragma unroll 4
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n[seg]; i += (int64_t)gridDim.x * 256) {
         const float gi = g[i];
         const float mi = m[i] + w1 * (gi - m[i]);
@@ -449,9 +450,9 @@ hipError_t nca_launch_adam(const NcaAdamArgs& a, hipStream_t st) {
     for (int s = 0; s < a.n_seg; ++s) nmax = a.n[s] > nmax ? a.n[s] : nmax;
     // few, fat workgroups: the launch ends with ONE same-address atomic per workgroup (the arrival count of the in-kernel tick), and those
     // serialise at ~25 ns each -- 602 of them were 15 us of a 20 us launch at the default nets' 77 056 parameters (profiles/r06_small_batch_trace.txt);
-    // 32 workgroups per segment move the same 1.2 MB in ~4 us
-    int gx = (int)((nmax + 2047) / 2048);
-    gx = gx < 1 ? 1 : (gx > 32 ? 32 : gx);
+    // 64 workgroups per segment, four elements in flight per thread, move the same 1.2 MB in a few microseconds
+    int gx = (int)((nmax + 1023) / 1024);
+    gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
     hipLaunchKernelGGL(nca_adam_k, dim3(gx, a.n_seg), dim3(256), 0, st, a);
     return hipGetLastError();
 }

@@ -215,24 +215,39 @@ inline int nca_build_layout_bf16(const NcaNet& n, NcaLayout* out, const char** w
     int rc = nca_build_layout(n, out, why);
     if (rc != NCA_OK) return rc;
     NcaLayout& y = *out;
-    if (n.n_late > 0) { *why = "bf16 path: skip/late layers are not implemented (use the f32 path)"; return NCA_E_UNSUPPORTED; }
     if (n.T > 16 || y.P > 16) { *why = "bf16 path: num_time_dim and phases must be <= 16"; return NCA_E_UNSUPPORTED; }
     if (y.Kenc > (n.T > 0 ? NCA_BF_LAT_SLOT : NCA_BF_K0SLOTS)) { *why = "bf16 path: encoded input too wide (pos_enc_basis <= 12 with latents, <= 15 without)"; return NCA_E_UNSUPPORTED; }
     uint32_t boff = 0, maxb = 0;
     const uint32_t tail = nca_img_tail_bytes(y.MT);
     for (int j = 0; j < y.NL; ++j) {
         NcaLayerL& l = y.layer[j];
-        l.ksteps = (j == 0) ? NCA_BF_K0SLOTS / 16 : y.F / 16;
-        l.ksteps_enc = (j == 0) ? l.ksteps : 0;
+        const uint32_t wo_tail = (j == y.NL - 1) ? tail + 16u : 0u;
         l.img_off = boff;
-        l.img_bytes = (uint32_t)y.MT * (uint32_t)l.ksteps * 1024u + tail + (j == y.NL - 1 ? tail + 16u : 0u);
-        boff += (l.img_bytes + 1023u) & ~1023u;
+        l.img2_off = 0; l.img2_bytes = 0;
+        if (l.kind == NCA_IN_SKIP) {
+            // a skip layer (CPPN with num_late_layers > 0, model/CPPN.py:53-58, 102-106) reads cat[encoded input, h]: two images, two LDS stages --
+            // `img` = the encoded part (the layer-0 slots: 6 k-steps) + the bias tail, `img2` = the hidden part (F / 16 k-steps) (+ [Wo | bo] on the last layer)
+            l.ksteps_enc = NCA_BF_K0SLOTS / 16;
+            l.ksteps = l.ksteps_enc + y.F / 16;
+            l.img_bytes = (uint32_t)y.MT * (uint32_t)l.ksteps_enc * 1024u + tail;
+            boff += (l.img_bytes + 1023u) & ~1023u;
+            l.img2_off = boff;
+            l.img2_bytes = (uint32_t)y.MT * (uint32_t)(y.F / 16) * 1024u + wo_tail;
+            boff += (l.img2_bytes + 1023u) & ~1023u;
+            if (l.img2_bytes > maxb) maxb = l.img2_bytes;
+        } else {
+            l.ksteps = (j == 0) ? NCA_BF_K0SLOTS / 16 : y.F / 16;
+            l.ksteps_enc = (j == 0) ? l.ksteps : 0;
+            l.img_bytes = (uint32_t)y.MT * (uint32_t)l.ksteps * 1024u + tail + wo_tail;
+            boff += (l.img_bytes + 1023u) & ~1023u;
+        }
         if (l.img_bytes > maxb) maxb = l.img_bytes;
     }
     for (int j = 0; j < y.NL; ++j) {
         NcaLayerL& l = y.layer[j];
+        l.imgT2_off = 0; l.imgT2_bytes = 0;
         if (j == 0) { l.imgT_off = 0; l.imgT_bytes = 0; continue; }
-        l.imgT_off = boff;
+        l.imgT_off = boff;                                  // (a skip layer: the transposed image of its HIDDEN part -- the sweep needs no gradient of the encoded input)
         l.imgT_bytes = (uint32_t)y.MT * (uint32_t)(y.F / 16) * 1024u;
         boff += l.imgT_bytes;
         if (l.imgT_bytes > maxb) maxb = l.imgT_bytes;
@@ -240,6 +255,11 @@ inline int nca_build_layout_bf16(const NcaNet& n, NcaLayout* out, const char** w
     y.packed_bytes = boff;
     y.max_img_bytes = maxb;
     return NCA_OK;
+}
+// does the net have a skip layer (bf16 mode: streaming kernels, their SKIP instantiation)
+NCA_HD inline bool nca_has_skip(const NcaLayout& y) {
+    for (int j = 0; j < y.NL; ++j) if (y.layer[j].kind == NCA_IN_SKIP) return true;
+    return false;
 }
 
 // The bf16 mode's forward store (8-bit staging, NCA_OPT_STAGE_FP8): the blocks that only the weight-gradient kernel reads cross HBM as

@@ -247,10 +247,15 @@ def test_precision_switch_is_per_model_pair():
     assert s._binding.prec == t._binding.prec == _capi.PREC_BF16
     lib = _capi.lib()
     assert lib.nca_packed_bytes(C.byref(s._binding.net), _capi.PREC_BF16) > 0
-    # configurations the bf16 kernels do not implement are explicit errors, not fallbacks
+    # a CPPN with a skip layer runs in both precisions since ABI 11 (two images for the skip layer: encoded part + hidden part)
     late = CPPN(model_def(F=32, early=1, late=2))
-    assert lib.nca_packed_bytes(C.byref(late._binding.net), _capi.PREC_BF16) == -2 and b"bf16" in lib.nca_last_error()
-    assert lib.nca_packed_bytes(C.byref(late._binding.net), _capi.PREC_F32) > 0
+    nb16, nb32 = lib.nca_packed_bytes(C.byref(late._binding.net), _capi.PREC_BF16), lib.nca_packed_bytes(C.byref(late._binding.net), _capi.PREC_F32)
+    plain16 = lib.nca_packed_bytes(C.byref(CPPN(model_def(F=32, early=2, late=0))._binding.net), _capi.PREC_BF16)         # the same number of F-wide layers without the skip input
+    assert nb32 > 0 and nb16 > plain16 > 0
+    # configurations the bf16 kernels do not implement are explicit errors, not fallbacks: more than 16 latent dimensions
+    wide_t = _capi.NcaNet(F=32, n_hidden=1, n_late=0, enc_mode=1, L=4, T=20, P=10, reserved=0)
+    assert lib.nca_packed_bytes(C.byref(wide_t), _capi.PREC_BF16) == -2 and b"bf16" in lib.nca_last_error()
+    assert lib.nca_packed_bytes(C.byref(wide_t), _capi.PREC_F32) > 0
 
 
 def test_graft_entry_build_contract():
