@@ -379,6 +379,18 @@ def _measure(args, prec, stage_fp8, data, dev, rank, world, use_pg, steps, warmu
     base_iter = 75000    # steady state: half of the frequency bands open
     step = tr.step_graph if args.graph else tr.step
     fallbacks0 = fused_mod.STORE_FALLBACKS
+    if args.graph and use_pg and warmup > 0:
+        # The sharded step records its RCCL all-reduce INTO the step graph (one replay per step).  That was verified under a one-rank group on
+        # one GPU; no multi-GPU node was available to any round.  Should the capture of the collective fail on a real node, fall back -- on every
+        # rank alike -- to round 5's structure (two graph segments, the collective issued from the host between them) rather than lose the run.
+        try:
+            step(base_iter)
+        except Exception as e:          # noqa: BLE001
+            print(f"bench.py: capturing the all-reduce into the step graph failed ({type(e).__name__}: {e}); falling back to a host-issued collective between two graph segments", file=sys.stderr, flush=True)
+            os.environ["NERFCA_GRAPH_COLLECTIVE"] = "0"
+            torch.cuda.synchronize()
+            tr = make_trainer(args, prec, data, dev, rank, world, use_pg, plan_opts=None if stage_fp8 is None else {"stage_fp8": stage_fp8})
+            step = tr.step_graph
     for i in range(warmup):
         step(base_iter + i)
     barrier()
@@ -762,6 +774,10 @@ def main():
         rccl_ranks = dist.get_world_size()
         if rccl_ranks != world or dist.get_rank() != rank:
             raise SystemExit(f"process group reports rank {dist.get_rank()} of {rccl_ranks}, the environment said {rank} of {world}")
+        # one eager collective before anything is captured: the communicator exists when the step graph records its all-reduce
+        warm = torch.zeros(8, device=dev)
+        dist.all_reduce(warm)
+        torch.cuda.synchronize()
 
     from nerfca_amd import _capi, synthetic
     _capi.lib()   # fail loudly if the HIP library is missing
