@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NCA_ABI_VERSION 11
+#define NCA_ABI_VERSION 12
 
 enum {
     NCA_OK = 0,
@@ -63,16 +63,27 @@ enum {
  *   [time_latents P*T]  W0[F,K0] b0[F]  {W_i[F,F] b_i[F]} x n_hidden
  *   [Wskip[F,F+K0] bskip[F]  {W[F,F] b[F]} x (n_late-1)]   Wo[1,F] bo[1]
  * with K0 = enc features + T. */
+/* Two families of kernels run a net.  The FUSED kernels keep a sample's activations in registers through the whole net: F = 32, 64 or 128, three
+ * input channels, one output channel, both precisions -- every net the reference ships.  The GENERAL kernels (ABI 12) run what those cannot hold --
+ * F any multiple of 16 up to 1024 (model/CPPN.py:40-65 takes any num_filters), 1..8 input and output channels -- layer by layer with the
+ * activations in HBM: f32 only (v_mfma_f32_32x32x2_f32), no forward store, no depth gradients, and a workspace for every call
+ * (nca_render_fwd_workspace_nets, nca_mlp_fwd_workspace).  A ray batch may mix the two: each net leaves its raw field, one compositing kernel follows.
+ * Their packed image (nca_pack_weights) is [fan-in-padded weights | biases | output layer]. */
 typedef struct NcaNet {
-    int32_t F;        /* num_filters: 32, 64 or 128                          */
+    int32_t F;        /* num_filters: 32, 64 or 128 (fused kernels); a multiple of 16 in [16, 1024] (general kernels: F > 128, or see `reserved`) */
     int32_t n_hidden; /* num_early_layers (F->F layers after the input layer) */
     int32_t n_late;   /* num_late_layers (CPPN only; skip connection); both precisions since ABI 11 */
     int32_t enc_mode; /* NCA_ENC_*                                            */
     int32_t L;        /* pos_enc_basis                                        */
     int32_t T;        /* num_time_dim; 0 for the static net                   */
     int32_t P;        /* rows of time_latents (10 in the reference)           */
-    int32_t reserved;
+    int32_t reserved; /* 0 = three input channels, one output channel.  ABI 12: bits 0..7 num_input_channels (0 = 3), bits 8..15
+                         num_output_channels (0 = 1), bit 16 (NCA_NET_GENERAL) = run on the general kernels whatever the width;
+                         anything but 0 selects the general kernels.  Parameter order with C_out outputs: ... Wo[C_out,F] bo[C_out];
+                         encoded width K0 = C (none), C (1 + 2 L) (bands), 2 C L (fourier; coefficients f32[C L]) + T */
 } NcaNet;
+#define NCA_NET_CHANNELS(c_in, c_out) (((c_in) == 3 ? 0 : (c_in)) | (((c_out) == 1 ? 0 : (c_out)) << 8))
+#define NCA_NET_GENERAL 0x10000
 
 /* Per-call planner options (NcaRays.plan_opts): a field that is not NCA_OPT_UNSET replaces the process-wide tunable of the same name
  * (nca_set_option) for THIS call only -- two trainers, or two threads, of one process then do not see each other's settings.  A
@@ -165,6 +176,9 @@ int nca_pack_weights2(const NcaNet* net_a, const float* params_a, void* packed_a
  * Returns a negative error code, or >= 0: the format of the store it wrote (NCA_STORE_*, 0 = none) -- hand it to the backward
  * in NcaRays.store_format. */
 int64_t nca_render_fwd_workspace(const NcaRays* rays);
+/* The same when a net of the batch runs on the general kernels (ABI 12): a chunk of activations on top ([rows][K0p + 2 F] floats, at most 2^18 rows,
+ * fewer under `max_bytes` > 0).  Equal to nca_render_fwd_workspace() for nets of the fused kernels. */
+int64_t nca_render_fwd_workspace_nets(const NcaRays* rays, const NcaNet* net_s, const NcaNet* net_d, int32_t prec, int64_t max_bytes);
 int64_t nca_render_store_bytes(const NcaRays* rays, const NcaNet* net_s, const NcaNet* net_d, int32_t prec);
 int nca_render_fwd(const NcaRays* rays, int32_t prec,
                    const NcaNet* net_s, const void* packed_s, const float* win_s, const float* four_s,
@@ -202,6 +216,12 @@ int nca_render_bwd_depth(const NcaRays* rays, int32_t prec,
 int nca_mlp_fwd(const NcaNet* net, int32_t prec, const void* packed, const float* win, const float* four,
                 const float* params, int64_t N, const float* pts /*[N,3]*/, const int32_t* phase /*[N] or NULL*/,
                 float* raw /*[N]*/, void* stream);
+/* ABI 12: the forward with a workspace -- what a net on the general kernels needs (nca_mlp_fwd refuses it with NCA_E_WORKSPACE); any other net runs as
+ * nca_mlp_fwd and nca_mlp_fwd_workspace returns 0.  pts f32[N, C_in], raw f32[N, C_out]; g_raw / grads of nca_mlp_bwd likewise. */
+int64_t nca_mlp_fwd_workspace(const NcaNet* net, int32_t prec, int64_t N, int64_t max_bytes);
+int nca_mlp_fwd_ws(const NcaNet* net, int32_t prec, const void* packed, const float* win, const float* four,
+                   const float* params, int64_t N, const float* pts, const int32_t* phase, float* raw,
+                   void* work, int64_t work_bytes, void* stream);
 int64_t nca_mlp_bwd_workspace(const NcaNet* net, int32_t prec, int64_t N, int64_t max_bytes);
 /* g_latents: NULL, or f32[N, T] (ABI 9): d loss / d latent INPUT of every point -- what autograd hands back through
  * Temporal.query_time's latent vectors (model/Temporal.py:113-136), one row per point whichever points share a table row; `grads`

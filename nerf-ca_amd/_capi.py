@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("NERFCA_LIB") or os.path.join(_HERE, "lib", "libnerfca
 ENC_NONE, ENC_BANDS, ENC_FOURIER = 0, 1, 2
 ACT_SIGMOID, ACT_SOFTPLUS, ACT_CLAMP = 0, 1, 2
 PREC_F32, PREC_BF16 = 0, 1
-ABI_VERSION = 11
+ABI_VERSION = 12
 OPT_STAGE_FP8 = 1          # (0 is reserved: the retired bf16-staged backward's on-chip threshold)
 OPT_RESIDENT_MIN_TILES = 2
 OPT_STAGE_FP8_MIN_TILES = 3
@@ -31,6 +31,19 @@ KERNEL_KINDS = {"pack": K_PACK, "fwd": K_FWD, "bwd_dgrad": K_BWD_DGRAD, "bwd_wgr
                 "loss": K_LOSS, "adam": K_ADAM}
 TERM_NAMES = ["loss", "pixel", "blendw", "sigma_s_max", "sigma_d_max", "favor_s", "s_entropy", "s_entropy_sum", "d_entropy",
               "d_entropy_sum", "d_occl", "s_l1", "s_l2"]
+
+
+NET_GENERAL = 0x10000      # NcaNet.reserved: run on the general kernels whatever the width
+
+
+def net_channels(c_in: int, c_out: int) -> int:
+    """NcaNet.reserved for a net with these channel counts (0 = 3 -> 1: the fused kernels' nets)."""
+    return (0 if c_in == 3 else c_in) | ((0 if c_out == 1 else c_out) << 8)
+
+
+def net_is_general(net) -> bool:
+    """Does this net run on the general kernels (more than 128 units, other channels than 3 -> 1, or NET_GENERAL set)?"""
+    return net.F > 128 or net.reserved != 0
 
 
 class NcaNet(C.Structure):
@@ -118,6 +131,7 @@ SYMBOLS = {
     "nca_pack_weights": (C.c_int, [C.POINTER(NcaNet), _P, _P, _I32, _P]),
     "nca_pack_weights2": (C.c_int, [C.POINTER(NcaNet), _P, _P, C.POINTER(NcaNet), _P, _P, _I32, _P]),
     "nca_render_fwd_workspace": (_I64, [C.POINTER(NcaRays)]),
+    "nca_render_fwd_workspace_nets": (_I64, [C.POINTER(NcaRays), C.POINTER(NcaNet), C.POINTER(NcaNet), _I32, _I64]),
     "nca_render_store_bytes": (_I64, [C.POINTER(NcaRays), C.POINTER(NcaNet), C.POINTER(NcaNet), _I32]),
     "nca_render_fwd": (C.c_int, [C.POINTER(NcaRays), _I32, C.POINTER(NcaNet), _P, _P, _P, C.POINTER(NcaNet), _P, _P, _P, _P,
                                  _P, _P, _P, _P, _I64, _P, _I64, _P]),
@@ -127,6 +141,8 @@ SYMBOLS = {
     "nca_render_bwd_depth": (C.c_int, [C.POINTER(NcaRays), _I32, C.POINTER(NcaNet), _P, _P, _P, _P, C.POINTER(NcaNet), _P, _P, _P, _P,
                                        _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _P]),
     "nca_mlp_fwd": (C.c_int, [C.POINTER(NcaNet), _I32, _P, _P, _P, _P, _I64, _P, _P, _P, _P]),
+    "nca_mlp_fwd_workspace": (_I64, [C.POINTER(NcaNet), _I32, _I64, _I64]),
+    "nca_mlp_fwd_ws": (C.c_int, [C.POINTER(NcaNet), _I32, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _I64, _P]),
     "nca_mlp_bwd_workspace": (_I64, [C.POINTER(NcaNet), _I32, _I64, _I64]),
     "nca_mlp_bwd": (C.c_int, [C.POINTER(NcaNet), _I32, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "nca_composite_fwd": (C.c_int, [_I64, _I32, _I32, _I32, C.c_float, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 #include "nca_kernels.hpp"
+#include "nca_wide.hpp"
 
 static thread_local char g_err[512] = "";
 
@@ -323,7 +324,17 @@ static int layout_of(const NcaNet* net, NcaLayout* y, int32_t prec = NCA_PREC_F3
     return NCA_OK;
 }
 
+// the general kernels (nets wider than 128 units / other channel counts: nca_wide.hpp); defined in nca_api_wide.inc behind run_bwd
+struct NetBind;
+static bool is_wide(const NcaNet* net);
+static int wide_layout_of(const NcaNet* net, NcaWideLayout* y, int32_t prec);
+
 extern "C" int64_t nca_param_count(const NcaNet* net) {
+    if (is_wide(net)) {
+        NcaWideLayout w;
+        int rc = wide_layout_of(net, &w, NCA_PREC_F32);
+        return rc == NCA_OK ? w.n_params : rc;
+    }
     NcaLayout y;
     int rc = layout_of(net, &y);
     return rc == NCA_OK ? y.n_params : rc;
@@ -333,6 +344,11 @@ extern "C" int64_t nca_packed_bytes(const NcaNet* net, int32_t prec) {
     NcaLayout y;
     int rc = check_prec(prec);
     if (rc) return rc;
+    if (is_wide(net)) {
+        NcaWideLayout w;
+        rc = wide_layout_of(net, &w, prec);
+        return rc == NCA_OK ? w.packed_floats * 4 : rc;
+    }
     rc = layout_of(net, &y, prec);
     if (rc != NCA_OK) return rc;
     return y.packed_bytes;
@@ -342,6 +358,15 @@ extern "C" int nca_pack_weights(const NcaNet* net, const float* params, void* pa
     NcaLayout y;
     int rc = check_prec(prec);
     if (rc) return rc;
+    if (is_wide(net)) {
+        NcaWideLayout w;
+        rc = wide_layout_of(net, &w, prec);
+        if (rc) return rc;
+        if (!params || !packed) return fail(NCA_E_INVALID, "params/packed is NULL");
+        Span sp(NCA_K_PACK, (hipStream_t)stream);
+        HIPCHK(nca_launch_wide_pack(w, params, static_cast<float*>(packed), (hipStream_t)stream));
+        return NCA_OK;
+    }
     rc = layout_of(net, &y, prec);
     if (rc != NCA_OK) return rc;
     if (!params || !packed) return fail(NCA_E_INVALID, "params/packed is NULL");
@@ -356,6 +381,10 @@ extern "C" int nca_pack_weights2(const NcaNet* net_a, const float* params_a, voi
     NcaLayout ya, yb;
     int rc = check_prec(prec);
     if (rc) return rc;
+    if (is_wide(net_a) || is_wide(net_b)) {
+        rc = nca_pack_weights(net_a, params_a, packed_a, prec, stream);
+        return rc ? rc : nca_pack_weights(net_b, params_b, packed_b, prec, stream);
+    }
     rc = layout_of(net_a, &ya, prec);
     if (rc != NCA_OK) return rc;
     rc = layout_of(net_b, &yb, prec);
@@ -550,6 +579,7 @@ extern "C" int64_t nca_render_store_bytes(const NcaRays* rays, const NcaNet* net
     if (rc) return rc;
     NcaLayout lays[2];
     const int nn = rays->single_field ? 1 : 2;
+    if (is_wide(net_s) || (nn == 2 && is_wide(net_d))) return 0;          // the general kernels keep no store
     rc = layout_of(net_s, &lays[0], prec);
     if (rc) return rc;
     if (nn == 2) { rc = layout_of(net_d, &lays[1], prec); if (rc) return rc; }
@@ -567,6 +597,21 @@ extern "C" int64_t nca_render_fwd_workspace(const NcaRays* rays) {
     int rc = check_rays(rays);
     if (rc) return rc;
     return align_up(rays->R * ((rays->S + 31) / 32) * (int64_t)sizeof(double), 256);
+}
+
+static int64_t general_fwd_bytes(const NcaRays* rays, const NcaNet* const* nets, int nn, int32_t prec, int64_t max_bytes);
+static int render_fwd_general(const NcaRays* rays, int32_t prec, const NetBind* binds, int nn, double* pix, float* sig_s, float* sig_d,
+                              void* work, int64_t work_bytes, const void* store, hipStream_t st);
+extern "C" int64_t nca_render_fwd_workspace_nets(const NcaRays* rays, const NcaNet* net_s, const NcaNet* net_d, int32_t prec, int64_t max_bytes) {
+    int rc = check_rays(rays);
+    if (rc) return rc;
+    rc = check_prec(prec);
+    if (rc) return rc;
+    const int64_t base = nca_render_fwd_workspace(rays);
+    const NcaNet* nets[2] = {net_s, net_d};
+    const int64_t gen = general_fwd_bytes(rays, nets, rays->single_field ? 1 : 2, prec, max_bytes);
+    if (gen < 0) return gen;
+    return gen > base ? gen : base;
 }
 
 extern "C" int nca_render_fwd(const NcaRays* rays, int32_t prec,
@@ -592,6 +637,8 @@ extern "C" int nca_render_fwd(const NcaRays* rays, int32_t prec,
     rays_to_args(rays, &a, prec);
     a.nnets = rays->single_field ? 1 : 2;
     NetBind binds[2] = {{net_s, packed_s, win_s, four_s, nullptr}, {net_d, packed_d, win_d, four_d, latents_d}};
+    if (is_wide(net_s) || (a.nnets == 2 && is_wide(net_d)))          // a net on the general kernels (more than 128 units): raw fields, then the compositing kernel
+        return render_fwd_general(rays, prec, binds, a.nnets, pix, sig_s, sig_d, work, work_bytes, store, (hipStream_t)stream);
     for (int n = 0; n < a.nnets; ++n) {
         rc = fill_net(binds[n], &a.net[n], prec);
         if (rc) return rc;
@@ -1242,6 +1289,8 @@ static int run_bwd(NcaFusedArgs& a, int32_t prec, const NetBind* binds, int64_t 
     return NCA_OK;
 }
 
+#include "nca_api_wide.inc"
+
 extern "C" int64_t nca_render_bwd_workspace(const NcaRays* rays, const NcaNet* net_s, const NcaNet* net_d, int32_t prec, int64_t max_bytes) {
     CallOpts co(rays);
     int rc = check_rays(rays);
@@ -1250,6 +1299,10 @@ extern "C" int64_t nca_render_bwd_workspace(const NcaRays* rays, const NcaNet* n
     if (rc) return rc;
     NcaLayout lays[2];
     int nn = rays->single_field ? 1 : 2;
+    if (is_wide(net_s) || (nn == 2 && is_wide(net_d))) {
+        const NcaNet* nets[2] = {net_s, net_d};
+        return general_bwd_bytes(rays, nets, nn, prec, max_bytes);
+    }
     rc = layout_of(net_s, &lays[0], prec);
     if (rc) return rc;
     if (nn == 2) { rc = layout_of(net_d, &lays[1], prec); if (rc) return rc; }
@@ -1316,6 +1369,10 @@ extern "C" int nca_render_bwd_depth(const NcaRays* rays, int32_t prec,
     rays_to_args(rays, &a, prec);
     a.nnets = rays->single_field ? 1 : 2;
     NetBind binds[2] = {{net_s, packed_s, win_s, four_s, params_s}, {net_d, packed_d, win_d, four_d, params_d}};
+    if (is_wide(net_s) || (a.nnets == 2 && is_wide(net_d))) {
+        float* gr[2] = {grads_s, grads_d};
+        return render_bwd_general(rays, prec, binds, a.nnets, g_pix, g_sig_s, g_sig_d, gr, g_depth, work, work_bytes, store, (hipStream_t)stream);
+    }
     for (int n = 0; n < a.nnets; ++n) {
         rc = fill_net(binds[n], &a.net[n], prec);
         if (rc) return rc;
@@ -1382,6 +1439,7 @@ extern "C" int nca_mlp_fwd(const NcaNet* net, int32_t prec, const void* packed, 
     if (rc) return rc;
     if (N <= 0) return fail(NCA_E_INVALID, "empty point batch");
     if (!pts || !raw) return fail(NCA_E_INVALID, "pts/raw is NULL");
+    if (is_wide(net)) return fail(NCA_E_WORKSPACE, "a net on the general kernels (more than 128 units, or other channels than 3 -> 1) needs a workspace: call nca_mlp_fwd_ws");
     static thread_local NcaFusedArgs a;
     memset(&a, 0, sizeof(a));
     a.mode = NCA_MODE_POINTS;
@@ -1408,10 +1466,53 @@ extern "C" int nca_mlp_fwd(const NcaNet* net, int32_t prec, const void* packed, 
     return NCA_OK;
 }
 
+static void points_to_geom(const float* pts, const int32_t* phase, NcaWideGeom* g) {
+    memset(g, 0, sizeof(*g));
+    g->mode = NCA_MODE_POINTS;
+    g->pts = pts;
+    g->phase = phase;
+}
+extern "C" int64_t nca_mlp_fwd_workspace(const NcaNet* net, int32_t prec, int64_t N, int64_t max_bytes) {
+    int rc = check_prec(prec);
+    if (rc) return rc;
+    if (N <= 0) return fail(NCA_E_INVALID, "empty point batch");
+    if (!is_wide(net)) return 0;
+    NcaWideLayout y;
+    rc = wide_layout_of(net, &y, prec);
+    if (rc) return rc;
+    WidePlan p;
+    wide_plan(y, N, false, max_bytes, &p);
+    return p.bytes;
+}
+extern "C" int nca_mlp_fwd_ws(const NcaNet* net, int32_t prec, const void* packed, const float* win, const float* four,
+                              const float* params, int64_t N, const float* pts, const int32_t* phase, float* raw,
+                              void* work, int64_t work_bytes, void* stream) {
+    if (!is_wide(net)) return nca_mlp_fwd(net, prec, packed, win, four, params, N, pts, phase, raw, stream);
+    int rc = check_prec(prec);
+    if (rc) return rc;
+    if (N <= 0) return fail(NCA_E_INVALID, "empty point batch");
+    if (!pts || !raw) return fail(NCA_E_INVALID, "pts/raw is NULL");
+    WideBind w;
+    NetBind b{net, packed, win, four, params};
+    rc = wide_bind(b, prec, &w);
+    if (rc) return rc;
+    NcaWideGeom geom;
+    points_to_geom(pts, phase, &geom);
+    return wide_forward(w, geom, N, raw, work, work_bytes, (hipStream_t)stream);
+}
+
 extern "C" int64_t nca_mlp_bwd_workspace(const NcaNet* net, int32_t prec, int64_t N, int64_t max_bytes) {
     int rc = check_prec(prec);
     if (rc) return rc;
     if (N <= 0) return fail(NCA_E_INVALID, "empty point batch");
+    if (is_wide(net)) {
+        NcaWideLayout y;
+        rc = wide_layout_of(net, &y, prec);
+        if (rc) return rc;
+        WidePlan p;
+        wide_plan(y, N, true, max_bytes, &p);
+        return p.bytes;
+    }
     NcaLayout lay;
     rc = layout_of(net, &lay, prec);
     if (rc) return rc;
@@ -1429,6 +1530,16 @@ extern "C" int nca_mlp_bwd(const NcaNet* net, int32_t prec, const void* packed, 
     if (rc) return rc;
     if (N <= 0) return fail(NCA_E_INVALID, "empty point batch");
     if (!pts || !g_raw || !grads || !params) return fail(NCA_E_INVALID, "a pointer is NULL");
+    if (is_wide(net)) {
+        if (g_latents) return fail(NCA_E_UNSUPPORTED, "per-point latent gradients of a net on the general kernels (the table-row sums in `grads` are complete)");
+        WideBind w;
+        NetBind b{net, packed, win, four, params};
+        rc = wide_bind(b, prec, &w);
+        if (rc) return rc;
+        NcaWideGeom geom;
+        points_to_geom(pts, phase, &geom);
+        return wide_backward(w, geom, N, g_raw, grads, work, work_bytes, (hipStream_t)stream);
+    }
     static thread_local NcaFusedArgs a;
     memset(&a, 0, sizeof(a));
     a.mode = NCA_MODE_POINTS;

@@ -154,7 +154,7 @@ class FieldBinding:
         dev = ps[0].device
         biasless = not getattr(self.module, "use_bias", True)
         F = int(getattr(self.module, "num_filters", self.net.F))
-        Fp = int(self.net.F)                          # the kernels' width: F rounded up to 32 / 64 / 128 (model/_field.py)
+        Fp = int(self.net.F)                          # the kernels' width: F rounded up to 32 / 64 / 128, or to a multiple of 16 on the general kernels (model/_field.py)
         # (parameter, logical shape, padded shape) per slot of the library's natural order.  A net narrower than the kernels' width
         # runs as the wider net whose extra units have zero weights and biases: they stay at relu(0) = 0, feed nothing and receive
         # zero gradients, so no optimiser ever moves them; every parameter is the leading [rows, columns] block of its padded matrix.
@@ -165,9 +165,9 @@ class FieldBinding:
                 first, last = name.startswith("early_pts_layers.0."), name.startswith("output_linear.")
                 slots.append((p, (out, inn), (out if last else Fp, inn if first else inn + (Fp - F))))
                 if biasless:
-                    slots.append((None, None, (1 if last else Fp,)))
+                    slots.append((None, None, (out if last else Fp,)))
             elif name.endswith(".bias"):
-                slots.append((p, tuple(p.shape), (1 if name.startswith("output_linear.") else Fp,)))
+                slots.append((p, tuple(p.shape), (p.shape[0] if name.startswith("output_linear.") else Fp,)))
             else:
                 slots.append((p, tuple(p.shape), tuple(p.shape)))
         numel = lambda shp: int(torch.Size(shp).numel())
@@ -366,14 +366,19 @@ def render_forward_raw(batch: _RayBatch, bs: FieldBinding, bd: Optional[FieldBin
     if bd is not None and win_s is not None and win_d is not None and win_s.data_ptr() != win_d.data_ptr() and _same_window(bs, bd):
         win_d = win_s      # one vector for both nets: the library then stores the encoded input once (see share_enc)
     R, S = batch.R, batch.S
-    if bd is not None and bd.net.F != bs.net.F:
-        want_pix = True          # (nets of different width composite in a kernel of their own)
+    general = _capi.net_is_general(bs.net) or (bd is not None and _capi.net_is_general(bd.net))
+    if general or (bd is not None and bd.net.F != bs.net.F):
+        want_pix = True          # (nets of different width, or on the general kernels, composite in a kernel of their own)
     pix = torch.empty(R, dtype=torch.float64, device=dev) if want_pix else None
     sig_s = torch.empty((R, S), dtype=torch.float32, device=dev)
     sig_d = torch.empty((R, S), dtype=torch.float32, device=dev) if bd is not None else None
     desc = batch.desc()
-    wbytes = check(lib.nca_render_fwd_workspace(C.byref(desc)))
-    work = _scratch(wbytes, dev)
+    if general:     # a chunk of activations on top of the ray sums (include/nerfca_hip.h: nca_render_fwd_workspace_nets)
+        net_d_ = C.byref(bd.net) if bd is not None else None
+        work, wbytes = _alloc_workspace(lambda cap: check(lib.nca_render_fwd_workspace_nets(C.byref(desc), C.byref(bs.net), net_d_, bs.prec, cap)), dev)
+    else:
+        wbytes = check(lib.nca_render_fwd_workspace(C.byref(desc)))
+        work = _scratch(wbytes, dev)
     store = None
     global STORE_FALLBACKS
     if for_backward and STORE_FORWARD_LIMIT_BYTES > 0:
@@ -947,6 +952,21 @@ def render_rays(static_model, temp_model, origins, directions, phases, I0, z, di
     return _RenderFn.apply(batch, bs, bd, len(bs.params()), z_in, dists_in, *params)
 
 
+def _mlp_forward(binding: "FieldBinding", packed, win, four, prm, N: int, pts, phase) -> torch.Tensor:
+    """nca_mlp_fwd, or -- a net on the general kernels -- nca_mlp_fwd_ws with its workspace: raw f32[N, num_output_channels]."""
+    lib = _capi.lib()
+    c_out = ((binding.net.reserved >> 8) & 0xFF) or 1
+    raw = torch.empty((N, c_out), dtype=torch.float32, device=pts.device)
+    if _capi.net_is_general(binding.net):
+        work, wbytes = _alloc_workspace(lambda cap: check(lib.nca_mlp_fwd_workspace(C.byref(binding.net), binding.prec, N, cap)), pts.device)
+        check(lib.nca_mlp_fwd_ws(C.byref(binding.net), binding.prec, ptr(packed), ptr(win), ptr(four), ptr(prm), N,
+                                 ptr(pts), ptr(phase), ptr(raw), ptr(work), wbytes, _stream()))
+    else:
+        check(lib.nca_mlp_fwd(C.byref(binding.net), binding.prec, ptr(packed), ptr(win), ptr(four), ptr(prm), N,
+                              ptr(pts), ptr(phase), ptr(raw), _stream()))
+    return raw
+
+
 class _PointsFn(torch.autograd.Function):
     """raw[n] = net(points[n] (, phase[n]))  --  CPPN.forward / Temporal.forward_composite."""
 
@@ -956,11 +976,9 @@ class _PointsFn(torch.autograd.Function):
         packed = binding.ensure_packed()
         win, four = binding.module._enc_buffers()
         N = pts.shape[0]
-        raw = torch.empty(N, dtype=torch.float32, device=pts.device)
-        check(lib.nca_mlp_fwd(C.byref(binding.net), binding.prec, ptr(packed), ptr(win), ptr(four), ptr(binding.flat), N,
-                              ptr(pts), ptr(phase), ptr(raw), _stream()))
+        raw = _mlp_forward(binding, packed, win, four, binding.flat, N, pts, phase)
         ctx.binding, ctx.keep = binding, (packed, win, four, pts, phase)
-        return raw.view(N, 1)
+        return raw
 
     @staticmethod
     def backward(ctx, g_raw):
@@ -978,12 +996,13 @@ class _PointsFn(torch.autograd.Function):
 
 
 def eval_points(model, pts: torch.Tensor, phase: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Evaluate one network on arbitrary points: f32[n,3] (, ids[n]) -> f32[n,1]."""
+    """Evaluate one network on arbitrary points: f32[n, num_input_channels] (, ids[n]) -> f32[n, num_output_channels]."""
     _require_cuda(pts, "query points")
     binding: FieldBinding = model._binding
+    c_in, c_out = (binding.net.reserved & 0xFF) or 3, ((binding.net.reserved >> 8) & 0xFF) or 1
     if pts.shape[0] == 0:
-        return torch.empty((0, 1), dtype=torch.float32, device=pts.device)
-    p = pts.detach().reshape(-1, 3).to(torch.float32).contiguous()
+        return torch.empty((0, c_out), dtype=torch.float32, device=pts.device)
+    p = pts.detach().reshape(-1, c_in).to(torch.float32).contiguous()
     ph = None
     if phase is not None:
         ph = phase.detach().flatten().to(device=p.device, dtype=torch.int32).contiguous()
@@ -1003,10 +1022,9 @@ class _PointsLatentsFn(torch.autograd.Function):
         N = pts.shape[0]
         prm = binding.flat.detach().clone()                 # natural parameters with the table where the latents sit
         prm[: table.numel()] = table.reshape(-1)
-        raw = torch.empty(N, dtype=torch.float32, device=pts.device)
-        check(lib.nca_mlp_fwd(C.byref(binding.net), binding.prec, ptr(packed), ptr(win), ptr(four), ptr(prm), N, ptr(pts), ptr(ids), ptr(raw), _stream()))
+        raw = _mlp_forward(binding, packed, win, four, prm, N, pts, ids)
         ctx.binding, ctx.keep, ctx.n_lat = binding, (packed, win, four, pts, ids, prm), table.numel()
-        return raw.view(N, 1)
+        return raw
 
     @staticmethod
     def backward(ctx, g_raw):

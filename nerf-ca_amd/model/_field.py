@@ -44,8 +44,8 @@ class FieldBase(nn.Module):
         self.act_func = nn.ReLU()
         self.store_activations = False
         self.activation_dictionary = {}
-        if self.num_input_channels != 3 or self.num_output_channels != 1:
-            raise _capi.NcaError("the fused kernels take 3 input channels and produce 1 output channel")
+        if not (1 <= self.num_input_channels <= 8 and 1 <= self.num_output_channels <= 8):
+            raise _capi.NcaError("the kernels take 1 .. 8 input channels and produce 1 .. 8 output channels")
         self.pos_enc_basis = 0
         enc_features = self.num_input_channels
         if self.use_pos_enc != "none":
@@ -78,12 +78,20 @@ class FieldBase(nn.Module):
         mode = _capi.ENC_NONE
         if self.use_pos_enc != "none" and self.pos_enc_basis > 0:
             mode = _capi.ENC_FOURIER if self.use_pos_enc == "fourier" else _capi.ENC_BANDS
-        if self.num_filters < 1 or self.num_filters > 128:
-            raise _capi.NcaError(f"num_filters = {self.num_filters}: the fused kernels run nets of up to 128 units per layer")
-        # the kernels exist for 32, 64 and 128 units: a net of another width runs as the next one up with zero-weight units (FieldBinding)
-        width = 32 if self.num_filters <= 32 else (64 if self.num_filters <= 64 else 128)
+        if self.num_filters < 1 or self.num_filters > 1024:
+            raise _capi.NcaError(f"num_filters = {self.num_filters}: the kernels run nets of up to 1024 units per layer")
+        chan = _capi.net_channels(self.num_input_channels, self.num_output_channels)
+        if chan and time_dim > 0:
+            raise _capi.NcaError("a Temporal net takes 3 input channels and produces 1 output channel")
+        # The fused kernels exist for 32, 64 and 128 units (3 -> 1 channels); the general kernels (f32; wider nets, other channel counts:
+        # CPPN.py:40-65 takes any) for every multiple of 16 up to 1024.  A net of another width runs as the next one up with zero-weight
+        # units (FieldBinding).
+        if self.num_filters > 128 or chan:
+            width = (self.num_filters + 15) // 16 * 16
+        else:
+            width = 32 if self.num_filters <= 32 else (64 if self.num_filters <= 64 else 128)
         net = _capi.NcaNet(F=width, n_hidden=self.num_early_layers, n_late=self.num_late_layers, enc_mode=mode,
-                           L=self.pos_enc_basis if mode != _capi.ENC_NONE else 0, T=time_dim, P=phases, reserved=0)
+                           L=self.pos_enc_basis if mode != _capi.ENC_NONE else 0, T=time_dim, P=phases, reserved=chan)
         object.__setattr__(self, "_binding", FieldBinding(self, net))
 
     def _apply(self, fn, *args, **kwargs):

@@ -557,7 +557,77 @@ def gen_checkpoint_keys():
     npz("checkpoint_keys", **out)
 
 
+# ----------------------------------------------------------------------------------- (11)
+def gen_wide():
+    """Nets outside the fused kernels' range (model/CPPN.py:40-65 takes any num_filters / channel counts): more than 128 units per layer,
+    other channel counts than 3 -> 1 -- on points (values + every parameter gradient) and through the composite render of a small ray batch."""
+    out = {}
+    torch.manual_seed(1111)
+    x = (torch.rand(200, 3) * 2 - 1).float()          # more than one 128-row tile, not a multiple of it
+    ts = torch.randint(0, 10, (200,)).int()
+    gout = torch.randn(200, 1)
+    out["x"], out["ts"], out["gout"] = x, ts, gout
+    for (F, early, late) in ((136, 1, 0), (136, 1, 2), (256, 1, 0)):
+        tag = f"F{F}_e{early}_l{late}"
+        torch.manual_seed(1100 + F + late)
+        m = CPPN(static_def(F=F, early=early, late=late))
+        m.update_freq_mask_alpha(60000, 150000)
+        y = m(x)
+        (y * gout).sum().backward()
+        out[f"s_{tag}_y"] = y
+        out.update(sd(m, f"s_{tag}_p_"))
+        out.update(grads(m, f"s_{tag}_g_"))
+    torch.manual_seed(1199)
+    t = Temporal(temporal_def(F=136, early=1, late=0))
+    t.update_freq_mask_alpha(60000, 150000)
+    y = t.forward_composite(x, ts)
+    (y * gout).sum().backward()
+    out["d_F136_y"] = y
+    out.update(sd(t, "d_F136_p_"))
+    out.update(grads(t, "d_F136_g_"))
+    # other channel counts: 2 -> 3 (plain bands) and 4 -> 2 (fourier)
+    g = torch.Generator().manual_seed(19)
+    for (cin, cout, enc, L) in ((2, 3, "vanilla", 5), (4, 2, "fourier", 3), (1, 1, "none", 0)):
+        tag = f"c{cin}to{cout}"
+        torch.manual_seed(1200 + cin)
+        gauss = torch.randn(cin * max(L, 1), generator=g)
+        d = static_def(F=48, early=2, late=1, pos_enc=enc, L=L, gauss=gauss, sigma=2)
+        d.update(num_input_channels=cin, num_output_channels=cout)
+        m = CPPN(d)
+        xc = (torch.rand(150, cin, generator=g) * 2 - 1).float()
+        gc = torch.randn(150, cout, generator=g)
+        y = m(xc)
+        (y * gc).sum().backward()
+        out[f"{tag}_x"], out[f"{tag}_gout"], out[f"{tag}_y"], out[f"{tag}_gauss"] = xc, gc, y, gauss
+        out.update(sd(m, f"{tag}_p_"))
+        out.update(grads(m, f"{tag}_g_"))
+    # composite render: static 136 + dynamic 136, and static 64 (a fused-kernel net) + dynamic 136
+    for (Fs, Fd) in ((136, 136), (64, 136)):
+        tag = f"rays_s{Fs}_d{Fd}"
+        torch.manual_seed(1300 + Fs)
+        s = CPPN(static_def(F=Fs, early=1))
+        t = Temporal(temporal_def(F=Fd, early=1))
+        for m in (s, t):
+            m.update_freq_mask_alpha(75000, 150000)
+        R, S = 7, 40
+        o, dd, ph = sample_rays(R, np.float64, 77)
+        z = DH.create_depth_values(3.4259, 5.5741, S, DEV)
+        I0 = torch.full((R,), float(np.log(8.670397)))
+        torch.manual_seed(1301)
+        pix, sig_s, sig_d, dists, *_ = MH.obtain_train_predictions_iter(s, t, None, None, o, dd, ph[:, None].repeat(1, S), I0, z, "softplus", 32768, 0, DEV)
+        torch.manual_seed(1301)
+        out[f"{tag}_t_rand"] = torch.rand(z.shape)
+        (pix.sum() + 30 * sig_s.sum() + 20 * sig_d.sum()).backward()
+        out[f"{tag}_o"], out[f"{tag}_d"], out[f"{tag}_ph"], out[f"{tag}_z"], out[f"{tag}_I0"] = o, dd, ph, z, I0
+        out[f"{tag}_pix"], out[f"{tag}_sig_s"], out[f"{tag}_sig_d"] = pix, sig_s, sig_d
+        out.update(sd(s, f"{tag}_sp_"))
+        out.update(sd(t, f"{tag}_dp_"))
+        out.update(grads(s, f"{tag}_sg_"))
+        out.update(grads(t, f"{tag}_dg_"))
+    npz("wide", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["posenc", "mlps", "depth", "predict_iter", "render", "losses", "full_step", "full_step_fine", "static_step", "geometry", "schedules", "checkpoint_keys"]
+    which = sys.argv[1:] or ["posenc", "mlps", "depth", "predict_iter", "render", "losses", "full_step", "full_step_fine", "static_step", "geometry", "schedules", "checkpoint_keys", "wide"]
     for w in which:
         globals()["gen_" + w]()

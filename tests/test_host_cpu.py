@@ -433,8 +433,18 @@ def test_flat_buffer_of_padded_and_biasless_nets():
             for p in m.parameters():
                 p.add_(1.0)
         assert float(b.flat[~mask].min()) == 1.5 and float(b.flat[mask].abs().max()) == 0.0
-    with pytest.raises(_capi.NcaError, match="128"):
-        CPPN(dict(sdef, num_filters=256))
+    # beyond 128 units (and other channel counts than 3 -> 1) a net is bound to the general kernels, at the next multiple of 16
+    for F, cin, cout, width in ((256, 3, 1, 256), (200, 3, 1, 208), (48, 2, 3, 48), (40, 3, 2, 48)):
+        m = CPPN(dict(sdef, num_filters=F, num_input_channels=cin, num_output_channels=cout))
+        b = m._binding
+        assert _capi.net_is_general(b.net) and b.net.F == width and b.net.reserved == _capi.net_channels(cin, cout)
+        assert b.flat.numel() == _capi.check(_capi.lib().nca_param_count(C.byref(b.net))) and b._is_flat()
+        assert tuple(m.state_dict()["output_linear.0.weight"].shape) == (cout, F) and tuple(m.state_dict()["output_linear.0.bias"].shape) == (cout,)
+        assert _capi.check(_capi.lib().nca_packed_bytes(C.byref(b.net), _capi.PREC_F32)) >= 4 * width * width
+    with pytest.raises(_capi.NcaError, match="1024"):
+        CPPN(dict(sdef, num_filters=1040))
+    with pytest.raises(_capi.NcaError, match="Temporal net takes 3 input channels"):
+        Temporal(dict(tdef, num_input_channels=2))
 
 
 def test_planner_host_arithmetic_through_the_c_abi():
@@ -497,10 +507,21 @@ def test_planner_host_arithmetic_through_the_c_abi():
     with pytest.raises(_capi.NcaError):
         _capi.NcaPlanOpts(onchip_min_tiles=0)       # ... and its name
     assert store(0, 64, _capi.PREC_BF16) < 0 and b"empty" in L.nca_last_error()
-    # a net the kernels do not have is an explicit error, not a size
+    # a net on the general kernels (more than 128 units) keeps no forward store: size 0, the backward recomputes; its workspaces carry a chunk of
+    # activations, bounded by the caller's cap; a net no kernels have is an explicit error, not a size
     wide = _capi.NcaNet(F=256, n_hidden=4, n_late=0, enc_mode=_capi.ENC_BANDS, L=12, T=0, P=0)
     r = rays(64, 64, 1)
-    assert L.nca_render_store_bytes(C.byref(r), C.byref(wide), None, _capi.PREC_BF16) < 0 and b"32, 64 or 128" in L.nca_last_error()
+    assert L.nca_render_store_bytes(C.byref(r), C.byref(wide), None, _capi.PREC_F32) == 0
+    full = L.nca_render_fwd_workspace_nets(C.byref(r), C.byref(wide), None, _capi.PREC_F32, 0)
+    assert full == (64 * 64) * (80 + 2 * 256) * 4 and L.nca_render_fwd_workspace(C.byref(r)) < full
+    assert L.nca_render_fwd_workspace_nets(C.byref(r), C.byref(wide), None, _capi.PREC_F32, full // 3) == (64 * 64 // 4) * (80 + 2 * 256) * 4
+    assert L.nca_render_fwd_workspace_nets(C.byref(r), C.byref(wide), None, _capi.PREC_BF16, 0) == -2 and b"bf16 mode runs nets of up to 128" in L.nca_last_error()
+    assert L.nca_render_bwd_workspace(C.byref(r), C.byref(wide), None, _capi.PREC_F32, 1 << 40) > full > L.nca_render_bwd_workspace(C.byref(r), C.byref(wide), None, _capi.PREC_F32, 1 << 20) > 0
+    assert L.nca_mlp_fwd_workspace(C.byref(wide), _capi.PREC_F32, 1000, 0) == 1024 * (80 + 2 * 256) * 4
+    narrow = _capi.NcaNet(F=64, n_hidden=4, n_late=0, enc_mode=_capi.ENC_BANDS, L=12, T=0, P=0)
+    assert L.nca_mlp_fwd_workspace(C.byref(narrow), _capi.PREC_F32, 1000, 0) == 0
+    odd = _capi.NcaNet(F=200, n_hidden=4, n_late=0, enc_mode=_capi.ENC_BANDS, L=12, T=0, P=0)
+    assert L.nca_render_store_bytes(C.byref(r), C.byref(odd), None, _capi.PREC_F32) == 0 and L.nca_param_count(C.byref(odd)) == -2 and b"multiple of 16" in L.nca_last_error()
 
 
 def test_plan_scope_is_a_per_thread_stack():
