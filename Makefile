@@ -5,11 +5,16 @@ ARCH  ?= gfx950
 CSRC  := nerf-ca_amd/csrc
 OUT   := nerf-ca_amd/lib/libnerfca_hip.so
 SRCS  := $(CSRC)/nca_api.hip $(CSRC)/nca_kernels_f32.hip $(CSRC)/nca_kernels_bf16.hip $(CSRC)/nca_kernels_loss.hip $(CSRC)/nca_kernels_wide.hip
-HDRS  := include/nerfca_hip.h $(CSRC)/nca_layout.hpp $(CSRC)/nca_kernels.hpp $(CSRC)/nca_rng.hpp $(CSRC)/nca_f32_layer.inc $(CSRC)/nca_wide.hpp $(CSRC)/nca_api_wide.inc
+HDRS  := include/nerfca_hip.h $(CSRC)/nca_layout.hpp $(CSRC)/nca_kernels.hpp $(CSRC)/nca_rng.hpp
 OBJS  := $(SRCS:.hip=.o)
 FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function
 
 all: $(OUT)
+
+# headers only some translation units include
+$(CSRC)/nca_kernels_f32.o: $(CSRC)/nca_f32_layer.inc
+$(CSRC)/nca_kernels_wide.o $(CSRC)/nca_api.o: $(CSRC)/nca_wide.hpp
+$(CSRC)/nca_api.o: $(CSRC)/nca_api_wide.inc
 
 %.o: %.hip $(HDRS)
 	$(HIPCC) $(FLAGS) $(EXTRA) -c $< -o $@
