@@ -535,6 +535,19 @@ def predicted_scaling(args, data, dev, step_ms_1gpu):
     return out
 
 
+def general_kernels_record():
+    """Nets beyond the fused kernels' range (more than 128 units per layer): a composite render of 8 192 rays x 192 samples with two
+    256-unit nets on the general f32 kernels, forward and forward + backward (tools/wide_bench.py).  In the full record only."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("wide_bench", os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "wide_bench.py"))
+    wb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(wb)
+    rec = wb.measure([256], 8192, 192, 3)[0]
+    rec["note"] = ("f32 GEMM per layer on v_mfma_f32_32x32x2_f32, activations in HBM; frac = algorithmic FLOPs (forward + backward = 4 x forward) / time / 157.3 TFLOP/s; "
+                   "not part of the headline (BASELINE configs use 128 units)")
+    return rec
+
+
 def configs3_record(args, dev):
     """BASELINE configs[3] -- "MAGIX 4D phantom, 8 angiogram sequences, 512^2 x 256 samples, fp32, 1 x MI355X" -- as a short leg of the
     default line, so that it is timed by whoever runs the bench: synthetic data of that shape (MAGIX cone beam DSD 2000 / DSO 600 mm,
@@ -842,6 +855,8 @@ def main():
                 out["configs3"] = configs3_record(args, dev)
             if args.latency_steps > 0 and args.prec == "bf16":
                 out["latency_regime"] = latency_record(args, dev)
+            if args.prec == "bf16":
+                out["general_kernels"] = general_kernels_record()
         path = write_full_record(args, out)
         print(headline_line(out, path), flush=True)
     if use_pg:

@@ -1342,8 +1342,13 @@ def test_error_paths_are_explicit(dev):
         MH.render_volume_density(raw, torch.ones(4, device=dev), o, z[None, :].repeat(4, 1))
     with pytest.raises(_capi.NcaError, match="GPU"):
         MH.render_volume_density_composite(raw.cpu(), raw.cpu(), torch.ones(4), o.cpu(), z.cpu())
-    bad = _capi.NcaNet(F=256, n_hidden=4, n_late=0, enc_mode=1, L=12, T=0, P=0, reserved=0)
-    assert _capi.lib().nca_packed_bytes(C.byref(bad), 0) == -2
+    # a width no kernel family has (the general kernels take multiples of 16 up to 1 024: the host pads), and a net of theirs in bf16 mode
+    for F in (200, 2048):
+        bad = _capi.NcaNet(F=F, n_hidden=4, n_late=0, enc_mode=1, L=12, T=0, P=0, reserved=0)
+        assert _capi.lib().nca_packed_bytes(C.byref(bad), 0) == -2 and b"multiple of 16" in _capi.lib().nca_last_error()
+    wide = _capi.NcaNet(F=256, n_hidden=4, n_late=0, enc_mode=1, L=12, T=0, P=0, reserved=0)
+    assert _capi.lib().nca_packed_bytes(C.byref(wide), 0) == 4 * (256 * 80 + 4 * 256 * 256 + 5 * 256 + 256 + 4)
+    assert _capi.lib().nca_packed_bytes(C.byref(wide), 1) == -2 and b"bf16 mode runs nets of up to 128" in _capi.lib().nca_last_error()
 
 
 # ----------------------------------------------------------------------------- optimiser + graph-replayed step
