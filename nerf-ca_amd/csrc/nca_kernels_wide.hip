@@ -228,28 +228,33 @@ __global__ __launch_bounds__(256, 2) void nca_wide_gemm(const NcaWideGemmArgs a)
             }
         }
     }
-    // epilogue: register v of lane (j, h) of block (bi, bj) = C[r0 + 64 wr + 32 bi + 8 (v >> 2) + 4 h + (v & 3)][c0 + 64 wc + 32 bj + j]
+    // epilogue: register v of lane (j, h) of block (bi, bj) = C[r0 + 64 wr + 32 bi + 8 (v >> 2) + 4 h + (v & 3)][c0 + 64 wc + 32 bj + j].  One 64-bit base per lane,
+    // 32-bit offsets inside the tile (a tile spans at most 128 rows of at most 2^20 floats)
     float* Cb = a.C + (KIND == NCA_WG_WGRAD ? (int64_t)blockIdx.z * a.split_stride : 0);
+    const int64_t rl = r0 + wr * 64 + 4 * lh, cl = c0 + wc * 64 + lj;          // this lane's first row / column
+    float* const cp = Cb + rl * a.ldc + cl;
+    const float* const mp = (KIND == NCA_WG_DGRAD && a.mask) ? a.mask + rl * a.ldm + cl : nullptr;
+    const int ldc = (int)a.ldc, ldm = (int)a.ldm;
+    const int rleft = (int)(a.rows - rl < 128 ? a.rows - rl : 128), cleft = (int)(a.cols - cl < 128 ? a.cols - cl : 128);          // valid offsets: < these
 #pragma unroll
     for (int bj = 0; bj < 2; ++bj) {
-        const int64_t c = c0 + wc * 64 + bj * 32 + lj;
-        if (c >= a.cols) continue;
+        if (bj * 32 >= cleft) continue;
         float bias = 0.f;
-        if (KIND == NCA_WG_FWD && a.bias) bias = a.bias[c];
+        if (KIND == NCA_WG_FWD && a.bias) bias = a.bias[cl + bj * 32];
 #pragma unroll
         for (int bi = 0; bi < 2; ++bi) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
-                const int64_t r = r0 + wr * 64 + bi * 32 + 8 * (v >> 2) + 4 * lh + (v & 3);
-                if (r >= a.rows) continue;
+                const int ro = bi * 32 + 8 * (v >> 2) + (v & 3);
+                if (ro >= rleft) continue;
                 float x = acc[bi][bj][v];
                 if (KIND == NCA_WG_FWD) {
                     x += bias;
                     if (a.relu) x = x > 0.f ? x : 0.f;
                 } else if (KIND == NCA_WG_DGRAD) {
-                    if (a.mask) x = a.mask[r * a.ldm + c] > 0.f ? x : 0.f;
+                    if (mp) x = mp[ro * ldm + bj * 32] > 0.f ? x : 0.f;
                 }
-                Cb[r * a.ldc + c] = x;
+                cp[ro * ldc + bj * 32] = x;
             }
         }
     }
