@@ -543,7 +543,7 @@ def general_kernels_record():
     wb = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(wb)
     rec = wb.measure([256], 8192, 192, 3)[0]
-    rec["note"] = ("f32 GEMM per layer on v_mfma_f32_32x32x2_f32, activations in HBM; frac = algorithmic FLOPs (forward + backward = 4 x forward) / time / 157.3 TFLOP/s; "
+    rec["note"] = ("f32 GEMM per layer on v_mfma_f32_32x32x2_f32, activations in HBM; frac = algorithmic FLOPs (forward + backward = 3 x forward; the backward runs from the forward's store) / time / 157.3 TFLOP/s; "
                    "not part of the headline (BASELINE configs use 128 units)")
     return rec
 

@@ -66,7 +66,7 @@ enum {
 /* Two families of kernels run a net.  The FUSED kernels keep a sample's activations in registers through the whole net: F = 32, 64 or 128, three
  * input channels, one output channel, both precisions -- every net the reference ships.  The GENERAL kernels (ABI 12) run what those cannot hold --
  * F any multiple of 16 up to 1024 (model/CPPN.py:40-65 takes any num_filters), 1..8 input and output channels -- layer by layer with the
- * activations in HBM: f32 only (v_mfma_f32_32x32x2_f32), no forward store, no depth gradients, and a workspace for every call
+ * activations in HBM: f32 only (v_mfma_f32_32x32x2_f32), a forward store only when EVERY net of the batch is theirs (NCA_STORE_GENERAL), no depth gradients, and a workspace for every call
  * (nca_render_fwd_workspace_nets, nca_mlp_fwd_workspace).  A ray batch may mix the two: each net leaves its raw field, one compositing kernel follows.
  * Their packed image (nca_pack_weights) is [fan-in-padded weights | biases | output layer]. */
 typedef struct NcaNet {
@@ -137,6 +137,8 @@ enum {
     NCA_STORE_BF16 = 4,       /* bf16 mode with NCA_OPT_STAGE_FP8 = 0 (ABI 10): layer inputs as bf16 fragments, masks of all layers, raw
                                  outputs -- nothing in 8 bits, nothing recomputed: the backward writes bf16 output gradients and the
                                  weight gradient contracts bf16 x bf16                                                */
+    NCA_STORE_GENERAL = 5,    /* every net of the batch on the general kernels (ABI 12): X0 and every layer's output of every sample, f32, by runs of whole rays, and the
+                                 raw fields -- what autograd keeps in the reference; the backward recomputes nothing                                   */
     NCA_STORE_KIND_MASK = 15,
     NCA_STORE_SHARED_ENC = 16 /* flag: both nets share one stored input block (same encoding vectors)          */
 };

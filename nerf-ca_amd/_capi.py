@@ -22,7 +22,7 @@ OPT_STAGE_FP8_MIN_TILES = 3
 OPT_WGRAD_REBUILD_WEIGHT_PCT = 4
 OPT_OVERLAP_CUS = 5
 OPT_BF16_STORE = 6
-STORE_NONE, STORE_F32, STORE_FP8, STORE_BF16, STORE_KIND_MASK, STORE_SHARED_ENC = 0, 1, 3, 4, 15, 16       # (2 was round 3's bf16-staged store: retired)
+STORE_NONE, STORE_F32, STORE_FP8, STORE_BF16, STORE_GENERAL, STORE_KIND_MASK, STORE_SHARED_ENC = 0, 1, 3, 4, 5, 15, 16       # (2 was round 3's bf16-staged store: retired)
 WINDOW_NONE, WINDOW_FREE = 0, 1          # NcaWindowSched.kind
 RNG_STREAM_IDS, RNG_STREAM_PERM, RNG_STREAM_JITTER, RNG_STREAM_USER = 0, 1, 2, 16
 OPT_UNSET = -(1 << 63)     # NCA_OPT_UNSET: "use the process-wide value" in an NcaPlanOpts field

@@ -328,6 +328,7 @@ static int layout_of(const NcaNet* net, NcaLayout* y, int32_t prec = NCA_PREC_F3
 struct NetBind;
 static bool is_wide(const NcaNet* net);
 static int wide_layout_of(const NcaNet* net, NcaWideLayout* y, int32_t prec);
+static int64_t general_store_bytes(const NcaRays* rays, const NcaNet* const* nets, int nn, int32_t prec);
 
 extern "C" int64_t nca_param_count(const NcaNet* net) {
     if (is_wide(net)) {
@@ -579,7 +580,10 @@ extern "C" int64_t nca_render_store_bytes(const NcaRays* rays, const NcaNet* net
     if (rc) return rc;
     NcaLayout lays[2];
     const int nn = rays->single_field ? 1 : 2;
-    if (is_wide(net_s) || (nn == 2 && is_wide(net_d))) return 0;          // the general kernels keep no store
+    if (is_wide(net_s) || (nn == 2 && is_wide(net_d))) {          // the general kernels' store: every layer's output, f32 (0 when a fused-kernel net shares the batch)
+        const NcaNet* nets[2] = {net_s, net_d};
+        return general_store_bytes(rays, nets, nn, prec);
+    }
     rc = layout_of(net_s, &lays[0], prec);
     if (rc) return rc;
     if (nn == 2) { rc = layout_of(net_d, &lays[1], prec); if (rc) return rc; }
@@ -601,7 +605,7 @@ extern "C" int64_t nca_render_fwd_workspace(const NcaRays* rays) {
 
 static int64_t general_fwd_bytes(const NcaRays* rays, const NcaNet* const* nets, int nn, int32_t prec, int64_t max_bytes);
 static int render_fwd_general(const NcaRays* rays, int32_t prec, const NetBind* binds, int nn, double* pix, float* sig_s, float* sig_d,
-                              void* work, int64_t work_bytes, const void* store, hipStream_t st);
+                              void* work, int64_t work_bytes, void* store, int64_t store_bytes, hipStream_t st);
 extern "C" int64_t nca_render_fwd_workspace_nets(const NcaRays* rays, const NcaNet* net_s, const NcaNet* net_d, int32_t prec, int64_t max_bytes) {
     int rc = check_rays(rays);
     if (rc) return rc;
@@ -638,7 +642,7 @@ extern "C" int nca_render_fwd(const NcaRays* rays, int32_t prec,
     a.nnets = rays->single_field ? 1 : 2;
     NetBind binds[2] = {{net_s, packed_s, win_s, four_s, nullptr}, {net_d, packed_d, win_d, four_d, latents_d}};
     if (is_wide(net_s) || (a.nnets == 2 && is_wide(net_d)))          // a net on the general kernels (more than 128 units): raw fields, then the compositing kernel
-        return render_fwd_general(rays, prec, binds, a.nnets, pix, sig_s, sig_d, work, work_bytes, store, (hipStream_t)stream);
+        return render_fwd_general(rays, prec, binds, a.nnets, pix, sig_s, sig_d, work, work_bytes, store, store_bytes, (hipStream_t)stream);
     for (int n = 0; n < a.nnets; ++n) {
         rc = fill_net(binds[n], &a.net[n], prec);
         if (rc) return rc;
@@ -1371,7 +1375,7 @@ extern "C" int nca_render_bwd_depth(const NcaRays* rays, int32_t prec,
     NetBind binds[2] = {{net_s, packed_s, win_s, four_s, params_s}, {net_d, packed_d, win_d, four_d, params_d}};
     if (is_wide(net_s) || (a.nnets == 2 && is_wide(net_d))) {
         float* gr[2] = {grads_s, grads_d};
-        return render_bwd_general(rays, prec, binds, a.nnets, g_pix, g_sig_s, g_sig_d, gr, g_depth, work, work_bytes, store, (hipStream_t)stream);
+        return render_bwd_general(rays, prec, binds, a.nnets, g_pix, g_sig_s, g_sig_d, gr, g_depth, work, work_bytes, store, store_bytes, (hipStream_t)stream);
     }
     for (int n = 0; n < a.nnets; ++n) {
         rc = fill_net(binds[n], &a.net[n], prec);

@@ -185,14 +185,34 @@ __global__ __launch_bounds__(256, 2) void nca_wide_gemm(const NcaWideGemmArgs a)
     __shared__ __attribute__((aligned(16))) float Bs[WG_BK * WG_PITCH];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lj = lane & 31, lh = lane >> 5;
     const int wr = wave >> 1, wc = wave & 1;
-    const int64_t r0 = (int64_t)blockIdx.x * WG_BM, c0 = (int64_t)blockIdx.y * WG_BN;
+    // XCD-aware tile order.  Workgroups are dealt to the 8 XCDs round-robin by their linear id, and each XCD has its own L2: the workgroups that read the
+    // SAME operand tile -- the column tiles of one row tile (forward, dgrad: the A rows), all output tiles of one sample split (wgrad: both operands) -- are
+    // made neighbours ON ONE XCD (ids l, l + 8, l + 16, ...) instead of neighbours in id, which would spread them over the XCDs (forward at 256 units: 472 -> 3xx MB
+    // read per launch, profiles/r06_wide_pmc.json).  Groups are dealt to the XCDs in turn when their number is a multiple of 8; otherwise in id order.
+    const int nrt = (int)((a.rows + WG_BM - 1) / WG_BM), nct = (int)((a.cols + WG_BN - 1) / WG_BN);
+    const int gs = KIND == NCA_WG_WGRAD ? nrt * nct : nct;                       // workgroups per group
+    const int64_t ng = KIND == NCA_WG_WGRAD ? a.nsplit : nrt;                   // groups
+    const int64_t lid = blockIdx.x;
+    int64_t group;
+    int member;
+    if ((ng & 7) == 0) {
+        const int64_t q = lid >> 3;
+        member = (int)(q % gs);
+        group = (q / gs) * 8 + (lid & 7);
+    } else {
+        member = (int)(lid % gs);
+        group = lid / gs;
+    }
+    const int rt = KIND == NCA_WG_WGRAD ? member % nrt : (int)group, ct = KIND == NCA_WG_WGRAD ? member / nrt : member;
+    const int64_t zsplit = KIND == NCA_WG_WGRAD ? group : 0;
+    const int64_t r0 = (int64_t)rt * WG_BM, c0 = (int64_t)ct * WG_BN;
 
     // contraction range of this workgroup: [kb, ke) over the concatenation of A's two segments
     const int64_t ktot = a.ka[0] + a.ka[1];
     int64_t kb = 0, ke = ktot;
     if (KIND == NCA_WG_WGRAD) {
         const int64_t per = ((ktot + a.nsplit - 1) / a.nsplit + WG_BK - 1) / WG_BK * WG_BK;
-        kb = (int64_t)blockIdx.z * per;
+        kb = zsplit * per;
         ke = kb + per < ktot ? kb + per : ktot;
     }
     wf32x16 acc[2][2];
@@ -230,11 +250,17 @@ __global__ __launch_bounds__(256, 2) void nca_wide_gemm(const NcaWideGemmArgs a)
     }
     // epilogue: register v of lane (j, h) of block (bi, bj) = C[r0 + 64 wr + 32 bi + 8 (v >> 2) + 4 h + (v & 3)][c0 + 64 wc + 32 bj + j].  One 64-bit base per lane,
     // 32-bit offsets inside the tile (a tile spans at most 128 rows of at most 2^20 floats)
-    float* Cb = a.C + (KIND == NCA_WG_WGRAD ? (int64_t)blockIdx.z * a.split_stride : 0);
+    float* Cb = a.C + (KIND == NCA_WG_WGRAD ? zsplit * a.split_stride : 0);
     const int64_t rl = r0 + wr * 64 + 4 * lh, cl = c0 + wc * 64 + lj;          // this lane's first row / column
     float* const cp = Cb + rl * a.ldc + cl;
-    const float* const mp = (KIND == NCA_WG_DGRAD && a.mask) ? a.mask + rl * a.ldm + cl : nullptr;
-    const int ldc = (int)a.ldc, ldm = (int)a.ldm;
+    const int ldc = (int)a.ldc;
+    uint32_t* const mbp = (KIND != NCA_WG_WGRAD && a.maskbits) ? a.maskbits + (((int64_t)rt * nct + ct) * 256 + tid) * 2 : nullptr;
+    uint32_t mb[2] = {0xffffffffu, 0xffffffffu};
+    if (KIND == NCA_WG_DGRAD && mbp) {
+        const uint2 t = *reinterpret_cast<const uint2*>(mbp);
+        mb[0] = t.x; mb[1] = t.y;
+    }
+    uint32_t mo[2] = {0u, 0u};
     const int rleft = (int)(a.rows - rl < 128 ? a.rows - rl : 128), cleft = (int)(a.cols - cl < 128 ? a.cols - cl : 128);          // valid offsets: < these
 #pragma unroll
     for (int bj = 0; bj < 2; ++bj) {
@@ -251,17 +277,20 @@ __global__ __launch_bounds__(256, 2) void nca_wide_gemm(const NcaWideGemmArgs a)
                 if (KIND == NCA_WG_FWD) {
                     x += bias;
                     if (a.relu) x = x > 0.f ? x : 0.f;
+                    if (x > 0.f) mo[bi] |= 1u << (bj * 16 + v);
                 } else if (KIND == NCA_WG_DGRAD) {
-                    if (mp) x = mp[ro * ldm + bj * 32] > 0.f ? x : 0.f;
+                    x = (mb[bi] >> (bj * 16 + v)) & 1u ? x : 0.f;
                 }
                 cp[ro * ldc + bj * 32] = x;
             }
         }
     }
+    if (KIND == NCA_WG_FWD && mbp) *reinterpret_cast<uint2*>(mbp) = make_uint2(mo[0], mo[1]);
 }
 hipError_t nca_launch_wide_gemm(int kind, const NcaWideGemmArgs& a, hipStream_t st) {
     if (a.rows <= 0 || a.cols <= 0) return hipSuccess;
-    const dim3 grid((unsigned)((a.rows + WG_BM - 1) / WG_BM), (unsigned)((a.cols + WG_BN - 1) / WG_BN), kind == NCA_WG_WGRAD ? (unsigned)a.nsplit : 1u);
+    const int64_t tiles = ((a.rows + WG_BM - 1) / WG_BM) * ((a.cols + WG_BN - 1) / WG_BN);
+    const dim3 grid((unsigned)(tiles * (kind == NCA_WG_WGRAD ? a.nsplit : 1)));
     if (kind == NCA_WG_FWD) hipLaunchKernelGGL(nca_wide_gemm<NCA_WG_FWD>, grid, dim3(256), 0, st, a);
     else if (kind == NCA_WG_DGRAD) hipLaunchKernelGGL(nca_wide_gemm<NCA_WG_DGRAD>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(nca_wide_gemm<NCA_WG_WGRAD>, grid, dim3(256), 0, st, a);

@@ -9,6 +9,7 @@
 //
 //   X0 block  [sample][K0p]   columns: encoded input (natural order) | time latents | one-hot phase (backward only) | zero pad to 16
 //   H_j       [sample][F]     output of layer j (after ReLU); F is a multiple of 16
+//   M_j       ReLU bit masks of H_j, j < NL - 1 (backward only): 2 KiB per 128 x 128 tile, written by the forward GEMM, read by the dgrad GEMM
 //   Wp_j      [F][Kp_j]       layer j's weight with its fan-in padded: layer 0 K0p; hidden F; skip K0p + F (encoded part first, CPPN.py:102)
 //   packed    [Wp_0 .. Wp_{NL-1} | biases [NL][F] | Wo [Cout][F] | bo [Cout]]   (nca_pack_weights)
 // Rows are padded to a multiple of 128 per chunk; padded rows hold zeros in X0 and in every output gradient.
@@ -103,7 +104,7 @@ hipError_t nca_launch_wide_pack(const NcaWideLayout& y, const float* prm, float*
 
 // C[r][c] (+ epilogue) = sum_k A(r, k) B(c, k), k over seg 0 then seg 1 of A (B's k runs on)
 enum { NCA_WG_FWD = 0,            // A [r][k] k contiguous, B [c][k] k contiguous;  + bias[c], ReLU (or not)
-       NCA_WG_DGRAD = 1,          // A [r][k],              B [k][c] c contiguous;  x (mask[r][c] > 0)
+       NCA_WG_DGRAD = 1,          // A [r][k],              B [k][c] c contiguous;  x ReLU mask bits of the layer input (maskbits)
        NCA_WG_WGRAD = 2 };        // A [k][r] r contiguous, B [k][c];  contraction split over gridDim.z, partial sums to C + z * split_stride
 struct NcaWideGemmArgs {
     const float* A[2]; int64_t lda[2]; int64_t ka[2];     // ka multiples of 16 (seg 1 may be empty)
@@ -111,7 +112,9 @@ struct NcaWideGemmArgs {
     float* C; int64_t ldc;
     int64_t rows, cols;           // extents: loads beyond them read as zero, stores beyond them are dropped
     const float* bias; int32_t relu;
-    const float* mask; int64_t ldm;
+    uint32_t* maskbits;           // ReLU bit masks of a [rows][cols] layer output, per 128 x 128 tile and thread two words (bit (2 bi + bj) 16 + v = accumulator register v of MFMA
+                                  // block (bi, bj) is positive): NCA_WG_FWD writes them (null: not), NCA_WG_DGRAD -- whose output has the same shape and tiling -- multiplies
+                                  // by them instead of reading the layer output back (64 loads per lane and rows x cols x 4 bytes less per launch)
     int64_t split_stride;         // NCA_WG_WGRAD
     int32_t nsplit, pad;
 };

@@ -309,3 +309,43 @@ def test_trainer_steps_with_wide_nets(dev):
     assert abs(first["fused"] - first["autograd"]) <= 1e-5 * abs(first["autograd"]), first
     assert abs(first["graph"] - first["fused"]) <= 1e-6 * abs(first["fused"]), first
     assert all(last[m] < first[m] for m in first), (first, last)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,S", [(7, 40), (1500, 192)])
+def test_general_forward_store_equals_recompute(dev, R, S):
+    """Both nets on the general kernels: the forward leaves every layer's output in a store (NCA_STORE_GENERAL: what autograd keeps in the reference) and
+    the backward recomputes nothing; without a store (fused.STORE_FORWARD_LIMIT_BYTES = 0) it recomputes per run of whole rays.  Same runs, same split
+    sums: the gradients are the same BITS either way -- one run (7 x 40) or two (1 500 x 192 > 2^18 samples)."""
+    from nerfca_amd import _capi, fused as FZ, render_rays
+    gen = torch.Generator().manual_seed(11)
+    ps = O.init_params(spec_from(144, 1, 0), gen)
+    pd = O.init_params(spec_from(144, 1, 0, T=8), gen)
+    o = (torch.rand(R, 3, generator=gen) * 0.1 + torch.tensor([3.0, -2.0, 2.5])).double().to(dev)
+    d = (torch.rand(R, 3, generator=gen) - 0.5).double().to(dev)
+    ph = torch.randint(0, 10, (R,), generator=gen).to(dev)
+    z = torch.linspace(3.4, 5.6, S).to(dev)
+    dists = torch.cat([z[1:] - z[:-1], torch.tensor([1e-10], device=dev)]).double()
+    I0 = torch.full((R,), 2.16, device=dev)
+
+    def run(limit):
+        s = make_static(ps, dev, F=144, early=1, late=0)
+        t = make_dynamic(pd, dev, F=144, early=1, late=0, T=8)
+        for m in (s, t):
+            m.update_freq_mask_alpha(75000, 150000)
+        old = FZ.STORE_FORWARD_LIMIT_BYTES
+        FZ.STORE_FORWARD_LIMIT_BYTES = limit
+        try:
+            pix, a, b = render_rays(s, t, o, d, ph, I0, z, dists)
+            fmt = _capi.last_plan()["fwd_store_format"]
+            (pix.sum() + 30 * a.sum() + 20 * b.sum()).backward()
+        finally:
+            FZ.STORE_FORWARD_LIMIT_BYTES = old
+        return fmt, pix.detach().cpu(), {**{"s." + k: v for k, v in grads_of(s).items()}, **{"d." + k: v for k, v in grads_of(t).items()}}
+
+    f1, p1, g1 = run(96 << 30)
+    f0, p0, g0 = run(0)
+    assert f1 == _capi.STORE_GENERAL and f0 == _capi.STORE_NONE
+    assert torch.equal(p1, p0)
+    for k in g0:
+        assert torch.equal(g1[k], g0[k]), k

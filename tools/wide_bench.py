@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Time the GENERAL kernels (nets beyond 128 units: nerf-ca_amd/csrc/nca_wide.hpp) on a composite render of synthetic rays:
 forward, and forward + backward, per net width.  Prints one JSON line per width with ms, the f32 FLOP rate against the
-v_mfma_f32_32x32x2_f32 peak (157.3 TFLOP/s) and the library's own per-kernel-class timing.
+v_mfma_f32_32x32x2_f32 peak (157.3 TFLOP/s; forward + backward = 3 x the forward's FLOPs) and the library's own per-kernel-class timing.
 
     python tools/wide_bench.py [--rays 8192] [--samples 192] [--widths 256,512] [--steps 5]"""
 import argparse
@@ -69,7 +69,7 @@ def measure(widths, rays=8192, samples=192, steps=5):
                 if n:
                     kms[k] = round(tot / steps, 3)
             _capi.timing_enable(False)
-            flop = flop_fwd * (1 if what == "fwd" else 4)          # backward: the forward again (no store), dgrad, wgrad
+            flop = flop_fwd * (1 if what == "fwd" else 3)          # forward, dgrad, wgrad (the backward runs from the forward's store: nothing recomputed)
             rec[what] = {"ms": round(ms, 3), "tflops": round(flop / ms / 1e9, 1), "frac_of_f32_mfma_peak": round(flop / (ms * 1e-3) / PEAK_F32_MFMA, 3),
                          "kernel_ms": kms}
         out.append(rec)
