@@ -179,7 +179,7 @@ __device__ __forceinline__ void wg_stash(float* __restrict__ s, int tid, const f
 }
 
 template <int KIND>
-__global__ __launch_bounds__(256, 2) void nca_wide_gemm(const NcaWideGemmArgs a) {
+__global__ __launch_bounds__(256, KIND == NCA_WG_WGRAD ? 4 : 2) void nca_wide_gemm(const NcaWideGemmArgs a) {          // (all three run four workgroups per CU; wgrad needs telling to stay within 128 registers)
     constexpr bool AKC = KIND != NCA_WG_WGRAD, BKC = KIND == NCA_WG_FWD;
     __shared__ __attribute__((aligned(16))) float As[WG_BK * WG_PITCH];
     __shared__ __attribute__((aligned(16))) float Bs[WG_BK * WG_PITCH];
@@ -227,6 +227,8 @@ __global__ __launch_bounds__(256, 2) void nca_wide_gemm(const NcaWideGemmArgs a)
         wg_fetch<AKC>(a.A[seg], a.lda[seg], r0, a.rows, kk, tid, va);
         wg_fetch<BKC>(a.B, a.ldb, c0, a.cols, k, tid, vb);
     };
+    const bool sums = KIND == NCA_WG_WGRAD && a.rowsum && ct == 0;          // (uniform per workgroup)
+    float rsum = 0.f;
     if (kb < ke) {
         float4 va[2], vb[2];
         fetch(kb, va, vb);
@@ -236,6 +238,10 @@ __global__ __launch_bounds__(256, 2) void nca_wide_gemm(const NcaWideGemmArgs a)
             wg_stash<BKC>(Bs, tid, vb);
             __syncthreads();
             if (k + WG_BK < ke) fetch(k + WG_BK, va, vb);
+            if (sums && tid < WG_BM) {
+#pragma unroll
+                for (int kk = 0; kk < WG_BK; ++kk) rsum += As[kk * WG_PITCH + tid];          // (slab by slab, k ascending: a fixed order)
+            }
 #pragma unroll
             for (int s = 0; s < WG_BK / 2; ++s) {
                 const float* ar = As + (2 * s + lh) * WG_PITCH + wr * 64 + lj;
@@ -248,6 +254,7 @@ __global__ __launch_bounds__(256, 2) void nca_wide_gemm(const NcaWideGemmArgs a)
             }
         }
     }
+    if (sums && tid < WG_BM && r0 + tid < a.rows) a.rowsum[zsplit * a.split_stride + r0 + tid] = rsum;
     // epilogue: register v of lane (j, h) of block (bi, bj) = C[r0 + 64 wr + 32 bi + 8 (v >> 2) + 4 h + (v & 3)][c0 + 64 wc + 32 bj + j].  One 64-bit base per lane,
     // 32-bit offsets inside the tile (a tile spans at most 128 rows of at most 2^20 floats)
     float* Cb = a.C + (KIND == NCA_WG_WGRAD ? zsplit * a.split_stride : 0);

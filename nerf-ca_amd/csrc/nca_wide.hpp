@@ -116,6 +116,8 @@ struct NcaWideGemmArgs {
                                   // block (bi, bj) is positive): NCA_WG_FWD writes them (null: not), NCA_WG_DGRAD -- whose output has the same shape and tiling -- multiplies
                                   // by them instead of reading the layer output back (64 loads per lane and rows x cols x 4 bytes less per launch)
     int64_t split_stride;         // NCA_WG_WGRAD
+    float* rowsum;                // NCA_WG_WGRAD: null, or where the sums of A over the contraction go -- rowsum[z * split_stride + r] = sum_k A(r, k) of split z (the
+                                  // bias gradient sum_n D[n][f] rides along with the weight gradient: the column-0 workgroups add up the A slabs they stage anyway)
     int32_t nsplit, pad;
 };
 hipError_t nca_launch_wide_gemm(int kind, const NcaWideGemmArgs& a, hipStream_t st);
