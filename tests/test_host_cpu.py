@@ -507,11 +507,15 @@ def test_planner_host_arithmetic_through_the_c_abi():
     with pytest.raises(_capi.NcaError):
         _capi.NcaPlanOpts(onchip_min_tiles=0)       # ... and its name
     assert store(0, 64, _capi.PREC_BF16) < 0 and b"empty" in L.nca_last_error()
-    # a net on the general kernels (more than 128 units) keeps no forward store: size 0, the backward recomputes; its workspaces carry a chunk of
-    # activations, bounded by the caller's cap; a net no kernels have is an explicit error, not a size
+    # a net on the general kernels (more than 128 units): a forward store when every net of the batch is theirs (0 beside a fused-kernel net: that backward
+    # recomputes); its workspaces carry a chunk of activations, bounded by the caller's cap; a net no kernels have is an explicit error, not a size
     wide = _capi.NcaNet(F=256, n_hidden=4, n_late=0, enc_mode=_capi.ENC_BANDS, L=12, T=0, P=0)
     r = rays(64, 64, 1)
-    assert L.nca_render_store_bytes(C.byref(r), C.byref(wide), None, _capi.PREC_F32) == 0
+    # its forward store: X0 (80 padded columns), five layer outputs of 256 units, four layers' ReLU bit masks (2 KiB per 128 x 128 tile) and the raw field, f32
+    rows = 64 * 64
+    assert L.nca_render_store_bytes(C.byref(r), C.byref(wide), None, _capi.PREC_F32) == (rows * (80 + 5 * 256) + 4 * (rows // 128) * 2 * 512 + rows) * 4
+    mixed = rays(64, 64, 0)
+    assert L.nca_render_store_bytes(C.byref(mixed), C.byref(net_s), C.byref(_capi.NcaNet(F=256, n_hidden=4, n_late=0, enc_mode=_capi.ENC_BANDS, L=12, T=8, P=10)), _capi.PREC_F32) == 0
     full = L.nca_render_fwd_workspace_nets(C.byref(r), C.byref(wide), None, _capi.PREC_F32, 0)
     assert full == (64 * 64) * (80 + 2 * 256) * 4 and L.nca_render_fwd_workspace(C.byref(r)) < full
     assert L.nca_render_fwd_workspace_nets(C.byref(r), C.byref(wide), None, _capi.PREC_F32, full // 3) == (64 * 64 // 4) * (80 + 2 * 256) * 4
@@ -521,7 +525,7 @@ def test_planner_host_arithmetic_through_the_c_abi():
     narrow = _capi.NcaNet(F=64, n_hidden=4, n_late=0, enc_mode=_capi.ENC_BANDS, L=12, T=0, P=0)
     assert L.nca_mlp_fwd_workspace(C.byref(narrow), _capi.PREC_F32, 1000, 0) == 0
     odd = _capi.NcaNet(F=200, n_hidden=4, n_late=0, enc_mode=_capi.ENC_BANDS, L=12, T=0, P=0)
-    assert L.nca_render_store_bytes(C.byref(r), C.byref(odd), None, _capi.PREC_F32) == 0 and L.nca_param_count(C.byref(odd)) == -2 and b"multiple of 16" in L.nca_last_error()
+    assert L.nca_render_store_bytes(C.byref(r), C.byref(odd), None, _capi.PREC_F32) == -2 and L.nca_param_count(C.byref(odd)) == -2 and b"multiple of 16" in L.nca_last_error()
 
 
 def test_plan_scope_is_a_per_thread_stack():

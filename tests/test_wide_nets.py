@@ -253,8 +253,8 @@ def test_general_kernels_equal_fused_kernels_on_nets_both_run(dev, F, late, T):
 
 @pytest.mark.gpu
 def test_general_kernels_refusals(golden, dev):
-    """What the general kernels do not do is refused by name, never approximated: bf16 mode, a forward store, depth gradients, per-point latent
-    gradients, a width that is not a multiple of 16 at the C ABI."""
+    """What the general kernels do not do is refused by name, never approximated: bf16 mode, a width that is not a multiple of 16 at the C ABI, a forward
+    without a workspace (depth gradients and per-point latent gradients likewise: nca_api_wide.inc)."""
     from nerfca_amd import _capi, fused as FZ
     g = golden("wide")
     m = make_static(g.prefixed("s_F256_e1_l0_p_"), dev, F=256, early=1, late=0)
