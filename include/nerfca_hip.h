@@ -174,7 +174,8 @@ int nca_pack_weights2(const NcaNet* net_a, const float* params_a, void* packed_a
  *         raw outputs; bf16: the layer inputs as e4m3, the ReLU masks of every layer and the raw outputs (NCA_OPT_STAGE_FP8 = 0:
  *         no store at all) -- and nca_render_bwd given the same buffer does not recompute the layers.
  *         nca_render_store_bytes() returns 0 where this is not available (nets of different width, nets without a hidden
- *         layer): pass NULL there.
+ *         layer, a general-kernel net beside a fused-kernel one): pass NULL there.  Every net on the general kernels (ABI 12): the store holds
+ *         X0, every layer's output and ReLU bit masks by runs of whole rays, and the raw fields, f32 (NCA_STORE_GENERAL).
  * Returns a negative error code, or >= 0: the format of the store it wrote (NCA_STORE_*, 0 = none) -- hand it to the backward
  * in NcaRays.store_format. */
 int64_t nca_render_fwd_workspace(const NcaRays* rays);

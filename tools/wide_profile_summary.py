@@ -38,9 +38,9 @@ with open(find("stats/**/*kernel_stats.csv")) as f, open(os.path.join(dst, f"{ta
     g.write("".join(l for l in f if "nca_" in l or l.startswith('"Name"')))
 fetch, write, sq = counters("pmc_FETCH_SIZE"), counters("pmc_WRITE_SIZE"), counters("pmc_SQ")
 rows, F = 262144, 256
-alg = {"nca_wide_gemm<0>": (rows * F * 2 + F * F) * 4, "nca_wide_gemm<1>": (rows * F * 3 + F * F) * 4, "nca_wide_gemm<2>": (rows * F * 2) * 4}
+alg = {"nca_wide_gemm<0>": (rows * F * 2 + F * F) * 4 + rows * F // 8, "nca_wide_gemm<1>": (rows * F * 2 + F * F) * 4 + rows * F // 8, "nca_wide_gemm<2>": (rows * F * 2) * 4}
 out = {"source_sha": source_sha(), "how": "tools/wide_profile.sh; means over the dispatches of the LARGEST grid of each kernel (the 262 144-row hidden-layer launches)",
-       "algorithmic_bytes_note": "forward: A rows x F read, C rows x F written, W; dgrad: + the mask source rows x F; wgrad: both operands read once", "kernels": {}}
+       "algorithmic_bytes_note": "forward: A rows x F read, C rows x F written, W, one mask bit per output written; dgrad: the same with the bits read; wgrad: both operands read once", "kernels": {}}
 for kern in sorted({k[0] for k in fetch}):
     grids = [k for k in fetch if k[0] == kern]
     big = max(grids, key=lambda k: (len(fetch[k]["FETCH_SIZE"]) > 2, sum(fetch[k]["FETCH_SIZE"]) / len(fetch[k]["FETCH_SIZE"])))
