@@ -349,3 +349,122 @@ def test_general_forward_store_equals_recompute(dev, R, S):
     assert torch.equal(p1, p0)
     for k in g0:
         assert torch.equal(g1[k], g0[k]), k
+
+
+EDGE_CASES = [
+    # (F, early, late, enc, L, T, N, bias)
+    (16, 0, 0, "none", 0, 0, 1, True),               # one layer, one point, the smallest width
+    (144, 0, 1, "free_windowed", 4, 0, 129, True),   # the skip layer is the only hidden-width layer and the last one
+    (160, 2, 3, "fourier", 5, 0, 300, True),         # skip in the middle, fourier features
+    (1024, 1, 0, "free_windowed", 12, 0, 200, True), # the widest net
+    (208, 1, 0, "vanilla", 10, 16, 257, True),       # latents: 16 of them, 63 + 16 + 10 one-hot columns -> two 16-column pads
+    (136, 2, 0, "free_windowed", 12, 8, 500, False), # no biases (zero gaps in the flat buffer), a width the host pads (144)
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("F,early,late,enc,L,T,N,bias", EDGE_CASES)
+def test_general_kernels_edge_shapes_vs_oracle(dev, F, early, late, enc, L, T, N, bias):
+    """Shapes at the edges of the general kernels -- one layer, one point, 1 024 units, a skip layer that is the last layer, 16 latents, no biases, widths the
+    host pads -- against the oracle in f32 (values 1e-5; gradients 1e-5 or three times the f32 oracle's own distance from the f64 oracle, as everywhere)."""
+    from nerfca_amd import _capi
+    gen = torch.Generator().manual_seed(100 + F)
+    coef = torch.randn(3 * max(L, 1), generator=gen) if enc == "fourier" else None
+    spec = spec_from(F, early, late, enc, L, T=T, coef=coef * 2 if coef is not None else None)
+    p = O.init_params(spec, gen)
+    if not bias:
+        p = {k: v for k, v in p.items() if not k.endswith(".bias")}
+    x = (torch.rand(N, 3, generator=gen) * 2 - 1)
+    ts = torch.randint(0, 10, (N,), generator=gen).int()
+    go = torch.randn(N, 1, generator=gen)
+    win = O.freq_mask_alpha(L, 60000, 150000, 1)[0] if enc == "free_windowed" else None
+
+    def oracle(dt):
+        pp = {k: v.clone().to(dt).requires_grad_(True) for k, v in p.items()}
+        full = dict(pp)
+        if not bias:          # the oracle's layers take a bias: zeros
+            for k, shp in O.param_shapes(spec).items():
+                if k not in full:
+                    full[k] = torch.zeros(shp, dtype=dt)
+        w = win.to(dt) if win is not None else None
+        y = O.dynamic_forward(full, spec, x.to(dt), ts, w) if T else O.static_forward(full, spec, x.to(dt), w)
+        (y * go.to(dt)).sum().backward()
+        return y.detach(), {k: v.grad for k, v in pp.items()}
+
+    y32, g32 = oracle(torch.float32)
+    y64, g64 = oracle(torch.float64)
+    kw = dict(F=F, early=early, late=late, pos_enc=enc, L=L, gauss=coef, sigma=2)
+    d = model_def(device=dev, **kw, **({"T": T} if T else {}))
+    d["use_bias"] = bias
+    if T:
+        from nerfca_amd.model.Temporal import Temporal as M
+    else:
+        from nerfca_amd.model.CPPN import CPPN as M
+    m = M(d)
+    m.load_state_dict(p)
+    m = m.to(dev)
+    if F <= 128:
+        _force_general(m)
+    assert _capi.net_is_general(m._binding.net)
+    if enc == "free_windowed":
+        m.update_freq_mask_alpha(60000, 150000)
+    y = m.forward_composite(x.to(dev), ts.to(dev)) if T else m(x.to(dev))
+    assert rel_err(y.cpu(), y64) < max(TOL, 3 * rel_err(y32, y64))
+    (y * go.to(dev)).sum().backward()
+    got = grads_of(m)
+    for k, ref in g64.items():
+        assert rel_err(got[k], ref) < max(TOL, 3 * rel_err(g32[k], ref)), k
+
+
+@pytest.mark.gpu
+def test_single_field_and_two_wide_widths_vs_oracle(dev):
+    """render_volume_density's single-field render through a 256-unit net, and a composite render of a 144-unit static net with a 256-unit dynamic net (both on
+    the general kernels, different widths: the store holds one block per net), against the f64 oracle."""
+    from nerfca_amd import _capi, render_rays
+    gen = torch.Generator().manual_seed(77)
+    R, S = 9, 48
+    ss, sd = spec_from(144, 1, 0), spec_from(256, 1, 0, T=8)
+    ps, pd = O.init_params(ss, gen), O.init_params(sd, gen)
+    win = O.freq_mask_alpha(12, 75000, 150000, 1)[0]
+    o = (torch.rand(R, 3, generator=gen) * 0.1 + torch.tensor([3.0, -2.0, 2.5])).double()
+    d = (torch.rand(R, 3, generator=gen) - 0.5).double()
+    ph = torch.randint(0, 10, (R,), generator=gen)
+    z = O.stratified_depths(O.depth_values(3.4259, 5.5741, S), torch.rand(S, generator=gen))
+    I0 = torch.full((R,), 2.15991)
+
+    def oracle(dt, single):
+        pso = {k: v.clone().to(dt).requires_grad_(True) for k, v in ps.items()}
+        pdo = {k: v.clone().to(dt).requires_grad_(True) for k, v in pd.items()}
+        pts = O.query_points(o, d, z).to(dt)
+        raw_s = O.static_forward(pso, ss, pts, win.to(dt)).reshape(R, S, -1)
+        if single:
+            out = O.composite_single(raw_s, I0.to(dt), d, z.to(dt))
+            (out[0].sum() + 30 * out[1].sum()).backward()
+            return out, pso, None
+        raw_d = O.dynamic_forward(pdo, sd, pts, ph[:, None].repeat(1, S).flatten(), win.to(dt)).reshape(R, S, -1)
+        out = O.composite(raw_s, raw_d, I0.to(dt), d, z.to(dt))
+        (out[0].sum() + 30 * out[1].sum() + 20 * out[2].sum()).backward()
+        return out, pso, pdo
+
+    for single in (True, False):
+        o32, s32, d32 = oracle(torch.float32, single)
+        o64, s64, d64 = oracle(torch.float64, single)
+        s = make_static(ps, dev, F=144, early=1, late=0)
+        t = make_dynamic(pd, dev, F=256, early=1, late=0, T=8)
+        for m in (s, t):
+            m.update_freq_mask_alpha(75000, 150000)
+        dists = o64[-1].to(dev)
+        if single:
+            pix, a = render_rays(s, None, o.to(dev), d.to(dev), ph.to(dev), I0.to(dev), z.to(dev), dists, single=True)
+            (pix.sum() + 30 * a.sum()).backward()
+            outs = (pix, a)
+        else:
+            pix, a, b = render_rays(s, t, o.to(dev), d.to(dev), ph.to(dev), I0.to(dev), z.to(dev), dists)
+            assert _capi.last_plan()["fwd_store_format"] == _capi.STORE_GENERAL
+            (pix.sum() + 30 * a.sum() + 20 * b.sum()).backward()
+            outs = (pix, a, b)
+        for v, r64, r32 in zip(outs, o64, o32):
+            assert rel_err(v.cpu(), r64) < max(TOL, 3 * rel_err(r32, r64))
+        for m, g64, g32 in ((s, s64, s32),) + (() if single else ((t, d64, d32),)):
+            for k, prm in m.named_parameters():
+                assert rel_err(prm.grad.cpu(), g64[k].grad) < max(TOL, 3 * rel_err(g32[k].grad, g64[k].grad)), (single, k)
