@@ -139,8 +139,10 @@ hipError_t nca_launch_wide_pack(const NcaWideLayout& y, const float* prm, float*
 // ------------------------------------------------------------------------------------------ GEMM
 // Workgroup: 256 threads = 4 waves in 2 x 2, each wave a 64 x 64 block of the 128 x 128 tile = 2 x 2 MFMA blocks of 32 x 32 (64 accumulator
 // registers).  Operand tiles sit in LDS k-major, As[k][r] / Bs[k][c] with a row pitch of 132 floats: lane (j, h) of a k-step reads As[2 s + h][r0 + j]
-// -- 32 consecutive floats per half wave, no bank conflict.  Global loads are float4 along whichever index is contiguous in memory; the next
-// k-slab is fetched into registers while the current one is multiplied (one LDS buffer pair, two barriers per slab).
+// -- 32 consecutive floats per half wave, no bank conflict on the reads (the four-scalar stash of an operand that is k-contiguous in memory does conflict two ways:
+// 3 - 5 % of a launch by SQ_LDS_BANK_CONFLICT; the row-major alternative with ds_read_b128 operand reads was measured and is slower).  Global loads are
+// float4 along whichever index is contiguous in memory; the next k-slab is fetched into registers while the current one is multiplied (one LDS buffer pair, two
+// barriers per slab).
 #define WG_BM 128
 #define WG_BN 128
 #define WG_BK 16
@@ -187,8 +189,9 @@ __global__ __launch_bounds__(256, KIND == NCA_WG_WGRAD ? 4 : 2) void nca_wide_ge
     const int wr = wave >> 1, wc = wave & 1;
     // XCD-aware tile order.  Workgroups are dealt to the 8 XCDs round-robin by their linear id, and each XCD has its own L2: the workgroups that read the
     // SAME operand tile -- the column tiles of one row tile (forward, dgrad: the A rows), all output tiles of one sample split (wgrad: both operands) -- are
-    // made neighbours ON ONE XCD (ids l, l + 8, l + 16, ...) instead of neighbours in id, which would spread them over the XCDs (forward at 256 units: 472 -> 3xx MB
-    // read per launch, profiles/r06_wide_pmc.json).  Groups are dealt to the XCDs in turn when their number is a multiple of 8; otherwise in id order.
+    // made neighbours ON ONE XCD (ids l, l + 8, l + 16, ...) instead of neighbours in id, which would spread them over the XCDs (at 256 units, per 262 144-row launch:
+    // forward 472 -> 241 MB read, dgrad 812 -> 549, wgrad 1 074 -> 537; profiles/r06_wide_pmc.json).  Groups are dealt to the XCDs in turn when their number is a
+    // multiple of 8; otherwise in id order.
     const int nrt = (int)((a.rows + WG_BM - 1) / WG_BM), nct = (int)((a.cols + WG_BN - 1) / WG_BN);
     const int gs = KIND == NCA_WG_WGRAD ? nrt * nct : nct;                       // workgroups per group
     const int64_t ng = KIND == NCA_WG_WGRAD ? a.nsplit : nrt;                   // groups
